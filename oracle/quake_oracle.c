@@ -1,0 +1,826 @@
+/*
+ * quake_oracle.c -- CPU restatement of the Quake search / k-means hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under quake_amd/ may import, link or call this file.
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use it, as the checker /
+ * the timed CPU port -- never as the product path.
+ *
+ * What it restates (citations are relative to /root/reference):
+ *   - TypedTopKBuffer<float,int64_t>        src/cpp/include/list_scanning.h:41-204
+ *   - scan_list (+4 specialisations)         src/cpp/include/list_scanning.h:241-311
+ *   - batched_scan_list                      src/cpp/include/list_scanning.h:313-366
+ *   - QueryCoordinator::serial_scan          src/cpp/src/query_coordinator.cpp:471-611 (fixed nprobe; APS branch not restated)
+ *   - QueryCoordinator::batched_serial_scan  src/cpp/src/query_coordinator.cpp:675-799
+ *   - QueryCoordinator::search               src/cpp/src/query_coordinator.cpp:612-657 (coarse = parent batched scan)
+ *   - kmeans                                 src/cpp/src/clustering.cpp:13-97
+ *   - kmeans_refine_partitions               src/cpp/src/clustering.cpp:99-182
+ *   - parallel_for                           src/cpp/include/parallel.h:41-63 (static chunking over threads)
+ *
+ * Third-party arithmetic.  The distance primitives live in facebookresearch/faiss, pinned by the
+ * reference only as an un-populated git submodule (src/cpp/third_party/faiss is an empty directory;
+ * gitlink SHA not recoverable; "FAISS main at or before 2025-05-23").  The published semantics are
+ * restated here:  fvec_inner_product = sum x_i*y_i,  fvec_L2sqr = sum (x_i-y_i)^2,
+ * knn_L2sqr(batched) = ||x||^2 + ||y||^2 - 2 x.y clamped at 0, ascending, returns SQUARED distances,
+ * knn_inner_product descending.  FAISS leaves the float summation order to its SIMD/BLAS back end;
+ * this restatement FIXES it (the "canonical arithmetic"):
+ *     every dot product is ONE k-ordered fp32 fmaf chain  acc = fmaf(x[k], y[k], acc), k = 0..d-1, acc0 = +0
+ * which is bit-for-bit what gfx950's v_mfma_f32_16x16x4_f32 computes.
+ *
+ * Tie rule.  The reference's comparators look at the distance only (list_scanning.h:154-171), so the
+ * order of equal distances is unspecified (its own tests accept either id, test/cpp/list_scanning.cpp:52-54).
+ * This restatement uses the total order (key, id): L2 ascending squared distance then ascending id;
+ * IP descending inner product then ascending id.  L2 results are selected on the SQUARED distance and
+ * sqrt is applied to what is returned -- a refinement of the reference's order on sqrt(d2) (sqrt is monotone).
+ *
+ * Pinning.  The reference cannot be built here (FAISS absent), so this oracle is pinned against
+ * (a) the hand-computed vectors of test/cpp/list_scanning.cpp and test/cpp/topk_buffer.cpp transcribed
+ * as data in tests/golden/, (b) torch brute force (the reference tests' own ground truth,
+ * list_scanning.cpp:432-562), (c) fixtures produced by importing the reference's src/python/utils.py
+ * (knn / compute_recall) in the authoring container.  k-means: parity unpinned (no reference test
+ * checks centroids or assignments; FAISS's RNG stream is not reproducible here).
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include <float.h>
+#include <immintrin.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define QO_METRIC_IP 0 /* faiss::METRIC_INNER_PRODUCT */
+#define QO_METRIC_L2 1 /* faiss::METRIC_L2 */
+
+#define QO_API __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------------------------------------
+ * Distance primitives (canonical k-ordered fmaf chains)
+ * ---------------------------------------------------------------------------------------------- */
+
+/* faiss::fvec_inner_product call sites: list_scanning.h:248,273 */
+QO_API float qo_ip(const float *x, const float *y, int d) {
+    float acc = 0.0f;
+    for (int k = 0; k < d; k++) acc = fmaf(x[k], y[k], acc);
+    return acc;
+}
+
+/* faiss::fvec_L2sqr call sites: list_scanning.h:260,286 -- direct form sum (x-y)^2 */
+QO_API float qo_l2sqr_direct(const float *x, const float *y, int d) {
+    float acc = 0.0f;
+    for (int k = 0; k < d; k++) {
+        float t = x[k] - y[k];
+        acc = fmaf(t, t, acc);
+    }
+    return acc;
+}
+
+/* faiss::knn_L2sqr (BLAS path): ||x||^2 + ||y||^2 - 2 x.y, negative clamped to 0 */
+static inline float l2sqr_expanded(float xn, float yn, float ip) {
+    float s = xn + yn;
+    float r = fmaf(-2.0f, ip, s); /* == s - 2*ip exactly rounded once (2*ip is exact) */
+    return r < 0.0f ? 0.0f : r;
+}
+QO_API float qo_l2sqr_expanded(float xn, float yn, float ip) { return l2sqr_expanded(xn, yn, ip); }
+
+QO_API void qo_row_norms(const float *x, int64_t n, int d, float *out) {
+    for (int64_t i = 0; i < n; i++) out[i] = qo_ip(x + i * d, x + i * d, d);
+}
+
+/* 8 independent chains at once (8 queries vs one row): each lane is still ONE k-ordered fmaf chain,
+ * so the result is bit-identical to qo_ip; this only makes the CPU port run at SIMD speed. */
+static inline __m256 ip8_chain(const float *xT /* [d][8] */, const float *y, int d) {
+    __m256 acc = _mm256_setzero_ps();
+    for (int k = 0; k < d; k++)
+        acc = _mm256_fmadd_ps(_mm256_load_ps(xT + (size_t)k * 8), _mm256_broadcast_ss(y + k), acc);
+    return acc;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * TopkBuffer  (list_scanning.h:41-204)
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    float v;
+    int64_t id;
+} qo_pair;
+
+typedef struct qo_topk {
+    int k;        /* k_ */
+    int cap;      /* topk_.size(), default TOP_K_BUFFER_CAPACITY 8192 (list_scanning.h:39) */
+    int curr;     /* curr_offset_ */
+    int desc;     /* is_descending_ */
+    qo_pair *buf; /* topk_ */
+} qo_topk;
+
+static int cmp_asc(const void *a, const void *b) {
+    const qo_pair *p = (const qo_pair *)a, *q = (const qo_pair *)b;
+    if (p->v < q->v) return -1;
+    if (p->v > q->v) return 1;
+    return (p->id > q->id) - (p->id < q->id);
+}
+static int cmp_desc(const void *a, const void *b) {
+    const qo_pair *p = (const qo_pair *)a, *q = (const qo_pair *)b;
+    if (p->v > q->v) return -1;
+    if (p->v < q->v) return 1;
+    return (p->id > q->id) - (p->id < q->id);
+}
+
+static void topk_init(qo_topk *t, int k, int desc, int cap) {
+    if (cap < k + 1) cap = k + 1; /* the reference asserts k <= capacity (list_scanning.h:55); +1 keeps add() in bounds */
+    t->k = k;
+    t->cap = cap;
+    t->curr = 0;
+    t->desc = desc;
+    t->buf = (qo_pair *)malloc(sizeof(qo_pair) * (size_t)cap);
+    for (int i = 0; i < cap; i++) { /* sentinels, list_scanning.h:57-63 */
+        t->buf[i].v = desc ? -INFINITY : FLT_MAX;
+        t->buf[i].id = -1;
+    }
+}
+
+/* flush(): list_scanning.h:151-173.  partial_sort keeping k, or full sort of curr (<= k) entries. */
+static void topk_flush(qo_topk *t) {
+    qsort(t->buf, (size_t)t->curr, sizeof(qo_pair), t->desc ? cmp_desc : cmp_asc);
+    if (t->curr > t->k) t->curr = t->k;
+}
+
+/* add(): list_scanning.h:117-122 */
+static inline void topk_add(qo_topk *t, float v, int64_t id) {
+    if (t->curr >= t->cap) topk_flush(t);
+    t->buf[t->curr].v = v;
+    t->buf[t->curr].id = id;
+    t->curr++;
+}
+
+/* batch_add(): list_scanning.h:124-149 (job counters are threading bookkeeping, not restated) */
+static void topk_batch_add(qo_topk *t, const float *v, const int64_t *ids, int n) {
+    for (int i = 0; i < n; i++) topk_add(t, v[i], ids[i]);
+}
+
+QO_API qo_topk *qo_topk_create(int k, int is_descending, int capacity) {
+    qo_topk *t = (qo_topk *)malloc(sizeof(qo_topk));
+    topk_init(t, k, is_descending, capacity > 0 ? capacity : 8192);
+    return t;
+}
+QO_API void qo_topk_destroy(qo_topk *t) {
+    if (!t) return;
+    free(t->buf);
+    free(t);
+}
+QO_API void qo_topk_add(qo_topk *t, float v, int64_t id) { topk_add(t, v, id); }
+QO_API void qo_topk_batch_add(qo_topk *t, const float *v, const int64_t *ids, int n) { topk_batch_add(t, v, ids, n); }
+/* reset(): list_scanning.h:104-115 */
+QO_API void qo_topk_reset(qo_topk *t) {
+    t->curr = 0;
+    for (int i = 0; i < t->k && i < t->cap; i++) {
+        t->buf[i].v = t->desc ? -INFINITY : FLT_MAX;
+        t->buf[i].id = -1;
+    }
+}
+/* get_topk()/get_topk_indices(): list_scanning.h:175-203 -> min(curr,k) sorted entries; returns count */
+QO_API int qo_topk_get(qo_topk *t, float *out_v, int64_t *out_id) {
+    topk_flush(t);
+    int n = t->curr < t->k ? t->curr : t->k;
+    for (int i = 0; i < n; i++) {
+        if (out_v) out_v[i] = t->buf[i].v;
+        if (out_id) out_id[i] = t->buf[i].id;
+    }
+    return n;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * scan_list  (list_scanning.h:241-311): one query x one partition, direct per-row distances.
+ * squared_domain = 0: literal -- L2 adds sqrtf(fvec_L2sqr) like the reference (list_scanning.h:260,286)
+ * squared_domain = 1: L2 adds the squared distance (search-level callers sqrt what they return)
+ * list_ids == NULL: ids are row numbers (scan_list_no_ids_*)
+ * ---------------------------------------------------------------------------------------------- */
+QO_API void qo_scan_list(const float *q, const float *vecs, const int64_t *ids, int n, int d, qo_topk *buf, int metric,
+                         int squared_domain) {
+    const float *v = vecs;
+    for (int l = 0; l < n; l++, v += d) {
+        float val;
+        if (metric == QO_METRIC_IP) {
+            val = qo_ip(q, v, d);
+        } else {
+            val = qo_l2sqr_direct(q, v, d);
+            if (!squared_domain) val = sqrtf(val);
+        }
+        topk_add(buf, val, ids ? ids[l] : (int64_t)l);
+    }
+}
+
+/* 8-rows-at-a-time form of the L2 direct chain (8x8 register transpose): same bits as
+ * qo_l2sqr_direct per row, used by the timed cpu_baseline so the port is not handicapped by
+ * a scalar latency chain the reference (FAISS AVX2) does not have. */
+static inline void transpose8(__m256 r[8]) {
+    __m256 t0 = _mm256_unpacklo_ps(r[0], r[1]), t1 = _mm256_unpackhi_ps(r[0], r[1]);
+    __m256 t2 = _mm256_unpacklo_ps(r[2], r[3]), t3 = _mm256_unpackhi_ps(r[2], r[3]);
+    __m256 t4 = _mm256_unpacklo_ps(r[4], r[5]), t5 = _mm256_unpackhi_ps(r[4], r[5]);
+    __m256 t6 = _mm256_unpacklo_ps(r[6], r[7]), t7 = _mm256_unpackhi_ps(r[6], r[7]);
+    __m256 s0 = _mm256_shuffle_ps(t0, t2, 0x44), s1 = _mm256_shuffle_ps(t0, t2, 0xEE);
+    __m256 s2 = _mm256_shuffle_ps(t1, t3, 0x44), s3 = _mm256_shuffle_ps(t1, t3, 0xEE);
+    __m256 s4 = _mm256_shuffle_ps(t4, t6, 0x44), s5 = _mm256_shuffle_ps(t4, t6, 0xEE);
+    __m256 s6 = _mm256_shuffle_ps(t5, t7, 0x44), s7 = _mm256_shuffle_ps(t5, t7, 0xEE);
+    r[0] = _mm256_permute2f128_ps(s0, s4, 0x20);
+    r[1] = _mm256_permute2f128_ps(s1, s5, 0x20);
+    r[2] = _mm256_permute2f128_ps(s2, s6, 0x20);
+    r[3] = _mm256_permute2f128_ps(s3, s7, 0x20);
+    r[4] = _mm256_permute2f128_ps(s0, s4, 0x31);
+    r[5] = _mm256_permute2f128_ps(s1, s5, 0x31);
+    r[6] = _mm256_permute2f128_ps(s2, s6, 0x31);
+    r[7] = _mm256_permute2f128_ps(s3, s7, 0x31);
+}
+
+/* values for rows [0,n): out[l] = chain(q, vecs[l]) ; metric L2 -> direct squared form, IP -> dot */
+static void row_values_fast(const float *q, const float *vecs, int n, int d, int metric, float *out) {
+    int l = 0;
+    int d8 = d & ~7;
+    for (; l + 8 <= n; l += 8) {
+        __m256 acc = _mm256_setzero_ps();
+        const float *base = vecs + (size_t)l * d;
+        for (int k = 0; k < d8; k += 8) {
+            __m256 r[8];
+            for (int j = 0; j < 8; j++) r[j] = _mm256_loadu_ps(base + (size_t)j * d + k);
+            transpose8(r); /* r[t] = element k+t of the 8 rows */
+            for (int t = 0; t < 8; t++) {
+                __m256 qk = _mm256_broadcast_ss(q + k + t);
+                if (metric == QO_METRIC_IP) {
+                    acc = _mm256_fmadd_ps(qk, r[t], acc);
+                } else {
+                    __m256 df = _mm256_sub_ps(qk, r[t]);
+                    acc = _mm256_fmadd_ps(df, df, acc);
+                }
+            }
+        }
+        float a[8] __attribute__((aligned(32)));
+        _mm256_store_ps(a, acc);
+        for (int j = 0; j < 8; j++) { /* tail dims, still the same sequential chain */
+            float s = a[j];
+            const float *y = base + (size_t)j * d;
+            for (int k = d8; k < d; k++) {
+                if (metric == QO_METRIC_IP) {
+                    s = fmaf(q[k], y[k], s);
+                } else {
+                    float t = q[k] - y[k];
+                    s = fmaf(t, t, s);
+                }
+            }
+            out[l + j] = s;
+        }
+    }
+    for (; l < n; l++) {
+        const float *y = vecs + (size_t)l * d;
+        out[l] = metric == QO_METRIC_IP ? qo_ip(q, y, d) : qo_l2sqr_direct(q, y, d);
+    }
+}
+
+/* bit-identical to qo_scan_list(..., squared_domain=1) but SIMD across rows */
+static void scan_list_fast(const float *q, const float *vecs, const int64_t *ids, int n, int d, qo_topk *buf, int metric) {
+    enum { BLK = 1024 };
+    float vals[BLK];
+    for (int s = 0; s < n; s += BLK) {
+        int m = n - s < BLK ? n - s : BLK;
+        row_values_fast(q, vecs + (size_t)s * d, m, d, metric, vals);
+        for (int l = 0; l < m; l++) topk_add(buf, vals[l], ids ? ids[s + l] : (int64_t)(s + l));
+    }
+}
+QO_API void qo_scan_list_fast(const float *q, const float *vecs, const int64_t *ids, int n, int d, qo_topk *buf, int metric) {
+    scan_list_fast(q, vecs, ids, n, d, buf, metric);
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * knn_L2sqr / knn_inner_product restatement + batched_scan_list (list_scanning.h:313-366)
+ *   nq queries x one list -> per query local top-k_max (k_max = min(k, n)), selected on the squared
+ *   distance (L2) / inner product (IP) with the (key,id) tie rule on the MAPPED id, then pushed into
+ *   the per-query buffers with batch_add.  squared_domain as in qo_scan_list (the reference sqrt()s
+ *   before batch_add, list_scanning.h:353-357).
+ * ---------------------------------------------------------------------------------------------- */
+static void batched_values(const float *queries, const float *qnorm, int nq, const float *vecs, int n, int d, int metric,
+                           float *out /* [nq][n] */) {
+    /* blocks of 8 queries, transposed to [d][8] so that 8 chains run in one AVX register */
+    float *xT = (float *)aligned_alloc(32, sizeof(float) * 8 * (size_t)d);
+    for (int q0 = 0; q0 < nq; q0 += 8) {
+        int nb = nq - q0 < 8 ? nq - q0 : 8;
+        for (int k = 0; k < d; k++)
+            for (int j = 0; j < 8; j++) xT[(size_t)k * 8 + j] = j < nb ? queries[(size_t)(q0 + j) * d + k] : 0.0f;
+        for (int l = 0; l < n; l++) {
+            const float *y = vecs + (size_t)l * d;
+            float ip[8] __attribute__((aligned(32)));
+            _mm256_store_ps(ip, ip8_chain(xT, y, d));
+            if (metric == QO_METRIC_IP) {
+                for (int j = 0; j < nb; j++) out[(size_t)(q0 + j) * n + l] = ip[j];
+            } else {
+                float yn = qo_ip(y, y, d);
+                for (int j = 0; j < nb; j++) out[(size_t)(q0 + j) * n + l] = l2sqr_expanded(qnorm[q0 + j], yn, ip[j]);
+            }
+        }
+    }
+    free(xT);
+}
+
+QO_API void qo_batched_scan_list(const float *queries, const float *vecs, const int64_t *ids, int nq, int n, int d,
+                                 qo_topk **bufs, int metric, int squared_domain) {
+    if (n == 0 || vecs == NULL) return; /* list_scanning.h:321-324 */
+    int k = bufs[0]->k;
+    int k_max = k < n ? k : n; /* list_scanning.h:327-328 */
+    int desc = metric == QO_METRIC_IP;
+    float *qnorm = (float *)malloc(sizeof(float) * (size_t)nq);
+    if (metric == QO_METRIC_L2) qo_row_norms(queries, nq, d, qnorm);
+    enum { QB = 64 };
+    float *vals = (float *)malloc(sizeof(float) * (size_t)QB * (size_t)n);
+    qo_topk local;
+    topk_init(&local, k_max, desc, k_max * 10 > 8192 ? k_max * 10 : 8192);
+    float *ov = (float *)malloc(sizeof(float) * (size_t)k_max);
+    int64_t *oi = (int64_t *)malloc(sizeof(int64_t) * (size_t)k_max);
+    for (int q0 = 0; q0 < nq; q0 += QB) {
+        int nb = nq - q0 < QB ? nq - q0 : QB;
+        batched_values(queries + (size_t)q0 * d, qnorm + q0, nb, vecs, n, d, metric, vals);
+        for (int j = 0; j < nb; j++) {
+            local.curr = 0;
+            for (int l = 0; l < n; l++) topk_add(&local, vals[(size_t)j * n + l], ids ? ids[l] : (int64_t)l);
+            topk_flush(&local);
+            int m = local.curr;
+            for (int i = 0; i < m; i++) {
+                ov[i] = (metric == QO_METRIC_L2 && !squared_domain) ? sqrtf(local.buf[i].v) : local.buf[i].v;
+                oi[i] = local.buf[i].id;
+            }
+            topk_batch_add(bufs[q0 + j], ov, oi, m);
+        }
+    }
+    free(ov);
+    free(oi);
+    free(local.buf);
+    free(vals);
+    free(qnorm);
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Partition store view used by the search-level restatements: CSR arena
+ *   vecs [offsets[nlist]][d], ids [offsets[nlist]], partition p = rows offsets[p] .. offsets[p+1]-1
+ * (row order inside a partition = IndexPartition::codes_/ids_ order, index_partition.cpp:52-59)
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    const float *vecs;
+    const int64_t *ids;
+    const int64_t *offsets;
+    int64_t nlist;
+    int d;
+} qo_store;
+
+static void emit_result(qo_topk *t, int k, int metric, int64_t *out_ids, float *out_dist) {
+    /* output + padding: query_coordinator.cpp:586-601 / 774-788 */
+    topk_flush(t);
+    int n = t->curr < k ? t->curr : k;
+    for (int i = 0; i < n; i++) {
+        out_ids[i] = t->buf[i].id;
+        out_dist[i] = metric == QO_METRIC_L2 ? sqrtf(t->buf[i].v) : t->buf[i].v;
+    }
+    for (int i = n; i < k; i++) {
+        out_ids[i] = -1;
+        out_dist[i] = metric == QO_METRIC_IP ? -INFINITY : INFINITY;
+    }
+}
+
+/* serial_scan: query_coordinator.cpp:471-611.  pids [nq][P] (-1 = skip, :540).  fast=1 uses the
+ * SIMD-across-rows form (bit-identical).  num_threads as SearchParams::num_threads (parallel_for). */
+QO_API void qo_serial_scan(const float *x, int64_t nq, const float *vecs, const int64_t *ids, const int64_t *offsets,
+                           int64_t nlist, int d, const int64_t *pids, int P, int k, int metric, int num_threads, int fast,
+                           int64_t *out_ids, float *out_dist) {
+    if (k <= 0) k = 1; /* :490 */
+    if (num_threads <= 0) {
+#ifdef _OPENMP
+        num_threads = omp_get_max_threads();
+#else
+        num_threads = 1;
+#endif
+    }
+#pragma omp parallel for num_threads(num_threads) schedule(static)
+    for (int64_t q = 0; q < nq; q++) {
+        qo_topk buf;
+        topk_init(&buf, k, metric == QO_METRIC_IP, 8192 > k ? 8192 : k); /* :517 */
+        for (int p = 0; p < P; p++) {
+            int64_t pi = pids[q * P + p];
+            if (pi < 0 || pi >= nlist) continue;
+            int64_t o = offsets[pi];
+            int n = (int)(offsets[pi + 1] - o);
+            if (fast)
+                scan_list_fast(x + q * d, vecs + o * d, ids + o, n, d, &buf, metric);
+            else
+                qo_scan_list(x + q * d, vecs + o * d, ids + o, n, d, &buf, metric, 1);
+        }
+        emit_result(&buf, k, metric, out_ids + q * k, out_dist + q * k);
+        free(buf.buf);
+    }
+}
+
+/* batched_serial_scan: query_coordinator.cpp:675-799.  Group queries by partition (:707-721), one
+ * batched_scan_list per group (:742-749), merge into per-query global buffers (:752-758). */
+QO_API void qo_batched_serial_scan(const float *x, int64_t nq, const float *vecs, const int64_t *ids,
+                                   const int64_t *offsets, int64_t nlist, int d, const int64_t *pids, int P, int k,
+                                   int metric, int num_threads, int64_t *out_ids, float *out_dist) {
+    if (k <= 0) k = 1;
+    int desc = metric == QO_METRIC_IP;
+    qo_topk **global = (qo_topk **)malloc(sizeof(qo_topk *) * (size_t)(nq > 0 ? nq : 1));
+    for (int64_t q = 0; q < nq; q++) global[q] = qo_topk_create(k, desc, 10 * k); /* create_buffers :233-239 */
+    /* counting sort of (q,p) pairs by partition id */
+    int64_t *cnt = (int64_t *)calloc((size_t)nlist + 1, sizeof(int64_t));
+    for (int64_t i = 0; i < nq * P; i++) {
+        int64_t pi = pids[i];
+        if (pi >= 0 && pi < nlist) cnt[pi + 1]++;
+    }
+    for (int64_t p = 0; p < nlist; p++) cnt[p + 1] += cnt[p];
+    int64_t total = cnt[nlist];
+    int64_t *grouped = (int64_t *)malloc(sizeof(int64_t) * (size_t)(total > 0 ? total : 1));
+    int64_t *cur = (int64_t *)malloc(sizeof(int64_t) * (size_t)(nlist > 0 ? nlist : 1));
+    memcpy(cur, cnt, sizeof(int64_t) * (size_t)nlist);
+    for (int64_t q = 0; q < nq; q++)
+        for (int p = 0; p < P; p++) {
+            int64_t pi = pids[q * P + p];
+            if (pi >= 0 && pi < nlist) grouped[cur[pi]++] = q;
+        }
+    if (num_threads <= 0) {
+#ifdef _OPENMP
+        num_threads = omp_get_max_threads();
+#else
+        num_threads = 1;
+#endif
+    }
+    /* the merge into global buffers is order-independent under the (key,id) total order, so the
+     * parallel loop only needs mutual exclusion per query (the reference holds a mutex, :133) */
+#pragma omp parallel for num_threads(num_threads) schedule(dynamic, 1)
+    for (int64_t p = 0; p < nlist; p++) {
+        int64_t g0 = cnt[p], g1 = cnt[p + 1];
+        int nb = (int)(g1 - g0);
+        if (nb == 0) continue;
+        int64_t o = offsets[p];
+        int n = (int)(offsets[p + 1] - o);
+        if (n == 0) continue;
+        float *xs = (float *)malloc(sizeof(float) * (size_t)nb * (size_t)d); /* index_select :728-729 */
+        qo_topk **local = (qo_topk **)malloc(sizeof(qo_topk *) * (size_t)nb);
+        for (int j = 0; j < nb; j++) {
+            memcpy(xs + (size_t)j * d, x + grouped[g0 + j] * d, sizeof(float) * (size_t)d);
+            local[j] = qo_topk_create(k, desc, 10 * k);
+        }
+        qo_batched_scan_list(xs, vecs + o * d, ids + o, nb, n, d, local, metric, 1);
+        for (int j = 0; j < nb; j++) {
+            topk_flush(local[j]);
+            int m = local[j]->curr;
+            float *v = (float *)malloc(sizeof(float) * (size_t)(m > 0 ? m : 1));
+            int64_t *id = (int64_t *)malloc(sizeof(int64_t) * (size_t)(m > 0 ? m : 1));
+            for (int i = 0; i < m; i++) {
+                v[i] = local[j]->buf[i].v;
+                id[i] = local[j]->buf[i].id;
+            }
+#pragma omp critical(qo_global_merge)
+            topk_batch_add(global[grouped[g0 + j]], v, id, m);
+            free(v);
+            free(id);
+            qo_topk_destroy(local[j]);
+        }
+        free(local);
+        free(xs);
+    }
+    for (int64_t q = 0; q < nq; q++) {
+        emit_result(global[q], k, metric, out_ids + q * k, out_dist + q * k);
+        qo_topk_destroy(global[q]);
+    }
+    free(global);
+    free(cnt);
+    free(grouped);
+    free(cur);
+}
+
+/* Coarse step = parent (flat) index search, query_coordinator.cpp:628-644: batched scan of the
+ * centroid list with k = min(nprobe, nlist); ids returned are the parent's ids_ = partition ids.
+ * out_pids [nq][kk], kk = min(nprobe, nlist); out_cdist may be NULL. */
+QO_API int qo_coarse(const float *x, int64_t nq, const float *centroids, const int64_t *centroid_ids, int64_t nlist, int d,
+                     int nprobe, int metric, int num_threads, int64_t *out_pids, float *out_cdist) {
+    int kk = nprobe < nlist ? nprobe : (int)nlist;
+    if (kk <= 0) return 0;
+    int64_t offsets[2] = {0, nlist};
+    int64_t *zero = (int64_t *)calloc((size_t)(nq > 0 ? nq : 1), sizeof(int64_t));
+    float *dist = out_cdist ? out_cdist : (float *)malloc(sizeof(float) * (size_t)(nq > 0 ? nq : 1) * (size_t)kk);
+    int64_t *own_ids = NULL;
+    if (!centroid_ids) {
+        own_ids = (int64_t *)calloc((size_t)nlist, sizeof(int64_t));
+        for (int64_t i = 0; i < nlist; i++) own_ids[i] = i;
+        centroid_ids = own_ids;
+    }
+    qo_batched_serial_scan(x, nq, centroids, centroid_ids, offsets, 1, d, zero, 1, kk, metric, num_threads, out_pids, dist);
+    if (!out_cdist) free(dist);
+    free(own_ids);
+    free(zero);
+    return kk;
+}
+
+/* QueryCoordinator::search, query_coordinator.cpp:612-657, fixed nprobe.  batched_scan selects
+ * batched_serial_scan vs serial_scan (:659-673); centroids==NULL = flat index (scan every partition). */
+QO_API void qo_search(const float *x, int64_t nq, const float *centroids, const int64_t *centroid_ids, const float *vecs,
+                      const int64_t *ids, const int64_t *offsets, int64_t nlist, int d, int nprobe, int k, int metric,
+                      int batched_scan, int num_threads, int fast, int64_t *out_ids, float *out_dist) {
+    int P;
+    int64_t *pids;
+    if (!centroids) { /* :624-626 arange(nlist) for every query */
+        P = (int)nlist;
+        pids = (int64_t *)malloc(sizeof(int64_t) * (size_t)(nq > 0 ? nq : 1) * (size_t)(P > 0 ? P : 1));
+        for (int64_t q = 0; q < nq; q++)
+            for (int p = 0; p < P; p++) pids[q * P + p] = p;
+    } else {
+        P = nprobe < nlist ? nprobe : (int)nlist;
+        pids = (int64_t *)malloc(sizeof(int64_t) * (size_t)(nq > 0 ? nq : 1) * (size_t)(P > 0 ? P : 1));
+        qo_coarse(x, nq, centroids, centroid_ids, nlist, d, nprobe, metric, num_threads, pids, NULL);
+    }
+    if (batched_scan)
+        qo_batched_serial_scan(x, nq, vecs, ids, offsets, nlist, d, pids, P, k, metric, num_threads, out_ids, out_dist);
+    else
+        qo_serial_scan(x, nq, vecs, ids, offsets, nlist, d, pids, P, k, metric, num_threads, fast, out_ids, out_dist);
+    free(pids);
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * k-means (clustering.cpp:13-97 wraps faiss::Clustering::train + IndexFlat::search(k=1))
+ * PARITY UNPINNED: no reference test checks centroids/assignments and FAISS's RNG is not reproducible
+ * here.  Canonical choices (shared with the HIP path):
+ *   assign : argmin over centroids of the expanded L2 (or argmax of the dot) with ties -> lower index
+ *   update : centroid = (sum of assigned rows, added in ascending row order, fp32) * (1/count)... see below
+ *   empty  : FAISS split_clusters semantics restated: an empty cluster takes a copy of a large cluster's
+ *            centroid, the pair perturbed by (1 +/- 1/1024), chosen deterministically (largest count first)
+ *   init   : centroids = rows perm[0..k) of a splitmix64-driven Fisher-Yates permutation (seed 1234)
+ *   subsample: if n > 256*k (FAISS max_points_per_centroid), train on the first 256*k rows of that permutation
+ * ---------------------------------------------------------------------------------------------- */
+static inline uint64_t splitmix64(uint64_t *s) {
+    uint64_t z = (*s += 0x9E3779B97F4A7C15ULL);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+
+/* perm[0..m): first m entries of the Fisher-Yates permutation of [0,n) */
+QO_API void qo_rand_perm(int64_t n, int64_t m, uint64_t seed, int64_t *perm_out) {
+    int64_t *p = (int64_t *)malloc(sizeof(int64_t) * (size_t)n);
+    for (int64_t i = 0; i < n; i++) p[i] = i;
+    uint64_t s = seed;
+    for (int64_t i = 0; i < m && i < n - 1; i++) {
+        uint64_t r = splitmix64(&s);
+        int64_t j = i + (int64_t)(r % (uint64_t)(n - i));
+        int64_t t = p[i];
+        p[i] = p[j];
+        p[j] = t;
+    }
+    memcpy(perm_out, p, sizeof(int64_t) * (size_t)(m < n ? m : n));
+    free(p);
+}
+
+/* assign: IndexFlat::search(n, x, 1) (clustering.cpp:63-66).  out_val = squared L2 / dot. */
+QO_API void qo_kmeans_assign(const float *x, int64_t n, const float *c, int64_t m, int d, int metric, int num_threads,
+                             int64_t *assign, float *out_val) {
+    float *cn = (float *)malloc(sizeof(float) * (size_t)m);
+    qo_row_norms(c, m, d, cn);
+    if (num_threads <= 0) {
+#ifdef _OPENMP
+        num_threads = omp_get_max_threads();
+#else
+        num_threads = 1;
+#endif
+    }
+#pragma omp parallel num_threads(num_threads)
+    {
+        float *xT = (float *)aligned_alloc(32, sizeof(float) * 8 * (size_t)d);
+#pragma omp for schedule(static)
+        for (int64_t b = 0; b < (n + 7) / 8; b++) {
+            int64_t i0 = b * 8;
+            int nb = (int)(n - i0 < 8 ? n - i0 : 8);
+            float xn[8];
+            for (int k = 0; k < d; k++)
+                for (int j = 0; j < 8; j++) xT[(size_t)k * 8 + j] = j < nb ? x[(size_t)(i0 + j) * d + k] : 0.0f;
+            for (int j = 0; j < nb; j++) xn[j] = qo_ip(x + (i0 + j) * d, x + (i0 + j) * d, d);
+            float best[8];
+            int64_t bi[8];
+            for (int j = 0; j < 8; j++) {
+                best[j] = metric == QO_METRIC_IP ? -INFINITY : INFINITY;
+                bi[j] = -1;
+            }
+            for (int64_t cc = 0; cc < m; cc++) {
+                float ip[8] __attribute__((aligned(32)));
+                _mm256_store_ps(ip, ip8_chain(xT, c + cc * d, d));
+                for (int j = 0; j < nb; j++) {
+                    if (metric == QO_METRIC_IP) {
+                        if (ip[j] > best[j] || bi[j] < 0) {
+                            best[j] = ip[j];
+                            bi[j] = cc;
+                        }
+                    } else {
+                        float v = l2sqr_expanded(xn[j], cn[cc], ip[j]);
+                        if (v < best[j] || bi[j] < 0) {
+                            best[j] = v;
+                            bi[j] = cc;
+                        }
+                    }
+                }
+            }
+            for (int j = 0; j < nb; j++) {
+                assign[i0 + j] = bi[j];
+                if (out_val) out_val[i0 + j] = best[j];
+            }
+        }
+        free(xT);
+    }
+    free(cn);
+}
+
+/* update: per-cluster sums (fp32, rows added in ascending row index order) and counts.
+ * This is the accumulate loop of kmeans_refine_partitions (clustering.cpp:168-171) and the mean
+ * update of faiss::Clustering. */
+QO_API void qo_kmeans_accumulate(const float *x, int64_t n, int d, const int64_t *assign, int64_t m, float *sums,
+                                 int64_t *counts) {
+    memset(sums, 0, sizeof(float) * (size_t)m * (size_t)d);
+    memset(counts, 0, sizeof(int64_t) * (size_t)m);
+    for (int64_t i = 0; i < n; i++) {
+        int64_t a = assign[i];
+        if (a < 0 || a >= m) continue;
+        float *s = sums + a * d;
+        const float *v = x + i * d;
+        for (int k = 0; k < d; k++) s[k] += v[k];
+        counts[a]++;
+    }
+}
+
+/* centroids = sums / counts (clustering.cpp:122-124: float division by the count; count 0 -> NaN there;
+ * keep_empty=1 leaves the previous centroid instead, used by qo_kmeans which then splits) */
+QO_API void qo_kmeans_finalize(const float *sums, const int64_t *counts, int64_t m, int d, int keep_empty, float *c) {
+    for (int64_t j = 0; j < m; j++) {
+        if (counts[j] == 0 && keep_empty) continue;
+        float cnt = (float)counts[j];
+        for (int k = 0; k < d; k++) c[j * d + k] = sums[j * d + k] / cnt;
+    }
+}
+
+/* faiss split_clusters restated deterministically: for each empty cluster (ascending index) pick the
+ * currently largest cluster (ties -> lowest index), copy its centroid, perturb the pair by (1 +/- eps)
+ * alternating sign per dimension, split the count.  Returns number of splits. */
+static int split_empty(float *c, int64_t *counts, int64_t m, int d) {
+    const float EPS = 1.0f / 1024.0f;
+    int nsplit = 0;
+    for (int64_t ci = 0; ci < m; ci++) {
+        if (counts[ci] != 0) continue;
+        int64_t cj = 0;
+        for (int64_t j = 1; j < m; j++)
+            if (counts[j] > counts[cj]) cj = j;
+        if (counts[cj] < 2) continue;
+        memcpy(c + ci * d, c + cj * d, sizeof(float) * (size_t)d);
+        for (int k = 0; k < d; k++) {
+            if (k % 2 == 0) {
+                c[ci * d + k] *= 1 + EPS;
+                c[cj * d + k] *= 1 - EPS;
+            } else {
+                c[ci * d + k] *= 1 - EPS;
+                c[cj * d + k] *= 1 + EPS;
+            }
+        }
+        counts[ci] = counts[cj] / 2;
+        counts[cj] -= counts[ci];
+        nsplit++;
+    }
+    return nsplit;
+}
+
+static void normalize_rows(float *x, int64_t n, int d) {
+    /* vectors / vectors.norm(2,1).unsqueeze(1) (clustering.cpp:25-26,59-60): canonical norm = sqrtf(chain) */
+    for (int64_t i = 0; i < n; i++) {
+        float nn = sqrtf(qo_ip(x + i * d, x + i * d, d));
+        for (int k = 0; k < d; k++) x[i * d + k] = x[i * d + k] / nn;
+    }
+}
+QO_API void qo_normalize_rows(float *x, int64_t n, int d) { normalize_rows(x, n, d); }
+
+/* kmeans(): clustering.cpp:13-97.  x is modified in place for IP (normalised copies are what get stored,
+ * clustering.cpp:25-26,71).  Outputs centroids [m][d] and the final full assignment [n]. */
+QO_API void qo_kmeans(float *x, int64_t n, int d, int64_t m, int metric, int niter, uint64_t seed, int num_threads,
+                      float *centroids, int64_t *assign) {
+    if (metric == QO_METRIC_IP) normalize_rows(x, n, d);
+    int64_t ntrain = n;
+    const int64_t max_pts = 256; /* faiss ClusteringParameters::max_points_per_centroid */
+    int64_t *perm = (int64_t *)malloc(sizeof(int64_t) * (size_t)n);
+    int64_t need = n > max_pts * m ? max_pts * m : m;
+    qo_rand_perm(n, need, seed, perm);
+    float *xt = x;
+    if (n > max_pts * m) {
+        ntrain = max_pts * m;
+        xt = (float *)malloc(sizeof(float) * (size_t)ntrain * (size_t)d);
+        for (int64_t i = 0; i < ntrain; i++) memcpy(xt + i * d, x + perm[i] * d, sizeof(float) * (size_t)d);
+        for (int64_t j = 0; j < m; j++) memcpy(centroids + j * d, xt + j * d, sizeof(float) * (size_t)d);
+    } else {
+        for (int64_t j = 0; j < m; j++) memcpy(centroids + j * d, x + perm[j] * d, sizeof(float) * (size_t)d);
+    }
+    float *sums = (float *)malloc(sizeof(float) * (size_t)m * (size_t)d);
+    int64_t *counts = (int64_t *)malloc(sizeof(int64_t) * (size_t)m);
+    int64_t *ta = (int64_t *)malloc(sizeof(int64_t) * (size_t)ntrain);
+    for (int it = 0; it < niter; it++) {
+        qo_kmeans_assign(xt, ntrain, centroids, m, d, metric, num_threads, ta, NULL);
+        qo_kmeans_accumulate(xt, ntrain, d, ta, m, sums, counts);
+        qo_kmeans_finalize(sums, counts, m, d, 1, centroids);
+        split_empty(centroids, counts, m, d);
+    }
+    if (metric == QO_METRIC_IP) normalize_rows(centroids, m, d); /* clustering.cpp:59-60 */
+    qo_kmeans_assign(x, n, centroids, m, d, metric, num_threads, assign, NULL); /* :63-66 */
+    if (xt != x) free(xt);
+    free(perm);
+    free(sums);
+    free(counts);
+    free(ta);
+}
+
+/* kmeans_refine_partitions(): clustering.cpp:99-182 on the CSR view.  In: centroids [m][d] (updated in
+ * place to "the centroids used for the last assignment", :178), vecs/ids/offsets over m partitions.
+ * Out: new CSR (out_vecs [total][d], out_ids [total], out_offsets [m+1]).  Row order of each new
+ * partition = order of append (:174): input partitions in order, rows in order.
+ * NB create_buffers(nvec, 1, false) (:146): k=1, so the buffer's ascending flag is irrelevant;
+ * batched_scan_list(metric) picks min squared L2 or max dot. */
+QO_API void qo_kmeans_refine_partitions(float *centroids, int64_t m, int d, const float *vecs, const int64_t *ids,
+                                        const int64_t *offsets, int metric, int refinement_iterations, int num_threads,
+                                        float *out_vecs, int64_t *out_ids, int64_t *out_offsets) {
+    int iterations = refinement_iterations > 0 ? refinement_iterations : 1; /* :110 */
+    int64_t total = offsets[m];
+    float *cur_v = (float *)malloc(sizeof(float) * (size_t)(total > 0 ? total : 1) * (size_t)d);
+    int64_t *cur_i = (int64_t *)malloc(sizeof(int64_t) * (size_t)(total > 0 ? total : 1));
+    int64_t *cur_o = (int64_t *)malloc(sizeof(int64_t) * (size_t)(m + 1));
+    memcpy(cur_v, vecs, sizeof(float) * (size_t)total * (size_t)d);
+    memcpy(cur_i, ids, sizeof(int64_t) * (size_t)total);
+    memcpy(cur_o, offsets, sizeof(int64_t) * (size_t)(m + 1));
+    float *sums = (float *)calloc((size_t)m * (size_t)d, sizeof(float));
+    int64_t *counts = (int64_t *)calloc((size_t)m, sizeof(int64_t));
+    int64_t *assign = (int64_t *)malloc(sizeof(int64_t) * (size_t)(total > 0 ? total : 1));
+    for (int iter = 0; iter < iterations; iter++) {
+        if (iter > 0) qo_kmeans_finalize(sums, counts, m, d, 0, centroids); /* :122-124 (count 0 -> NaN, as there) */
+        /* the arena is the concatenation of the partitions in order, so one assign over all rows ==
+         * the per-partition batched_scan_list(k=1) loop (:139-159) */
+        qo_kmeans_assign(cur_v, total, centroids, m, d, metric, num_threads, assign, NULL);
+        qo_kmeans_accumulate(cur_v, total, d, assign, m, sums, counts); /* :168-171 */
+        /* stable bucket by assignment == per-vector append (:174) */
+        out_offsets[0] = 0;
+        for (int64_t j = 0; j < m; j++) out_offsets[j + 1] = out_offsets[j] + counts[j];
+        int64_t *cursor = (int64_t *)malloc(sizeof(int64_t) * (size_t)m);
+        memcpy(cursor, out_offsets, sizeof(int64_t) * (size_t)m);
+        for (int64_t i = 0; i < total; i++) {
+            int64_t a = assign[i];
+            if (a < 0) continue; /* NaN centroids: unassigned (cannot happen unless a cluster emptied) */
+            int64_t pos = cursor[a]++;
+            memcpy(out_vecs + pos * d, cur_v + i * d, sizeof(float) * (size_t)d);
+            out_ids[pos] = cur_i[i];
+        }
+        free(cursor);
+        memcpy(cur_v, out_vecs, sizeof(float) * (size_t)total * (size_t)d);
+        memcpy(cur_i, out_ids, sizeof(int64_t) * (size_t)total);
+        memcpy(cur_o, out_offsets, sizeof(int64_t) * (size_t)(m + 1));
+    }
+    free(cur_v);
+    free(cur_i);
+    free(cur_o);
+    free(sums);
+    free(counts);
+    free(assign);
+}
+
+/* calculate_recall (list_scanning.h:14-37): per-query |ids ∩ gt| / k */
+QO_API void qo_recall(const int64_t *ids, const int64_t *gt, int64_t nq, int k, float *out) {
+    for (int64_t q = 0; q < nq; q++) {
+        int c = 0;
+        for (int j = 0; j < k; j++) {
+            int64_t v = ids[q * k + j];
+            for (int t = 0; t < k; t++)
+                if (gt[q * k + t] == v) {
+                    c++;
+                    break;
+                }
+        }
+        out[q] = (float)c / (float)k;
+    }
+}
+
+/* compute_recall (src/python/utils.py:162-177): per-query |set(ids) & set(gt)| / k  (duplicates count once) */
+QO_API void qo_recall_set(const int64_t *ids, const int64_t *gt, int64_t nq, int k, float *out) {
+    for (int64_t q = 0; q < nq; q++) {
+        int c = 0;
+        for (int j = 0; j < k; j++) {
+            int64_t v = ids[q * k + j];
+            int seen = 0;
+            for (int t = 0; t < j; t++)
+                if (ids[q * k + t] == v) seen = 1;
+            if (seen) continue;
+            for (int t = 0; t < k; t++)
+                if (gt[q * k + t] == v) {
+                    c++;
+                    break;
+                }
+        }
+        out[q] = (float)c / (float)k;
+    }
+}
+
+QO_API int qo_max_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
