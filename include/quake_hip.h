@@ -1,0 +1,160 @@
+/*
+ * quake_hip.h -- C ABI of libquake_hip.so: the MI355X (gfx950) implementation of Quake's
+ * search / k-means hot path.
+ *
+ * The reference (marius-team/quake @ 2025-05-23) has NO C ABI or plugin registry: its boundary is the
+ * C++ class API + pybind11.  These entry points are what the bodies of the
+ * reference's C++ methods would bind when the hot path is delegated to the GPU; each one cites the
+ * reference interface it replaces (paths relative to the reference checkout).  The host-side mirror of
+ * the C++/Python surface (quake_amd/) is written against exactly this header.
+ *
+ * Conventions
+ *   - plain pointers + sizes, no torch / C++ types; every function returns a qk_status (0 = ok) and
+ *     records a message retrievable with qk_last_error() (the C++ side turns it into
+ *     std::runtime_error / std::invalid_argument like the reference's throws).
+ *   - `mem` says where the caller's data pointers live: QK_MEM_HOST (pageable or pinned host memory,
+ *     what the reference's CPU tensors are) or QK_MEM_DEVICE (HBM of the context's device).
+ *   - metric codes are faiss::MetricType's: 0 = inner product, 1 = L2 (common.h:145-156).
+ *   - L2 results are sqrt distances, like the reference (list_scanning.h:260,286,353-357).
+ *   - fewer than k results: ids -1, distances +inf (L2) / -inf (IP) (query_coordinator.cpp:589-601,774-788).
+ *   - ordering is the total order (key, id) -- DESIGN.md section 3.
+ *   - all work is enqueued on the context's HIP stream; host-memory outputs are complete on return,
+ *     device-memory outputs are complete after qk_ctx_synchronize() (or stream order).
+ */
+#ifndef QUAKE_HIP_H
+#define QUAKE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QK_API __attribute__((visibility("default")))
+
+typedef enum {
+    QK_OK = 0,
+    QK_ERR_INVALID = 1,     /* bad argument (std::invalid_argument in the reference) */
+    QK_ERR_NOT_FOUND = 2,   /* "List does not exist" (dynamic_inverted_list.cpp:71,79,87) */
+    QK_ERR_HIP = 3,         /* HIP runtime error */
+    QK_ERR_UNSUPPORTED = 4, /* outside the implemented envelope (e.g. k > QK_MAX_K) */
+    QK_ERR_OOM = 5
+} qk_status;
+
+#define QK_METRIC_IP 0
+#define QK_METRIC_L2 1
+#define QK_MEM_HOST 0
+#define QK_MEM_DEVICE 1
+#define QK_MAX_K 512 /* largest k / nprobe of the fused LDS top-k (reference: 8192, list_scanning.h:39) */
+
+typedef struct qk_ctx qk_ctx;     /* device + stream + scratch workspace                     */
+typedef struct qk_store qk_store; /* device mirror of faiss::DynamicInvertedLists (one level) */
+
+/* Per-call timing, filled from HIP events; mirrors the fields of SearchTimingInfo (common.h:214-228)
+ * that still mean something on a GPU. */
+typedef struct {
+    float coarse_ms;  /* parent search (query_coordinator.cpp:644)            */
+    float group_ms;   /* partition -> query grouping (query_coordinator.cpp:707-721) */
+    float scan_ms;    /* partition scan kernel(s)                               */
+    float merge_ms;   /* per-query merge + output                               */
+    float total_ms;
+    int64_t n_items;          /* work items scanned                              */
+    int64_t scan_bytes;       /* algorithmic bytes of the scan: sum over unique probed partitions n_p*d*4 */
+    int64_t partitions_scanned; /* (query, partition) pairs scanned              */
+} qk_timing;
+
+/* ---- errors ------------------------------------------------------------------------------------ */
+QK_API const char *qk_last_error(void);
+QK_API const char *qk_version(void);
+
+/* ---- context ----------------------------------------------------------------------------------- */
+/* device: HIP ordinal.  Creates a private non-blocking stream. */
+QK_API int qk_ctx_create(int device, qk_ctx **out);
+QK_API int qk_ctx_destroy(qk_ctx *ctx);
+/* Run on a caller-owned hipStream_t instead (e.g. torch's current stream); NULL restores the private one. */
+QK_API int qk_ctx_set_stream(qk_ctx *ctx, void *hip_stream);
+QK_API int qk_ctx_synchronize(qk_ctx *ctx);
+/* Enable/disable hipEvent timing of the phases (fills qk_timing; adds event records to the stream). */
+QK_API int qk_ctx_set_timing(qk_ctx *ctx, int enabled);
+/* Device properties the harness prints: CU count, clock (kHz), total HBM bytes, gcnArchName. */
+QK_API int qk_ctx_device_info(qk_ctx *ctx, int *num_cus, int *clock_khz, int64_t *hbm_bytes, char *arch, int arch_len);
+
+/* ---- partition store ---------------------------------------------------------------------------
+ * Replaces faiss::DynamicInvertedLists / IndexPartition as the thing the scan reads
+ * (dynamic_inverted_list.h:25-33, index_partition.h:19-32, accessors dynamic_inverted_list.cpp:68-90).
+ * Observable behaviour kept: append order, swap-with-last remove (index_partition.cpp:79-102).      */
+QK_API int qk_store_create(qk_ctx *ctx, int d, qk_store **out);                 /* DynamicInvertedLists(0, d*4) */
+QK_API int qk_store_destroy(qk_store *s);
+QK_API int qk_store_reset(qk_store *s);                                         /* reset() :300-304 */
+QK_API int qk_store_add_list(qk_store *s, int64_t list_no);                     /* add_list :262-270 */
+QK_API int qk_store_remove_list(qk_store *s, int64_t list_no);                  /* remove_list :251-260 */
+/* add_entries :152-173 -> IndexPartition::append (index_partition.cpp:52-59).  vecs [n][d] row-major f32. */
+QK_API int qk_store_add_entries(qk_store *s, int64_t list_no, int64_t n, const int64_t *ids, const float *vecs, int mem);
+/* Bulk form of init_partitions (partition_manager.cpp:33-121): lists 0..nlist-1 created and filled from a CSR
+ * arena (vecs [offsets[nlist]][d], ids, offsets [nlist+1] on the HOST always; vecs/ids in `mem`). */
+QK_API int qk_store_build_csr(qk_store *s, int64_t nlist, const int64_t *offsets_host, const int64_t *ids,
+                              const float *vecs, int mem);
+/* remove_vectors :137-149: remove every id in `ids` from every list, swap-with-last per removal.
+ * n_removed (may be NULL) receives the number of rows removed. */
+QK_API int qk_store_remove_ids(qk_store *s, int64_t n, const int64_t *ids_host, int64_t *n_removed);
+QK_API int qk_store_list_size(qk_store *s, int64_t list_no, int64_t *out);      /* list_size :68-74 */
+QK_API int64_t qk_store_ntotal(qk_store *s);                                    /* ntotal :60-66 */
+QK_API int64_t qk_store_nlist(qk_store *s);
+QK_API int qk_store_d(qk_store *s);
+/* list numbers currently present, ascending; out may be NULL to query the count (return value via *n). */
+QK_API int qk_store_list_ids(qk_store *s, int64_t *out_host, int64_t *n);
+/* get_codes / get_ids :76-90 as a copy-out: rows in partition order, row-major [n][d]. */
+QK_API int qk_store_get_list(qk_store *s, int64_t list_no, float *vecs_out, int64_t *ids_out, int mem);
+/* get_vector_for_id :280-293 (first match in ascending list order); *found = 0 if absent. */
+QK_API int qk_store_get_vector(qk_store *s, int64_t id, float *vec_out_host, int *found);
+/* bytes of HBM held by the arena (vectors+norms+ids), for capacity planning */
+QK_API int64_t qk_store_device_bytes(qk_store *s);
+
+/* ---- search ------------------------------------------------------------------------------------ */
+/* Coarse step = parent_->search(x, {k = min(nprobe, nlist), batched_scan = true})
+ * (query_coordinator.cpp:628-644 -> batched_scan_list over the centroid list, list_scanning.h:313-366).
+ * `parent` is the store of the parent (flat) index: its lists hold the centroids, ids = partition ids.
+ * out_pids [Q][kk], out_dist [Q][kk] (may be NULL), kk = min(nprobe, parent ntotal); rows padded with -1. */
+QK_API int qk_coarse(qk_ctx *ctx, qk_store *parent, const float *x, int64_t Q, int nprobe, int metric, int64_t *out_pids,
+                     float *out_dist, int mem);
+
+/* QueryCoordinator::scan_partitions (query_coordinator.cpp:659-673; serial_scan :471-611 and
+ * batched_serial_scan :675-799 give the same result here).  x [Q][d]; pids [Q][P] partition numbers to scan
+ * per query, -1 = skip (:540); out_ids/out_dist [Q][k].  timing may be NULL. */
+QK_API int qk_scan(qk_ctx *ctx, qk_store *s, const float *x, int64_t Q, const int64_t *pids, int P, int k, int metric,
+                   int64_t *out_ids, float *out_dist, int mem, qk_timing *timing);
+
+/* QueryCoordinator::search (query_coordinator.cpp:612-657) at fixed nprobe: coarse + scan in one enqueue,
+ * no host round trip between the two.  parent == NULL: flat index, every list of `s` is scanned (:624-626). */
+QK_API int qk_search(qk_ctx *ctx, qk_store *parent, qk_store *s, const float *x, int64_t Q, int nprobe, int k, int metric,
+                     int64_t *out_ids, float *out_dist, int mem, qk_timing *timing);
+
+/* Multi-GPU merge step (the cross-worker batch_add of worker_scan, query_coordinator.cpp:167-173,231-235):
+ * merge G per-rank results [G][Q][k] (already all-gathered by the caller, e.g. torch.distributed over RCCL) into
+ * [Q][k] under the same (key,id) order.  in_key are SQUARED L2 distances / inner products, i.e. what qk_search
+ * returns after qk_ctx_set_squared_l2(ctx, 1); the output distances are sqrt'd.  Device pointers only. */
+QK_API int qk_merge_topk(qk_ctx *ctx, const int64_t *in_ids, const float *in_key, int G, int64_t Q, int k, int metric,
+                         int64_t *out_ids, float *out_dist);
+/* When enabled, qk_scan/qk_search return squared L2 distances (the merge key) instead of sqrt distances. */
+QK_API int qk_ctx_set_squared_l2(qk_ctx *ctx, int enabled);
+
+/* ---- k-means ----------------------------------------------------------------------------------- */
+/* Nearest-centroid assignment: IndexFlat::search(n, x, 1) (clustering.cpp:63-66) and the
+ * batched_scan_list(k=1) of kmeans_refine_partitions (clustering.cpp:149-159).
+ * x [n][d], c [m][d]; assign [n] (row index into c, ties -> lower index); val [n] squared L2 / dot (may be NULL). */
+QK_API int qk_kmeans_assign(qk_ctx *ctx, const float *x, int64_t n, const float *c, int64_t m, int d, int metric,
+                            int64_t *assign, float *val, int mem);
+/* Update: per-centroid fp32 sums (rows added in ascending row order) and counts
+ * (clustering.cpp:162-176 accumulate loop / faiss::Clustering mean update). sums [m][d], counts [m]. */
+QK_API int qk_kmeans_accumulate(qk_ctx *ctx, const float *x, int64_t n, int d, const int64_t *assign, int64_t m,
+                                float *sums, int64_t *counts, int mem);
+/* kmeans() (clustering.cpp:13-97): Lloyd iterations on the GPU.  x [n][d] (IP: normalised IN PLACE, as the
+ * reference stores the normalised copy, clustering.cpp:25-26,71); centroids [m][d] out; assign [n] out =
+ * final full assignment.  seed drives the documented splitmix64 initialisation. */
+QK_API int qk_kmeans(qk_ctx *ctx, float *x, int64_t n, int d, int64_t m, int metric, int niter, uint64_t seed,
+                     float *centroids, int64_t *assign, int mem);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QUAKE_HIP_H */

@@ -1,0 +1,274 @@
+"""Thin object wrappers over the C ABI (include/quake_hip.h) for Python callers and the test-suite.
+
+Host data is passed as numpy arrays (QK_MEM_HOST); device data as torch CUDA tensors (QK_MEM_DEVICE).
+Every call goes through libquake_hip.so -- there is no alternative code path.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import QK_MEM_DEVICE, QK_MEM_HOST, QK_METRIC_IP, QK_METRIC_L2, QkTiming, check
+
+
+def metric_code(metric):
+    """str_to_metric_type (src/cpp/include/common.h:145-156)."""
+    if isinstance(metric, str):
+        m = metric.lower()
+        if m == "l2":
+            return QK_METRIC_L2
+        if m == "ip":
+            return QK_METRIC_IP
+        raise ValueError("Invalid metric type: " + metric)
+    return int(metric)
+
+
+def _is_torch(a):
+    return type(a).__module__.startswith("torch")
+
+
+def _ptr(a):
+    if a is None:
+        return None
+    if _is_torch(a):
+        return C.c_void_p(a.data_ptr())
+    return C.c_void_p(a.ctypes.data)
+
+
+def _mem_of(*arrs):
+    kinds = set()
+    for a in arrs:
+        if a is None:
+            continue
+        if _is_torch(a):
+            kinds.add(QK_MEM_DEVICE if a.is_cuda else QK_MEM_HOST)
+        else:
+            kinds.add(QK_MEM_HOST)
+    if len(kinds) > 1:
+        raise ValueError("mixed host/device arguments")
+    return kinds.pop() if kinds else QK_MEM_HOST
+
+
+def _f32(a):
+    if _is_torch(a):
+        import torch
+        return a.contiguous().to(torch.float32)
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _i64(a):
+    if _is_torch(a):
+        import torch
+        return a.contiguous().to(torch.int64)
+    return np.ascontiguousarray(a, dtype=np.int64)
+
+
+def _empty_like_mem(shape, dtype, ref):
+    if _is_torch(ref) and ref.is_cuda:
+        import torch
+        return torch.empty(shape, dtype=torch.int64 if dtype == np.int64 else torch.float32, device=ref.device)
+    return np.empty(shape, dtype)
+
+
+def timing_dict(t):
+    return {f: getattr(t, f) for f, _ in QkTiming._fields_}
+
+
+class Context:
+    def __init__(self, device=0):
+        self.lib = _lib.load()
+        self.h = C.c_void_p()
+        check(self.lib.qk_ctx_create(int(device), C.byref(self.h)))
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "h", None) and self.h:
+            self.lib.qk_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        check(self.lib.qk_ctx_synchronize(self.h))
+
+    def set_stream(self, hip_stream):
+        check(self.lib.qk_ctx_set_stream(self.h, C.c_void_p(hip_stream) if hip_stream else None))
+
+    def set_timing(self, on=True):
+        check(self.lib.qk_ctx_set_timing(self.h, int(bool(on))))
+
+    def set_squared_l2(self, on=True):
+        check(self.lib.qk_ctx_set_squared_l2(self.h, int(bool(on))))
+
+    def device_info(self):
+        cus, clk, hbm = C.c_int(), C.c_int(), C.c_int64()
+        arch = C.create_string_buffer(64)
+        check(self.lib.qk_ctx_device_info(self.h, C.byref(cus), C.byref(clk), C.byref(hbm), arch, 64))
+        return dict(num_cus=cus.value, clock_khz=clk.value, hbm_bytes=hbm.value, arch=arch.value.decode())
+
+    # ---- search ---------------------------------------------------------------------------------------
+    def coarse(self, parent, x, nprobe, metric):
+        x = _f32(x)
+        Q = x.shape[0]
+        kk = int(min(nprobe, parent.ntotal()))
+        mem = _mem_of(x)
+        out_p = _empty_like_mem((Q, kk), np.int64, x)
+        out_d = _empty_like_mem((Q, kk), np.float32, x)
+        check(self.lib.qk_coarse(self.h, parent.h, _ptr(x), Q, int(nprobe), metric_code(metric), _ptr(out_p), _ptr(out_d),
+                                 mem))
+        return out_p, out_d
+
+    def scan(self, store, x, pids, k, metric, timing=False):
+        x, pids = _f32(x), _i64(pids)
+        Q = x.shape[0]
+        if pids.ndim == 1:  # same set for every query (query_coordinator.cpp:506-508)
+            pids = (pids[None, :].expand(Q, -1).contiguous() if _is_torch(pids)
+                    else np.ascontiguousarray(np.broadcast_to(pids[None, :], (Q, pids.shape[0]))))
+        mem = _mem_of(x, pids)
+        out_i = _empty_like_mem((Q, k), np.int64, x)
+        out_d = _empty_like_mem((Q, k), np.float32, x)
+        t = QkTiming()
+        check(self.lib.qk_scan(self.h, store.h, _ptr(x), Q, _ptr(pids) if pids.shape[1] > 0 else None, int(pids.shape[1]),
+                               int(k), metric_code(metric), _ptr(out_i), _ptr(out_d), mem, C.byref(t) if timing else None))
+        return (out_i, out_d, timing_dict(t)) if timing else (out_i, out_d)
+
+    def search(self, parent, store, x, nprobe, k, metric, timing=False, out=None):
+        x = _f32(x)
+        Q = x.shape[0]
+        mem = _mem_of(x)
+        if out is None:
+            out_i = _empty_like_mem((Q, k), np.int64, x)
+            out_d = _empty_like_mem((Q, k), np.float32, x)
+        else:
+            out_i, out_d = out
+        t = QkTiming()
+        check(self.lib.qk_search(self.h, parent.h if parent is not None else None, store.h, _ptr(x), Q, int(nprobe), int(k),
+                                 metric_code(metric), _ptr(out_i), _ptr(out_d), mem, C.byref(t) if timing else None))
+        return (out_i, out_d, timing_dict(t)) if timing else (out_i, out_d)
+
+    def merge_topk(self, ids, keys, metric):
+        """ids/keys: CUDA tensors [G][Q][k] (keys = squared L2 / dot); returns ([Q][k] ids, [Q][k] distances)."""
+        import torch
+        ids, keys = _i64(ids), _f32(keys)
+        G, Q, k = ids.shape
+        out_i = torch.empty((Q, k), dtype=torch.int64, device=ids.device)
+        out_d = torch.empty((Q, k), dtype=torch.float32, device=ids.device)
+        check(self.lib.qk_merge_topk(self.h, _ptr(ids), _ptr(keys), G, Q, k, metric_code(metric), _ptr(out_i), _ptr(out_d)))
+        return out_i, out_d
+
+    # ---- k-means ----------------------------------------------------------------------------------------
+    def kmeans_assign(self, x, c, metric):
+        x, c = _f32(x), _f32(c)
+        n, d = x.shape
+        mem = _mem_of(x, c)
+        a = _empty_like_mem((n,), np.int64, x)
+        v = _empty_like_mem((n,), np.float32, x)
+        check(self.lib.qk_kmeans_assign(self.h, _ptr(x), n, _ptr(c), c.shape[0], d, metric_code(metric), _ptr(a), _ptr(v), mem))
+        return a, v
+
+    def kmeans_accumulate(self, x, assign, m):
+        x, assign = _f32(x), _i64(assign)
+        n, d = x.shape
+        mem = _mem_of(x, assign)
+        sums = _empty_like_mem((m, d), np.float32, x)
+        counts = _empty_like_mem((m,), np.int64, x)
+        check(self.lib.qk_kmeans_accumulate(self.h, _ptr(x), n, d, _ptr(assign), m, _ptr(sums), _ptr(counts), mem))
+        return sums, counts
+
+    def kmeans(self, x, m, metric, niter=5, seed=1234):
+        """Returns (centroids, assign, x_used); x_used is the (IP-normalised) copy the caller should store."""
+        x = _f32(x)
+        x = x.clone() if _is_torch(x) else x.copy()
+        n, d = x.shape
+        mem = _mem_of(x)
+        c = _empty_like_mem((m, d), np.float32, x)
+        a = _empty_like_mem((n,), np.int64, x)
+        check(self.lib.qk_kmeans(self.h, _ptr(x), n, d, m, metric_code(metric), int(niter), int(seed), _ptr(c), _ptr(a), mem))
+        return c, a, x
+
+
+class Store:
+    """Device mirror of faiss::DynamicInvertedLists (dynamic_inverted_list.h:25-33)."""
+
+    def __init__(self, ctx, d):
+        self.ctx = ctx
+        self.lib = ctx.lib
+        self.h = C.c_void_p()
+        check(self.lib.qk_store_create(ctx.h, int(d), C.byref(self.h)))
+        self.d = int(d)
+
+    def close(self):
+        if getattr(self, "h", None) and self.h and self.ctx.h:
+            self.lib.qk_store_destroy(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reset(self):
+        check(self.lib.qk_store_reset(self.h))
+
+    def add_list(self, list_no):
+        check(self.lib.qk_store_add_list(self.h, int(list_no)))
+
+    def remove_list(self, list_no):
+        check(self.lib.qk_store_remove_list(self.h, int(list_no)))
+
+    def add_entries(self, list_no, ids, vecs):
+        ids, vecs = _i64(ids), _f32(vecs)
+        n = ids.shape[0]
+        check(self.lib.qk_store_add_entries(self.h, int(list_no), n, _ptr(ids), _ptr(vecs), _mem_of(ids, vecs)))
+
+    def build_csr(self, offsets, ids, vecs):
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        ids, vecs = _i64(ids), _f32(vecs)
+        check(self.lib.qk_store_build_csr(self.h, offsets.shape[0] - 1, _ptr(offsets), _ptr(ids), _ptr(vecs),
+                                          _mem_of(ids, vecs)))
+
+    def remove_ids(self, ids):
+        ids = np.ascontiguousarray(ids, dtype=np.int64)
+        n = C.c_int64()
+        check(self.lib.qk_store_remove_ids(self.h, ids.shape[0], _ptr(ids), C.byref(n)))
+        return n.value
+
+    def list_size(self, list_no):
+        out = C.c_int64()
+        check(self.lib.qk_store_list_size(self.h, int(list_no), C.byref(out)))
+        return out.value
+
+    def ntotal(self):
+        return self.lib.qk_store_ntotal(self.h)
+
+    def nlist(self):
+        return self.lib.qk_store_nlist(self.h)
+
+    def list_ids(self):
+        n = C.c_int64()
+        check(self.lib.qk_store_list_ids(self.h, None, C.byref(n)))
+        out = np.empty(n.value, np.int64)
+        if n.value:
+            check(self.lib.qk_store_list_ids(self.h, _ptr(out), C.byref(n)))
+        return out
+
+    def get_list(self, list_no):
+        n = self.list_size(list_no)
+        vecs = np.empty((n, self.d), np.float32)
+        ids = np.empty(n, np.int64)
+        check(self.lib.qk_store_get_list(self.h, int(list_no), _ptr(vecs), _ptr(ids), QK_MEM_HOST))
+        return vecs, ids
+
+    def get_vector(self, vid):
+        out = np.empty(self.d, np.float32)
+        found = C.c_int()
+        check(self.lib.qk_store_get_vector(self.h, int(vid), _ptr(out), C.byref(found)))
+        return out if found.value else None
+
+    def device_bytes(self):
+        return self.lib.qk_store_device_bytes(self.h)

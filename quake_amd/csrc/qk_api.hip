@@ -1,0 +1,208 @@
+// qk_api.hip -- C-ABI search entry points (include/quake_hip.h): marshalling between caller memory and the
+// device pipeline of qk_scan.hip.  No arithmetic lives here.
+#include "qk_internal.h"
+
+#include <algorithm>
+#include <cstring>
+
+namespace {
+
+struct Staged {  // device-side views of the caller's buffers for one call
+    const float *x = nullptr;
+    const int64_t *pids = nullptr;
+    int64_t *out_ids = nullptr;
+    float *out_dist = nullptr;
+};
+
+inline size_t al256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+// read back phase timings (events) and device scalars after the stream has drained
+int finish_timing(qk_ctx *ctx, qk_store *s, qk_timing *t, bool have_coarse, int scan_ev_base) {
+    if (!t) return QK_OK;
+    QK_HIP(hipStreamSynchronize(ctx->stream));
+    const int32_t *hs = (const int32_t *)ctx->pinned;
+    t->n_items = hs[0];
+    int64_t rows_unique;
+    memcpy(&rows_unique, hs + 2, sizeof(int64_t));
+    t->scan_bytes = rows_unique * (int64_t)s->d * 4;
+    if (ctx->timing) {
+        float ms = 0.f;
+        if (have_coarse) {
+            QK_HIP(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[3]));
+            t->coarse_ms = ms;
+        }
+        QK_HIP(hipEventElapsedTime(&ms, ctx->ev[scan_ev_base + 0], ctx->ev[scan_ev_base + 1]));
+        t->group_ms = ms;
+        QK_HIP(hipEventElapsedTime(&ms, ctx->ev[scan_ev_base + 1], ctx->ev[scan_ev_base + 2]));
+        t->scan_ms = ms;
+        QK_HIP(hipEventElapsedTime(&ms, ctx->ev[scan_ev_base + 2], ctx->ev[scan_ev_base + 3]));
+        t->merge_ms = ms;
+        QK_HIP(hipEventElapsedTime(&ms, ctx->ev[have_coarse ? 0 : scan_ev_base], ctx->ev[scan_ev_base + 3]));
+        t->total_ms = ms;
+    }
+    return QK_OK;
+}
+
+int check_metric(int metric) {
+    if (metric != QK_METRIC_L2 && metric != QK_METRIC_IP) QK_FAIL(QK_ERR_INVALID, "Metric type not supported");
+    return QK_OK;
+}
+
+// scan with every pointer in `mem`; parent == nullptr && pids == nullptr -> all lists
+int run_search(qk_ctx *ctx, qk_store *parent, qk_store *s, const float *x, int64_t Q, const int64_t *pids, int P, int nprobe,
+               int k, int metric, int64_t *out_ids, float *out_dist, int mem, qk_timing *timing, bool coarse_only) {
+    QK_HIP(hipSetDevice(ctx->device));
+    if (timing) memset(timing, 0, sizeof(*timing));
+    if (Q <= 0) return QK_OK;
+    const int d = s->d;
+    const bool use_parent = parent != nullptr;
+    int kk = 0;
+    if (use_parent) {
+        if (parent->d != d) QK_FAIL(QK_ERR_INVALID, "parent store dimension %d != store dimension %d", parent->d, d);
+        kk = (int)std::min<int64_t>(nprobe, parent->ntotal);  // query_coordinator.cpp:641
+        if (kk > QK_MAX_K) QK_FAIL(QK_ERR_UNSUPPORTED, "nprobe=%d exceeds QK_MAX_K=%d", kk, QK_MAX_K);
+    }
+    const int Ps = coarse_only ? 0 : (use_parent ? kk : P);
+    const int kout = coarse_only ? kk : k;
+    // ---- stage caller buffers ------------------------------------------------------------------------
+    size_t bx = al256((size_t)Q * d * 4), bp = al256((size_t)Q * std::max(Ps, 1) * 8);
+    size_t bi = al256((size_t)Q * std::max(kout, 1) * 8), bd = al256((size_t)Q * std::max(kout, 1) * 4);
+    Staged sv;
+    if (mem == QK_MEM_HOST) {
+        QK_TRY(qk_stage_reserve(ctx, bx + bp + bi + bd + 256));
+        char *b = ctx->stage;
+        QK_HIP(hipMemcpyAsync(b, x, (size_t)Q * d * 4, hipMemcpyHostToDevice, ctx->stream));
+        sv.x = (const float *)b;
+        b += bx;
+        if (!use_parent && pids && Ps > 0) {
+            QK_HIP(hipMemcpyAsync(b, pids, (size_t)Q * Ps * 8, hipMemcpyHostToDevice, ctx->stream));
+        }
+        sv.pids = (const int64_t *)b;
+        b += bp;
+        sv.out_ids = (int64_t *)b;
+        b += bi;
+        sv.out_dist = (float *)b;
+    } else {
+        sv.x = x;
+        sv.out_ids = out_ids;
+        sv.out_dist = out_dist;
+        if (use_parent && !coarse_only) {
+            QK_TRY(qk_stage_reserve(ctx, bp + 256));
+            sv.pids = (const int64_t *)ctx->stage;
+        } else {
+            sv.pids = pids;
+        }
+    }
+    // ---- coarse --------------------------------------------------------------------------------------
+    if (use_parent && kk <= 0 && coarse_only) return QK_OK;
+    if (use_parent && kk > 0) {
+        qk_scan_args ca;
+        ca.x = sv.x;
+        ca.Q = Q;
+        ca.all_lists = true;
+        ca.k = kk;
+        ca.metric = metric;
+        ca.out_ids = coarse_only ? sv.out_ids : (int64_t *)sv.pids;
+        ca.out_dist = coarse_only ? sv.out_dist : nullptr;
+        QK_TRY(qk_scan_device(ctx, parent, ca, coarse_only ? timing : nullptr, 0));
+    }
+    // ---- scan ------------------------------------------------------------------------------------------
+    if (!coarse_only) {
+        qk_scan_args sa;
+        sa.x = sv.x;
+        sa.Q = Q;
+        sa.k = k;
+        sa.metric = metric;
+        sa.out_ids = sv.out_ids;
+        sa.out_dist = sv.out_dist;
+        if (!use_parent && !pids) {
+            sa.all_lists = true;
+        } else {
+            sa.pids = sv.pids;
+            sa.P = Ps;
+        }
+        sa.sqrt_l2 = !ctx->squared_l2;
+        if (use_parent && kk <= 0) {  // empty parent: nothing to probe -> padding only
+            QK_HIP(hipMemsetAsync((void *)sv.pids, 0xFF, (size_t)Q * 8, ctx->stream));
+            sa.P = 1;
+        }
+        QK_TRY(qk_scan_device(ctx, s, sa, timing, 4));
+    }
+    // ---- results back ------------------------------------------------------------------------------------
+    if (mem == QK_MEM_HOST) {
+        if (out_ids) QK_HIP(hipMemcpyAsync(out_ids, sv.out_ids, (size_t)Q * kout * 8, hipMemcpyDeviceToHost, ctx->stream));
+        if (out_dist) QK_HIP(hipMemcpyAsync(out_dist, sv.out_dist, (size_t)Q * kout * 4, hipMemcpyDeviceToHost, ctx->stream));
+        QK_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    if (timing) QK_TRY(finish_timing(ctx, coarse_only ? parent : s, timing, use_parent && !coarse_only, coarse_only ? 0 : 4));
+    return QK_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int qk_coarse(qk_ctx *ctx, qk_store *parent, const float *x, int64_t Q, int nprobe, int metric, int64_t *out_pids, float *out_dist,
+              int mem) {
+    if (!ctx || !parent || (Q > 0 && (!x || !out_pids))) QK_FAIL(QK_ERR_INVALID, "qk_coarse: null argument");
+    if (nprobe <= 0) QK_FAIL(QK_ERR_INVALID, "qk_coarse: nprobe must be positive");
+    QK_TRY(check_metric(metric));
+    return run_search(ctx, parent, parent, x, Q, nullptr, 0, nprobe, 0, metric, out_pids, out_dist, mem, nullptr, true);
+}
+
+int qk_scan(qk_ctx *ctx, qk_store *s, const float *x, int64_t Q, const int64_t *pids, int P, int k, int metric, int64_t *out_ids,
+            float *out_dist, int mem, qk_timing *timing) {
+    if (!ctx || !s || (Q > 0 && (!x || !out_ids))) QK_FAIL(QK_ERR_INVALID, "qk_scan: null argument");
+    if (P < 0 || (P > 0 && !pids)) QK_FAIL(QK_ERR_INVALID, "qk_scan: bad partition id list");
+    if (k <= 0) QK_FAIL(QK_ERR_INVALID, "qk_scan: k must be positive");
+    QK_TRY(check_metric(metric));
+    if (mem == QK_MEM_HOST && pids) {
+        // the reference throws "List does not exist" from get_codes (dynamic_inverted_list.cpp:76-82)
+        for (int64_t i = 0; i < Q * (int64_t)P; i++) {
+            int64_t p = pids[i];
+            if (p < 0) continue;
+            if (p >= (int64_t)s->parts.size() || !s->parts[p].present)
+                QK_FAIL(QK_ERR_NOT_FOUND, "List does not exist in get_codes (list %lld)", (long long)p);
+        }
+    }
+    // P == 0: zero partitions to scan -> padded output (query_coordinator.cpp:459-497); the pipeline handles it
+    static const int64_t dummy = -1;
+    const int64_t *pp = pids;
+    int PP = P;
+    if (P == 0) {
+        if (mem == QK_MEM_HOST) {
+            // build a [Q][1] list of -1
+            std::vector<int64_t> neg((size_t)std::max<int64_t>(Q, 1), -1);
+            return run_search(ctx, nullptr, s, x, Q, neg.data(), 1, 0, k, metric, out_ids, out_dist, mem, timing, false);
+        }
+        (void)dummy;
+        QK_FAIL(QK_ERR_INVALID, "qk_scan: P == 0 needs host memory (pass a [Q][1] list of -1 instead)");
+    }
+    return run_search(ctx, nullptr, s, x, Q, pp, PP, 0, k, metric, out_ids, out_dist, mem, timing, false);
+}
+
+int qk_search(qk_ctx *ctx, qk_store *parent, qk_store *s, const float *x, int64_t Q, int nprobe, int k, int metric,
+              int64_t *out_ids, float *out_dist, int mem, qk_timing *timing) {
+    if (!ctx || !s || (Q > 0 && (!x || !out_ids))) QK_FAIL(QK_ERR_INVALID, "qk_search: null argument");
+    if (k <= 0) QK_FAIL(QK_ERR_INVALID, "qk_search: k must be positive");
+    if (parent && nprobe <= 0) QK_FAIL(QK_ERR_INVALID, "qk_search: nprobe must be positive");
+    QK_TRY(check_metric(metric));
+    return run_search(ctx, parent, s, x, Q, nullptr, 0, nprobe, k, metric, out_ids, out_dist, mem, timing, false);
+}
+
+int qk_ctx_set_squared_l2(qk_ctx *ctx, int enabled) {
+    if (!ctx) QK_FAIL(QK_ERR_INVALID, "qk_ctx_set_squared_l2: ctx is null");
+    ctx->squared_l2 = enabled != 0;
+    return QK_OK;
+}
+
+int qk_merge_topk(qk_ctx *ctx, const int64_t *in_ids, const float *in_key, int G, int64_t Q, int k, int metric, int64_t *out_ids,
+                  float *out_dist) {
+    if (!ctx || (Q > 0 && (!in_ids || !in_key || !out_ids))) QK_FAIL(QK_ERR_INVALID, "qk_merge_topk: null argument");
+    if (G <= 0 || k <= 0) QK_FAIL(QK_ERR_INVALID, "qk_merge_topk: bad sizes");
+    QK_TRY(check_metric(metric));
+    QK_HIP(hipSetDevice(ctx->device));
+    return qk_merge_topk_device(ctx, in_ids, in_key, G, Q, k, metric, out_ids, out_dist, true);
+}
+
+}  // extern "C"

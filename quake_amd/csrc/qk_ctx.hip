@@ -1,0 +1,133 @@
+// qk_ctx.hip -- error state, context, scratch memory.
+#include "qk_internal.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+static thread_local char g_err[1024] = "";
+
+void qk_set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" {
+
+const char *qk_last_error(void) { return g_err; }
+const char *qk_version(void) { return "quake_hip 0.1 (gfx950)"; }
+
+int qk_ctx_create(int device, qk_ctx **out) {
+    if (!out) QK_FAIL(QK_ERR_INVALID, "qk_ctx_create: out is null");
+    int ndev = 0;
+    QK_HIP(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) QK_FAIL(QK_ERR_INVALID, "qk_ctx_create: device %d out of range (%d devices)", device, ndev);
+    QK_HIP(hipSetDevice(device));
+    qk_ctx *c = new qk_ctx();
+    c->device = device;
+    QK_HIP(hipGetDeviceProperties(&c->prop, device));
+    QK_HIP(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    c->stream = c->own_stream;
+    for (auto &e : c->ev) QK_HIP(hipEventCreate(&e));
+    *out = c;
+    return QK_OK;
+}
+
+int qk_ctx_destroy(qk_ctx *c) {
+    if (!c) return QK_OK;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    if (c->ws) hipFree(c->ws);
+    if (c->stage) hipFree(c->stage);
+    if (c->pinned) hipHostFree(c->pinned);
+    for (auto &e : c->ev)
+        if (e) hipEventDestroy(e);
+    if (c->own_stream) hipStreamDestroy(c->own_stream);
+    delete c;
+    return QK_OK;
+}
+
+int qk_ctx_set_stream(qk_ctx *c, void *hip_stream) {
+    if (!c) QK_FAIL(QK_ERR_INVALID, "qk_ctx_set_stream: ctx is null");
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return QK_OK;
+}
+
+int qk_ctx_synchronize(qk_ctx *c) {
+    if (!c) QK_FAIL(QK_ERR_INVALID, "qk_ctx_synchronize: ctx is null");
+    QK_HIP(hipStreamSynchronize(c->stream));
+    return QK_OK;
+}
+
+int qk_ctx_set_timing(qk_ctx *c, int enabled) {
+    if (!c) QK_FAIL(QK_ERR_INVALID, "qk_ctx_set_timing: ctx is null");
+    c->timing = enabled != 0;
+    return QK_OK;
+}
+
+int qk_ctx_device_info(qk_ctx *c, int *num_cus, int *clock_khz, int64_t *hbm_bytes, char *arch, int arch_len) {
+    if (!c) QK_FAIL(QK_ERR_INVALID, "qk_ctx_device_info: ctx is null");
+    if (num_cus) *num_cus = c->prop.multiProcessorCount;
+    if (clock_khz) *clock_khz = c->prop.clockRate;
+    if (hbm_bytes) *hbm_bytes = (int64_t)c->prop.totalGlobalMem;
+    if (arch && arch_len > 0) {
+        strncpy(arch, c->prop.gcnArchName, (size_t)arch_len - 1);
+        arch[arch_len - 1] = 0;
+    }
+    return QK_OK;
+}
+
+}  // extern "C"
+
+int qk_ws_reserve(qk_ctx *c, size_t bytes) {
+    c->ws_off = 0;
+    if (bytes <= c->ws_cap) return QK_OK;
+    QK_HIP(hipStreamSynchronize(c->stream));
+    if (c->ws) QK_HIP(hipFree(c->ws));
+    c->ws = nullptr;
+    c->ws_cap = 0;
+    size_t want = bytes + bytes / 4 + (1u << 20);
+    hipError_t e = hipMalloc((void **)&c->ws, want);
+    if (e != hipSuccess) {
+        qk_set_error("workspace allocation of %zu bytes failed: %s", want, hipGetErrorString(e));
+        return QK_ERR_OOM;
+    }
+    c->ws_cap = want;
+    return QK_OK;
+}
+
+void *qk_ws_alloc(qk_ctx *c, size_t bytes) {
+    size_t off = (c->ws_off + 255) & ~(size_t)255;
+    if (off + bytes > c->ws_cap) return nullptr;
+    c->ws_off = off + bytes;
+    return c->ws + off;
+}
+
+int qk_pinned_reserve(qk_ctx *c, size_t bytes) {
+    if (bytes <= c->pinned_cap) return QK_OK;
+    QK_HIP(hipStreamSynchronize(c->stream));
+    if (c->pinned) QK_HIP(hipHostFree(c->pinned));
+    c->pinned = nullptr;
+    c->pinned_cap = 0;
+    size_t want = bytes + bytes / 4 + 4096;
+    QK_HIP(hipHostMalloc((void **)&c->pinned, want, hipHostMallocDefault));
+    c->pinned_cap = want;
+    return QK_OK;
+}
+
+int qk_stage_reserve(qk_ctx *c, size_t bytes) {
+    if (bytes <= c->stage_cap) return QK_OK;
+    QK_HIP(hipStreamSynchronize(c->stream));
+    if (c->stage) QK_HIP(hipFree(c->stage));
+    c->stage = nullptr;
+    c->stage_cap = 0;
+    hipError_t e = hipMalloc((void **)&c->stage, bytes);
+    if (e != hipSuccess) {
+        qk_set_error("staging allocation of %zu bytes failed: %s", bytes, hipGetErrorString(e));
+        return QK_ERR_OOM;
+    }
+    c->stage_cap = bytes;
+    return QK_OK;
+}

@@ -1,0 +1,135 @@
+// qk_internal.h -- shared declarations of libquake_hip.so (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include <unordered_map>
+
+#include "../../include/quake_hip.h"
+
+// ---- error plumbing -------------------------------------------------------------------------
+void qk_set_error(const char *fmt, ...);
+
+#define QK_HIP(call)                                                                          \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess) {                                                               \
+            qk_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); \
+            return QK_ERR_HIP;                                                                \
+        }                                                                                     \
+    } while (0)
+
+#define QK_TRY(call)               \
+    do {                           \
+        int s_ = (call);           \
+        if (s_ != QK_OK) return s_; \
+    } while (0)
+
+#define QK_FAIL(code, ...)        \
+    do {                          \
+        qk_set_error(__VA_ARGS__); \
+        return (code);            \
+    } while (0)
+
+// ---- geometry of the tile-major arena ----------------------------------
+// A "tile" is 16 rows.  Within a tile the d dimension is cut into 16-column blocks; block c of a tile is
+// 64 float4 stored in LANE ORDER of v_mfma_f32_16x16x4_f32's A operand:
+//     float4 index (tile*nblk + c)*64 + (g*16 + r)  holds row r, columns 16c + {g, 4+g, 8+g, 12+g}
+// so one global_load_dwordx4 per lane reads a contiguous 1 KiB and element t of the float4 is the operand
+// of MFMA step 4c+t, whose four k-slices (g = 0..3) are columns 16c+4t+g: the dot product accumulates
+// in natural column order k = 0..d-1.
+constexpr int QK_TILE = 16;
+constexpr int QK_WAVES = 4;            // waves per scan workgroup
+constexpr int QK_QT = 16;              // queries per query tile (MFMA N)
+
+static inline int qk_round_up(int64_t v, int m) { return (int)(((v + m - 1) / m) * m); }
+static inline int64_t qk_round_up64(int64_t v, int64_t m) { return ((v + m - 1) / m) * m; }
+
+// ---- context ---------------------------------------------------------------------------------
+struct qk_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    bool timing = false;
+    hipDeviceProp_t prop{};
+    // bump-allocated scratch, reset at the start of every API call
+    char *ws = nullptr;
+    size_t ws_cap = 0;
+    size_t ws_off = 0;
+    // pinned staging for host<->device result/query traffic
+    char *pinned = nullptr;
+    size_t pinned_cap = 0;
+    // device staging for ingest of host data
+    char *stage = nullptr;
+    size_t stage_cap = 0;
+    hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool squared_l2 = false;  // L2 entry points return squared distances (sharded path, before the final merge)
+};
+
+int qk_ws_reserve(qk_ctx *ctx, size_t bytes);          // make sure the workspace can hold `bytes` (may sync+realloc)
+void *qk_ws_alloc(qk_ctx *ctx, size_t bytes);          // 256-B aligned slice; nullptr if exhausted
+int qk_pinned_reserve(qk_ctx *ctx, size_t bytes);
+int qk_stage_reserve(qk_ctx *ctx, size_t bytes);
+
+// ---- store -----------------------------------------------------------------------------------
+struct qk_part {
+    int64_t row_off = 0;  // first arena row (multiple of 16)
+    int64_t size = 0;     // valid rows
+    int64_t cap = 0;      // reserved rows (multiple of 16)
+    bool present = false;
+    std::vector<int64_t> ids;  // host mirror of the ids, in row order
+};
+
+struct qk_store {
+    qk_ctx *ctx = nullptr;
+    int d = 0;
+    int dpad = 0;  // d rounded up to 16
+    int nblk = 0;  // dpad / 16
+    float *vecs = nullptr;     // tile-major arena, cap_rows * dpad floats
+    float *norms = nullptr;    // [cap_rows] squared norms (canonical chain)
+    int64_t *ids = nullptr;    // [cap_rows]
+    int64_t cap_rows = 0;
+    int64_t used_rows = 0;     // bump pointer
+    int64_t dead_rows = 0;     // rows in abandoned extents
+    std::vector<qk_part> parts;  // indexed by list number
+    int64_t nlist = 0;
+    int64_t ntotal = 0;
+    int64_t max_size = 0;      // upper bound of the largest partition size (monotone; refreshed on table sync)
+    // device partition table, indexed by list number
+    int64_t *d_off = nullptr;
+    int32_t *d_size = nullptr;
+    int64_t table_cap = 0;
+    bool table_dirty = true;
+};
+
+int qk_store_sync_table(qk_store *s);                  // upload (row_off, size) if dirty
+int qk_store_reserve_rows(qk_store *s, int64_t rows);  // grow the arena so that used_rows + rows fits
+
+// ---- kernels exposed across translation units --------------------------------------------------
+// ingest: row-major src [n][d] (device) -> arena rows [row0, row0+n) (tile-major) + norms (+ids if given)
+int qk_launch_ingest(qk_ctx *ctx, const float *src, const int64_t *src_ids, int64_t n, int d, int nblk, float *vecs,
+                     float *norms, int64_t *ids, int64_t row0);
+// gather rows back: arena rows listed in rows[] (device, nullptr = row0..row0+n) -> row-major dst [n][d]
+int qk_launch_extract(qk_ctx *ctx, const float *vecs, int nblk, int d, int64_t row0, const int64_t *rows, int64_t n,
+                      float *dst);
+// in-place row moves inside the arena: row dst[i] <- row src[i] (disjoint sets)
+int qk_launch_move_rows(qk_ctx *ctx, float *vecs, float *norms, int64_t *ids, int nblk, const int64_t *dst,
+                        const int64_t *src, int64_t n);
+
+struct qk_scan_args {
+    const float *x = nullptr;     // [Q][d] device, row-major
+    int64_t Q = 0;
+    const int64_t *pids = nullptr;  // [Q][P] device; nullptr with all_lists => every present list for every query
+    int P = 0;
+    int k = 0;
+    int metric = QK_METRIC_L2;
+    int64_t *out_ids = nullptr;   // [Q][k] device
+    float *out_dist = nullptr;    // [Q][k] device (may be nullptr)
+    bool all_lists = false;
+    bool share_tau = true;
+    bool sqrt_l2 = true;
+};
+int qk_merge_topk_device(qk_ctx *ctx, const int64_t *in_ids, const float *in_key, int G, int64_t Q, int k, int metric,
+                         int64_t *out_ids, float *out_dist, bool sqrt_l2);
+int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *timing, int ev_base);

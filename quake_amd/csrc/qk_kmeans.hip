@@ -1,0 +1,587 @@
+// qk_kmeans.hip -- k-means assign / update kernels and the Lloyd driver.
+//
+// Replaces (citations relative to the reference checkout):
+//   kmeans()                     src/cpp/src/clustering.cpp:13-97   (faiss::Clustering::train + IndexFlat::search(k=1))
+//   kmeans_refine_partitions()   src/cpp/src/clustering.cpp:99-182  (batched_scan_list(k=1) assign :149-159,
+//                                                                    scalar accumulate :162-176)
+// assign  : X x C^T on v_mfma_f32_16x16x4_f32 (same canonical fmaf-chain as the scan) + fused argmin, MFMA-bound
+// update  : stable radix sort of rows by assignment, then one workgroup per centroid adds its rows in ascending
+//           row order (fp32) -- the sequential order of the reference loop, so sums are bit-reproducible. HBM-bound.
+// PARITY UNPINNED vs FAISS (RNG / init), pinned vs oracle/quake_oracle.c (qo_kmeans*).
+#include "qk_internal.h"
+
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ uint32_t km_ord_l2(float d2) { return __float_as_uint(d2); }
+__device__ __forceinline__ uint32_t km_ord_ip(float ip) {
+    uint32_t b = __float_as_uint(ip);
+    uint32_t asc = b ^ ((b >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+    return ~asc;
+}
+__device__ __forceinline__ float km_ip_from_ord(uint32_t o) {
+    uint32_t asc = ~o;
+    uint32_t b = (asc & 0x80000000u) ? (asc ^ 0x80000000u) : ~asc;
+    return __uint_as_float(b);
+}
+__device__ __forceinline__ float km_l2_expanded(float xn, float yn, float ip) {
+    float r = __fmaf_rn(-2.0f, ip, xn + yn);
+    return r < 0.0f ? 0.0f : r;
+}
+
+struct AssignParams {
+    const float *x;        // [n][d] row-major
+    int64_t n;
+    int d;
+    int nblk;
+    const float4 *cvecs;   // centroids, tile-major, mt tiles
+    const float *cnorms;   // [mt*16]
+    int m;
+    int metric;
+    int64_t *assign;       // [n]
+    float *val;            // [n] or nullptr
+};
+
+// One workgroup = NQ*16 rows of x (the MFMA "query" side, staged in LDS) against all centroids (streamed as A
+// operands from L2/HBM, split across the 4 waves), running (ord, index) argmin per row.
+template <int DB, int NQ>
+__global__ __launch_bounds__(256) void k_assign(AssignParams P) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 15, g = lane >> 4;
+    const int nblk = P.nblk, d = P.d;
+    const bool l2 = P.metric == QK_METRIC_L2;
+    float4 *qs = (float4 *)smem;                                            // [NQ][nblk*64]
+    float *xn_s = (float *)(smem + (size_t)NQ * nblk * 1024);               // [NQ*16]
+    uint32_t *red_ord = (uint32_t *)(xn_s + NQ * 16);                       // [4][NQ*16]
+    int *red_idx = (int *)(red_ord + 4 * NQ * 16);                          // [4][NQ*16]
+    const int64_t row_base = (int64_t)blockIdx.x * (NQ * 16);
+
+    // stage the x rows in B-operand lane order
+    for (int t = wave; t < NQ * nblk; t += 4) {
+        const int nq = t / nblk, cb = t - nq * nblk;
+        const int64_t row = row_base + nq * 16 + j;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < P.n) {
+            const float *s = P.x + row * d;
+            const int col = 16 * cb + g;
+            v.x = col < d ? s[col] : 0.0f;
+            v.y = col + 4 < d ? s[col + 4] : 0.0f;
+            v.z = col + 8 < d ? s[col + 8] : 0.0f;
+            v.w = col + 12 < d ? s[col + 12] : 0.0f;
+        }
+        qs[(size_t)nq * nblk * 64 + cb * 64 + lane] = v;
+    }
+    if (tid < NQ * 16) {
+        const int64_t row = row_base + tid;
+        float acc = 0.0f;
+        if (row < P.n && l2) {
+            const float *s = P.x + row * d;
+            for (int k = 0; k < d; k++) acc = __fmaf_rn(s[k], s[k], acc);
+        }
+        xn_s[tid] = acc;
+    }
+    __syncthreads();
+
+    float xnj[NQ];
+    uint32_t best_ord[NQ];
+    int best_idx[NQ];
+#pragma unroll
+    for (int nq = 0; nq < NQ; nq++) {
+        xnj[nq] = xn_s[nq * 16 + j];
+        best_ord[nq] = 0xFFFFFFFFu;
+        best_idx[nq] = 0x7FFFFFFF;
+    }
+    const int mt = (P.m + 15) >> 4;
+    const int tpw = (mt + 3) >> 2;
+    const int t0 = wave * tpw, t1 = min(mt, t0 + tpw);
+    const int ncd = nblk / DB;
+    if (t1 > t0) {
+        const float4 *src = P.cvecs + (int64_t)t0 * nblk * 64 + lane;
+        const float4 *nsrc = (const float4 *)(P.cnorms + ((int64_t)t0 << 4)) + g;
+        const int nsteps = (t1 - t0) * ncd;
+        float4 a0[DB], a1[DB];
+        float4 yn_cur = make_float4(0.f, 0.f, 0.f, 0.f), yn_next = yn_cur;
+        f32x4 acc[NQ];
+        int dch = 0, tile = t0, ldch = 0, ltile = 0;
+
+#define KM_LOAD(A, S)                                                 \
+    {                                                                 \
+        const float4 *pp_ = src + (int64_t)(S) * (DB * 64);           \
+        _Pragma("unroll") for (int b_ = 0; b_ < DB; b_++) A[b_] = pp_[b_ * 64]; \
+        if (ldch == 0) {                                              \
+            if (l2) yn_next = nsrc[(int64_t)ltile * 4];               \
+            ltile++;                                                  \
+        }                                                             \
+        if (++ldch == ncd) ldch = 0;                                  \
+    }
+
+#define KM_STEP(A)                                                                                           \
+    {                                                                                                        \
+        if (dch == 0) {                                                                                      \
+            _Pragma("unroll") for (int nq_ = 0; nq_ < NQ; nq_++) acc[nq_] = (f32x4){0.f, 0.f, 0.f, 0.f};     \
+        }                                                                                                    \
+        _Pragma("unroll") for (int b_ = 0; b_ < DB; b_++) {                                                  \
+            _Pragma("unroll") for (int nq_ = 0; nq_ < NQ; nq_++) {                                           \
+                const float4 bq_ = qs[(size_t)nq_ * nblk * 64 + (dch * DB + b_) * 64 + lane];                \
+                acc[nq_] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[b_].x, bq_.x, acc[nq_], 0, 0, 0);          \
+                acc[nq_] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[b_].y, bq_.y, acc[nq_], 0, 0, 0);          \
+                acc[nq_] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[b_].z, bq_.z, acc[nq_], 0, 0, 0);          \
+                acc[nq_] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[b_].w, bq_.w, acc[nq_], 0, 0, 0);          \
+            }                                                                                                \
+        }                                                                                                    \
+        if (++dch == ncd) {                                                                                  \
+            dch = 0;                                                                                         \
+            const float yv_[4] = {yn_cur.x, yn_cur.y, yn_cur.z, yn_cur.w};                                   \
+            _Pragma("unroll") for (int reg_ = 0; reg_ < 4; reg_++) {                                         \
+                const int idx_ = (tile << 4) + 4 * g + reg_;                                                 \
+                _Pragma("unroll") for (int nq_ = 0; nq_ < NQ; nq_++) {                                       \
+                    const float v_ = acc[nq_][reg_];                                                         \
+                    const uint32_t o_ = l2 ? km_ord_l2(km_l2_expanded(xnj[nq_], yv_[reg_], v_)) : km_ord_ip(v_); \
+                    if (idx_ < P.m && o_ < best_ord[nq_]) {                                                  \
+                        best_ord[nq_] = o_;                                                                  \
+                        best_idx[nq_] = idx_;                                                                \
+                    }                                                                                        \
+                }                                                                                            \
+            }                                                                                                \
+            yn_cur = yn_next;                                                                                \
+            tile++;                                                                                          \
+        }                                                                                                    \
+    }
+
+        KM_LOAD(a0, 0);
+        yn_cur = yn_next;
+        int s = 0;
+        while (s < nsteps) {
+            if (s + 1 < nsteps) KM_LOAD(a1, s + 1);
+            KM_STEP(a0);
+            s++;
+            if (s >= nsteps) break;
+            if (s + 1 < nsteps) KM_LOAD(a0, s + 1);
+            KM_STEP(a1);
+            s++;
+        }
+#undef KM_LOAD
+#undef KM_STEP
+    }
+    // reduce over the 4 row groups (lanes j, j+16, j+32, j+48), then over the 4 waves; order = (ord, index)
+#pragma unroll
+    for (int nq = 0; nq < NQ; nq++) {
+#pragma unroll
+        for (int off = 16; off <= 32; off <<= 1) {
+            const uint32_t oo = __shfl_xor(best_ord[nq], off);
+            const int oi = __shfl_xor(best_idx[nq], off);
+            if (oo < best_ord[nq] || (oo == best_ord[nq] && oi < best_idx[nq])) {
+                best_ord[nq] = oo;
+                best_idx[nq] = oi;
+            }
+        }
+        if (g == 0) {
+            red_ord[wave * NQ * 16 + nq * 16 + j] = best_ord[nq];
+            red_idx[wave * NQ * 16 + nq * 16 + j] = best_idx[nq];
+        }
+    }
+    __syncthreads();
+    if (tid < NQ * 16) {
+        uint32_t bo = red_ord[tid];
+        int bi = red_idx[tid];
+        for (int w = 1; w < 4; w++) {
+            const uint32_t oo = red_ord[w * NQ * 16 + tid];
+            const int oi = red_idx[w * NQ * 16 + tid];
+            if (oo < bo || (oo == bo && oi < bi)) {
+                bo = oo;
+                bi = oi;
+            }
+        }
+        const int64_t row = row_base + tid;
+        if (row < P.n) {
+            P.assign[row] = bi == 0x7FFFFFFF ? -1 : bi;
+            if (P.val) P.val[row] = l2 ? __uint_as_float(bo) : km_ip_from_ord(bo);
+        }
+    }
+}
+
+// ---- update -------------------------------------------------------------------------------------------------
+__global__ void k_keys_from_assign(const int64_t *__restrict__ assign, int64_t n, int m, int32_t *keys, int32_t *vals) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int64_t a = assign[i];
+    keys[i] = (a < 0 || a >= m) ? m : (int32_t)a;  // out-of-range rows sort to the end and are ignored
+    vals[i] = (int32_t)i;
+}
+
+__global__ void k_segment_bounds(const int32_t *__restrict__ sorted_keys, int64_t n, int m, int64_t *seg_begin /*[m+1]*/) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n) return;
+    // seg_begin[c] = first position with key >= c
+    int prev = i == 0 ? -1 : sorted_keys[i - 1];
+    int cur = i == n ? m : min(sorted_keys[i], m);
+    for (int c = prev + 1; c <= cur; c++) seg_begin[c] = i;
+}
+
+// one workgroup per centroid; thread t owns dimensions t, t+256, ...; rows are added in ascending row order
+__global__ __launch_bounds__(256) void k_accumulate(const float *__restrict__ x, int d, const int32_t *__restrict__ sorted_rows,
+                                                    const int64_t *__restrict__ seg_begin, float *__restrict__ sums,
+                                                    int64_t *__restrict__ counts) {
+    const int c = blockIdx.x;
+    const int64_t b = seg_begin[c], e = seg_begin[c + 1];
+    if (threadIdx.x == 0) counts[c] = e - b;
+    for (int k = threadIdx.x; k < d; k += blockDim.x) {
+        float s = 0.0f;
+        int64_t i = b;
+        for (; i + 4 <= e; i += 4) {
+            const float v0 = x[(int64_t)sorted_rows[i] * d + k];
+            const float v1 = x[(int64_t)sorted_rows[i + 1] * d + k];
+            const float v2 = x[(int64_t)sorted_rows[i + 2] * d + k];
+            const float v3 = x[(int64_t)sorted_rows[i + 3] * d + k];
+            s += v0;
+            s += v1;
+            s += v2;
+            s += v3;
+        }
+        for (; i < e; i++) s += x[(int64_t)sorted_rows[i] * d + k];
+        sums[(int64_t)c * d + k] = s;
+    }
+}
+
+__global__ void k_finalize_centroids(const float *__restrict__ sums, const int64_t *__restrict__ counts, int64_t m, int d,
+                                     int keep_empty, float *__restrict__ c) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= m * d) return;
+    int64_t jn = idx / d;
+    int64_t cnt = counts[jn];
+    if (cnt == 0 && keep_empty) return;
+    c[idx] = sums[idx] / (float)cnt;
+}
+
+__global__ void k_normalize_rows(float *x, int64_t n, int d) {
+    // vectors / vectors.norm(2,1) (clustering.cpp:25-26): canonical norm = sqrt of the fmaf chain
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float *s = x + i * d;
+    float acc = 0.0f;
+    for (int k = 0; k < d; k++) acc = __fmaf_rn(s[k], s[k], acc);
+    const float nn = sqrtf(acc);
+    for (int k = 0; k < d; k++) s[k] = s[k] / nn;
+}
+
+__global__ void k_gather_rows(const float *__restrict__ x, int d, const int64_t *__restrict__ rows, int64_t n, float *__restrict__ out) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * d) return;
+    int64_t i = idx / d;
+    out[idx] = x[rows[i] * d + (idx - i * d)];
+}
+
+// ---- host side ----------------------------------------------------------------------------------------------
+static inline unsigned km_grid(int64_t n, int b) { return (unsigned)((n + b - 1) / b); }
+
+struct KmScratch {  // device buffers owned by one qk_kmeans* call
+    std::vector<void *> ptrs;
+    ~KmScratch() {
+        for (void *p : ptrs)
+            if (p) (void)hipFree(p);
+    }
+    template <typename T>
+    int alloc(T **out, size_t count) {
+        void *p = nullptr;
+        hipError_t e = hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T));
+        if (e != hipSuccess) {
+            qk_set_error("k-means scratch allocation of %zu bytes failed: %s", count * sizeof(T), hipGetErrorString(e));
+            return QK_ERR_OOM;
+        }
+        ptrs.push_back(p);
+        *out = (T *)p;
+        return QK_OK;
+    }
+};
+
+template <int DB, int NQ>
+static int launch_assign_t(hipStream_t st, unsigned grid, size_t lds, const AssignParams &ap) {
+    QK_HIP(hipFuncSetAttribute((const void *)k_assign<DB, NQ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_assign<DB, NQ>), dim3(grid), dim3(256), lds, st, ap);
+    return QK_OK;
+}
+
+// assign on device pointers; ctile/cnorm are scratch for the tile-major centroid copy (mt*16 rows)
+static int assign_device(qk_ctx *ctx, const float *x, int64_t n, const float *c, int64_t m, int d, int metric, int64_t *assign,
+                         float *val, float *ctile, float *cnorm) {
+    if (n <= 0) return QK_OK;
+    const int dpad = qk_round_up(d, 16), nblk = dpad / 16;
+    const int64_t mt = (m + 15) / 16;
+    QK_HIP(hipMemsetAsync(ctile, 0, (size_t)mt * 16 * dpad * sizeof(float), ctx->stream));
+    QK_HIP(hipMemsetAsync(cnorm, 0, (size_t)mt * 16 * sizeof(float), ctx->stream));
+    QK_TRY(qk_launch_ingest(ctx, c, nullptr, m, d, nblk, ctile, cnorm, nullptr, 0));
+    AssignParams ap;
+    ap.x = x;
+    ap.n = n;
+    ap.d = d;
+    ap.nblk = nblk;
+    ap.cvecs = (const float4 *)ctile;
+    ap.cnorms = cnorm;
+    ap.m = (int)m;
+    ap.metric = metric;
+    ap.assign = assign;
+    ap.val = val;
+    const int DB = (nblk % 8 == 0) ? 8 : (nblk % 4 == 0) ? 4 : (nblk % 2 == 0) ? 2 : 1;
+    // query tiles per workgroup: as many as fit 64 KiB of LDS (more tiles = fewer passes over the centroids)
+    int NQ = 4;
+    while (NQ > 1 && (size_t)NQ * nblk * 1024 > 64 * 1024) NQ >>= 1;
+    if (n <= 16) NQ = 1;
+    const size_t lds = (size_t)NQ * nblk * 1024 + (size_t)NQ * 16 * 4 + (size_t)4 * NQ * 16 * 8 + 64;
+    if (lds > 160 * 1024) QK_FAIL(QK_ERR_UNSUPPORTED, "qk_kmeans_assign: d=%d too large for the LDS query tile", d);
+    const unsigned grid = km_grid(n, NQ * 16);
+#define KM_CASE(D, N) \
+    if (DB == D && NQ == N) QK_TRY((launch_assign_t<D, N>(ctx->stream, grid, lds, ap)));
+    KM_CASE(8, 4) KM_CASE(8, 2) KM_CASE(8, 1) KM_CASE(4, 4) KM_CASE(4, 2) KM_CASE(4, 1)
+    KM_CASE(2, 4) KM_CASE(2, 2) KM_CASE(2, 1) KM_CASE(1, 4) KM_CASE(1, 2) KM_CASE(1, 1)
+#undef KM_CASE
+    QK_HIP(hipGetLastError());
+    return QK_OK;
+}
+
+struct AccumScratch {
+    int32_t *keys = nullptr, *vals = nullptr, *keys2 = nullptr, *vals2 = nullptr;
+    int64_t *seg = nullptr;
+    void *tmp = nullptr;
+    size_t tmp_bytes = 0;
+};
+
+static int accum_prepare(KmScratch &ks, AccumScratch &as, int64_t n, int64_t m) {
+    QK_TRY(ks.alloc(&as.keys, (size_t)n));
+    QK_TRY(ks.alloc(&as.vals, (size_t)n));
+    QK_TRY(ks.alloc(&as.keys2, (size_t)n));
+    QK_TRY(ks.alloc(&as.vals2, (size_t)n));
+    QK_TRY(ks.alloc(&as.seg, (size_t)m + 2));
+    size_t bytes = 0;
+    hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, as.keys, as.keys2, as.vals, as.vals2, (int)n);
+    char *t = nullptr;
+    QK_TRY(ks.alloc(&t, bytes + 256));
+    as.tmp = t;
+    as.tmp_bytes = bytes;
+    return QK_OK;
+}
+
+static int accumulate_device(qk_ctx *ctx, AccumScratch &as, const float *x, int64_t n, int d, const int64_t *assign, int64_t m,
+                             float *sums, int64_t *counts) {
+    hipStream_t st = ctx->stream;
+    if (n > 0x7FFFFFF0LL) QK_FAIL(QK_ERR_UNSUPPORTED, "qk_kmeans_accumulate: n too large for 32-bit row indices");
+    if (n > 0) {
+        hipLaunchKernelGGL(k_keys_from_assign, dim3(km_grid(n, 256)), dim3(256), 0, st, assign, n, (int)m, as.keys, as.vals);
+        int bits = 1;
+        while ((1LL << bits) <= m) bits++;
+        size_t bytes = as.tmp_bytes;
+        QK_HIP(hipcub::DeviceRadixSort::SortPairs(as.tmp, bytes, as.keys, as.keys2, as.vals, as.vals2, (int)n, 0, bits, st));
+    }
+    hipLaunchKernelGGL(k_segment_bounds, dim3(km_grid(n + 1, 256)), dim3(256), 0, st, as.keys2, n, (int)m, as.seg);
+    hipLaunchKernelGGL(k_accumulate, dim3((unsigned)m), dim3(256), 0, st, x, d, as.vals2, as.seg, sums, counts);
+    QK_HIP(hipGetLastError());
+    return QK_OK;
+}
+
+// faiss split_clusters restated deterministically -- identical to oracle split_empty()
+static int split_empty_host(float *c, int64_t *counts, int64_t m, int d) {
+    const float EPS = 1.0f / 1024.0f;
+    int nsplit = 0;
+    for (int64_t ci = 0; ci < m; ci++) {
+        if (counts[ci] != 0) continue;
+        int64_t cj = 0;
+        for (int64_t j = 1; j < m; j++)
+            if (counts[j] > counts[cj]) cj = j;
+        if (counts[cj] < 2) continue;
+        memcpy(c + ci * d, c + cj * d, sizeof(float) * (size_t)d);
+        for (int k = 0; k < d; k++) {
+            if (k % 2 == 0) {
+                c[ci * d + k] *= 1 + EPS;
+                c[cj * d + k] *= 1 - EPS;
+            } else {
+                c[ci * d + k] *= 1 - EPS;
+                c[cj * d + k] *= 1 + EPS;
+            }
+        }
+        counts[ci] = counts[cj] / 2;
+        counts[cj] -= counts[ci];
+        nsplit++;
+    }
+    return nsplit;
+}
+
+static inline uint64_t splitmix64(uint64_t *s) {
+    uint64_t z = (*s += 0x9E3779B97F4A7C15ULL);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+
+static void rand_perm_prefix(int64_t n, int64_t mcount, uint64_t seed, std::vector<int64_t> &out) {
+    std::vector<int64_t> p((size_t)n);
+    for (int64_t i = 0; i < n; i++) p[i] = i;
+    uint64_t s = seed;
+    for (int64_t i = 0; i < mcount && i < n - 1; i++) {
+        uint64_t r = splitmix64(&s);
+        int64_t j = i + (int64_t)(r % (uint64_t)(n - i));
+        std::swap(p[i], p[j]);
+    }
+    out.assign(p.begin(), p.begin() + std::min(n, mcount));
+}
+
+extern "C" {
+
+int qk_kmeans_assign(qk_ctx *ctx, const float *x, int64_t n, const float *c, int64_t m, int d, int metric, int64_t *assign,
+                     float *val, int mem) {
+    if (!ctx || !x || !c || !assign) QK_FAIL(QK_ERR_INVALID, "qk_kmeans_assign: null argument");
+    if (n < 0 || m <= 0 || d <= 0) QK_FAIL(QK_ERR_INVALID, "qk_kmeans_assign: bad sizes");
+    if (metric != QK_METRIC_L2 && metric != QK_METRIC_IP) QK_FAIL(QK_ERR_INVALID, "Metric type not supported");
+    if (n == 0) return QK_OK;
+    QK_HIP(hipSetDevice(ctx->device));
+    KmScratch ks;
+    const int dpad = qk_round_up(d, 16);
+    const int64_t mt16 = ((m + 15) / 16) * 16;
+    float *ctile, *cnorm;
+    QK_TRY(ks.alloc(&ctile, (size_t)mt16 * dpad));
+    QK_TRY(ks.alloc(&cnorm, (size_t)mt16));
+    const float *dx = x, *dc = c;
+    int64_t *da = assign;
+    float *dv = val;
+    float *bx = nullptr, *bc = nullptr, *bv = nullptr;
+    int64_t *ba = nullptr;
+    if (mem == QK_MEM_HOST) {
+        QK_TRY(ks.alloc(&bx, (size_t)n * d));
+        QK_TRY(ks.alloc(&bc, (size_t)m * d));
+        QK_TRY(ks.alloc(&ba, (size_t)n));
+        if (val) QK_TRY(ks.alloc(&bv, (size_t)n));
+        QK_HIP(hipMemcpyAsync(bx, x, (size_t)n * d * 4, hipMemcpyHostToDevice, ctx->stream));
+        QK_HIP(hipMemcpyAsync(bc, c, (size_t)m * d * 4, hipMemcpyHostToDevice, ctx->stream));
+        dx = bx;
+        dc = bc;
+        da = ba;
+        dv = bv;
+    }
+    QK_TRY(assign_device(ctx, dx, n, dc, m, d, metric, da, dv, ctile, cnorm));
+    if (mem == QK_MEM_HOST) {
+        QK_HIP(hipMemcpyAsync(assign, ba, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+        if (val) QK_HIP(hipMemcpyAsync(val, bv, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    QK_HIP(hipStreamSynchronize(ctx->stream));  // scratch is freed on return
+    return QK_OK;
+}
+
+int qk_kmeans_accumulate(qk_ctx *ctx, const float *x, int64_t n, int d, const int64_t *assign, int64_t m, float *sums,
+                         int64_t *counts, int mem) {
+    if (!ctx || !x || !assign || !sums || !counts) QK_FAIL(QK_ERR_INVALID, "qk_kmeans_accumulate: null argument");
+    if (n < 0 || m <= 0 || d <= 0) QK_FAIL(QK_ERR_INVALID, "qk_kmeans_accumulate: bad sizes");
+    QK_HIP(hipSetDevice(ctx->device));
+    KmScratch ks;
+    AccumScratch as;
+    QK_TRY(accum_prepare(ks, as, std::max<int64_t>(n, 1), m));
+    const float *dx = x;
+    const int64_t *da = assign;
+    float *ds = sums;
+    int64_t *dc = counts;
+    float *bx = nullptr, *bs = nullptr;
+    int64_t *ba = nullptr, *bc = nullptr;
+    if (mem == QK_MEM_HOST) {
+        QK_TRY(ks.alloc(&bx, (size_t)n * d));
+        QK_TRY(ks.alloc(&ba, (size_t)n));
+        QK_TRY(ks.alloc(&bs, (size_t)m * d));
+        QK_TRY(ks.alloc(&bc, (size_t)m));
+        QK_HIP(hipMemcpyAsync(bx, x, (size_t)n * d * 4, hipMemcpyHostToDevice, ctx->stream));
+        QK_HIP(hipMemcpyAsync(ba, assign, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+        dx = bx;
+        da = ba;
+        ds = bs;
+        dc = bc;
+    }
+    QK_TRY(accumulate_device(ctx, as, dx, n, d, da, m, ds, dc));
+    if (mem == QK_MEM_HOST) {
+        QK_HIP(hipMemcpyAsync(sums, bs, (size_t)m * d * 4, hipMemcpyDeviceToHost, ctx->stream));
+        QK_HIP(hipMemcpyAsync(counts, bc, (size_t)m * 8, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    QK_HIP(hipStreamSynchronize(ctx->stream));
+    return QK_OK;
+}
+
+int qk_kmeans(qk_ctx *ctx, float *x, int64_t n, int d, int64_t m, int metric, int niter, uint64_t seed, float *centroids,
+              int64_t *assign, int mem) {
+    if (!ctx || !x || !centroids || !assign) QK_FAIL(QK_ERR_INVALID, "qk_kmeans: null argument");
+    if (n <= 0 || m <= 0 || d <= 0 || m > n) QK_FAIL(QK_ERR_INVALID, "qk_kmeans: bad sizes (n=%lld m=%lld d=%d)", (long long)n, (long long)m, d);
+    if (metric != QK_METRIC_L2 && metric != QK_METRIC_IP) QK_FAIL(QK_ERR_INVALID, "Metric type not supported");
+    QK_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    KmScratch ks;
+    float *dx = x;
+    if (mem == QK_MEM_HOST) {
+        QK_TRY(ks.alloc(&dx, (size_t)n * d));
+        QK_HIP(hipMemcpyAsync(dx, x, (size_t)n * d * 4, hipMemcpyHostToDevice, st));
+    }
+    if (metric == QK_METRIC_IP) hipLaunchKernelGGL(k_normalize_rows, dim3(km_grid(n, 256)), dim3(256), 0, st, dx, n, d);
+    // subsample + init (oracle qo_kmeans: identical permutation)
+    const int64_t max_pts = 256;
+    const bool sub = n > max_pts * m;
+    const int64_t ntrain = sub ? max_pts * m : n;
+    std::vector<int64_t> perm;
+    rand_perm_prefix(n, sub ? ntrain : m, seed, perm);
+    int64_t *dperm;
+    QK_TRY(ks.alloc(&dperm, perm.size()));
+    QK_HIP(hipMemcpyAsync(dperm, perm.data(), perm.size() * 8, hipMemcpyHostToDevice, st));
+    float *xt = dx;
+    if (sub) {
+        QK_TRY(ks.alloc(&xt, (size_t)ntrain * d));
+        hipLaunchKernelGGL(k_gather_rows, dim3(km_grid(ntrain * d, 256)), dim3(256), 0, st, dx, d, dperm, ntrain, xt);
+    }
+    float *dc, *dsums, *ctile, *cnorm;
+    int64_t *dcounts, *dta, *dassign = assign;
+    const int dpad = qk_round_up(d, 16);
+    const int64_t mt16 = ((m + 15) / 16) * 16;
+    QK_TRY(ks.alloc(&dc, (size_t)m * d));
+    QK_TRY(ks.alloc(&dsums, (size_t)m * d));
+    QK_TRY(ks.alloc(&dcounts, (size_t)m));
+    QK_TRY(ks.alloc(&ctile, (size_t)mt16 * dpad));
+    QK_TRY(ks.alloc(&cnorm, (size_t)mt16));
+    QK_TRY(ks.alloc(&dta, (size_t)ntrain));
+    if (mem == QK_MEM_HOST) QK_TRY(ks.alloc(&dassign, (size_t)n));
+    // centroids = first m rows of the permutation (of the subsample if any)
+    hipLaunchKernelGGL(k_gather_rows, dim3(km_grid(m * d, 256)), dim3(256), 0, st, dx, d, dperm, m, dc);
+    AccumScratch as;
+    QK_TRY(accum_prepare(ks, as, ntrain, m));
+    std::vector<int64_t> hcounts((size_t)m);
+    std::vector<float> hc;
+    for (int it = 0; it < niter; it++) {
+        QK_TRY(assign_device(ctx, xt, ntrain, dc, m, d, metric, dta, nullptr, ctile, cnorm));
+        QK_TRY(accumulate_device(ctx, as, xt, ntrain, d, dta, m, dsums, dcounts));
+        hipLaunchKernelGGL(k_finalize_centroids, dim3(km_grid(m * d, 256)), dim3(256), 0, st, dsums, dcounts, m, d, 1, dc);
+        QK_HIP(hipMemcpyAsync(hcounts.data(), dcounts, (size_t)m * 8, hipMemcpyDeviceToHost, st));
+        QK_HIP(hipStreamSynchronize(st));
+        bool any_empty = false;
+        for (int64_t j = 0; j < m; j++)
+            if (hcounts[j] == 0) {
+                any_empty = true;
+                break;
+            }
+        if (any_empty) {
+            hc.resize((size_t)m * d);
+            QK_HIP(hipMemcpy(hc.data(), dc, (size_t)m * d * 4, hipMemcpyDeviceToHost));
+            split_empty_host(hc.data(), hcounts.data(), m, d);
+            QK_HIP(hipMemcpy(dc, hc.data(), (size_t)m * d * 4, hipMemcpyHostToDevice));
+        }
+    }
+    if (metric == QK_METRIC_IP) hipLaunchKernelGGL(k_normalize_rows, dim3(km_grid(m, 256)), dim3(256), 0, st, dc, m, d);
+    QK_TRY(assign_device(ctx, dx, n, dc, m, d, metric, dassign, nullptr, ctile, cnorm));
+    if (mem == QK_MEM_HOST) {
+        QK_HIP(hipMemcpyAsync(centroids, dc, (size_t)m * d * 4, hipMemcpyDeviceToHost, st));
+        QK_HIP(hipMemcpyAsync(assign, dassign, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+        if (metric == QK_METRIC_IP) QK_HIP(hipMemcpyAsync(x, dx, (size_t)n * d * 4, hipMemcpyDeviceToHost, st));
+    } else {
+        QK_HIP(hipMemcpyAsync(centroids, dc, (size_t)m * d * 4, hipMemcpyDeviceToDevice, st));
+    }
+    QK_HIP(hipGetLastError());
+    QK_HIP(hipStreamSynchronize(st));
+    return QK_OK;
+}
+
+}  // extern "C"

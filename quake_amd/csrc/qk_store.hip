@@ -1,0 +1,568 @@
+// qk_store.hip -- device partition store: the tile-major arena the scan kernels stream.
+//
+// Mirrors what faiss::DynamicInvertedLists / IndexPartition provide to the reference's hot path
+// (src/cpp/include/dynamic_inverted_list.h:25-33, src/cpp/include/index_partition.h:19-32): per-list
+// vectors + ids with append and swap-with-last remove (index_partition.cpp:52-59,79-102).  The memory
+// layout is NOT the reference's row-major malloc array: it is the MFMA-fragment tile-major layout
+// described in qk_internal.h / DESIGN.md section 4, plus a per-row squared norm.
+#include "qk_internal.h"
+
+#include <algorithm>
+#include <cstring>
+#include <unordered_set>
+
+// ------------------------------------------------------------------------------------------------
+// kernels
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int64_t csr_find(const int64_t *offsets, int64_t nlist, int64_t i) {
+    // largest p with offsets[p] <= i  (offsets[nlist] > i guaranteed by the caller)
+    int64_t lo = 0, hi = nlist;
+    while (hi - lo > 1) {
+        int64_t mid = (lo + hi) >> 1;
+        if (offsets[mid] <= i)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    return lo;
+}
+
+// dst row of source row i:  rowmap_off == nullptr -> row0 + i ;  else CSR: partition p = find(i), row = part_row[p] + (i - offsets[p])
+struct IngestMap {
+    int64_t row0;
+    const int64_t *offsets;   // [nlist+1] source-row CSR (device) or nullptr
+    const int64_t *part_row;  // [nlist] arena row of each partition's first NEW row
+    int64_t nlist;
+    int64_t src_base;         // global index of src[0] within the CSR numbering
+};
+
+__device__ __forceinline__ int64_t ingest_dst_row(const IngestMap &m, int64_t i) {
+    if (!m.offsets) return m.row0 + i;
+    int64_t gi = m.src_base + i;
+    int64_t p = csr_find(m.offsets, m.nlist, gi);
+    return m.part_row[p] + (gi - m.offsets[p]);
+}
+
+__global__ void k_ingest_vecs(const float *__restrict__ src, int64_t n, int d, int nblk, float4 *__restrict__ vecs, IngestMap m) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t per_row = (int64_t)nblk * 4;
+    if (idx >= n * per_row) return;
+    int64_t i = idx / per_row;
+    int rem = (int)(idx - i * per_row);
+    int c = rem >> 2, g = rem & 3;
+    int64_t row = ingest_dst_row(m, i);
+    int64_t tile = row >> 4;
+    int r = (int)(row & 15);
+    const float *s = src + i * d;
+    float4 v;
+    int col = 16 * c + g;
+    v.x = col < d ? s[col] : 0.0f;
+    v.y = col + 4 < d ? s[col + 4] : 0.0f;
+    v.z = col + 8 < d ? s[col + 8] : 0.0f;
+    v.w = col + 12 < d ? s[col + 12] : 0.0f;
+    vecs[(tile * nblk + c) * 64 + g * 16 + r] = v;
+}
+
+// canonical squared norm: one k-ordered fmaf chain per row (oracle: qo_row_norms)
+__global__ void k_ingest_norms_ids(const float *__restrict__ src, const int64_t *__restrict__ src_ids, int64_t n, int d,
+                                   float *__restrict__ norms, int64_t *__restrict__ ids, IngestMap m) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float *s = src + i * d;
+    float acc = 0.0f;
+    for (int k = 0; k < d; k++) acc = __fmaf_rn(s[k], s[k], acc);
+    int64_t row = ingest_dst_row(m, i);
+    norms[row] = acc;
+    if (ids && src_ids) ids[row] = src_ids[i];
+}
+
+__global__ void k_extract(const float *__restrict__ vecs, int nblk, int d, int64_t row0, const int64_t *__restrict__ rows,
+                          int64_t n, float *__restrict__ dst) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * d) return;
+    int64_t i = idx / d;
+    int col = (int)(idx - i * d);
+    int64_t row = rows ? rows[i] : row0 + i;
+    int64_t tile = row >> 4;
+    int r = (int)(row & 15);
+    int c = col >> 4, w = col & 15, g = w & 3, t = w >> 2;
+    dst[idx] = vecs[(((tile * nblk + c) * 64) + g * 16 + r) * 4 + t];
+}
+
+__global__ void k_move_rows(float4 *vecs, float *norms, int64_t *ids, int nblk, const int64_t *__restrict__ dstr,
+                            const int64_t *__restrict__ srcr, int64_t n) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t per_row = (int64_t)nblk * 4;
+    if (idx >= n * per_row) return;
+    int64_t i = idx / per_row;
+    int rem = (int)(idx - i * per_row);
+    int c = rem >> 2, g = rem & 3;
+    int64_t dr = dstr[i], sr = srcr[i];
+    vecs[((dr >> 4) * nblk + c) * 64 + g * 16 + (dr & 15)] = vecs[((sr >> 4) * nblk + c) * 64 + g * 16 + (sr & 15)];
+    if (rem == 0) {
+        norms[dr] = norms[sr];
+        ids[dr] = ids[sr];
+    }
+}
+
+static inline unsigned grid_for(int64_t n, int block) { return (unsigned)((n + block - 1) / block); }
+
+static int launch_ingest(qk_ctx *ctx, const float *src, const int64_t *src_ids, int64_t n, int d, int nblk, float *vecs,
+                         float *norms, int64_t *ids, const IngestMap &m) {
+    if (n <= 0) return QK_OK;
+    int64_t total = n * nblk * 4;
+    hipLaunchKernelGGL(k_ingest_vecs, dim3(grid_for(total, 256)), dim3(256), 0, ctx->stream, src, n, d, nblk, (float4 *)vecs, m);
+    hipLaunchKernelGGL(k_ingest_norms_ids, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, src, src_ids, n, d, norms, ids, m);
+    QK_HIP(hipGetLastError());
+    return QK_OK;
+}
+
+int qk_launch_ingest(qk_ctx *ctx, const float *src, const int64_t *src_ids, int64_t n, int d, int nblk, float *vecs,
+                     float *norms, int64_t *ids, int64_t row0) {
+    IngestMap m{row0, nullptr, nullptr, 0, 0};
+    return launch_ingest(ctx, src, src_ids, n, d, nblk, vecs, norms, ids, m);
+}
+
+int qk_launch_extract(qk_ctx *ctx, const float *vecs, int nblk, int d, int64_t row0, const int64_t *rows, int64_t n, float *dst) {
+    if (n <= 0) return QK_OK;
+    hipLaunchKernelGGL(k_extract, dim3(grid_for(n * d, 256)), dim3(256), 0, ctx->stream, vecs, nblk, d, row0, rows, n, dst);
+    QK_HIP(hipGetLastError());
+    return QK_OK;
+}
+
+int qk_launch_move_rows(qk_ctx *ctx, float *vecs, float *norms, int64_t *ids, int nblk, const int64_t *dst, const int64_t *src,
+                        int64_t n) {
+    if (n <= 0) return QK_OK;
+    hipLaunchKernelGGL(k_move_rows, dim3(grid_for(n * nblk * 4, 256)), dim3(256), 0, ctx->stream, (float4 *)vecs, norms, ids,
+                       nblk, dst, src, n);
+    QK_HIP(hipGetLastError());
+    return QK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// arena management
+// ------------------------------------------------------------------------------------------------
+int qk_store_reserve_rows(qk_store *s, int64_t rows) {
+    int64_t need = s->used_rows + rows;
+    if (need <= s->cap_rows) return QK_OK;
+    qk_ctx *c = s->ctx;
+    int64_t ncap = std::max<int64_t>(need, s->cap_rows + s->cap_rows / 2);
+    ncap = qk_round_up64(std::max<int64_t>(ncap, 1024), 16);
+    float *nv = nullptr, *nn = nullptr;
+    int64_t *ni = nullptr;
+    size_t vb = (size_t)ncap * s->dpad * sizeof(float);
+    if (hipMalloc((void **)&nv, vb) != hipSuccess || hipMalloc((void **)&nn, (size_t)ncap * sizeof(float)) != hipSuccess ||
+        hipMalloc((void **)&ni, (size_t)ncap * sizeof(int64_t)) != hipSuccess) {
+        if (nv) hipFree(nv);
+        if (nn) hipFree(nn);
+        if (ni) hipFree(ni);
+        QK_FAIL(QK_ERR_OOM, "store arena allocation failed for %lld rows x %d dims", (long long)ncap, s->dpad);
+    }
+    if (s->used_rows > 0) {
+        QK_HIP(hipMemcpyAsync(nv, s->vecs, (size_t)s->used_rows * s->dpad * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+        QK_HIP(hipMemcpyAsync(nn, s->norms, (size_t)s->used_rows * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+        QK_HIP(hipMemcpyAsync(ni, s->ids, (size_t)s->used_rows * sizeof(int64_t), hipMemcpyDeviceToDevice, c->stream));
+    }
+    // rows past used_rows are only ever read masked, but keep them finite and deterministic
+    QK_HIP(hipMemsetAsync((char *)nv + (size_t)s->used_rows * s->dpad * sizeof(float), 0,
+                          (size_t)(ncap - s->used_rows) * s->dpad * sizeof(float), c->stream));
+    QK_HIP(hipMemsetAsync(nn + s->used_rows, 0, (size_t)(ncap - s->used_rows) * sizeof(float), c->stream));
+    QK_HIP(hipMemsetAsync(ni + s->used_rows, 0xFF, (size_t)(ncap - s->used_rows) * sizeof(int64_t), c->stream));
+    QK_HIP(hipStreamSynchronize(c->stream));
+    if (s->vecs) hipFree(s->vecs);
+    if (s->norms) hipFree(s->norms);
+    if (s->ids) hipFree(s->ids);
+    s->vecs = nv;
+    s->norms = nn;
+    s->ids = ni;
+    s->cap_rows = ncap;
+    return QK_OK;
+}
+
+int qk_store_sync_table(qk_store *s) {
+    if (!s->table_dirty) return QK_OK;
+    qk_ctx *c = s->ctx;
+    int64_t n = (int64_t)s->parts.size();
+    if (n > s->table_cap) {
+        QK_HIP(hipStreamSynchronize(c->stream));
+        if (s->d_off) hipFree(s->d_off);
+        if (s->d_size) hipFree(s->d_size);
+        s->table_cap = std::max<int64_t>(n + n / 2, 64);
+        QK_HIP(hipMalloc((void **)&s->d_off, (size_t)s->table_cap * sizeof(int64_t)));
+        QK_HIP(hipMalloc((void **)&s->d_size, (size_t)s->table_cap * sizeof(int32_t)));
+    }
+    if (n > 0) {
+        size_t bytes = (size_t)n * (sizeof(int64_t) + sizeof(int32_t));
+        QK_TRY(qk_pinned_reserve(c, bytes));
+        QK_HIP(hipStreamSynchronize(c->stream));  // pinned buffer may still feed an earlier async copy
+        int64_t *ho = (int64_t *)c->pinned;
+        int32_t *hs = (int32_t *)(c->pinned + (size_t)n * sizeof(int64_t));
+        int64_t mx = 0;
+        for (int64_t p = 0; p < n; p++) {
+            const qk_part &pt = s->parts[p];
+            ho[p] = pt.row_off;
+            hs[p] = pt.present ? (int32_t)pt.size : -1;
+            if (pt.present) mx = std::max(mx, pt.size);
+        }
+        s->max_size = mx;
+        QK_HIP(hipMemcpyAsync(s->d_off, ho, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
+        QK_HIP(hipMemcpyAsync(s->d_size, hs, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+        QK_HIP(hipStreamSynchronize(c->stream));
+    } else {
+        s->max_size = 0;
+    }
+    s->table_dirty = false;
+    return QK_OK;
+}
+
+static int check_list(qk_store *s, int64_t list_no, const char *who) {
+    if (list_no < 0 || list_no >= (int64_t)s->parts.size() || !s->parts[list_no].present)
+        QK_FAIL(QK_ERR_NOT_FOUND, "List does not exist in %s (list %lld)", who, (long long)list_no);
+    return QK_OK;
+}
+
+// make sure partition `p` can take `extra` more rows; relocates the extent (amortised doubling, like
+// IndexPartition::ensure_capacity index_partition.cpp:247-255) when it does not fit
+static int ensure_part_capacity(qk_store *s, qk_part &p, int64_t extra) {
+    int64_t need = p.size + extra;
+    if (need <= p.cap) return QK_OK;
+    qk_ctx *c = s->ctx;
+    int64_t ncap = qk_round_up64(std::max<int64_t>(need, p.cap * 2), 16);
+    // extent at the very end of the arena can grow in place
+    if (p.cap > 0 && p.row_off + p.cap == s->used_rows) {
+        QK_TRY(qk_store_reserve_rows(s, ncap - p.cap));
+        s->used_rows += ncap - p.cap;
+        p.cap = ncap;
+        return QK_OK;
+    }
+    QK_TRY(qk_store_reserve_rows(s, ncap));
+    int64_t nrow = s->used_rows;
+    s->used_rows += ncap;
+    if (p.size > 0) {
+        int64_t tiles = (p.size + 15) / 16;
+        QK_HIP(hipMemcpyAsync(s->vecs + nrow * s->dpad, s->vecs + p.row_off * s->dpad, (size_t)tiles * 16 * s->dpad * sizeof(float),
+                              hipMemcpyDeviceToDevice, c->stream));
+        QK_HIP(hipMemcpyAsync(s->norms + nrow, s->norms + p.row_off, (size_t)p.size * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+        QK_HIP(hipMemcpyAsync(s->ids + nrow, s->ids + p.row_off, (size_t)p.size * sizeof(int64_t), hipMemcpyDeviceToDevice, c->stream));
+    }
+    s->dead_rows += p.cap;
+    p.row_off = nrow;
+    p.cap = ncap;
+    s->table_dirty = true;
+    return QK_OK;
+}
+
+// copy `bytes` from caller memory (host or device) to a device pointer usable by kernels; returns the device pointer
+static int to_device(qk_ctx *c, const void *src, size_t bytes, int mem, char *stage_dst, const void **out) {
+    if (mem == QK_MEM_DEVICE) {
+        *out = src;
+        return QK_OK;
+    }
+    QK_HIP(hipMemcpyAsync(stage_dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    *out = stage_dst;
+    return QK_OK;
+}
+
+extern "C" {
+
+int qk_store_create(qk_ctx *ctx, int d, qk_store **out) {
+    if (!ctx || !out) QK_FAIL(QK_ERR_INVALID, "qk_store_create: null argument");
+    if (d <= 0) QK_FAIL(QK_ERR_INVALID, "qk_store_create: d must be positive (got %d)", d);
+    qk_store *s = new qk_store();
+    s->ctx = ctx;
+    s->d = d;
+    s->dpad = qk_round_up(d, 16);
+    s->nblk = s->dpad / 16;
+    *out = s;
+    return QK_OK;
+}
+
+int qk_store_destroy(qk_store *s) {
+    if (!s) return QK_OK;
+    hipSetDevice(s->ctx->device);
+    hipStreamSynchronize(s->ctx->stream);
+    if (s->vecs) hipFree(s->vecs);
+    if (s->norms) hipFree(s->norms);
+    if (s->ids) hipFree(s->ids);
+    if (s->d_off) hipFree(s->d_off);
+    if (s->d_size) hipFree(s->d_size);
+    delete s;
+    return QK_OK;
+}
+
+int qk_store_reset(qk_store *s) {
+    if (!s) QK_FAIL(QK_ERR_INVALID, "qk_store_reset: null store");
+    s->parts.clear();
+    s->nlist = 0;
+    s->ntotal = 0;
+    s->used_rows = 0;
+    s->dead_rows = 0;
+    s->table_dirty = true;
+    return QK_OK;
+}
+
+int qk_store_add_list(qk_store *s, int64_t list_no) {
+    if (!s) QK_FAIL(QK_ERR_INVALID, "qk_store_add_list: null store");
+    if (list_no < 0) QK_FAIL(QK_ERR_INVALID, "qk_store_add_list: negative list number");
+    if (list_no < (int64_t)s->parts.size() && s->parts[list_no].present)
+        QK_FAIL(QK_ERR_INVALID, "List already exists in add_list (list %lld)", (long long)list_no);
+    if (list_no >= (int64_t)s->parts.size()) s->parts.resize(list_no + 1);
+    qk_part &p = s->parts[list_no];
+    p = qk_part();
+    p.present = true;
+    s->nlist++;
+    s->table_dirty = true;
+    return QK_OK;
+}
+
+int qk_store_remove_list(qk_store *s, int64_t list_no) {
+    if (!s) QK_FAIL(QK_ERR_INVALID, "qk_store_remove_list: null store");
+    if (list_no < 0 || list_no >= (int64_t)s->parts.size() || !s->parts[list_no].present) return QK_OK;  // "Already doesn't exist"
+    qk_part &p = s->parts[list_no];
+    s->ntotal -= p.size;
+    s->dead_rows += p.cap;
+    p = qk_part();
+    s->nlist--;
+    s->table_dirty = true;
+    return QK_OK;
+}
+
+int qk_store_add_entries(qk_store *s, int64_t list_no, int64_t n, const int64_t *ids, const float *vecs, int mem) {
+    if (!s) QK_FAIL(QK_ERR_INVALID, "qk_store_add_entries: null store");
+    if (n == 0) return QK_OK;
+    if (n < 0 || !ids || !vecs) QK_FAIL(QK_ERR_INVALID, "qk_store_add_entries: bad arguments");
+    QK_TRY(check_list(s, list_no, "add_entries"));
+    qk_ctx *c = s->ctx;
+    QK_HIP(hipSetDevice(c->device));
+    qk_part &p = s->parts[list_no];
+    QK_TRY(ensure_part_capacity(s, p, n));
+    size_t vb = (size_t)n * s->d * sizeof(float), ib = (size_t)n * sizeof(int64_t);
+    const void *dv = vecs, *di = ids;
+    size_t old = p.ids.size();
+    p.ids.resize(old + n);
+    if (mem == QK_MEM_HOST) {
+        QK_TRY(qk_stage_reserve(c, vb + ib + 256));
+        QK_TRY(to_device(c, vecs, vb, mem, c->stage, &dv));
+        QK_TRY(to_device(c, ids, ib, mem, c->stage + ((vb + 255) & ~(size_t)255), &di));
+        memcpy(p.ids.data() + old, ids, ib);
+    } else {
+        QK_HIP(hipMemcpyAsync(p.ids.data() + old, ids, ib, hipMemcpyDeviceToHost, c->stream));
+    }
+    QK_TRY(qk_launch_ingest(c, (const float *)dv, (const int64_t *)di, n, s->d, s->nblk, s->vecs, s->norms, s->ids, p.row_off + p.size));
+    QK_HIP(hipStreamSynchronize(c->stream));  // staging buffer / caller memory reusable on return
+    p.size += n;
+    s->ntotal += n;
+    s->table_dirty = true;
+    return QK_OK;
+}
+
+int qk_store_build_csr(qk_store *s, int64_t nlist, const int64_t *offsets, const int64_t *ids, const float *vecs, int mem) {
+    if (!s || !offsets || nlist < 0) QK_FAIL(QK_ERR_INVALID, "qk_store_build_csr: bad arguments");
+    qk_ctx *c = s->ctx;
+    QK_HIP(hipSetDevice(c->device));
+    QK_TRY(qk_store_reset(s));
+    int64_t total = offsets[nlist];
+    if (total > 0 && (!ids || !vecs)) QK_FAIL(QK_ERR_INVALID, "qk_store_build_csr: null data");
+    s->parts.resize(nlist);
+    int64_t rows = 0;
+    std::vector<int64_t> part_row(nlist);
+    for (int64_t p = 0; p < nlist; p++) {
+        int64_t sz = offsets[p + 1] - offsets[p];
+        if (sz < 0) QK_FAIL(QK_ERR_INVALID, "qk_store_build_csr: offsets not monotone at %lld", (long long)p);
+        qk_part &pt = s->parts[p];
+        pt.present = true;
+        pt.size = sz;
+        pt.cap = qk_round_up64(sz, 16);
+        pt.row_off = rows;
+        part_row[p] = rows;
+        rows += pt.cap;
+    }
+    s->nlist = nlist;
+    s->ntotal = total;
+    QK_TRY(qk_store_reserve_rows(s, rows));
+    s->used_rows = rows;
+    // host mirror of ids
+    std::vector<int64_t> host_ids;
+    const int64_t *hid = ids;
+    if (mem == QK_MEM_DEVICE && total > 0) {
+        host_ids.resize(total);
+        QK_HIP(hipMemcpy(host_ids.data(), ids, (size_t)total * sizeof(int64_t), hipMemcpyDeviceToHost));
+        hid = host_ids.data();
+    }
+    for (int64_t p = 0; p < nlist; p++) s->parts[p].ids.assign(hid + offsets[p], hid + offsets[p + 1]);
+    if (total > 0) {
+        // CSR tables on the device
+        int64_t *d_offsets = nullptr, *d_part_row = nullptr;
+        QK_HIP(hipMalloc((void **)&d_offsets, (size_t)(nlist + 1) * sizeof(int64_t)));
+        QK_HIP(hipMalloc((void **)&d_part_row, (size_t)nlist * sizeof(int64_t)));
+        QK_HIP(hipMemcpy(d_offsets, offsets, (size_t)(nlist + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
+        QK_HIP(hipMemcpy(d_part_row, part_row.data(), (size_t)nlist * sizeof(int64_t), hipMemcpyHostToDevice));
+        const int64_t CH = mem == QK_MEM_HOST ? std::max<int64_t>(1, (int64_t)(128u << 20) / ((int64_t)s->d * 4 + 8)) : total;
+        int rc = QK_OK;
+        if (mem == QK_MEM_HOST) rc = qk_stage_reserve(c, (size_t)CH * ((size_t)s->d * 4 + 8) + 512);
+        for (int64_t i0 = 0; rc == QK_OK && i0 < total; i0 += CH) {
+            int64_t n = std::min(CH, total - i0);
+            const float *dv = vecs + i0 * s->d;
+            const int64_t *di = ids + i0;
+            if (mem == QK_MEM_HOST) {
+                size_t vb = (size_t)n * s->d * sizeof(float);
+                char *si = c->stage + ((vb + 255) & ~(size_t)255);
+                if (hipMemcpyAsync(c->stage, dv, vb, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+                    hipMemcpyAsync(si, di, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, c->stream) != hipSuccess) {
+                    qk_set_error("qk_store_build_csr: H2D copy failed");
+                    rc = QK_ERR_HIP;
+                    break;
+                }
+                dv = (const float *)c->stage;
+                di = (const int64_t *)si;
+            }
+            IngestMap m{0, d_offsets, d_part_row, nlist, i0};
+            rc = launch_ingest(c, dv, di, n, s->d, s->nblk, s->vecs, s->norms, s->ids, m);
+            if (rc == QK_OK && mem == QK_MEM_HOST && hipStreamSynchronize(c->stream) != hipSuccess) rc = QK_ERR_HIP;
+        }
+        hipStreamSynchronize(c->stream);
+        hipFree(d_offsets);
+        hipFree(d_part_row);
+        QK_TRY(rc);
+    }
+    s->table_dirty = true;
+    return qk_store_sync_table(s);
+}
+
+int qk_store_remove_ids(qk_store *s, int64_t n, const int64_t *ids_host, int64_t *n_removed) {
+    if (!s) QK_FAIL(QK_ERR_INVALID, "qk_store_remove_ids: null store");
+    if (n_removed) *n_removed = 0;
+    if (n <= 0) return QK_OK;
+    if (!ids_host) QK_FAIL(QK_ERR_INVALID, "qk_store_remove_ids: null ids");
+    qk_ctx *c = s->ctx;
+    QK_HIP(hipSetDevice(c->device));
+    std::unordered_set<int64_t> kill(ids_host, ids_host + n);
+    std::vector<int64_t> mv_dst, mv_src;
+    int64_t removed = 0;
+    std::vector<int64_t> cur;
+    for (size_t pi = 0; pi < s->parts.size(); pi++) {
+        qk_part &p = s->parts[pi];
+        if (!p.present || p.size == 0) continue;
+        // DynamicInvertedLists::remove_vectors (dynamic_inverted_list.cpp:137-149): scan, swap-with-last on a hit,
+        // re-examine the swapped-in row
+        bool touched = false;
+        int64_t sz = p.size;
+        for (int64_t i = 0; i < sz;) {
+            if (kill.count(p.ids[i])) {
+                if (!touched) {
+                    cur.resize(p.size);
+                    for (int64_t t = 0; t < p.size; t++) cur[t] = t;
+                    touched = true;
+                }
+                if (i != sz - 1) {
+                    p.ids[i] = p.ids[sz - 1];
+                    cur[i] = cur[sz - 1];
+                }
+                sz--;
+            } else {
+                i++;
+            }
+        }
+        if (!touched) continue;
+        for (int64_t i = 0; i < sz; i++)
+            if (cur[i] != i) {
+                mv_dst.push_back(p.row_off + i);
+                mv_src.push_back(p.row_off + cur[i]);
+            }
+        removed += p.size - sz;
+        p.size = sz;
+        p.ids.resize(sz);
+    }
+    if (!mv_dst.empty()) {
+        size_t b = mv_dst.size() * sizeof(int64_t);
+        QK_TRY(qk_stage_reserve(c, 2 * b + 256));
+        int64_t *dd = (int64_t *)c->stage, *ds = (int64_t *)(c->stage + ((b + 255) & ~(size_t)255));
+        QK_HIP(hipMemcpyAsync(dd, mv_dst.data(), b, hipMemcpyHostToDevice, c->stream));
+        QK_HIP(hipMemcpyAsync(ds, mv_src.data(), b, hipMemcpyHostToDevice, c->stream));
+        QK_TRY(qk_launch_move_rows(c, s->vecs, s->norms, s->ids, s->nblk, dd, ds, (int64_t)mv_dst.size()));
+        QK_HIP(hipStreamSynchronize(c->stream));
+    }
+    s->ntotal -= removed;
+    if (removed) s->table_dirty = true;
+    if (n_removed) *n_removed = removed;
+    return QK_OK;
+}
+
+int qk_store_list_size(qk_store *s, int64_t list_no, int64_t *out) {
+    if (!s || !out) QK_FAIL(QK_ERR_INVALID, "qk_store_list_size: null argument");
+    QK_TRY(check_list(s, list_no, "list_size"));
+    *out = s->parts[list_no].size;
+    return QK_OK;
+}
+
+int64_t qk_store_ntotal(qk_store *s) { return s ? s->ntotal : 0; }
+int64_t qk_store_nlist(qk_store *s) { return s ? s->nlist : 0; }
+int qk_store_d(qk_store *s) { return s ? s->d : 0; }
+
+int qk_store_list_ids(qk_store *s, int64_t *out_host, int64_t *n) {
+    if (!s || !n) QK_FAIL(QK_ERR_INVALID, "qk_store_list_ids: null argument");
+    int64_t cnt = 0;
+    for (size_t p = 0; p < s->parts.size(); p++)
+        if (s->parts[p].present) {
+            if (out_host) out_host[cnt] = (int64_t)p;
+            cnt++;
+        }
+    *n = cnt;
+    return QK_OK;
+}
+
+int qk_store_get_list(qk_store *s, int64_t list_no, float *vecs_out, int64_t *ids_out, int mem) {
+    if (!s) QK_FAIL(QK_ERR_INVALID, "qk_store_get_list: null store");
+    QK_TRY(check_list(s, list_no, "get_codes"));
+    qk_ctx *c = s->ctx;
+    QK_HIP(hipSetDevice(c->device));
+    qk_part &p = s->parts[list_no];
+    if (p.size == 0) return QK_OK;
+    if (ids_out) {
+        if (mem == QK_MEM_HOST)
+            memcpy(ids_out, p.ids.data(), (size_t)p.size * sizeof(int64_t));
+        else
+            QK_HIP(hipMemcpyAsync(ids_out, s->ids + p.row_off, (size_t)p.size * sizeof(int64_t), hipMemcpyDeviceToDevice, c->stream));
+    }
+    if (vecs_out) {
+        size_t vb = (size_t)p.size * s->d * sizeof(float);
+        if (mem == QK_MEM_HOST) {
+            QK_TRY(qk_stage_reserve(c, vb));
+            QK_TRY(qk_launch_extract(c, s->vecs, s->nblk, s->d, p.row_off, nullptr, p.size, (float *)c->stage));
+            QK_HIP(hipMemcpyAsync(vecs_out, c->stage, vb, hipMemcpyDeviceToHost, c->stream));
+        } else {
+            QK_TRY(qk_launch_extract(c, s->vecs, s->nblk, s->d, p.row_off, nullptr, p.size, vecs_out));
+        }
+    }
+    if (mem == QK_MEM_HOST) QK_HIP(hipStreamSynchronize(c->stream));
+    return QK_OK;
+}
+
+int qk_store_get_vector(qk_store *s, int64_t id, float *vec_out_host, int *found) {
+    if (!s || !vec_out_host || !found) QK_FAIL(QK_ERR_INVALID, "qk_store_get_vector: null argument");
+    qk_ctx *c = s->ctx;
+    QK_HIP(hipSetDevice(c->device));
+    *found = 0;
+    for (size_t pi = 0; pi < s->parts.size(); pi++) {
+        qk_part &p = s->parts[pi];
+        if (!p.present) continue;
+        for (int64_t i = 0; i < p.size; i++)  // IndexPartition::find_id is a linear scan too (index_partition.cpp:129-145)
+            if (p.ids[i] == id) {
+                size_t vb = (size_t)s->d * sizeof(float);
+                QK_TRY(qk_stage_reserve(c, vb));
+                QK_TRY(qk_launch_extract(c, s->vecs, s->nblk, s->d, p.row_off + i, nullptr, 1, (float *)c->stage));
+                QK_HIP(hipMemcpyAsync(vec_out_host, c->stage, vb, hipMemcpyDeviceToHost, c->stream));
+                QK_HIP(hipStreamSynchronize(c->stream));
+                *found = 1;
+                return QK_OK;
+            }
+    }
+    return QK_OK;
+}
+
+int64_t qk_store_device_bytes(qk_store *s) {
+    if (!s) return 0;
+    return s->cap_rows * ((int64_t)s->dpad * 4 + 4 + 8);
+}
+
+}  // extern "C"
