@@ -74,8 +74,12 @@ QK_API int qk_ctx_destroy(qk_ctx *ctx);
 /* Run on a caller-owned hipStream_t instead (e.g. torch's current stream); NULL restores the private one. */
 QK_API int qk_ctx_set_stream(qk_ctx *ctx, void *hip_stream);
 QK_API int qk_ctx_synchronize(qk_ctx *ctx);
-/* Enable/disable hipEvent timing of the phases (fills qk_timing; adds event records to the stream). */
-QK_API int qk_ctx_set_timing(qk_ctx *ctx, int enabled);
+/* hipEvent timing of the phases, recorded on the context's stream around the kernels:
+ *   0 off; 1 per call (the qk_timing* passed to qk_scan/qk_search is filled, which synchronises the stream);
+ *   2 deferred (no synchronisation inside the calls; qk_ctx_read_timing sums everything recorded since the last read). */
+QK_API int qk_ctx_set_timing(qk_ctx *ctx, int mode);
+/* Synchronises, then returns the SUM of the phase durations over the calls recorded in deferred mode and their count. */
+QK_API int qk_ctx_read_timing(qk_ctx *ctx, qk_timing *sum, int64_t *calls);
 /* Device properties the harness prints: CU count, clock (kHz), total HBM bytes, gcnArchName. */
 QK_API int qk_ctx_device_info(qk_ctx *ctx, int *num_cus, int *clock_khz, int64_t *hbm_bytes, char *arch, int arch_len);
 

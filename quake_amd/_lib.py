@@ -42,6 +42,7 @@ SIGNATURES = {
     "qk_ctx_synchronize": (_int, [_vp]),
     "qk_ctx_set_timing": (_int, [_vp, _int]),
     "qk_ctx_set_squared_l2": (_int, [_vp, _int]),
+    "qk_ctx_read_timing": (_int, [_vp, C.POINTER(QkTiming), C.POINTER(_i64)]),
     "qk_ctx_device_info": (_int, [_vp, C.POINTER(_int), C.POINTER(_int), C.POINTER(_i64), C.c_char_p, _int]),
     "qk_store_create": (_int, [_vp, _int, C.POINTER(_vp)]),
     "qk_store_destroy": (_int, [_vp]),
@@ -79,6 +80,13 @@ def load():
             raise ImportError(
                 f"{LIB_PATH} is missing: the HIP extension has not been built (run `python -m quake_amd.build` or "
                 "__graft_entry__.build()). quake_amd has no CPU fallback.")
+        # PyTorch-ROCm ships its own libamdhip64 and loads it by path; if ours binds the system copy first, two HIP
+        # runtimes end up in one process and the second one finds no device.  Import torch first so that both sides
+        # share the runtime that is already loaded (same SONAME).
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)

@@ -17,7 +17,7 @@ LIB = os.path.join(LIBDIR, "libquake_hip.so")
 SOURCES = ["qk_ctx.hip", "qk_store.hip", "qk_scan.hip", "qk_kmeans.hip", "qk_api.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fvisibility=hidden",
-         "-Wall", "-Wno-unused-function", "-Wno-unused-variable"]
+         "-Wall", "-Wno-unused-function", "-Wno-unused-variable", "-Wno-unused-value"]
 
 
 def _stale(out, deps):

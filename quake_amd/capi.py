@@ -98,8 +98,16 @@ class Context:
     def set_stream(self, hip_stream):
         check(self.lib.qk_ctx_set_stream(self.h, C.c_void_p(hip_stream) if hip_stream else None))
 
-    def set_timing(self, on=True):
-        check(self.lib.qk_ctx_set_timing(self.h, int(bool(on))))
+    def set_timing(self, mode=1):
+        """0 off, 1 per-call (synchronising), 2 deferred (read with read_timing())."""
+        check(self.lib.qk_ctx_set_timing(self.h, int(mode)))
+
+    def read_timing(self):
+        t, n = QkTiming(), C.c_int64()
+        check(self.lib.qk_ctx_read_timing(self.h, C.byref(t), C.byref(n)))
+        out = timing_dict(t)
+        out["calls"] = n.value
+        return out
 
     def set_squared_l2(self, on=True):
         check(self.lib.qk_ctx_set_squared_l2(self.h, int(bool(on))))

@@ -104,6 +104,7 @@ int run_search(qk_ctx *ctx, qk_store *parent, qk_store *s, const float *x, int64
         ca.metric = metric;
         ca.out_ids = coarse_only ? sv.out_ids : (int64_t *)sv.pids;
         ca.out_dist = coarse_only ? sv.out_dist : nullptr;
+        ca.record_events = timing != nullptr;
         QK_TRY(qk_scan_device(ctx, parent, ca, coarse_only ? timing : nullptr, 0));
     }
     // ---- scan ------------------------------------------------------------------------------------------

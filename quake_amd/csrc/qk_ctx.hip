@@ -44,6 +44,9 @@ int qk_ctx_destroy(qk_ctx *c) {
     if (c->pinned) hipHostFree(c->pinned);
     for (auto &e : c->ev)
         if (e) hipEventDestroy(e);
+    for (auto e : c->ev_free) hipEventDestroy(e);
+    for (auto e : c->ev_pending) hipEventDestroy(e);
+    for (auto e : c->ev_pending_coarse) hipEventDestroy(e);
     if (c->own_stream) hipStreamDestroy(c->own_stream);
     delete c;
     return QK_OK;
@@ -63,7 +66,35 @@ int qk_ctx_synchronize(qk_ctx *c) {
 
 int qk_ctx_set_timing(qk_ctx *c, int enabled) {
     if (!c) QK_FAIL(QK_ERR_INVALID, "qk_ctx_set_timing: ctx is null");
-    c->timing = enabled != 0;
+    c->timing = enabled == 1;
+    c->timing_mode = enabled;
+    return QK_OK;
+}
+
+static float elapsed_or_zero(hipEvent_t a, hipEvent_t b) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, a, b) != hipSuccess) return 0.f;
+    return ms;
+}
+
+int qk_ctx_read_timing(qk_ctx *c, qk_timing *sum, int64_t *calls) {
+    if (!c || !sum || !calls) QK_FAIL(QK_ERR_INVALID, "qk_ctx_read_timing: null argument");
+    QK_HIP(hipStreamSynchronize(c->stream));
+    memset(sum, 0, sizeof(*sum));
+    *calls = (int64_t)(c->ev_pending.size() / 4);
+    for (size_t i = 0; i + 3 < c->ev_pending.size(); i += 4) {
+        hipEvent_t *e = &c->ev_pending[i];
+        sum->group_ms += elapsed_or_zero(e[0], e[1]);
+        sum->scan_ms += elapsed_or_zero(e[1], e[2]);
+        sum->merge_ms += elapsed_or_zero(e[2], e[3]);
+        sum->total_ms += elapsed_or_zero(e[0], e[3]);
+    }
+    for (size_t i = 0; i + 1 < c->ev_pending_coarse.size(); i += 2)
+        sum->coarse_ms += elapsed_or_zero(c->ev_pending_coarse[i], c->ev_pending_coarse[i + 1]);
+    for (auto e : c->ev_pending) c->ev_free.push_back(e);
+    for (auto e : c->ev_pending_coarse) c->ev_free.push_back(e);
+    c->ev_pending.clear();
+    c->ev_pending_coarse.clear();
     return QK_OK;
 }
 

@@ -64,6 +64,11 @@ struct qk_ctx {
     char *stage = nullptr;
     size_t stage_cap = 0;
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    // deferred timing (qk_ctx_set_timing(ctx, 2)): per-call event quads, read back by qk_ctx_read_timing
+    int timing_mode = 0;  // 0 off, 1 per call (sync), 2 deferred
+    std::vector<hipEvent_t> ev_free;
+    std::vector<hipEvent_t> ev_pending;  // groups of 4: group start, scan start, scan end, merge end
+    std::vector<hipEvent_t> ev_pending_coarse;  // groups of 2: coarse start, coarse end
     bool squared_l2 = false;  // L2 entry points return squared distances (sharded path, before the final merge)
 };
 
@@ -129,6 +134,7 @@ struct qk_scan_args {
     bool all_lists = false;
     bool share_tau = true;
     bool sqrt_l2 = true;
+    bool record_events = false;  // record the per-call phase events even when no qk_timing is passed
 };
 int qk_merge_topk_device(qk_ctx *ctx, const int64_t *in_ids, const float *in_key, int G, int64_t Q, int k, int metric,
                          int64_t *out_ids, float *out_dist, bool sqrt_l2);

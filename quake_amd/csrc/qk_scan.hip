@@ -606,7 +606,20 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
     const int npids = (int)s->parts.size();
     const int P = a.all_lists ? npids : a.P;
     hipStream_t st = ctx->stream;
-    const bool tm = ctx->timing && timing;
+    const bool tm = ctx->timing && (timing || a.record_events);
+    // deferred timing: events are parked in the context and read by qk_ctx_read_timing (no sync here)
+    hipEvent_t dev[4] = {nullptr, nullptr, nullptr, nullptr};
+    const bool dtm = ctx->timing_mode == 2;
+    if (dtm) {
+        for (int i = 0; i < 4; i++) {
+            if (!ctx->ev_free.empty()) {
+                dev[i] = ctx->ev_free.back();
+                ctx->ev_free.pop_back();
+            } else {
+                QK_HIP(hipEventCreate(&dev[i]));
+            }
+        }
+    }
 
     // nothing to scan: pure padding (query_coordinator.cpp:459-497 zero-partitions case)
     const int64_t npairs = Q * (int64_t)P;
@@ -673,6 +686,7 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
         QK_FAIL(QK_ERR_OOM, "qk_scan: workspace exhausted");
 
     if (tm) QK_HIP(hipEventRecord(ctx->ev[ev_base + 0], st));
+    if (dtm) QK_HIP(hipEventRecord(dev[0], st));
     // ---- prep + grouping -------------------------------------------------------------------------------
     {
         int64_t total = std::max<int64_t>(Q * nblk * 4, Q);
@@ -700,6 +714,7 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
     hipLaunchKernelGGL(k_group_scan, dim3(1), dim3(1024), 0, st, G);
     if (npairs > 0) hipLaunchKernelGGL(k_group_scatter, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, st, G);
     if (tm) QK_HIP(hipEventRecord(ctx->ev[ev_base + 1], st));
+    if (dtm) QK_HIP(hipEventRecord(dev[1], st));
 
     // ---- scan ------------------------------------------------------------------------------------------------
     ScanParams sp;
@@ -740,6 +755,7 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
         }
     }
     if (tm) QK_HIP(hipEventRecord(ctx->ev[ev_base + 2], st));
+    if (dtm) QK_HIP(hipEventRecord(dev[2], st));
 
     // ---- merge ---------------------------------------------------------------------------------------------------
     MergeParams mp;
@@ -767,6 +783,17 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
     }
     QK_HIP(hipGetLastError());
     if (tm) QK_HIP(hipEventRecord(ctx->ev[ev_base + 3], st));
+    if (dtm) {
+        QK_HIP(hipEventRecord(dev[3], st));
+        if (ev_base == 4) {
+            for (int i = 0; i < 4; i++) ctx->ev_pending.push_back(dev[i]);
+        } else {  // coarse stage: keep (start, end)
+            ctx->ev_pending_coarse.push_back(dev[0]);
+            ctx->ev_pending_coarse.push_back(dev[3]);
+            ctx->ev_free.push_back(dev[1]);
+            ctx->ev_free.push_back(dev[2]);
+        }
+    }
     if (timing) {
         // device scalars come back through pinned memory; the caller synchronises before reading them
         QK_TRY(qk_pinned_reserve(ctx, 64));

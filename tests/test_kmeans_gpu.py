@@ -1,0 +1,83 @@
+"""GPU k-means kernels vs the oracle (clustering.cpp:13-182 restated in oracle/quake_oracle.c).
+assign: bit-exact indices and values; update: bit-exact fp32 sums (same ascending-row order); Lloyd driver:
+identical centroids and assignments (same documented init / split rules).  FAISS parity itself is unpinned."""
+import numpy as np
+import pytest
+
+import oracle as O
+from helpers import make_ivf
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from quake_amd.capi import Context
+    c = Context(0)
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("metric", ["l2", "ip"])
+@pytest.mark.parametrize("n,m,d", [(5000, 37, 32), (3000, 256, 128), (700, 5, 4), (2000, 64, 100)])
+def test_assign_bit_exact(ctx, metric, n, m, d):
+    rng = np.random.default_rng(n + m + d)
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    c = rng.standard_normal((m, d)).astype(np.float32)
+    ga, gv = ctx.kmeans_assign(x, c, metric)
+    oa, ov = O.kmeans_assign(x, c, metric)
+    np.testing.assert_array_equal(ga, oa)
+    np.testing.assert_array_equal(gv.view(np.uint32), ov.view(np.uint32))
+
+
+def test_assign_ties_take_lower_index(ctx):
+    x = np.zeros((40, 8), np.float32)
+    c = np.ones((10, 8), np.float32)  # all centroids equidistant
+    ga, _ = ctx.kmeans_assign(x, c, "l2")
+    assert (ga == 0).all()
+    c[3] = 0
+    c[7] = 0
+    ga, _ = ctx.kmeans_assign(x, c, "l2")
+    assert (ga == 3).all()
+
+
+def test_accumulate_bit_exact(ctx):
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((20000, 48)).astype(np.float32)
+    a = rng.integers(0, 29, size=20000).astype(np.int64)
+    a[a == 11] = 12  # an empty cluster
+    gs, gc = ctx.kmeans_accumulate(x, a, 29)
+    os_, oc = O.kmeans_accumulate(x, a, 29)
+    np.testing.assert_array_equal(gc, oc)
+    np.testing.assert_array_equal(gs.view(np.uint32), os_.view(np.uint32))
+    assert gc[11] == 0
+
+
+@pytest.mark.parametrize("metric", ["l2", "ip"])
+def test_kmeans_driver_matches_oracle(ctx, metric):
+    ivf = make_ivf(30000, 32, 24, seed=3, metric=metric)
+    x = ivf["x"]
+    gc, ga, gx = ctx.kmeans(x, 24, metric, niter=5, seed=1234)
+    oc, oa, ox = O.kmeans(x, 24, metric, niter=5, seed=1234)
+    np.testing.assert_array_equal(gx.view(np.uint32), ox.view(np.uint32))
+    np.testing.assert_array_equal(gc.view(np.uint32), oc.view(np.uint32))
+    np.testing.assert_array_equal(ga, oa)
+    # sanity: a real clustering (every list non-empty, sizes sum to n)
+    assert np.bincount(ga, minlength=24).min() > 0
+
+
+def test_kmeans_subsample_and_empty_split(ctx):
+    # n > 256*m triggers the FAISS-style subsample; duplicated points force empty clusters -> split path
+    rng = np.random.default_rng(5)
+    base = rng.standard_normal((6, 16)).astype(np.float32)
+    x = np.repeat(base, 500, axis=0)  # 3000 rows, only 6 distinct points, m = 8 > 6 -> empties
+    x += 1e-3 * rng.standard_normal(x.shape).astype(np.float32)
+    gc, ga, _ = ctx.kmeans(x, 8, "l2", niter=4, seed=7)
+    oc, oa, _ = O.kmeans(x, 8, "l2", niter=4, seed=7)
+    np.testing.assert_array_equal(gc.view(np.uint32), oc.view(np.uint32))
+    np.testing.assert_array_equal(ga, oa)
+    x2 = rng.standard_normal((3000, 8)).astype(np.float32)  # 3000 > 256*10 -> subsample
+    gc, ga, _ = ctx.kmeans(x2, 10, "l2", niter=3, seed=9)
+    oc, oa, _ = O.kmeans(x2, 10, "l2", niter=3, seed=9)
+    np.testing.assert_array_equal(gc.view(np.uint32), oc.view(np.uint32))
+    np.testing.assert_array_equal(ga, oa)
