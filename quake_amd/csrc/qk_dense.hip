@@ -1,0 +1,313 @@
+// qk_dense.hip -- dense form of the scan: every query of the batch against ONE list.
+//
+// This is the coarse step of QueryCoordinator::search (src/cpp/src/query_coordinator.cpp:628-644: the parent is a flat
+// QuakeIndex whose single partition holds the centroids; batched_scan_list(x, centroids, ..., k = nprobe),
+// src/cpp/include/list_scanning.h:313-366) and the flat-index search (query_coordinator.cpp:624-626).
+// FAISS does this as sgemm + norm fix-up + heap; here:
+//   k_dense_ord<DB,NQ>  Q x n distance keys on v_mfma_f32_16x16x4_f32 (same canonical fmaf chain as k_scan),
+//                       NQ*16 queries staged in LDS per workgroup, list rows streamed as A operands   -> MFMA-bound
+//   k_select_rows<MAXCH> one wave per query: threshold-filter + rank-compaction top-k over its key row -> L2/HBM-bound
+#include "qk_internal.h"
+#include "qk_device.h"
+
+#include <algorithm>
+#include <cstring>
+
+struct DenseParams {
+    const float4 *vecs;  // arena
+    const float *norms;
+    int64_t row_off;     // first arena row of the list (multiple of 16)
+    int nrows;
+    int nblk;
+    const float *x;      // [Q][d] row-major
+    int64_t Q;
+    int d;
+    int metric;
+    uint32_t *D;         // [Q][ld] keys
+    int64_t ld;          // nrows rounded up to 16
+    int tiles_per_wg;    // row tiles per workgroup (split over its 4 waves)
+};
+
+template <int DB, int NQ>
+__global__ __launch_bounds__(256) void k_dense_ord(DenseParams P) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 15, g = lane >> 4;
+    const int nblk = P.nblk, d = P.d;
+    const bool l2 = P.metric == QK_METRIC_L2;
+    float4 *qs = (float4 *)smem;                               // [NQ][nblk*64]
+    float *xn_s = (float *)(smem + (size_t)NQ * nblk * 1024);  // [NQ*16]
+    const int64_t q_base = (int64_t)blockIdx.x * (NQ * 16);
+
+    for (int t = wave; t < NQ * nblk; t += 4) {
+        const int nq = t / nblk, cb = t - nq * nblk;
+        const int64_t row = q_base + nq * 16 + j;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < P.Q) {
+            const float *s = P.x + row * d;
+            const int col = 16 * cb + g;
+            v.x = col < d ? s[col] : 0.0f;
+            v.y = col + 4 < d ? s[col + 4] : 0.0f;
+            v.z = col + 8 < d ? s[col + 8] : 0.0f;
+            v.w = col + 12 < d ? s[col + 12] : 0.0f;
+        }
+        qs[(size_t)nq * nblk * 64 + cb * 64 + lane] = v;
+    }
+    if (tid < NQ * 16) {
+        const int64_t row = q_base + tid;
+        float acc = 0.0f;
+        if (row < P.Q && l2) {
+            const float *s = P.x + row * d;
+            for (int k = 0; k < d; k++) acc = __fmaf_rn(s[k], s[k], acc);
+        }
+        xn_s[tid] = acc;
+    }
+    __syncthreads();
+    float xnj[NQ];
+#pragma unroll
+    for (int nq = 0; nq < NQ; nq++) xnj[nq] = xn_s[nq * 16 + j];
+
+    const int ntile_all = (P.nrows + 15) >> 4;
+    const int wg_t0 = blockIdx.y * P.tiles_per_wg;
+    const int wg_t1 = min(ntile_all, wg_t0 + P.tiles_per_wg);
+    const int tpw = (wg_t1 - wg_t0 + 3) >> 2;
+    const int t0 = wg_t0 + wave * tpw, t1 = min(wg_t1, t0 + tpw);
+    const int ncd = nblk / DB;
+    if (t1 <= t0) return;
+    const int64_t tile_abs0 = (P.row_off >> 4) + t0;
+    const float4 *src = P.vecs + tile_abs0 * nblk * 64 + lane;
+    const float4 *nsrc = (const float4 *)(P.norms + (tile_abs0 << 4)) + g;
+    const int nsteps = (t1 - t0) * ncd;
+    float4 a0[DB], a1[DB];
+    float4 yn_cur = make_float4(0.f, 0.f, 0.f, 0.f), yn_next = yn_cur;
+    f32x4 acc[NQ];
+    int dch = 0, tile = t0, ldch = 0, ltile = 0;
+
+#define DN_LOAD(A, S)                                                 \
+    {                                                                 \
+        const float4 *pp_ = src + (int64_t)(S) * (DB * 64);           \
+        _Pragma("unroll") for (int b_ = 0; b_ < DB; b_++) A[b_] = pp_[b_ * 64]; \
+        if (ldch == 0) {                                              \
+            if (l2) yn_next = nsrc[(int64_t)ltile * 4];               \
+            ltile++;                                                  \
+        }                                                             \
+        if (++ldch == ncd) ldch = 0;                                  \
+    }
+
+#define DN_STEP(A)                                                                                           \
+    {                                                                                                        \
+        if (dch == 0) {                                                                                      \
+            _Pragma("unroll") for (int nq_ = 0; nq_ < NQ; nq_++) acc[nq_] = (f32x4){0.f, 0.f, 0.f, 0.f};     \
+        }                                                                                                    \
+        _Pragma("unroll") for (int b_ = 0; b_ < DB; b_++) {                                                  \
+            _Pragma("unroll") for (int nq_ = 0; nq_ < NQ; nq_++) {                                           \
+                const float4 bq_ = qs[(size_t)nq_ * nblk * 64 + (dch * DB + b_) * 64 + lane];                \
+                acc[nq_] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[b_].x, bq_.x, acc[nq_], 0, 0, 0);          \
+                acc[nq_] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[b_].y, bq_.y, acc[nq_], 0, 0, 0);          \
+                acc[nq_] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[b_].z, bq_.z, acc[nq_], 0, 0, 0);          \
+                acc[nq_] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[b_].w, bq_.w, acc[nq_], 0, 0, 0);          \
+            }                                                                                                \
+        }                                                                                                    \
+        if (++dch == ncd) {                                                                                  \
+            dch = 0;                                                                                         \
+            const float yv_[4] = {yn_cur.x, yn_cur.y, yn_cur.z, yn_cur.w};                                   \
+            const int row0_ = (tile << 4) + 4 * g;                                                           \
+            _Pragma("unroll") for (int nq_ = 0; nq_ < NQ; nq_++) {                                           \
+                const int64_t q_ = q_base + nq_ * 16 + j;                                                    \
+                uint4 o_;                                                                                    \
+                uint32_t *op_ = (uint32_t *)&o_;                                                             \
+                _Pragma("unroll") for (int reg_ = 0; reg_ < 4; reg_++) {                                     \
+                    const float v_ = acc[nq_][reg_];                                                         \
+                    const uint32_t k_ = l2 ? ord_from_l2(l2_expanded(xnj[nq_], yv_[reg_], v_)) : ord_from_ip(v_); \
+                    op_[reg_] = (row0_ + reg_ < P.nrows) ? k_ : 0xFFFFFFFFu;                                 \
+                }                                                                                            \
+                if (q_ < P.Q) *(uint4 *)(P.D + q_ * P.ld + row0_) = o_;                                      \
+            }                                                                                                \
+            yn_cur = yn_next;                                                                                \
+            tile++;                                                                                          \
+        }                                                                                                    \
+    }
+
+    DN_LOAD(a0, 0);
+    yn_cur = yn_next;
+    int s = 0;
+    while (s < nsteps) {
+        if (s + 1 < nsteps) DN_LOAD(a1, s + 1);
+        DN_STEP(a0);
+        s++;
+        if (s >= nsteps) break;
+        if (s + 1 < nsteps) DN_LOAD(a0, s + 1);
+        DN_STEP(a1);
+        s++;
+    }
+#undef DN_LOAD
+#undef DN_STEP
+}
+
+struct SelectParams {
+    const uint32_t *D;
+    int64_t ld;
+    int nrows;
+    const int64_t *ids;  // arena ids + row_off
+    int k;
+    int Cm;
+    int metric;
+    int sqrt_l2;
+    int64_t *out_ids;
+    float *out_dist;
+};
+
+template <int MAXCH>
+__global__ __launch_bounds__(64) void k_select_rows(SelectParams S) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int lane = threadIdx.x;
+    const int64_t q = blockIdx.x;
+    const int k = S.k, Cm = S.Cm;
+    int64_t *pool_id = (int64_t *)smem;
+    uint32_t *pool_ord = (uint32_t *)(smem + (size_t)Cm * 8);
+    const uint32_t *row = S.D + q * S.ld;
+    uint32_t tau = 0xFFFFFFFFu;
+    int cnt = 0;
+    // 4 keys per lane per step (16-byte loads): 256 rows per wave step
+    for (int base = 0; base < S.nrows; base += 256) {
+        const int r0 = base + lane * 4;
+        uint4 kv = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+        if (r0 < S.nrows) kv = *(const uint4 *)(row + r0);  // ld is a multiple of 16 and the tail is 0xFFFFFFFF
+        const uint32_t kk[4] = {kv.x, kv.y, kv.z, kv.w};
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const int r = r0 + t;
+            const bool pass = r < S.nrows && kk[t] <= tau && kk[t] != 0xFFFFFFFFu;
+            const uint64_t m = __ballot(pass);
+            if (m) {
+                if (pass) {
+                    const int sl = cnt + __popcll(m & ((1ull << lane) - 1ull));
+                    pool_ord[sl] = kk[t];
+                    pool_id[sl] = S.ids[r];
+                }
+                cnt += __popcll(m);
+                if (cnt > Cm - 64) {
+                    cnt = compact_pool<MAXCH>(pool_ord, pool_id, cnt, k, lane);
+                    if (cnt >= k) tau = min(tau, pool_ord[k - 1]);
+                }
+            }
+        }
+    }
+    cnt = compact_pool<MAXCH>(pool_ord, pool_id, cnt, k, lane);
+    for (int e = lane; e < k; e += 64) {
+        int64_t oid = -1;
+        float od = S.metric == QK_METRIC_IP ? -INFINITY : INFINITY;
+        if (e < cnt) {
+            oid = pool_id[e];
+            const uint32_t o = pool_ord[e];
+            if (S.metric == QK_METRIC_L2) {
+                const float d2 = __uint_as_float(o);
+                od = S.sqrt_l2 ? sqrtf(d2) : d2;
+            } else {
+                od = ip_from_ord(o);
+            }
+        }
+        S.out_ids[q * k + e] = oid;
+        if (S.out_dist) S.out_dist[q * k + e] = od;
+    }
+}
+
+template <int DB, int NQ>
+static int launch_dense_t(hipStream_t st, dim3 grid, size_t lds, const DenseParams &dp) {
+    QK_HIP(hipFuncSetAttribute((const void *)k_dense_ord<DB, NQ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_dense_ord<DB, NQ>), grid, dim3(256), lds, st, dp);
+    return QK_OK;
+}
+
+int qk_dense_device(qk_ctx *ctx, qk_store *s, int64_t list_no, const qk_scan_args &a, qk_timing *timing, int ev_base) {
+    const int64_t Q = a.Q;
+    const int k = a.k;
+    const qk_part &pt = s->parts[list_no];
+    const int nrows = (int)pt.size;
+    hipStream_t st = ctx->stream;
+    const bool tm = ctx->timing && (timing || a.record_events);
+    qk_phase_events pe;
+    QK_TRY(pe.begin(ctx, tm, ev_base));
+    const int nblk = s->nblk;
+    const int DB = (nblk % 8 == 0) ? 8 : (nblk % 4 == 0) ? 4 : (nblk % 2 == 0) ? 2 : 1;
+    int NQ = 4;
+    while (NQ > 1 && (size_t)NQ * nblk * 1024 > 64 * 1024) NQ >>= 1;
+    const size_t lds = (size_t)NQ * nblk * 1024 + (size_t)NQ * 16 * 4 + 64;
+    if (lds > 160 * 1024) QK_FAIL(QK_ERR_UNSUPPORTED, "dense scan: d=%d too large for the LDS query tile", s->d);
+    const int64_t ld = qk_round_up64(std::max(nrows, 1), 16);
+    const int Cm = qk_round_up(k + 64, 64);
+    if (Cm > 1024) QK_FAIL(QK_ERR_UNSUPPORTED, "dense scan: k=%d too large", k);
+    const int mc = Cm <= 128 ? 2 : Cm <= 256 ? 4 : Cm <= 512 ? 8 : 16;
+    // query batching keeps the key matrix under 1 GiB
+    int64_t qb = std::max<int64_t>(NQ * 16, ((int64_t)1 << 30) / (ld * 4));
+    qb = std::min<int64_t>(Q, (qb / (NQ * 16)) * (NQ * 16));
+    QK_TRY(qk_ws_reserve(ctx, (size_t)qb * ld * 4 + 4096));
+    uint32_t *D = (uint32_t *)qk_ws_alloc(ctx, (size_t)qb * ld * 4);
+    if (!D) QK_FAIL(QK_ERR_OOM, "dense scan: workspace exhausted");
+    const int num_cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
+    QK_TRY(pe.mark(0));
+    QK_TRY(pe.mark(1));
+    for (int64_t q0 = 0; q0 < Q; q0 += qb) {
+        const int64_t nq = std::min(qb, Q - q0);
+        DenseParams dp;
+        dp.vecs = (const float4 *)s->vecs;
+        dp.norms = s->norms;
+        dp.row_off = pt.row_off;
+        dp.nrows = nrows;
+        dp.nblk = nblk;
+        dp.x = a.x + q0 * s->d;
+        dp.Q = nq;
+        dp.d = s->d;
+        dp.metric = a.metric;
+        dp.D = D;
+        dp.ld = ld;
+        const int64_t qgroups = (nq + NQ * 16 - 1) / (NQ * 16);
+        const int ntile = (nrows + 15) / 16;
+        // enough workgroups to fill the chip, at least 4 tiles (one per wave) each
+        int64_t want_chunks = std::max<int64_t>(1, ((int64_t)4 * num_cus + qgroups - 1) / qgroups);
+        int tiles_per_wg = (int)std::max<int64_t>(4, (ntile + want_chunks - 1) / want_chunks);
+        tiles_per_wg = qk_round_up(tiles_per_wg, 4);
+        dp.tiles_per_wg = tiles_per_wg;
+        const int rchunks = std::max(1, (ntile + tiles_per_wg - 1) / tiles_per_wg);
+        if (nrows > 0) {
+            dim3 grid((unsigned)qgroups, (unsigned)rchunks);
+#define DN_CASE(D_, N_) \
+    if (DB == D_ && NQ == N_) QK_TRY((launch_dense_t<D_, N_>(st, grid, lds, dp)));
+            DN_CASE(8, 4) DN_CASE(8, 2) DN_CASE(8, 1) DN_CASE(4, 4) DN_CASE(4, 2) DN_CASE(4, 1)
+            DN_CASE(2, 4) DN_CASE(2, 2) DN_CASE(2, 1) DN_CASE(1, 4) DN_CASE(1, 2) DN_CASE(1, 1)
+#undef DN_CASE
+        }
+        if (q0 + qb >= Q) QK_TRY(pe.mark(2));
+        SelectParams sp;
+        sp.D = D;
+        sp.ld = ld;
+        sp.nrows = nrows;
+        sp.ids = s->ids + pt.row_off;
+        sp.k = k;
+        sp.Cm = Cm;
+        sp.metric = a.metric;
+        sp.sqrt_l2 = a.sqrt_l2 ? 1 : 0;
+        sp.out_ids = a.out_ids + q0 * k;
+        sp.out_dist = a.out_dist ? a.out_dist + q0 * k : nullptr;
+        const size_t lds_s = (size_t)Cm * 12;
+        switch (mc) {
+            case 2: hipLaunchKernelGGL((k_select_rows<2>), dim3((unsigned)nq), dim3(64), lds_s, st, sp); break;
+            case 4: hipLaunchKernelGGL((k_select_rows<4>), dim3((unsigned)nq), dim3(64), lds_s, st, sp); break;
+            case 8: hipLaunchKernelGGL((k_select_rows<8>), dim3((unsigned)nq), dim3(64), lds_s, st, sp); break;
+            default: hipLaunchKernelGGL((k_select_rows<16>), dim3((unsigned)nq), dim3(64), lds_s, st, sp); break;
+        }
+    }
+    QK_HIP(hipGetLastError());
+    QK_TRY(pe.mark(3));
+    if (timing) {
+        // same scalar block the generic path reports: n_items, -, rows scanned
+        QK_TRY(qk_pinned_reserve(ctx, 64));
+        int32_t *hs = (int32_t *)ctx->pinned;
+        QK_HIP(hipStreamSynchronize(st));
+        hs[0] = 1;
+        hs[1] = 0;
+        int64_t rows = nrows;
+        memcpy(hs + 2, &rows, sizeof(rows));
+    }
+    return QK_OK;
+}

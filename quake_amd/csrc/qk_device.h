@@ -1,0 +1,62 @@
+// qk_device.h -- device-side helpers shared by the scan / dense / k-means kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <climits>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---- orderable keys: smaller = better --------------------------------------------------------------
+__device__ __forceinline__ uint32_t ord_from_l2(float d2) { return __float_as_uint(d2); }  // d2 >= +0
+__device__ __forceinline__ uint32_t ord_from_ip(float ip) {
+    uint32_t b = __float_as_uint(ip);
+    uint32_t asc = b ^ ((b >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+    return ~asc;
+}
+__device__ __forceinline__ float ip_from_ord(uint32_t o) {
+    uint32_t asc = ~o;
+    uint32_t b = (asc & 0x80000000u) ? (asc ^ 0x80000000u) : ~asc;
+    return __uint_as_float(b);
+}
+// faiss::knn_L2sqr expansion, clamped at 0 (oracle: l2sqr_expanded)
+__device__ __forceinline__ float l2_expanded(float xn, float yn, float ip) {
+    float r = __fmaf_rn(-2.0f, ip, xn + yn);
+    return r < 0.0f ? 0.0f : r;
+}
+
+// ---- LDS pool compaction (the TopkBuffer::flush of this design) ------------------------------------
+// Keeps the k best of n entries under the total order (ord, id, position) and leaves them sorted in [0,k).
+template <int MAXCH>
+__device__ __forceinline__ int compact_pool(uint32_t *ord, int64_t *id, int n, int k, int lane) {
+    uint32_t o[MAXCH];
+    int64_t d[MAXCH];
+    int rk[MAXCH];
+#pragma unroll
+    for (int i = 0; i < MAXCH; i++) {
+        int e = lane + 64 * i;
+        bool has = e < n;
+        o[i] = has ? ord[e] : 0xFFFFFFFFu;
+        d[i] = has ? id[e] : LLONG_MAX;
+        rk[i] = 0;
+    }
+    for (int t = 0; t < n; t++) {
+        uint32_t ot = ord[t];
+        int64_t it = id[t];
+#pragma unroll
+        for (int i = 0; i < MAXCH; i++) {
+            int e = lane + 64 * i;
+            bool less = (ot < o[i]) || (ot == o[i] && (it < d[i] || (it == d[i] && t < e)));
+            rk[i] += less ? 1 : 0;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MAXCH; i++) {
+        int e = lane + 64 * i;
+        if (e < n && rk[i] < k) {
+            ord[rk[i]] = o[i];
+            id[rk[i]] = d[i];
+        }
+    }
+    return n < k ? n : k;
+}
+

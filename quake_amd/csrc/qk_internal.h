@@ -139,3 +139,45 @@ struct qk_scan_args {
 int qk_merge_topk_device(qk_ctx *ctx, const int64_t *in_ids, const float *in_key, int G, int64_t Q, int k, int metric,
                          int64_t *out_ids, float *out_dist, bool sqrt_l2);
 int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *timing, int ev_base);
+// dense form (every query x one list, Q large): distance matrix on MFMA + per-query select.  qk_dense.hip
+int qk_dense_device(qk_ctx *ctx, qk_store *s, int64_t list_no, const qk_scan_args &a, qk_timing *timing, int ev_base);
+
+// phase events of one pipeline run: per-call mode (ctx->ev[ev_base..]) and/or deferred mode (parked in the ctx)
+struct qk_phase_events {
+    qk_ctx *ctx = nullptr;
+    bool tm = false, dtm = false;
+    int ev_base = 0;
+    hipEvent_t dev[4] = {nullptr, nullptr, nullptr, nullptr};
+    int begin(qk_ctx *c, bool per_call, int base) {
+        ctx = c;
+        tm = per_call;
+        dtm = c->timing_mode == 2;
+        ev_base = base;
+        if (dtm) {
+            for (int i = 0; i < 4; i++) {
+                if (!c->ev_free.empty()) {
+                    dev[i] = c->ev_free.back();
+                    c->ev_free.pop_back();
+                } else {
+                    QK_HIP(hipEventCreate(&dev[i]));
+                }
+            }
+        }
+        return QK_OK;
+    }
+    int mark(int i) {
+        if (tm) QK_HIP(hipEventRecord(ctx->ev[ev_base + i], ctx->stream));
+        if (dtm) QK_HIP(hipEventRecord(dev[i], ctx->stream));
+        if (dtm && i == 3) {
+            if (ev_base == 4) {
+                for (int t = 0; t < 4; t++) ctx->ev_pending.push_back(dev[t]);
+            } else {  // coarse stage: keep (start, end)
+                ctx->ev_pending_coarse.push_back(dev[0]);
+                ctx->ev_pending_coarse.push_back(dev[3]);
+                ctx->ev_free.push_back(dev[1]);
+                ctx->ev_free.push_back(dev[2]);
+            }
+        }
+        return QK_OK;
+    }
+};

@@ -10,38 +10,27 @@
 //
 // Pipeline (all on one stream, no host round trip):
 //   k_prep_queries   x[Q][d] -> fragment-ordered copy + squared norms
-//   k_group_count / k_group_scan / k_group_scatter   (q,p) pairs -> per-partition query groups, work-item table
-//   k_scan<DB,MAXCH> persistent workgroups pull work items (partition, 16-query tile, row chunk); each wave streams
-//                    its rows as contiguous 1 KiB float4 loads straight into MFMA A operands, queries come from LDS,
-//                    v_mfma_f32_16x16x4_f32 accumulates the dot products in natural k order; candidates that beat
-//                    the running k-th best are appended to a per-(wave,query) LDS pool that is compacted by rank
-//   k_merge<MAXCH>   one wave per query merges its candidate lists, applies sqrt / padding, writes [Q][k]
+//   k_group_count / k_group_scan / k_group_scatter
+//                    (q,p) pairs -> per-partition query groups; the work is the sequence of "items"
+//                    (partition p, 16-query tile qt), each ntiles(p) row tiles long, laid end to end in tile units
+//   k_scan<DB,MAXCH> persistent, ONE WAVE PER WORKGROUP.  The tile sequence is cut into equal contiguous ranges, one
+//                    per wave (perfect byte balance whatever the partition sizes).  A wave walks its range segment by
+//                    segment (a segment = part of one item): stages the 16 queries in LDS in B-operand lane order,
+//                    streams the rows as contiguous 1 KiB float4 loads straight into MFMA A operands (register
+//                    double-buffered), v_mfma_f32_16x16x4_f32 accumulates dot products in natural k order; candidates
+//                    that beat the running k-th best go to a per-query LDS pool compacted by rank (the TopkBuffer
+//                    append + flush); at the segment end each non-empty pool becomes a record chained to its
+//                    (query, partition) pair.  A per-query bound shared through global memory (gtau) lets later
+//                    segments skip almost everything.
+//   k_merge<MAXCH>   one wave per query walks its pairs' record chains, merges, applies sqrt / padding -> [Q][k]
 //
 // Roofline: HBM.  Algorithmic bytes per batch = sum over unique probed partitions of n_p*d*4.
 #include "qk_internal.h"
+#include "qk_device.h"
 
 #include <algorithm>
 #include <climits>
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-// ---- orderable keys: smaller = better --------------------------------------------------------------
-__device__ __forceinline__ uint32_t ord_from_l2(float d2) { return __float_as_uint(d2); }  // d2 >= +0
-__device__ __forceinline__ uint32_t ord_from_ip(float ip) {
-    uint32_t b = __float_as_uint(ip);
-    uint32_t asc = b ^ ((b >> 31) ? 0xFFFFFFFFu : 0x80000000u);
-    return ~asc;
-}
-__device__ __forceinline__ float ip_from_ord(uint32_t o) {
-    uint32_t asc = ~o;
-    uint32_t b = (asc & 0x80000000u) ? (asc ^ 0x80000000u) : ~asc;
-    return __uint_as_float(b);
-}
-// faiss::knn_L2sqr expansion, clamped at 0 (oracle: l2sqr_expanded)
-__device__ __forceinline__ float l2_expanded(float xn, float yn, float ip) {
-    float r = __fmaf_rn(-2.0f, ip, xn + yn);
-    return r < 0.0f ? 0.0f : r;
-}
+#include <cstdlib>
 
 // ---- query preparation -----------------------------------------------------------------------------
 // xq4[(q*nblk + c)*4 + g] = {x[q][16c+g], x[q][16c+g+4], x[q][16c+g+8], x[q][16c+g+12]}  (B-operand order)
@@ -77,15 +66,17 @@ struct GroupParams {
     int P;
     const int32_t *pt_size;
     int npids;
-    int chunk_rows;
-    int32_t *g_cnt;     // [npids]
-    int32_t *g_cursor;  // [npids]
-    int32_t *g_qoff;    // [npids+1]
-    int32_t *g_ioff;    // [npids+1]
-    int32_t *n_items;   // [1]
-    int32_t *grouped_q; // [npairs]
-    int32_t *pair_pos;  // [npairs]
-    int64_t *n_rows_unique;  // [1] sum of sizes of partitions with >=1 query (algorithmic bytes / (d*4))
+    int32_t *g_cnt;       // [npids] queries probing each partition
+    int32_t *g_cursor;    // [npids]
+    int32_t *g_qoff;      // [npids+1] offsets into grouped_*
+    int32_t *n_active;    // [1]
+    int32_t *active_p;    // [npids] partitions with >= 1 query, ascending
+    int64_t *active_toff; // [npids+1] first tile of each active partition in the global tile sequence
+    int64_t *n_tiles;     // [1] total tiles = sum over active p of ntiles(p) * ceil(cnt_p/16)
+    int64_t *n_rows_unique;  // [1] sum of sizes of active partitions (algorithmic bytes / (d*4))
+    int32_t *grouped_q;   // [npairs] query of each grouped entry
+    int32_t *grouped_pair;// [npairs] pair index (q*P + r) of each grouped entry
+    int32_t *pair_head;   // [npairs] head of the record chain of each pair (-1 = none)
 };
 
 __device__ __forceinline__ int pair_pid(const GroupParams &G, int64_t i) {
@@ -97,58 +88,69 @@ __device__ __forceinline__ int pair_pid(const GroupParams &G, int64_t i) {
 __global__ void k_group_count(GroupParams G) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= G.npairs) return;
+    G.pair_head[i] = -1;
     int p = pair_pid(G, i);
     if (p >= 0) atomicAdd(&G.g_cnt[p], 1);
 }
 
-// single workgroup of 1024 threads: exclusive scans of per-partition query counts and work-item counts
+// single workgroup of 1024 threads: exclusive scans over the partitions
 __global__ __launch_bounds__(1024) void k_group_scan(GroupParams G) {
     __shared__ int s_q[1024];
-    __shared__ int s_i[1024];
+    __shared__ int s_a[1024];
+    __shared__ long long s_t[1024];
     __shared__ long long s_r[1024];
     const int tid = threadIdx.x;
     const int per = (G.npids + 1023) / 1024;
     const int b = tid * per, e = min(G.npids, b + per);
-    int sq = 0, si = 0;
-    long long sr = 0;
+    int sq = 0, sa = 0;
+    long long stl = 0, sr = 0;
     for (int p = b; p < e; p++) {
         int c = G.g_cnt[p];
         if (c > 0) {
             int sz = G.pt_size[p];
             sq += c;
-            si += ((c + 15) >> 4) * ((sz + G.chunk_rows - 1) / G.chunk_rows);
+            sa += 1;
+            stl += (long long)((c + 15) >> 4) * ((sz + 15) >> 4);
             sr += sz;
         }
     }
     s_q[tid] = sq;
-    s_i[tid] = si;
+    s_a[tid] = sa;
+    s_t[tid] = stl;
     s_r[tid] = sr;
     __syncthreads();
     if (tid == 0) {
-        int aq = 0, ai = 0;
-        long long ar = 0;
+        int aq = 0, aa = 0;
+        long long at = 0, ar = 0;
         for (int t = 0; t < 1024; t++) {
-            int vq = s_q[t], vi = s_i[t];
+            int vq = s_q[t], va = s_a[t];
+            long long vt = s_t[t];
             s_q[t] = aq;
-            s_i[t] = ai;
+            s_a[t] = aa;
+            s_t[t] = at;
             aq += vq;
-            ai += vi;
+            aa += va;
+            at += vt;
             ar += s_r[t];
         }
         G.g_qoff[G.npids] = aq;
-        G.g_ioff[G.npids] = ai;
-        *G.n_items = ai;
+        *G.n_active = aa;
+        G.active_toff[aa] = at;
+        *G.n_tiles = at;
         *G.n_rows_unique = ar;
     }
     __syncthreads();
-    int aq = s_q[tid], ai = s_i[tid];
+    int aq = s_q[tid], aa = s_a[tid];
+    long long at = s_t[tid];
     for (int p = b; p < e; p++) {
         G.g_qoff[p] = aq;
-        G.g_ioff[p] = ai;
         int c = G.g_cnt[p];
         if (c > 0) {
+            G.active_p[aa] = p;
+            G.active_toff[aa] = at;
             aq += c;
-            ai += ((c + 15) >> 4) * ((G.pt_size[p] + G.chunk_rows - 1) / G.chunk_rows);
+            aa += 1;
+            at += (long long)((c + 15) >> 4) * ((G.pt_size[p] + 15) >> 4);
         }
     }
 }
@@ -157,48 +159,11 @@ __global__ void k_group_scatter(GroupParams G) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= G.npairs) return;
     int p = pair_pid(G, i);
-    int pos = -1;
     if (p >= 0) {
-        pos = atomicAdd(&G.g_cursor[p], 1);
+        int pos = atomicAdd(&G.g_cursor[p], 1);
         G.grouped_q[G.g_qoff[p] + pos] = (int32_t)(i / G.P);
+        G.grouped_pair[G.g_qoff[p] + pos] = (int32_t)i;
     }
-    G.pair_pos[i] = pos;
-}
-
-// ---- LDS pool compaction (the TopkBuffer::flush of this design) ------------------------------------
-// Keeps the k best of n entries under the total order (ord, id, position) and leaves them sorted in [0,k).
-template <int MAXCH>
-__device__ __forceinline__ int compact_pool(uint32_t *ord, int64_t *id, int n, int k, int lane) {
-    uint32_t o[MAXCH];
-    int64_t d[MAXCH];
-    int rk[MAXCH];
-#pragma unroll
-    for (int i = 0; i < MAXCH; i++) {
-        int e = lane + 64 * i;
-        bool has = e < n;
-        o[i] = has ? ord[e] : 0xFFFFFFFFu;
-        d[i] = has ? id[e] : LLONG_MAX;
-        rk[i] = 0;
-    }
-    for (int t = 0; t < n; t++) {
-        uint32_t ot = ord[t];
-        int64_t it = id[t];
-#pragma unroll
-        for (int i = 0; i < MAXCH; i++) {
-            int e = lane + 64 * i;
-            bool less = (ot < o[i]) || (ot == o[i] && (it < d[i] || (it == d[i] && t < e)));
-            rk[i] += less ? 1 : 0;
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < MAXCH; i++) {
-        int e = lane + 64 * i;
-        if (e < n && rk[i] < k) {
-            ord[rk[i]] = o[i];
-            id[rk[i]] = d[i];
-        }
-    }
-    return n < k ? n : k;
 }
 
 // ---- the scan kernel ---------------------------------------------------------------------------------
@@ -208,135 +173,181 @@ struct ScanParams {
     const int64_t *ids;
     const int64_t *pt_off;
     const int32_t *pt_size;
-    int npids;
     int nblk;
     const float4 *xq4;
     const float *xn;
     const int32_t *grouped_q;
+    const int32_t *grouped_pair;
     const int32_t *g_cnt;
     const int32_t *g_qoff;
-    const int32_t *g_ioff;
-    const int32_t *n_items;
-    int32_t *item_counter;
+    const int32_t *n_active;
+    const int32_t *active_p;
+    const int64_t *active_toff;
+    const int64_t *n_tiles;
     uint32_t *gtau;  // [Q] shared running bound per query, or nullptr
-    int chunk_rows;
     int k;
-    int C;  // pool capacity per (wave, query); k <= C - 4
+    int C;  // pool capacity per query; k <= C - 4
     int metric;
-    uint32_t *cand_ord;  // [slot][k]
-    int64_t *cand_id;    // [slot][k]
-    int32_t *cand_cnt;   // [slot]
+    int32_t *pair_head;
+    int32_t *rec_counter;
+    int32_t max_recs;
+    int32_t *rec_next;   // [max_recs]
+    int32_t *rec_cnt;    // [max_recs]
+    uint32_t *rec_ord;   // [max_recs][k]
+    int64_t *rec_id;     // [max_recs][k]
 };
 
-template <int DB, int MAXCH>
-__global__ __launch_bounds__(256) void k_scan(ScanParams P) {
+// MODE 0 = product; 1 = skip the top-k epilogue; 2 = loads only (probe variants for bandwidth attribution, QK_SCAN_MODE)
+template <int DB, int MAXCH, int MODE = 0>
+__global__ __launch_bounds__(64) void k_scan(ScanParams P) {
     extern __shared__ __align__(16) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lane = threadIdx.x;
     const int j = lane & 15, g = lane >> 4;
     const int nblk = P.nblk, C = P.C, k = P.k;
     const bool l2 = P.metric == QK_METRIC_L2;
-    float4 *qs = (float4 *)smem;
-    const size_t wave_bytes = (size_t)16 * C * 12;
-    unsigned char *wbase = smem + (size_t)nblk * 1024 + wave * wave_bytes;
-    int64_t *pool_id = (int64_t *)wbase;                      // [16][C]
-    uint32_t *pool_ord = (uint32_t *)(wbase + (size_t)16 * C * 8);  // [16][C]
-    volatile int *s_item = (volatile int *)(smem + (size_t)nblk * 1024 + QK_WAVES * wave_bytes);
-    const int n_items = *P.n_items;
-    constexpr int NCD_UNUSED = 0;
-    (void)NCD_UNUSED;
+    float4 *qs = (float4 *)smem;                                               // [nblk*64]
+    int64_t *pool_id = (int64_t *)(smem + (size_t)nblk * 1024);                // [16][C]
+    uint32_t *pool_ord = (uint32_t *)(smem + (size_t)nblk * 1024 + (size_t)16 * C * 8);  // [16][C]
+    uint32_t *my_ord = pool_ord + j * C;
+    int64_t *my_id = pool_id + j * C;
     const int ncd = nblk / DB;  // d-chunks per tile
 
-    for (;;) {
-        if (tid == 0) *s_item = atomicAdd(P.item_counter, 1);
-        __syncthreads();
-        const int item = *s_item;
-        if (item >= n_items) break;
-        // ---- decode the work item --------------------------------------------------------------
-        int lo = 0, hi = P.npids;
-        while (hi - lo > 1) {
-            int mid = (lo + hi) >> 1;
-            if (P.g_ioff[mid] <= item)
-                lo = mid;
-            else
-                hi = mid;
-        }
-        const int p = lo;
-        const int local = item - P.g_ioff[p];
+    // ---- this wave's contiguous share of the global tile sequence ------------------------------------------
+    const long long T = *P.n_tiles;
+    const long long W = gridDim.x;
+    const long long T0 = (T * blockIdx.x) / W, T1 = (T * (blockIdx.x + 1)) / W;
+    if (T1 <= T0) return;
+    const int n_active = *P.n_active;
+    int lo = 0, hi = n_active;  // active_toff[lo] <= T0 < active_toff[hi]
+    while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (P.active_toff[mid] <= T0)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    int ai = lo;
+    long long cur = T0;
+
+    while (cur < T1) {
+        // ---- segment = tiles [tl, tend) of item (p, qt) ---------------------------------------------------------
+        const int p = P.active_p[ai];
+        const long long base = P.active_toff[ai];
         const int size_p = P.pt_size[p];
         const int64_t row_off = P.pt_off[p];
-        const int nchunk = (size_p + P.chunk_rows - 1) / P.chunk_rows;
-        const int qt = local / nchunk, ch = local - qt * nchunk;
-        const int nq = min(16, P.g_cnt[p] - 16 * qt);
-        const int myq = (j < nq) ? P.grouped_q[P.g_qoff[p] + 16 * qt + j] : -1;
-        // ---- query tile -> LDS in B-operand lane order --------------------------------------------
-        for (int cb = wave; cb < nblk; cb += QK_WAVES) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (myq >= 0) v = P.xq4[((int64_t)myq * nblk + cb) * 4 + g];
-            qs[cb * 64 + lane] = v;
+        const int ntl = (size_p + 15) >> 4;
+        const int cnt_p = P.g_cnt[p];
+        const int nqt = (cnt_p + 15) >> 4;
+        const long long local = cur - base;
+        const int qt = (int)(local / ntl);
+        const int tl = (int)(local - (long long)qt * ntl);
+        const int tend = (int)min((long long)ntl, (long long)tl + (T1 - cur));
+        cur += tend - tl;
+        if (qt == nqt - 1 && tend == ntl) ai++;  // item sequence of this partition exhausted
+        const int nq = min(16, cnt_p - 16 * qt);
+        const int gidx = P.g_qoff[p] + 16 * qt + j;
+        const int myq = (j < nq) ? P.grouped_q[gidx] : -1;
+        const int mypair = (j < nq) ? P.grouped_pair[gidx] : -1;
+        // ---- query tile -> LDS in B-operand lane order (wave-private); loads batched DB at a time ---------------
+        {
+            const int qsafe = myq >= 0 ? myq : 0;
+            const float4 *qsrc = P.xq4 + (int64_t)qsafe * nblk * 4 + g;
+            for (int cb0 = 0; cb0 < nblk; cb0 += DB) {
+                float4 qv[DB];
+#pragma unroll
+                for (int b = 0; b < DB; b++) qv[b] = qsrc[(cb0 + b) * 4];
+#pragma unroll
+                for (int b = 0; b < DB; b++) {
+                    if (myq < 0) qv[b] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    qs[(cb0 + b) * 64 + lane] = qv[b];
+                }
+            }
         }
-        __syncthreads();
-        // ---- this wave's rows ---------------------------------------------------------------------
-        const int row_c0 = ch * P.chunk_rows;
-        const int nrows = min(size_p - row_c0, P.chunk_rows);
-        const int ntile = (nrows + 15) >> 4;
-        const int tpw = (ntile + QK_WAVES - 1) / QK_WAVES;
-        const int t0 = wave * tpw, t1 = min(ntile, t0 + tpw);
         uint32_t tau = 0xFFFFFFFFu;
         if (myq >= 0 && P.gtau) tau = __hip_atomic_load(&P.gtau[myq], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         int cnt = 0;
         const float xnj = (myq >= 0 && l2) ? P.xn[myq] : 0.0f;
-        uint32_t *my_ord = pool_ord + j * C;
-        int64_t *my_id = pool_id + j * C;
-
-        if (t1 > t0) {
-            const int64_t tile_abs0 = (row_off >> 4) + (row_c0 >> 4) + t0;
+        {
+            const int64_t tile_abs0 = (row_off >> 4) + tl;
             const float4 *src = P.vecs + tile_abs0 * nblk * 64 + lane;
             const float4 *nsrc = (const float4 *)(P.norms + (tile_abs0 << 4)) + g;  // +4 float4 per tile
-            const int nsteps = (t1 - t0) * ncd;
+            // ids of this lane's 4 rows travel with the tile (static prefetch): an id load inside the append path
+            // would force s_waitcnt vmcnt(0) and drain the prefetched tile every time a candidate passes
+            const longlong2 *isrc = (const longlong2 *)(P.ids + (tile_abs0 << 4)) + 2 * g;  // +8 longlong2 per tile
+            longlong2 id_cur0 = {0, 0}, id_cur1 = {0, 0}, id_next0 = {0, 0}, id_next1 = {0, 0};
+            const int nsteps = (tend - tl) * ncd;
             float4 a0[DB], a1[DB];
             float4 yn_cur = make_float4(0.f, 0.f, 0.f, 0.f), yn_next = yn_cur;
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            int dch = 0;       // d-chunk of the step being computed
-            int tile = t0;     // tile of the step being computed
-            int ldch = 0;      // d-chunk of the step being loaded
-            int ltile = 0;     // tiles loaded so far (relative)
+            float probe_sink = 0.f;
+            int dch = 0;    // d-chunk of the step being computed
+            int tile = tl;  // tile of the step being computed
+            int ldch = 0;   // d-chunk of the step being loaded
+            int ltile = 0;  // tiles loaded so far (relative)
 
-#define QK_LOAD(A, S)                                                 \
+            // The load stream is STATIC (same loads every iteration, clamped at the end of the segment) so that the
+            // compiler can place counted s_waitcnt vmcnt(N) and keep the next step's loads in flight under the MFMAs.
+            int lS = 0;  // next step to load (clamped to nsteps-1)
+#define QK_LOAD(A)                                                    \
     {                                                                 \
-        const float4 *pp_ = src + (int64_t)(S) * (DB * 64);           \
+        const float4 *pp_ = src + (int64_t)lS * (DB * 64);            \
         _Pragma("unroll") for (int b_ = 0; b_ < DB; b_++) A[b_] = pp_[b_ * 64]; \
-        if (ldch == 0) {                                              \
-            if (l2) yn_next = nsrc[(int64_t)ltile * 4];               \
-            ltile++;                                                  \
+        yn_next = nsrc[(int64_t)ltile * 4];                           \
+        id_next0 = isrc[(int64_t)ltile * 8];                          \
+        id_next1 = isrc[(int64_t)ltile * 8 + 1];                      \
+        if (lS < nsteps - 1) {                                        \
+            lS++;                                                     \
+            if (++ldch == ncd) {                                      \
+                ldch = 0;                                             \
+                ltile++;                                              \
+            }                                                         \
         }                                                             \
-        if (++ldch == ncd) ldch = 0;                                  \
     }
 
-#define QK_STEP(A)                                                                                         \
+#define QK_STEP(A, LIVE)                                                                                    \
     {                                                                                                      \
         if (dch == 0) acc = (f32x4){0.f, 0.f, 0.f, 0.f};                                                   \
         _Pragma("unroll") for (int b_ = 0; b_ < DB; b_++) {                                                \
-            const float4 bq_ = qs[(dch * DB + b_) * 64 + lane];                                            \
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(A[b_].x, bq_.x, acc, 0, 0, 0);                      \
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(A[b_].y, bq_.y, acc, 0, 0, 0);                      \
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(A[b_].z, bq_.z, acc, 0, 0, 0);                      \
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(A[b_].w, bq_.w, acc, 0, 0, 0);                      \
+            if (MODE == 2) {                                                                               \
+                acc[0] += A[b_].x;                                                                         \
+                acc[1] += A[b_].y;                                                                         \
+                acc[2] += A[b_].z;                                                                         \
+                acc[3] += A[b_].w;                                                                         \
+            } else {                                                                                       \
+                const float4 bq_ = qs[(dch * DB + b_) * 64 + lane];                                        \
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(A[b_].x, bq_.x, acc, 0, 0, 0);                  \
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(A[b_].y, bq_.y, acc, 0, 0, 0);                  \
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(A[b_].z, bq_.z, acc, 0, 0, 0);                  \
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(A[b_].w, bq_.w, acc, 0, 0, 0);                  \
+            }                                                                                              \
         }                                                                                                  \
         if (++dch == ncd) {                                                                                \
             dch = 0;                                                                                       \
-            epilogue(tile);                                                                                \
+            if (MODE == 0) {                                                                               \
+                epilogue(tile, LIVE);                                                                      \
+            } else {                                                                                       \
+                probe_sink += acc[0] + acc[1] + acc[2] + acc[3] + yn_cur.x + (float)id_cur0.x;             \
+                yn_cur = yn_next;                                                                          \
+                id_cur0 = id_next0;                                                                        \
+                id_cur1 = id_next1;                                                                        \
+            }                                                                                              \
             tile++;                                                                                        \
         }                                                                                                  \
     }
 
-            auto epilogue = [&](int tl) {
-                const int row0 = row_c0 + (tl << 4);
-                const int64_t arow = row_off + row0 + 4 * g;
+            auto epilogue = [&](int tl_, bool live) {
+                const int row0 = tl_ << 4;
                 const float yv[4] = {yn_cur.x, yn_cur.y, yn_cur.z, yn_cur.w};
+                const int64_t idv[4] = {id_cur0.x, id_cur0.y, id_cur1.x, id_cur1.y};
+                // every 8 tiles pick up bounds published by other waves working on the same query.  Measured
+                // (scan_probe.py, 10M x 128, P=32): this agent-scope re-read beats a per-tile plain (L1-stale) or
+                // sc1 load folded into the prefetch stream by 15-25 %, although consuming it drains the prefetch.
+                if (P.gtau && (tl_ & 7) == 7 && myq >= 0)
+                    tau = min(tau, __hip_atomic_load(&P.gtau[myq], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 #pragma unroll
                 for (int reg = 0; reg < 4; reg++) {
                     const int row = row0 + 4 * g + reg;
-                    const bool valid = (myq >= 0) && (row < size_p);
+                    const bool valid = live && (myq >= 0) && (row < size_p);
                     const float v = acc[reg];
                     const uint32_t ord = l2 ? ord_from_l2(l2_expanded(xnj, yv[reg], v)) : ord_from_ip(v);
                     const bool pass = valid && ord <= tau;
@@ -346,7 +357,7 @@ __global__ __launch_bounds__(256) void k_scan(ScanParams P) {
                         if (pass) {
                             const int slot = cnt + __popcll(gm & ((1ull << lane) - 1ull));
                             my_ord[slot] = ord;
-                            my_id[slot] = P.ids[arow + reg];
+                            my_id[slot] = idv[reg];
                         }
                         cnt += __popcll(gm);
                         uint64_t need = __ballot(cnt > C - 4) & 0xFFFFull;
@@ -357,30 +368,34 @@ __global__ __launch_bounds__(256) void k_scan(ScanParams P) {
                             const int nn = compact_pool<MAXCH>(pool_ord + jq * C, pool_id + jq * C, n, k, lane);
                             if (j == jq) {
                                 cnt = nn;
-                                if (nn >= k) tau = min(tau, pool_ord[jq * C + k - 1]);
+                                if (nn >= k) {
+                                    tau = min(tau, pool_ord[jq * C + k - 1]);
+                                    if (P.gtau && lane < 16) atomicMin(&P.gtau[myq], tau);
+                                }
                             }
                         }
                     }
                 }
                 yn_cur = yn_next;
+                id_cur0 = id_next0;
+                id_cur1 = id_next1;
             };
 
-            QK_LOAD(a0, 0);
+            QK_LOAD(a0);
             yn_cur = yn_next;
-            int s = 0;
-            while (s < nsteps) {
-                if (s + 1 < nsteps) QK_LOAD(a1, s + 1);
-                QK_STEP(a0);
-                s++;
-                if (s >= nsteps) break;
-                if (s + 1 < nsteps) QK_LOAD(a0, s + 1);
-                QK_STEP(a1);
-                s++;
+            id_cur0 = id_next0;
+            id_cur1 = id_next1;
+            for (int s = 0; s < nsteps; s += 2) {
+                QK_LOAD(a1);
+                QK_STEP(a0, true);
+                QK_LOAD(a0);
+                QK_STEP(a1, s + 1 < nsteps);
             }
 #undef QK_LOAD
 #undef QK_STEP
+            if (MODE != 0 && probe_sink == 12345.678f) my_ord[0] = 1;  // keep the probe's loads alive
         }
-        // ---- final compaction (sorts, caps at k) + emit ---------------------------------------------
+        // ---- segment end: final compaction (sorts, caps at k), publish bound, emit records ---------------------------
         {
             uint64_t need = __ballot(cnt > 0) & 0xFFFFull;
             while (need) {
@@ -390,16 +405,32 @@ __global__ __launch_bounds__(256) void k_scan(ScanParams P) {
                 const int nn = compact_pool<MAXCH>(pool_ord + jq * C, pool_id + jq * C, n, k, lane);
                 if (j == jq) cnt = nn;
             }
-            const int64_t slot0 = ((int64_t)item * QK_WAVES + wave) * 16;
-            if (lane < 16) {
-                P.cand_cnt[slot0 + lane] = cnt;
-                if (P.gtau && myq >= 0 && cnt >= k) atomicMin(&P.gtau[myq], my_ord[k - 1]);
-            }
-            for (int jq = 0; jq < 16; jq++) {
-                const int n = __builtin_amdgcn_readlane(cnt, jq);
-                for (int e = lane; e < n; e += 64) {
-                    P.cand_ord[(slot0 + jq) * k + e] = pool_ord[jq * C + e];
-                    P.cand_id[(slot0 + jq) * k + e] = pool_id[jq * C + e];
+            const uint64_t have = __ballot(cnt > 0) & 0xFFFFull;
+            if (have) {
+                const int nrec = __popcll(have);
+                int base_rec = 0;
+                if (lane == 0) base_rec = atomicAdd(P.rec_counter, nrec);
+                base_rec = __builtin_amdgcn_readfirstlane(base_rec);
+                int myrec = -1;
+                if (lane < 16 && cnt > 0) {
+                    myrec = base_rec + __popcll(have & ((1ull << lane) - 1ull));
+                    if (myrec < P.max_recs) {
+                        P.rec_cnt[myrec] = cnt;
+                        P.rec_next[myrec] = atomicExch(&P.pair_head[mypair], myrec);
+                        if (P.gtau && cnt >= k) atomicMin(&P.gtau[myq], my_ord[k - 1]);
+                    }
+                }
+                uint64_t todo = have;
+                while (todo) {
+                    const int jq = __ffsll((unsigned long long)todo) - 1;
+                    todo &= todo - 1;
+                    const int n = __builtin_amdgcn_readlane(cnt, jq);
+                    const int rec = __builtin_amdgcn_readlane(myrec, jq);
+                    if (rec < P.max_recs)
+                        for (int e = lane; e < n; e += 64) {
+                            P.rec_ord[(int64_t)rec * k + e] = pool_ord[jq * C + e];
+                            P.rec_id[(int64_t)rec * k + e] = pool_id[jq * C + e];
+                        }
                 }
             }
         }
@@ -408,22 +439,19 @@ __global__ __launch_bounds__(256) void k_scan(ScanParams P) {
 
 // ---- merge kernel: one wave per query ---------------------------------------------------------------------
 struct MergeParams {
-    const int64_t *pids;  // [Q*P] or nullptr
     int P;
-    int npids;
-    const int32_t *pt_size;
-    const int32_t *pair_pos;
-    const int32_t *g_ioff;
-    int chunk_rows;
+    const int32_t *pair_head;
+    const int32_t *rec_next;
+    const int32_t *rec_cnt;
+    const uint32_t *rec_ord;
+    const int64_t *rec_id;
+    int32_t max_recs;
     int k;
     int Cm;  // pool capacity, k <= Cm - 64
     int metric;
-    const uint32_t *cand_ord;
-    const int64_t *cand_id;
-    const int32_t *cand_cnt;
     int64_t *out_ids;   // [Q][k]
     float *out_dist;    // [Q][k] or nullptr
-    int sqrt_l2;        // 1: output sqrt(d2) (search results); 0: squared (k-means internals)
+    int sqrt_l2;        // 1: output sqrt(d2) (search results); 0: squared (merge key of the sharded path)
 };
 
 template <int MAXCH>
@@ -437,26 +465,20 @@ __global__ __launch_bounds__(64) void k_merge(MergeParams M) {
     uint32_t tau = 0xFFFFFFFFu;
     int cnt = 0;
     for (int r = 0; r < M.P; r++) {
-        const int64_t pi = q * M.P + r;
-        const int pos = M.pair_pos[pi];
-        if (pos < 0) continue;
-        const int p = M.pids ? (int)M.pids[pi] : r;
-        const int nchunk = (M.pt_size[p] + M.chunk_rows - 1) / M.chunk_rows;
-        const int64_t item0 = (int64_t)M.g_ioff[p] + (int64_t)(pos >> 4) * nchunk;
-        for (int64_t lst = 0; lst < (int64_t)nchunk * QK_WAVES; lst++) {
-            const int64_t slot = (item0 * QK_WAVES + lst) * 16 + (pos & 15);
-            const int n = M.cand_cnt[slot];
+        int rec = M.pair_head[q * M.P + r];
+        while (rec >= 0 && rec < M.max_recs) {
+            const int n = M.rec_cnt[rec];
             for (int base = 0; base < n; base += 64) {
                 const int e = base + lane;
                 const bool has = e < n;
-                const uint32_t o = has ? M.cand_ord[slot * k + e] : 0xFFFFFFFFu;
+                const uint32_t o = has ? M.rec_ord[(int64_t)rec * k + e] : 0xFFFFFFFFu;
                 const bool pass = has && o <= tau;
                 const uint64_t m = __ballot(pass);
                 if (m) {
                     if (pass) {
                         const int sl = cnt + __popcll(m & ((1ull << lane) - 1ull));
                         pool_ord[sl] = o;
-                        pool_id[sl] = M.cand_id[slot * k + e];
+                        pool_id[sl] = M.rec_id[(int64_t)rec * k + e];
                     }
                     cnt += __popcll(m);
                     if (cnt > Cm - 64) {
@@ -464,9 +486,10 @@ __global__ __launch_bounds__(64) void k_merge(MergeParams M) {
                         if (cnt >= k) tau = min(tau, pool_ord[k - 1]);
                     }
                 }
-                // lists are sorted ascending: once a valid lane fails the bound, the rest of the list fails too
+                // records are sorted ascending: once a valid lane fails the bound, the rest of the record fails too
                 if (__popcll(m) < min(64, n - base)) break;
             }
+            rec = M.rec_next[rec];
         }
     }
     cnt = compact_pool<MAXCH>(pool_ord, pool_id, cnt, k, lane);
@@ -548,8 +571,6 @@ __global__ __launch_bounds__(64) void k_merge_ranks(const int64_t *__restrict__ 
     }
 }
 
-static int pick_maxch(int cap);
-
 int qk_merge_topk_device(qk_ctx *ctx, const int64_t *in_ids, const float *in_key, int G, int64_t Q, int k, int metric,
                          int64_t *out_ids, float *out_dist, bool sqrt_l2) {
     if (Q <= 0) return QK_OK;
@@ -569,29 +590,31 @@ int qk_merge_topk_device(qk_ctx *ctx, const int64_t *in_ids, const float *in_key
 }
 
 // ---- host orchestration -------------------------------------------------------------------------------------
-template <int DB>
-static void launch_scan_db(int maxch, dim3 grid, size_t lds, hipStream_t st, const ScanParams &sp) {
-    switch (maxch) {
-        case 1: hipLaunchKernelGGL((k_scan<DB, 1>), grid, dim3(256), lds, st, sp); break;
-        case 2: hipLaunchKernelGGL((k_scan<DB, 2>), grid, dim3(256), lds, st, sp); break;
-        case 4: hipLaunchKernelGGL((k_scan<DB, 4>), grid, dim3(256), lds, st, sp); break;
-        default: hipLaunchKernelGGL((k_scan<DB, 8>), grid, dim3(256), lds, st, sp); break;
-    }
-}
-
 template <int DB, int MAXCH>
-static int set_scan_lds(size_t lds) {
+static int launch_scan_t(dim3 grid, size_t lds, hipStream_t st, const ScanParams &sp) {
     QK_HIP(hipFuncSetAttribute((const void *)k_scan<DB, MAXCH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_scan<DB, MAXCH>), grid, dim3(64), lds, st, sp);
     return QK_OK;
 }
 
-static int set_scan_lds_attr(int db, int maxch, size_t lds) {
+static int launch_scan(int db, int maxch, dim3 grid, size_t lds, hipStream_t st, const ScanParams &sp) {
+    static const int probe_mode = getenv("QK_SCAN_MODE") ? atoi(getenv("QK_SCAN_MODE")) : 0;
+    if (probe_mode == 1 && db == 8 && maxch == 1) {
+        QK_HIP(hipFuncSetAttribute((const void *)k_scan<8, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((k_scan<8, 1, 1>), grid, dim3(64), lds, st, sp);
+        return QK_OK;
+    }
+    if (probe_mode == 2 && db == 8 && maxch == 1) {
+        QK_HIP(hipFuncSetAttribute((const void *)k_scan<8, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((k_scan<8, 1, 2>), grid, dim3(64), lds, st, sp);
+        return QK_OK;
+    }
 #define QK_CASE(D, M) \
-    if (db == D && maxch == M) return set_scan_lds<D, M>(lds);
+    if (db == D && maxch == M) return launch_scan_t<D, M>(grid, lds, st, sp);
     QK_CASE(1, 1) QK_CASE(1, 2) QK_CASE(1, 4) QK_CASE(1, 8) QK_CASE(2, 1) QK_CASE(2, 2) QK_CASE(2, 4) QK_CASE(2, 8)
     QK_CASE(4, 1) QK_CASE(4, 2) QK_CASE(4, 4) QK_CASE(4, 8) QK_CASE(8, 1) QK_CASE(8, 2) QK_CASE(8, 4) QK_CASE(8, 8)
 #undef QK_CASE
-    return QK_OK;
+    QK_FAIL(QK_ERR_UNSUPPORTED, "no scan kernel for DB=%d MAXCH=%d", db, maxch);
 }
 
 static int pick_maxch(int cap) { return cap <= 64 ? 1 : cap <= 128 ? 2 : cap <= 256 ? 4 : 8; }
@@ -604,95 +627,93 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
     if (k > QK_MAX_K) QK_FAIL(QK_ERR_UNSUPPORTED, "qk_scan: k=%d exceeds QK_MAX_K=%d", k, QK_MAX_K);
     QK_TRY(qk_store_sync_table(s));
     const int npids = (int)s->parts.size();
+    // dense form: every query against ONE list (the parent / flat index of query_coordinator.cpp:624-626,644)
+    if (a.all_lists && s->nlist == 1 && Q >= 32) {
+        for (int64_t p = 0; p < npids; p++)
+            if (s->parts[p].present) return qk_dense_device(ctx, s, p, a, timing, ev_base);
+    }
     const int P = a.all_lists ? npids : a.P;
     hipStream_t st = ctx->stream;
     const bool tm = ctx->timing && (timing || a.record_events);
-    // deferred timing: events are parked in the context and read by qk_ctx_read_timing (no sync here)
-    hipEvent_t dev[4] = {nullptr, nullptr, nullptr, nullptr};
-    const bool dtm = ctx->timing_mode == 2;
-    if (dtm) {
-        for (int i = 0; i < 4; i++) {
-            if (!ctx->ev_free.empty()) {
-                dev[i] = ctx->ev_free.back();
-                ctx->ev_free.pop_back();
-            } else {
-                QK_HIP(hipEventCreate(&dev[i]));
-            }
-        }
-    }
-
-    // nothing to scan: pure padding (query_coordinator.cpp:459-497 zero-partitions case)
-    const int64_t npairs = Q * (int64_t)P;
+    qk_phase_events pe;
+    QK_TRY(pe.begin(ctx, tm, ev_base));
+    const int64_t npairs = Q * (int64_t)P;  // may be 0: pure padding (query_coordinator.cpp:459-497)
+    if (npairs > 0x7FFFFFF0LL) QK_FAIL(QK_ERR_UNSUPPORTED, "qk_scan: Q*P too large");
 
     // ---- geometry ----------------------------------------------------------------------------------
     const int nblk = s->nblk;
     const int DB = (nblk % 8 == 0) ? 8 : (nblk % 4 == 0) ? 4 : (nblk % 2 == 0) ? 2 : 1;
-    // pool capacity per (wave, query): k + slack, limited by LDS (160 KiB per workgroup)
+    // pool capacity per query: k + slack, limited by LDS (one wave per workgroup, 160 KiB max)
     const size_t lds_budget = 160 * 1024 - 64;
     const size_t q_bytes = (size_t)nblk * 1024;
-    int C = k + std::max(28, std::min(k, 64));
-    C = qk_round_up(C, 4);
-    while ((size_t)QK_WAVES * 16 * C * 12 + q_bytes + 16 > lds_budget && C > k + 4) C -= 4;
-    if ((size_t)QK_WAVES * 16 * C * 12 + q_bytes + 16 > lds_budget || C < k + 4)
+    int C = qk_round_up(k + std::max(28, std::min(k, 64)), 4);
+    while ((size_t)16 * C * 12 + q_bytes > lds_budget && C > k + 4) C -= 4;
+    if ((size_t)16 * C * 12 + q_bytes > lds_budget || C < k + 4 || C > 512)
         QK_FAIL(QK_ERR_UNSUPPORTED, "qk_scan: k=%d with d=%d does not fit the LDS top-k pools", k, s->d);
-    if (C > 512) QK_FAIL(QK_ERR_UNSUPPORTED, "qk_scan: pool capacity %d > 512", C);
     const int maxch = pick_maxch(C);
-    const size_t lds_scan = q_bytes + (size_t)QK_WAVES * 16 * C * 12 + 16;
+    const size_t lds_scan = q_bytes + (size_t)16 * C * 12;
     const int Cm = qk_round_up(k + 64, 64);
     const int maxch_m = Cm <= 128 ? 2 : Cm <= 256 ? 4 : Cm <= 512 ? 8 : 16;
     const size_t lds_merge = (size_t)Cm * 12;
 
     const int num_cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
-    int64_t npresent = std::max<int64_t>(1, s->nlist);
-    int64_t max_size = std::max<int64_t>(1, s->max_size);
-    int64_t tiles_est = std::max<int64_t>(1, std::min<int64_t>(npairs, npresent + npairs / 16));
-    int64_t desired_items = (int64_t)8 * num_cus;
-    int64_t nchunk_target = std::max<int64_t>(1, (desired_items + tiles_est - 1) / tiles_est);
-    int64_t chunk_rows = std::max<int64_t>(256, qk_round_up64((max_size + nchunk_target - 1) / nchunk_target, 64));
-    int64_t max_nchunk = (max_size + chunk_rows - 1) / chunk_rows;
-    int64_t tiles_bound = std::max<int64_t>(1, npairs / 16 + std::min<int64_t>(npresent, npairs));
-    int64_t items_bound = tiles_bound * max_nchunk;
-    int64_t slots_bound = items_bound * QK_WAVES * 16;
+    // persistent grid: as many single-wave workgroups as stay resident (LDS-limited; registers allow ~12 per CU)
+    // static tile partition => every wave must be resident at once; 8 per CU measured best (scan_probe.py), LDS may cap it
+    int waves_per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / (lds_scan + 512)));
+    if (getenv("QK_SCAN_WAVES_PER_CU")) waves_per_cu = std::max(1, atoi(getenv("QK_SCAN_WAVES_PER_CU")));
+    const int64_t n_waves = (int64_t)num_cus * waves_per_cu;
+    // records: every wave-segment emits at most 16; segments <= items + waves
+    const int64_t npresent = std::max<int64_t>(1, s->nlist);
+    const int64_t items_bound = std::max<int64_t>(1, npairs / 16 + std::min<int64_t>(npresent, npairs));
+    const int64_t max_recs = std::min<int64_t>(0x7FFFFFF0LL, std::min<int64_t>(16 * (items_bound + n_waves), npairs + 16 * n_waves));
 
     // ---- workspace ---------------------------------------------------------------------------------
+    const int64_t np1 = std::max<int64_t>(npairs, 1);
     size_t need = 0;
     auto add = [&](size_t b) { need += (b + 255) & ~(size_t)255; };
-    add((size_t)Q * s->dpad * 4);            // xq4
-    add((size_t)Q * 4);                      // xn
-    add((size_t)npids * 4 * 2);              // g_cnt, g_cursor
-    add((size_t)(npids + 1) * 4 * 2 + 512);  // g_qoff, g_ioff
-    add(256);                                // n_items, item_counter, n_rows_unique
-    add((size_t)std::max<int64_t>(npairs, 1) * 4 * 2);  // grouped_q, pair_pos
-    add((size_t)Q * 4);                      // gtau
-    add((size_t)slots_bound * k * 12 + (size_t)slots_bound * 4);
-    need += 4096;
+    add((size_t)Q * s->dpad * 4);
+    add((size_t)Q * 4);
+    add((size_t)npids * 4 * 3 + 64);
+    add((size_t)(npids + 1) * 4 + 64);
+    add((size_t)(npids + 1) * 8 + 64);
+    add(256);
+    add((size_t)np1 * 4 * 3);
+    add((size_t)Q * 4);
+    add((size_t)max_recs * 8);
+    add((size_t)max_recs * k * 4);
+    add((size_t)max_recs * k * 8);
+    need += 8192;
     QK_TRY(qk_ws_reserve(ctx, need));
     float4 *xq4 = (float4 *)qk_ws_alloc(ctx, (size_t)Q * s->dpad * 4);
     float *xn = (float *)qk_ws_alloc(ctx, (size_t)Q * 4);
-    int32_t *g_cnt = (int32_t *)qk_ws_alloc(ctx, (size_t)npids * 4 * 2);
+    int32_t *g_cnt = (int32_t *)qk_ws_alloc(ctx, (size_t)npids * 4 * 3 + 64);
     int32_t *g_cursor = g_cnt + npids;
-    int32_t *g_qoff = (int32_t *)qk_ws_alloc(ctx, (size_t)(npids + 1) * 4 * 2 + 512);
-    int32_t *g_ioff = g_qoff + npids + 1;
+    int32_t *active_p = g_cursor + npids;
+    int32_t *g_qoff = (int32_t *)qk_ws_alloc(ctx, (size_t)(npids + 1) * 4 + 64);
+    int64_t *active_toff = (int64_t *)qk_ws_alloc(ctx, (size_t)(npids + 1) * 8 + 64);
     int32_t *scal = (int32_t *)qk_ws_alloc(ctx, 256);
-    int32_t *n_items = scal, *item_counter = scal + 1;
+    // scal layout (int32 units): [0] n_active, [1] rec_counter, [2..3] n_rows_unique (i64), [4..5] n_tiles (i64)
+    int32_t *n_active = scal, *rec_counter = scal + 1;
     int64_t *n_rows_unique = (int64_t *)(scal + 2);
-    int32_t *grouped_q = (int32_t *)qk_ws_alloc(ctx, (size_t)std::max<int64_t>(npairs, 1) * 4 * 2);
-    int32_t *pair_pos = grouped_q + std::max<int64_t>(npairs, 1);
+    int64_t *n_tiles = (int64_t *)(scal + 4);
+    int32_t *grouped_q = (int32_t *)qk_ws_alloc(ctx, (size_t)np1 * 4 * 3);
+    int32_t *grouped_pair = grouped_q + np1;
+    int32_t *pair_head = grouped_pair + np1;
     uint32_t *gtau = (uint32_t *)qk_ws_alloc(ctx, (size_t)Q * 4);
-    uint32_t *cand_ord = (uint32_t *)qk_ws_alloc(ctx, (size_t)slots_bound * k * 4);
-    int64_t *cand_id = (int64_t *)qk_ws_alloc(ctx, (size_t)slots_bound * k * 8);
-    int32_t *cand_cnt = (int32_t *)qk_ws_alloc(ctx, (size_t)slots_bound * 4);
-    if (!xq4 || !xn || !g_cnt || !g_qoff || !scal || !grouped_q || !gtau || !cand_ord || !cand_id || !cand_cnt)
+    int32_t *rec_next = (int32_t *)qk_ws_alloc(ctx, (size_t)max_recs * 8);
+    int32_t *rec_cnt = rec_next + max_recs;
+    uint32_t *rec_ord = (uint32_t *)qk_ws_alloc(ctx, (size_t)max_recs * k * 4);
+    int64_t *rec_id = (int64_t *)qk_ws_alloc(ctx, (size_t)max_recs * k * 8);
+    if (!xq4 || !xn || !g_cnt || !g_qoff || !active_toff || !scal || !grouped_q || !gtau || !rec_next || !rec_ord || !rec_id)
         QK_FAIL(QK_ERR_OOM, "qk_scan: workspace exhausted");
 
-    if (tm) QK_HIP(hipEventRecord(ctx->ev[ev_base + 0], st));
-    if (dtm) QK_HIP(hipEventRecord(dev[0], st));
+    QK_TRY(pe.mark(0));
     // ---- prep + grouping -------------------------------------------------------------------------------
     {
         int64_t total = std::max<int64_t>(Q * nblk * 4, Q);
         hipLaunchKernelGGL(k_prep_queries, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a.x, Q, s->d, nblk, xq4, xn);
     }
-    QK_HIP(hipMemsetAsync(g_cnt, 0, (size_t)npids * 4 * 2, st));
+    if (npids > 0) QK_HIP(hipMemsetAsync(g_cnt, 0, (size_t)npids * 4 * 2, st));
     QK_HIP(hipMemsetAsync(scal, 0, 256, st));
     QK_HIP(hipMemsetAsync(gtau, 0xFF, (size_t)Q * 4, st));
     GroupParams G;
@@ -701,77 +722,71 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
     G.P = std::max(P, 1);
     G.pt_size = s->d_size;
     G.npids = npids;
-    G.chunk_rows = (int)chunk_rows;
     G.g_cnt = g_cnt;
     G.g_cursor = g_cursor;
     G.g_qoff = g_qoff;
-    G.g_ioff = g_ioff;
-    G.n_items = n_items;
-    G.grouped_q = grouped_q;
-    G.pair_pos = pair_pos;
+    G.n_active = n_active;
+    G.active_p = active_p;
+    G.active_toff = active_toff;
+    G.n_tiles = n_tiles;
     G.n_rows_unique = n_rows_unique;
+    G.grouped_q = grouped_q;
+    G.grouped_pair = grouped_pair;
+    G.pair_head = pair_head;
     if (npairs > 0) hipLaunchKernelGGL(k_group_count, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, st, G);
     hipLaunchKernelGGL(k_group_scan, dim3(1), dim3(1024), 0, st, G);
     if (npairs > 0) hipLaunchKernelGGL(k_group_scatter, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, st, G);
-    if (tm) QK_HIP(hipEventRecord(ctx->ev[ev_base + 1], st));
-    if (dtm) QK_HIP(hipEventRecord(dev[1], st));
+    QK_TRY(pe.mark(1));
 
     // ---- scan ------------------------------------------------------------------------------------------------
-    ScanParams sp;
-    sp.vecs = (const float4 *)s->vecs;
-    sp.norms = s->norms;
-    sp.ids = s->ids;
-    sp.pt_off = s->d_off;
-    sp.pt_size = s->d_size;
-    sp.npids = npids;
-    sp.nblk = nblk;
-    sp.xq4 = xq4;
-    sp.xn = xn;
-    sp.grouped_q = grouped_q;
-    sp.g_cnt = g_cnt;
-    sp.g_qoff = g_qoff;
-    sp.g_ioff = g_ioff;
-    sp.n_items = n_items;
-    sp.item_counter = item_counter;
-    sp.gtau = a.share_tau ? gtau : nullptr;
-    sp.chunk_rows = (int)chunk_rows;
-    sp.k = k;
-    sp.C = C;
-    sp.metric = a.metric;
-    sp.cand_ord = cand_ord;
-    sp.cand_id = cand_id;
-    sp.cand_cnt = cand_cnt;
     if (npairs > 0 && npids > 0) {
-        QK_TRY(set_scan_lds_attr(DB, maxch, lds_scan));
-        int wg_per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds_scan));
-        int64_t grid = std::min<int64_t>(items_bound, (int64_t)num_cus * wg_per_cu);
-        grid = std::max<int64_t>(grid, 1);
-        dim3 gd((unsigned)grid);
-        switch (DB) {
-            case 8: launch_scan_db<8>(maxch, gd, lds_scan, st, sp); break;
-            case 4: launch_scan_db<4>(maxch, gd, lds_scan, st, sp); break;
-            case 2: launch_scan_db<2>(maxch, gd, lds_scan, st, sp); break;
-            default: launch_scan_db<1>(maxch, gd, lds_scan, st, sp); break;
-        }
+        ScanParams sp;
+        sp.vecs = (const float4 *)s->vecs;
+        sp.norms = s->norms;
+        sp.ids = s->ids;
+        sp.pt_off = s->d_off;
+        sp.pt_size = s->d_size;
+        sp.nblk = nblk;
+        sp.xq4 = xq4;
+        sp.xn = xn;
+        sp.grouped_q = grouped_q;
+        sp.grouped_pair = grouped_pair;
+        sp.g_cnt = g_cnt;
+        sp.g_qoff = g_qoff;
+        sp.n_active = n_active;
+        sp.active_p = active_p;
+        sp.active_toff = active_toff;
+        sp.n_tiles = n_tiles;
+        sp.gtau = a.share_tau ? gtau : nullptr;
+        sp.k = k;
+        sp.C = C;
+        sp.metric = a.metric;
+        sp.pair_head = pair_head;
+        sp.rec_counter = rec_counter;
+        sp.max_recs = (int32_t)max_recs;
+        sp.rec_next = rec_next;
+        sp.rec_cnt = rec_cnt;
+        sp.rec_ord = rec_ord;
+        sp.rec_id = rec_id;
+        // do not launch (many) more waves than there are tiles to hand out
+        int64_t tiles_ub = std::max<int64_t>(1, items_bound * ((std::max<int64_t>(1, s->max_size) + 15) / 16));
+        int64_t grid = std::max<int64_t>(1, std::min<int64_t>(n_waves, tiles_ub));
+        QK_TRY(launch_scan(DB, maxch, dim3((unsigned)grid), lds_scan, st, sp));
     }
-    if (tm) QK_HIP(hipEventRecord(ctx->ev[ev_base + 2], st));
-    if (dtm) QK_HIP(hipEventRecord(dev[2], st));
+    QK_TRY(pe.mark(2));
 
     // ---- merge ---------------------------------------------------------------------------------------------------
     MergeParams mp;
-    mp.pids = G.pids;
     mp.P = P;
-    mp.npids = npids;
-    mp.pt_size = s->d_size;
-    mp.pair_pos = pair_pos;
-    mp.g_ioff = g_ioff;
-    mp.chunk_rows = (int)chunk_rows;
+    mp.pair_head = pair_head;
+    mp.rec_next = rec_next;
+    mp.rec_cnt = rec_cnt;
+    mp.rec_ord = rec_ord;
+    mp.rec_id = rec_id;
+    mp.max_recs = (int32_t)max_recs;
     mp.k = k;
     mp.Cm = Cm;
     mp.metric = a.metric;
-    mp.cand_ord = cand_ord;
-    mp.cand_id = cand_id;
-    mp.cand_cnt = cand_cnt;
     mp.out_ids = a.out_ids;
     mp.out_dist = a.out_dist;
     mp.sqrt_l2 = a.sqrt_l2 ? 1 : 0;
@@ -782,22 +797,11 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
         default: hipLaunchKernelGGL((k_merge<16>), dim3((unsigned)Q), dim3(64), lds_merge, st, mp); break;
     }
     QK_HIP(hipGetLastError());
-    if (tm) QK_HIP(hipEventRecord(ctx->ev[ev_base + 3], st));
-    if (dtm) {
-        QK_HIP(hipEventRecord(dev[3], st));
-        if (ev_base == 4) {
-            for (int i = 0; i < 4; i++) ctx->ev_pending.push_back(dev[i]);
-        } else {  // coarse stage: keep (start, end)
-            ctx->ev_pending_coarse.push_back(dev[0]);
-            ctx->ev_pending_coarse.push_back(dev[3]);
-            ctx->ev_free.push_back(dev[1]);
-            ctx->ev_free.push_back(dev[2]);
-        }
-    }
+    QK_TRY(pe.mark(3));
     if (timing) {
         // device scalars come back through pinned memory; the caller synchronises before reading them
         QK_TRY(qk_pinned_reserve(ctx, 64));
-        QK_HIP(hipMemcpyAsync(ctx->pinned, scal, 16, hipMemcpyDeviceToHost, st));
+        QK_HIP(hipMemcpyAsync(ctx->pinned, scal, 32, hipMemcpyDeviceToHost, st));
     }
     return QK_OK;
 }
