@@ -94,11 +94,16 @@ int run_search(qk_ctx *ctx, qk_store *parent, qk_store *s, const float *x, int64
             sv.pids = pids;
         }
     }
+    const float4 *xq4 = nullptr;
+    const float *xn = nullptr;
+    QK_TRY(qk_prep_queries(ctx, sv.x, Q, d, &xq4, &xn));
     // ---- coarse --------------------------------------------------------------------------------------
     if (use_parent && kk <= 0 && coarse_only) return QK_OK;
     if (use_parent && kk > 0) {
         qk_scan_args ca;
         ca.x = sv.x;
+        ca.xq4 = xq4;
+        ca.xn = xn;
         ca.Q = Q;
         ca.all_lists = true;
         ca.k = kk;
@@ -112,6 +117,8 @@ int run_search(qk_ctx *ctx, qk_store *parent, qk_store *s, const float *x, int64
     if (!coarse_only) {
         qk_scan_args sa;
         sa.x = sv.x;
+        sa.xq4 = xq4;
+        sa.xn = xn;
         sa.Q = Q;
         sa.k = k;
         sa.metric = metric;

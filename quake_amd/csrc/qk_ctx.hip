@@ -41,6 +41,7 @@ int qk_ctx_destroy(qk_ctx *c) {
     hipStreamSynchronize(c->stream);
     if (c->ws) hipFree(c->ws);
     if (c->stage) hipFree(c->stage);
+    if (c->qprep) hipFree(c->qprep);
     if (c->pinned) hipHostFree(c->pinned);
     for (auto &e : c->ev)
         if (e) hipEventDestroy(e);

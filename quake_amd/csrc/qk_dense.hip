@@ -19,7 +19,8 @@ struct DenseParams {
     int64_t row_off;     // first arena row of the list (multiple of 16)
     int nrows;
     int nblk;
-    const float *x;      // [Q][d] row-major
+    const float4 *xq4;   // [Q][nblk][4] fragment-ordered queries
+    const float *xn;     // [Q]
     int64_t Q;
     int d;
     int metric;
@@ -33,7 +34,7 @@ __global__ __launch_bounds__(256) void k_dense_ord(DenseParams P) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, g = lane >> 4;
-    const int nblk = P.nblk, d = P.d;
+    const int nblk = P.nblk;
     const bool l2 = P.metric == QK_METRIC_L2;
     float4 *qs = (float4 *)smem;                               // [NQ][nblk*64]
     float *xn_s = (float *)(smem + (size_t)NQ * nblk * 1024);  // [NQ*16]
@@ -43,24 +44,12 @@ __global__ __launch_bounds__(256) void k_dense_ord(DenseParams P) {
         const int nq = t / nblk, cb = t - nq * nblk;
         const int64_t row = q_base + nq * 16 + j;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (row < P.Q) {
-            const float *s = P.x + row * d;
-            const int col = 16 * cb + g;
-            v.x = col < d ? s[col] : 0.0f;
-            v.y = col + 4 < d ? s[col + 4] : 0.0f;
-            v.z = col + 8 < d ? s[col + 8] : 0.0f;
-            v.w = col + 12 < d ? s[col + 12] : 0.0f;
-        }
+        if (row < P.Q) v = P.xq4[(row * nblk + cb) * 4 + g];
         qs[(size_t)nq * nblk * 64 + cb * 64 + lane] = v;
     }
     if (tid < NQ * 16) {
         const int64_t row = q_base + tid;
-        float acc = 0.0f;
-        if (row < P.Q && l2) {
-            const float *s = P.x + row * d;
-            for (int k = 0; k < d; k++) acc = __fmaf_rn(s[k], s[k], acc);
-        }
-        xn_s[tid] = acc;
+        xn_s[tid] = (row < P.Q && l2) ? P.xn[row] : 0.0f;
     }
     __syncthreads();
     float xnj[NQ];
@@ -168,27 +157,39 @@ __global__ __launch_bounds__(64) void k_select_rows(SelectParams S) {
     const uint32_t *row = S.D + q * S.ld;
     uint32_t tau = 0xFFFFFFFFu;
     int cnt = 0;
-    // 4 keys per lane per step (16-byte loads): 256 rows per wave step
-    for (int base = 0; base < S.nrows; base += 256) {
-        const int r0 = base + lane * 4;
-        uint4 kv = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
-        if (r0 < S.nrows) kv = *(const uint4 *)(row + r0);  // ld is a multiple of 16 and the tail is 0xFFFFFFFF
-        const uint32_t kk[4] = {kv.x, kv.y, kv.z, kv.w};
+    // 4 keys per lane per load (16 B), 4 loads in flight: 1024 rows per wave step
+    for (int base = 0; base < S.nrows; base += 1024) {
+        uint4 kv4[4];
 #pragma unroll
-        for (int t = 0; t < 4; t++) {
-            const int r = r0 + t;
-            const bool pass = r < S.nrows && kk[t] <= tau && kk[t] != 0xFFFFFFFFu;
-            const uint64_t m = __ballot(pass);
-            if (m) {
-                if (pass) {
-                    const int sl = cnt + __popcll(m & ((1ull << lane) - 1ull));
-                    pool_ord[sl] = kk[t];
-                    pool_id[sl] = S.ids[r];
-                }
-                cnt += __popcll(m);
-                if (cnt > Cm - 64) {
-                    cnt = compact_pool<MAXCH>(pool_ord, pool_id, cnt, k, lane);
-                    if (cnt >= k) tau = min(tau, pool_ord[k - 1]);
+        for (int u = 0; u < 4; u++) {
+            const int r0 = base + u * 256 + lane * 4;
+            kv4[u] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+            if (r0 < S.nrows) kv4[u] = *(const uint4 *)(row + r0);  // ld is a multiple of 16, tail keys are 0xFFFFFFFF
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int r0 = base + u * 256 + lane * 4;
+            const uint32_t kk[4] = {kv4[u].x, kv4[u].y, kv4[u].z, kv4[u].w};
+            // one ballot for the 4 keys of the step; the per-key work only runs when something passes
+            const bool any = r0 < S.nrows && (min(min(kk[0], kk[1]), min(kk[2], kk[3])) <= tau) &&
+                             (min(min(kk[0], kk[1]), min(kk[2], kk[3])) != 0xFFFFFFFFu);
+            if (!__ballot(any)) continue;
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const int r = r0 + t;
+                const bool pass = r < S.nrows && kk[t] <= tau && kk[t] != 0xFFFFFFFFu;
+                const uint64_t m = __ballot(pass);
+                if (m) {
+                    if (pass) {
+                        const int sl = cnt + __popcll(m & ((1ull << lane) - 1ull));
+                        pool_ord[sl] = kk[t];
+                        pool_id[sl] = S.ids[r];
+                    }
+                    cnt += __popcll(m);
+                    if (cnt > Cm - 64) {
+                        cnt = compact_pool<MAXCH>(pool_ord, pool_id, cnt, k, lane);
+                        if (cnt >= k) tau = min(tau, pool_ord[k - 1]);
+                    }
                 }
             }
         }
@@ -255,7 +256,8 @@ int qk_dense_device(qk_ctx *ctx, qk_store *s, int64_t list_no, const qk_scan_arg
         dp.row_off = pt.row_off;
         dp.nrows = nrows;
         dp.nblk = nblk;
-        dp.x = a.x + q0 * s->d;
+        dp.xq4 = a.xq4 + q0 * nblk * 4;
+        dp.xn = a.xn + q0;
         dp.Q = nq;
         dp.d = s->d;
         dp.metric = a.metric;
@@ -264,8 +266,9 @@ int qk_dense_device(qk_ctx *ctx, qk_store *s, int64_t list_no, const qk_scan_arg
         const int64_t qgroups = (nq + NQ * 16 - 1) / (NQ * 16);
         const int ntile = (nrows + 15) / 16;
         // enough workgroups to fill the chip, at least 4 tiles (one per wave) each
-        int64_t want_chunks = std::max<int64_t>(1, ((int64_t)4 * num_cus + qgroups - 1) / qgroups);
-        int tiles_per_wg = (int)std::max<int64_t>(4, (ntile + want_chunks - 1) / want_chunks);
+        // staging the query tile costs as much as ~8 row tiles per wave: aim at one workgroup per CU, >= 16 tiles each
+        int64_t want_chunks = std::max<int64_t>(1, ((int64_t)num_cus + qgroups - 1) / qgroups);
+        int tiles_per_wg = (int)std::max<int64_t>(16, (ntile + want_chunks - 1) / want_chunks);
         tiles_per_wg = qk_round_up(tiles_per_wg, 4);
         dp.tiles_per_wg = tiles_per_wg;
         const int rchunks = std::max(1, (ntile + tiles_per_wg - 1) / tiles_per_wg);

@@ -63,6 +63,9 @@ struct qk_ctx {
     // device staging for ingest of host data
     char *stage = nullptr;
     size_t stage_cap = 0;
+    // fragment-ordered copy of the current query batch + norms (shared by the coarse and the scan stage)
+    char *qprep = nullptr;
+    size_t qprep_cap = 0;
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     // deferred timing (qk_ctx_set_timing(ctx, 2)): per-call event quads, read back by qk_ctx_read_timing
     int timing_mode = 0;  // 0 off, 1 per call (sync), 2 deferred
@@ -135,7 +138,11 @@ struct qk_scan_args {
     bool share_tau = true;
     bool sqrt_l2 = true;
     bool record_events = false;  // record the per-call phase events even when no qk_timing is passed
+    const float4 *xq4 = nullptr;  // [Q][nblk][4] fragment-ordered queries (qk_prep_queries), required
+    const float *xn = nullptr;    // [Q] squared norms, required
 };
+// x[Q][d] -> ctx->qprep (xq4 then xn); returns the two device pointers
+int qk_prep_queries(qk_ctx *ctx, const float *x, int64_t Q, int d, const float4 **xq4, const float **xn);
 int qk_merge_topk_device(qk_ctx *ctx, const int64_t *in_ids, const float *in_key, int G, int64_t Q, int k, int metric,
                          int64_t *out_ids, float *out_dist, bool sqrt_l2);
 int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *timing, int ev_base);

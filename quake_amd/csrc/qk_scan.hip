@@ -34,29 +34,59 @@
 
 // ---- query preparation -----------------------------------------------------------------------------
 // xq4[(q*nblk + c)*4 + g] = {x[q][16c+g], x[q][16c+g+4], x[q][16c+g+8], x[q][16c+g+12]}  (B-operand order)
-__global__ void k_prep_queries(const float *__restrict__ x, int64_t Q, int d, int nblk, float4 *__restrict__ xq4,
-                               float *__restrict__ xn) {
-    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    int64_t per_q = (int64_t)nblk * 4;
-    if (idx < Q * per_q) {
-        int64_t q = idx / per_q;
-        int rem = (int)(idx - q * per_q);
+// xn[q] = canonical squared norm (k-ordered fmaf chain).  One workgroup = 16 queries staged through LDS so that the
+// global reads are coalesced and the 16 serial norm chains run out of LDS.
+__global__ __launch_bounds__(256) void k_prep_queries(const float *__restrict__ x, int64_t Q, int d, int nblk,
+                                                      float4 *__restrict__ xq4, float *__restrict__ xn) {
+    extern __shared__ float sq[];  // [16][d+1]
+    const int ldq = d + 1;
+    const int64_t q0 = (int64_t)blockIdx.x * 16;
+    const int nq = (int)min((int64_t)16, Q - q0);
+    for (int i = threadIdx.x; i < nq * d; i += 256) {
+        int r = i / d, c = i - r * d;
+        sq[r * ldq + c] = x[(q0 + r) * d + c];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nq * nblk * 4; i += 256) {
+        int r = i / (nblk * 4), rem = i - r * nblk * 4;
         int c = rem >> 2, g = rem & 3;
-        const float *s = x + q * d;
         int col = 16 * c + g;
+        const float *s = sq + r * ldq;
         float4 v;
         v.x = col < d ? s[col] : 0.0f;
         v.y = col + 4 < d ? s[col + 4] : 0.0f;
         v.z = col + 8 < d ? s[col + 8] : 0.0f;
         v.w = col + 12 < d ? s[col + 12] : 0.0f;
-        xq4[idx] = v;
+        xq4[(q0 + r) * nblk * 4 + rem] = v;
     }
-    if (idx < Q) {
-        const float *s = x + idx * d;
+    if (threadIdx.x < nq) {
+        const float *s = sq + threadIdx.x * ldq;
         float acc = 0.0f;
         for (int k = 0; k < d; k++) acc = __fmaf_rn(s[k], s[k], acc);
-        xn[idx] = acc;
+        xn[q0 + threadIdx.x] = acc;
     }
+}
+
+int qk_prep_queries(qk_ctx *ctx, const float *x, int64_t Q, int d, const float4 **xq4, const float **xn) {
+    const int dpad = qk_round_up(d, 16), nblk = dpad / 16;
+    size_t need = (((size_t)Q * dpad * 4 + 255) & ~(size_t)255) + (size_t)Q * 4 + 256;
+    if (need > ctx->qprep_cap) {
+        QK_HIP(hipStreamSynchronize(ctx->stream));
+        if (ctx->qprep) QK_HIP(hipFree(ctx->qprep));
+        ctx->qprep = nullptr;
+        ctx->qprep_cap = 0;
+        if (hipMalloc((void **)&ctx->qprep, need + need / 4) != hipSuccess) QK_FAIL(QK_ERR_OOM, "query prep buffer allocation failed");
+        ctx->qprep_cap = need + need / 4;
+    }
+    float4 *q4 = (float4 *)ctx->qprep;
+    float *n = (float *)(ctx->qprep + (((size_t)Q * dpad * 4 + 255) & ~(size_t)255));
+    const size_t lds = (size_t)16 * (d + 1) * 4;
+    if (lds > 64 * 1024) QK_FAIL(QK_ERR_UNSUPPORTED, "d=%d too large for the query prep kernel", d);
+    hipLaunchKernelGGL(k_prep_queries, dim3((unsigned)((Q + 15) / 16)), dim3(256), lds, ctx->stream, x, Q, d, nblk, q4, n);
+    QK_HIP(hipGetLastError());
+    *xq4 = q4;
+    *xn = n;
+    return QK_OK;
 }
 
 // ---- grouping ---------------------------------------------------------------------------------------
@@ -77,6 +107,7 @@ struct GroupParams {
     int32_t *grouped_q;   // [npairs] query of each grouped entry
     int32_t *grouped_pair;// [npairs] pair index (q*P + r) of each grouped entry
     int32_t *pair_head;   // [npairs] head of the record chain of each pair (-1 = none)
+    uint32_t *gtau;       // [Q] per-query shared bound, reset here
 };
 
 __device__ __forceinline__ int pair_pid(const GroupParams &G, int64_t i) {
@@ -89,16 +120,39 @@ __global__ void k_group_count(GroupParams G) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= G.npairs) return;
     G.pair_head[i] = -1;
+    if (i % G.P == 0) G.gtau[i / G.P] = 0xFFFFFFFFu;
     int p = pair_pid(G, i);
     if (p >= 0) atomicAdd(&G.g_cnt[p], 1);
 }
 
-// single workgroup of 1024 threads: exclusive scans over the partitions
+// block-wide exclusive scan of one value per thread (1024 threads = 16 waves); returns the exclusive prefix, *total
+// receives the block sum.  wave-level shuffles + one LDS hop.
+template <typename T>
+__device__ __forceinline__ T block_exscan_1024(T v, T *s_wave /*[16]*/, T *total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    T inc = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        T o = __shfl_up(inc, off);
+        if (lane >= off) inc += o;
+    }
+    if (lane == 63) s_wave[wave] = inc;
+    __syncthreads();
+    T wpre = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 16; w++) {
+        T sv = s_wave[w];
+        if (w < wave) wpre += sv;
+        tot += sv;
+    }
+    __syncthreads();
+    *total = tot;
+    return wpre + inc - v;
+}
+
+// single workgroup of 1024 threads: exclusive scans over the partitions.  Also clears the per-call counters.
 __global__ __launch_bounds__(1024) void k_group_scan(GroupParams G) {
-    __shared__ int s_q[1024];
-    __shared__ int s_a[1024];
-    __shared__ long long s_t[1024];
-    __shared__ long long s_r[1024];
+    __shared__ long long s_w[16];
     const int tid = threadIdx.x;
     const int per = (G.npids + 1023) / 1024;
     const int b = tid * per, e = min(G.npids, b + per);
@@ -114,36 +168,20 @@ __global__ __launch_bounds__(1024) void k_group_scan(GroupParams G) {
             sr += sz;
         }
     }
-    s_q[tid] = sq;
-    s_a[tid] = sa;
-    s_t[tid] = stl;
-    s_r[tid] = sr;
-    __syncthreads();
+    long long tq, ta, tt, tr;
+    long long aq = block_exscan_1024<long long>(sq, s_w, &tq);
+    long long aa = block_exscan_1024<long long>(sa, s_w, &ta);
+    long long at = block_exscan_1024<long long>(stl, s_w, &tt);
+    (void)block_exscan_1024<long long>(sr, s_w, &tr);
     if (tid == 0) {
-        int aq = 0, aa = 0;
-        long long at = 0, ar = 0;
-        for (int t = 0; t < 1024; t++) {
-            int vq = s_q[t], va = s_a[t];
-            long long vt = s_t[t];
-            s_q[t] = aq;
-            s_a[t] = aa;
-            s_t[t] = at;
-            aq += vq;
-            aa += va;
-            at += vt;
-            ar += s_r[t];
-        }
-        G.g_qoff[G.npids] = aq;
-        *G.n_active = aa;
-        G.active_toff[aa] = at;
-        *G.n_tiles = at;
-        *G.n_rows_unique = ar;
+        G.g_qoff[G.npids] = (int)tq;
+        *G.n_active = (int)ta;
+        G.active_toff[ta] = tt;
+        *G.n_tiles = tt;
+        *G.n_rows_unique = tr;
     }
-    __syncthreads();
-    int aq = s_q[tid], aa = s_a[tid];
-    long long at = s_t[tid];
     for (int p = b; p < e; p++) {
-        G.g_qoff[p] = aq;
+        G.g_qoff[p] = (int)aq;
         int c = G.g_cnt[p];
         if (c > 0) {
             G.active_p[aa] = p;
@@ -339,11 +377,6 @@ __global__ __launch_bounds__(64) void k_scan(ScanParams P) {
                 const int row0 = tl_ << 4;
                 const float yv[4] = {yn_cur.x, yn_cur.y, yn_cur.z, yn_cur.w};
                 const int64_t idv[4] = {id_cur0.x, id_cur0.y, id_cur1.x, id_cur1.y};
-                // every 8 tiles pick up bounds published by other waves working on the same query.  Measured
-                // (scan_probe.py, 10M x 128, P=32): this agent-scope re-read beats a per-tile plain (L1-stale) or
-                // sc1 load folded into the prefetch stream by 15-25 %, although consuming it drains the prefetch.
-                if (P.gtau && (tl_ & 7) == 7 && myq >= 0)
-                    tau = min(tau, __hip_atomic_load(&P.gtau[myq], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 #pragma unroll
                 for (int reg = 0; reg < 4; reg++) {
                     const int row = row0 + 4 * g + reg;
@@ -370,7 +403,13 @@ __global__ __launch_bounds__(64) void k_scan(ScanParams P) {
                                 cnt = nn;
                                 if (nn >= k) {
                                     tau = min(tau, pool_ord[jq * C + k - 1]);
-                                    if (P.gtau && lane < 16) atomicMin(&P.gtau[myq], tau);
+                                    // exchange bounds with the other waves working on this query -- here, in the slow
+                                    // path, because consuming a load drains the prefetched tile (in-order vmcnt): a
+                                    // wave with a loose bound compacts often and so refreshes often, a tight one never
+                                    if (P.gtau) {  // all 4 lanes of the query, so that they keep one common bound
+                                        const uint32_t other = atomicMin(&P.gtau[myq], tau);
+                                        tau = min(tau, other);
+                                    }
                                 }
                             }
                         }
@@ -671,12 +710,10 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
     const int64_t np1 = std::max<int64_t>(npairs, 1);
     size_t need = 0;
     auto add = [&](size_t b) { need += (b + 255) & ~(size_t)255; };
-    add((size_t)Q * s->dpad * 4);
-    add((size_t)Q * 4);
-    add((size_t)npids * 4 * 3 + 64);
+    add((size_t)npids * 4 * 2 + 256 + 64);
+    add((size_t)npids * 4 + 64);
     add((size_t)(npids + 1) * 4 + 64);
     add((size_t)(npids + 1) * 8 + 64);
-    add(256);
     add((size_t)np1 * 4 * 3);
     add((size_t)Q * 4);
     add((size_t)max_recs * 8);
@@ -684,14 +721,17 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
     add((size_t)max_recs * k * 8);
     need += 8192;
     QK_TRY(qk_ws_reserve(ctx, need));
-    float4 *xq4 = (float4 *)qk_ws_alloc(ctx, (size_t)Q * s->dpad * 4);
-    float *xn = (float *)qk_ws_alloc(ctx, (size_t)Q * 4);
-    int32_t *g_cnt = (int32_t *)qk_ws_alloc(ctx, (size_t)npids * 4 * 3 + 64);
+    const float4 *xq4 = a.xq4;
+    const float *xn = a.xn;
+    if (!xq4 || !xn) QK_FAIL(QK_ERR_INVALID, "qk_scan: queries were not prepared");
+    // zeroed region: g_cnt [npids], g_cursor [npids], scal [64]  (one memset per call)
+    const size_t zero_bytes = (size_t)npids * 4 * 2 + 256;
+    int32_t *g_cnt = (int32_t *)qk_ws_alloc(ctx, zero_bytes + 64);
     int32_t *g_cursor = g_cnt + npids;
-    int32_t *active_p = g_cursor + npids;
+    int32_t *scal = g_cursor + npids;
+    int32_t *active_p = (int32_t *)qk_ws_alloc(ctx, (size_t)npids * 4 + 64);
     int32_t *g_qoff = (int32_t *)qk_ws_alloc(ctx, (size_t)(npids + 1) * 4 + 64);
     int64_t *active_toff = (int64_t *)qk_ws_alloc(ctx, (size_t)(npids + 1) * 8 + 64);
-    int32_t *scal = (int32_t *)qk_ws_alloc(ctx, 256);
     // scal layout (int32 units): [0] n_active, [1] rec_counter, [2..3] n_rows_unique (i64), [4..5] n_tiles (i64)
     int32_t *n_active = scal, *rec_counter = scal + 1;
     int64_t *n_rows_unique = (int64_t *)(scal + 2);
@@ -704,18 +744,12 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
     int32_t *rec_cnt = rec_next + max_recs;
     uint32_t *rec_ord = (uint32_t *)qk_ws_alloc(ctx, (size_t)max_recs * k * 4);
     int64_t *rec_id = (int64_t *)qk_ws_alloc(ctx, (size_t)max_recs * k * 8);
-    if (!xq4 || !xn || !g_cnt || !g_qoff || !active_toff || !scal || !grouped_q || !gtau || !rec_next || !rec_ord || !rec_id)
+    if (!g_cnt || !active_p || !g_qoff || !active_toff || !grouped_q || !gtau || !rec_next || !rec_ord || !rec_id)
         QK_FAIL(QK_ERR_OOM, "qk_scan: workspace exhausted");
 
     QK_TRY(pe.mark(0));
-    // ---- prep + grouping -------------------------------------------------------------------------------
-    {
-        int64_t total = std::max<int64_t>(Q * nblk * 4, Q);
-        hipLaunchKernelGGL(k_prep_queries, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a.x, Q, s->d, nblk, xq4, xn);
-    }
-    if (npids > 0) QK_HIP(hipMemsetAsync(g_cnt, 0, (size_t)npids * 4 * 2, st));
-    QK_HIP(hipMemsetAsync(scal, 0, 256, st));
-    QK_HIP(hipMemsetAsync(gtau, 0xFF, (size_t)Q * 4, st));
+    // ---- grouping -----------------------------------------------------------------------------------------
+    QK_HIP(hipMemsetAsync(g_cnt, 0, zero_bytes, st));
     GroupParams G;
     G.pids = a.all_lists ? nullptr : a.pids;
     G.npairs = npairs;
@@ -733,6 +767,7 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
     G.grouped_q = grouped_q;
     G.grouped_pair = grouped_pair;
     G.pair_head = pair_head;
+    G.gtau = gtau;
     if (npairs > 0) hipLaunchKernelGGL(k_group_count, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, st, G);
     hipLaunchKernelGGL(k_group_scan, dim3(1), dim3(1024), 0, st, G);
     if (npairs > 0) hipLaunchKernelGGL(k_group_scatter, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, st, G);
