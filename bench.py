@@ -179,18 +179,16 @@ def main():
 
     out_i = torch.empty((Q, k), dtype=torch.int64, device=dev)
     out_d = torch.empty((Q, k), dtype=torch.float32, device=dev)
+    sharded = None
     if world > 1:
-        ctx.set_squared_l2(True)  # ranks exchange the merge key (squared distance); sqrt after the merge
-        g_i = torch.empty((world, Q, k), dtype=torch.int64, device=dev)
-        g_d = torch.empty((world, Q, k), dtype=torch.float32, device=dev)
+        # ranks exchange the merge key (squared distance) with one all-gather over RCCL; sqrt after the merge
+        from quake_amd.sharded import GpuEngine, ShardedIndex
+        sharded = ShardedIndex(GpuEngine(ctx, parent, store, "l2"), dist, world, rank)
 
     def step(nprobe):
-        ctx.search(parent, store, q, nprobe, k, "l2", out=(out_i, out_d))
-        if world > 1:
-            dist.all_gather_into_tensor(g_i, out_i)
-            dist.all_gather_into_tensor(g_d, out_d)
-            return ctx.merge_topk(g_i, g_d, "l2")
-        return out_i, out_d
+        if sharded is not None:
+            return sharded.search(q, nprobe, k, out=(out_i, out_d))
+        return ctx.search(parent, store, q, nprobe, k, "l2", out=(out_i, out_d))
 
     # ---- nprobe: smallest reaching the recall target ----------------------------------------------------------------
     sweep = []
