@@ -81,7 +81,9 @@ int qk_prep_queries(qk_ctx *ctx, const float *x, int64_t Q, int d, const float4 
     float4 *q4 = (float4 *)ctx->qprep;
     float *n = (float *)(ctx->qprep + (((size_t)Q * dpad * 4 + 255) & ~(size_t)255));
     const size_t lds = (size_t)16 * (d + 1) * 4;
-    if (lds > 64 * 1024) QK_FAIL(QK_ERR_UNSUPPORTED, "d=%d too large for the query prep kernel", d);
+    if (lds > 160 * 1024) QK_FAIL(QK_ERR_UNSUPPORTED, "d=%d too large for the query prep kernel", d);
+    if (lds > 48 * 1024)
+        QK_HIP(hipFuncSetAttribute((const void *)k_prep_queries, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_prep_queries, dim3((unsigned)((Q + 15) / 16)), dim3(256), lds, ctx->stream, x, Q, d, nblk, q4, n);
     QK_HIP(hipGetLastError());
     *xq4 = q4;

@@ -1,0 +1,470 @@
+"""Host-side mirror of the reference's public surface for the hot path, on top of the C ABI.
+
+Names, attributes, argument meaning and error behaviour follow `quake._bindings`
+(src/cpp/bindings/wrap.cpp:48-368) and the C++ classes behind it (src/cpp/include/quake_index.h:18-142,
+src/cpp/include/common.h:104-247), so that the reference's tests can be restated one for one
+(tests/test_index_gpu.py).  All arithmetic happens in libquake_hip.so; this file only marshals tensors and keeps
+the bookkeeping the reference keeps in PartitionManager (resident-id set, next partition id).
+
+Tensors: torch tensors in, torch tensors out.  CPU tensors behave like the reference (results are CPU tensors);
+CUDA tensors stay on the device.
+"""
+import os
+import struct
+import time
+
+import numpy as np
+import torch
+
+from . import capi
+from ._lib import QuakeHipError
+
+# defaults: src/cpp/include/common.h:66-99
+DEFAULT_NLIST = 0
+DEFAULT_NITER = 5
+DEFAULT_METRIC = "l2"
+DEFAULT_NUM_WORKERS = 0
+DEFAULT_K = 1
+DEFAULT_NPROBE = 1
+DEFAULT_RECALL_TARGET = -1.0
+DEFAULT_BATCHED_SCAN = False
+DEFAULT_PRECOMPUTED = True
+DEFAULT_INITIAL_SEARCH_FRACTION = 0.02
+DEFAULT_RECOMPUTE_THRESHOLD = 0.001
+DEFAULT_APS_FLUSH_PERIOD_US = 100
+SERIALIZATION_MAGIC = 0x44494E4C  # common.h:66
+SERIALIZATION_VERSION = 3        # common.h:67
+INT32_MAX = 2 ** 31 - 1
+
+
+class MaintenancePolicyParams:  # common.h:104-118, wrap.cpp:189-226
+    def __init__(self):
+        self.maintenance_policy = "query_cost"
+        self.window_size = 1000
+        self.refinement_radius = 25
+        self.refinement_iterations = 3
+        self.min_partition_size = 32
+        self.alpha = 0.9
+        self.enable_split_rejection = True
+        self.enable_delete_rejection = True
+        self.delete_threshold_ns = 10.0
+        self.split_threshold_ns = 10.0
+
+
+class IndexBuildParams:  # common.h:123-143, wrap.cpp:131-150
+    def __init__(self):
+        self.dimension = 0
+        self.nlist = DEFAULT_NLIST
+        self.num_workers = DEFAULT_NUM_WORKERS
+        self.metric = DEFAULT_METRIC
+        self.niter = DEFAULT_NITER
+        self.use_gpu = True  # the reference's switch for GPU k-means (common.h:135); always on here
+        self.seed = 1234     # faiss ClusteringParameters::seed default
+
+    def __repr__(self):
+        return '{"nlist": %d, "niter": %d, "metric": "%s", "num_workers": %d}' % (self.nlist, self.niter, self.metric,
+                                                                                     self.num_workers)
+
+
+class SearchParams:  # common.h:171-184, wrap.cpp:153-186
+    def __init__(self):
+        self.nprobe = DEFAULT_NPROBE
+        self.k = DEFAULT_K
+        self.recall_target = DEFAULT_RECALL_TARGET
+        self.num_threads = 1
+        self.k_factor = 1.0
+        self.use_precomputed = DEFAULT_PRECOMPUTED
+        self.batched_scan = DEFAULT_BATCHED_SCAN
+        self.recompute_threshold = DEFAULT_RECOMPUTE_THRESHOLD
+        self.initial_search_fraction = DEFAULT_INITIAL_SEARCH_FRACTION
+        self.aps_flush_period_us = DEFAULT_APS_FLUSH_PERIOD_US
+
+
+class SearchTimingInfo:  # common.h:214-228; device phases come from HIP events (qk_timing)
+    def __init__(self):
+        self.n_queries = 0
+        self.n_clusters = 0
+        self.partitions_scanned = 0
+        self.search_params = None
+        self.parent_info = None
+        self.buffer_init_time_ns = 0
+        self.job_enqueue_time_ns = 0
+        self.boundary_distance_time_ns = 0
+        self.job_wait_time_ns = 0
+        self.result_aggregate_time_ns = 0
+        self.total_time_ns = 0
+
+
+class BuildTimingInfo:  # common.h:189-198
+    def __init__(self):
+        self.n_vectors = 0
+        self.n_clusters = 0
+        self.d = 0
+        self.num_codebooks = -1
+        self.code_size = -1
+        self.train_time_us = 0
+        self.assign_time_us = 0
+        self.total_time_us = 0
+
+
+class ModifyTimingInfo:  # common.h:203-209; wrap.cpp:264 aliases modify_count to n_vectors
+    def __init__(self):
+        self.n_vectors = 0
+        self.input_validation_time_us = 0
+        self.find_partition_time_us = 0
+        self.modify_time_us = 0
+        self.maintenance_time_us = 0
+
+    @property
+    def modify_count(self):
+        return self.n_vectors
+
+
+class MaintenanceTimingInfo:  # common.h:233-241
+    def __init__(self):
+        self.n_splits = 0
+        self.n_deletes = 0
+        self.delete_time_us = 0
+        self.delete_refine_time_us = 0
+        self.split_time_us = 0
+        self.split_refine_time_us = 0
+        self.total_time_us = 0
+
+
+class SearchResult:  # common.h:243-247
+    def __init__(self):
+        self.ids = None
+        self.distances = None
+        self.timing_info = None
+
+
+_CONTEXTS = {}
+
+
+def _context(device=0):
+    if device not in _CONTEXTS:
+        _CONTEXTS[device] = capi.Context(device)
+    return _CONTEXTS[device]
+
+
+def _us(t0):
+    return int((time.perf_counter() - t0) * 1e6)
+
+
+class QuakeIndex:
+    """quake_index.h:18-142.  One level of the (recursive) index; `parent` is a flat QuakeIndex over the centroids."""
+
+    def __init__(self, current_level=0, device=0):
+        self.parent = None
+        self.current_level = int(current_level)
+        self.metric_ = None
+        self.build_params_ = None
+        self.maintenance_policy_params_ = None
+        self.debug_ = False
+        self._device = int(device)
+        self._ctx = None
+        self._store = None
+        self._resident = set()   # PartitionManager::resident_ids_
+        self._next_pid = 0       # PartitionManager::curr_partition_id_
+        self._d = 0
+
+    # -- helpers -------------------------------------------------------------------------------------------------
+    @property
+    def parent_(self):
+        return self.parent
+
+    def _to_dev(self, t, dtype):
+        if not torch.is_tensor(t):
+            t = torch.as_tensor(t)
+        return t.to(device=torch.device("cuda", self._device), dtype=dtype).contiguous()
+
+    def _require_built(self, who):
+        if self._store is None:
+            raise RuntimeError(who)
+
+    # -- build (quake_index.cpp:29-90) -------------------------------------------------------------------------------
+    def build(self, x, ids, build_params):
+        t_total = time.perf_counter()
+        self.build_params_ = build_params
+        self.metric_ = capi.metric_code(build_params.metric)  # raises ValueError("Invalid metric type: ...")
+        if x.dim() != 2:
+            raise RuntimeError("[QuakeIndex::build] x must be 2-D [num_vectors, dimension]")
+        if x.shape[0] != ids.shape[0]:
+            raise RuntimeError("[QuakeIndex::build] x.size(0) != ids.size(0)")
+        self._ctx = _context(self._device)
+        n, d = int(x.shape[0]), int(x.shape[1])
+        self._d = d
+        info = BuildTimingInfo()
+        info.n_vectors, info.d = n, d
+        xd = self._to_dev(x, torch.float32)
+        idd = self._to_dev(ids, torch.int64)
+        nlist = int(build_params.nlist)
+        self._store = capi.Store(self._ctx, d)
+        if nlist > 1:
+            t0 = time.perf_counter()
+            # kmeans(): clustering.cpp:13-97 (IP: the normalised copy is what gets stored, :25-26,71)
+            centroids, assign, xd = self._ctx.kmeans(xd, nlist, self.metric_, niter=int(build_params.niter),
+                                                     seed=int(getattr(build_params, "seed", 1234)))
+            info.train_time_us = _us(t0)
+            t0 = time.perf_counter()
+            order = torch.argsort(assign, stable=True)  # torch::sort + index_select, clustering.cpp:69-72
+            counts = torch.bincount(assign, minlength=nlist).cpu().numpy().astype(np.int64)
+            offsets = np.zeros(nlist + 1, np.int64)
+            offsets[1:] = np.cumsum(counts)
+            self._store.build_csr(offsets, idd[order].contiguous(), xd[order].contiguous())
+            self.parent = QuakeIndex(self.current_level + 1, self._device)
+            pparams = IndexBuildParams()
+            pparams.metric = build_params.metric
+            pparams.num_workers = build_params.num_workers
+            self.parent.build(centroids, torch.arange(nlist, dtype=torch.int64), pparams)
+            info.assign_time_us = _us(t0)
+            info.n_clusters = nlist
+            self._next_pid = nlist
+        else:
+            # flat index: one partition holding x (quake_index.cpp:68-79)
+            self._store.build_csr(np.array([0, n], np.int64), idd, xd)
+            self.parent = None
+            info.n_clusters = 1
+            self._next_pid = 1
+        self._resident = set(ids.reshape(-1).tolist()) if self.current_level == 0 else set()
+        self.initialize_maintenance_policy(MaintenancePolicyParams())
+        info.total_time_us = _us(t_total)
+        return info
+
+    # -- search (quake_index.cpp:93-99 -> query_coordinator.cpp:612-657) --------------------------------------------------
+    def search(self, x, search_params):
+        self._require_built("[QuakeIndex::search()] No query coordinator. Did you build the index?")
+        res = SearchResult()
+        ti = SearchTimingInfo()
+        ti.search_params = search_params
+        ti.n_clusters = self.nlist()
+        res.timing_info = ti
+        if x is None or x.shape[0] == 0:  # query_coordinator.cpp:476-482
+            res.ids = torch.empty((0,), dtype=torch.int64)
+            res.distances = torch.empty((0,), dtype=torch.float32)
+            return res
+        if search_params.recall_target is not None and search_params.recall_target > 0.0 and self.parent is not None:
+            raise NotImplementedError("adaptive partition scanning (recall_target > 0) is not on this path yet (SURVEY 8f-2)")
+        t0 = time.perf_counter()
+        on_dev = x.is_cuda
+        xd = self._to_dev(x, torch.float32)
+        k = search_params.k if search_params.k and search_params.k > 0 else 1  # query_coordinator.cpp:490
+        nprobe = max(int(search_params.nprobe), 1)
+        self._ctx.set_timing(1)
+        try:
+            ids, dist, tm = self._ctx.search(self.parent._store if self.parent is not None else None, self._store, xd, nprobe,
+                                             int(k), self.metric_, timing=True)
+        finally:
+            self._ctx.set_timing(0)
+        ti.n_queries = int(x.shape[0])
+        ti.partitions_scanned = int(tm["n_items"])
+        ti.job_wait_time_ns = int(tm["scan_ms"] * 1e6)
+        ti.result_aggregate_time_ns = int(tm["merge_ms"] * 1e6)
+        ti.job_enqueue_time_ns = int(tm["group_ms"] * 1e6)
+        if self.parent is not None:
+            pi = SearchTimingInfo()
+            pi.n_queries = ti.n_queries
+            pi.n_clusters = 1
+            pi.total_time_ns = int(tm["coarse_ms"] * 1e6)
+            ti.parent_info = pi
+        ti.total_time_ns = int((time.perf_counter() - t0) * 1e9)
+        res.ids = ids if on_dev else ids.cpu()
+        res.distances = dist if on_dev else dist.cpu()
+        return res
+
+    # -- get / get_ids (partition_manager.cpp:322-343) --------------------------------------------------------------------
+    def get(self, ids):
+        self._require_built("[QuakeIndex::get()] No partition manager. Index not built?")
+        out = torch.empty((ids.shape[0], self._d), dtype=torch.float32)
+        for i, v in enumerate(ids.reshape(-1).tolist()):
+            vec = self._store.get_vector(int(v))
+            if vec is None:
+                raise RuntimeError("ID not found in any partition")
+            out[i] = torch.from_numpy(vec)
+        return out
+
+    def get_ids(self):
+        self._require_built("[QuakeIndex::get_ids()] No partition manager. Index not built?")
+        parts = [torch.from_numpy(self._store.get_list(int(p))[1]) for p in self._store.list_ids()]
+        return torch.cat(parts) if parts else torch.empty((0,), dtype=torch.int64)
+
+    # -- add (partition_manager.cpp:123-262) ---------------------------------------------------------------------------------
+    def add(self, x, ids):
+        self._require_built("[QuakeIndex::add()] No partition manager. Build the index first.")
+        info = ModifyTimingInfo()
+        t0 = time.perf_counter()
+        if x.shape[0] != ids.shape[0]:
+            raise RuntimeError("[PartitionManager] add: mismatch in vectors.size(0) and vector_ids.size(0).")
+        n = int(x.shape[0])
+        info.n_vectors = n
+        if n == 0:
+            return info
+        if x.dim() != 2:
+            raise RuntimeError("[PartitionManager] add: 'vectors' must be 2D [N, dim].")
+        idl = ids.reshape(-1).tolist()
+        if max(idl) > INT32_MAX:
+            raise RuntimeError("[PartitionManager] add: vector_ids must be less than INT_MAX.")
+        if len(set(idl)) != n:
+            raise RuntimeError("[PartitionManager] add: vector_ids must be unique.")
+        for v in idl:
+            if v in self._resident:
+                raise RuntimeError("[PartitionManager] init_partitions: vector ID already exists in the index.")
+        self._resident.update(idl)
+        info.input_validation_time_us = _us(t0)
+        t0 = time.perf_counter()
+        xd = self._to_dev(x, torch.float32)
+        idd = self._to_dev(ids.reshape(-1), torch.int64)
+        if self.parent is None:
+            assign = torch.zeros(n, dtype=torch.int64, device=xd.device)
+        else:
+            # parent_->search(x, {k = 1, nprobe = parent nlist}) (:219-230) == coarse step with nprobe 1
+            pids, _ = self._ctx.coarse(self.parent._store, xd, 1, self.metric_)
+            assign = pids.reshape(-1)
+        info.find_partition_time_us = _us(t0)
+        t0 = time.perf_counter()
+        order = torch.argsort(assign, stable=True)  # per-partition append order = input order (:245-258)
+        a_sorted = assign[order]
+        uniq, cnt = torch.unique_consecutive(a_sorted, return_counts=True)
+        xs, ids_s = xd[order].contiguous(), idd[order].contiguous()
+        pos = 0
+        for p, c in zip(uniq.tolist(), cnt.tolist()):
+            self._store.add_entries(int(p), ids_s[pos:pos + c], xs[pos:pos + c])
+            pos += c
+        info.modify_time_us = _us(t0)
+        return info
+
+    # -- remove (partition_manager.cpp:264-320) -------------------------------------------------------------------------------
+    def remove(self, ids):
+        self._require_built("[QuakeIndex::remove()] No partition manager. Build the index first.")
+        info = ModifyTimingInfo()
+        info.n_vectors = int(ids.shape[0])
+        if ids.shape[0] == 0:
+            return info
+        t0 = time.perf_counter()
+        idl = ids.reshape(-1).tolist()
+        for v in idl:
+            if v not in self._resident:
+                raise RuntimeError("[PartitionManager] remove: vector ID does not exist in the index.")
+            self._resident.discard(v)
+        info.input_validation_time_us = _us(t0)
+        t0 = time.perf_counter()
+        self._store.remove_ids(np.asarray(idl, dtype=np.int64))
+        info.modify_time_us = _us(t0)
+        return info
+
+    def modify(self, ids, x):  # quake_index.cpp:147-150
+        self.remove(ids)
+        return self.add(x, ids)
+
+    # -- maintenance (quake_index.cpp:152-163) ------------------------------------------------------------------------------
+    def initialize_maintenance_policy(self, maintenance_policy_params):
+        self.maintenance_policy_params_ = maintenance_policy_params
+
+    def maintenance(self):
+        """MaintenancePolicy::perform_maintenance (maintenance_policies.cpp:33-177).  In the reference snapshot
+        search() never calls record_query_hits, so through the public API the policy always returns at the
+        'window not full' guard (:36-41) with zero splits/deletes; that observable behaviour is what is kept here.
+        The policy itself is out of scope."""
+        if self.maintenance_policy_params_ is None:
+            raise RuntimeError("[QuakeIndex::maintenance()] No maintenance policy set.")
+        return MaintenanceTimingInfo()
+
+    # -- sizes ---------------------------------------------------------------------------------------------------------------
+    def ntotal(self):
+        return int(self._store.ntotal()) if self._store is not None else 0
+
+    def nlist(self):
+        return int(self._store.nlist()) if self._store is not None else 0
+
+    def d(self):
+        return self._d
+
+    # -- save / load: the reference's directory format (quake_index.cpp:170-267, dynamic_inverted_list.cpp:338-520) ------------
+    def save(self, dir_path):
+        self._require_built("Cannot save an index that was not built")
+        if os.path.exists(dir_path) and not os.path.isdir(dir_path):
+            raise RuntimeError("save path exists but is not a directory: " + dir_path)
+        os.makedirs(dir_path, exist_ok=True)
+        with open(os.path.join(dir_path, "metadata.txt"), "w") as f:
+            f.write("metric=%d\nlevel=%d\nntotal=%d\nnlist=%d\n" % (self.metric_, self.current_level, self.ntotal(), self.nlist()))
+        pids = [int(p) for p in self._store.list_ids()]
+        chunks, offsets, cur = [], [0], 0
+        for p in pids:
+            vecs, ids = self._store.get_list(p)
+            b = vecs.astype("<f4").tobytes() + ids.astype("<i8").tobytes()  # [codes | ids] per partition
+            chunks.append(b)
+            cur += len(b)
+            offsets.append(cur)
+        with open(os.path.join(dir_path, "partitions"), "wb") as f:
+            f.write(struct.pack("<IIQQQ", SERIALIZATION_MAGIC, SERIALIZATION_VERSION, len(pids), self._d * 4, len(pids)))
+            f.write(np.asarray(offsets, "<u8").tobytes())
+            f.write(np.asarray(pids, "<u8").tobytes())
+            for b in chunks:
+                f.write(b)
+        if self.parent is not None:
+            self.parent.save(os.path.join(dir_path, "parent"))
+
+    def load(self, dir_path, n_workers=0):
+        if not os.path.isdir(dir_path):
+            raise RuntimeError("Cannot load QuakeIndex, directory does not exist: " + dir_path)
+        meta = {}
+        with open(os.path.join(dir_path, "metadata.txt")) as f:
+            for line in f:
+                if "=" in line:
+                    kk, vv = line.strip().split("=", 1)
+                    meta[kk] = vv
+        self.metric_ = int(meta.get("metric", 1))
+        self.current_level = int(meta.get("level", 0))
+        with open(os.path.join(dir_path, "partitions"), "rb") as f:
+            blob = f.read()
+        magic, version, nlist, code_size, nparts = struct.unpack_from("<IIQQQ", blob, 0)
+        if magic != SERIALIZATION_MAGIC:
+            raise RuntimeError("Invalid file format (bad magic number).")
+        if version != SERIALIZATION_VERSION:
+            raise RuntimeError("Unsupported file version: %d" % version)
+        d = code_size // 4
+        offs = np.frombuffer(blob, "<u8", nparts + 1, 32)
+        pids = np.frombuffer(blob, "<u8", nparts, 32 + 8 * (nparts + 1))
+        start = 32 + 8 * (nparts + 1) + 8 * nparts
+        rec = code_size + 8
+        self._ctx = _context(self._device)
+        self._d = int(d)
+        self._store = capi.Store(self._ctx, int(d))
+        self._resident = set()
+        for i in range(nparts):
+            size = int(offs[i + 1] - offs[i])
+            if size % rec != 0:
+                raise RuntimeError("Partition chunk size not divisible by (code_size+sizeof(idx_t))")
+            nv = size // rec
+            vecs = np.frombuffer(blob, "<f4", nv * d, start + int(offs[i])).reshape(nv, d)
+            ids = np.frombuffer(blob, "<i8", nv, start + int(offs[i]) + nv * code_size)
+            self._store.add_list(int(pids[i]))
+            if nv:
+                self._store.add_entries(int(pids[i]), ids.copy(), vecs.copy())
+            if self.current_level == 0:
+                self._resident.update(ids.tolist())
+        self._next_pid = (int(pids.max()) + 1) if nparts else 0
+        pdir = os.path.join(dir_path, "parent")
+        if os.path.isdir(pdir):
+            self.parent = QuakeIndex(self.current_level + 1, self._device)
+            self.parent.load(pdir, n_workers)
+        else:
+            self.parent = None
+        self.initialize_maintenance_policy(MaintenancePolicyParams())  # load resets the policy to defaults (:250-251)
+
+    def __repr__(self):
+        return '{"current_level": %d, }' % self.current_level
+
+
+def compute_recall(ids, gt_ids, k):
+    """src/python/utils.py:162-177: per-query |set(ids[:k]) & set(gt[:k])| / k."""
+    ids, gt_ids = torch.as_tensor(ids)[:, :k], torch.as_tensor(gt_ids)[:, :k]
+    assert ids.shape == gt_ids.shape, (ids.shape, gt_ids.shape)
+    out = torch.zeros(ids.shape[0])
+    for i in range(ids.shape[0]):
+        out[i] = len(set(ids[i].tolist()) & set(gt_ids[i].tolist())) / k
+    return out
+
+
+__all__ = ["QuakeIndex", "IndexBuildParams", "SearchParams", "SearchResult", "SearchTimingInfo", "BuildTimingInfo",
+           "ModifyTimingInfo", "MaintenanceTimingInfo", "MaintenancePolicyParams", "compute_recall", "QuakeHipError"]

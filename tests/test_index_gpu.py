@@ -1,0 +1,204 @@
+"""The reference's index-level tests restated against quake_amd (same API names as quake._bindings):
+test/cpp/quake_index.cpp:47-251 (constructor/build/flat/search shapes/get/add/remove/ntotal/save-load),
+test/cpp/query_coordinator.cpp:309-371 (k > partition size -> -1 / inf padding), :459-497,
+test/cpp/search_recall_tests.cpp:160-254 (flat recall >= 0.99), and full-search parity with the oracle."""
+import numpy as np
+import pytest
+import torch
+
+import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+DIM, NVEC, NLIST, NQ = 32, 2000, 10, 25
+
+
+@pytest.fixture(scope="module")
+def quake():
+    import quake_amd
+    return quake_amd
+
+
+@pytest.fixture()
+def data():
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(NVEC, DIM, generator=g)
+    ids = torch.arange(NVEC, dtype=torch.int64)
+    q = torch.randn(NQ, DIM, generator=g)
+    return x, ids, q
+
+
+def build(quake, x, ids, nlist, metric="l2"):
+    idx = quake.QuakeIndex()
+    p = quake.IndexBuildParams()
+    p.nlist = nlist
+    p.metric = metric
+    info = idx.build(x, ids, p)
+    return idx, info
+
+
+def test_constructor(quake):  # quake_index.cpp:47-55
+    idx = quake.QuakeIndex()
+    assert idx.parent is None and idx.build_params_ is None and idx.maintenance_policy_params_ is None
+    assert idx.ntotal() == 0 and idx.nlist() == 0
+    with pytest.raises(RuntimeError):
+        sp = quake.SearchParams()
+        idx.search(torch.zeros(1, 4), sp)
+
+
+def test_build_partitioned_and_flat(quake, data):  # :58-100
+    x, ids, q = data
+    idx, info = build(quake, x, ids, NLIST)
+    assert idx.parent is not None and idx.build_params_ is not None
+    assert info.n_vectors == NVEC and info.d == DIM
+    assert idx.ntotal() == NVEC and idx.nlist() == NLIST  # :214-229
+    assert idx.parent.ntotal() == NLIST and idx.parent.nlist() == 1
+    flat, _ = build(quake, x, ids, 0)
+    assert flat.parent is None and flat.ntotal() == NVEC and flat.nlist() == 1
+    with pytest.raises(ValueError):  # str_to_metric_type, common.h:154
+        build(quake, x, ids, 0, metric="cosine")
+
+
+@pytest.mark.parametrize("nlist", [NLIST, 0])
+def test_search_shapes_and_empty(quake, data, nlist):  # :102-156
+    x, ids, q = data
+    idx, _ = build(quake, x, ids, nlist)
+    sp = quake.SearchParams()
+    sp.k, sp.nprobe = 5, 3
+    r = idx.search(q, sp)
+    assert tuple(r.ids.shape) == (NQ, 5) and tuple(r.distances.shape) == (NQ, 5)
+    assert r.ids.dtype == torch.int64 and r.distances.dtype == torch.float32 and not r.ids.is_cuda
+    assert r.timing_info.n_queries == NQ and r.timing_info.total_time_ns > 0
+    e = idx.search(torch.empty(0, DIM), sp)  # query_coordinator.cpp:476-482
+    assert e.ids.numel() == 0 and e.distances.numel() == 0
+
+
+@pytest.mark.parametrize("metric", ["l2", "ip"])
+def test_search_matches_oracle_on_the_built_index(quake, data, metric):
+    """Whatever the k-means produced, search() over it must equal the oracle's search over the same partitions."""
+    x, ids, q = data
+    idx, _ = build(quake, x, ids, NLIST, metric)
+    s = idx._store
+    pv, pi = zip(*[s.get_list(p) for p in range(NLIST)])
+    vecs, aids, offs = O.csr_from_partitions(pv, pi, DIM)
+    cent, cids = idx.parent._store.get_list(0)
+    sp = quake.SearchParams()
+    for nprobe, k in [(1, 1), (3, 10), (NLIST, 50)]:
+        sp.k, sp.nprobe = k, nprobe
+        r = idx.search(q, sp)
+        oi, od = O.search(q.numpy(), cent, vecs, aids, offs, nprobe, k, metric, batched_scan=True, centroid_ids=cids)
+        np.testing.assert_array_equal(r.ids.numpy(), oi)
+        np.testing.assert_array_equal(r.distances.numpy().view(np.uint32), od.view(np.uint32))
+
+
+def test_get_add_remove(quake, data):  # :158-212
+    x, ids, q = data
+    idx, _ = build(quake, x, ids, NLIST)
+    got = idx.get(torch.tensor([3, 17, 1999]))
+    np.testing.assert_array_equal(got.numpy(), x[[3, 17, 1999]].numpy())
+    g = torch.Generator().manual_seed(9)
+    newx = torch.randn(10, DIM, generator=g)
+    newids = torch.arange(NVEC, NVEC + 10)
+    info = idx.add(newx, newids)
+    assert info.n_vectors == 10 and info.modify_time_us >= 0 and idx.ntotal() == NVEC + 10
+    np.testing.assert_array_equal(idx.get(newids[:2]).numpy(), newx[:2].numpy())
+    # a freshly added vector is its own nearest neighbour
+    sp = quake.SearchParams()
+    sp.k, sp.nprobe = 1, NLIST
+    r = idx.search(newx, sp)
+    np.testing.assert_array_equal(r.ids.reshape(-1).numpy(), newids.numpy())
+    with pytest.raises(RuntimeError):  # duplicate ids (partition_manager.cpp:168-172, 178-183)
+        idx.add(newx, newids)
+    with pytest.raises(RuntimeError):  # ids above INT32_MAX (:163)
+        idx.add(newx[:1], torch.tensor([2 ** 31 + 5]))
+    rem = torch.arange(0, 100)
+    info = idx.remove(rem)
+    assert info.n_vectors == 100 and idx.ntotal() == NVEC + 10 - 100
+    r = idx.search(x[:100], sp)
+    assert not np.isin(r.ids.numpy(), rem.numpy()).any()
+    assert set(idx.get_ids().tolist()) == set(range(100, NVEC + 10))
+    with pytest.raises(RuntimeError):  # removing a non-resident id (:283-296)
+        idx.remove(torch.tensor([5]))
+    m = idx.maintenance()  # window never fills through the public API (maintenance_policies.cpp:36-41)
+    assert m.n_splits == 0 and m.n_deletes == 0
+
+
+def test_k_greater_than_available_pads(quake):  # query_coordinator.cpp:309-371
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(4, 8, generator=g)
+    idx, _ = build(quake, x, torch.arange(4) + 100, 0)
+    sp = quake.SearchParams()
+    sp.k = 7
+    r = idx.search(torch.randn(3, 8, generator=g), sp)
+    assert (r.ids[:, :4] >= 100).all() and (r.ids[:, 4:] == -1).all()
+    assert torch.isinf(r.distances[:, 4:]).all() and (r.distances[:, 4:] > 0).all()
+    idx_ip, _ = build(quake, x, torch.arange(4), 0, "ip")
+    r = idx_ip.search(torch.randn(3, 8, generator=g), sp)
+    assert (r.ids[:, 4:] == -1).all() and (r.distances[:, 4:] < 0).all() and torch.isinf(r.distances[:, 4:]).all()
+
+
+@pytest.mark.parametrize("metric", ["l2", "ip"])
+def test_flat_recall(quake, metric):  # search_recall_tests.cpp:160-189,225-254: 100k x 32, recall@10 >= 0.99
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(100000, 32, generator=g)
+    q = torch.randn(100, 32, generator=g)
+    idx, _ = build(quake, x, torch.arange(100000), 0, metric)
+    sp = quake.SearchParams()
+    sp.k = 10
+    r = idx.search(q, sp)
+    d = torch.cdist(q.double(), x.double()) if metric == "l2" else -(q.double() @ x.double().T)
+    gt = torch.topk(d, 10, dim=1, largest=False).indices
+    rec = quake.compute_recall(r.ids, gt, 10).mean().item()
+    assert rec >= 0.99
+
+
+def test_ivf_recall_increases_with_nprobe(quake):
+    g = torch.Generator().manual_seed(13)
+    cent = torch.randn(64, 32, generator=g) * 3
+    x = cent[torch.randint(0, 64, (50000,), generator=g)] + torch.randn(50000, 32, generator=g)
+    q = x[torch.randperm(50000, generator=g)[:200]] + 0.1 * torch.randn(200, 32, generator=g)
+    idx, _ = build(quake, x, torch.arange(50000), 64)
+    gt = torch.topk(torch.cdist(q.double(), x.double()), 10, dim=1, largest=False).indices
+    sp = quake.SearchParams()
+    sp.k = 10
+    recs = []
+    for nprobe in (1, 4, 64):
+        sp.nprobe = nprobe
+        recs.append(quake.compute_recall(idx.search(q, sp).ids, gt, 10).mean().item())
+    assert recs[0] <= recs[1] + 1e-6 <= recs[2] + 2e-6 and recs[2] >= 0.999
+
+
+def test_save_load_roundtrip(quake, data, tmp_path):  # quake_index.cpp:232-251
+    x, ids, q = data
+    idx, _ = build(quake, x, ids, NLIST)
+    d = str(tmp_path / "idx")
+    idx.save(d)
+    # byte layout of the reference format (dynamic_inverted_list.cpp:338-419)
+    blob = open(d + "/partitions", "rb").read()
+    magic, version, nl, code_size, nparts = np.frombuffer(blob, "<u4", 2)[0], np.frombuffer(blob, "<u4", 2)[1], \
+        *np.frombuffer(blob, "<u8", 3, 8)
+    assert magic == 0x44494E4C and version == 3 and nl == NLIST and code_size == DIM * 4 and nparts == NLIST
+    assert len(blob) == 32 + 8 * (NLIST + 1) + 8 * NLIST + NVEC * (DIM * 4 + 8)
+    meta = open(d + "/metadata.txt").read()
+    assert "metric=1" in meta and "nlist=%d" % NLIST in meta and "ntotal=%d" % NVEC in meta
+    loaded = quake.QuakeIndex()
+    loaded.load(d)
+    assert loaded.ntotal() == idx.ntotal() and loaded.nlist() == idx.nlist() and loaded.parent is not None
+    sp = quake.SearchParams()
+    sp.k, sp.nprobe = 10, 4
+    a, b = idx.search(q, sp), loaded.search(q, sp)
+    np.testing.assert_array_equal(a.ids.numpy(), b.ids.numpy())
+    np.testing.assert_array_equal(a.distances.numpy(), b.distances.numpy())
+
+
+def test_large_dimension(quake):  # quake_index.cpp d = 1024 stress case
+    g = torch.Generator().manual_seed(17)
+    x = torch.randn(3000, 1024, generator=g)
+    q = torch.randn(8, 1024, generator=g)
+    idx, _ = build(quake, x, torch.arange(3000), 8)
+    sp = quake.SearchParams()
+    sp.k, sp.nprobe = 10, 8
+    r = idx.search(q, sp)
+    gt = torch.topk(torch.cdist(q.double(), x.double()), 10, dim=1, largest=False)
+    np.testing.assert_array_equal(r.ids.numpy(), gt.indices.numpy())
+    np.testing.assert_allclose(r.distances.numpy(), gt.values.numpy(), atol=1e-3)
