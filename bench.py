@@ -100,16 +100,22 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run for --gpus > 1")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # QUAKE_BENCH_BACKEND=gloo lets two ranks share one GPU (functional check of the N>1 path on a 1-GPU box)
+    backend = os.environ.get("QUAKE_BENCH_BACKEND", "nccl")
+    dev_index = local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist_
         dist = dist_
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from quake_amd.capi import Context, Store
-    ctx = Context(local_rank)
+    ctx = Context(dev_index)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     info = ctx.device_info()
     log("device", info)
