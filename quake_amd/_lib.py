@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libquake_hip.so")
+LIB_PATH = os.environ.get("QUAKE_HIP_LIB") or os.path.join(HERE, "lib", "libquake_hip.so")  # override: A/B builds
 
 QK_OK = 0
 QK_METRIC_IP = 0

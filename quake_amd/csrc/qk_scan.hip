@@ -92,6 +92,16 @@ int qk_prep_queries(qk_ctx *ctx, const float *x, int64_t Q, int d, const float4 
 }
 
 // ---- grouping ---------------------------------------------------------------------------------------
+// everything a wave needs to start on an active partition, in one 32-byte load
+struct __align__(16) ActiveInfo {
+    long long toff;     // first tile of this partition's items in the global tile sequence
+    long long row_off;  // first arena row
+    int p;              // list number
+    int size;           // rows
+    int cnt;            // queries probing it
+    int qoff;           // offset of its group in grouped_q / grouped_pair
+};
+
 struct GroupParams {
     const int64_t *pids;  // [Q*P] or nullptr (all_lists: pair i -> list i % P)
     int64_t npairs;
@@ -102,8 +112,8 @@ struct GroupParams {
     int32_t *g_cursor;    // [npids]
     int32_t *g_qoff;      // [npids+1] offsets into grouped_*
     int32_t *n_active;    // [1]
-    int32_t *active_p;    // [npids] partitions with >= 1 query, ascending
-    int64_t *active_toff; // [npids+1] first tile of each active partition in the global tile sequence
+    ActiveInfo *active;   // [npids+1] partitions with >= 1 query, ascending; entry n_active is a sentinel (toff = total)
+    const int64_t *pt_off;
     int64_t *n_tiles;     // [1] total tiles = sum over active p of ntiles(p) * ceil(cnt_p/16)
     int64_t *n_rows_unique;  // [1] sum of sizes of active partitions (algorithmic bytes / (d*4))
     int32_t *grouped_q;   // [npairs] query of each grouped entry
@@ -178,7 +188,12 @@ __global__ __launch_bounds__(1024) void k_group_scan(GroupParams G) {
     if (tid == 0) {
         G.g_qoff[G.npids] = (int)tq;
         *G.n_active = (int)ta;
-        G.active_toff[ta] = tt;
+        ActiveInfo sent;
+        sent.toff = tt;
+        sent.row_off = 0;
+        sent.p = -1;
+        sent.size = sent.cnt = sent.qoff = 0;
+        G.active[ta] = sent;
         *G.n_tiles = tt;
         *G.n_rows_unique = tr;
     }
@@ -186,8 +201,14 @@ __global__ __launch_bounds__(1024) void k_group_scan(GroupParams G) {
         G.g_qoff[p] = (int)aq;
         int c = G.g_cnt[p];
         if (c > 0) {
-            G.active_p[aa] = p;
-            G.active_toff[aa] = at;
+            ActiveInfo inf;
+            inf.toff = at;
+            inf.row_off = G.pt_off[p];
+            inf.p = p;
+            inf.size = G.pt_size[p];
+            inf.cnt = c;
+            inf.qoff = (int)aq;
+            G.active[aa] = inf;
             aq += c;
             aa += 1;
             at += (long long)((c + 15) >> 4) * ((G.pt_size[p] + 15) >> 4);
@@ -218,11 +239,8 @@ struct ScanParams {
     const float *xn;
     const int32_t *grouped_q;
     const int32_t *grouped_pair;
-    const int32_t *g_cnt;
-    const int32_t *g_qoff;
     const int32_t *n_active;
-    const int32_t *active_p;
-    const int64_t *active_toff;
+    const ActiveInfo *active;
     const int64_t *n_tiles;
     uint32_t *gtau;  // [Q] shared running bound per query, or nullptr
     int k;
@@ -236,6 +254,21 @@ struct ScanParams {
     uint32_t *rec_ord;   // [max_recs][k]
     int64_t *rec_id;     // [max_recs][k]
 };
+
+// Compile-time experiment switches (scripts/scan_ab.sh builds one library per combination)
+#ifndef QK_OPT_EARLY_LOAD
+#define QK_OPT_EARLY_LOAD 1   // first tile's loads before the query staging
+#endif
+#ifndef QK_OPT_EARLY_REC
+#define QK_OPT_EARLY_REC 0    // reserve record slots at segment start + deferred rec_next store
+#endif
+#ifndef QK_OPT_ONE_BALLOT
+#define QK_OPT_ONE_BALLOT 1   // one ballot per tile in the steady state
+#endif
+
+#ifndef QK_OPT_STEP_DRAIN
+#define QK_OPT_STEP_DRAIN 0   // s_waitcnt vmcnt(0) after every step (limits the bytes in flight per wave)
+#endif
 
 // MODE 0 = product; 1 = skip the top-k epilogue; 2 = loads only (probe variants for bandwidth attribution, QK_SCAN_MODE)
 template <int DB, int MAXCH, int MODE = 0>
@@ -258,25 +291,32 @@ __global__ __launch_bounds__(64) void k_scan(ScanParams P) {
     const long long T0 = (T * blockIdx.x) / W, T1 = (T * (blockIdx.x + 1)) / W;
     if (T1 <= T0) return;
     const int n_active = *P.n_active;
-    int lo = 0, hi = n_active;  // active_toff[lo] <= T0 < active_toff[hi]
+    // 64-ary search for the partition containing tile T0: active[lo].toff <= T0 < active[lo+1].toff
+    int lo = 0, hi = n_active;
     while (hi - lo > 1) {
-        int mid = (lo + hi) >> 1;
-        if (P.active_toff[mid] <= T0)
-            lo = mid;
-        else
-            hi = mid;
+        const int span = hi - lo;
+        const int step = (span + 63) >> 6;
+        const int probe = min(lo + (lane + 1) * step, hi);          // lanes probe lo+step, lo+2step, ..., hi
+        const bool gt = (probe >= hi) || (P.active[probe].toff > T0);  // active[hi].toff > T0 by the invariant
+        const uint64_t m = __ballot(gt);
+        const int first = __ffsll((unsigned long long)m) - 1;      // first lane whose probe is beyond T0 (always exists)
+        const int nlo = min(lo + first * step, hi - 1);
+        const int nhi = min(lo + (first + 1) * step, hi);
+        lo = nlo;
+        hi = nhi;
     }
     int ai = lo;
     long long cur = T0;
+    int pend_rec = -1, pend_old = -1;  // deferred rec_next store of this lane's previous record
 
     while (cur < T1) {
         // ---- segment = tiles [tl, tend) of item (p, qt) ---------------------------------------------------------
-        const int p = P.active_p[ai];
-        const long long base = P.active_toff[ai];
-        const int size_p = P.pt_size[p];
-        const int64_t row_off = P.pt_off[p];
+        const ActiveInfo inf = P.active[ai];
+        const long long base = inf.toff;
+        const int size_p = inf.size;
+        const int64_t row_off = inf.row_off;
         const int ntl = (size_p + 15) >> 4;
-        const int cnt_p = P.g_cnt[p];
+        const int cnt_p = inf.cnt;
         const int nqt = (cnt_p + 15) >> 4;
         const long long local = cur - base;
         const int qt = (int)(local / ntl);
@@ -285,28 +325,16 @@ __global__ __launch_bounds__(64) void k_scan(ScanParams P) {
         cur += tend - tl;
         if (qt == nqt - 1 && tend == ntl) ai++;  // item sequence of this partition exhausted
         const int nq = min(16, cnt_p - 16 * qt);
-        const int gidx = P.g_qoff[p] + 16 * qt + j;
+        const int gidx = inf.qoff + 16 * qt + j;
+        // grouped entry of this lane's query + record slots for the segment: issued FIRST so that they return first
+        // (loads complete in order); the first tile's loads go out right behind them and fly under the query staging
         const int myq = (j < nq) ? P.grouped_q[gidx] : -1;
         const int mypair = (j < nq) ? P.grouped_pair[gidx] : -1;
-        // ---- query tile -> LDS in B-operand lane order (wave-private); loads batched DB at a time ---------------
-        {
-            const int qsafe = myq >= 0 ? myq : 0;
-            const float4 *qsrc = P.xq4 + (int64_t)qsafe * nblk * 4 + g;
-            for (int cb0 = 0; cb0 < nblk; cb0 += DB) {
-                float4 qv[DB];
-#pragma unroll
-                for (int b = 0; b < DB; b++) qv[b] = qsrc[(cb0 + b) * 4];
-#pragma unroll
-                for (int b = 0; b < DB; b++) {
-                    if (myq < 0) qv[b] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    qs[(cb0 + b) * 64 + lane] = qv[b];
-                }
-            }
-        }
+        int base_rec = 0;
+        if (QK_OPT_EARLY_REC && MODE == 0 && lane == 0) base_rec = atomicAdd(P.rec_counter, nq);
         uint32_t tau = 0xFFFFFFFFu;
-        if (myq >= 0 && P.gtau) tau = __hip_atomic_load(&P.gtau[myq], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         int cnt = 0;
-        const float xnj = (myq >= 0 && l2) ? P.xn[myq] : 0.0f;
+        float xnj = 0.0f;
         {
             const int64_t tile_abs0 = (row_off >> 4) + tl;
             const float4 *src = P.vecs + tile_abs0 * nblk * 64 + lane;
@@ -314,10 +342,12 @@ __global__ __launch_bounds__(64) void k_scan(ScanParams P) {
             // ids of this lane's 4 rows travel with the tile (static prefetch): an id load inside the append path
             // would force s_waitcnt vmcnt(0) and drain the prefetched tile every time a candidate passes
             const longlong2 *isrc = (const longlong2 *)(P.ids + (tile_abs0 << 4)) + 2 * g;  // +8 longlong2 per tile
-            longlong2 id_cur0 = {0, 0}, id_cur1 = {0, 0}, id_next0 = {0, 0}, id_next1 = {0, 0};
+            // norms + ids are double-buffered with the tile data (y0/i0* with a0, y1/i1* with a1): no register copies,
+            // so the only wait on a buffer is its first use -- after the following step's loads have been issued
+            longlong2 i00 = {0, 0}, i01 = {0, 0}, i10 = {0, 0}, i11 = {0, 0};
             const int nsteps = (tend - tl) * ncd;
             float4 a0[DB], a1[DB];
-            float4 yn_cur = make_float4(0.f, 0.f, 0.f, 0.f), yn_next = yn_cur;
+            float4 y0 = make_float4(0.f, 0.f, 0.f, 0.f), y1 = y0;
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
             float probe_sink = 0.f;
             int dch = 0;    // d-chunk of the step being computed
@@ -328,13 +358,13 @@ __global__ __launch_bounds__(64) void k_scan(ScanParams P) {
             // The load stream is STATIC (same loads every iteration, clamped at the end of the segment) so that the
             // compiler can place counted s_waitcnt vmcnt(N) and keep the next step's loads in flight under the MFMAs.
             int lS = 0;  // next step to load (clamped to nsteps-1)
-#define QK_LOAD(A)                                                    \
+#define QK_LOAD(A, Y, I0, I1)                                         \
     {                                                                 \
         const float4 *pp_ = src + (int64_t)lS * (DB * 64);            \
         _Pragma("unroll") for (int b_ = 0; b_ < DB; b_++) A[b_] = pp_[b_ * 64]; \
-        yn_next = nsrc[(int64_t)ltile * 4];                           \
-        id_next0 = isrc[(int64_t)ltile * 8];                          \
-        id_next1 = isrc[(int64_t)ltile * 8 + 1];                      \
+        Y = nsrc[(int64_t)ltile * 4];                                 \
+        I0 = isrc[(int64_t)ltile * 8];                                \
+        I1 = isrc[(int64_t)ltile * 8 + 1];                            \
         if (lS < nsteps - 1) {                                        \
             lS++;                                                     \
             if (++ldch == ncd) {                                      \
@@ -344,7 +374,7 @@ __global__ __launch_bounds__(64) void k_scan(ScanParams P) {
         }                                                             \
     }
 
-#define QK_STEP(A, LIVE)                                                                                    \
+#define QK_STEP(A, Y, I0, I1, LIVE)                                                                                    \
     {                                                                                                      \
         if (dch == 0) acc = (f32x4){0.f, 0.f, 0.f, 0.f};                                                   \
         _Pragma("unroll") for (int b_ = 0; b_ < DB; b_++) {                                                \
@@ -364,73 +394,101 @@ __global__ __launch_bounds__(64) void k_scan(ScanParams P) {
         if (++dch == ncd) {                                                                                \
             dch = 0;                                                                                       \
             if (MODE == 0) {                                                                               \
-                epilogue(tile, LIVE);                                                                      \
+                epilogue(tile, LIVE, Y, I0, I1);                                                           \
             } else {                                                                                       \
-                probe_sink += acc[0] + acc[1] + acc[2] + acc[3] + yn_cur.x + (float)id_cur0.x;             \
-                yn_cur = yn_next;                                                                          \
-                id_cur0 = id_next0;                                                                        \
-                id_cur1 = id_next1;                                                                        \
+                probe_sink += acc[0] + acc[1] + acc[2] + acc[3] + Y.x + (float)I0.x + (float)I1.x;         \
             }                                                                                              \
             tile++;                                                                                        \
         }                                                                                                  \
     }
 
-            auto epilogue = [&](int tl_, bool live) {
+            auto epilogue = [&](int tl_, bool live, const float4 yn, const longlong2 ia, const longlong2 ib) {
                 const int row0 = tl_ << 4;
-                const float yv[4] = {yn_cur.x, yn_cur.y, yn_cur.z, yn_cur.w};
-                const int64_t idv[4] = {id_cur0.x, id_cur0.y, id_cur1.x, id_cur1.y};
+                const float yv[4] = {yn.x, yn.y, yn.z, yn.w};
+                const int64_t idv[4] = {ia.x, ia.y, ib.x, ib.y};
+                // every 8 tiles pick up bounds published by other waves working on the same query (only when queries
+                // probe more than one partition: gtau is null otherwise).  Measured (scan_probe.py, 10M x 128, P=32)
+                // against a per-tile plain (L1-stale) load, a per-tile sc1 load in the prefetch stream and an
+                // exchange at compaction time: this variant is 5-25 % faster although consuming the load drains
+                // the prefetched tile.
+                if (P.gtau && (tl_ & 7) == 7 && myq >= 0)
+                    tau = min(tau, __hip_atomic_load(&P.gtau[myq], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                uint32_t ordv[4];
+                bool anyp = false;
 #pragma unroll
                 for (int reg = 0; reg < 4; reg++) {
                     const int row = row0 + 4 * g + reg;
                     const bool valid = live && (myq >= 0) && (row < size_p);
                     const float v = acc[reg];
-                    const uint32_t ord = l2 ? ord_from_l2(l2_expanded(xnj, yv[reg], v)) : ord_from_ip(v);
-                    const bool pass = valid && ord <= tau;
-                    const uint64_t m = __ballot(pass);
-                    if (m) {
-                        const uint64_t gm = m & (0x0001000100010001ull << j);
-                        if (pass) {
-                            const int slot = cnt + __popcll(gm & ((1ull << lane) - 1ull));
-                            my_ord[slot] = ord;
-                            my_id[slot] = idv[reg];
-                        }
-                        cnt += __popcll(gm);
-                        uint64_t need = __ballot(cnt > C - 4) & 0xFFFFull;
-                        while (need) {
-                            const int jq = __ffsll((unsigned long long)need) - 1;
-                            need &= need - 1;
-                            const int n = __builtin_amdgcn_readlane(cnt, jq);
-                            const int nn = compact_pool<MAXCH>(pool_ord + jq * C, pool_id + jq * C, n, k, lane);
-                            if (j == jq) {
-                                cnt = nn;
-                                if (nn >= k) {
-                                    tau = min(tau, pool_ord[jq * C + k - 1]);
-                                    // exchange bounds with the other waves working on this query -- here, in the slow
-                                    // path, because consuming a load drains the prefetched tile (in-order vmcnt): a
-                                    // wave with a loose bound compacts often and so refreshes often, a tight one never
-                                    if (P.gtau) {  // all 4 lanes of the query, so that they keep one common bound
-                                        const uint32_t other = atomicMin(&P.gtau[myq], tau);
-                                        tau = min(tau, other);
+                    const uint32_t o = l2 ? ord_from_l2(l2_expanded(xnj, yv[reg], v)) : ord_from_ip(v);
+                    ordv[reg] = valid ? o : 0xFFFFFFFFu;  // an invalid row can never pass (tau < 0xFFFFFFFF once set; see below)
+                    anyp |= valid && o <= tau;
+                }
+                // steady state: nothing beats the running k-th best -> one ballot, one branch per tile
+                if (!QK_OPT_ONE_BALLOT || __ballot(anyp)) {
+#pragma unroll
+                    for (int reg = 0; reg < 4; reg++) {
+                        const uint32_t ord = ordv[reg];
+                        const bool pass = ord != 0xFFFFFFFFu && ord <= tau;
+                        const uint64_t m = __ballot(pass);
+                        if (m) {
+                            const uint64_t gm = m & (0x0001000100010001ull << j);
+                            if (pass) {
+                                const int slot = cnt + __popcll(gm & ((1ull << lane) - 1ull));
+                                my_ord[slot] = ord;
+                                my_id[slot] = idv[reg];
+                            }
+                            cnt += __popcll(gm);
+                            uint64_t need = __ballot(cnt > C - 4) & 0xFFFFull;
+                            while (need) {
+                                const int jq = __ffsll((unsigned long long)need) - 1;
+                                need &= need - 1;
+                                const int n = __builtin_amdgcn_readlane(cnt, jq);
+                                const int nn = compact_pool<MAXCH>(pool_ord + jq * C, pool_id + jq * C, n, k, lane);
+                                if (j == jq) {
+                                    cnt = nn;
+                                    if (nn >= k) {
+                                        tau = min(tau, pool_ord[jq * C + k - 1]);
+                                        // publish (fire and forget: no returned value, no wait)
+                                        if (P.gtau && lane < 16) atomicMin(&P.gtau[myq], tau);
                                     }
                                 }
                             }
                         }
                     }
                 }
-                yn_cur = yn_next;
-                id_cur0 = id_next0;
-                id_cur1 = id_next1;
             };
 
-            QK_LOAD(a0);
-            yn_cur = yn_next;
-            id_cur0 = id_next0;
-            id_cur1 = id_next1;
+            if (QK_OPT_EARLY_LOAD) QK_LOAD(a0, y0, i00, i01);
+            // ---- query tile -> LDS in B-operand lane order (wave-private), while the first tile is in flight --------
+            {
+                const int qsafe = myq >= 0 ? myq : 0;
+                const float4 *qsrc = P.xq4 + (int64_t)qsafe * nblk * 4 + g;
+                if (P.gtau) tau = __hip_atomic_load(&P.gtau[qsafe], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (l2) xnj = P.xn[qsafe];
+                for (int cb0 = 0; cb0 < nblk; cb0 += DB) {
+                    float4 qv[DB];
+#pragma unroll
+                    for (int b = 0; b < DB; b++) qv[b] = qsrc[(cb0 + b) * 4];
+#pragma unroll
+                    for (int b = 0; b < DB; b++) {
+                        if (myq < 0) qv[b] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        qs[(cb0 + b) * 64 + lane] = qv[b];
+                    }
+                }
+                if (myq < 0) {
+                    tau = 0xFFFFFFFFu;
+                    xnj = 0.0f;
+                }
+            }
+            if (!QK_OPT_EARLY_LOAD) QK_LOAD(a0, y0, i00, i01);
             for (int s = 0; s < nsteps; s += 2) {
-                QK_LOAD(a1);
-                QK_STEP(a0, true);
-                QK_LOAD(a0);
-                QK_STEP(a1, s + 1 < nsteps);
+                QK_LOAD(a1, y1, i10, i11);
+                QK_STEP(a0, y0, i00, i01, true);
+                if (QK_OPT_STEP_DRAIN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                QK_LOAD(a0, y0, i00, i01);
+                QK_STEP(a1, y1, i10, i11, s + 1 < nsteps);
+                if (QK_OPT_STEP_DRAIN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
 #undef QK_LOAD
 #undef QK_STEP
@@ -448,16 +506,23 @@ __global__ __launch_bounds__(64) void k_scan(ScanParams P) {
             }
             const uint64_t have = __ballot(cnt > 0) & 0xFFFFull;
             if (have) {
-                const int nrec = __popcll(have);
-                int base_rec = 0;
-                if (lane == 0) base_rec = atomicAdd(P.rec_counter, nrec);
-                base_rec = __builtin_amdgcn_readfirstlane(base_rec);
+                // record slots were reserved at segment start (base_rec .. base_rec + nq): no atomic round trip here
+                if (!QK_OPT_EARLY_REC && lane == 0) base_rec = atomicAdd(P.rec_counter, nq);
+                const int rec0 = __builtin_amdgcn_readfirstlane(base_rec);
                 int myrec = -1;
                 if (lane < 16 && cnt > 0) {
-                    myrec = base_rec + __popcll(have & ((1ull << lane) - 1ull));
+                    myrec = rec0 + lane;
                     if (myrec < P.max_recs) {
                         P.rec_cnt[myrec] = cnt;
-                        P.rec_next[myrec] = atomicExch(&P.pair_head[mypair], myrec);
+                        // the store of the previous head is deferred to the next emit (or kernel end) so that the
+                        // wave does not stall on the exchange's round trip
+                        if (pend_rec >= 0) P.rec_next[pend_rec] = pend_old;
+                        pend_old = atomicExch(&P.pair_head[mypair], myrec);
+                        pend_rec = myrec;
+                        if (!QK_OPT_EARLY_REC) {
+                            P.rec_next[pend_rec] = pend_old;
+                            pend_rec = -1;
+                        }
                         if (P.gtau && cnt >= k) atomicMin(&P.gtau[myq], my_ord[k - 1]);
                     }
                 }
@@ -476,6 +541,7 @@ __global__ __launch_bounds__(64) void k_scan(ScanParams P) {
             }
         }
     }
+    if (pend_rec >= 0) P.rec_next[pend_rec] = pend_old;
 }
 
 // ---- merge kernel: one wave per query ---------------------------------------------------------------------
@@ -713,9 +779,8 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
     size_t need = 0;
     auto add = [&](size_t b) { need += (b + 255) & ~(size_t)255; };
     add((size_t)npids * 4 * 2 + 256 + 64);
-    add((size_t)npids * 4 + 64);
+    add((size_t)(npids + 1) * sizeof(ActiveInfo) + 64);
     add((size_t)(npids + 1) * 4 + 64);
-    add((size_t)(npids + 1) * 8 + 64);
     add((size_t)np1 * 4 * 3);
     add((size_t)Q * 4);
     add((size_t)max_recs * 8);
@@ -731,9 +796,8 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
     int32_t *g_cnt = (int32_t *)qk_ws_alloc(ctx, zero_bytes + 64);
     int32_t *g_cursor = g_cnt + npids;
     int32_t *scal = g_cursor + npids;
-    int32_t *active_p = (int32_t *)qk_ws_alloc(ctx, (size_t)npids * 4 + 64);
+    ActiveInfo *active = (ActiveInfo *)qk_ws_alloc(ctx, (size_t)(npids + 1) * sizeof(ActiveInfo) + 64);
     int32_t *g_qoff = (int32_t *)qk_ws_alloc(ctx, (size_t)(npids + 1) * 4 + 64);
-    int64_t *active_toff = (int64_t *)qk_ws_alloc(ctx, (size_t)(npids + 1) * 8 + 64);
     // scal layout (int32 units): [0] n_active, [1] rec_counter, [2..3] n_rows_unique (i64), [4..5] n_tiles (i64)
     int32_t *n_active = scal, *rec_counter = scal + 1;
     int64_t *n_rows_unique = (int64_t *)(scal + 2);
@@ -746,7 +810,7 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
     int32_t *rec_cnt = rec_next + max_recs;
     uint32_t *rec_ord = (uint32_t *)qk_ws_alloc(ctx, (size_t)max_recs * k * 4);
     int64_t *rec_id = (int64_t *)qk_ws_alloc(ctx, (size_t)max_recs * k * 8);
-    if (!g_cnt || !active_p || !g_qoff || !active_toff || !grouped_q || !gtau || !rec_next || !rec_ord || !rec_id)
+    if (!g_cnt || !active || !g_qoff || !grouped_q || !gtau || !rec_next || !rec_ord || !rec_id)
         QK_FAIL(QK_ERR_OOM, "qk_scan: workspace exhausted");
 
     QK_TRY(pe.mark(0));
@@ -762,8 +826,8 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
     G.g_cursor = g_cursor;
     G.g_qoff = g_qoff;
     G.n_active = n_active;
-    G.active_p = active_p;
-    G.active_toff = active_toff;
+    G.active = active;
+    G.pt_off = s->d_off;
     G.n_tiles = n_tiles;
     G.n_rows_unique = n_rows_unique;
     G.grouped_q = grouped_q;
@@ -788,13 +852,15 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
         sp.xn = xn;
         sp.grouped_q = grouped_q;
         sp.grouped_pair = grouped_pair;
-        sp.g_cnt = g_cnt;
-        sp.g_qoff = g_qoff;
         sp.n_active = n_active;
-        sp.active_p = active_p;
-        sp.active_toff = active_toff;
+        sp.active = active;
         sp.n_tiles = n_tiles;
-        sp.gtau = a.share_tau ? gtau : nullptr;
+        sp.gtau = (a.share_tau && P > 1) ? gtau : nullptr;  // one partition per query: nothing to share
+        static const int probe_tau0 = getenv("QK_SCAN_TAU0") ? atoi(getenv("QK_SCAN_TAU0")) : 0;
+        if (probe_tau0) {  // probe: a bound of 0 -> nothing ever passes (isolates the steady-state epilogue cost)
+            QK_HIP(hipMemsetAsync(gtau, 0, (size_t)Q * 4, st));
+            sp.gtau = gtau;
+        }
         sp.k = k;
         sp.C = C;
         sp.metric = a.metric;
