@@ -302,30 +302,40 @@ def main():
         hv, hi, ho, hc = host_csr
         qh = q.cpu().numpy()
         cores = O.max_threads()
-        # bounded sample: the bench batch is replayed until ~cpu_seconds of host work have been timed
-        t_cpu, ns, reps = 0.0, 0, 0
-        ci_ = None
-        while t_cpu < args.cpu_seconds and reps < 10000:
-            t0 = time.perf_counter()
-            ci_, cd_ = O.search(qh, hc, hv, hi, ho, nprobe, k, "l2", batched_scan=False, num_threads=cores)
-            t_cpu += time.perf_counter() - t0
-            ns += Q
-            reps += 1
-        n1 = max(1, min(Q, int(Q * 3.0 / max(t_cpu / reps * cores, 1e-3)) or 1))  # ~3 s single-threaded
-        n1 = min(n1, Q)
+        # bounded sample: the bench batch is replayed until ~cpu_seconds of host work have been timed, for both of the
+        # reference's scan variants (serial_scan = its default, batched_serial_scan = SearchParams::batched_scan);
+        # the faster one is reported as the baseline
+        def time_cpu(batched, budget):
+            t, n, reps, ids = 0.0, 0, 0, None
+            while t < budget and reps < 10000:
+                t0 = time.perf_counter()
+                ids, _ = O.search(qh, hc, hv, hi, ho, nprobe, k, "l2", batched_scan=batched, num_threads=cores)
+                t += time.perf_counter() - t0
+                n += Q
+                reps += 1
+            return n / t, n, reps, t, ids
+
+        qps_serial, ns_s, reps_s, t_s, ci_ = time_cpu(False, args.cpu_seconds * 0.6)
+        qps_batched, ns_b, reps_b, t_b, _ = time_cpu(True, args.cpu_seconds * 0.4)
+        best_batched = qps_batched > qps_serial
+        cpu_qps = max(qps_serial, qps_batched)
+        ns, reps, t_cpu = (ns_b, reps_b, t_b) if best_batched else (ns_s, reps_s, t_s)
+        n1 = max(1, min(Q, int(3.0 * qps_serial / max(cores, 1) * 4) or 1))  # a few seconds single-threaded
         t0 = time.perf_counter()
         O.search(qh[:n1], hc, hv, hi, ho, nprobe, k, "l2", batched_scan=False, num_threads=1)
         t_cpu1 = time.perf_counter() - t0
         # the CPU path returns the same neighbours (direct-form L2 vs expanded: ids equal unless near-tied)
         same = float((ci_ == ri.cpu().numpy()).mean())
         result["cpu_baseline"] = {
-            "value": round(ns / t_cpu, 1), "unit": "queries/s", "cores": cores, "kind": "port",
-            "sample": f"the {Q}-query bench batch replayed {reps}x ({ns} queries), same index/nprobe/k, oracle "
-                      f"search() = coarse + serial_scan semantics, parallel_for over queries on {cores} threads, {t_cpu:.1f}s",
+            "value": round(cpu_qps, 1), "unit": "queries/s", "cores": cores, "kind": "port",
+            "sample": f"the {Q}-query bench batch replayed {reps}x ({ns} queries), same index/nprobe/k, oracle search() = "
+                      f"coarse + {'batched_serial_scan' if best_batched else 'serial_scan'} semantics on {cores} threads, "
+                      f"{t_cpu:.1f}s (the faster of the reference's two scan variants)",
+            "serial_scan_qps": round(qps_serial, 1), "batched_scan_qps": round(qps_batched, 1),
             "single_thread_qps": round(n1 / t_cpu1, 1),
             "ids_equal_to_gpu_frac": round(same, 5),
         }
-        result["speedup_vs_cpu"] = round(qps / (ns / t_cpu), 1)
+        result["speedup_vs_cpu"] = round(qps / cpu_qps, 1)
     elif world == 1:
         result["cpu_baseline"] = None
 

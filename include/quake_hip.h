@@ -152,6 +152,13 @@ QK_API int qk_kmeans_assign(qk_ctx *ctx, const float *x, int64_t n, const float 
  * (clustering.cpp:162-176 accumulate loop / faiss::Clustering mean update). sums [m][d], counts [m]. */
 QK_API int qk_kmeans_accumulate(qk_ctx *ctx, const float *x, int64_t n, int d, const int64_t *assign, int64_t m,
                                 float *sums, int64_t *counts, int mem);
+/* kmeans_refine_partitions() (clustering.cpp:99-182) together with the partition replacement of
+ * PartitionManager::refine_partitions (partition_manager.cpp:446-487), applied to the device store: the vectors of the m
+ * lists `list_nos` (host array) are re-assigned to the nearest of the m centroids [m][d] (in `mem`; row c = centroid of
+ * list_nos[c]) for max(refinement_iterations, 1) passes, centroids recomputed between passes; on return list_nos[c] holds
+ * the vectors assigned to centroid c (append order of the reference) and `centroids` the ones used for the last pass. */
+QK_API int qk_store_refine_lists(qk_store *s, const int64_t *list_nos, int64_t m, float *centroids, int metric,
+                                 int refinement_iterations, int mem);
 /* kmeans() (clustering.cpp:13-97): Lloyd iterations on the GPU.  x [n][d] (IP: normalised IN PLACE, as the
  * reference stores the normalised copy, clustering.cpp:25-26,71); centroids [m][d] out; assign [n] out =
  * final full assignment.  seed drives the documented splitmix64 initialisation. */

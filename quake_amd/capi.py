@@ -278,5 +278,14 @@ class Store:
         check(self.lib.qk_store_get_vector(self.h, int(vid), _ptr(out), C.byref(found)))
         return out if found.value else None
 
+    def refine_lists(self, list_nos, centroids, metric, refinement_iterations=0):
+        """kmeans_refine_partitions on the device store; returns the centroids used for the last assignment."""
+        list_nos = np.ascontiguousarray(list_nos, dtype=np.int64)
+        c = _f32(centroids)
+        c = c.clone() if _is_torch(c) else c.copy()
+        check(self.lib.qk_store_refine_lists(self.h, _ptr(list_nos), list_nos.shape[0], _ptr(c), metric_code(metric),
+                                             int(refinement_iterations), _mem_of(c)))
+        return c
+
     def device_bytes(self):
         return self.lib.qk_store_device_bytes(self.h)

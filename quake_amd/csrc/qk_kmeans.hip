@@ -278,6 +278,20 @@ __global__ void k_gather_rows(const float *__restrict__ x, int d, const int64_t 
     out[idx] = x[rows[i] * d + (idx - i * d)];
 }
 
+__global__ void k_gather_rows_i32(const float *__restrict__ x, int d, const int32_t *__restrict__ rows, int64_t n,
+                                  float *__restrict__ out) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * d) return;
+    int64_t i = idx / d;
+    out[idx] = x[(int64_t)rows[i] * d + (idx - i * d)];
+}
+
+__global__ void k_gather_ids_i32(const int64_t *__restrict__ ids, const int32_t *__restrict__ rows, int64_t n,
+                                 int64_t *__restrict__ out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = ids[rows[i]];
+}
+
 // ---- host side ----------------------------------------------------------------------------------------------
 static inline unsigned km_grid(int64_t n, int b) { return (unsigned)((n + b - 1) / b); }
 
@@ -503,6 +517,89 @@ int qk_kmeans_accumulate(qk_ctx *ctx, const float *x, int64_t n, int d, const in
         QK_HIP(hipMemcpyAsync(counts, bc, (size_t)m * 8, hipMemcpyDeviceToHost, ctx->stream));
     }
     QK_HIP(hipStreamSynchronize(ctx->stream));
+    return QK_OK;
+}
+
+// kmeans_refine_partitions (clustering.cpp:99-182) + the partition replacement of PartitionManager::refine_partitions
+// (partition_manager.cpp:446-487), on the device store.  list_nos [m] (host) name the partitions, centroids [m][d]
+// (in `mem`) are their centroids in the same order; on return they hold "the centroids used for the last
+// assignment" (:178) and list list_nos[c] holds the vectors assigned to centroid c, in append order (:174).
+int qk_store_refine_lists(qk_store *s, const int64_t *list_nos, int64_t m, float *centroids, int metric,
+                          int refinement_iterations, int mem) {
+    if (!s || !list_nos || !centroids || m <= 0) QK_FAIL(QK_ERR_INVALID, "qk_store_refine_lists: bad arguments");
+    if (metric != QK_METRIC_L2 && metric != QK_METRIC_IP) QK_FAIL(QK_ERR_INVALID, "Metric type not supported");
+    qk_ctx *ctx = s->ctx;
+    QK_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const int d = s->d;
+    int64_t total = 0;
+    for (int64_t c = 0; c < m; c++) {
+        int64_t p = list_nos[c];
+        if (p < 0 || p >= (int64_t)s->parts.size() || !s->parts[p].present)
+            QK_FAIL(QK_ERR_NOT_FOUND, "List does not exist in refine_partitions (list %lld)", (long long)p);
+        for (int64_t c2 = 0; c2 < c; c2++)
+            if (list_nos[c2] == p) QK_FAIL(QK_ERR_INVALID, "qk_store_refine_lists: duplicate list %lld", (long long)p);
+        total += s->parts[p].size;
+    }
+    const int iterations = refinement_iterations > 0 ? refinement_iterations : 1;  // clustering.cpp:110
+    KmScratch ks;
+    float *xa, *xb, *dc, *dsums, *ctile, *cnorm;
+    int64_t *ia, *ib, *dassign, *dcounts;
+    const int dpad = qk_round_up(d, 16);
+    const int64_t mt16 = ((m + 15) / 16) * 16;
+    QK_TRY(ks.alloc(&xa, (size_t)total * d));
+    QK_TRY(ks.alloc(&xb, (size_t)total * d));
+    QK_TRY(ks.alloc(&ia, (size_t)total));
+    QK_TRY(ks.alloc(&ib, (size_t)total));
+    QK_TRY(ks.alloc(&dassign, (size_t)total));
+    QK_TRY(ks.alloc(&dc, (size_t)m * d));
+    QK_TRY(ks.alloc(&dsums, (size_t)m * d));
+    QK_TRY(ks.alloc(&dcounts, (size_t)m));
+    QK_TRY(ks.alloc(&ctile, (size_t)mt16 * dpad));
+    QK_TRY(ks.alloc(&cnorm, (size_t)mt16));
+    QK_HIP(hipMemcpyAsync(dc, centroids, (size_t)m * d * 4, mem == QK_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, st));
+    // concatenate the partitions in the given order (row order inside a partition = arena order)
+    int64_t pos = 0;
+    for (int64_t c = 0; c < m; c++) {
+        const qk_part &pt = s->parts[list_nos[c]];
+        if (pt.size == 0) continue;
+        QK_TRY(qk_launch_extract(ctx, s->vecs, s->nblk, d, pt.row_off, nullptr, pt.size, xa + pos * d));
+        QK_HIP(hipMemcpyAsync(ia + pos, s->ids + pt.row_off, (size_t)pt.size * 8, hipMemcpyDeviceToDevice, st));
+        pos += pt.size;
+    }
+    AccumScratch as;
+    QK_TRY(accum_prepare(ks, as, std::max<int64_t>(total, 1), m));
+    std::vector<int64_t> hcounts((size_t)m, 0);
+    for (int iter = 0; iter < iterations; iter++) {
+        if (iter > 0)  // centroids = sums / counts; a count of 0 gives NaN exactly like the reference (:122-124)
+            hipLaunchKernelGGL(k_finalize_centroids, dim3(km_grid(m * d, 256)), dim3(256), 0, st, dsums, dcounts, m, d, 0, dc);
+        QK_TRY(assign_device(ctx, xa, total, dc, m, d, metric, dassign, nullptr, ctile, cnorm));
+        QK_TRY(accumulate_device(ctx, as, xa, total, d, dassign, m, dsums, dcounts));
+        // stable bucket by assignment == the per-vector append into the new partitions (:174); accumulate_device left
+        // the stably sorted row list in as.vals2
+        if (total > 0) {
+            hipLaunchKernelGGL(k_gather_rows_i32, dim3(km_grid(total * d, 256)), dim3(256), 0, st, xa, d, as.vals2, total, xb);
+            hipLaunchKernelGGL(k_gather_ids_i32, dim3(km_grid(total, 256)), dim3(256), 0, st, ia, as.vals2, total, ib);
+        }
+        std::swap(xa, xb);
+        std::swap(ia, ib);
+    }
+    QK_HIP(hipMemcpyAsync(hcounts.data(), dcounts, (size_t)m * 8, hipMemcpyDeviceToHost, st));
+    QK_HIP(hipMemcpyAsync(centroids, dc, (size_t)m * d * 4, mem == QK_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, st));
+    QK_HIP(hipStreamSynchronize(st));
+    int64_t assigned = 0;
+    for (int64_t c = 0; c < m; c++) assigned += hcounts[c];
+    if (assigned != total)
+        QK_FAIL(QK_ERR_INVALID, "qk_store_refine_lists: %lld of %lld vectors could not be assigned (NaN centroid from an emptied cluster)",
+                (long long)(total - assigned), (long long)total);
+    // replace the partitions (partition_manager.cpp:481-483)
+    pos = 0;
+    for (int64_t c = 0; c < m; c++) {
+        QK_TRY(qk_store_remove_list(s, list_nos[c]));
+        QK_TRY(qk_store_add_list(s, list_nos[c]));
+        if (hcounts[c] > 0) QK_TRY(qk_store_add_entries(s, list_nos[c], hcounts[c], ia + pos, xa + pos * d, QK_MEM_DEVICE));
+        pos += hcounts[c];
+    }
     return QK_OK;
 }
 

@@ -226,7 +226,7 @@ class QuakeIndex:
             self.parent = None
             info.n_clusters = 1
             self._next_pid = 1
-        self._resident = set(ids.reshape(-1).tolist()) if self.current_level == 0 else set()
+        self._resident = set(ids.reshape(-1).tolist())
         self.initialize_maintenance_policy(MaintenancePolicyParams())
         info.total_time_us = _us(t_total)
         return info
@@ -356,6 +356,22 @@ class QuakeIndex:
         self.remove(ids)
         return self.add(x, ids)
 
+    # -- local refinement (partition_manager.cpp:446-487 -> kmeans_refine_partitions, clustering.cpp:99-182) ----------------
+    def refine_partitions(self, partition_ids=None, iterations=0):
+        """PartitionManager::refine_partitions: re-assign the vectors of the given partitions among their centroids on the
+        GPU (assign = MFMA kernel, update = ordered sums), replace the partitions, write the centroids back to the parent
+        with parent_->modify (:478)."""
+        self._require_built("[PartitionManager] refine_partitions: index not built")
+        if self.parent is None:
+            return
+        if partition_ids is None:
+            partition_ids = self.parent.get_ids()
+        if partition_ids.shape[0] == 0:
+            return
+        cent = self.parent.get(partition_ids)
+        new_c = self._store.refine_lists(partition_ids.reshape(-1).cpu().numpy(), cent.numpy(), self.metric_, int(iterations))
+        self.parent.modify(partition_ids, torch.from_numpy(np.ascontiguousarray(new_c)))
+
     # -- maintenance (quake_index.cpp:152-163) ------------------------------------------------------------------------------
     def initialize_maintenance_policy(self, maintenance_policy_params):
         self.maintenance_policy_params_ = maintenance_policy_params
@@ -441,8 +457,7 @@ class QuakeIndex:
             self._store.add_list(int(pids[i]))
             if nv:
                 self._store.add_entries(int(pids[i]), ids.copy(), vecs.copy())
-            if self.current_level == 0:
-                self._resident.update(ids.tolist())
+            self._resident.update(ids.tolist())
         self._next_pid = (int(pids.max()) + 1) if nparts else 0
         pdir = os.path.join(dir_path, "parent")
         if os.path.isdir(pdir):

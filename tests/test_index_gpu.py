@@ -202,3 +202,16 @@ def test_large_dimension(quake):  # quake_index.cpp d = 1024 stress case
     gt = torch.topk(torch.cdist(q.double(), x.double()), 10, dim=1, largest=False)
     np.testing.assert_array_equal(r.ids.numpy(), gt.indices.numpy())
     np.testing.assert_allclose(r.distances.numpy(), gt.values.numpy(), atol=1e-3)
+
+
+def test_refine_partitions_keeps_everything_searchable(quake, data):  # partition_manager.cpp:121-167 spirit
+    x, ids, q = data
+    idx, _ = build(quake, x, ids, NLIST)
+    before = idx.ntotal()
+    idx.refine_partitions(torch.tensor([1, 3, 5]), iterations=2)
+    assert idx.ntotal() == before and idx.nlist() == NLIST and idx.parent.ntotal() == NLIST
+    assert set(idx.get_ids().tolist()) == set(range(NVEC))
+    sp = quake.SearchParams()
+    sp.k, sp.nprobe = 1, NLIST
+    r = idx.search(x[:200], sp)  # every vector still finds itself
+    np.testing.assert_array_equal(r.ids.reshape(-1).numpy(), np.arange(200))

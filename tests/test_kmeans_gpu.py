@@ -81,3 +81,35 @@ def test_kmeans_subsample_and_empty_split(ctx):
     oc, oa, _ = O.kmeans(x2, 10, "l2", niter=3, seed=9)
     np.testing.assert_array_equal(gc.view(np.uint32), oc.view(np.uint32))
     np.testing.assert_array_equal(ga, oa)
+
+
+@pytest.mark.parametrize("metric", ["l2", "ip"])
+@pytest.mark.parametrize("iters", [0, 1, 3])
+def test_refine_partitions_matches_oracle(ctx, metric, iters):
+    """kmeans_refine_partitions (clustering.cpp:99-182) on the device store: centroids and the refined partitions
+    (ids in append order, vectors) equal the oracle's; with 0 iterations the sizes only move by re-assignment
+    (test/cpp/partition_manager.cpp:121-167)."""
+    from quake_amd.capi import Store
+    ivf = make_ivf(6000, 24, 12, seed=21, metric=metric)
+    s = Store(ctx, 24)
+    s.build_csr(ivf["offsets"], ivf["ids"], ivf["vecs"])
+    sel = np.array([7, 2, 9, 4, 11], np.int64)  # a subset, in a non-sorted order
+    # slightly off-centre centroids so that vectors really move
+    rng = np.random.default_rng(5)
+    cent = (ivf["centroids"][sel] + 0.05 * rng.standard_normal((5, 24))).astype(np.float32)
+    pv = [ivf["part_vecs"][p] for p in sel]
+    pi = [ivf["part_ids"][p] for p in sel]
+    vecs, ids, offs = O.csr_from_partitions(pv, pi, 24)
+    oc, ov, oi, oo = O.kmeans_refine_partitions(cent, vecs, ids, offs, metric, iters)
+    gc = s.refine_lists(sel, cent, metric, iters)
+    np.testing.assert_array_equal(gc.view(np.uint32), oc.view(np.uint32))
+    total = 0
+    for c, p in enumerate(sel):
+        gv, gi = s.get_list(int(p))
+        np.testing.assert_array_equal(gi, oi[oo[c]:oo[c + 1]])
+        np.testing.assert_array_equal(gv, ov[oo[c]:oo[c + 1]])
+        total += len(gi)
+    assert total == len(ids) and s.ntotal() == 6000
+    # untouched partitions are untouched
+    gv, gi = s.get_list(0)
+    np.testing.assert_array_equal(gi, ivf["part_ids"][0])
