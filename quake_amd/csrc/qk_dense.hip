@@ -157,6 +157,30 @@ __global__ __launch_bounds__(64) void k_select_rows(SelectParams S) {
     const uint32_t *row = S.D + q * S.ld;
     uint32_t tau = 0xFFFFFFFFu;
     int cnt = 0;
+    // pass 1: a bound without any top-k bookkeeping.  Every lane keeps the minimum of the keys it sees; the k-th smallest
+    // of the 64 lane minima has at least k keys <= it, so it bounds the k-th best overall (k <= 64).  Without it the
+    // first 64+ keys all pass (tau = inf) and the pool is compacted several times per query.
+    if (k <= 64) {
+        uint32_t lmin = 0xFFFFFFFFu;
+        for (int base = 0; base < S.nrows; base += 1024) {
+            uint4 kv4[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int r0 = base + u * 256 + lane * 4;
+                kv4[u] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+                if (r0 < S.nrows) kv4[u] = *(const uint4 *)(row + r0);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) lmin = min(lmin, min(min(kv4[u].x, kv4[u].y), min(kv4[u].z, kv4[u].w)));
+        }
+        int rk = 0;
+        for (int t = 0; t < 64; t++) {
+            const uint32_t ot = __builtin_amdgcn_readlane(lmin, t);
+            rk += (ot < lmin || (ot == lmin && t < lane)) ? 1 : 0;
+        }
+        const uint64_t mk = __ballot(rk == k - 1);
+        tau = __builtin_amdgcn_readlane(lmin, __ffsll((unsigned long long)mk) - 1);
+    }
     // 4 keys per lane per load (16 B), 4 loads in flight: 1024 rows per wave step
     for (int base = 0; base < S.nrows; base += 1024) {
         uint4 kv4[4];

@@ -39,7 +39,7 @@ __device__ __forceinline__ int compact_pool(uint32_t *ord, int64_t *id, int n, i
         d[i] = has ? id[e] : LLONG_MAX;
         rk[i] = 0;
     }
-    if (MAXCH == 1) {
+    if (MAXCH == 1 || n <= 64) {  // (n is wave-uniform)
         // n <= 64: every entry lives in one lane; broadcast entry t with v_readlane (SGPR operands, no LDS round trip
         // per iteration) -- ~3x faster than re-reading the pool from LDS, and this is the cold-start cost of every segment
         const uint32_t dlo = (uint32_t)(uint64_t)d[0], dhi = (uint32_t)((uint64_t)d[0] >> 32);

@@ -249,8 +249,7 @@ struct ScanParams {
     int32_t *pair_head;
     int32_t *rec_counter;
     int32_t max_recs;
-    int32_t *rec_next;   // [max_recs]
-    int32_t *rec_cnt;    // [max_recs]
+    int2 *rec_hdr;       // [max_recs] {next record of the pair (-1 = end), entry count}
     uint32_t *rec_ord;   // [max_recs][k]
     int64_t *rec_id;     // [max_recs][k]
 };
@@ -319,7 +318,7 @@ __global__ __launch_bounds__(64) void k_scan(ScanParams P) {
     }
     int ai = lo;
     long long cur = T0;
-    int pend_rec = -1, pend_old = -1;  // deferred rec_next store of this lane's previous record
+    int pend_rec = -1, pend_old = -1, pend_cnt = 0;  // deferred header store of this lane's previous record
 
     while (cur < T1) {
         // ---- segment = tiles [tl, tend) of item (p, qt) ---------------------------------------------------------
@@ -526,14 +525,14 @@ __global__ __launch_bounds__(64) void k_scan(ScanParams P) {
                 if (lane < 16 && cnt > 0) {
                     myrec = rec0 + lane;
                     if (myrec < P.max_recs) {
-                        P.rec_cnt[myrec] = cnt;
                         // the store of the previous head is deferred to the next emit (or kernel end) so that the
                         // wave does not stall on the exchange's round trip
-                        if (pend_rec >= 0) P.rec_next[pend_rec] = pend_old;
+                        if (pend_rec >= 0) P.rec_hdr[pend_rec] = make_int2(pend_old, pend_cnt);
                         pend_old = atomicExch(&P.pair_head[mypair], myrec);
                         pend_rec = myrec;
+                        pend_cnt = cnt;
                         if (!QK_OPT_EARLY_REC) {
-                            P.rec_next[pend_rec] = pend_old;
+                            P.rec_hdr[pend_rec] = make_int2(pend_old, pend_cnt);
                             pend_rec = -1;
                         }
                         if (P.gtau && cnt >= k) atomicMin(&P.gtau[myq], my_ord[k - 1]);
@@ -554,15 +553,14 @@ __global__ __launch_bounds__(64) void k_scan(ScanParams P) {
             }
         }
     }
-    if (pend_rec >= 0) P.rec_next[pend_rec] = pend_old;
+    if (pend_rec >= 0) P.rec_hdr[pend_rec] = make_int2(pend_old, pend_cnt);
 }
 
 // ---- merge kernel: one wave per query ---------------------------------------------------------------------
 struct MergeParams {
     int P;
     const int32_t *pair_head;
-    const int32_t *rec_next;
-    const int32_t *rec_cnt;
+    const int2 *rec_hdr;
     const uint32_t *rec_ord;
     const int64_t *rec_id;
     int32_t max_recs;
@@ -587,18 +585,31 @@ __global__ __launch_bounds__(64) void k_merge(MergeParams M) {
     for (int r = 0; r < M.P; r++) {
         int rec = M.pair_head[q * M.P + r];
         while (rec >= 0 && rec < M.max_recs) {
-            const int n = M.rec_cnt[rec];
+            // header and the first 64 entries are requested together (entries beyond the count are ignored)
+            const int2 hdr = M.rec_hdr[rec];
+            uint32_t o0 = 0xFFFFFFFFu;
+            int64_t d0 = -1;
+            if (lane < k) {
+                o0 = M.rec_ord[(int64_t)rec * k + lane];
+                d0 = M.rec_id[(int64_t)rec * k + lane];
+            }
+            const int n = hdr.y;
             for (int base = 0; base < n; base += 64) {
                 const int e = base + lane;
                 const bool has = e < n;
-                const uint32_t o = has ? M.rec_ord[(int64_t)rec * k + e] : 0xFFFFFFFFu;
+                uint32_t o = o0;
+                int64_t dd = d0;
+                if (base > 0) {
+                    o = has ? M.rec_ord[(int64_t)rec * k + e] : 0xFFFFFFFFu;
+                    dd = has ? M.rec_id[(int64_t)rec * k + e] : -1;
+                }
                 const bool pass = has && o <= tau;
                 const uint64_t m = __ballot(pass);
                 if (m) {
                     if (pass) {
                         const int sl = cnt + __popcll(m & ((1ull << lane) - 1ull));
                         pool_ord[sl] = o;
-                        pool_id[sl] = M.rec_id[(int64_t)rec * k + e];
+                        pool_id[sl] = dd;
                     }
                     cnt += __popcll(m);
                     if (cnt > Cm - 64) {
@@ -609,7 +620,7 @@ __global__ __launch_bounds__(64) void k_merge(MergeParams M) {
                 // records are sorted ascending: once a valid lane fails the bound, the rest of the record fails too
                 if (__popcll(m) < min(64, n - base)) break;
             }
-            rec = M.rec_next[rec];
+            rec = hdr.x;
         }
     }
     cnt = compact_pool<MAXCH>(pool_ord, pool_id, cnt, k, lane);
@@ -819,11 +830,10 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
     int32_t *grouped_pair = grouped_q + np1;
     int32_t *pair_head = grouped_pair + np1;
     uint32_t *gtau = (uint32_t *)qk_ws_alloc(ctx, (size_t)Q * 4);
-    int32_t *rec_next = (int32_t *)qk_ws_alloc(ctx, (size_t)max_recs * 8);
-    int32_t *rec_cnt = rec_next + max_recs;
+    int2 *rec_hdr = (int2 *)qk_ws_alloc(ctx, (size_t)max_recs * 8);
     uint32_t *rec_ord = (uint32_t *)qk_ws_alloc(ctx, (size_t)max_recs * k * 4);
     int64_t *rec_id = (int64_t *)qk_ws_alloc(ctx, (size_t)max_recs * k * 8);
-    if (!g_cnt || !active || !g_qoff || !grouped_q || !gtau || !rec_next || !rec_ord || !rec_id)
+    if (!g_cnt || !active || !g_qoff || !grouped_q || !gtau || !rec_hdr || !rec_ord || !rec_id)
         QK_FAIL(QK_ERR_OOM, "qk_scan: workspace exhausted");
 
     QK_TRY(pe.mark(0));
@@ -880,8 +890,7 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
         sp.pair_head = pair_head;
         sp.rec_counter = rec_counter;
         sp.max_recs = (int32_t)max_recs;
-        sp.rec_next = rec_next;
-        sp.rec_cnt = rec_cnt;
+        sp.rec_hdr = rec_hdr;
         sp.rec_ord = rec_ord;
         sp.rec_id = rec_id;
         // do not launch (many) more waves than there are tiles to hand out
@@ -895,8 +904,7 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
     MergeParams mp;
     mp.P = P;
     mp.pair_head = pair_head;
-    mp.rec_next = rec_next;
-    mp.rec_cnt = rec_cnt;
+    mp.rec_hdr = rec_hdr;
     mp.rec_ord = rec_ord;
     mp.rec_id = rec_id;
     mp.max_recs = (int32_t)max_recs;
