@@ -132,7 +132,6 @@ __global__ void k_group_count(GroupParams G) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= G.npairs) return;
     G.pair_head[i] = -1;
-    if (i % G.P == 0) G.gtau[i / G.P] = 0xFFFFFFFFu;
     int p = pair_pid(G, i);
     if (p >= 0) atomicAdd(&G.g_cnt[p], 1);
 }
@@ -227,6 +226,92 @@ __global__ void k_group_scatter(GroupParams G) {
     }
 }
 
+// ---- bound seeding ---------------------------------------------------------------------------------------
+// One wave per (query, partition) pair: exact distances (same canonical chain as the MFMA path) from the query to the
+// first min(64, n_p) rows of the partition, one row per lane; the k-th smallest of them bounds the query's final k-th
+// best, and goes into gtau[q] with atomicMin.  k_scan then starts every segment with a bound instead of +inf, which
+// removes most of the cold-start appends/compactions (the slow path of the scan epilogue).
+struct SeedParams {
+    const int64_t *pids;  // [Q*P] or nullptr (pair i -> list i % P)
+    int64_t npairs;
+    int P;
+    const int32_t *pt_size;
+    const int64_t *pt_off;
+    int npids;
+    const float4 *vecs;
+    const float *norms;
+    int nblk;
+    int d;
+    const float *x;   // [Q][d] row-major queries
+    const float *xn;  // [Q]
+    int k;
+    int metric;
+    uint32_t *gtau;
+    int seed_ranks;      // pairs with r < seed_ranks are sampled (the nearest partitions give the tight bound)
+};
+
+// grid = Q * seed_ranks waves: wave w -> query w / seed_ranks, rank w % seed_ranks
+__global__ __launch_bounds__(64) void k_seed_tau(SeedParams S) {
+    const int lane = threadIdx.x;
+    const int64_t qq = blockIdx.x / S.seed_ranks;
+    const int rr = blockIdx.x % S.seed_ranks;
+    if (rr >= S.P) return;
+    const int64_t pair = qq * S.P + rr;
+    int64_t p = S.pids ? S.pids[pair] : (pair % S.P);
+    if (p < 0 || p >= S.npids) return;
+    const int size_p = S.pt_size[p];
+    if (size_p < S.k) return;  // fewer than k rows: no bound from this partition
+    const int n = min(size_p, 64);
+    const int64_t q = qq;
+    const float *xq = S.x + q * S.d;
+    const int lrow = min(lane, n - 1);  // idle lanes recompute the last row (keeps every load unconditional)
+    const int64_t row = S.pt_off[p] + lrow;
+    const int64_t tile = row >> 4;
+    const int r = (int)(row & 15);
+    const float yn = S.norms[row];
+    const float xnq = S.xn[q];
+    float acc = 0.0f;
+    // 8 blocks (128 columns) at a time: the 32 float4 of the lane's row and the 128 query values (2 per lane, broadcast
+    // with v_readlane) are requested together, then one k-ordered fmaf chain -- the same arithmetic as the MFMA path
+    for (int c0 = 0; c0 < S.nblk; c0 += 8) {
+        float4 v[8][4];
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            const int cc = min(c0 + c, S.nblk - 1);
+            const float4 *blk = S.vecs + (tile * S.nblk + cc) * 64 + r;
+#pragma unroll
+            for (int g = 0; g < 4; g++) v[c][g] = blk[g * 16];
+        }
+        const int colA = c0 * 16 + lane, colB = c0 * 16 + 64 + lane;
+        const float xa = colA < S.d ? xq[colA] : 0.0f;
+        const float xb = colB < S.d ? xq[colB] : 0.0f;
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            if (c0 + c < S.nblk) {
+                const float e[16] = {v[c][0].x, v[c][1].x, v[c][2].x, v[c][3].x, v[c][0].y, v[c][1].y, v[c][2].y, v[c][3].y,
+                                     v[c][0].z, v[c][1].z, v[c][2].z, v[c][3].z, v[c][0].w, v[c][1].w, v[c][2].w, v[c][3].w};
+#pragma unroll
+                for (int t = 0; t < 16; t++) {
+                    const int cl = c * 16 + t;  // column within this group of 128
+                    // (the builtin is typed int -> int: move the bits, not the value)
+                    const float xv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cl < 64 ? xa : xb), cl & 63));
+                    acc = __fmaf_rn(e[t], xv, acc);  // padded columns: e[t] == 0 and xv == 0 -> acc unchanged
+                }
+            }
+        }
+    }
+    uint32_t key = S.metric == QK_METRIC_L2 ? ord_from_l2(l2_expanded(xnq, yn, acc)) : ord_from_ip(acc);
+    if (lane >= n) key = 0xFFFFFFFFu;
+    int rk = 0;
+    for (int t = 0; t < 64; t++) {
+        const uint32_t ot = __builtin_amdgcn_readlane(key, t);
+        rk += (ot < key || (ot == key && t < lane)) ? 1 : 0;
+    }
+    const uint64_t mk = __ballot(rk == S.k - 1);
+    const uint32_t bound = __builtin_amdgcn_readlane(key, __ffsll((unsigned long long)mk) - 1);
+    if (lane == 0 && bound != 0xFFFFFFFFu) atomicMax(&S.gtau[q], ~bound);  // gtau holds ~bound: 0 = no bound yet
+}
+
 // ---- the scan kernel ---------------------------------------------------------------------------------
 struct ScanParams {
     const float4 *vecs;
@@ -242,7 +327,8 @@ struct ScanParams {
     const int32_t *n_active;
     const ActiveInfo *active;
     const int64_t *n_tiles;
-    uint32_t *gtau;  // [Q] shared running bound per query, or nullptr
+    uint32_t *gtau;  // [Q] shared running bound per query stored as ~bound (0 = none, so one memset clears it), or nullptr
+    int tau_refresh;  // re-read gtau every 8 tiles (only useful when a query probes several partitions)
     int k;
     int C;  // pool capacity per query; k <= C - 4
     int metric;
@@ -423,8 +509,8 @@ __global__ __launch_bounds__(64) void k_scan(ScanParams P) {
                 // against a per-tile plain (L1-stale) load, a per-tile sc1 load in the prefetch stream and an
                 // exchange at compaction time: this variant is 5-25 % faster although consuming the load drains
                 // the prefetched tile.
-                if (P.gtau && (tl_ & 7) == 7 && myq >= 0)
-                    tau = min(tau, __hip_atomic_load(&P.gtau[myq], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                if (P.gtau && P.tau_refresh && (tl_ & 7) == 7 && myq >= 0)
+                    tau = min(tau, ~__hip_atomic_load(&P.gtau[myq], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
                 uint32_t ordv[4];
                 bool anyp = false;
 #pragma unroll
@@ -462,7 +548,7 @@ __global__ __launch_bounds__(64) void k_scan(ScanParams P) {
                                     if (nn >= k) {
                                         tau = min(tau, pool_ord[jq * C + k - 1]);
                                         // publish (fire and forget: no returned value, no wait)
-                                        if (P.gtau && lane < 16) atomicMin(&P.gtau[myq], tau);
+                                        if (P.gtau && lane < 16) atomicMax(&P.gtau[myq], ~tau);
                                     }
                                 }
                             }
@@ -476,7 +562,7 @@ __global__ __launch_bounds__(64) void k_scan(ScanParams P) {
             {
                 const int qsafe = myq >= 0 ? myq : 0;
                 const float4 *qsrc = P.xq4 + (int64_t)qsafe * nblk * 4 + g;
-                if (P.gtau) tau = __hip_atomic_load(&P.gtau[qsafe], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (P.gtau) tau = ~__hip_atomic_load(&P.gtau[qsafe], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (l2) xnj = P.xn[qsafe];
                 for (int cb0 = 0; cb0 < nblk; cb0 += DB) {
                     float4 qv[DB];
@@ -535,7 +621,7 @@ __global__ __launch_bounds__(64) void k_scan(ScanParams P) {
                             P.rec_hdr[pend_rec] = make_int2(pend_old, pend_cnt);
                             pend_rec = -1;
                         }
-                        if (P.gtau && cnt >= k) atomicMin(&P.gtau[myq], my_ord[k - 1]);
+                        if (P.gtau && cnt >= k) atomicMax(&P.gtau[myq], ~my_ord[k - 1]);
                     }
                 }
                 uint64_t todo = have;
@@ -802,7 +888,7 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
     const int64_t np1 = std::max<int64_t>(npairs, 1);
     size_t need = 0;
     auto add = [&](size_t b) { need += (b + 255) & ~(size_t)255; };
-    add((size_t)npids * 4 * 2 + 256 + 64);
+    add((size_t)npids * 4 * 2 + 256 + (size_t)Q * 4 + 64);
     add((size_t)(npids + 1) * sizeof(ActiveInfo) + 64);
     add((size_t)(npids + 1) * 4 + 64);
     add((size_t)np1 * 4 * 3);
@@ -815,8 +901,8 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
     const float4 *xq4 = a.xq4;
     const float *xn = a.xn;
     if (!xq4 || !xn) QK_FAIL(QK_ERR_INVALID, "qk_scan: queries were not prepared");
-    // zeroed region: g_cnt [npids], g_cursor [npids], scal [64]  (one memset per call)
-    const size_t zero_bytes = (size_t)npids * 4 * 2 + 256;
+    // zeroed region: g_cnt [npids], g_cursor [npids], scal [64], gtau [Q]  (one memset per call)
+    const size_t zero_bytes = (size_t)npids * 4 * 2 + 256 + (size_t)Q * 4;
     int32_t *g_cnt = (int32_t *)qk_ws_alloc(ctx, zero_bytes + 64);
     int32_t *g_cursor = g_cnt + npids;
     int32_t *scal = g_cursor + npids;
@@ -829,7 +915,7 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
     int32_t *grouped_q = (int32_t *)qk_ws_alloc(ctx, (size_t)np1 * 4 * 3);
     int32_t *grouped_pair = grouped_q + np1;
     int32_t *pair_head = grouped_pair + np1;
-    uint32_t *gtau = (uint32_t *)qk_ws_alloc(ctx, (size_t)Q * 4);
+    uint32_t *gtau = (uint32_t *)(scal + 64);
     int2 *rec_hdr = (int2 *)qk_ws_alloc(ctx, (size_t)max_recs * 8);
     uint32_t *rec_ord = (uint32_t *)qk_ws_alloc(ctx, (size_t)max_recs * k * 4);
     int64_t *rec_id = (int64_t *)qk_ws_alloc(ctx, (size_t)max_recs * k * 8);
@@ -857,6 +943,31 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
     G.grouped_pair = grouped_pair;
     G.pair_head = pair_head;
     G.gtau = gtau;
+    static const int no_seed = getenv("QK_NO_SEED") ? atoi(getenv("QK_NO_SEED")) : 0;
+    const bool seeded = !no_seed && a.share_tau && k <= 64 && npairs > 0 && npids > 0;
+    if (seeded) {
+        // bound seeding: for the first (nearest) partitions of every query, the k-th smallest distance of a 64-row
+        // sample goes into gtau[q]
+        SeedParams sd;
+        sd.pids = G.pids;
+        sd.npairs = npairs;
+        sd.P = G.P;
+        sd.pt_size = s->d_size;
+        sd.pt_off = s->d_off;
+        sd.npids = npids;
+        sd.vecs = (const float4 *)s->vecs;
+        sd.norms = s->norms;
+        sd.nblk = nblk;
+        sd.d = s->d;
+        sd.x = a.x;
+        sd.xn = xn;
+        sd.k = k;
+        sd.metric = a.metric;
+        sd.gtau = gtau;
+        sd.seed_ranks = std::min(2, G.P);
+        // (a side stream + fork/join events was measured slower than running it in line: 45 vs 40 us group phase)
+        hipLaunchKernelGGL(k_seed_tau, dim3((unsigned)(Q * sd.seed_ranks)), dim3(64), 0, st, sd);
+    }
     if (npairs > 0) hipLaunchKernelGGL(k_group_count, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, st, G);
     hipLaunchKernelGGL(k_group_scan, dim3(1), dim3(1024), 0, st, G);
     if (npairs > 0) hipLaunchKernelGGL(k_group_scatter, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, st, G);
@@ -878,10 +989,12 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
         sp.n_active = n_active;
         sp.active = active;
         sp.n_tiles = n_tiles;
-        sp.gtau = (a.share_tau && P > 1) ? gtau : nullptr;  // one partition per query: nothing to share
+        sp.gtau = a.share_tau ? gtau : nullptr;
+        sp.tau_refresh = P > 1 ? 1 : 0;  // one partition per query: the seed is all there is to share
+
         static const int probe_tau0 = getenv("QK_SCAN_TAU0") ? atoi(getenv("QK_SCAN_TAU0")) : 0;
         if (probe_tau0) {  // probe: a bound of 0 -> nothing ever passes (isolates the steady-state epilogue cost)
-            QK_HIP(hipMemsetAsync(gtau, 0, (size_t)Q * 4, st));
+            QK_HIP(hipMemsetAsync(gtau, 0xFF, (size_t)Q * 4, st));
             sp.gtau = gtau;
         }
         sp.k = k;

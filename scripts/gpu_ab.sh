@@ -1,9 +1,10 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
 for round in 1 2; do
-for wpc in 5 6 7 8 10; do
+for side in 0 1; do
   for P in 1 32; do
-    QK_SCAN_WAVES_PER_CU=$wpc timeout 300 python scripts/scan_probe.py 10000000 4096 $P 2>&1 | grep -v amdgpu.ids | tail -1 | sed "s/^/wpc$wpc /"
+    QK_SEED_SIDE_STREAM=$side timeout 300 python scripts/scan_probe.py 10000000 4096 $P 2>&1 | grep -v amdgpu.ids | tail -1 | sed "s/^/side$side /"
   done
 done
+QK_NO_SEED=1 timeout 300 python scripts/scan_probe.py 10000000 4096 1 2>&1 | grep -v amdgpu.ids | tail -1 | sed "s/^/noseed /"
 done
