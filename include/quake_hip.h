@@ -45,7 +45,7 @@ typedef enum {
 #define QK_METRIC_L2 1
 #define QK_MEM_HOST 0
 #define QK_MEM_DEVICE 1
-#define QK_MAX_K 512 /* largest k / nprobe of the fused LDS top-k (reference: 8192, list_scanning.h:39) */
+#define QK_MAX_K 448 /* largest k / nprobe of the fused LDS top-k: pool capacity k+64 <= 512 (reference: 8192, list_scanning.h:39) */
 
 typedef struct qk_ctx qk_ctx;     /* device + stream + scratch workspace                     */
 typedef struct qk_store qk_store; /* device mirror of faiss::DynamicInvertedLists (one level) */

@@ -144,6 +144,15 @@ class Context:
                                int(k), metric_code(metric), _ptr(out_i), _ptr(out_d), mem, C.byref(t) if timing else None))
         return (out_i, out_d, timing_dict(t)) if timing else (out_i, out_d)
 
+    def scan_into(self, store, x, pids, k, metric, out):
+        """scan() writing into caller-provided (ids, dist) tensors (no allocation in the timed loop)."""
+        x, pids = _f32(x), _i64(pids)
+        Q = x.shape[0]
+        out_i, out_d = out
+        check(self.lib.qk_scan(self.h, store.h, _ptr(x), Q, _ptr(pids), int(pids.shape[1]), int(k), metric_code(metric),
+                               _ptr(out_i), _ptr(out_d), _mem_of(x, pids), None))
+        return out_i, out_d
+
     def search(self, parent, store, x, nprobe, k, metric, timing=False, out=None):
         x = _f32(x)
         Q = x.shape[0]

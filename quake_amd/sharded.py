@@ -45,32 +45,58 @@ class GpuEngine:
         self.ctx, self.parent, self.store, self.metric = ctx, parent, store, metric
         ctx.set_squared_l2(True)  # ranks exchange the merge key; sqrt happens after the merge
 
-    def search_local(self, q, nprobe, k, out=None):
-        return self.ctx.search(self.parent, self.store, q, nprobe, k, self.metric, out=out)
+    def coarse(self, q, nprobe):
+        """[n, nprobe] global partition numbers for a slice of the batch (replicated centroids)."""
+        return self.ctx.coarse(self.parent, q, nprobe, self.metric)[0]
+
+    def scan(self, q, pids, k, out=None):
+        """local top-k over the probed lists this rank owns: (ids [Q,k], merge keys [Q,k])."""
+        if out is not None:
+            return self.ctx.scan_into(self.store, q, pids, k, self.metric, out)
+        return self.ctx.scan(self.store, q, pids, k, self.metric)
 
     def merge(self, ids, keys):
         return self.ctx.merge_topk(ids, keys, self.metric)
 
 
 class ShardedIndex:
-    """search() = local scan + all-gather + merge.  `dist` is torch.distributed (nccl = RCCL on ROCm, or gloo)."""
+    """search() = sharded coarse + all-gather(pids) + local scan + all-gather(top-k) + merge.
+    `dist` is torch.distributed (nccl = RCCL on ROCm, or gloo).  The coarse step is split by QUERIES (rank r takes
+    the r-th slice of the batch against the replicated centroids) so its cost per rank does not grow with the number of
+    ranks; the [Q, nprobe] partition lists are then all-gathered -- the one real exchange the path has besides the
+    final top-k gather."""
 
     def __init__(self, engine, dist=None, world=1, rank=0):
         self.engine, self.dist, self.world, self.rank = engine, dist, int(world), int(rank)
-        self._g_ids = self._g_keys = None
+        self._g_ids = self._g_keys = self._g_pids = None
+
+    def _gather(self, buf_name, t, dtype):
+        import torch
+        t = t if torch.is_tensor(t) else torch.from_numpy(np.ascontiguousarray(t))
+        shape = (self.world,) + tuple(t.shape)
+        buf = getattr(self, buf_name)
+        if buf is None or tuple(buf.shape) != shape or buf.device != t.device:
+            buf = torch.empty(shape, dtype=dtype, device=t.device)
+            setattr(self, buf_name, buf)
+        # concatenation form ([world*n, c]) is accepted by both the RCCL and the gloo backend
+        self.dist.all_gather_into_tensor(buf.view(-1, t.shape[-1]), t.contiguous())
+        return buf
 
     def search(self, q, nprobe, k, out=None):
         import torch
-        ids, keys = self.engine.search_local(q, nprobe, k, out=out)
+        Q = q.shape[0]
         if self.world == 1 or self.dist is None:
+            pids = self.engine.coarse(q, nprobe)
+            ids, keys = self.engine.scan(q, pids, k, out=out)
             return self.engine.merge(ids.reshape((1,) + tuple(ids.shape)), keys.reshape((1,) + tuple(keys.shape)))
-        t_ids = ids if torch.is_tensor(ids) else torch.from_numpy(np.ascontiguousarray(ids))
-        t_keys = keys if torch.is_tensor(keys) else torch.from_numpy(np.ascontiguousarray(keys))
-        shape = (self.world,) + tuple(t_ids.shape)
-        if self._g_ids is None or tuple(self._g_ids.shape) != shape or self._g_ids.device != t_ids.device:
-            self._g_ids = torch.empty(shape, dtype=torch.int64, device=t_ids.device)
-            self._g_keys = torch.empty(shape, dtype=torch.float32, device=t_ids.device)
-        # concatenation form ([world*Q, k]) is accepted by both the RCCL and the gloo backend
-        self.dist.all_gather_into_tensor(self._g_ids.view(-1, t_ids.shape[-1]), t_ids.contiguous())
-        self.dist.all_gather_into_tensor(self._g_keys.view(-1, t_keys.shape[-1]), t_keys.contiguous())
-        return self.engine.merge(self._g_ids, self._g_keys)
+        if Q % self.world != 0:
+            raise ValueError("batch size must be a multiple of the number of ranks")
+        per = Q // self.world
+        pl = self.engine.coarse(q[self.rank * per:(self.rank + 1) * per], nprobe)
+        pids = self._gather("_g_pids", pl, torch.int64).view(Q, -1)
+        if not torch.is_tensor(q):
+            pids = pids.numpy()
+        ids, keys = self.engine.scan(q, pids, k, out=out)
+        g_ids = self._gather("_g_ids", ids, torch.int64)
+        g_keys = self._gather("_g_keys", keys, torch.float32)
+        return self.engine.merge(g_ids, g_keys)

@@ -129,3 +129,18 @@ def test_large_flat_list_vs_torch_bruteforce(ctx):
             tv, ti = torch.topk(dist, 10, dim=1, largest=True)
         np.testing.assert_array_equal(gi, ti.numpy())
         np.testing.assert_allclose(gd, tv.numpy(), atol=1e-4)
+
+
+def test_large_k_and_limits(ctx):
+    """k up to QK_MAX_K goes through the multi-chunk pools; beyond it the call fails loudly (no silent truncation)."""
+    from quake_amd._lib import QK_MAX_K, QuakeHipError
+    ivf = make_ivf(6000, 48, 6, seed=31)
+    q = make_queries(40, 48, seed=32, like=ivf["x"])
+    parent, s = build_stores(ctx, ivf)
+    for k in (200, QK_MAX_K):
+        gi, gd = ctx.search(parent, s, q, 6, k, "l2")
+        oi, od = O.search(q, ivf["centroids"], ivf["vecs"], ivf["ids"], ivf["offsets"], 6, k, "l2", batched_scan=True)
+        np.testing.assert_array_equal(gi, oi)
+        np.testing.assert_array_equal(gd.view(np.uint32), od.view(np.uint32))
+    with pytest.raises(QuakeHipError):
+        ctx.search(parent, s, q, 6, QK_MAX_K + 1, "l2")

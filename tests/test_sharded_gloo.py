@@ -22,9 +22,13 @@ class OracleEngine:
     def __init__(self, centroids, vecs, ids, offsets, metric):
         self.c, self.v, self.i, self.o, self.metric = centroids, vecs, ids, offsets, metric
 
-    def search_local(self, q, nprobe, k, out=None):
+    def coarse(self, q, nprobe):
         import oracle as O
-        oi, od = O.search(q, self.c, self.v, self.i, self.o, nprobe, k, self.metric, batched_scan=True)
+        return O.coarse(q, self.c, None, nprobe, self.metric)[0]
+
+    def scan(self, q, pids, k, out=None):
+        import oracle as O
+        oi, od = O.batched_serial_scan(q, self.v, self.i, self.o, pids, k, self.metric)
         key = od.copy()
         if self.metric == "l2":
             # recover the squared merge key exactly: recompute it with the oracle's canonical arithmetic
@@ -63,7 +67,7 @@ def _worker(rank, world, port, metric, ret):
         from helpers import make_ivf, make_queries
         from quake_amd.sharded import ShardedIndex, owner_of_list, shard_offsets
         ivf = make_ivf(6000, 24, 16, seed=3, metric=metric, empty=(2,))
-        q = make_queries(17, 24, seed=4, like=ivf["x"], metric=metric)
+        q = make_queries(18, 24, seed=4, like=ivf["x"], metric=metric)
         lo, rows = shard_offsets(ivf["offsets"], rank, world)
         # every list is owned by exactly one rank
         own = [owner_of_list(p, world) for p in range(16)]
