@@ -60,3 +60,27 @@ def test_product_does_not_import_oracle():
                 txt = open(os.path.join(dp, f), errors="replace").read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, re.M), os.path.join(dp, f)
                 assert "libquake_oracle" not in txt, os.path.join(dp, f)
+
+
+def test_compiled_surface_builds_and_exposes_reference_names():
+    """quake_amd/_bindings.so (C++ host mirror + pybind11) must build on CPU and expose the class / attribute names of
+    the reference's quake._bindings (src/cpp/bindings/wrap.cpp:57-368).  No device call is made."""
+    from quake_amd.build_ext import build_bindings
+    build_bindings()
+    import quake_amd.bindings as b
+    for cls in ("QuakeIndex", "IndexBuildParams", "SearchParams", "MaintenancePolicyParams", "SearchResult",
+                "SearchTimingInfo", "BuildTimingInfo", "ModifyTimingInfo", "MaintenanceTimingInfo"):
+        assert hasattr(b, cls), cls
+    for m in ("build", "search", "get", "get_ids", "add", "remove", "maintenance", "initialize_maintenance_policy",
+              "save", "load", "ntotal", "nlist", "parent", "current_level"):
+        assert hasattr(b.QuakeIndex, m), m
+    sp = b.SearchParams()
+    for a, v in (("k", 1), ("nprobe", 1), ("batched_scan", False), ("num_threads", 1), ("use_precomputed", True)):
+        assert getattr(sp, a) == v
+    assert abs(sp.recall_target + 1.0) < 1e-6 and abs(sp.initial_search_fraction - 0.02) < 1e-6
+    bp = b.IndexBuildParams()
+    assert (bp.nlist, bp.niter, bp.metric, bp.num_workers) == (0, 5, "l2", 0)
+    mp = b.MaintenancePolicyParams()
+    assert (mp.window_size, mp.refinement_radius, mp.refinement_iterations, mp.min_partition_size) == (1000, 25, 3, 32)
+    idx = b.QuakeIndex()
+    assert idx.ntotal() == 0 and idx.nlist() == 0 and idx.parent is None and idx.current_level == 0
