@@ -875,9 +875,19 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
 
     const int num_cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
     // persistent grid: as many single-wave workgroups as stay resident (LDS-limited; registers allow ~12 per CU)
-    // static tile partition => every wave must be resident at once; 8 per CU measured best (scan_probe.py), LDS may cap it
+    // static tile partition => every wave must be resident at once.  Measured (bench.py / scan_probe.py): 8 per CU is best
+    // for long launches; when a wave would get fewer than ~160 tiles, 6 per CU wins (fewer, longer segments: less
+    // per-segment cost, fewer records to merge) -- 5.06 -> 5.5 TB/s on the bench configuration; 10+ lose bandwidth.
     int waves_per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / (lds_scan + 512)));
-    if (getenv("QK_SCAN_WAVES_PER_CU")) waves_per_cu = std::max(1, atoi(getenv("QK_SCAN_WAVES_PER_CU")));
+    {
+        const int64_t npresent_e = std::max<int64_t>(1, s->nlist);
+        const int64_t mean_tiles = std::max<int64_t>(1, (s->ntotal / npresent_e + 15) / 16);
+        const int64_t tiles_est = std::max<int64_t>(1, npairs / 16 + std::min<int64_t>(npresent_e, npairs)) * mean_tiles;
+        if (waves_per_cu > 6 && tiles_est < (int64_t)8 * num_cus * 160) waves_per_cu = 6;
+    }
+    if (const char *e = getenv("QK_SCAN_WAVES_PER_CU")) {  // probe override, read per call so one process can sweep it
+        if (atoi(e) > 0) waves_per_cu = atoi(e);
+    }
     const int64_t n_waves = (int64_t)num_cus * waves_per_cu;
     // records: every wave-segment emits at most 16; segments <= items + waves
     const int64_t npresent = std::max<int64_t>(1, s->nlist);
@@ -1009,7 +1019,14 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
         // do not launch (many) more waves than there are tiles to hand out
         int64_t tiles_ub = std::max<int64_t>(1, items_bound * ((std::max<int64_t>(1, s->max_size) + 15) / 16));
         int64_t grid = std::max<int64_t>(1, std::min<int64_t>(n_waves, tiles_ub));
-        QK_TRY(launch_scan(DB, maxch, dim3((unsigned)grid), lds_scan, st, sp));
+        // every wave must be resident at once AND evenly spread: pad the LDS request so that exactly waves_per_cu
+        // workgroups fit on a CU (the dispatcher otherwise packs up to 10 on some CUs and leaves others short, and with
+        // a static partition the slowest CU sets the kernel time)
+        // (measured +2 % at 6 and 8 per CU; at 5 per CU the padded request only fits 4 -- pad the tested counts only)
+        size_t lds_launch = lds_scan;
+        if (waves_per_cu == 4 || waves_per_cu == 6 || waves_per_cu == 8)
+            lds_launch = std::max<size_t>(lds_scan, (size_t)(160 * 1024) / waves_per_cu - 512);
+        QK_TRY(launch_scan(DB, maxch, dim3((unsigned)grid), lds_launch, st, sp));
     }
     QK_TRY(pe.mark(2));
 
