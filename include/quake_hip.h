@@ -94,6 +94,9 @@ QK_API int qk_store_add_list(qk_store *s, int64_t list_no);                     
 QK_API int qk_store_remove_list(qk_store *s, int64_t list_no);                  /* remove_list :251-260 */
 /* add_entries :152-173 -> IndexPartition::append (index_partition.cpp:52-59).  vecs [n][d] row-major f32. */
 QK_API int qk_store_add_entries(qk_store *s, int64_t list_no, int64_t n, const int64_t *ids, const float *vecs, int mem);
+/* Batched form of the add loop of PartitionManager::add (partition_manager.cpp:236-258): vector i is appended to list
+ * assign[i]; the append order inside a list is the input order.  ids/vecs/assign all live in `mem`. */
+QK_API int qk_store_add_batch(qk_store *s, int64_t n, const int64_t *ids, const float *vecs, const int64_t *assign, int mem);
 /* Bulk form of init_partitions (partition_manager.cpp:33-121): lists 0..nlist-1 created and filled from a CSR
  * arena (vecs [offsets[nlist]][d], ids, offsets [nlist+1] on the HOST always; vecs/ids in `mem`). */
 QK_API int qk_store_build_csr(qk_store *s, int64_t nlist, const int64_t *offsets_host, const int64_t *ids,

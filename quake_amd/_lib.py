@@ -50,6 +50,7 @@ SIGNATURES = {
     "qk_store_add_list": (_int, [_vp, _i64]),
     "qk_store_remove_list": (_int, [_vp, _i64]),
     "qk_store_add_entries": (_int, [_vp, _i64, _i64, _vp, _vp, _int]),
+    "qk_store_add_batch": (_int, [_vp, _i64, _vp, _vp, _vp, _int]),
     "qk_store_build_csr": (_int, [_vp, _i64, _vp, _vp, _vp, _int]),
     "qk_store_remove_ids": (_int, [_vp, _i64, _vp, C.POINTER(_i64)]),
     "qk_store_list_size": (_int, [_vp, _i64, C.POINTER(_i64)]),

@@ -243,6 +243,10 @@ class Store:
         n = ids.shape[0]
         check(self.lib.qk_store_add_entries(self.h, int(list_no), n, _ptr(ids), _ptr(vecs), _mem_of(ids, vecs)))
 
+    def add_batch(self, ids, vecs, assign):
+        ids, vecs, assign = _i64(ids), _f32(vecs), _i64(assign)
+        check(self.lib.qk_store_add_batch(self.h, ids.shape[0], _ptr(ids), _ptr(vecs), _ptr(assign), _mem_of(ids, vecs, assign)))
+
     def build_csr(self, offsets, ids, vecs):
         offsets = np.ascontiguousarray(offsets, dtype=np.int64)
         ids, vecs = _i64(ids), _f32(vecs)

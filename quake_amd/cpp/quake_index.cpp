@@ -220,18 +220,8 @@ shared_ptr<ModifyTimingInfo> QuakeIndex::add(Tensor x, Tensor ids) {  // partiti
     }
     info->find_partition_time_us = us_since(t0);
     t0 = clk::now();
-    Tensor order = torch::argsort(assign, /*stable=*/true);  // per-partition append order = input order (:245-258)
-    Tensor as = assign.index_select(0, order);
-    Tensor xs = xh.index_select(0, order).contiguous();
-    Tensor is = idh.index_select(0, order).contiguous();
-    const int64_t *ap = as.data_ptr<int64_t>();
-    int64_t pos = 0;
-    while (pos < n) {
-        int64_t end = pos;
-        while (end < n && ap[end] == ap[pos]) end++;
-        check(qk_store_add_entries(store_, ap[pos], end - pos, is.data_ptr<int64_t>() + pos, xs.data_ptr<float>() + pos * d_, QK_MEM_HOST));
-        pos = end;
-    }
+    // per-list append order = input order (:245-258)
+    check(qk_store_add_batch(store_, n, idh.data_ptr<int64_t>(), xh.data_ptr<float>(), assign.data_ptr<int64_t>(), QK_MEM_HOST));
     info->modify_time_us = us_since(t0);
     return info;
 }

@@ -109,7 +109,11 @@ struct qk_store {
     int32_t *d_size = nullptr;
     int64_t table_cap = 0;
     bool table_dirty = true;
+    // id -> list number (lazy; makes get_vector / remove_ids proportional to the touched lists)
+    std::unordered_map<int64_t, int32_t> id_to_list;
+    bool index_valid = false;
 };
+void qk_store_ensure_index(qk_store *s);
 
 int qk_store_sync_table(qk_store *s);                  // upload (row_off, size) if dirty
 int qk_store_reserve_rows(qk_store *s, int64_t rows);  // grow the arena so that used_rows + rows fits

@@ -34,9 +34,11 @@ struct IngestMap {
     const int64_t *part_row;  // [nlist] arena row of each partition's first NEW row
     int64_t nlist;
     int64_t src_base;         // global index of src[0] within the CSR numbering
+    const int64_t *rows;      // explicit destination row of every source row (device) or nullptr
 };
 
 __device__ __forceinline__ int64_t ingest_dst_row(const IngestMap &m, int64_t i) {
+    if (m.rows) return m.rows[i];
     if (!m.offsets) return m.row0 + i;
     int64_t gi = m.src_base + i;
     int64_t p = csr_find(m.offsets, m.nlist, gi);
@@ -119,7 +121,7 @@ static int launch_ingest(qk_ctx *ctx, const float *src, const int64_t *src_ids, 
 
 int qk_launch_ingest(qk_ctx *ctx, const float *src, const int64_t *src_ids, int64_t n, int d, int nblk, float *vecs,
                      float *norms, int64_t *ids, int64_t row0) {
-    IngestMap m{row0, nullptr, nullptr, 0, 0};
+    IngestMap m{row0, nullptr, nullptr, 0, 0, nullptr};
     return launch_ingest(ctx, src, src_ids, n, d, nblk, vecs, norms, ids, m);
 }
 
@@ -215,6 +217,19 @@ int qk_store_sync_table(qk_store *s) {
     return QK_OK;
 }
 
+// id -> list number, built lazily from the id mirrors (the reference has no such index: find_id / remove_vectors scan)
+void qk_store_ensure_index(qk_store *s) {
+    if (s->index_valid) return;
+    s->id_to_list.clear();
+    s->id_to_list.reserve((size_t)s->ntotal * 2 + 16);
+    for (size_t pi = 0; pi < s->parts.size(); pi++) {
+        const qk_part &p = s->parts[pi];
+        if (!p.present) continue;
+        for (int64_t i = 0; i < p.size; i++) s->id_to_list.emplace(p.ids[i], (int32_t)pi);  // first list wins (get order)
+    }
+    s->index_valid = true;
+}
+
 static int check_list(qk_store *s, int64_t list_no, const char *who) {
     if (list_no < 0 || list_no >= (int64_t)s->parts.size() || !s->parts[list_no].present)
         QK_FAIL(QK_ERR_NOT_FOUND, "List does not exist in %s (list %lld)", who, (long long)list_no);
@@ -298,6 +313,8 @@ int qk_store_reset(qk_store *s) {
     s->used_rows = 0;
     s->dead_rows = 0;
     s->table_dirty = true;
+    s->id_to_list.clear();
+    s->index_valid = false;
     return QK_OK;
 }
 
@@ -319,6 +336,8 @@ int qk_store_remove_list(qk_store *s, int64_t list_no) {
     if (!s) QK_FAIL(QK_ERR_INVALID, "qk_store_remove_list: null store");
     if (list_no < 0 || list_no >= (int64_t)s->parts.size() || !s->parts[list_no].present) return QK_OK;  // "Already doesn't exist"
     qk_part &p = s->parts[list_no];
+    if (s->index_valid)
+        for (int64_t id : p.ids) s->id_to_list.erase(id);
     s->ntotal -= p.size;
     s->dead_rows += p.cap;
     p = qk_part();
@@ -350,6 +369,8 @@ int qk_store_add_entries(qk_store *s, int64_t list_no, int64_t n, const int64_t 
     }
     QK_TRY(qk_launch_ingest(c, (const float *)dv, (const int64_t *)di, n, s->d, s->nblk, s->vecs, s->norms, s->ids, p.row_off + p.size));
     QK_HIP(hipStreamSynchronize(c->stream));  // staging buffer / caller memory reusable on return
+    if (s->index_valid)
+        for (int64_t i = 0; i < n; i++) s->id_to_list[p.ids[old + i]] = (int32_t)list_no;
     p.size += n;
     s->ntotal += n;
     s->table_dirty = true;
@@ -416,7 +437,7 @@ int qk_store_build_csr(qk_store *s, int64_t nlist, const int64_t *offsets, const
                 dv = (const float *)c->stage;
                 di = (const int64_t *)si;
             }
-            IngestMap m{0, d_offsets, d_part_row, nlist, i0};
+            IngestMap m{0, d_offsets, d_part_row, nlist, i0, nullptr};
             rc = launch_ingest(c, dv, di, n, s->d, s->nblk, s->vecs, s->norms, s->ids, m);
             if (rc == QK_OK && mem == QK_MEM_HOST && hipStreamSynchronize(c->stream) != hipSuccess) rc = QK_ERR_HIP;
         }
@@ -440,11 +461,18 @@ int qk_store_remove_ids(qk_store *s, int64_t n, const int64_t *ids_host, int64_t
     std::vector<int64_t> mv_dst, mv_src;
     int64_t removed = 0;
     std::vector<int64_t> cur;
+    // the id -> list index tells which lists hold something to remove; only those are swept (the reference sweeps
+    // every partition, dynamic_inverted_list.cpp:137-149 -- same result, O(touched lists) instead of O(N))
+    qk_store_ensure_index(s);
+    std::vector<char> touched_list(s->parts.size(), 0);
+    for (int64_t i = 0; i < n; i++) {
+        auto it = s->id_to_list.find(ids_host[i]);
+        if (it != s->id_to_list.end()) touched_list[(size_t)it->second] = 1;
+    }
     for (size_t pi = 0; pi < s->parts.size(); pi++) {
         qk_part &p = s->parts[pi];
-        if (!p.present || p.size == 0) continue;
-        // DynamicInvertedLists::remove_vectors (dynamic_inverted_list.cpp:137-149): scan, swap-with-last on a hit,
-        // re-examine the swapped-in row
+        if (!touched_list[pi] || !p.present || p.size == 0) continue;
+        // scan, swap-with-last on a hit, re-examine the swapped-in row (IndexPartition::remove, index_partition.cpp:79-102)
         bool touched = false;
         int64_t sz = p.size;
         for (int64_t i = 0; i < sz;) {
@@ -454,6 +482,7 @@ int qk_store_remove_ids(qk_store *s, int64_t n, const int64_t *ids_host, int64_t
                     for (int64_t t = 0; t < p.size; t++) cur[t] = t;
                     touched = true;
                 }
+                s->id_to_list.erase(p.ids[i]);
                 if (i != sz - 1) {
                     p.ids[i] = p.ids[sz - 1];
                     cur[i] = cur[sz - 1];
@@ -543,20 +572,73 @@ int qk_store_get_vector(qk_store *s, int64_t id, float *vec_out_host, int *found
     qk_ctx *c = s->ctx;
     QK_HIP(hipSetDevice(c->device));
     *found = 0;
-    for (size_t pi = 0; pi < s->parts.size(); pi++) {
-        qk_part &p = s->parts[pi];
-        if (!p.present) continue;
-        for (int64_t i = 0; i < p.size; i++)  // IndexPartition::find_id is a linear scan too (index_partition.cpp:129-145)
-            if (p.ids[i] == id) {
-                size_t vb = (size_t)s->d * sizeof(float);
-                QK_TRY(qk_stage_reserve(c, vb));
-                QK_TRY(qk_launch_extract(c, s->vecs, s->nblk, s->d, p.row_off + i, nullptr, 1, (float *)c->stage));
-                QK_HIP(hipMemcpyAsync(vec_out_host, c->stage, vb, hipMemcpyDeviceToHost, c->stream));
-                QK_HIP(hipStreamSynchronize(c->stream));
-                *found = 1;
-                return QK_OK;
-            }
+    qk_store_ensure_index(s);
+    auto it = s->id_to_list.find(id);
+    if (it == s->id_to_list.end()) return QK_OK;
+    qk_part &p = s->parts[(size_t)it->second];
+    for (int64_t i = 0; i < p.size; i++)  // find_id inside the one list that holds it (index_partition.cpp:129-145)
+        if (p.ids[i] == id) {
+            size_t vb = (size_t)s->d * sizeof(float);
+            QK_TRY(qk_stage_reserve(c, vb));
+            QK_TRY(qk_launch_extract(c, s->vecs, s->nblk, s->d, p.row_off + i, nullptr, 1, (float *)c->stage));
+            QK_HIP(hipMemcpyAsync(vec_out_host, c->stage, vb, hipMemcpyDeviceToHost, c->stream));
+            QK_HIP(hipStreamSynchronize(c->stream));
+            *found = 1;
+            return QK_OK;
+        }
+    return QK_OK;
+}
+
+// Batched PartitionManager::add (partition_manager.cpp:236-258): n vectors, each appended to list assign[i]; per-list
+// append order = input order.  One grouping pass on the host, one capacity check per touched list, ONE ingest launch.
+int qk_store_add_batch(qk_store *s, int64_t n, const int64_t *ids, const float *vecs, const int64_t *assign, int mem) {
+    if (!s) QK_FAIL(QK_ERR_INVALID, "qk_store_add_batch: null store");
+    if (n == 0) return QK_OK;
+    if (n < 0 || !ids || !vecs || !assign) QK_FAIL(QK_ERR_INVALID, "qk_store_add_batch: bad arguments");
+    qk_ctx *c = s->ctx;
+    QK_HIP(hipSetDevice(c->device));
+    std::vector<int64_t> h_assign((size_t)n), h_ids((size_t)n);
+    if (mem == QK_MEM_HOST) {
+        memcpy(h_assign.data(), assign, (size_t)n * 8);
+        memcpy(h_ids.data(), ids, (size_t)n * 8);
+    } else {
+        QK_HIP(hipMemcpyAsync(h_assign.data(), assign, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+        QK_HIP(hipMemcpyAsync(h_ids.data(), ids, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+        QK_HIP(hipStreamSynchronize(c->stream));
     }
+    std::vector<int64_t> extra(s->parts.size(), 0);
+    for (int64_t i = 0; i < n; i++) {
+        QK_TRY(check_list(s, h_assign[i], "add_entries"));
+        extra[(size_t)h_assign[i]]++;
+    }
+    for (size_t p = 0; p < extra.size(); p++)
+        if (extra[p]) QK_TRY(ensure_part_capacity(s, s->parts[p], extra[p]));
+    std::vector<int64_t> rows((size_t)n);
+    for (int64_t i = 0; i < n; i++) {
+        qk_part &p = s->parts[(size_t)h_assign[i]];
+        rows[i] = p.row_off + p.size;
+        p.ids.push_back(h_ids[i]);
+        p.size++;
+        if (s->index_valid) s->id_to_list[h_ids[i]] = (int32_t)h_assign[i];
+    }
+    s->ntotal += n;
+    s->table_dirty = true;
+    size_t vb = (size_t)n * s->d * 4, ib = (size_t)n * 8;
+    size_t off_rows = (mem == QK_MEM_HOST) ? (((vb + 255) & ~(size_t)255) + ((ib + 255) & ~(size_t)255)) : 0;
+    QK_TRY(qk_stage_reserve(c, off_rows + ib + 256));
+    const float *dv = vecs;
+    const int64_t *di = ids;
+    if (mem == QK_MEM_HOST) {
+        QK_HIP(hipMemcpyAsync(c->stage, vecs, vb, hipMemcpyHostToDevice, c->stream));
+        QK_HIP(hipMemcpyAsync(c->stage + ((vb + 255) & ~(size_t)255), ids, ib, hipMemcpyHostToDevice, c->stream));
+        dv = (const float *)c->stage;
+        di = (const int64_t *)(c->stage + ((vb + 255) & ~(size_t)255));
+    }
+    int64_t *drows = (int64_t *)(c->stage + off_rows);
+    QK_HIP(hipMemcpyAsync(drows, rows.data(), ib, hipMemcpyHostToDevice, c->stream));
+    IngestMap m{0, nullptr, nullptr, 0, 0, drows};
+    QK_TRY(launch_ingest(c, dv, di, n, s->d, s->nblk, s->vecs, s->norms, s->ids, m));
+    QK_HIP(hipStreamSynchronize(c->stream));
     return QK_OK;
 }
 

@@ -322,14 +322,7 @@ class QuakeIndex:
             assign = pids.reshape(-1)
         info.find_partition_time_us = _us(t0)
         t0 = time.perf_counter()
-        order = torch.argsort(assign, stable=True)  # per-partition append order = input order (:245-258)
-        a_sorted = assign[order]
-        uniq, cnt = torch.unique_consecutive(a_sorted, return_counts=True)
-        xs, ids_s = xd[order].contiguous(), idd[order].contiguous()
-        pos = 0
-        for p, c in zip(uniq.tolist(), cnt.tolist()):
-            self._store.add_entries(int(p), ids_s[pos:pos + c], xs[pos:pos + c])
-            pos += c
+        self._store.add_batch(idd, xd, assign.contiguous())  # per-list append order = input order (:245-258)
         info.modify_time_us = _us(t0)
         return info
 

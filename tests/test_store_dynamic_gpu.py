@@ -1,0 +1,119 @@
+"""Dynamic device partition store: append / swap-with-last remove / add-drop list / batched add, checked
+against a host model with the reference's semantics (index_partition.cpp:52-102, dynamic_inverted_list.cpp:137-173),
+and search parity with the oracle after a stream of mutations."""
+import numpy as np
+import pytest
+
+import oracle as O
+from helpers import make_ivf, make_queries
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from quake_amd.capi import Context
+    c = Context(0)
+    yield c
+    c.close()
+
+
+class HostModel:
+    """list number -> (ids list, vectors list) with append and the reference's remove sweep."""
+
+    def __init__(self, ivf):
+        self.parts = {p: (list(ivf["part_ids"][p]), [v for v in ivf["part_vecs"][p]]) for p in range(ivf["nlist"])}
+
+    def add(self, p, ids, vecs):
+        self.parts[p][0].extend(int(i) for i in ids)
+        self.parts[p][1].extend(v for v in vecs)
+
+    def remove(self, kill):
+        kill = set(int(i) for i in kill)
+        for p, (ids, vecs) in self.parts.items():
+            i = 0
+            while i < len(ids):  # DynamicInvertedLists::remove_vectors: swap-with-last, re-examine position i
+                if ids[i] in kill:
+                    ids[i], vecs[i] = ids[-1], vecs[-1]
+                    ids.pop()
+                    vecs.pop()
+                else:
+                    i += 1
+
+    def csr(self, d):
+        keys = sorted(self.parts)
+        pv = [np.array(self.parts[p][1], np.float32).reshape(-1, d) for p in keys]
+        pi = [np.array(self.parts[p][0], np.int64) for p in keys]
+        return keys, O.csr_from_partitions(pv, pi, d)
+
+
+def check_equal(store, model, d):
+    for p, (ids, vecs) in model.parts.items():
+        gv, gi = store.get_list(p)
+        np.testing.assert_array_equal(gi, np.array(ids, np.int64))
+        np.testing.assert_array_equal(gv, np.array(vecs, np.float32).reshape(-1, d))
+
+
+def test_mutation_stream_matches_host_model_and_oracle(ctx):
+    from quake_amd.capi import Store
+    d, nlist = 40, 9
+    ivf = make_ivf(5000, d, nlist, seed=41, empty=(4,))
+    s = Store(ctx, d)
+    s.build_csr(ivf["offsets"], ivf["ids"], ivf["vecs"])
+    m = HostModel(ivf)
+    rng = np.random.default_rng(42)
+    next_id = 100000
+    for step in range(12):
+        kind = step % 3
+        if kind == 0:  # per-list append, large enough to force extent relocation
+            p = int(rng.integers(0, nlist))
+            n = int(rng.integers(1, 900))
+            v = rng.standard_normal((n, d)).astype(np.float32)
+            ids = np.arange(next_id, next_id + n, dtype=np.int64)
+            next_id += n
+            s.add_entries(p, ids, v)
+            m.add(p, ids, v)
+        elif kind == 1:  # batched add with arbitrary assignment
+            n = int(rng.integers(1, 700))
+            v = rng.standard_normal((n, d)).astype(np.float32)
+            ids = np.arange(next_id, next_id + n, dtype=np.int64)
+            next_id += n
+            a = rng.integers(0, nlist, size=n).astype(np.int64)
+            s.add_batch(ids, v, a)
+            for i in range(n):
+                m.add(int(a[i]), ids[i:i + 1], v[i:i + 1])
+        else:  # remove a random subset of resident ids (+ ids that do not exist)
+            allids = np.concatenate([np.array(x[0], np.int64) for x in m.parts.values()])
+            kill = rng.choice(allids, size=min(400, len(allids) // 3), replace=False)
+            kill = np.concatenate([kill, np.array([10 ** 9, 10 ** 9 + 1])])
+            removed = s.remove_ids(kill)
+            m.remove(kill)
+            assert removed == len(kill) - 2
+        assert s.ntotal() == sum(len(x[0]) for x in m.parts.values())
+    check_equal(s, m, d)
+    # get_vector through the id index
+    some = m.parts[2][0][5]
+    np.testing.assert_array_equal(s.get_vector(some), m.parts[2][1][5])
+    assert s.get_vector(10 ** 9) is None
+    # drop / re-add a list
+    s.remove_list(1)
+    del m.parts[1]
+    s.add_list(nlist)
+    m.parts[nlist] = ([], [])
+    v = rng.standard_normal((50, d)).astype(np.float32)
+    s.add_entries(nlist, np.arange(next_id, next_id + 50), v)
+    m.add(nlist, np.arange(next_id, next_id + 50), v)
+    check_equal(s, m, d)
+    # search over the mutated store == oracle over the host model (partition numbers are the model's keys)
+    keys, (vecs, ids, offs) = m.csr(d)
+    dense_offs = np.zeros(max(keys) + 2, np.int64)
+    sizes = {p: len(m.parts[p][0]) for p in keys}
+    for p in range(max(keys) + 1):
+        dense_offs[p + 1] = dense_offs[p] + sizes.get(p, 0)
+    order = np.concatenate([np.arange(offs[keys.index(p)], offs[keys.index(p) + 1]) for p in range(max(keys) + 1) if p in sizes])
+    q = make_queries(30, d, seed=43)
+    pids = np.stack([rng.permutation(np.array(keys))[:4] for _ in range(30)]).astype(np.int64)
+    gi, gd = ctx.scan(s, q, pids, 10, "l2")
+    oi, od = O.batched_serial_scan(q, vecs[order], ids[order], dense_offs, pids, 10, "l2")
+    np.testing.assert_array_equal(gi, oi)
+    np.testing.assert_array_equal(gd.view(np.uint32), od.view(np.uint32))
