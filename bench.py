@@ -38,31 +38,34 @@ def log(*a):
         print("[bench]", *a, file=sys.stderr, flush=True)
 
 
-def gen_mixture(n, d, ncent, seed, device, sigma=0.3, chunk=1 << 20):
+def gen_mixture(n, d, ncent, seed, device, sigma=0.3, chunk=1 << 20, unit=False):
     g = torch.Generator(device=device).manual_seed(seed)
     cent = torch.randn(ncent, d, generator=g, device=device)
     x = torch.empty(n, d, device=device)
     for i0 in range(0, n, chunk):
         m = min(chunk, n - i0)
         a = torch.randint(0, ncent, (m,), generator=g, device=device)
-        x[i0:i0 + m] = cent[a] + sigma * torch.randn(m, d, generator=g, device=device)
+        v = cent[a] + sigma * torch.randn(m, d, generator=g, device=device)
+        x[i0:i0 + m] = torch.nn.functional.normalize(v, dim=1) if unit else v
     return x, cent
 
 
-def gen_queries(nq, cent_all, seed, device, sigma=0.3):
+def gen_queries(nq, cent_all, seed, device, sigma=0.3, unit=False):
     g = torch.Generator(device=device).manual_seed(seed)
     a = torch.randint(0, cent_all.shape[0], (nq,), generator=g, device=device)
-    return (cent_all[a] + sigma * torch.randn(nq, cent_all.shape[1], generator=g, device=device)).contiguous()
+    v = cent_all[a] + sigma * torch.randn(nq, cent_all.shape[1], generator=g, device=device)
+    return (torch.nn.functional.normalize(v, dim=1) if unit else v).contiguous()
 
 
-def brute_force_topk(q, x, k, id_base=0, chunk=1 << 20):
-    """exact top-k by squared L2 (fp32 matmul expansion); returns (ids [Q,k], d2 [Q,k])."""
+def brute_force_topk(q, x, k, id_base=0, chunk=1 << 20, metric="l2"):
+    """exact top-k (fp32 matmul; squared L2 in expanded form, or negated inner product); returns (ids [Q,k], key [Q,k])
+    with smaller key = better."""
     qn = (q * q).sum(1, keepdim=True)
     best_d = torch.full((q.shape[0], k), float("inf"), device=q.device)
     best_i = torch.full((q.shape[0], k), -1, dtype=torch.int64, device=q.device)
     for i0 in range(0, x.shape[0], chunk):
         xc = x[i0:i0 + chunk]
-        d2 = qn + (xc * xc).sum(1)[None, :] - 2.0 * (q @ xc.T)
+        d2 = (qn + (xc * xc).sum(1)[None, :] - 2.0 * (q @ xc.T)) if metric == "l2" else -(q @ xc.T)
         v, i = torch.topk(d2, min(k, xc.shape[0]), dim=1, largest=False)
         cd = torch.cat([best_d, v], 1)
         ci = torch.cat([best_i, i + i0 + id_base], 1)
@@ -87,6 +90,8 @@ def main():
     ap.add_argument("--nlist", type=int, default=4096, help="lists per GPU")
     ap.add_argument("--batch", type=int, default=1024, help="queries per GPU per step")
     ap.add_argument("--k", type=int, default=10)
+    ap.add_argument("--metric", choices=("l2", "ip"), default="l2",
+                    help="ip: unit-norm mixture (embedding-like), BASELINE.json configs[2] with --dim 768 --k 100")
     ap.add_argument("--nprobe", type=int, default=0, help="0 = sweep for recall@k >= target")
     ap.add_argument("--recall-target", type=float, default=0.9)
     ap.add_argument("--niter", type=int, default=5)
@@ -126,11 +131,13 @@ def main():
 
     # ---- corpus shard + index build (untimed) -------------------------------------------------------------
     t0 = time.time()
-    x, cent_true = gen_mixture(n, d, nlist, seed=1 + 100 * rank, device=dev)
+    metric = args.metric
+    unit = metric == "ip"
+    x, cent_true = gen_mixture(n, d, nlist, seed=1 + 100 * rank, device=dev, unit=unit)
     torch.cuda.synchronize()
     log(f"generated {n}x{d} shard in {time.time() - t0:.1f}s")
     t0 = time.time()
-    centroids, assign, _ = ctx.kmeans(x, nlist, "l2", niter=args.niter, seed=1234)
+    centroids, assign, _ = ctx.kmeans(x, nlist, metric, niter=args.niter, seed=1234)
     torch.cuda.synchronize()
     t_kmeans = time.time() - t0
     log(f"k-means nlist={nlist} niter={args.niter}: {t_kmeans:.2f}s")
@@ -168,9 +175,9 @@ def main():
     parent.build_csr(np.array([0, nlist_g], np.int64), torch.arange(nlist_g, device=dev), cent_all.contiguous())
 
     # ---- queries + exact ground truth --------------------------------------------------------------------------
-    q = gen_queries(Q, cent_true_all, seed=2, device=dev)
+    q = gen_queries(Q, cent_true_all, seed=2, device=dev, unit=unit)
     t0 = time.time()
-    gi, gd2 = brute_force_topk(q, x, k, id_base=id_base)
+    gi, gd2 = brute_force_topk(q, x, k, id_base=id_base, metric=metric)
     if world > 1:
         gl_i = [torch.empty_like(gi) for _ in range(world)]
         gl_d = [torch.empty_like(gd2) for _ in range(world)]
@@ -189,12 +196,12 @@ def main():
     if world > 1:
         # ranks exchange the merge key (squared distance) with one all-gather over RCCL; sqrt after the merge
         from quake_amd.sharded import GpuEngine, ShardedIndex
-        sharded = ShardedIndex(GpuEngine(ctx, parent, store, "l2"), dist, world, rank)
+        sharded = ShardedIndex(GpuEngine(ctx, parent, store, metric), dist, world, rank)
 
     def step(nprobe):
         if sharded is not None:
             return sharded.search(q, nprobe, k, out=(out_i, out_d))
-        return ctx.search(parent, store, q, nprobe, k, "l2", out=(out_i, out_d))
+        return ctx.search(parent, store, q, nprobe, k, metric, out=(out_i, out_d))
 
     # ---- nprobe: smallest reaching the recall target ----------------------------------------------------------------
     sweep = []
@@ -217,7 +224,7 @@ def main():
 
     # per-call phase breakdown + algorithmic bytes (one synchronising call, outside the timed region)
     ctx.set_timing(1)
-    _, _, tinfo = ctx.search(parent, store, q, nprobe, k, "l2", timing=True)
+    _, _, tinfo = ctx.search(parent, store, q, nprobe, k, metric, timing=True)
     scan_bytes = int(tinfo["scan_bytes"])
     log("phases (ms):", {kk: round(v, 4) if isinstance(v, float) else v for kk, v in tinfo.items()})
 
@@ -253,7 +260,7 @@ def main():
     if os.path.exists(pmc_path) and world == 1:
         try:
             pj = json.load(open(pmc_path))
-            if pj.get("nvec") == n and pj.get("nprobe") == nprobe:
+            if pj.get("nvec") == n and pj.get("nprobe") == nprobe and pj.get("dim", 128) == d and pj.get("k", 10) == k:
                 traffic = pj.get("traffic_bytes_per_launch")
         except Exception:
             traffic = None
@@ -272,14 +279,16 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "config": {
-            "workload": f"Synthetic {n * world // 1_000_000}M x {d} f32 L2 Gaussian mixture, nlist={nlist_g}, "
-                        f"batch={Q} queries, k={k}, nprobe={nprobe} (BASELINE.json configs[1] per GPU)",
-            "nvec_per_gpu": n, "dim": d, "nlist_per_gpu": nlist, "batch": Q, "k": k, "nprobe": nprobe,
+            "workload": f"Synthetic {n * world // 1_000_000}M x {d} f32 {metric.upper()} "
+                        f"{'unit-norm ' if unit else ''}Gaussian mixture, nlist={nlist_g}, "
+                        f"batch={Q} queries, k={k}, nprobe={nprobe} "
+                        f"(BASELINE.json configs[{2 if (metric == 'ip' and d == 768) else 1}] per GPU)",
+            "nvec_per_gpu": n, "dim": d, "metric_type": metric, "nlist_per_gpu": nlist, "batch": Q, "k": k, "nprobe": nprobe,
             "recall_at_k": round(recall, 4), "recall_sweep": sweep,
             "sharding": "lists by number across ranks, centroids replicated, RCCL all-gather + merge" if world > 1 else "single GPU",
         },
         "roofline": {
-            "kernel": "k_scan<8,1>",
+            "kernel": "k_scan",
             "bound": "hbm",
             "achieved": round(achieved, 1),
             "peak": HBM_PEAK_GBS,
@@ -309,7 +318,7 @@ def main():
             t, n, reps, ids = 0.0, 0, 0, None
             while t < budget and reps < 10000:
                 t0 = time.perf_counter()
-                ids, _ = O.search(qh, hc, hv, hi, ho, nprobe, k, "l2", batched_scan=batched, num_threads=cores)
+                ids, _ = O.search(qh, hc, hv, hi, ho, nprobe, k, metric, batched_scan=batched, num_threads=cores)
                 t += time.perf_counter() - t0
                 n += Q
                 reps += 1
@@ -322,7 +331,7 @@ def main():
         ns, reps, t_cpu = (ns_b, reps_b, t_b) if best_batched else (ns_s, reps_s, t_s)
         n1 = max(1, min(Q, int(3.0 * qps_serial / max(cores, 1) * 4) or 1))  # a few seconds single-threaded
         t0 = time.perf_counter()
-        O.search(qh[:n1], hc, hv, hi, ho, nprobe, k, "l2", batched_scan=False, num_threads=1)
+        O.search(qh[:n1], hc, hv, hi, ho, nprobe, k, metric, batched_scan=False, num_threads=1)
         t_cpu1 = time.perf_counter() - t0
         # the CPU path returns the same neighbours (direct-form L2 vs expanded: ids equal unless near-tied)
         same = float((ci_ == ri.cpu().numpy()).mean())

@@ -39,19 +39,32 @@ __device__ __forceinline__ int compact_pool(uint32_t *ord, int64_t *id, int n, i
         d[i] = has ? id[e] : LLONG_MAX;
         rk[i] = 0;
     }
-    if (MAXCH == 1 || n <= 64) {  // (n is wave-uniform)
-        // n <= 64: every entry lives in one lane; broadcast entry t with v_readlane (SGPR operands, no LDS round trip
-        // per iteration) -- ~3x faster than re-reading the pool from LDS, and this is the cold-start cost of every segment
-        const uint32_t dlo = (uint32_t)(uint64_t)d[0], dhi = (uint32_t)((uint64_t)d[0] >> 32);
-        for (int t = 0; t < n; t++) {
-            const uint32_t ot = __builtin_amdgcn_readlane(o[0], t);
-            const uint32_t tlo = __builtin_amdgcn_readlane(dlo, t);
-            const uint32_t thi = __builtin_amdgcn_readlane(dhi, t);
-            const int64_t it = (int64_t)(((uint64_t)thi << 32) | tlo);
-            const bool less = (ot < o[0]) || (ot == o[0] && (it < d[0] || (it == d[0] && t < lane)));
-            rk[0] += less ? 1 : 0;
+    // Fast path: rank on the key alone.  Entry t is broadcast from the register of the lane that holds it
+    // (v_readlane -> SGPR operand, no LDS round trip), one compare + add per held entry.  Keys are distinct except
+    // for exact fp32 distance ties; those are detected with the same pass (eq > 1) and re-ranked under the full
+    // (ord, id, position) order below, so the result is always the total order of the oracle.
+    n = __builtin_amdgcn_readfirstlane(n);
+    int eq[MAXCH];
+#pragma unroll
+    for (int i = 0; i < MAXCH; i++) eq[i] = 0;
+#pragma unroll
+    for (int ci = 0; ci < MAXCH; ci++) {
+        const int nt = min(64, n - 64 * ci);
+        for (int t = 0; t < nt; t++) {
+            const uint32_t ot = __builtin_amdgcn_readlane(o[ci], t);
+#pragma unroll
+            for (int i = 0; i < MAXCH; i++) {
+                rk[i] += ot < o[i] ? 1 : 0;
+                eq[i] += ot == o[i] ? 1 : 0;
+            }
         }
-    } else {
+    }
+    bool tie = false;
+#pragma unroll
+    for (int i = 0; i < MAXCH; i++) tie |= (lane + 64 * i < n) && eq[i] > 1;
+    if (__ballot(tie) != 0) {
+#pragma unroll
+        for (int i = 0; i < MAXCH; i++) rk[i] = 0;
         for (int t = 0; t < n; t++) {
             uint32_t ot = ord[t];
             int64_t it = id[t];
@@ -72,4 +85,59 @@ __device__ __forceinline__ int compact_pool(uint32_t *ord, int64_t *id, int n, i
         }
     }
     return n < k ? n : k;
+}
+
+// In-loop variant for pools wider than one wave (k > 36): keeps the k best of n entries WITHOUT sorting them and
+// returns the k-th key.  The k-th smallest key is found by bisection on the 32 key bits (one ballot + popcount per held
+// entry and bit: ~30x fewer instructions than ranking 160+ entries), the survivors are packed with a ballot prefix.
+// A tie on the key that straddles the cut needs the (id, position) order: that case falls back to compact_pool.  The
+// segment-end compaction always goes through compact_pool, so records leave the kernel sorted under the total order.
+template <int MAXCH>
+__device__ __forceinline__ int select_pool(uint32_t *ord, int64_t *id, int n, int k, int lane, uint32_t &kth) {
+    n = __builtin_amdgcn_readfirstlane(n);
+    if (n <= k) {
+        const int nn = compact_pool<MAXCH>(ord, id, n, k, lane);
+        kth = nn >= k ? ord[k - 1] : 0xFFFFFFFFu;
+        return nn;
+    }
+    uint32_t o[MAXCH];
+    int64_t d[MAXCH];
+#pragma unroll
+    for (int i = 0; i < MAXCH; i++) {
+        const int e = lane + 64 * i;
+        const bool has = e < n;
+        o[i] = has ? ord[e] : 0xFFFFFFFFu;  // (a live key is never 0xFFFFFFFF: the append path rejects it)
+        d[i] = has ? id[e] : LLONG_MAX;
+    }
+    // T = the largest value with fewer than k keys below it = the k-th smallest key
+    uint32_t T = 0;
+    for (int b = 31; b >= 0; b--) {
+        const uint32_t tr = T | (1u << b);
+        int c = 0;
+#pragma unroll
+        for (int i = 0; i < MAXCH; i++) c += __popcll(__ballot(o[i] < tr));
+        if (c < k) T = tr;
+    }
+    int c_le = 0;
+#pragma unroll
+    for (int i = 0; i < MAXCH; i++) c_le += __popcll(__ballot(o[i] <= T));
+    if (c_le != k) {  // several entries share the k-th key
+        const int nn = compact_pool<MAXCH>(ord, id, n, k, lane);
+        kth = ord[k - 1];
+        return nn;
+    }
+    int base = 0;
+#pragma unroll
+    for (int i = 0; i < MAXCH; i++) {
+        const bool keep = o[i] <= T;
+        const uint64_t m = __ballot(keep);
+        if (keep) {
+            const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+            ord[pos] = o[i];
+            id[pos] = d[i];
+        }
+        base += __popcll(m);
+    }
+    kth = T;
+    return k;
 }

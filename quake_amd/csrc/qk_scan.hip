@@ -250,7 +250,9 @@ struct SeedParams {
     int seed_ranks;      // pairs with r < seed_ranks are sampled (the nearest partitions give the tight bound)
 };
 
-// grid = Q * seed_ranks waves: wave w -> query w / seed_ranks, rank w % seed_ranks
+// grid = Q * seed_ranks waves: wave w -> query w / seed_ranks, rank w % seed_ranks.  M rows per lane: the sample is the
+// first min(n_p, 64*M) rows, so that it can bound k <= 64*M.
+template <int M>
 __global__ __launch_bounds__(64) void k_seed_tau(SeedParams S) {
     const int lane = threadIdx.x;
     const int64_t qq = blockIdx.x / S.seed_ranks;
@@ -261,54 +263,71 @@ __global__ __launch_bounds__(64) void k_seed_tau(SeedParams S) {
     if (p < 0 || p >= S.npids) return;
     const int size_p = S.pt_size[p];
     if (size_p < S.k) return;  // fewer than k rows: no bound from this partition
-    const int n = min(size_p, 64);
+    const int n = min(size_p, 64 * M);
     const int64_t q = qq;
     const float *xq = S.x + q * S.d;
-    const int lrow = min(lane, n - 1);  // idle lanes recompute the last row (keeps every load unconditional)
-    const int64_t row = S.pt_off[p] + lrow;
-    const int64_t tile = row >> 4;
-    const int r = (int)(row & 15);
-    const float yn = S.norms[row];
     const float xnq = S.xn[q];
-    float acc = 0.0f;
-    // 8 blocks (128 columns) at a time: the 32 float4 of the lane's row and the 128 query values (2 per lane, broadcast
-    // with v_readlane) are requested together, then one k-ordered fmaf chain -- the same arithmetic as the MFMA path
-    for (int c0 = 0; c0 < S.nblk; c0 += 8) {
-        float4 v[8][4];
+    const int64_t row_base = S.pt_off[p];
+    uint32_t key[M];
 #pragma unroll
-        for (int c = 0; c < 8; c++) {
-            const int cc = min(c0 + c, S.nblk - 1);
-            const float4 *blk = S.vecs + (tile * S.nblk + cc) * 64 + r;
+    for (int i = 0; i < M; i++) {
+        const int lrow = min(lane + 64 * i, n - 1);  // idle lanes recompute the last row (keeps every load unconditional)
+        const int64_t row = row_base + lrow;
+        const int64_t tile = row >> 4;
+        const int r = (int)(row & 15);
+        const float yn = S.norms[row];
+        float acc = 0.0f;
+        // 8 blocks (128 columns) at a time: the 32 float4 of the lane's row and the 128 query values (2 per lane,
+        // broadcast with v_readlane) are requested together, then one k-ordered fmaf chain -- the arithmetic of the MFMA path
+        for (int c0 = 0; c0 < S.nblk; c0 += 8) {
+            float4 v[8][4];
 #pragma unroll
-            for (int g = 0; g < 4; g++) v[c][g] = blk[g * 16];
-        }
-        const int colA = c0 * 16 + lane, colB = c0 * 16 + 64 + lane;
-        const float xa = colA < S.d ? xq[colA] : 0.0f;
-        const float xb = colB < S.d ? xq[colB] : 0.0f;
+            for (int c = 0; c < 8; c++) {
+                const int cc = min(c0 + c, S.nblk - 1);
+                const float4 *blk = S.vecs + (tile * S.nblk + cc) * 64 + r;
 #pragma unroll
-        for (int c = 0; c < 8; c++) {
-            if (c0 + c < S.nblk) {
-                const float e[16] = {v[c][0].x, v[c][1].x, v[c][2].x, v[c][3].x, v[c][0].y, v[c][1].y, v[c][2].y, v[c][3].y,
-                                     v[c][0].z, v[c][1].z, v[c][2].z, v[c][3].z, v[c][0].w, v[c][1].w, v[c][2].w, v[c][3].w};
+                for (int g = 0; g < 4; g++) v[c][g] = blk[g * 16];
+            }
+            const int colA = c0 * 16 + lane, colB = c0 * 16 + 64 + lane;
+            const float xa = colA < S.d ? xq[colA] : 0.0f;
+            const float xb = colB < S.d ? xq[colB] : 0.0f;
 #pragma unroll
-                for (int t = 0; t < 16; t++) {
-                    const int cl = c * 16 + t;  // column within this group of 128
-                    // (the builtin is typed int -> int: move the bits, not the value)
-                    const float xv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cl < 64 ? xa : xb), cl & 63));
-                    acc = __fmaf_rn(e[t], xv, acc);  // padded columns: e[t] == 0 and xv == 0 -> acc unchanged
+            for (int c = 0; c < 8; c++) {
+                if (c0 + c < S.nblk) {
+                    const float e[16] = {v[c][0].x, v[c][1].x, v[c][2].x, v[c][3].x, v[c][0].y, v[c][1].y, v[c][2].y, v[c][3].y,
+                                         v[c][0].z, v[c][1].z, v[c][2].z, v[c][3].z, v[c][0].w, v[c][1].w, v[c][2].w, v[c][3].w};
+#pragma unroll
+                    for (int t = 0; t < 16; t++) {
+                        const int cl = c * 16 + t;  // column within this group of 128
+                        // (the builtin is typed int -> int: move the bits, not the value)
+                        const float xv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cl < 64 ? xa : xb), cl & 63));
+                        acc = __fmaf_rn(e[t], xv, acc);  // padded columns: e[t] == 0 and xv == 0 -> acc unchanged
+                    }
                 }
             }
         }
+        key[i] = S.metric == QK_METRIC_L2 ? ord_from_l2(l2_expanded(xnq, yn, acc)) : ord_from_ip(acc);
+        if (lane + 64 * i >= n) key[i] = 0xFFFFFFFFu;
     }
-    uint32_t key = S.metric == QK_METRIC_L2 ? ord_from_l2(l2_expanded(xnq, yn, acc)) : ord_from_ip(acc);
-    if (lane >= n) key = 0xFFFFFFFFu;
-    int rk = 0;
-    for (int t = 0; t < 64; t++) {
-        const uint32_t ot = __builtin_amdgcn_readlane(key, t);
-        rk += (ot < key || (ot == key && t < lane)) ? 1 : 0;
+    // rank of every sampled key under (key, sample position); the one with rank k-1 is the bound
+    int rk[M];
+#pragma unroll
+    for (int i = 0; i < M; i++) rk[i] = 0;
+#pragma unroll
+    for (int jj = 0; jj < M; jj++) {
+        for (int t = 0; t < 64; t++) {
+            const uint32_t ot = __builtin_amdgcn_readlane(key[jj], t);
+            const int pos_t = t + 64 * jj;
+#pragma unroll
+            for (int i = 0; i < M; i++) rk[i] += (ot < key[i] || (ot == key[i] && pos_t < lane + 64 * i)) ? 1 : 0;
+        }
     }
-    const uint64_t mk = __ballot(rk == S.k - 1);
-    const uint32_t bound = __builtin_amdgcn_readlane(key, __ffsll((unsigned long long)mk) - 1);
+    uint32_t bound = 0xFFFFFFFFu;
+#pragma unroll
+    for (int i = 0; i < M; i++) {
+        const uint64_t mk = __ballot(rk[i] == S.k - 1);
+        if (mk) bound = __builtin_amdgcn_readlane(key[i], __ffsll((unsigned long long)mk) - 1);
+    }
     if (lane == 0 && bound != 0xFFFFFFFFu) atomicMax(&S.gtau[q], ~bound);  // gtau holds ~bound: 0 = no bound yet
 }
 
@@ -542,11 +561,18 @@ __global__ __launch_bounds__(64) void k_scan(ScanParams P) {
                                 const int jq = __ffsll((unsigned long long)need) - 1;
                                 need &= need - 1;
                                 const int n = __builtin_amdgcn_readlane(cnt, jq);
-                                const int nn = compact_pool<MAXCH>(pool_ord + jq * C, pool_id + jq * C, n, k, lane);
+                                uint32_t kth;
+                                int nn;
+                                if (MAXCH > 1) {
+                                    nn = select_pool<MAXCH>(pool_ord + jq * C, pool_id + jq * C, n, k, lane, kth);
+                                } else {
+                                    nn = compact_pool<MAXCH>(pool_ord + jq * C, pool_id + jq * C, n, k, lane);
+                                    kth = nn >= k ? pool_ord[jq * C + k - 1] : 0xFFFFFFFFu;
+                                }
                                 if (j == jq) {
                                     cnt = nn;
                                     if (nn >= k) {
-                                        tau = min(tau, pool_ord[jq * C + k - 1]);
+                                        tau = min(tau, kth);
                                         // publish (fire and forget: no returned value, no wait)
                                         if (P.gtau && lane < 16) atomicMax(&P.gtau[myq], ~tau);
                                     }
@@ -830,6 +856,7 @@ static int launch_scan(int db, int maxch, dim3 grid, size_t lds, hipStream_t st,
     if (db == D && maxch == M) return launch_scan_t<D, M>(grid, lds, st, sp);
     QK_CASE(1, 1) QK_CASE(1, 2) QK_CASE(1, 4) QK_CASE(1, 8) QK_CASE(2, 1) QK_CASE(2, 2) QK_CASE(2, 4) QK_CASE(2, 8)
     QK_CASE(4, 1) QK_CASE(4, 2) QK_CASE(4, 4) QK_CASE(4, 8) QK_CASE(8, 1) QK_CASE(8, 2) QK_CASE(8, 4) QK_CASE(8, 8)
+    QK_CASE(16, 1) QK_CASE(16, 2) QK_CASE(16, 4) QK_CASE(16, 8)
 #undef QK_CASE
     QK_FAIL(QK_ERR_UNSUPPORTED, "no scan kernel for DB=%d MAXCH=%d", db, maxch);
 }
@@ -859,7 +886,7 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
 
     // ---- geometry ----------------------------------------------------------------------------------
     const int nblk = s->nblk;
-    const int DB = (nblk % 8 == 0) ? 8 : (nblk % 4 == 0) ? 4 : (nblk % 2 == 0) ? 2 : 1;
+    int DB = (nblk % 8 == 0) ? 8 : (nblk % 4 == 0) ? 4 : (nblk % 2 == 0) ? 2 : 1;
     // pool capacity per query: k + slack, limited by LDS (one wave per workgroup, 160 KiB max)
     const size_t lds_budget = 160 * 1024 - 64;
     const size_t q_bytes = (size_t)nblk * 1024;
@@ -888,6 +915,9 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
     if (const char *e = getenv("QK_SCAN_WAVES_PER_CU")) {  // probe override, read per call so one process can sweep it
         if (atoi(e) > 0) waves_per_cu = atoi(e);
     }
+    // wide rows (d >= 256: the LDS query tile leaves room for <= 4 waves per CU): 16 blocks = 16 KB per load step, so
+    // that the few resident waves still keep enough bytes in flight to cover the HBM latency
+    if (nblk % 16 == 0 && waves_per_cu <= 4 && !getenv("QK_SCAN_NO_DB16")) DB = 16;
     const int64_t n_waves = (int64_t)num_cus * waves_per_cu;
     // records: every wave-segment emits at most 16; segments <= items + waves
     const int64_t npresent = std::max<int64_t>(1, s->nlist);
@@ -954,7 +984,10 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
     G.pair_head = pair_head;
     G.gtau = gtau;
     static const int no_seed = getenv("QK_NO_SEED") ? atoi(getenv("QK_NO_SEED")) : 0;
-    const bool seeded = !no_seed && a.share_tau && k <= 64 && npairs > 0 && npids > 0;
+    // (measured: for k > 64 a sample bound is far looser than the bound the pools reach by themselves -- no gain, and
+    //  the 64*M-row sample costs 0.1 ms at d = 768; the wider instantiations stay available for probing)
+    static const int seed_max_k = getenv("QK_SEED_MAX_K") ? atoi(getenv("QK_SEED_MAX_K")) : 64;
+    const bool seeded = !no_seed && a.share_tau && k <= std::min(seed_max_k, 512) && npairs > 0 && npids > 0;
     if (seeded) {
         // bound seeding: for the first (nearest) partitions of every query, the k-th smallest distance of a 64-row
         // sample goes into gtau[q]
@@ -976,7 +1009,15 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
         sd.gtau = gtau;
         sd.seed_ranks = std::min(2, G.P);
         // (a side stream + fork/join events was measured slower than running it in line: 45 vs 40 us group phase)
-        hipLaunchKernelGGL(k_seed_tau, dim3((unsigned)(Q * sd.seed_ranks)), dim3(64), 0, st, sd);
+        const dim3 sg((unsigned)(Q * sd.seed_ranks));
+        if (k <= 64)
+            hipLaunchKernelGGL((k_seed_tau<1>), sg, dim3(64), 0, st, sd);
+        else if (k <= 128)
+            hipLaunchKernelGGL((k_seed_tau<2>), sg, dim3(64), 0, st, sd);
+        else if (k <= 256)
+            hipLaunchKernelGGL((k_seed_tau<4>), sg, dim3(64), 0, st, sd);
+        else
+            hipLaunchKernelGGL((k_seed_tau<8>), sg, dim3(64), 0, st, sd);
     }
     if (npairs > 0) hipLaunchKernelGGL(k_group_count, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, st, G);
     hipLaunchKernelGGL(k_group_scan, dim3(1), dim3(1024), 0, st, G);

@@ -14,7 +14,9 @@ def main():
     ctx = Context(0)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     g = torch.Generator(device=dev).manual_seed(0)
-    d = 128
+    d = int(os.environ.get("PROBE_D", "128"))
+    kk = int(os.environ.get("PROBE_K", "10"))
+    metric = os.environ.get("PROBE_METRIC", "l2")
     x = torch.randn(nvec, d, generator=g, device=dev)
     # partition sizes: lognormal-ish spread around nvec/nlist, like a k-means build
     w = torch.exp(0.5 * torch.randn(nlist, generator=g, device=dev))
@@ -30,14 +32,14 @@ def main():
     bytes_alg = int(sizes[uniq].sum().item()) * d * 4
     ctx.set_timing(0)
     for _ in range(3):
-        ctx.scan(s, q, pids, 10, "l2")
+        ctx.scan(s, q, pids, kk, metric)
     ctx.set_timing(2)
     for _ in range(20):
-        ctx.scan(s, q, pids, 10, "l2")
+        ctx.scan(s, q, pids, kk, metric)
     t = ctx.read_timing()
     ms = t["scan_ms"] / t["calls"]
     print(json.dumps({"mode": os.environ.get("QK_SCAN_MODE", "0"), "wpc": os.environ.get("QK_SCAN_WAVES_PER_CU", "auto"),
-                      "P": P, "scan_ms": round(ms, 4), "GBs": round(bytes_alg / ms / 1e6, 1), "group_ms": round(t["group_ms"] / t["calls"], 4),
+                      "d": d, "k": kk, "metric": metric, "P": P, "scan_ms": round(ms, 4), "GBs": round(bytes_alg / ms / 1e6, 1), "group_ms": round(t["group_ms"] / t["calls"], 4),
                       "merge_ms": round(t["merge_ms"] / t["calls"], 4)}), flush=True)
 
 if __name__ == "__main__":
