@@ -388,15 +388,20 @@ __device__ __forceinline__ float4 qk_ld_stream(const float4 *p) {
 
 // MODE 0 = product; 1 = skip the top-k epilogue; 2 = loads only (probe variants for bandwidth attribution, QK_SCAN_MODE)
 template <int DB, int MAXCH, int MODE = 0>
-__global__ __launch_bounds__(64) void k_scan(ScanParams P) {
+__global__ __launch_bounds__(256) void k_scan(ScanParams P) {
     extern __shared__ __align__(16) unsigned char smem[];
-    const int lane = threadIdx.x;
+    // nw waves per workgroup (1, 2 or 4) share ONE LDS query tile and split every segment's tiles between them; each
+    // wave keeps its own pools and emits its own records.  nw > 1 is chosen by the host for wide rows, where a
+    // wave-private query tile (1 KiB per 16 columns) would leave room for only 2-3 waves per CU.
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int j = lane & 15, g = lane >> 4;
     const int nblk = P.nblk, C = P.C, k = P.k;
     const bool l2 = P.metric == QK_METRIC_L2;
-    float4 *qs = (float4 *)smem;                                               // [nblk*64]
-    int64_t *pool_id = (int64_t *)(smem + (size_t)nblk * 1024);                // [16][C]
-    uint32_t *pool_ord = (uint32_t *)(smem + (size_t)nblk * 1024 + (size_t)16 * C * 8);  // [16][C]
+    float4 *qs = (float4 *)smem;                                               // [nblk*64], shared by the workgroup
+    unsigned char *pool_base = smem + (size_t)nblk * 1024 + (size_t)wv * 16 * C * 12;
+    int64_t *pool_id = (int64_t *)pool_base;                                   // [16][C]
+    uint32_t *pool_ord = (uint32_t *)(pool_base + (size_t)16 * C * 8);         // [16][C]
     uint32_t *my_ord = pool_ord + j * C;
     int64_t *my_id = pool_id + j * C;
     const int ncd = nblk / DB;  // d-chunks per tile
@@ -436,10 +441,13 @@ __global__ __launch_bounds__(64) void k_scan(ScanParams P) {
         const int nqt = (cnt_p + 15) >> 4;
         const long long local = cur - base;
         const int qt = (int)(local / ntl);
-        const int tl = (int)(local - (long long)qt * ntl);
-        const int tend = (int)min((long long)ntl, (long long)tl + (T1 - cur));
-        cur += tend - tl;
-        if (qt == nqt - 1 && tend == ntl) ai++;  // item sequence of this partition exhausted
+        const int tl_wg = (int)(local - (long long)qt * ntl);
+        const int tend_wg = (int)min((long long)ntl, (long long)tl_wg + (T1 - cur));
+        cur += tend_wg - tl_wg;
+        // this wave's contiguous share of the segment (the whole of it when nw == 1)
+        const int tl = tl_wg + (int)(((long long)(tend_wg - tl_wg) * wv) / nw);
+        const int tend = tl_wg + (int)(((long long)(tend_wg - tl_wg) * (wv + 1)) / nw);
+        if (qt == nqt - 1 && tend_wg == ntl) ai++;  // item sequence of this partition exhausted
         const int nq = min(16, cnt_p - 16 * qt);
         const int gidx = inf.qoff + 16 * qt + j;
         // grouped entry of this lane's query + record slots for the segment: issued FIRST so that they return first
@@ -452,7 +460,8 @@ __global__ __launch_bounds__(64) void k_scan(ScanParams P) {
         int cnt = 0;
         float xnj = 0.0f;
         {
-            const int64_t tile_abs0 = (row_off >> 4) + tl;
+            // (a wave whose share is empty still issues the static loads: keep them inside the segment)
+            const int64_t tile_abs0 = (row_off >> 4) + min(tl, tend_wg - 1);
             const float4 *src = P.vecs + tile_abs0 * nblk * 64 + lane;
             const float4 *nsrc = (const float4 *)(P.norms + (tile_abs0 << 4)) + g;  // +4 float4 per tile
             // ids of this lane's 4 rows travel with the tile (static prefetch): an id load inside the append path
@@ -590,7 +599,9 @@ __global__ __launch_bounds__(64) void k_scan(ScanParams P) {
                 const float4 *qsrc = P.xq4 + (int64_t)qsafe * nblk * 4 + g;
                 if (P.gtau) tau = ~__hip_atomic_load(&P.gtau[qsafe], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (l2) xnj = P.xn[qsafe];
-                for (int cb0 = 0; cb0 < nblk; cb0 += DB) {
+                // LDS only (no vmcnt wait: the first tile stays in flight): every wave has left the previous tile
+                if (nw > 1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                for (int cb0 = wv * DB; cb0 < nblk; cb0 += nw * DB) {
                     float4 qv[DB];
 #pragma unroll
                     for (int b = 0; b < DB; b++) qv[b] = qsrc[(cb0 + b) * 4];
@@ -604,6 +615,7 @@ __global__ __launch_bounds__(64) void k_scan(ScanParams P) {
                     tau = 0xFFFFFFFFu;
                     xnj = 0.0f;
                 }
+                if (nw > 1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             }
             if (!QK_OPT_EARLY_LOAD) QK_LOAD(a0, y0, i00, i01);
             for (int s = 0; s < nsteps; s += 2) {
@@ -724,9 +736,10 @@ __global__ __launch_bounds__(64) void k_merge(MergeParams M) {
                         pool_id[sl] = dd;
                     }
                     cnt += __popcll(m);
-                    if (cnt > Cm - 64) {
-                        cnt = compact_pool<MAXCH>(pool_ord, pool_id, cnt, k, lane);
-                        if (cnt >= k) tau = min(tau, pool_ord[k - 1]);
+                    if (cnt > Cm - 64) {  // (unsorted k best + their bound; the final compaction sorts)
+                        uint32_t kth;
+                        cnt = select_pool<MAXCH>(pool_ord, pool_id, cnt, k, lane, kth);
+                        if (cnt >= k) tau = min(tau, kth);
                     }
                 }
                 // records are sorted ascending: once a valid lane fails the bound, the rest of the record fails too
@@ -789,8 +802,9 @@ __global__ __launch_bounds__(64) void k_merge_ranks(const int64_t *__restrict__ 
                 }
                 cnt += __popcll(m);
                 if (cnt > Cm - 64) {
-                    cnt = compact_pool<MAXCH>(pool_ord, pool_id, cnt, k, lane);
-                    if (cnt >= k) tau = min(tau, pool_ord[k - 1]);
+                    uint32_t kth;
+                    cnt = select_pool<MAXCH>(pool_ord, pool_id, cnt, k, lane, kth);
+                    if (cnt >= k) tau = min(tau, kth);
                 }
             }
         }
@@ -834,26 +848,26 @@ int qk_merge_topk_device(qk_ctx *ctx, const int64_t *in_ids, const float *in_key
 
 // ---- host orchestration -------------------------------------------------------------------------------------
 template <int DB, int MAXCH>
-static int launch_scan_t(dim3 grid, size_t lds, hipStream_t st, const ScanParams &sp) {
+static int launch_scan_t(dim3 grid, dim3 block, size_t lds, hipStream_t st, const ScanParams &sp) {
     QK_HIP(hipFuncSetAttribute((const void *)k_scan<DB, MAXCH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((k_scan<DB, MAXCH>), grid, dim3(64), lds, st, sp);
+    hipLaunchKernelGGL((k_scan<DB, MAXCH>), grid, block, lds, st, sp);
     return QK_OK;
 }
 
-static int launch_scan(int db, int maxch, dim3 grid, size_t lds, hipStream_t st, const ScanParams &sp) {
+static int launch_scan(int db, int maxch, dim3 grid, dim3 block, size_t lds, hipStream_t st, const ScanParams &sp) {
     static const int probe_mode = getenv("QK_SCAN_MODE") ? atoi(getenv("QK_SCAN_MODE")) : 0;
     if (probe_mode == 1 && db == 8 && maxch == 1) {
         QK_HIP(hipFuncSetAttribute((const void *)k_scan<8, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((k_scan<8, 1, 1>), grid, dim3(64), lds, st, sp);
+        hipLaunchKernelGGL((k_scan<8, 1, 1>), grid, block, lds, st, sp);
         return QK_OK;
     }
     if (probe_mode == 2 && db == 8 && maxch == 1) {
         QK_HIP(hipFuncSetAttribute((const void *)k_scan<8, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((k_scan<8, 1, 2>), grid, dim3(64), lds, st, sp);
+        hipLaunchKernelGGL((k_scan<8, 1, 2>), grid, block, lds, st, sp);
         return QK_OK;
     }
 #define QK_CASE(D, M) \
-    if (db == D && maxch == M) return launch_scan_t<D, M>(grid, lds, st, sp);
+    if (db == D && maxch == M) return launch_scan_t<D, M>(grid, block, lds, st, sp);
     QK_CASE(1, 1) QK_CASE(1, 2) QK_CASE(1, 4) QK_CASE(1, 8) QK_CASE(2, 1) QK_CASE(2, 2) QK_CASE(2, 4) QK_CASE(2, 8)
     QK_CASE(4, 1) QK_CASE(4, 2) QK_CASE(4, 4) QK_CASE(4, 8) QK_CASE(8, 1) QK_CASE(8, 2) QK_CASE(8, 4) QK_CASE(8, 8)
     QK_CASE(16, 1) QK_CASE(16, 2) QK_CASE(16, 4) QK_CASE(16, 8)
@@ -894,8 +908,32 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
     while ((size_t)16 * C * 12 + q_bytes > lds_budget && C > k + 4) C -= 4;
     if ((size_t)16 * C * 12 + q_bytes > lds_budget || C < k + 4 || C > 512)
         QK_FAIL(QK_ERR_UNSUPPORTED, "qk_scan: k=%d with d=%d does not fit the LDS top-k pools", k, s->d);
+    // waves per workgroup: 1 unless the wave-private query tile keeps a CU below 4 resident waves; then 2 or 4 waves
+    // share the tile (and, if that is what it takes to reach 4 waves, the pools give up part of their slack)
+    int nw = 1;
+    {
+        auto waves_for = [&](int w, int cap) {
+            const size_t need = q_bytes + (size_t)w * 16 * cap * 12 + 512;
+            return need > 160 * 1024 ? 0 : (int)std::min<size_t>(8, w * ((160 * 1024) / need));
+        };
+        int best = waves_for(1, C);
+        if (best < 4) {
+            const int Cs = qk_round_up(k + 28, 4);
+            for (int w = 2; w <= 4; w *= 2) {
+                if (waves_for(w, C) > best) { best = waves_for(w, C); nw = w; }
+            }
+            if (best < 4 && Cs < C) {
+                for (int w = 1; w <= 4; w *= 2)
+                    if (waves_for(w, Cs) > best) { best = waves_for(w, Cs); nw = w; C = Cs; }
+            }
+        }
+        if (const char *e = getenv("QK_SCAN_NW")) {
+            const int w = atoi(e);
+            if ((w == 1 || w == 2 || w == 4) && waves_for(w, C) > 0) nw = w;
+        }
+    }
     const int maxch = pick_maxch(C);
-    const size_t lds_scan = q_bytes + (size_t)16 * C * 12;
+    const size_t lds_scan = q_bytes + (size_t)nw * 16 * C * 12;
     const int Cm = qk_round_up(k + 64, 64);
     const int maxch_m = Cm <= 128 ? 2 : Cm <= 256 ? 4 : Cm <= 512 ? 8 : 16;
     const size_t lds_merge = (size_t)Cm * 12;
@@ -905,24 +943,27 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
     // static tile partition => every wave must be resident at once.  Measured (bench.py / scan_probe.py): 8 per CU is best
     // for long launches; when a wave would get fewer than ~160 tiles, 6 per CU wins (fewer, longer segments: less
     // per-segment cost, fewer records to merge) -- 5.06 -> 5.5 TB/s on the bench configuration; 10+ lose bandwidth.
-    int waves_per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / (lds_scan + 512)));
+    int waves_per_cu = nw * (int)std::max<size_t>(1, std::min<size_t>(8 / nw, (160 * 1024) / (lds_scan + 512)));
     {
         const int64_t npresent_e = std::max<int64_t>(1, s->nlist);
         const int64_t mean_tiles = std::max<int64_t>(1, (s->ntotal / npresent_e + 15) / 16);
         const int64_t tiles_est = std::max<int64_t>(1, npairs / 16 + std::min<int64_t>(npresent_e, npairs)) * mean_tiles;
-        if (waves_per_cu > 6 && tiles_est < (int64_t)8 * num_cus * 160) waves_per_cu = 6;
+        if (nw == 1 && waves_per_cu > 6 && tiles_est < (int64_t)8 * num_cus * 160) waves_per_cu = 6;
     }
     if (const char *e = getenv("QK_SCAN_WAVES_PER_CU")) {  // probe override, read per call so one process can sweep it
-        if (atoi(e) > 0) waves_per_cu = atoi(e);
+        if (atoi(e) > 0) waves_per_cu = std::max(nw, atoi(e) / nw * nw);
     }
     // wide rows (d >= 256: the LDS query tile leaves room for <= 4 waves per CU): 16 blocks = 16 KB per load step, so
     // that the few resident waves still keep enough bytes in flight to cover the HBM latency
     if (nblk % 16 == 0 && waves_per_cu <= 4 && !getenv("QK_SCAN_NO_DB16")) DB = 16;
-    const int64_t n_waves = (int64_t)num_cus * waves_per_cu;
+    const int wgs_per_cu = waves_per_cu / nw;
+    const int64_t n_wgs = (int64_t)num_cus * wgs_per_cu;
+    const int64_t n_waves = n_wgs * nw;
     // records: every wave-segment emits at most 16; segments <= items + waves
     const int64_t npresent = std::max<int64_t>(1, s->nlist);
     const int64_t items_bound = std::max<int64_t>(1, npairs / 16 + std::min<int64_t>(npresent, npairs));
-    const int64_t max_recs = std::min<int64_t>(0x7FFFFFF0LL, std::min<int64_t>(16 * (items_bound + n_waves), npairs + 16 * n_waves));
+    // (with nw waves per workgroup every segment is cut nw ways: nw records per pair and segment)
+    const int64_t max_recs = std::min<int64_t>(0x7FFFFFF0LL, nw * std::min<int64_t>(16 * (items_bound + n_wgs), npairs + 16 * n_wgs));
 
     // ---- workspace ---------------------------------------------------------------------------------
     const int64_t np1 = std::max<int64_t>(npairs, 1);
@@ -1059,15 +1100,15 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
         sp.rec_id = rec_id;
         // do not launch (many) more waves than there are tiles to hand out
         int64_t tiles_ub = std::max<int64_t>(1, items_bound * ((std::max<int64_t>(1, s->max_size) + 15) / 16));
-        int64_t grid = std::max<int64_t>(1, std::min<int64_t>(n_waves, tiles_ub));
+        int64_t grid = std::max<int64_t>(1, std::min<int64_t>(n_wgs, tiles_ub));
         // every wave must be resident at once AND evenly spread: pad the LDS request so that exactly waves_per_cu
         // workgroups fit on a CU (the dispatcher otherwise packs up to 10 on some CUs and leaves others short, and with
         // a static partition the slowest CU sets the kernel time)
         // (measured +2 % at 6 and 8 per CU; at 5 per CU the padded request only fits 4 -- pad the tested counts only)
         size_t lds_launch = lds_scan;
-        if (waves_per_cu == 4 || waves_per_cu == 6 || waves_per_cu == 8)
-            lds_launch = std::max<size_t>(lds_scan, (size_t)(160 * 1024) / waves_per_cu - 512);
-        QK_TRY(launch_scan(DB, maxch, dim3((unsigned)grid), lds_launch, st, sp));
+        if (wgs_per_cu == 4 || wgs_per_cu == 6 || wgs_per_cu == 8 || (nw > 1 && wgs_per_cu <= 2))
+            lds_launch = std::max<size_t>(lds_scan, (size_t)(160 * 1024) / wgs_per_cu - 512);
+        QK_TRY(launch_scan(DB, maxch, dim3((unsigned)grid), dim3(64 * nw), lds_launch, st, sp));
     }
     QK_TRY(pe.mark(2));
 

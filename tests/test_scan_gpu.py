@@ -144,3 +144,30 @@ def test_large_k_and_limits(ctx):
         np.testing.assert_array_equal(gd.view(np.uint32), od.view(np.uint32))
     with pytest.raises(QuakeHipError):
         ctx.search(parent, s, q, 6, QK_MAX_K + 1, "l2")
+
+
+@pytest.mark.parametrize("d,metric", [(768, "ip"), (768, "l2"), (1024, "l2"), (512, "ip")])
+def test_wide_rows_shared_query_tile(ctx, d, metric):
+    """d >= 512: several waves of a workgroup share one LDS query tile and split each segment (k_scan nw = 2/4), pools
+    wider than one wave use the bisection select; exact duplicates force the tie fallback of both compactions."""
+    ivf = make_ivf(12000, d, 12, seed=41, metric=metric, empty=(2,))
+    # duplicate vectors under different ids: equal keys that must come back ordered by id
+    vecs = ivf["vecs"].copy()
+    off = ivf["offsets"]
+    for p in (0, 4, 7):
+        a, b = int(off[p]), int(off[p + 1])
+        if b - a > 40:
+            vecs[a + 20:a + 40] = vecs[a:a + 20]
+    from quake_amd.capi import Store
+    s = Store(ctx, d)
+    s.build_csr(off, ivf["ids"], vecs)
+    q = make_queries(70, d, seed=42, like=ivf["x"], metric=metric)
+    q[:20] = vecs[int(off[0]):int(off[0]) + 20]  # queries that hit the duplicated rows exactly
+    rng = np.random.default_rng(43)
+    for P, k in [(1, 10), (5, 100), (12, 100), (12, 37), (3, 300)]:
+        pids = np.stack([rng.permutation(12)[:P] for _ in range(q.shape[0])]).astype(np.int64)
+        pids[:20, 0] = 0
+        gi, gd = ctx.scan(s, q, pids, k, metric)
+        oi, od = O.batched_serial_scan(q, vecs, ivf["ids"], off, pids, k, metric)
+        np.testing.assert_array_equal(gi, oi)
+        np.testing.assert_array_equal(gd.view(np.uint32), od.view(np.uint32))
