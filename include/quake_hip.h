@@ -136,6 +136,18 @@ QK_API int qk_scan(qk_ctx *ctx, qk_store *s, const float *x, int64_t Q, const in
 QK_API int qk_search(qk_ctx *ctx, qk_store *parent, qk_store *s, const float *x, int64_t Q, int nprobe, int k, int metric,
                      int64_t *out_ids, float *out_dist, int mem, qk_timing *timing);
 
+/* QueryCoordinator::search with SearchParams::recall_target > 0 and batched_scan == false: adaptive partition
+ * scanning (query_coordinator.cpp:612-657 picks M = max((int)(nlist * initial_search_fraction), 1) candidate partitions
+ * from the parent; the use_aps branch of serial_scan, :471-611, scans them in rank order and stops a query once the
+ * recall estimate of include/geometry.h:57-113,247-295,345-407 reaches recall_target).  The batch advances in rounds on
+ * the device; per query the result and the count of partitions scanned are those of the sequential walk.
+ * out_ids/out_dist [Q][k]; out_nscanned [Q] (may be NULL) = partitions the walk visited; timing (may be NULL):
+ * total_ms and n_items = rounds.  Errors: parent == NULL or fewer than 2 candidates -> QK_ERR_INVALID
+ * ("Boundary distances must have at least 2 partitions to create an estimate.", geometry.h:350). */
+QK_API int qk_search_aps(qk_ctx *ctx, qk_store *parent, qk_store *s, const float *x, int64_t Q, int k, int metric,
+                         float recall_target, float recompute_threshold, int use_precomputed, float initial_search_fraction,
+                         int64_t *out_ids, float *out_dist, int32_t *out_nscanned, int mem, qk_timing *timing);
+
 /* Multi-GPU merge step (the cross-worker batch_add of worker_scan, query_coordinator.cpp:167-173,231-235):
  * merge G per-rank results [G][Q][k] (already all-gathered by the caller, e.g. torch.distributed over RCCL) into
  * [Q][k] under the same (key,id) order.  in_key are SQUARED L2 distances / inner products, i.e. what qk_search

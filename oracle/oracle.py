@@ -20,7 +20,8 @@ __all__ = [
     "METRIC_IP", "METRIC_L2", "build", "lib", "metric_code", "ip", "l2sqr_direct", "row_norms", "TopkBuffer",
     "scan_list", "batched_scan_list", "serial_scan", "batched_serial_scan", "coarse", "search", "rand_perm",
     "kmeans_assign", "kmeans_accumulate", "kmeans", "kmeans_refine_partitions", "recall", "csr_from_partitions",
-    "max_threads",
+    "max_threads", "incomplete_beta", "incomplete_beta_table", "incomplete_beta_lookup", "log_cap_volume", "recall_profile",
+    "boundary_distances", "search_aps",
 ]
 
 
@@ -82,6 +83,21 @@ def lib():
         L.qo_recall.argtypes = [_i64p, _i64p, C.c_int64, C.c_int, _f32p]
         L.qo_recall_set.argtypes = [_i64p, _i64p, C.c_int64, C.c_int, _f32p]
         L.qo_max_threads.restype = C.c_int
+        _f64p = C.POINTER(C.c_double)
+        L.qo_incomplete_beta.restype = C.c_double
+        L.qo_incomplete_beta.argtypes = [C.c_double, C.c_double, C.c_double]
+        L.qo_incomplete_beta_table.argtypes = [C.c_int, _f64p]
+        L.qo_incomplete_beta_lookup.restype = C.c_double
+        L.qo_incomplete_beta_lookup.argtypes = [_f64p, C.c_double]
+        L.qo_log_cap_volume.restype = C.c_double
+        L.qo_log_cap_volume.argtypes = [C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, _f64p]
+        L.qo_recall_profile.restype = C.c_int
+        L.qo_recall_profile.argtypes = [_f32p, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, _f64p, _f32p]
+        L.qo_boundary_distances.argtypes = [_f32p, C.POINTER(_f32p), C.c_int, C.c_int, C.c_int, _f32p]
+        L.qo_search_aps.restype = C.c_int
+        L.qo_search_aps.argtypes = [_f32p, C.c_int64, _f32p, _i64p, C.c_int64, _f32p, _i64p, _i64p, C.c_int64, C.c_int,
+                                    C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_float, C.c_int, C.c_int, _i64p,
+                                    _f32p, C.POINTER(C.c_int32)]
         _lib = L
     return _lib
 
@@ -309,3 +325,73 @@ def recall(ids, gt, set_semantics=True):
     gtk = np.ascontiguousarray(gt[:, :k])
     (lib().qo_recall_set if set_semantics else lib().qo_recall)(_pi(ids), _pi(gtk), nq, k, _pf(out))
     return out
+
+
+# ---- adaptive partition scanning (geometry.h + serial_scan's use_aps branch) -----------------------------------------
+def incomplete_beta(a, b, x):
+    return float(lib().qo_incomplete_beta(float(a), float(b), float(x)))
+
+
+def incomplete_beta_table(d):
+    t = np.empty(1001, np.float64)
+    lib().qo_incomplete_beta_table(int(d), t.ctypes.data_as(C.POINTER(C.c_double)))
+    return t
+
+
+def incomplete_beta_lookup(table, x):
+    table = np.ascontiguousarray(table, np.float64)
+    return float(lib().qo_incomplete_beta_lookup(table.ctypes.data_as(C.POINTER(C.c_double)), float(x)))
+
+
+def log_cap_volume(radius, boundary_distance, d, use_precomputed=True, euclidean=True, table=None):
+    if table is None:
+        table = incomplete_beta_table(d)
+    table = np.ascontiguousarray(table, np.float64)
+    return float(lib().qo_log_cap_volume(float(radius), float(boundary_distance), int(d), int(use_precomputed), int(euclidean),
+                                         table.ctypes.data_as(C.POINTER(C.c_double))))
+
+
+def recall_profile(boundary_distances, query_radius, d, use_precomputed=True, euclidean=True):
+    bd = _f32(boundary_distances)
+    table = incomplete_beta_table(d)
+    out = np.empty(bd.shape[0], np.float32)
+    rc = lib().qo_recall_profile(_pf(bd), bd.shape[0], float(query_radius), int(d), int(use_precomputed), int(euclidean),
+                                 table.ctypes.data_as(C.POINTER(C.c_double)), _pf(out))
+    if rc != 0:
+        raise RuntimeError("Boundary distances must have at least 2 partitions to create an estimate.")  # geometry.h:350
+    return out
+
+
+def boundary_distances(q, centroids, euclidean=True):
+    """centroids [M][d] in rank order (row 0 = nearest)."""
+    q = _f32(q)
+    c = _f32(centroids)
+    M, d = c.shape
+    ptrs = (_f32p * M)(*[c[j].ctypes.data_as(_f32p) for j in range(M)])
+    out = np.empty(M, np.float32)
+    lib().qo_boundary_distances(_pf(q), ptrs, M, d, int(euclidean), _pf(out))
+    return out
+
+
+def search_aps(x, centroids, vecs, ids, offsets, k, metric, recall_target, recompute_threshold=0.001, use_precomputed=True,
+               initial_search_fraction=0.02, centroid_ids=None, expanded=True, num_threads=1):
+    """QuakeIndex::search with SearchParams.recall_target > 0 (serial_scan APS).  Returns (ids, dist, nscanned)."""
+    x = _f32(x)
+    centroids = _f32(centroids)
+    vecs = _f32(vecs)
+    ids = _i64(ids)
+    offsets = _i64(offsets)
+    nq, d = x.shape
+    nlist = offsets.shape[0] - 1
+    k = max(int(k), 1)
+    cid = _i64(centroid_ids) if centroid_ids is not None else None
+    out_i = np.empty((nq, k), np.int64)
+    out_d = np.empty((nq, k), np.float32)
+    out_n = np.zeros(nq, np.int32)
+    rc = lib().qo_search_aps(_pf(x), nq, _pf(centroids), _pi(cid), centroids.shape[0], _pf(vecs), _pi(ids), _pi(offsets), nlist, d,
+                             k, metric_code(metric), float(recall_target), float(recompute_threshold), int(use_precomputed),
+                             float(initial_search_fraction), int(expanded), int(num_threads), _pi(out_i), _pf(out_d),
+                             out_n.ctypes.data_as(C.POINTER(C.c_int32)))
+    if rc != 0:
+        raise RuntimeError("Boundary distances must have at least 2 partitions to create an estimate.")
+    return out_i, out_d, out_n

@@ -9,7 +9,8 @@
  *   - TypedTopKBuffer<float,int64_t>        src/cpp/include/list_scanning.h:41-204
  *   - scan_list (+4 specialisations)         src/cpp/include/list_scanning.h:241-311
  *   - batched_scan_list                      src/cpp/include/list_scanning.h:313-366
- *   - QueryCoordinator::serial_scan          src/cpp/src/query_coordinator.cpp:471-611 (fixed nprobe; APS branch not restated)
+ *   - QueryCoordinator::serial_scan          src/cpp/src/query_coordinator.cpp:471-611 (fixed nprobe, and the use_aps branch: qo_search_aps)
+ *   - APS geometry                           src/cpp/include/geometry.h:57-211,247-295,345-407
  *   - QueryCoordinator::batched_serial_scan  src/cpp/src/query_coordinator.cpp:675-799
  *   - QueryCoordinator::search               src/cpp/src/query_coordinator.cpp:612-657 (coarse = parent batched scan)
  *   - kmeans                                 src/cpp/src/clustering.cpp:13-97
@@ -823,4 +824,237 @@ QO_API int qo_max_threads(void) {
 #else
     return 1;
 #endif
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Adaptive partition scanning (APS): geometry.h + the use_aps branch of serial_scan.
+ * PARITY UNPINNED: the reference holds no golden vector for any of this (its tests only print the
+ * recall reached, test/cpp/search_recall_tests.cpp:284-340).  The incomplete beta function is pinned
+ * against scipy.special.betainc in tests/test_oracle_aps.py; the stopping rule is restated literally.
+ * Canonical choices beyond the reference (all dot products are the k-ordered fmaf chain as everywhere
+ * else; FAISS leaves the order open):
+ *   - acos of the IP boundary angle is (float)acos((double)x) (std::acos(float) is <= 1 ulp of that)
+ *   - expression contraction is off (the build flag), like the HIP path
+ * ---------------------------------------------------------------------------------------------- */
+#define QO_NUM_X_VALUES 1001 /* geometry.h:7 */
+#define QO_STOP 1.0e-8       /* geometry.h:9 */
+#define QO_TINY 1.0e-30      /* geometry.h:10 */
+
+/* geometry.h:115-161: regularised incomplete beta I_x(a,b), Lentz continued fraction */
+QO_API double qo_incomplete_beta(double a, double b, double x) {
+    if (x < 0.0 || x > 1.0) return INFINITY;
+    if (x > (a + 1.0) / (a + b + 2.0)) return (1.0 - qo_incomplete_beta(b, a, 1.0 - x));
+    const double lbeta_ab = lgamma(a) + lgamma(b) - lgamma(a + b);
+    const double front = exp(log(x) * a + log(1.0 - x) * b - lbeta_ab) / a;
+    double f = 1.0, c = 1.0, d = 0.0;
+    for (int i = 0; i <= 200; ++i) {
+        int m = i / 2;
+        double numerator;
+        if (i == 0)
+            numerator = 1.0;
+        else if (i % 2 == 0)
+            numerator = (m * (b - m) * x) / ((a + 2.0 * m - 1.0) * (a + 2.0 * m));
+        else
+            numerator = -((a + m) * (a + b + m) * x) / ((a + 2.0 * m) * (a + 2.0 * m + 1));
+        d = 1.0 + numerator * d;
+        if (fabs(d) < QO_TINY) d = QO_TINY;
+        d = 1.0 / d;
+        c = 1.0 + numerator / c;
+        if (fabs(c) < QO_TINY) c = QO_TINY;
+        const double cd = c * d;
+        f *= cd;
+        if (fabs(1.0 - cd) < QO_STOP) return front * (f - 1.0);
+    }
+    return INFINITY;
+}
+
+/* geometry.h:163-180: table of I_x((d+1)/2, 1/2) at x = i/1000.  (The reference fills ONE process-wide table
+ * for the first d it sees, :184-188; this restatement takes the table of the index's own d.) */
+QO_API void qo_incomplete_beta_table(int d, double *table) {
+    double dx = 1.0 / (QO_NUM_X_VALUES - 1);
+    double a = (d + 1.0) / 2.0, b = 0.5;
+    for (int i = 0; i < QO_NUM_X_VALUES; i++) table[i] = qo_incomplete_beta(a, b, i * dx);
+}
+
+/* geometry.h:182-211: linear interpolation in the table (std::max/std::min argument order kept: NaN -> 1.0) */
+QO_API double qo_incomplete_beta_lookup(const double *table, double x) {
+    double t = (x < 1.0) ? x : 1.0; /* std::min(1.0, x) */
+    x = (0.0 < t) ? t : 0.0;        /* std::max(0.0, .) */
+    double scaled_x = x * (QO_NUM_X_VALUES - 1);
+    int x_index = (int)scaled_x;
+    if (x_index > QO_NUM_X_VALUES - 2) x_index = QO_NUM_X_VALUES - 2;
+    if (x_index < 0) x_index = 0;
+    double y1 = table[x_index], y2 = table[x_index + 1];
+    double dx = 1.0 / (QO_NUM_X_VALUES - 1);
+    double x1 = x_index * dx;
+    return y1 + (x - x1) * (y2 - y1) / dx;
+}
+
+/* geometry.h:247-295, ratio = true */
+QO_API double qo_log_cap_volume(double radius, double boundary_distance, int d, int use_precomputed, int euclidean,
+                                const double *table) {
+    double h = radius - boundary_distance;
+    double t = (h < 2 * radius) ? h : 2 * radius; /* std::min(2 * radius, h) */
+    h = (0.0 < t) ? t : 0.0;                      /* std::max(0.0, .) */
+    if (euclidean) {
+        double x = sqrt((2 * radius * h - h * h) / (radius * radius));
+        double inc_beta = use_precomputed ? qo_incomplete_beta_lookup(table, x) : qo_incomplete_beta((d + 1.0) / 2.0, 0.5, x);
+        if (inc_beta <= 0.0 || isnan(inc_beta) || isinf(inc_beta)) return -INFINITY;
+        return log(0.5) + log(inc_beta);
+    }
+    double s1 = sin(radius / 2.0), s2 = sin(boundary_distance / 2.0);
+    double log_inc_beta = log(qo_incomplete_beta((d - 1) / 2.0, 0.5, s1 * s1));
+    double log_inc_beta_boundary = log(qo_incomplete_beta((d - 1) / 2.0, 0.5, s2 * s2));
+    return log(0.5) + log_inc_beta - log_inc_beta_boundary;
+}
+
+/* geometry.h:345-407.  returns -1 when fewer than 2 partitions (the reference throws) */
+QO_API int qo_recall_profile(const float *bd, int M, float query_radius, int d, int use_precomputed, int euclidean,
+                             const double *table, float *probs) {
+    if (M < 2) return -1;
+    for (int j = 0; j < M; j++) probs[j] = 0.0f;
+    for (int j = 1; j < M; j++) {
+        float b = bd[j];
+        if (b >= query_radius) {
+            probs[j] = 0.0f;
+            continue;
+        }
+        double volume_ratio = exp(qo_log_cap_volume(query_radius, b, d, use_precomputed, euclidean, table));
+        probs[j] = (float)((volume_ratio > 0.0) ? volume_ratio : 0.0);
+    }
+    probs[0] = (float)(2.0 * probs[1]);
+    double sum = 0.0;
+    for (int j = 0; j < M; j++) sum += probs[j];
+    if (sum > 0.0f) {
+        for (int j = 0; j < M; j++) probs[j] = (float)(probs[j] / sum);
+    } else {
+        for (int j = 0; j < M; j++) probs[j] = (float)(1.0 / M);
+    }
+    return 0;
+}
+
+/* geometry.h:57-113.  cent[j] = centroid of the j-th ranked candidate partition; out[0] = -1 */
+QO_API void qo_boundary_distances(const float *q, const float *const *cent, int M, int d, int euclidean, float *out) {
+    float *line = (float *)malloc(sizeof(float) * (size_t)d * 3);
+    float *mid = line + d, *res = line + 2 * d;
+    for (int j = 0; j < M; j++) out[j] = -1.0f;
+    const float *c0 = cent[0];
+    if (euclidean) {
+        for (int i = 0; i < d; i++) res[i] = q[i] - c0[i];
+        for (int j = 1; j < M; j++) {
+            for (int i = 0; i < d; i++) line[i] = cent[j][i] - c0[i];
+            float A2 = qo_ip(line, line, d);
+            float A = sqrtf(A2);
+            float dot_val = qo_ip(res, line, d);
+            out[j] = fabsf(dot_val - 0.5f * A2) / A;
+        }
+    } else {
+        for (int j = 1; j < M; j++) {
+            for (int i = 0; i < d; i++) line[i] = cent[j][i] - c0[i];
+            for (int i = 0; i < d; i++) mid[i] = line[i] / 2.0f;
+            for (int i = 0; i < d; i++) mid[i] = c0[i] + mid[i];
+            float norm = sqrtf(qo_ip(mid, mid, d));
+            for (int i = 0; i < d; i++) mid[i] = mid[i] / norm;
+            float ang = qo_ip(q, mid, d);
+            out[j] = (float)acos((double)ang);
+        }
+    }
+    free(line);
+}
+
+/* QueryCoordinator::search with recall_target > 0 and batched_scan == false (query_coordinator.cpp:612-657)
+ * followed by serial_scan's use_aps branch (:471-611):
+ *   M = max((int)(nlist * initial_search_fraction), 1) candidate partitions from the parent (:638-641),
+ *   boundary distances once per query (:529-536), then partition after partition: scan, radius = k-th distance
+ *   (TopkBuffer::get_kth_distance, list_scanning.h:187-191: the sentinel when fewer than k results),
+ *   recompute the profile when the radius moved by more than recompute_threshold (:562-571),
+ *   stop when the probabilities of the partitions BEFORE the current one reach the target (:572-578).
+ * expanded = 1: per-row distances in the expanded (norm) form of the batched path, the arithmetic of the HIP kernels;
+ * expanded = 0: direct form, as scan_list.  centroid_row_of[pid] = row of that partition's centroid in `centroids`.
+ * out_nscan[q] = partitions visited (p reached + 1, or M).  An empty profile (never computed because the radius test
+ * produced NaN) contributes 0 to the estimate -- the reference indexes an empty vector there.
+ * returns 0, or -1 when M < 2 (compute_recall_profile throws). */
+QO_API int qo_search_aps(const float *x, int64_t nq, const float *centroids, const int64_t *centroid_ids, int64_t nlist_parent,
+                         const float *vecs, const int64_t *ids, const int64_t *offsets, int64_t nlist, int d, int k, int metric,
+                         float recall_target, float recompute_threshold, int use_precomputed, float initial_search_fraction,
+                         int expanded, int num_threads, int64_t *out_ids, float *out_dist, int32_t *out_nscan) {
+    if (k <= 0) k = 1;
+    int M = (int)((float)nlist * initial_search_fraction);
+    if (M < 1) M = 1;
+    int kk = M < nlist_parent ? M : (int)nlist_parent;
+    if (kk < 2) return -1;
+    int64_t *pids = (int64_t *)malloc(sizeof(int64_t) * (size_t)(nq > 0 ? nq : 1) * (size_t)kk);
+    qo_coarse(x, nq, centroids, centroid_ids, nlist_parent, d, kk, metric, num_threads, pids, NULL);
+    /* partition id -> centroid row */
+    int64_t max_id = -1;
+    for (int64_t i = 0; i < nlist_parent; i++) {
+        int64_t id = centroid_ids ? centroid_ids[i] : i;
+        if (id > max_id) max_id = id;
+    }
+    int64_t *row_of = (int64_t *)malloc(sizeof(int64_t) * (size_t)(max_id + 2));
+    for (int64_t i = 0; i <= max_id; i++) row_of[i] = -1;
+    for (int64_t i = 0; i < nlist_parent; i++) row_of[centroid_ids ? centroid_ids[i] : i] = i;
+    double table[QO_NUM_X_VALUES];
+    qo_incomplete_beta_table(d, table);
+    const int euclid = metric == QO_METRIC_L2;
+    if (num_threads <= 0) {
+#ifdef _OPENMP
+        num_threads = omp_get_max_threads();
+#else
+        num_threads = 1;
+#endif
+    }
+#pragma omp parallel for num_threads(num_threads) schedule(dynamic, 4)
+    for (int64_t q = 0; q < nq; q++) {
+        const float *xq = x + q * d;
+        qo_topk buf;
+        topk_init(&buf, k, metric == QO_METRIC_IP, 8192 > k ? 8192 : k);
+        qo_topk *bufp = &buf;
+        const float **cent = (const float **)malloc(sizeof(float *) * (size_t)kk);
+        float *bd = (float *)malloc(sizeof(float) * (size_t)kk * 2);
+        float *probs = bd + kk;
+        int have_probs = 0;
+        for (int j = 0; j < kk; j++) {
+            int64_t pi = pids[q * kk + j];
+            cent[j] = centroids + (size_t)(pi >= 0 && pi <= max_id && row_of[pi] >= 0 ? row_of[pi] : 0) * d;
+        }
+        qo_boundary_distances(xq, cent, kk, d, euclid, bd);
+        float query_radius = euclid ? 1000000.0f : -1000000.0f;
+        int nscan = 0;
+        for (int p = 0; p < kk; p++) {
+            int64_t pi = pids[q * kk + p];
+            nscan = p + 1;
+            if (pi < 0 || pi >= nlist) continue; /* :540 */
+            int64_t o = offsets[pi];
+            int n = (int)(offsets[pi + 1] - o);
+            if (expanded)
+                qo_batched_scan_list(xq, vecs + o * d, ids + o, 1, n, d, &bufp, metric, 1);
+            else
+                scan_list_fast(xq, vecs + o * d, ids + o, n, d, &buf, metric);
+            topk_flush(&buf);
+            float curr_radius;
+            if (buf.curr >= k)
+                curr_radius = euclid ? sqrtf(buf.buf[k - 1].v) : buf.buf[k - 1].v;
+            else
+                curr_radius = euclid ? FLT_MAX : -INFINITY; /* sentinel slot, list_scanning.h:57-63,190 */
+            float percent_change = fabsf(curr_radius - query_radius) / curr_radius;
+            if (percent_change > recompute_threshold) {
+                query_radius = curr_radius;
+                qo_recall_profile(bd, kk, query_radius, d, use_precomputed, euclid, table, probs);
+                have_probs = 1;
+            }
+            float recall_estimate = 0.0f;
+            if (have_probs)
+                for (int i = 0; i < p; i++) recall_estimate += probs[i];
+            if (recall_estimate >= recall_target) break;
+        }
+        emit_result(&buf, k, metric, out_ids + q * k, out_dist + q * k);
+        if (out_nscan) out_nscan[q] = nscan;
+        free(buf.buf);
+        free(cent);
+        free(bd);
+    }
+    free(row_of);
+    free(pids);
+    return 0;
 }

@@ -64,6 +64,8 @@ SIGNATURES = {
     "qk_coarse": (_int, [_vp, _vp, _vp, _i64, _int, _int, _vp, _vp, _int]),
     "qk_scan": (_int, [_vp, _vp, _vp, _i64, _vp, _int, _int, _int, _vp, _vp, _int, C.POINTER(QkTiming)]),
     "qk_search": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _int, _int, _vp, _vp, _int, C.POINTER(QkTiming)]),
+    "qk_search_aps": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _int, C.c_float, C.c_float, _int, C.c_float, _vp, _vp, _vp, _int,
+                      C.POINTER(QkTiming)]),
     "qk_merge_topk": (_int, [_vp, _vp, _vp, _int, _i64, _int, _int, _vp, _vp]),
     "qk_kmeans_assign": (_int, [_vp, _vp, _i64, _vp, _i64, _int, _int, _vp, _vp, _int]),
     "qk_kmeans_accumulate": (_int, [_vp, _vp, _i64, _int, _vp, _i64, _vp, _vp, _int]),

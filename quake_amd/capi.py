@@ -66,7 +66,8 @@ def _i64(a):
 def _empty_like_mem(shape, dtype, ref):
     if _is_torch(ref) and ref.is_cuda:
         import torch
-        return torch.empty(shape, dtype=torch.int64 if dtype == np.int64 else torch.float32, device=ref.device)
+        tdt = torch.int64 if dtype == np.int64 else torch.int32 if dtype == np.int32 else torch.float32
+        return torch.empty(shape, dtype=tdt, device=ref.device)
     return np.empty(shape, dtype)
 
 
@@ -166,6 +167,23 @@ class Context:
         check(self.lib.qk_search(self.h, parent.h if parent is not None else None, store.h, _ptr(x), Q, int(nprobe), int(k),
                                  metric_code(metric), _ptr(out_i), _ptr(out_d), mem, C.byref(t) if timing else None))
         return (out_i, out_d, timing_dict(t)) if timing else (out_i, out_d)
+
+    def search_aps(self, parent, store, x, k, metric, recall_target, recompute_threshold=0.001, use_precomputed=True,
+                   initial_search_fraction=0.02, timing=False):
+        """recall-target search (adaptive partition scanning).  Returns (ids, dist, nscanned[, timing])."""
+        x = _f32(x)
+        Q = x.shape[0]
+        k = max(int(k), 1)
+        mem = _mem_of(x)
+        out_i = _empty_like_mem((Q, k), np.int64, x)
+        out_d = _empty_like_mem((Q, k), np.float32, x)
+        out_n = _empty_like_mem((Q,), np.int32, x)
+        t = QkTiming()
+        check(self.lib.qk_search_aps(self.h, parent.h if parent is not None else None, store.h, _ptr(x), Q, k, metric_code(metric),
+                                     float(recall_target), float(recompute_threshold), int(bool(use_precomputed)),
+                                     float(initial_search_fraction), _ptr(out_i), _ptr(out_d), _ptr(out_n), mem,
+                                     C.byref(t) if timing else None))
+        return (out_i, out_d, out_n, timing_dict(t)) if timing else (out_i, out_d, out_n)
 
     def merge_topk(self, ids, keys, metric):
         """ids/keys: CUDA tensors [G][Q][k] (keys = squared L2 / dot); returns ([Q][k] ids, [Q][k] distances)."""

@@ -129,8 +129,6 @@ shared_ptr<SearchResult> QuakeIndex::search(Tensor x, shared_ptr<SearchParams> s
         res->distances = torch::empty({0}, torch::kFloat32);
         return res;
     }
-    if (sp->recall_target > 0.0f && parent_)
-        throw std::runtime_error("adaptive partition scanning (recall_target > 0) is not on this path yet");
     auto t0 = clk::now();
     const bool on_dev = x.is_cuda();
     Tensor xq = on_dev ? x.to(torch::kFloat32).contiguous() : host_f32(x);
@@ -143,6 +141,23 @@ shared_ptr<SearchResult> QuakeIndex::search(Tensor x, shared_ptr<SearchParams> s
     res->distances = torch::empty({Q, k}, opts_f);
     qk_timing tm;
     std::memset(&tm, 0, sizeof(tm));
+    if (sp->recall_target > 0.0f && parent_ && !sp->batched_scan) {
+        // adaptive partition scanning (query_coordinator.cpp:502,637-641): candidates = nlist * initial_search_fraction
+        Tensor nscan = torch::empty({Q}, torch::TensorOptions().dtype(torch::kInt32).device(xq.device()));
+        check(qk_search_aps(ctx_, parent_->store_, store_, xq.data_ptr<float>(), Q, k, metric_, sp->recall_target,
+                            sp->recompute_threshold, sp->use_precomputed ? 1 : 0, sp->initial_search_fraction,
+                            res->ids.data_ptr<int64_t>(), res->distances.data_ptr<float>(), nscan.data_ptr<int32_t>(),
+                            on_dev ? QK_MEM_DEVICE : QK_MEM_HOST, &tm));
+        auto ti = res->timing_info;
+        ti->n_queries = Q;
+        ti->partitions_scanned = (int)nscan.sum().item<int64_t>();
+        ti->job_wait_time_ns = (int64_t)(tm.total_ms * 1e6);
+        ti->parent_info = std::make_shared<SearchTimingInfo>();
+        ti->parent_info->n_queries = Q;
+        ti->parent_info->n_clusters = 1;
+        ti->total_time_ns = std::chrono::duration_cast<std::chrono::nanoseconds>(clk::now() - t0).count();
+        return res;
+    }
     check(qk_ctx_set_timing(ctx_, 1));
     int st = qk_search(ctx_, parent_ ? parent_->store_ : nullptr, store_, xq.data_ptr<float>(), Q, nprobe, k, metric_,
                        res->ids.data_ptr<int64_t>(), res->distances.data_ptr<float>(), on_dev ? QK_MEM_DEVICE : QK_MEM_HOST, &tm);

@@ -1,0 +1,592 @@
+// qk_aps.hip -- adaptive partition scanning (recall-target search) on the device.
+//
+// Replaces, for SearchParams::recall_target > 0 and batched_scan == false:
+//   QueryCoordinator::search          src/cpp/src/query_coordinator.cpp:612-657  (M = nlist * initial_search_fraction candidates)
+//   serial_scan, use_aps branch       src/cpp/src/query_coordinator.cpp:471-611  (scan, radius, recall profile, stop)
+//   compute_boundary_distances        src/cpp/include/geometry.h:57-113
+//   incomplete_beta (+ table/lookup)  src/cpp/include/geometry.h:115-211
+//   log_hyperspherical_cap_volume     src/cpp/include/geometry.h:247-295
+//   compute_recall_profile            src/cpp/include/geometry.h:345-407
+//
+// The reference walks one query's candidate partitions one after the other on a CPU thread.  Here the whole batch
+// advances in ROUNDS: a round scans, for every query that has not stopped, its next few ranked partitions in one launch
+// of the scan pipeline with the results of every (query, partition) pair kept apart (qk_scan_args::per_pair); one wave
+// per query then replays the reference's sequential rule over those partitions in rank order -- merge, radius,
+// profile, estimate, stop -- so the answer and the number of partitions counted as scanned are those of the sequential
+// walk; partitions scanned past the stopping point in the same round are discarded.  How many partitions a query takes
+// into the next round is predicted from its current profile.
+#include "qk_internal.h"
+#include "qk_device.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+namespace {
+
+constexpr int APS_NX = 1001;      // geometry.h:7  NUM_X_VALUES
+constexpr double APS_STOP = 1.0e-8;   // geometry.h:9
+constexpr double APS_TINY = 1.0e-30;  // geometry.h:10
+constexpr int APS_CH = 32;        // partitions per query and round (upper bound)
+
+// ---- regularised incomplete beta I_x(a, b): Lentz's continued fraction, the published algorithm geometry.h uses.
+// One definition serves the host (table of the precomputed path) and the device (IP metric / use_precomputed = false).
+__host__ __device__ inline double beta_cf(double a, double b, double x) {
+    // caller guarantees 0 <= x <= (a+1)/(a+b+2)
+    const double lbeta = lgamma(a) + lgamma(b) - lgamma(a + b);
+    const double front = exp(log(x) * a + log(1.0 - x) * b - lbeta) / a;
+    double f = 1.0, c = 1.0, dd = 0.0;
+    for (int i = 0; i <= 200; ++i) {
+        const int m = i / 2;
+        double num;
+        if (i == 0)
+            num = 1.0;
+        else if ((i & 1) == 0)
+            num = (m * (b - m) * x) / ((a + 2.0 * m - 1.0) * (a + 2.0 * m));
+        else
+            num = -((a + m) * (a + b + m) * x) / ((a + 2.0 * m) * (a + 2.0 * m + 1));
+        dd = 1.0 + num * dd;
+        if (fabs(dd) < APS_TINY) dd = APS_TINY;
+        dd = 1.0 / dd;
+        c = 1.0 + num / c;
+        if (fabs(c) < APS_TINY) c = APS_TINY;
+        const double cd = c * dd;
+        f *= cd;
+        if (fabs(1.0 - cd) < APS_STOP) return front * (f - 1.0);
+    }
+    return INFINITY;  // did not converge
+}
+__host__ __device__ inline double inc_beta(double a, double b, double x) {
+    if (x < 0.0 || x > 1.0) return INFINITY;
+    // symmetry I_x(a,b) = 1 - I_{1-x}(b,a): the two thresholds sum to 1, so the swapped argument is below its own
+    if (x > (a + 1.0) / (a + b + 2.0)) return 1.0 - beta_cf(b, a, 1.0 - x);
+    return beta_cf(a, b, x);
+}
+
+// table lookup with linear interpolation (geometry.h:182-211); NaN clamps to 1 like std::max(0, std::min(1, x))
+__device__ inline double beta_lookup(const double *table, double x) {
+    const double t = (x < 1.0) ? x : 1.0;
+    x = (0.0 < t) ? t : 0.0;
+    const double scaled = x * (APS_NX - 1);
+    int xi = (int)scaled;
+    xi = xi > APS_NX - 2 ? APS_NX - 2 : xi;
+    xi = xi < 0 ? 0 : xi;
+    const double y1 = table[xi], y2 = table[xi + 1];
+    const double dx = 1.0 / (APS_NX - 1);
+    const double x1 = xi * dx;
+    return y1 + (x - x1) * (y2 - y1) / dx;
+}
+
+// log of the cap-volume ratio (geometry.h:247-295 with ratio = true)
+__device__ inline double log_cap_volume(double radius, double bdist, int d, bool precomputed, bool euclid, const double *table) {
+    double h = radius - bdist;
+    const double t = (h < 2 * radius) ? h : 2 * radius;
+    h = (0.0 < t) ? t : 0.0;
+    if (euclid) {
+        const double x = sqrt((2 * radius * h - h * h) / (radius * radius));
+        const double ib = precomputed ? beta_lookup(table, x) : inc_beta((d + 1.0) / 2.0, 0.5, x);
+        if (ib <= 0.0 || isnan(ib) || isinf(ib)) return -INFINITY;
+        return log(0.5) + log(ib);
+    }
+    const double s1 = sin(radius / 2.0), s2 = sin(bdist / 2.0);
+    const double l1 = log(inc_beta((d - 1) / 2.0, 0.5, s1 * s1));
+    const double l2 = log(inc_beta((d - 1) / 2.0, 0.5, s2 * s2));
+    return log(0.5) + l1 - l2;
+}
+
+// element (row, col) of the tile-major arena (qk_internal.h)
+__device__ inline float arena_at(const float *vecs, int nblk, int64_t row, int col) {
+    const int64_t tile = row >> 4;
+    const int r = (int)(row & 15), c = col >> 4, t = col & 15;
+    return vecs[(((tile * nblk + c) * 64 + (t & 3) * 16 + r) << 2) + (t >> 2)];
+}
+
+// ---- candidate rows + boundary distances (geometry.h:57-113): one thread per (query, candidate) ----------------------
+struct BoundaryParams {
+    const float *x;          // [Q][d]
+    const int64_t *pids;     // [Q][M] ranked candidate partitions
+    const int32_t *row_of;   // partition id -> arena row of its centroid (or -1)
+    int64_t n_row_of;
+    const float *cvecs;      // parent arena
+    int cnblk;
+    int64_t Q;
+    int M, d, euclid;
+    float *bd;               // [Q][M]
+};
+
+__global__ __launch_bounds__(256) void k_aps_boundary(BoundaryParams B) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B.Q * B.M) return;
+    const int64_t q = idx / B.M;
+    const int j = (int)(idx - q * B.M);
+    if (j == 0) {
+        B.bd[idx] = -1.0f;
+        return;
+    }
+    const int64_t p0 = B.pids[q * B.M], pj = B.pids[idx];
+    const int64_t r0 = (p0 >= 0 && p0 < B.n_row_of) ? B.row_of[p0] : -1;
+    const int64_t rj = (pj >= 0 && pj < B.n_row_of) ? B.row_of[pj] : -1;
+    if (r0 < 0 || rj < 0) {
+        B.bd[idx] = -1.0f;
+        return;
+    }
+    const float *xq = B.x + q * B.d;
+    float out;
+    if (B.euclid) {
+        float a2 = 0.0f, dot = 0.0f;
+        for (int i = 0; i < B.d; i++) {
+            const float c0 = arena_at(B.cvecs, B.cnblk, r0, i);
+            const float v = arena_at(B.cvecs, B.cnblk, rj, i) - c0;  // line vector c_j - c_0
+            const float res = xq[i] - c0;                            // residual q - c_0
+            a2 = __fmaf_rn(v, v, a2);
+            dot = __fmaf_rn(res, v, dot);
+        }
+        const float a = sqrtf(a2);
+        out = fabsf(dot - 0.5f * a2) / a;
+    } else {
+        float n2 = 0.0f;
+        for (int i = 0; i < B.d; i++) {
+            const float c0 = arena_at(B.cvecs, B.cnblk, r0, i);
+            const float mid = c0 + (arena_at(B.cvecs, B.cnblk, rj, i) - c0) / 2.0f;
+            n2 = __fmaf_rn(mid, mid, n2);
+        }
+        const float nrm = sqrtf(n2);
+        float ang = 0.0f;
+        for (int i = 0; i < B.d; i++) {
+            const float c0 = arena_at(B.cvecs, B.cnblk, r0, i);
+            const float mid = (c0 + (arena_at(B.cvecs, B.cnblk, rj, i) - c0) / 2.0f) / nrm;
+            ang = __fmaf_rn(xq[i], mid, ang);
+        }
+        out = (float)acos((double)ang);
+    }
+    B.bd[idx] = out;
+}
+
+// ---- per-round pid matrix ---------------------------------------------------------------------------------------------
+__global__ void k_aps_round_pids(const int64_t *pids, const int32_t *next_p, const int32_t *want, int64_t Q, int M, int CH,
+                                 int64_t *round_pids) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= Q * CH) return;
+    const int64_t q = idx / CH;
+    const int i = (int)(idx - q * CH);
+    const int p = next_p[q] + i;
+    round_pids[idx] = (i < want[q] && p < M) ? pids[q * M + p] : -1;
+}
+
+// ---- the sequential rule, one wave per query ------------------------------------------------------------------------
+struct UpdateParams {
+    int64_t Q;
+    int M, k, d, CH, metric;
+    float recall_target, recompute_threshold;
+    int precomputed;
+    const double *table;
+    const int64_t *pids;      // [Q][M]
+    const float *bd;          // [Q][M]
+    float *probs;             // [Q][M]  (persisted between rounds)
+    const int64_t *pr_ids;    // [Q*CH][k] results of this round's pairs
+    const float *pr_key;      // [Q*CH][k] squared L2 / inner product
+    uint32_t *run_ord;        // [Q][k]
+    int64_t *run_id;          // [Q][k]
+    int32_t *run_cnt, *have_probs, *next_p, *want, *nscan;
+    uint32_t *run_tau;        // [Q] ~(k-th key of the running result), 0 while it holds fewer than k: next round's bound
+    float *radius;
+    int32_t *n_active;
+    int64_t *out_ids;         // [Q][k]
+    float *out_dist;          // [Q][k]
+    int sqrt_l2;
+};
+
+template <int MAXCH>
+__global__ __launch_bounds__(64) void k_aps_update(UpdateParams U) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int lane = threadIdx.x;
+    const int64_t q = blockIdx.x;
+    const int k = U.k, M = U.M;
+    const int w = U.want[q];
+    if (w <= 0) return;  // stopped in an earlier round
+    int64_t *pool_id = (int64_t *)smem;                                  // [2k]
+    uint32_t *pool_ord = (uint32_t *)(smem + (size_t)2 * k * 8);         // [2k]
+    float *probs = (float *)(smem + (size_t)2 * k * 12);                 // [M]
+    const bool euclid = U.metric == QK_METRIC_L2;
+    int cnt = U.run_cnt[q];
+    for (int e = lane; e < cnt; e += 64) {
+        pool_ord[e] = U.run_ord[q * k + e];
+        pool_id[e] = U.run_id[q * k + e];
+    }
+    bool have = U.have_probs[q] != 0;
+    if (have)
+        for (int jj = lane; jj < M; jj += 64) probs[jj] = U.probs[q * M + jj];
+    float qr = U.radius[q];
+    const int p0 = U.next_p[q];
+    bool stop = false;
+    int nscan = p0;
+    for (int i = 0; i < w && p0 + i < M; i++) {
+        const int p = p0 + i;
+        nscan = p + 1;
+        if (U.pids[q * M + p] == -1) continue;  // query_coordinator.cpp:540
+        // merge this partition's top-k into the running one
+        const int64_t *nid = U.pr_ids + (q * U.CH + i) * k;
+        const float *nkey = U.pr_key + (q * U.CH + i) * k;
+        for (int base = 0; base < k; base += 64) {
+            const int e = base + lane;
+            int64_t id = -1;
+            uint32_t o = 0xFFFFFFFFu;
+            if (e < k) {
+                id = nid[e];
+                const float v = nkey[e];
+                o = euclid ? ord_from_l2(v) : ord_from_ip(v);
+            }
+            const bool ok = id >= 0;
+            const uint64_t m = __ballot(ok);
+            if (ok) {
+                const int sl = cnt + __popcll(m & ((1ull << lane) - 1ull));
+                pool_ord[sl] = o;
+                pool_id[sl] = id;
+            }
+            cnt += __popcll(m);
+        }
+        cnt = compact_pool<MAXCH>(pool_ord, pool_id, cnt, k, lane);
+        // radius = k-th distance, or the buffer's sentinel while it holds fewer than k (list_scanning.h:57-63,187-191)
+        float cur;
+        if (cnt >= k) {
+            const uint32_t ok_ = pool_ord[k - 1];
+            cur = euclid ? sqrtf(__uint_as_float(ok_)) : ip_from_ord(ok_);
+        } else {
+            cur = euclid ? 3.402823466e+38f : -INFINITY;
+        }
+        const float change = fabsf(cur - qr) / cur;
+        if (change > U.recompute_threshold) {
+            qr = cur;
+            // compute_recall_profile (geometry.h:345-407)
+            for (int jj = lane; jj < M; jj += 64) {
+                float pj = 0.0f;
+                if (jj >= 1) {
+                    const float b = U.bd[q * M + jj];
+                    if (!(b >= qr)) {
+                        const double vr = exp(log_cap_volume((double)qr, (double)b, U.d, U.precomputed != 0, euclid, U.table));
+                        pj = (float)((vr > 0.0) ? vr : 0.0);
+                    }
+                }
+                probs[jj] = pj;
+            }
+            __builtin_amdgcn_wave_barrier();
+            const float p1 = probs[1];
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) probs[0] = (float)(2.0 * p1);
+            __builtin_amdgcn_wave_barrier();
+            double sum = 0.0;  // sequential, in candidate order (every lane runs the same chain)
+            for (int jj = 0; jj < M; jj++) sum += (double)probs[jj];
+            __builtin_amdgcn_wave_barrier();
+            if (sum > 0.0) {
+                for (int jj = lane; jj < M; jj += 64) probs[jj] = (float)((double)probs[jj] / sum);
+            } else {
+                for (int jj = lane; jj < M; jj += 64) probs[jj] = (float)(1.0 / M);
+            }
+            __builtin_amdgcn_wave_barrier();
+            have = true;
+        }
+        float est = 0.0f;
+        if (have)
+            for (int t = 0; t < p; t++) est += probs[t];
+        if (est >= U.recall_target) {
+            stop = true;
+            break;
+        }
+    }
+    const int np = min(p0 + w, M);
+    const bool done = stop || np >= M;
+    if (done) {
+        if (!stop) nscan = M;
+        for (int e = lane; e < k; e += 64) {
+            int64_t oid = -1;
+            float od = euclid ? INFINITY : -INFINITY;
+            if (e < cnt) {
+                oid = pool_id[e];
+                const uint32_t o = pool_ord[e];
+                if (euclid) {
+                    const float d2 = __uint_as_float(o);
+                    od = U.sqrt_l2 ? sqrtf(d2) : d2;
+                } else {
+                    od = ip_from_ord(o);
+                }
+            }
+            U.out_ids[q * k + e] = oid;
+            if (U.out_dist) U.out_dist[q * k + e] = od;
+        }
+        if (lane == 0) {
+            U.want[q] = 0;
+            U.nscan[q] = nscan;
+        }
+        return;
+    }
+    // carry the state into the next round
+    for (int e = lane; e < cnt; e += 64) {
+        U.run_ord[q * k + e] = pool_ord[e];
+        U.run_id[q * k + e] = pool_id[e];
+    }
+    if (have)
+        for (int jj = lane; jj < M; jj += 64) U.probs[q * M + jj] = probs[jj];
+    // partitions for the next round: up to where the current profile says the estimate will reach the target
+    int wn = U.CH;
+    if (have) {
+        float est = 0.0f;
+        int t = 0;
+        for (; t < M; t++) {
+            if (t >= np && est >= U.recall_target) break;  // the walk would stop AT partition t (after scanning it)
+            est += probs[t];
+        }
+        wn = min(U.CH, max(1, t - np + 1));
+    }
+    wn = min(wn, M - np);
+    if (lane == 0) {
+        // nothing worse than the running k-th can enter a later running top-k (it only shrinks): safe for every partition
+        // of the next rounds.  (A bound learnt INSIDE a round is not: it could remove entries that belong to the running
+        // result of an earlier step of the walk and change that step's radius.)
+        U.run_tau[q] = cnt >= k ? ~pool_ord[k - 1] : 0u;
+        U.run_cnt[q] = cnt;
+        U.have_probs[q] = have ? 1 : 0;
+        U.radius[q] = qr;
+        U.next_p[q] = np;
+        U.want[q] = wn;
+        atomicAdd(U.n_active, 1);
+    }
+}
+
+__global__ void k_aps_init(int64_t Q, int M, int metric, int32_t *run_cnt, int32_t *have_probs, int32_t *next_p, int32_t *want,
+                           int32_t *nscan, float *radius, uint32_t *run_tau) {
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= Q) return;
+    run_cnt[q] = 0;
+    run_tau[q] = 0u;
+    have_probs[q] = 0;
+    next_p[q] = 0;
+    want[q] = min(2, M);  // the estimate is empty before the second partition: nobody stops earlier
+    nscan[q] = 0;
+    radius[q] = metric == QK_METRIC_L2 ? 1000000.0f : -1000000.0f;  // query_coordinator.cpp:523-527
+}
+
+inline size_t al256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+}  // namespace
+
+extern "C" int qk_search_aps(qk_ctx *ctx, qk_store *parent, qk_store *s, const float *x, int64_t Q, int k, int metric,
+                             float recall_target, float recompute_threshold, int use_precomputed, float initial_search_fraction,
+                             int64_t *out_ids, float *out_dist, int32_t *out_nscanned, int mem, qk_timing *timing) {
+    if (!ctx || !s || !parent) QK_FAIL(QK_ERR_INVALID, "qk_search_aps: ctx / parent / store is null (adaptive search needs a parent index)");
+    if (metric != QK_METRIC_L2 && metric != QK_METRIC_IP) QK_FAIL(QK_ERR_INVALID, "Metric type not supported");
+    if (!(recall_target > 0.0f)) QK_FAIL(QK_ERR_INVALID, "qk_search_aps: recall_target must be > 0");
+    QK_HIP(hipSetDevice(ctx->device));
+    if (timing) memset(timing, 0, sizeof(*timing));
+    if (Q <= 0) return QK_OK;
+    if (k <= 0) k = 1;  // query_coordinator.cpp:490
+    if (k > QK_MAX_K) QK_FAIL(QK_ERR_UNSUPPORTED, "qk_search_aps: k=%d exceeds QK_MAX_K=%d", k, QK_MAX_K);
+    const int d = s->d;
+    if (parent->d != d) QK_FAIL(QK_ERR_INVALID, "parent store dimension %d != store dimension %d", parent->d, d);
+    // query_coordinator.cpp:638-640: (int)(nlist * initial_search_fraction) in float arithmetic, at least 1
+    int M = (int)((float)s->nlist * initial_search_fraction);
+    if (M < 1) M = 1;
+    M = (int)std::min<int64_t>(M, parent->ntotal);
+    if (M < 2) QK_FAIL(QK_ERR_INVALID, "Boundary distances must have at least 2 partitions to create an estimate.");  // geometry.h:350
+    if (M > QK_MAX_K) QK_FAIL(QK_ERR_UNSUPPORTED, "qk_search_aps: %d candidate partitions exceed QK_MAX_K=%d", M, QK_MAX_K);
+    hipStream_t st = ctx->stream;
+    const int CH = std::min(APS_CH, M);
+
+    // ---- partition id -> arena row of its centroid (host mirror of the parent's ids) -------------------------------
+    int64_t max_id = -1;
+    for (auto &pt : parent->parts)
+        if (pt.present)
+            for (int64_t id : pt.ids) max_id = std::max(max_id, id);
+    if (max_id < 0) QK_FAIL(QK_ERR_INVALID, "qk_search_aps: empty parent index");
+    if (max_id > (int64_t)1 << 26) QK_FAIL(QK_ERR_UNSUPPORTED, "qk_search_aps: partition ids above 2^26 are not supported");
+    std::vector<int32_t> row_of((size_t)max_id + 1, -1);
+    for (auto &pt : parent->parts)
+        if (pt.present)
+            for (size_t r = 0; r < pt.ids.size(); r++)
+                if (pt.ids[r] >= 0) row_of[(size_t)pt.ids[r]] = (int32_t)(pt.row_off + (int64_t)r);
+    // ---- table of the precomputed path (geometry.h:163-180) ---------------------------------------------------------------
+    std::vector<double> table(APS_NX);
+    {
+        const double dx = 1.0 / (APS_NX - 1);
+        const double a = (d + 1.0) / 2.0, b = 0.5;
+        for (int i = 0; i < APS_NX; i++) table[i] = inc_beta(a, b, i * dx);
+    }
+
+    // ---- state ----------------------------------------------------------------------------------------------------------------
+    const size_t QM = (size_t)Q * M, Qk = (size_t)Q * k, QCk = (size_t)Q * CH * k;
+    size_t need = 0;
+    auto take = [&](size_t b) { size_t o = need; need += al256(b); return o; };
+    const size_t o_x = take((size_t)Q * d * 4), o_pids = take(QM * 8), o_bd = take(QM * 4), o_probs = take(QM * 4);
+    const size_t o_rord = take(Qk * 4), o_rid = take(Qk * 8), o_q = take((size_t)Q * 4 * 7 + 64);
+    const size_t o_rp = take((size_t)Q * CH * 8), o_pri = take(QCk * 8), o_prk = take(QCk * 4);
+    const size_t o_tab = take(APS_NX * 8), o_row = take(row_of.size() * 4), o_oi = take(Qk * 8), o_od = take(Qk * 4);
+    const size_t o_na = take(256);
+    QK_TRY(qk_aps_reserve(ctx, need));
+    char *B = ctx->aps;
+    const float *dx_;
+    int64_t *d_out_ids;
+    float *d_out_dist;
+    if (mem == QK_MEM_HOST) {
+        QK_HIP(hipMemcpyAsync(B + o_x, x, (size_t)Q * d * 4, hipMemcpyHostToDevice, st));
+        dx_ = (const float *)(B + o_x);
+        d_out_ids = (int64_t *)(B + o_oi);
+        d_out_dist = (float *)(B + o_od);
+    } else {
+        dx_ = x;
+        d_out_ids = out_ids;
+        d_out_dist = out_dist ? out_dist : (float *)(B + o_od);
+    }
+    int64_t *pids = (int64_t *)(B + o_pids);
+    float *bd = (float *)(B + o_bd), *probs = (float *)(B + o_probs);
+    uint32_t *run_ord = (uint32_t *)(B + o_rord);
+    int64_t *run_id = (int64_t *)(B + o_rid);
+    int32_t *run_cnt = (int32_t *)(B + o_q), *have_probs = run_cnt + Q, *next_p = have_probs + Q, *want = next_p + Q,
+            *nscan = want + Q;
+    float *radius = (float *)(nscan + Q);
+    uint32_t *run_tau = (uint32_t *)(radius + Q);
+    int64_t *round_pids = (int64_t *)(B + o_rp), *pr_ids = (int64_t *)(B + o_pri);
+    float *pr_key = (float *)(B + o_prk);
+    double *d_table = (double *)(B + o_tab);
+    int32_t *d_row_of = (int32_t *)(B + o_row), *n_active = (int32_t *)(B + o_na);
+    QK_HIP(hipMemcpyAsync(d_table, table.data(), APS_NX * 8, hipMemcpyHostToDevice, st));
+    QK_HIP(hipMemcpyAsync(d_row_of, row_of.data(), row_of.size() * 4, hipMemcpyHostToDevice, st));
+    // (both host vectors must outlive the copies: pageable memory -> the runtime stages them before returning)
+
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (timing) {
+        QK_HIP(hipEventCreate(&e0));
+        QK_HIP(hipEventCreate(&e1));
+        QK_HIP(hipEventRecord(e0, st));
+    }
+    const float4 *xq4 = nullptr;
+    const float *xn = nullptr;
+    QK_TRY(qk_prep_queries(ctx, dx_, Q, d, &xq4, &xn));
+    // ---- candidates: the parent's M nearest centroids (query_coordinator.cpp:643) -------------------------------------------
+    {
+        qk_scan_args ca;
+        ca.x = dx_;
+        ca.xq4 = xq4;
+        ca.xn = xn;
+        ca.Q = Q;
+        ca.all_lists = true;
+        ca.k = M;
+        ca.metric = metric;
+        ca.out_ids = pids;
+        ca.out_dist = nullptr;
+        QK_TRY(qk_scan_device(ctx, parent, ca, nullptr, 0));
+    }
+    {
+        BoundaryParams bp;
+        bp.x = dx_;
+        bp.pids = pids;
+        bp.row_of = d_row_of;
+        bp.n_row_of = (int64_t)row_of.size();
+        bp.cvecs = parent->vecs;
+        bp.cnblk = parent->nblk;
+        bp.Q = Q;
+        bp.M = M;
+        bp.d = d;
+        bp.euclid = metric == QK_METRIC_L2 ? 1 : 0;
+        bp.bd = bd;
+        hipLaunchKernelGGL(k_aps_boundary, dim3((unsigned)((QM + 255) / 256)), dim3(256), 0, st, bp);
+        hipLaunchKernelGGL(k_aps_init, dim3((unsigned)((Q + 255) / 256)), dim3(256), 0, st, Q, M, metric, run_cnt, have_probs, next_p,
+                           want, nscan, radius, run_tau);
+        QK_HIP(hipGetLastError());
+    }
+    // ---- rounds ---------------------------------------------------------------------------------------------------------------
+    UpdateParams up;
+    up.Q = Q;
+    up.M = M;
+    up.k = k;
+    up.d = d;
+    up.CH = CH;
+    up.metric = metric;
+    up.recall_target = recall_target;
+    up.recompute_threshold = recompute_threshold;
+    up.precomputed = use_precomputed ? 1 : 0;
+    up.table = d_table;
+    up.pids = pids;
+    up.bd = bd;
+    up.probs = probs;
+    up.pr_ids = pr_ids;
+    up.pr_key = pr_key;
+    up.run_ord = run_ord;
+    up.run_id = run_id;
+    up.run_cnt = run_cnt;
+    up.have_probs = have_probs;
+    up.next_p = next_p;
+    up.want = want;
+    up.nscan = nscan;
+    up.radius = radius;
+    up.run_tau = run_tau;
+    up.n_active = n_active;
+    up.out_ids = d_out_ids;
+    up.out_dist = d_out_dist;
+    up.sqrt_l2 = ctx->squared_l2 ? 0 : 1;
+    const size_t lds_up = (size_t)2 * k * 12 + (size_t)M * 4 + 64;
+    const int maxch_u = 2 * k <= 64 ? 1 : 2 * k <= 128 ? 2 : 2 * k <= 256 ? 4 : 2 * k <= 512 ? 8 : 16;
+    QK_TRY(qk_pinned_reserve(ctx, 64));
+    int rounds = 0;
+    int64_t pairs_scanned = 0;
+    for (;;) {
+        hipLaunchKernelGGL(k_aps_round_pids, dim3((unsigned)(((size_t)Q * CH + 255) / 256)), dim3(256), 0, st, pids, next_p, want, Q, M,
+                           CH, round_pids);
+        qk_scan_args sa;
+        sa.x = dx_;
+        sa.xq4 = xq4;
+        sa.xn = xn;
+        sa.Q = Q;
+        sa.pids = round_pids;
+        sa.P = CH;
+        sa.k = k;
+        sa.metric = metric;
+        sa.out_ids = pr_ids;
+        sa.out_dist = pr_key;
+        sa.per_pair = true;
+        sa.tau_init = run_tau;
+        sa.sqrt_l2 = false;  // merge keys: squared distances
+        QK_TRY(qk_scan_device(ctx, s, sa, nullptr, 4));
+        QK_HIP(hipMemsetAsync(n_active, 0, 4, st));
+#define QK_UP(MC)                                                                                         \
+    {                                                                                                     \
+        QK_HIP(hipFuncSetAttribute((const void *)k_aps_update<MC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_up)); \
+        hipLaunchKernelGGL((k_aps_update<MC>), dim3((unsigned)Q), dim3(64), lds_up, st, up);                \
+    }
+        switch (maxch_u) {
+            case 1: QK_UP(1) break;
+            case 2: QK_UP(2) break;
+            case 4: QK_UP(4) break;
+            case 8: QK_UP(8) break;
+            default: QK_UP(16) break;
+        }
+#undef QK_UP
+        QK_HIP(hipGetLastError());
+        QK_HIP(hipMemcpyAsync(ctx->pinned, n_active, 4, hipMemcpyDeviceToHost, st));
+        QK_HIP(hipStreamSynchronize(st));
+        rounds++;
+        const int32_t left = *(const int32_t *)ctx->pinned;
+        if (left <= 0) break;
+        if (rounds > M + 2) QK_FAIL(QK_ERR_HIP, "qk_search_aps: rounds did not terminate");
+    }
+    if (timing) QK_HIP(hipEventRecord(e1, st));
+    // ---- results back ---------------------------------------------------------------------------------------------------------
+    if (mem == QK_MEM_HOST) {
+        if (out_ids) QK_HIP(hipMemcpyAsync(out_ids, d_out_ids, Qk * 8, hipMemcpyDeviceToHost, st));
+        if (out_dist) QK_HIP(hipMemcpyAsync(out_dist, d_out_dist, Qk * 4, hipMemcpyDeviceToHost, st));
+        if (out_nscanned) QK_HIP(hipMemcpyAsync(out_nscanned, nscan, (size_t)Q * 4, hipMemcpyDeviceToHost, st));
+        QK_HIP(hipStreamSynchronize(st));
+    } else if (out_nscanned) {
+        QK_HIP(hipMemcpyAsync(out_nscanned, nscan, (size_t)Q * 4, hipMemcpyDeviceToDevice, st));
+    }
+    if (timing) {
+        QK_HIP(hipStreamSynchronize(st));
+        float ms = 0.f;
+        QK_HIP(hipEventElapsedTime(&ms, e0, e1));
+        timing->total_ms = ms;
+        timing->n_items = rounds;
+        QK_HIP(hipEventDestroy(e0));
+        QK_HIP(hipEventDestroy(e1));
+    }
+    (void)pairs_scanned;
+    return QK_OK;
+}

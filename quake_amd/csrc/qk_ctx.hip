@@ -42,6 +42,7 @@ int qk_ctx_destroy(qk_ctx *c) {
     if (c->ws) hipFree(c->ws);
     if (c->stage) hipFree(c->stage);
     if (c->qprep) hipFree(c->qprep);
+    if (c->aps) hipFree(c->aps);
     if (c->pinned) hipHostFree(c->pinned);
     for (auto &e : c->ev)
         if (e) hipEventDestroy(e);
@@ -135,6 +136,22 @@ void *qk_ws_alloc(qk_ctx *c, size_t bytes) {
     if (off + bytes > c->ws_cap) return nullptr;
     c->ws_off = off + bytes;
     return c->ws + off;
+}
+
+int qk_aps_reserve(qk_ctx *c, size_t bytes) {
+    if (bytes <= c->aps_cap) return QK_OK;
+    QK_HIP(hipStreamSynchronize(c->stream));
+    if (c->aps) QK_HIP(hipFree(c->aps));
+    c->aps = nullptr;
+    c->aps_cap = 0;
+    size_t want = bytes + bytes / 4 + (1u << 16);
+    hipError_t e = hipMalloc((void **)&c->aps, want);
+    if (e != hipSuccess) {
+        qk_set_error("adaptive-search state allocation of %zu bytes failed: %s", want, hipGetErrorString(e));
+        return QK_ERR_OOM;
+    }
+    c->aps_cap = want;
+    return QK_OK;
 }
 
 int qk_pinned_reserve(qk_ctx *c, size_t bytes) {

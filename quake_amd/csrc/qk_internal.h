@@ -73,12 +73,16 @@ struct qk_ctx {
     std::vector<hipEvent_t> ev_pending;  // groups of 4: group start, scan start, scan end, merge end
     std::vector<hipEvent_t> ev_pending_coarse;  // groups of 2: coarse start, coarse end
     bool squared_l2 = false;  // L2 entry points return squared distances (sharded path, before the final merge)
+    // state of an adaptive (recall-target) search: survives the scan calls of its rounds, which recycle `ws`
+    char *aps = nullptr;
+    size_t aps_cap = 0;
 };
 
 int qk_ws_reserve(qk_ctx *ctx, size_t bytes);          // make sure the workspace can hold `bytes` (may sync+realloc)
 void *qk_ws_alloc(qk_ctx *ctx, size_t bytes);          // 256-B aligned slice; nullptr if exhausted
 int qk_pinned_reserve(qk_ctx *ctx, size_t bytes);
 int qk_stage_reserve(qk_ctx *ctx, size_t bytes);
+int qk_aps_reserve(qk_ctx *ctx, size_t bytes);
 
 // ---- store -----------------------------------------------------------------------------------
 struct qk_part {
@@ -142,6 +146,9 @@ struct qk_scan_args {
     bool share_tau = true;
     bool sqrt_l2 = true;
     bool record_events = false;  // record the per-call phase events even when no qk_timing is passed
+    bool per_pair = false;       // keep the P results of a query apart: out_* are [Q*P][k], one top-k per (query, list)
+    // per_pair only: [Q] initial bound per query as ~ord (0 = none): entries worse than it are dropped in every list
+    const uint32_t *tau_init = nullptr;
     const float4 *xq4 = nullptr;  // [Q][nblk][4] fragment-ordered queries (qk_prep_queries), required
     const float *xn = nullptr;    // [Q] squared norms, required
 };

@@ -348,6 +348,7 @@ struct ScanParams {
     const int64_t *n_tiles;
     uint32_t *gtau;  // [Q] shared running bound per query stored as ~bound (0 = none, so one memset clears it), or nullptr
     int tau_refresh;  // re-read gtau every 8 tiles (only useful when a query probes several partitions)
+    int tau_publish;  // waves publish their bound into gtau (0: gtau is a read-only initial bound, qk_scan_args::tau_init)
     int k;
     int C;  // pool capacity per query; k <= C - 4
     int metric;
@@ -583,7 +584,7 @@ __global__ __launch_bounds__(256) void k_scan(ScanParams P) {
                                     if (nn >= k) {
                                         tau = min(tau, kth);
                                         // publish (fire and forget: no returned value, no wait)
-                                        if (P.gtau && lane < 16) atomicMax(&P.gtau[myq], ~tau);
+                                        if (P.gtau && P.tau_publish && lane < 16) atomicMax(&P.gtau[myq], ~tau);
                                     }
                                 }
                             }
@@ -659,7 +660,7 @@ __global__ __launch_bounds__(256) void k_scan(ScanParams P) {
                             P.rec_hdr[pend_rec] = make_int2(pend_old, pend_cnt);
                             pend_rec = -1;
                         }
-                        if (P.gtau && cnt >= k) atomicMax(&P.gtau[myq], ~my_ord[k - 1]);
+                        if (P.gtau && P.tau_publish && cnt >= k) atomicMax(&P.gtau[myq], ~my_ord[k - 1]);
                     }
                 }
                 uint64_t todo = have;
@@ -891,6 +892,8 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
             if (s->parts[p].present) return qk_dense_device(ctx, s, p, a, timing, ev_base);
     }
     const int P = a.all_lists ? npids : a.P;
+    // per-pair results: a bound learnt in one list must not prune another list's own top-k
+    const bool share_tau = a.share_tau && !a.per_pair;
     hipStream_t st = ctx->stream;
     const bool tm = ctx->timing && (timing || a.record_events);
     qk_phase_events pe;
@@ -1028,7 +1031,7 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
     // (measured: for k > 64 a sample bound is far looser than the bound the pools reach by themselves -- no gain, and
     //  the 64*M-row sample costs 0.1 ms at d = 768; the wider instantiations stay available for probing)
     static const int seed_max_k = getenv("QK_SEED_MAX_K") ? atoi(getenv("QK_SEED_MAX_K")) : 64;
-    const bool seeded = !no_seed && a.share_tau && k <= std::min(seed_max_k, 512) && npairs > 0 && npids > 0;
+    const bool seeded = !no_seed && share_tau && k <= std::min(seed_max_k, 512) && npairs > 0 && npids > 0;
     if (seeded) {
         // bound seeding: for the first (nearest) partitions of every query, the k-th smallest distance of a 64-row
         // sample goes into gtau[q]
@@ -1081,8 +1084,14 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
         sp.n_active = n_active;
         sp.active = active;
         sp.n_tiles = n_tiles;
-        sp.gtau = a.share_tau ? gtau : nullptr;
+        sp.gtau = share_tau ? gtau : nullptr;
         sp.tau_refresh = P > 1 ? 1 : 0;  // one partition per query: the seed is all there is to share
+        sp.tau_publish = 1;
+        if (!share_tau && a.tau_init) {  // caller-provided per-query bound (same ~bound format), never updated here
+            sp.gtau = const_cast<uint32_t *>(a.tau_init);
+            sp.tau_refresh = 0;
+            sp.tau_publish = 0;
+        }
 
         static const int probe_tau0 = getenv("QK_SCAN_TAU0") ? atoi(getenv("QK_SCAN_TAU0")) : 0;
         if (probe_tau0) {  // probe: a bound of 0 -> nothing ever passes (isolates the steady-state epilogue cost)
@@ -1114,7 +1123,7 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
 
     // ---- merge ---------------------------------------------------------------------------------------------------
     MergeParams mp;
-    mp.P = P;
+    mp.P = a.per_pair ? 1 : P;  // per_pair: every (query, list) pair is merged on its own
     mp.pair_head = pair_head;
     mp.rec_hdr = rec_hdr;
     mp.rec_ord = rec_ord;
@@ -1126,11 +1135,12 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
     mp.out_ids = a.out_ids;
     mp.out_dist = a.out_dist;
     mp.sqrt_l2 = a.sqrt_l2 ? 1 : 0;
+    const dim3 mgrid((unsigned)(a.per_pair ? Q * P : Q));
     switch (maxch_m) {
-        case 2: hipLaunchKernelGGL((k_merge<2>), dim3((unsigned)Q), dim3(64), lds_merge, st, mp); break;
-        case 4: hipLaunchKernelGGL((k_merge<4>), dim3((unsigned)Q), dim3(64), lds_merge, st, mp); break;
-        case 8: hipLaunchKernelGGL((k_merge<8>), dim3((unsigned)Q), dim3(64), lds_merge, st, mp); break;
-        default: hipLaunchKernelGGL((k_merge<16>), dim3((unsigned)Q), dim3(64), lds_merge, st, mp); break;
+        case 2: hipLaunchKernelGGL((k_merge<2>), mgrid, dim3(64), lds_merge, st, mp); break;
+        case 4: hipLaunchKernelGGL((k_merge<4>), mgrid, dim3(64), lds_merge, st, mp); break;
+        case 8: hipLaunchKernelGGL((k_merge<8>), mgrid, dim3(64), lds_merge, st, mp); break;
+        default: hipLaunchKernelGGL((k_merge<16>), mgrid, dim3(64), lds_merge, st, mp); break;
     }
     QK_HIP(hipGetLastError());
     QK_TRY(pe.mark(3));

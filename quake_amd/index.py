@@ -243,12 +243,29 @@ class QuakeIndex:
             res.ids = torch.empty((0,), dtype=torch.int64)
             res.distances = torch.empty((0,), dtype=torch.float32)
             return res
-        if search_params.recall_target is not None and search_params.recall_target > 0.0 and self.parent is not None:
-            raise NotImplementedError("adaptive partition scanning (recall_target > 0) is not on this path yet (SURVEY 8f-2)")
         t0 = time.perf_counter()
         on_dev = x.is_cuda
         xd = self._to_dev(x, torch.float32)
         k = search_params.k if search_params.k and search_params.k > 0 else 1  # query_coordinator.cpp:490
+        use_aps = (search_params.recall_target is not None and search_params.recall_target > 0.0 and self.parent is not None
+                   and not search_params.batched_scan)  # query_coordinator.cpp:502,637-641,659-673
+        if use_aps:
+            # adaptive partition scanning: candidates = nlist * initial_search_fraction, per-query early stop
+            ids, dist, nscan, tm = self._ctx.search_aps(
+                self.parent._store, self._store, xd, int(k), self.metric_, float(search_params.recall_target),
+                recompute_threshold=float(search_params.recompute_threshold), use_precomputed=bool(search_params.use_precomputed),
+                initial_search_fraction=float(search_params.initial_search_fraction), timing=True)
+            ti.n_queries = int(x.shape[0])
+            ti.partitions_scanned = int(nscan.sum().item())
+            ti.job_wait_time_ns = int(tm["total_ms"] * 1e6)
+            pi = SearchTimingInfo()
+            pi.n_queries = ti.n_queries
+            pi.n_clusters = 1
+            ti.parent_info = pi
+            ti.total_time_ns = int((time.perf_counter() - t0) * 1e9)
+            res.ids = ids if on_dev else ids.cpu()
+            res.distances = dist if on_dev else dist.cpu()
+            return res
         nprobe = max(int(search_params.nprobe), 1)
         self._ctx.set_timing(1)
         try:

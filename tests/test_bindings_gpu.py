@@ -83,3 +83,29 @@ def test_bindings_build_search_add_remove_save_load(qb, tmp_path):
     c = py.search(q, psp)
     np.testing.assert_array_equal(a.ids.numpy(), c.ids.numpy())
     np.testing.assert_array_equal(a.distances.numpy(), c.distances.numpy())
+
+
+def test_bindings_recall_target_search(qb):
+    """SearchParams.recall_target through the compiled mirror == the ctypes path (same C ABI call underneath)."""
+    import quake_amd
+    g = torch.Generator().manual_seed(23)
+    cent = torch.randn(80, 24, generator=g) * 2
+    x = cent[torch.randint(0, 80, (20000,), generator=g)] + torch.randn(20000, 24, generator=g)
+    q = x[:64] + 0.05 * torch.randn(64, 24, generator=g)
+    ids = torch.arange(20000)
+    res = []
+    for mod in (qb, quake_amd):
+        idx = mod.QuakeIndex()
+        bp = mod.IndexBuildParams()
+        bp.nlist = 80
+        idx.build(x, ids, bp)
+        sp = mod.SearchParams()
+        sp.k = 5
+        sp.recall_target = 0.9
+        sp.initial_search_fraction = 0.25
+        r = idx.search(q, sp)
+        assert tuple(r.ids.shape) == (64, 5)
+        res.append((r.ids.numpy().copy(), r.distances.numpy().copy(), r.timing_info.partitions_scanned))
+    np.testing.assert_array_equal(res[0][0], res[1][0])
+    np.testing.assert_array_equal(res[0][1], res[1][1])
+    assert res[0][2] == res[1][2] and res[0][2] >= 2 * 64

@@ -215,3 +215,50 @@ def test_refine_partitions_keeps_everything_searchable(quake, data):  # partitio
     sp.k, sp.nprobe = 1, NLIST
     r = idx.search(x[:200], sp)  # every vector still finds itself
     np.testing.assert_array_equal(r.ids.reshape(-1).numpy(), np.arange(200))
+
+
+def test_recall_vs_recall_target(quake):  # search_recall_tests.cpp:284-309 RecallVsRecallTargetL2 (it only prints; bounds added)
+    g = torch.Generator().manual_seed(17)
+    cent = torch.randn(100, 32, generator=g) * 2
+    x = cent[torch.randint(0, 100, (40000,), generator=g)] + torch.randn(40000, 32, generator=g)
+    q = x[torch.randperm(40000, generator=g)[:150]] + 0.1 * torch.randn(150, 32, generator=g)
+    idx, _ = build(quake, x, torch.arange(40000), 100)
+    gt = torch.topk(torch.cdist(q.double(), x.double()), 10, dim=1, largest=False).indices
+    sp = quake.SearchParams()
+    sp.k = 10
+    sp.recompute_threshold = 0.0
+    sp.initial_search_fraction = 0.5
+    prev_scanned, recs = 0, []
+    for rt in (0.5, 0.7, 0.9, 0.99, 1.0):
+        sp.recall_target = rt
+        r = idx.search(q, sp)
+        assert r.ids.shape == (150, 10) and r.distances.shape == (150, 10)
+        assert r.timing_info.partitions_scanned >= prev_scanned  # a higher target never scans fewer partitions
+        prev_scanned = r.timing_info.partitions_scanned
+        recs.append(quake.compute_recall(r.ids, gt, 10).mean().item())
+    assert recs[-1] >= recs[0] and recs[2] >= 0.9 and recs[-1] >= 0.99
+    # same walk as the oracle's restatement, through the index object (device tensors in, device tensors out)
+    sp.recall_target = 0.9
+    r = idx.search(q.cuda(), sp)
+    assert r.ids.is_cuda
+    cids = idx.parent.get_ids()
+    cvec = idx.parent.get(cids)
+    pv, pi = [], []
+    for p in cids.tolist():
+        sub = idx._store.get_list(p)
+        pv.append(sub[0])
+        pi.append(sub[1])
+    order = np.argsort(cids.numpy())
+    vecs, ids_, offsets = O.csr_from_partitions([pv[i] for i in order], [pi[i] for i in order], 32)
+    oi, od, on = O.search_aps(q.numpy(), cvec.numpy()[order], vecs, ids_, offsets, 10, "l2", 0.9, recompute_threshold=0.0,
+                              initial_search_fraction=0.5, centroid_ids=cids.numpy()[order], num_threads=8)
+    np.testing.assert_array_equal(r.ids.cpu().numpy(), oi)
+    np.testing.assert_array_equal(r.distances.cpu().numpy().view(np.uint32), od.view(np.uint32))
+    assert r.timing_info.partitions_scanned == int(on.sum())
+    # batched_scan = true ignores the target and uses nprobe (query_coordinator.cpp:637-641,659-673)
+    sp.batched_scan = True
+    sp.nprobe = 3
+    rb = idx.search(q, sp)
+    sp.recall_target = -1.0
+    rn = idx.search(q, sp)
+    np.testing.assert_array_equal(rb.ids.numpy(), rn.ids.numpy())
