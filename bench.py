@@ -196,12 +196,21 @@ def main():
     if world > 1:
         # ranks exchange the merge key (squared distance) with one all-gather over RCCL; sqrt after the merge
         from quake_amd.sharded import GpuEngine, ShardedIndex
-        sharded = ShardedIndex(GpuEngine(ctx, parent, store, metric), dist, world, rank)
+        sharded = ShardedIndex(GpuEngine(ctx, parent, store, metric), dist, world, rank, result="owner")
 
     def step(nprobe):
         if sharded is not None:
             return sharded.search(q, nprobe, k, out=(out_i, out_d))
         return ctx.search(parent, store, q, nprobe, k, metric, out=(out_i, out_d))
+
+    def batch_recall(ri):
+        """recall@k of the batch: with N ranks every rank holds the answer of its slice of the queries."""
+        if sharded is None:
+            return recall_at_k(ri, gi, k)
+        per = Q // world
+        r = torch.tensor([recall_at_k(ri, gi[rank * per:(rank + 1) * per], k)], device=dev, dtype=torch.float64)
+        dist.all_reduce(r, op=dist.ReduceOp.SUM)
+        return r.item() / world
 
     # ---- nprobe: smallest reaching the recall target ----------------------------------------------------------------
     sweep = []
@@ -210,7 +219,7 @@ def main():
         for p in (1, 2, 4, 8, 16, 32, 64):
             ri, _ = step(p)
             torch.cuda.synchronize()
-            r = recall_at_k(ri, gi, k)
+            r = batch_recall(ri)
             sweep.append((p, round(r, 4)))
             if r >= args.recall_target:
                 nprobe = p
@@ -219,7 +228,7 @@ def main():
             nprobe = 64
     ri, rd = step(nprobe)
     torch.cuda.synchronize()
-    recall = recall_at_k(ri, gi, k)
+    recall = batch_recall(ri)
     log(f"nprobe={nprobe} recall@{k}={recall:.4f} sweep={sweep}")
 
     # per-call phase breakdown + algorithmic bytes (one synchronising call, outside the timed region)
@@ -285,7 +294,8 @@ def main():
                         f"(BASELINE.json configs[{2 if (metric == 'ip' and d == 768) else 1}] per GPU)",
             "nvec_per_gpu": n, "dim": d, "metric_type": metric, "nlist_per_gpu": nlist, "batch": Q, "k": k, "nprobe": nprobe,
             "recall_at_k": round(recall, 4), "recall_sweep": sweep,
-            "sharding": "lists by number across ranks, centroids replicated, RCCL all-gather + merge" if world > 1 else "single GPU",
+            "sharding": ("lists by number across ranks, centroids replicated; all-gather of the probed-list ids, local scan, "
+                         "all-to-all of the per-rank top-k, merge on the rank that owns the query") if world > 1 else "single GPU",
         },
         "roofline": {
             "kernel": "k_scan",

@@ -163,7 +163,7 @@ __device__ __forceinline__ T block_exscan_1024(T v, T *s_wave /*[16]*/, T *total
 
 // single workgroup of 1024 threads: exclusive scans over the partitions.  Also clears the per-call counters.
 __global__ __launch_bounds__(1024) void k_group_scan(GroupParams G) {
-    __shared__ long long s_w[16];
+    __shared__ long long s_w[48];
     const int tid = threadIdx.x;
     const int per = (G.npids + 1023) / 1024;
     const int b = tid * per, e = min(G.npids, b + per);
@@ -179,11 +179,53 @@ __global__ __launch_bounds__(1024) void k_group_scan(GroupParams G) {
             sr += sz;
         }
     }
+    // three scans behind ONE pair of barriers: (active count | grouped-query count) packed in 64 bits (both < 2^31, so
+    // the halves never carry into each other), tiles, rows (total only)
     long long tq, ta, tt, tr;
-    long long aq = block_exscan_1024<long long>(sq, s_w, &tq);
-    long long aa = block_exscan_1024<long long>(sa, s_w, &ta);
-    long long at = block_exscan_1024<long long>(stl, s_w, &tt);
-    (void)block_exscan_1024<long long>(sr, s_w, &tr);
+    long long aq, aa, at;
+    {
+        const int lane = tid & 63, wave = tid >> 6;
+        unsigned long long i0 = ((unsigned long long)(unsigned)sa << 32) | (unsigned)sq;
+        long long i1 = stl, i2 = sr;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned long long o0 = __shfl_up(i0, off);
+            const long long o1 = __shfl_up(i1, off), o2 = __shfl_up(i2, off);
+            if (lane >= off) {
+                i0 += o0;
+                i1 += o1;
+                i2 += o2;
+            }
+        }
+        if (lane == 63) {
+            s_w[wave] = (long long)i0;
+            s_w[16 + wave] = i1;
+            s_w[32 + wave] = i2;
+        }
+        __syncthreads();
+        unsigned long long p0 = 0, t0 = 0;
+        long long p1 = 0, t1 = 0, t2 = 0;
+#pragma unroll
+        for (int w = 0; w < 16; w++) {
+            const unsigned long long v0 = (unsigned long long)s_w[w];
+            const long long v1 = s_w[16 + w];
+            if (w < wave) {
+                p0 += v0;
+                p1 += v1;
+            }
+            t0 += v0;
+            t1 += v1;
+            t2 += s_w[32 + w];
+        }
+        const unsigned long long e0 = p0 + i0 - (((unsigned long long)(unsigned)sa << 32) | (unsigned)sq);
+        aq = (long long)(e0 & 0xFFFFFFFFull);
+        aa = (long long)(e0 >> 32);
+        at = p1 + i1 - stl;
+        tq = (long long)(t0 & 0xFFFFFFFFull);
+        ta = (long long)(t0 >> 32);
+        tt = t1;
+        tr = t2;
+    }
     if (tid == 0) {
         G.g_qoff[G.npids] = (int)tq;
         *G.n_active = (int)ta;

@@ -3,9 +3,10 @@
 One process per GPU.  Partitions (lists) are sharded by list number -- the multi-GPU analogue of the reference's
 partition -> core map (PartitionManager::distribute_partitions, partition_manager.cpp:599-602) -- the centroids are
 replicated, every rank runs the coarse step for the whole batch and scans only the probed lists it owns (worker_scan's
-per-core jobs, query_coordinator.cpp:243-469), then the per-rank top-k are exchanged with ONE all-gather of ids and
-merge keys (the cross-worker batch_add, query_coordinator.cpp:167-173,231-235) and merged under the same (key, id)
-total order.  No other collective is on the search path.
+per-core jobs, query_coordinator.cpp:243-469), then the per-rank top-k (ids and merge keys) are exchanged -- an all-gather when every rank
+wants the whole answer, an all-to-all when each rank keeps the answer of its own slice of the batch -- and merged under the
+same (key, id) total order (the cross-worker batch_add, query_coordinator.cpp:167-173,231-235).  Besides the all-gather of
+the [Q, nprobe] partition lists no other collective is on the search path.
 
 The arithmetic lives in an *engine*:
   GpuEngine   -- libquake_hip.so (qk_search with squared-L2 keys + qk_merge_topk), the product path
@@ -66,9 +67,28 @@ class ShardedIndex:
     ranks; the [Q, nprobe] partition lists are then all-gathered -- the one real exchange the path has besides the
     final top-k gather."""
 
-    def __init__(self, engine, dist=None, world=1, rank=0):
+    def __init__(self, engine, dist=None, world=1, rank=0, result="all"):
+        """result = "all": every rank ends with the whole [Q, k] answer (all-gather of the per-rank top-k, G*Q*k*12 bytes
+        received per rank).  result = "owner": rank r ends with the answer of ITS slice of the batch, rows
+        [r*Q/G, (r+1)*Q/G) -- the per-rank top-k are exchanged with an all-to-all (Q*k*12 bytes per rank, independent of
+        the number of ranks) and each rank merges only its own queries; this is the serving layout (a query's answer goes
+        back to the rank that received it) and what bench.py times."""
         self.engine, self.dist, self.world, self.rank = engine, dist, int(world), int(rank)
+        if result not in ("all", "owner"):
+            raise ValueError("result must be 'all' or 'owner'")
+        self.result = result
         self._g_ids = self._g_keys = self._g_pids = None
+        self._x_ids = self._x_keys = None
+
+    def _exchange(self, buf_name, t):
+        """all-to-all of [G, per, k] blocks: block j goes to rank j; returns [G(source), per, k]."""
+        import torch
+        t = t if torch.is_tensor(t) else torch.from_numpy(np.ascontiguousarray(t))
+        buf = getattr(self, buf_name)
+        if buf is None or tuple(buf.shape) != tuple(t.shape) or buf.device != t.device or buf.dtype != t.dtype:
+            buf = torch.empty_like(t)
+            setattr(self, buf_name, buf)
+        return buf, self.dist.all_to_all_single(buf.view(-1), t.contiguous().view(-1), async_op=True)
 
     def _gather(self, buf_name, t, dtype):
         import torch
@@ -97,6 +117,14 @@ class ShardedIndex:
         if not torch.is_tensor(q):
             pids = pids.numpy()
         ids, keys = self.engine.scan(q, pids, k, out=out)
+        if self.result == "owner":
+            ids = ids if torch.is_tensor(ids) else torch.from_numpy(np.ascontiguousarray(ids))
+            keys = keys if torch.is_tensor(keys) else torch.from_numpy(np.ascontiguousarray(keys))
+            x_ids, w1 = self._exchange("_x_ids", ids.view(self.world, per, -1))
+            x_keys, w2 = self._exchange("_x_keys", keys.view(self.world, per, -1))
+            w1.wait()
+            w2.wait()
+            return self.engine.merge(x_ids, x_keys)
         g_ids = self._gather("_g_ids", ids, torch.int64)
         g_keys = self._gather("_g_keys", keys, torch.float32)
         return self.engine.merge(g_ids, g_keys)

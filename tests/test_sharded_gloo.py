@@ -79,6 +79,16 @@ def _worker(rank, world, port, metric, ret):
             fi, fd = O.search(q, ivf["centroids"], ivf["vecs"], ivf["ids"], ivf["offsets"], nprobe, k, metric, batched_scan=True)
             assert (gi == fi).all(), (rank, nprobe, k)
             assert (gd.view(np.uint32) == fd.view(np.uint32)).all(), (rank, nprobe, k)
+        # owner layout: all-to-all of the per-rank top-k, rank r keeps the answer of its slice of the batch
+        idx_o = ShardedIndex(eng, dist, world, rank, result="owner")
+        per = q.shape[0] // world
+        for nprobe, k in [(1, 5), (16, 40)]:
+            gi, gd = idx_o.search(q, nprobe, k)
+            fi, fd = O.search(q, ivf["centroids"], ivf["vecs"], ivf["ids"], ivf["offsets"], nprobe, k, metric, batched_scan=True)
+            sl = slice(rank * per, (rank + 1) * per)
+            assert gi.shape == (per, k)
+            assert (gi == fi[sl]).all(), (rank, nprobe, k)
+            assert (gd.view(np.uint32) == fd[sl].view(np.uint32)).all(), (rank, nprobe, k)
         ret[rank] = "ok"
     finally:
         dist.destroy_process_group()
