@@ -121,7 +121,10 @@ def main():
 
     from quake_amd.capi import Context, Store
     ctx = Context(dev_index)
-    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    # the library runs on torch's current stream, so that it is ordered with torch / torch.distributed work
+    # (QUAKE_BENCH_STREAM=private: A/B against the context's own non-blocking stream, single GPU only)
+    if not (os.environ.get("QUAKE_BENCH_STREAM") == "private" and world == 1):
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     info = ctx.device_info()
     log("device", info)
 

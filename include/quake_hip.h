@@ -73,6 +73,9 @@ QK_API int qk_ctx_create(int device, qk_ctx **out);
 QK_API int qk_ctx_destroy(qk_ctx *ctx);
 /* Run on a caller-owned hipStream_t instead (e.g. torch's current stream); NULL restores the private one. */
 QK_API int qk_ctx_set_stream(qk_ctx *ctx, void *hip_stream);
+/* Run on the device's NULL (legacy default) stream -- torch's default stream has the handle 0, which qk_ctx_set_stream reads
+ * as "restore the private stream". */
+QK_API int qk_ctx_set_null_stream(qk_ctx *ctx);
 QK_API int qk_ctx_synchronize(qk_ctx *ctx);
 /* hipEvent timing of the phases, recorded on the context's stream around the kernels:
  *   0 off; 1 per call (the qk_timing* passed to qk_scan/qk_search is filled, which synchronises the stream);

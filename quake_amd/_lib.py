@@ -39,6 +39,7 @@ SIGNATURES = {
     "qk_ctx_create": (_int, [_int, C.POINTER(_vp)]),
     "qk_ctx_destroy": (_int, [_vp]),
     "qk_ctx_set_stream": (_int, [_vp, _vp]),
+    "qk_ctx_set_null_stream": (_int, [_vp]),
     "qk_ctx_synchronize": (_int, [_vp]),
     "qk_ctx_set_timing": (_int, [_vp, _int]),
     "qk_ctx_set_squared_l2": (_int, [_vp, _int]),

@@ -97,7 +97,14 @@ class Context:
         check(self.lib.qk_ctx_synchronize(self.h))
 
     def set_stream(self, hip_stream):
-        check(self.lib.qk_ctx_set_stream(self.h, C.c_void_p(hip_stream) if hip_stream else None))
+        """hip_stream: a hipStream_t handle (e.g. torch.cuda.current_stream().cuda_stream); 0 = the device's NULL stream
+        (torch's default stream); None = back to the context's private stream."""
+        if hip_stream is None:
+            check(self.lib.qk_ctx_set_stream(self.h, None))
+        elif int(hip_stream) == 0:
+            check(self.lib.qk_ctx_set_null_stream(self.h))
+        else:
+            check(self.lib.qk_ctx_set_stream(self.h, C.c_void_p(int(hip_stream))))
 
     def set_timing(self, mode=1):
         """0 off, 1 per-call (synchronising), 2 deferred (read with read_timing())."""

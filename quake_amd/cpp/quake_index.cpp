@@ -132,6 +132,9 @@ shared_ptr<SearchResult> QuakeIndex::search(Tensor x, shared_ptr<SearchParams> s
     auto t0 = clk::now();
     const bool on_dev = x.is_cuda();
     Tensor xq = on_dev ? x.to(torch::kFloat32).contiguous() : host_f32(x);
+    // the library runs on its own stream: device inputs must be complete before it starts (the calls below hand back
+    // a drained stream, so the outputs are ready for torch's stream)
+    if (on_dev) torch::cuda::synchronize(xq.device().index());
     const int64_t Q = xq.size(0);
     const int k = sp->k > 0 ? sp->k : 1;  // query_coordinator.cpp:490
     const int nprobe = std::max(sp->nprobe, 1);

@@ -60,6 +60,12 @@ int qk_ctx_set_stream(qk_ctx *c, void *hip_stream) {
     return QK_OK;
 }
 
+int qk_ctx_set_null_stream(qk_ctx *c) {
+    if (!c) QK_FAIL(QK_ERR_INVALID, "qk_ctx_set_null_stream: ctx is null");
+    c->stream = nullptr;  // hipStream_t 0: ordered with every blocking stream of the device
+    return QK_OK;
+}
+
 int qk_ctx_synchronize(qk_ctx *c) {
     if (!c) QK_FAIL(QK_ERR_INVALID, "qk_ctx_synchronize: ctx is null");
     QK_HIP(hipStreamSynchronize(c->stream));

@@ -142,9 +142,13 @@ _CONTEXTS = {}
 
 
 def _context(device=0):
+    """the per-device context, bound to torch's CURRENT stream of that device: device tensors handed in were produced on
+    it and the tensors handed back are consumed on it, so the library's work has to be ordered with it"""
     if device not in _CONTEXTS:
         _CONTEXTS[device] = capi.Context(device)
-    return _CONTEXTS[device]
+    ctx = _CONTEXTS[device]
+    ctx.set_stream(torch.cuda.current_stream(device).cuda_stream)
+    return ctx
 
 
 def _us(t0):
@@ -160,9 +164,12 @@ class QuakeIndex:
         self.metric_ = None
         self.build_params_ = None
         self.maintenance_policy_params_ = None
+        self.maintenance_policy_ = None
+        self._policy_cost_estimator = None
+        self.track_hits = False  # record the partitions each query scans (maintenance_policies.cpp:179-182)
         self.debug_ = False
         self._device = int(device)
-        self._ctx = None
+        self._has_ctx = False
         self._store = None
         self._resident = set()   # PartitionManager::resident_ids_
         self._next_pid = 0       # PartitionManager::curr_partition_id_
@@ -172,6 +179,10 @@ class QuakeIndex:
     @property
     def parent_(self):
         return self.parent
+
+    @property
+    def _ctx(self):
+        return _context(self._device) if self._has_ctx else None
 
     def _to_dev(self, t, dtype):
         if not torch.is_tensor(t):
@@ -191,7 +202,7 @@ class QuakeIndex:
             raise RuntimeError("[QuakeIndex::build] x must be 2-D [num_vectors, dimension]")
         if x.shape[0] != ids.shape[0]:
             raise RuntimeError("[QuakeIndex::build] x.size(0) != ids.size(0)")
-        self._ctx = _context(self._device)
+        self._has_ctx = True
         n, d = int(x.shape[0]), int(x.shape[1])
         self._d = d
         info = BuildTimingInfo()
@@ -269,8 +280,15 @@ class QuakeIndex:
         nprobe = max(int(search_params.nprobe), 1)
         self._ctx.set_timing(1)
         try:
-            ids, dist, tm = self._ctx.search(self.parent._store if self.parent is not None else None, self._store, xd, nprobe,
-                                             int(k), self.metric_, timing=True)
+            if self.track_hits and self.parent is not None:
+                # hit tracking for maintenance(): the probed partitions are needed on the host, so coarse and scan are
+                # two calls here (same kernels, one extra copy of [Q, nprobe] ids)
+                pids, _ = self._ctx.coarse(self.parent._store, xd, nprobe, self.metric_)
+                ids, dist, tm = self._ctx.scan(self._store, xd, pids, int(k), self.metric_, timing=True)
+                self.record_query_hits(pids.cpu().numpy())
+            else:
+                ids, dist, tm = self._ctx.search(self.parent._store if self.parent is not None else None, self._store, xd,
+                                                 nprobe, int(k), self.metric_, timing=True)
         finally:
             self._ctx.set_timing(0)
         ti.n_queries = int(x.shape[0])
@@ -382,18 +400,93 @@ class QuakeIndex:
         new_c = self._store.refine_lists(partition_ids.reshape(-1).cpu().numpy(), cent.numpy(), self.metric_, int(iterations))
         self.parent.modify(partition_ids, torch.from_numpy(np.ascontiguousarray(new_c)))
 
-    # -- maintenance (quake_index.cpp:152-163) ------------------------------------------------------------------------------
-    def initialize_maintenance_policy(self, maintenance_policy_params):
+    # -- maintenance (quake_index.cpp:152-163; maintenance_policies.cpp; partition_manager.cpp:344-554) ---------------------
+    def initialize_maintenance_policy(self, maintenance_policy_params, cost_estimator=None):
+        """quake_index.cpp:165-168.  The policy object (cost model included) is created lazily: profiling the device scan
+        for the latency grid costs a few hundred launches, which a search-only user never needs."""
         self.maintenance_policy_params_ = maintenance_policy_params
+        self.maintenance_policy_ = None
+        self._policy_cost_estimator = cost_estimator
+
+    def _policy(self):
+        if self.maintenance_policy_ is None:
+            from .maintenance import MaintenancePolicy
+            self.maintenance_policy_ = MaintenancePolicy(self, self.maintenance_policy_params_, self._policy_cost_estimator)
+        return self.maintenance_policy_
+
+    def record_query_hits(self, pids):
+        """pids [Q, nprobe] (host): partitions every query scanned.  maintenance_policies.cpp:179-182."""
+        pol = self._policy()
+        arr = np.asarray(pids).reshape(len(pids), -1)
+        uniq = np.unique(arr[arr >= 0])
+        lut = np.zeros(int(uniq.max()) + 1 if uniq.size else 1, np.int64)
+        lut[uniq] = self._partition_sizes(uniq.tolist())
+        pol.hit_count_tracker_.add_batch(arr, lut[np.clip(arr, 0, None)])
 
     def maintenance(self):
-        """MaintenancePolicy::perform_maintenance (maintenance_policies.cpp:33-177).  In the reference snapshot
-        search() never calls record_query_hits, so through the public API the policy always returns at the
-        'window not full' guard (:36-41) with zero splits/deletes; that observable behaviour is what is kept here.
-        The policy itself is out of scope (SURVEY section 2 #7)."""
+        """MaintenancePolicy::perform_maintenance (maintenance_policies.cpp:33-177): nothing until window_size queries have
+        been recorded (:36-41), then delete / split / local refinement as the cost model decides."""
         if self.maintenance_policy_params_ is None:
             raise RuntimeError("[QuakeIndex::maintenance()] No maintenance policy set.")
-        return MaintenanceTimingInfo()
+        if self.parent is None:
+            return MaintenanceTimingInfo()
+        return self._policy().perform_maintenance()
+
+    def _partition_sizes(self, pids):
+        return [int(self._store.list_size(int(p))) for p in pids]
+
+    def _select_partitions(self, pids):  # partition_manager.cpp:344-390
+        vecs, ids = [], []
+        for p in pids:
+            v, i = self._store.get_list(int(p))
+            vecs.append(v)
+            ids.append(i)
+        return vecs, ids
+
+    def _split_partitions(self, pids):  # :392-444: 2-means of every partition (qk_kmeans on the GPU)
+        vecs, ids = self._select_partitions(pids)
+        out_c, out_v, out_i = [], [], []
+        for v, i in zip(vecs, ids):
+            assert v.shape[0] >= 4, "Partition must have at least 8 vectors to split."  # (the reference's message, :412)
+            xd = torch.from_numpy(v).cuda(self._device)
+            cent, assign, xd = self._ctx.kmeans(xd, 2, self.metric_, niter=5, seed=1234)
+            a = assign.cpu().numpy()
+            vv = xd.cpu().numpy()
+            cent = cent.cpu().numpy()
+            for j in range(2):
+                m = a == j
+                out_c.append(cent[j])
+                out_v.append(np.ascontiguousarray(vv[m]))
+                out_i.append(np.ascontiguousarray(i[m]))
+        return {"centroids": np.stack(out_c), "vectors": out_v, "vector_ids": out_i}
+
+    def _add_partitions(self, clustering):  # :489-520
+        n = len(clustering["vectors"])
+        new_pids = list(range(self._next_pid, self._next_pid + n))
+        self._next_pid += n
+        for pid, v, i in zip(new_pids, clustering["vectors"], clustering["vector_ids"]):
+            self._store.add_list(pid)
+            if v.shape[0]:
+                self._store.add_entries(pid, i, v)
+        self.parent.add(torch.from_numpy(np.ascontiguousarray(clustering["centroids"])),
+                        torch.tensor(new_pids, dtype=torch.int64))
+        return new_pids
+
+    def _delete_partitions(self, pids, reassign=True):  # :522-554
+        if self.parent is None:
+            raise RuntimeError("Index is not partitioned")
+        vecs, ids = self._select_partitions(pids)
+        self.parent.remove(torch.tensor([int(p) for p in pids], dtype=torch.int64))
+        for p in pids:
+            self._store.remove_list(int(p))
+        if reassign:
+            for v, i in zip(vecs, ids):
+                if v.shape[0] == 0:
+                    continue
+                # PartitionManager::add(vectors, ids, {}, check_uniques = false): nearest remaining centroid
+                xd = torch.from_numpy(v).cuda(self._device)
+                near, _ = self._ctx.coarse(self.parent._store, xd, 1, self.metric_)
+                self._store.add_batch(torch.from_numpy(i).cuda(self._device), xd, near.reshape(-1).contiguous())
 
     # -- sizes ---------------------------------------------------------------------------------------------------------------
     def ntotal(self):
@@ -453,7 +546,7 @@ class QuakeIndex:
         pids = np.frombuffer(blob, "<u8", nparts, 32 + 8 * (nparts + 1))
         start = 32 + 8 * (nparts + 1) + 8 * nparts
         rec = code_size + 8
-        self._ctx = _context(self._device)
+        self._has_ctx = True
         self._d = int(d)
         self._store = capi.Store(self._ctx, int(d))
         self._resident = set()

@@ -1,0 +1,413 @@
+"""Maintenance policy of the dynamic index: hit tracking, cost model, split / delete / local refinement.
+
+Host-side bookkeeping over the device store -- the counterpart of
+  HitCountTracker            src/cpp/src/hit_count_tracker.cpp:3-98
+  ListScanLatencyEstimator   src/cpp/src/maintenance_cost_estimator.cpp:21-365 (grid + bilinear inter/extrapolation)
+  MaintenanceCostEstimator   src/cpp/src/maintenance_cost_estimator.cpp:368-498
+  MaintenancePolicy          src/cpp/src/maintenance_policies.cpp:18-202
+Every data-parallel step it triggers runs on the GPU through the C ABI: the parent searches (qk_coarse), the 2-means
+split (qk_kmeans), the reassignment of a deleted partition's vectors (qk_coarse + qk_store_add_batch) and the local
+refinement (qk_store_refine_lists).
+
+Two deliberate differences from the reference snapshot, both named in SURVEY.md section 8f-4:
+  * QuakeIndex.search records the partitions each query scanned (the reference declares record_query_hits but never calls
+    it, so its maintenance() can never act);
+  * the latency model is profiled on the DEVICE scan (amortised per-query cost of scanning an n-row partition inside a
+    batch), not on the CPU scan_list; any other model can be injected with `profile_fn`.
+"""
+import bisect
+import math
+import time
+
+import numpy as np
+
+DEFAULT_LATENCY_ESTIMATOR_RANGE_N = [1, 2, 4, 16, 64, 256, 1024, 4096, 16384, 65536]  # common.h:97
+DEFAULT_LATENCY_ESTIMATOR_RANGE_K = [1, 4, 16, 64, 256]  # common.h:98
+DEFAULT_LATENCY_ESTIMATOR_NTRIALS = 5  # common.h:99
+
+
+class HitCountTracker:
+    """Sliding window over the last `window_size` queries: which partitions each scanned and how many vectors that was."""
+
+    def __init__(self, window_size, total_vectors):
+        if window_size <= 0:
+            raise ValueError("Window size must be positive")
+        if total_vectors <= 0:
+            raise ValueError("Total vectors must be positive")
+        self.window_size_ = int(window_size)
+        self.total_vectors_ = int(total_vectors)
+        self.reset()
+
+    def reset(self):
+        self.curr_query_index_ = 0
+        self.num_queries_recorded_ = 0
+        self.running_sum_scan_fraction_ = np.float32(0.0)
+        self.current_scan_fraction_ = np.float32(1.0)
+        self.per_query_hits_ = [[] for _ in range(self.window_size_)]
+        self.per_query_scanned_sizes_ = [[] for _ in range(self.window_size_)]
+
+    def set_total_vectors(self, total_vectors):
+        if total_vectors <= 0:
+            raise ValueError("Total vectors must be positive")
+        self.total_vectors_ = int(total_vectors)
+
+    def _fraction(self, scanned_sizes):
+        return np.float32(np.float32(int(sum(scanned_sizes))) / np.float32(self.total_vectors_))
+
+    def add_query_data(self, hit_partition_ids, scanned_sizes):
+        if len(hit_partition_ids) != len(scanned_sizes):
+            raise ValueError("hit_partition_ids and scanned_sizes must be of equal length")
+        frac = self._fraction(scanned_sizes)
+        if self.num_queries_recorded_ < self.window_size_:
+            self.per_query_hits_[self.num_queries_recorded_] = list(hit_partition_ids)
+            self.per_query_scanned_sizes_[self.num_queries_recorded_] = list(scanned_sizes)
+            self.running_sum_scan_fraction_ = np.float32(self.running_sum_scan_fraction_ + frac)
+            self.num_queries_recorded_ += 1
+        else:
+            old = self._fraction(self.per_query_scanned_sizes_[self.curr_query_index_])
+            self.running_sum_scan_fraction_ = np.float32(self.running_sum_scan_fraction_ - old)
+            self.per_query_hits_[self.curr_query_index_] = list(hit_partition_ids)
+            self.per_query_scanned_sizes_[self.curr_query_index_] = list(scanned_sizes)
+            self.running_sum_scan_fraction_ = np.float32(self.running_sum_scan_fraction_ + frac)
+            self.curr_query_index_ = (self.curr_query_index_ + 1) % self.window_size_
+        eff = min(self.num_queries_recorded_, self.window_size_)
+        self.current_scan_fraction_ = np.float32(self.running_sum_scan_fraction_ / np.float32(eff))
+
+    def add_batch(self, hit_partition_ids, scanned_sizes):
+        """A whole query batch at once ([Q, P] arrays, -1 = no partition): same window contents as Q add_query_data calls;
+        the running sum is recomputed from the window (no per-query float32 drift)."""
+        hp = np.asarray(hit_partition_ids).reshape(len(hit_partition_ids), -1)[-self.window_size_:]  # older rows cannot survive
+        sz = np.where(hp >= 0, np.asarray(scanned_sizes).reshape(-1, hp.shape[1])[-self.window_size_:], 0)
+        n = hp.shape[0]
+        fill = min(n, self.window_size_ - self.num_queries_recorded_)  # rows that go into still-empty slots
+        slots = np.empty(n, np.int64)
+        slots[:fill] = np.arange(self.num_queries_recorded_, self.num_queries_recorded_ + fill)
+        slots[fill:] = (self.curr_query_index_ + np.arange(n - fill)) % self.window_size_
+        self.num_queries_recorded_ += fill
+        self.curr_query_index_ = int((self.curr_query_index_ + (n - fill)) % self.window_size_)
+        clean = bool((hp >= 0).all())
+        for i, slot in enumerate(slots.tolist()):
+            if clean:
+                self.per_query_hits_[slot] = hp[i]
+                self.per_query_scanned_sizes_[slot] = sz[i]
+            else:
+                keep = hp[i] >= 0
+                self.per_query_hits_[slot] = hp[i][keep]
+                self.per_query_scanned_sizes_[slot] = sz[i][keep]
+        eff = min(self.num_queries_recorded_, self.window_size_)
+        tot = float(sum(int(np.sum(v)) for v in self.per_query_scanned_sizes_[:eff])) if eff <= 64 else float(
+            np.concatenate([np.asarray(v).reshape(-1) for v in self.per_query_scanned_sizes_[:eff]]).sum())
+        self.running_sum_scan_fraction_ = np.float32(tot / self.total_vectors_)
+        self.current_scan_fraction_ = np.float32(self.running_sum_scan_fraction_ / np.float32(max(eff, 1)))
+
+    def aggregated_hits(self):
+        """partition id -> number of window queries that scanned it (maintenance_policies.cpp:45-51)"""
+        eff = min(self.num_queries_recorded_, self.window_size_)
+        rows = [np.asarray(v, dtype=np.int64).reshape(-1) for v in self.per_query_hits_[:eff]]
+        if not rows:
+            return {}
+        u, c = np.unique(np.concatenate(rows), return_counts=True)
+        return dict(zip(u.tolist(), c.tolist()))
+
+    def get_current_scan_fraction(self):
+        return float(self.current_scan_fraction_)
+
+    def get_per_query_hits(self):
+        return self.per_query_hits_
+
+    def get_per_query_scanned_sizes(self):
+        return self.per_query_scanned_sizes_
+
+    def get_window_size(self):
+        return self.window_size_
+
+    def get_num_queries_recorded(self):
+        return self.num_queries_recorded_
+
+
+def _linear_extrapolate(f1, f2, t):
+    return f2 + t * (f2 - f1)  # maintenance_cost_estimator.h linear_extrapolate: slope of the last interval
+
+
+class ListScanLatencyEstimator:
+    """Latency grid L[n][k] in ns with bilinear interpolation inside the grid and linear extrapolation beyond it.
+    profile_fn(n, k) -> ns fills the grid (default: profile the device scan, see device_profile_fn)."""
+
+    def __init__(self, d, n_values, k_values, n_trials=DEFAULT_LATENCY_ESTIMATOR_NTRIALS, adaptive_nprobe=False,
+                 profile_filename="", profile_fn=None):
+        self.d_ = int(d)
+        self.n_values_ = [int(v) for v in n_values]
+        self.k_values_ = [int(v) for v in k_values]
+        self.n_trials_ = int(n_trials)
+        self.profile_filename_ = profile_filename
+        if self.n_values_ != sorted(self.n_values_):
+            raise RuntimeError("n_values must be sorted in ascending order.")
+        if self.k_values_ != sorted(self.k_values_):
+            raise RuntimeError("k_values must be sorted in ascending order.")
+        self.scan_latency_model_ = [[0.0] * len(self.k_values_) for _ in self.n_values_]
+        loaded = bool(profile_filename) and self.load_latency_profile(profile_filename)
+        if not loaded:
+            self.profile_scan_latency(profile_fn)
+            if profile_filename:
+                self.save_latency_profile(profile_filename)
+
+    def profile_scan_latency(self, profile_fn=None):
+        fn = profile_fn if profile_fn is not None else device_profile_fn(self.d_, self.n_trials_)
+        for i, n in enumerate(self.n_values_):
+            for j, k in enumerate(self.k_values_):
+                self.scan_latency_model_[i][j] = float(fn(n, k))
+
+    def set_scan_latency(self, n, k, latency_ns):
+        self.scan_latency_model_[self.n_values_.index(n)][self.k_values_.index(k)] = float(latency_ns)
+
+    @staticmethod
+    def _axis(values, v):
+        """(lower index, upper index, fraction, inside) along one axis; beyond the grid the fraction is measured from the
+        LAST node in units of the last interval (maintenance_cost_estimator.cpp:143-190)."""
+        if v <= values[-1]:
+            it = bisect.bisect_right(values, v)
+            if it == len(values):
+                return len(values) - 2, len(values) - 1, 1.0, True
+            lo, hi = it - 1, it
+            return lo, hi, (v - values[lo]) / float(values[hi] - values[lo]), True
+        lo, hi = len(values) - 2, len(values) - 1
+        return lo, hi, (v - values[hi]) / float(values[hi] - values[lo]), False
+
+    def estimate_scan_latency(self, n, k):
+        n, k = int(n), int(k)
+        if n == 0 or k == 0:
+            return 0.0
+        if n < self.n_values_[0] or k < self.k_values_[0]:
+            raise IndexError("n or k is below the minimum supported values.")
+        il, iu, t, n_in = self._axis(self.n_values_, n)
+        jl, ju, u, k_in = self._axis(self.k_values_, k)
+        m = self.scan_latency_model_
+        f11, f12, f21, f22 = m[il][jl], m[il][ju], m[iu][jl], m[iu][ju]
+        if n_in and k_in:
+            return (1 - t) * (1 - u) * f11 + t * (1 - u) * f21 + (1 - t) * u * f12 + t * u * f22
+        if not n_in and k_in:
+            lo, up = _linear_extrapolate(f11, f21, t), _linear_extrapolate(f12, f22, t)
+            return (1 - u) * lo + u * up
+        if n_in and not k_in:
+            lo, up = _linear_extrapolate(f11, f12, u), _linear_extrapolate(f21, f22, u)
+            return (1 - t) * lo + t * up
+        lo, up = _linear_extrapolate(f11, f21, t), _linear_extrapolate(f12, f22, t)
+        return _linear_extrapolate(lo, up, u)
+
+    # the reference's CSV layout (maintenance_cost_estimator.cpp:259-365): header, "n_size,k_size", n values, k values, rows
+    def save_latency_profile(self, filename):
+        try:
+            with open(filename, "w") as f:
+                f.write("n_size,k_size\n")
+                f.write(f"{len(self.n_values_)},{len(self.k_values_)}\n")
+                f.write(",".join(str(v) for v in self.n_values_) + "\n")
+                f.write(",".join(str(v) for v in self.k_values_) + "\n")
+                for row in self.scan_latency_model_:
+                    f.write(",".join(repr(float(v)) for v in row) + "\n")
+            return True
+        except OSError:
+            return False
+
+    def load_latency_profile(self, filename):
+        try:
+            with open(filename) as f:
+                lines = [ln.strip() for ln in f.read().splitlines()]
+        except OSError:
+            return False
+        try:
+            ns, ks = (int(v) for v in lines[1].split(","))
+            nv = [int(v) for v in lines[2].split(",")]
+            kv = [int(v) for v in lines[3].split(",")]
+            if len(nv) != ns or len(kv) != ks or nv != self.n_values_ or kv != self.k_values_:
+                return False
+            model = []
+            for i in range(ns):
+                row = [float(v) for v in lines[4 + i].split(",")]
+                if len(row) != ks:
+                    return False
+                model.append(row)
+        except (IndexError, ValueError):
+            return False
+        self.scan_latency_model_ = model
+        return True
+
+
+def device_profile_fn(d, n_trials=DEFAULT_LATENCY_ESTIMATOR_NTRIALS, device=0, max_rows=1 << 22):
+    """profile_fn for a GPU index, THROUGHPUT regime: many partitions of n rows are scanned in one qk_scan call, one query
+    each (up to 1024 pairs, at most max_rows rows in total), and the cost of one (query, partition) pair is the call's time
+    divided by the number of pairs -- what one more probed partition of that size costs inside a busy serving batch.
+    (A single-query latency, what the reference profiles on the CPU, is flat in n on a GPU: launch-bound.)"""
+    import torch
+    from . import capi
+
+    state = {}
+
+    def fn(n, k):
+        dev = torch.device("cuda", device)
+        if "ctx" not in state:
+            state["ctx"] = capi.Context(device)
+        ctx = state["ctx"]
+        if state.get("n") != n:
+            npart = int(max(16, min(1024, max_rows // max(n, 1))))
+            s = capi.Store(ctx, d)
+            s.build_csr(np.arange(npart + 1, dtype=np.int64) * n, torch.arange(npart * n, device=dev),
+                        torch.rand(npart * n, d, device=dev))
+            state.update(store=s, n=n, npart=npart, q=torch.rand(npart, d, device=dev),
+                         pids=torch.arange(npart, device=dev, dtype=torch.int64)[:, None].contiguous())
+        s, q, pids = state["store"], state["q"], state["pids"]
+        kk = min(int(k), 448)
+        ctx.scan(s, q, pids, kk, "l2")
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n_trials):
+            ctx.scan(s, q, pids, kk, "l2")
+        ctx.synchronize()
+        return (time.perf_counter() - t0) / n_trials / state["npart"] * 1e9
+
+    return fn
+
+
+class MaintenanceCostEstimator:
+    def __init__(self, d, alpha, k, latency_estimator=None, profile_fn=None):
+        if k <= 0:
+            raise ValueError("k must be positive")
+        if alpha <= 0.0:
+            raise ValueError("alpha must be positive")
+        self.d_, self.alpha_, self.k_ = int(d), float(alpha), int(k)
+        self.latency_estimator_ = latency_estimator or ListScanLatencyEstimator(
+            d, DEFAULT_LATENCY_ESTIMATOR_RANGE_N, DEFAULT_LATENCY_ESTIMATOR_RANGE_K, DEFAULT_LATENCY_ESTIMATOR_NTRIALS,
+            profile_fn=profile_fn)
+
+    def get_latency_estimator(self):
+        return self.latency_estimator_
+
+    def get_k(self):
+        return self.k_
+
+    def compute_split_delta(self, partition_size, hit_rate, total_partitions):  # :384-394
+        L = self.latency_estimator_.estimate_scan_latency
+        delta_overhead = L(total_partitions + 1, self.k_) - L(total_partitions, self.k_)
+        old_cost = L(partition_size, self.k_) * hit_rate
+        new_cost = L(partition_size // 2, self.k_) * hit_rate * (2.0 * self.alpha_)
+        return delta_overhead + new_cost - old_cost
+
+    def compute_delete_delta(self, partition_size, hit_rate, total_partitions, avg_partition_hit_rate, avg_partition_size):
+        if total_partitions <= 1:
+            return 0.0
+        L = self.latency_estimator_.estimate_scan_latency
+        k = self.k_
+        delta_overhead = L(total_partitions - 1, k) - L(total_partitions, k)
+        cost_old = (total_partitions - 1) * avg_partition_hit_rate * L(int(avg_partition_size), k) + hit_rate * L(partition_size, k)
+        merged_size = avg_partition_size + float(partition_size) / (total_partitions - 1)
+        merged_hit_rate = avg_partition_hit_rate + hit_rate / float(total_partitions - 1)
+        if partition_size < total_partitions:
+            cost_new = (partition_size * merged_hit_rate * L(int(avg_partition_size + 1), k)
+                        + (total_partitions - partition_size - 1) * merged_hit_rate * L(int(avg_partition_size), k))
+        else:
+            cost_new = (total_partitions - 1) * merged_hit_rate * L(int(math.ceil(merged_size)), k)
+        return delta_overhead + (cost_new - cost_old)
+
+    def compute_delete_delta_w_reassign(self, partition_size, hit_rate, total_partitions, reassign_counts, reassign_sizes,
+                                        reassign_hit_rates):
+        if total_partitions <= 1:
+            return 0.0
+        assert len(reassign_sizes) == len(reassign_counts) == len(reassign_hit_rates)
+        L = self.latency_estimator_.estimate_scan_latency
+        k = self.k_
+        delta_overhead = L(total_partitions - 1, k) - L(total_partitions, k)
+        removal_delta = hit_rate * L(partition_size, k)
+        reassign_delta = 0.0
+        for sz, hr in zip(reassign_sizes, reassign_hit_rates):
+            old = hr * L(int(sz), k)
+            reassign_delta += (hr + hit_rate) * L(int(sz + partition_size), k) - old
+        return delta_overhead + removal_delta + reassign_delta
+
+
+class MaintenancePolicy:
+    """perform_maintenance(): delete the partitions whose removal lowers the modelled query cost, split the ones whose
+    split does, then refine around the new partitions (maintenance_policies.cpp:33-177)."""
+
+    def __init__(self, index, params, cost_estimator=None):
+        self.index_ = index
+        self.params_ = params
+        self.cost_estimator_ = cost_estimator or MaintenanceCostEstimator(index.d(), params.alpha, 10)
+        self.hit_count_tracker_ = HitCountTracker(params.window_size, max(index.ntotal(), 1))
+
+    def record_query_hits(self, partition_ids, scanned_sizes=None):
+        ids = [int(p) for p in partition_ids]
+        if scanned_sizes is None:
+            scanned_sizes = self.index_._partition_sizes(ids)
+        self.hit_count_tracker_.add_query_data(ids, [int(s) for s in scanned_sizes])
+
+    def reset(self):
+        self.hit_count_tracker_.reset()
+
+    def perform_maintenance(self):
+        import torch
+        from .index import MaintenanceTimingInfo
+        info = MaintenanceTimingInfo()
+        idx, p, tr = self.index_, self.params_, self.hit_count_tracker_
+        if tr.get_num_queries_recorded() < p.window_size:  # :36-41
+            return info
+        t_total = time.perf_counter()
+        hits = tr.aggregated_hits()
+        all_pids = [int(v) for v in idx._store.list_ids()]
+        total_partitions = idx.nlist()
+        scan_fraction = tr.get_current_scan_fraction()
+        avg_size = idx.ntotal() // max(total_partitions, 1)
+        sizes = dict(zip(all_pids, idx._partition_sizes(all_pids)))
+        to_delete, to_split = [], []
+        ce = self.cost_estimator_
+        for pid in all_pids:
+            hit_rate = float(np.float32(hits.get(pid, 0)) / np.float32(p.window_size))
+            size = sizes[pid]
+            dd = ce.compute_delete_delta(size, hit_rate, total_partitions, scan_fraction, avg_size)
+            if dd < -p.delete_threshold_ns:
+                if p.enable_delete_rejection and size > p.min_partition_size:
+                    # where would its vectors go?  second-nearest centroid of every vector (:79-101)
+                    vecs, _ = idx._store.get_list(pid)
+                    near, _ = idx._ctx.coarse(idx.parent._store, torch.from_numpy(vecs).cuda(idx._device), 2, idx.metric_)
+                    flat = near.reshape(-1)
+                    flat = flat[flat != pid]
+                    uniq, counts = torch.unique(flat, return_counts=True)
+                    uniq = [int(v) for v in uniq.tolist()]
+                    rs = idx._partition_sizes(uniq)
+                    hr = [float(np.float32(hits.get(u, 0)) / np.float32(p.window_size)) for u in uniq]
+                    delta = ce.compute_delete_delta_w_reassign(size, hit_rate, total_partitions, counts.tolist(), rs, hr)
+                    if delta < -p.delete_threshold_ns:
+                        to_delete.append(pid)
+                else:
+                    to_delete.append(pid)
+            elif size > p.min_partition_size:
+                if ce.compute_split_delta(size, hit_rate, total_partitions) < -p.split_threshold_ns:
+                    to_split.append(pid)
+        t0 = time.perf_counter()
+        if to_delete:
+            idx._delete_partitions(to_delete, reassign=True)
+        info.delete_time_us = int((time.perf_counter() - t0) * 1e6)
+        t0 = time.perf_counter()
+        new_pids = []
+        if to_split:
+            split = idx._split_partitions(to_split)
+            idx._delete_partitions(to_split, reassign=False)
+            new_pids = idx._add_partitions(split)
+        info.split_time_us = int((time.perf_counter() - t0) * 1e6)
+        if new_pids:
+            self.local_refinement(new_pids)
+        info.n_splits = len(to_split)
+        info.n_deletes = len(to_delete)
+        info.total_time_us = int((time.perf_counter() - t_total) * 1e6)
+        tr.set_total_vectors(max(idx.ntotal(), 1))
+        return info
+
+    def local_refinement(self, partition_ids):  # :187-202
+        import torch
+        idx, p = self.index_, self.params_
+        if p.refinement_radius == 0:
+            return
+        pid_t = torch.tensor(list(partition_ids), dtype=torch.int64)
+        cent = idx.parent.get(pid_t)
+        near, _ = idx._ctx.coarse(idx.parent._store, cent.cuda(idx._device), int(p.refinement_radius), idx.metric_)
+        refine = torch.unique(near.reshape(-1))
+        refine = refine[refine != -1].cpu()
+        idx.refine_partitions(refine, int(p.refinement_iterations))

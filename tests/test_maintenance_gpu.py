@@ -1,0 +1,158 @@
+"""Maintenance on the device store: split / delete / local refinement keep every vector searchable, and the dynamic
+workload harness (generator + evaluator) behaves like the reference's (test/python/test_workload_generator.py:69-114;
+test/cpp/maintenance.cpp spirit: after maintenance the index answers exactly and its bookkeeping is consistent)."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def linear_model_estimator(d, alpha=0.9):
+    from quake_amd.maintenance import ListScanLatencyEstimator, MaintenanceCostEstimator
+    lat = ListScanLatencyEstimator(d, [1, 2, 4, 16, 64, 256, 1024, 4096, 16384, 65536], [1, 4, 16, 64, 256], 1,
+                                   profile_fn=lambda n, k: 200.0 + 10.0 * n)  # ns: fixed cost + per-row cost
+    return MaintenanceCostEstimator(d, alpha, 10, latency_estimator=lat)
+
+
+def check_consistent(idx, x, ids_all, q):
+    """every resident vector is in exactly one partition, centroids and partitions agree, exhaustive search is exact"""
+    import quake_amd as quake
+    got = idx.get_ids()
+    assert sorted(got.tolist()) == sorted(ids_all.tolist())
+    assert idx.parent.ntotal() == idx.nlist()
+    assert sorted(idx.parent.get_ids().tolist()) == sorted(int(v) for v in idx._store.list_ids())
+    sp = quake.SearchParams()
+    sp.k = 10
+    sp.nprobe = idx.nlist()
+    r = idx.search(q, sp)
+    xs = x[ids_all]
+    gt = torch.topk(torch.cdist(q.double(), xs.double()), 10, dim=1, largest=False)
+    # (fp64 ground truth vs the fp32 expanded form: near-equal distances may swap places, so compare as sets)
+    want = ids_all[gt.indices].numpy()
+    for a, b in zip(r.ids.numpy(), want):
+        assert len(set(a.tolist()) & set(b.tolist())) >= 9
+    np.testing.assert_allclose(r.distances.numpy(), gt.values.float().numpy(), atol=1e-3)
+
+
+def test_policy_splits_hot_and_deletes_cold_partitions():
+    import quake_amd as quake
+    from quake_amd.maintenance import ListScanLatencyEstimator, MaintenanceCostEstimator
+    g = torch.Generator().manual_seed(5)
+    d = 16
+    # background: 60000 vectors in 40 k-means partitions (~1500 each, nobody queries them).  The hot partitions below are
+    # a little below the average size on purpose: a partition much larger than the average looks deletable to compute_delete_delta and
+    # never reaches the split test (maintenance_policies.cpp:74-126 tests split only in the else branch)
+    NB = 60000
+    x_bg = torch.randn(NB, d, generator=g)
+    idx = quake.QuakeIndex()
+    bp = quake.IndexBuildParams()
+    bp.nlist = 40
+    idx.build(x_bg, torch.arange(NB), bp)
+    # two large HOT partitions and six tiny COLD ones, far from everything else (added as whole partitions)
+    hot_c = torch.stack([torch.full((d,), 8.0), torch.full((d,), -8.0)])
+    cold_c = torch.stack([torch.cat([torch.full((1,), 60.0 + 10 * i), torch.zeros(d - 1)]) for i in range(6)])
+    vecs, vids, nxt = [], [], NB
+    for c, n in [(hot_c[0], 1200), (hot_c[1], 1200)] + [(c, 10) for c in cold_c]:
+        vecs.append((c + 0.3 * torch.randn(n, d, generator=g)).numpy())
+        vids.append(np.arange(nxt, nxt + n, dtype=np.int64))
+        nxt += n
+    cents = np.stack([v.mean(0) for v in vecs]).astype(np.float32)
+    new_pids = idx._add_partitions({"centroids": cents, "vectors": vecs, "vector_ids": vids})
+    idx._resident.update(range(NB, nxt))
+    assert new_pids == list(range(40, 48)) and idx.nlist() == 48 and idx.ntotal() == nxt
+    x = torch.cat([x_bg] + [torch.from_numpy(v) for v in vecs])
+    ids = torch.arange(nxt)
+    # cost model: 100 ns per partition + 1 ns per row -> splitting pays above ~800 rows, deleting a 10-row partition pays
+    lat = ListScanLatencyEstimator(d, [1, 2, 4, 16, 64, 256, 1024, 4096, 16384, 65536], [1, 4, 16, 64, 256], 1,
+                                   profile_fn=lambda n, k: 100.0 + 1.0 * n)
+    mp = quake.MaintenancePolicyParams()
+    mp.window_size = 200
+    mp.refinement_radius = 4
+    mp.refinement_iterations = 2
+    mp.min_partition_size = 32
+    mp.delete_threshold_ns = 0.1
+    mp.split_threshold_ns = 0.1
+    idx.initialize_maintenance_policy(mp, cost_estimator=MaintenanceCostEstimator(d, 0.9, 10, latency_estimator=lat))
+    # window not full -> nothing happens (maintenance_policies.cpp:36-41)
+    t = idx.maintenance()
+    assert t.n_splits == 0 and t.n_deletes == 0 and idx.nlist() == 48
+    idx.track_hits = True
+    sp = quake.SearchParams()
+    sp.k = 10
+    sp.nprobe = 1
+    q = torch.cat([hot_c[0] + 0.3 * torch.randn(150, d, generator=g), hot_c[1] + 0.3 * torch.randn(100, d, generator=g)])
+    idx.search(q, sp)
+    pol = idx._policy()
+    assert pol.hit_count_tracker_.get_num_queries_recorded() == 200  # 250 recorded, the window keeps 200
+    assert pol.hit_count_tracker_.get_current_scan_fraction() == pytest.approx(1200 / nxt, rel=1e-3)
+    t = idx.maintenance()
+    assert t.n_splits == 2 and t.n_deletes == 6, (t.n_splits, t.n_deletes)
+    assert idx.nlist() == 48 + 2 - 6  # split: -1 +2, delete: -1
+    live = sorted(int(v) for v in idx._store.list_ids())
+    assert all(p not in live for p in range(40, 48)) and live[-4:] == [48, 49, 50, 51]  # curr_partition_id_ keeps counting
+    assert idx.ntotal() == nxt
+    check_consistent(idx, x, ids, q[:20])
+    # the index stays dynamic afterwards
+    idx.remove(ids[:100])
+    nx = torch.randn(50, d, generator=g)
+    idx.add(nx, torch.arange(nxt, nxt + 50))
+    check_consistent(idx, torch.cat([x, nx]), torch.cat([ids[100:], torch.arange(nxt, nxt + 50)]), q[:10])
+
+
+def test_device_profiled_cost_model():
+    from quake_amd.maintenance import ListScanLatencyEstimator, MaintenanceCostEstimator, device_profile_fn
+    lat = ListScanLatencyEstimator(32, [64, 1024, 16384], [1, 16], 2, profile_fn=device_profile_fn(32, 2))
+    a, b, c = (lat.estimate_scan_latency(n, 10) for n in (64, 1024, 16384))
+    assert 0 < a and b > 0 and c > b  # scanning more rows costs more
+    est = MaintenanceCostEstimator(32, 0.9, 10, latency_estimator=lat)
+    assert np.isfinite(est.compute_split_delta(8000, 0.5, 100))
+
+
+def test_workload_generation_and_evaluation(tmp_path):  # test_workload_generator.py:28-114
+    from quake_amd.workload import DynamicWorkloadGenerator, UniformSampler, WorkloadEvaluator
+    from quake_amd.wrapper import QuakeWrapper
+    import quake_amd as quake
+    torch.manual_seed(0)
+    base = torch.randn(1000, 16)
+    queries = torch.randn(100, 16)
+    wdir = tmp_path / "workload"
+    gen = DynamicWorkloadGenerator(workload_dir=wdir, base_vectors=base, metric="l2", insert_ratio=0.3, delete_ratio=0.2,
+                                   query_ratio=0.5, update_batch_size=20, query_batch_size=10, number_of_operations=10,
+                                   initial_size=200, cluster_size=50, cluster_sample_distribution="uniform",
+                                   queries=queries, seed=1738)
+    gen.sampler = UniformSampler()
+    gen.generate_workload()
+    assert (wdir / "runbook.json").exists() and (wdir / "operations").exists()
+    rb = json.load(open(wdir / "runbook.json"))
+    assert "initialize" in rb and "operations" in rb and "parameters" in rb and "summary" in rb
+    assert len(rb["operations"]) <= 10
+    for i, op in rb["operations"].items():
+        assert op["type"] in ("insert", "delete", "query") and op["sample_size"] > 0 and op["n_resident"] > 0
+        assert (wdir / "operations" / f"{i}.pt").exists()
+        if op["type"] == "query":
+            gt = torch.load(wdir / "operations" / f"{i}_gt_ids.pt", weights_only=True)
+            assert gt.shape == (op["sample_size"], 100) and "gt_time" in op
+    s = rb["summary"]
+    assert s["n_inserts"] + s["n_deletes"] + s["n_queries"] == s["n_operations"] == len(rb["operations"])
+    # same seed -> same operation stream
+    gen2 = DynamicWorkloadGenerator(workload_dir=tmp_path / "w2", base_vectors=base, metric="l2", insert_ratio=0.3,
+                                    delete_ratio=0.2, query_ratio=0.5, update_batch_size=20, query_batch_size=10,
+                                    number_of_operations=10, initial_size=200, cluster_size=50,
+                                    cluster_sample_distribution="uniform", queries=queries, seed=1738)
+    rb2 = gen2.generate_workload()
+    assert [o["type"] for o in rb2["operations"].values()] == [o["type"] for o in rb["operations"].values()]
+
+    ev = WorkloadEvaluator(workload_dir=wdir, output_dir=wdir)
+    mp = quake.MaintenancePolicyParams()
+    mp.window_size = 20
+    res = ev.evaluate_workload(name="quake_test", index=QuakeWrapper(), build_params={"nc": 10, "metric": "l2"},
+                               search_params={"k": 5, "nprobe": 10}, do_maintenance=True, m_params=mp, batch=True)
+    assert isinstance(res, list) and len(res) == len(rb["operations"])
+    for r in res:
+        assert r["latency_ms"] >= 0 and r["n_total"] == r["n_resident"]  # the index tracks the runbook's resident set
+        if r["operation_type"] == "query":
+            assert 0.0 <= r["recall"] <= 1.0
+            assert r["recall"] >= 0.99  # nprobe = nlist: exhaustive

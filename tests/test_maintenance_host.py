@@ -1,0 +1,131 @@
+"""Host logic of the maintenance policy (quake_amd/maintenance.py) against the reference's own unit tests, restated:
+test/cpp/hit_count_tracker.cpp, test/cpp/latency_estimator.cpp, test/cpp/maintenance_cost_estimator.cpp.  No GPU: the
+latency model is injected."""
+import math
+import random
+
+import numpy as np
+import pytest
+
+from quake_amd.maintenance import HitCountTracker, ListScanLatencyEstimator, MaintenanceCostEstimator
+
+
+def test_hit_count_tracker_sliding_average():  # hit_count_tracker.cpp RandomQueriesTest / MultipleWindowCyclesTest
+    for seed, nq, pmax in ((42, 20, 5), (123, 50, 4)):
+        rng = random.Random(seed)
+        window, total = 5, 1000
+        tr = HitCountTracker(window, total)
+        fr = []
+        for q in range(nq):
+            npart = rng.randint(1, pmax)
+            ids = list(range(npart))
+            sizes = [rng.randint(0, 300) for _ in range(npart)]
+            tr.add_query_data(ids, sizes)
+            fr.append(sum(sizes) / total)
+            eff = min(q + 1, window)
+            assert tr.get_current_scan_fraction() == pytest.approx(sum(fr[-eff:]) / eff, abs=1e-5)
+        assert tr.get_num_queries_recorded() == window and tr.get_window_size() == window
+        assert len(tr.get_per_query_hits()) == window
+
+
+def test_hit_count_tracker_errors_and_reset():
+    with pytest.raises(ValueError):
+        HitCountTracker(0, 10)
+    with pytest.raises(ValueError):
+        HitCountTracker(5, 0)
+    tr = HitCountTracker(3, 100)
+    with pytest.raises(ValueError):
+        tr.add_query_data([1, 2], [10])
+    tr.add_query_data([1], [50])
+    assert tr.get_current_scan_fraction() == pytest.approx(0.5)
+    tr.reset()
+    assert tr.get_num_queries_recorded() == 0 and tr.get_current_scan_fraction() == 1.0
+    tr.set_total_vectors(200)
+    tr.add_query_data([1], [50])
+    assert tr.get_current_scan_fraction() == pytest.approx(0.25)
+    with pytest.raises(ValueError):
+        tr.set_total_vectors(0)
+
+
+def test_hit_count_tracker_batch_path_equals_per_query_path():
+    a, b = HitCountTracker(5, 1000), HitCountTracker(5, 1000)
+    rng = np.random.default_rng(0)
+    for _ in range(12):
+        Q = int(rng.integers(1, 9))  # batches larger than the window included
+        hp, sz = rng.integers(0, 10, (Q, 3)), rng.integers(0, 300, (Q, 3))
+        for r, s_ in zip(hp, sz):
+            a.add_query_data(r.tolist(), s_.tolist())
+        b.add_batch(hp, sz)
+        assert a.get_current_scan_fraction() == pytest.approx(b.get_current_scan_fraction(), abs=1e-5)
+        # same window contents (the ring position may differ when one batch wraps the window more than once)
+        assert sorted(list(map(int, x)) for x in a.get_per_query_hits()) == sorted(list(map(int, x)) for x in b.get_per_query_hits())
+        ah = {}
+        for qh in a.get_per_query_hits():
+            for p_ in qh:
+                ah[p_] = ah.get(p_, 0) + 1
+        assert ah == b.aggregated_hits()
+
+
+def plane(n, k):  # a latency surface that is exactly bilinear: interpolation and extrapolation must reproduce it
+    return 100.0 + 3.0 * n + 7.0 * k + 0.5 * n * k
+
+
+def test_latency_estimator_interpolation_extrapolation(tmp_path):  # latency_estimator.cpp BasicInterpolationExtrapolation
+    fn = str(tmp_path / "test_latency_profile.csv")
+    est = ListScanLatencyEstimator(8, [16, 32, 64], [1, 2, 4], 2, False, fn, profile_fn=plane)
+    assert (tmp_path / "test_latency_profile.csv").exists()
+    for n, k in [(16, 1), (24, 1), (32, 3), (64, 4), (48, 2), (128, 2), (40, 8), (256, 16)]:
+        assert est.estimate_scan_latency(n, k) == pytest.approx(plane(n, k), rel=1e-6)
+    assert est.estimate_scan_latency(0, 4) == 0.0 and est.estimate_scan_latency(16, 0) == 0.0
+    with pytest.raises(IndexError):
+        est.estimate_scan_latency(8, 1)
+    # a second estimator with the same grid loads the file instead of profiling
+    calls = []
+    est2 = ListScanLatencyEstimator(8, [16, 32, 64], [1, 2, 4], 2, False, fn, profile_fn=lambda n, k: calls.append(1) or 0.0)
+    assert not calls and est2.estimate_scan_latency(24, 1) == pytest.approx(plane(24, 1), rel=1e-6)
+    # a different grid does not match the file -> re-profiles
+    est3 = ListScanLatencyEstimator(8, [16, 64], [1, 4], 2, False, fn, profile_fn=lambda n, k: calls.append(1) or 5.0)
+    assert len(calls) == 4 and est3.estimate_scan_latency(16, 1) == 5.0
+    with pytest.raises(RuntimeError):
+        ListScanLatencyEstimator(8, [32, 16], [1, 2], profile_fn=plane)
+
+
+def make_estimator(alpha=0.9, k=10):
+    lat = ListScanLatencyEstimator(128, [1, 2, 4, 16, 64, 256, 1024, 4096, 16384, 65536], [1, 4, 16, 64, 256], 1,
+                                   profile_fn=lambda n, kk: 50.0 + 12.0 * n + 2.0 * kk)
+    return MaintenanceCostEstimator(128, alpha, k, latency_estimator=lat), lat
+
+
+def test_cost_estimator_split_and_delete_delta():  # maintenance_cost_estimator.cpp ComputeSplitDelta / ComputeDeleteDelta
+    est, lat = make_estimator()
+    L, k, alpha = lat.estimate_scan_latency, 10, 0.9
+    size, hr, T = 1000, 0.3, 100
+    want = (L(T + 1, k) - L(T, k)) + L(size // 2, k) * hr * (2 * alpha) - L(size, k) * hr
+    assert est.compute_split_delta(size, hr, T) == pytest.approx(want, abs=1.0)
+    avg_hr, avg_size = 0.25, size
+    cost_old = (T - 1) * avg_hr * L(avg_size, k) + hr * L(size, k)
+    merged_size = avg_size + size / (T - 1)
+    merged_hr = avg_hr + hr / (T - 1)
+    cost_new = (T - 1) * merged_hr * L(math.ceil(merged_size), k)
+    want = (L(T - 1, k) - L(T, k)) + cost_new - cost_old
+    assert est.compute_delete_delta(size, hr, T, avg_hr, avg_size) == pytest.approx(want, abs=1.0)
+    # fewer vectors than partitions: only `size` partitions grow by one (maintenance_cost_estimator.cpp:439-442)
+    small = 40
+    cost_old = (T - 1) * avg_hr * L(avg_size, k) + hr * L(small, k)
+    merged_hr = avg_hr + hr / (T - 1)
+    cost_new = small * merged_hr * L(avg_size + 1, k) + (T - small - 1) * merged_hr * L(avg_size, k)
+    want = (L(T - 1, k) - L(T, k)) + cost_new - cost_old
+    assert est.compute_delete_delta(small, hr, T, avg_hr, avg_size) == pytest.approx(want, abs=1.0)
+    assert est.compute_delete_delta(size, hr, 1, avg_hr, avg_size) == 0.0
+    # reassignment-aware form (:456-490)
+    rc, rs, rh = [600, 400], [900, 1100], [0.2, 0.1]
+    want = (L(T - 1, k) - L(T, k)) + hr * L(size, k) + sum((h + hr) * L(s + size, k) - h * L(s, k) for s, h in zip(rs, rh))
+    assert est.compute_delete_delta_w_reassign(size, hr, T, rc, rs, rh) == pytest.approx(want, abs=1.0)
+    assert est.get_k() == 10 and est.get_latency_estimator() is lat
+
+
+def test_cost_estimator_invalid_parameters():  # InvalidParametersThrow
+    with pytest.raises(ValueError):
+        MaintenanceCostEstimator(128, -0.5, 10, latency_estimator=object())
+    with pytest.raises(ValueError):
+        MaintenanceCostEstimator(128, 0.9, 0, latency_estimator=object())
