@@ -26,6 +26,8 @@
 //
 // Roofline: HBM.  Algorithmic bytes per batch = sum over unique probed partitions of n_p*d*4.
 #include "qk_internal.h"
+#include <vector>
+#include <climits>
 #include "qk_device.h"
 
 #include <algorithm>
@@ -91,6 +93,8 @@ int qk_prep_queries(qk_ctx *ctx, const float *x, int64_t Q, int d, const float4 
     return QK_OK;
 }
 
+constexpr int QK_SLOTS = 32;  // ints per pair slot line: count + 31 record ids
+
 // ---- grouping ---------------------------------------------------------------------------------------
 // everything a wave needs to start on an active partition, in one 32-byte load
 struct __align__(16) ActiveInfo {
@@ -119,6 +123,8 @@ struct GroupParams {
     int32_t *grouped_q;   // [npairs] query of each grouped entry
     int32_t *grouped_pair;// [npairs] pair index (q*P + r) of each grouped entry
     int32_t *pair_head;   // [npairs] head of the record chain of each pair (-1 = none)
+    int32_t *pair_slots;  // [npairs][32]: {record count, first 31 record ids} -- what the merge reads in ONE load; later
+                          // records of the pair go to the chain
     uint32_t *gtau;       // [Q] per-query shared bound, reset here
 };
 
@@ -132,6 +138,7 @@ __global__ void k_group_count(GroupParams G) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= G.npairs) return;
     G.pair_head[i] = -1;
+    G.pair_slots[i * QK_SLOTS] = 0;
     int p = pair_pid(G, i);
     if (p >= 0) atomicAdd(&G.g_cnt[p], 1);
 }
@@ -395,11 +402,17 @@ struct ScanParams {
     int C;  // pool capacity per query; k <= C - 4
     int metric;
     int32_t *pair_head;
+    int32_t *pair_slots;
     int32_t *rec_counter;
     int32_t max_recs;
     int2 *rec_hdr;       // [max_recs] {next record of the pair (-1 = end), entry count}
     uint32_t *rec_ord;   // [max_recs][k]
     int64_t *rec_id;     // [max_recs][k]
+    // dynamic tail (one wave per workgroup only): the last dyn_tiles_pct % of the tile sequence is handed out in chunks of
+    // dyn_chunk tiles through this counter once a wave has finished its static share (nullptr: all static)
+    unsigned long long *dyn_counter;
+    int dyn_chunk, dyn_pct;
+    long long *wave_clock;  // probe (QK_SCAN_WAVE_CLOCK): [waves][2] start / end of every wave in wall_clock64 ticks, or nullptr
 };
 
 // Compile-time experiment switches (scripts/scan_ab.sh builds one library per combination)
@@ -411,6 +424,16 @@ struct ScanParams {
 #endif
 #ifndef QK_OPT_ONE_BALLOT
 #define QK_OPT_ONE_BALLOT 1   // one ballot per tile in the steady state
+#endif
+
+#ifndef QK_DYN_PCT_DEFAULT
+// Dynamic tail.  Measured on the bench configuration (QK_SCAN_DYN_PCT / QK_SCAN_DYN_CHUNK sweeps): 20 % in 16-tile chunks
+// takes 5-12 % off k_scan at 6 or 8 waves per CU, but every chunk is a segment and leaves a record per live query, and
+// k_merge pays it back (+10 us); at 4 waves per CU the static cut is already balanced.  Off by default.
+#define QK_DYN_PCT_DEFAULT 0     // share of the tile sequence handed out dynamically (0 = static cut only)
+#endif
+#ifndef QK_DYN_CHUNK_DEFAULT
+#define QK_DYN_CHUNK_DEFAULT 16  // tiles per dynamic chunk
 #endif
 
 #ifndef QK_OPT_NT
@@ -452,9 +475,18 @@ __global__ __launch_bounds__(256) void k_scan(ScanParams P) {
     // ---- this wave's contiguous share of the global tile sequence ------------------------------------------
     const long long T = *P.n_tiles;
     const long long W = gridDim.x;
-    const long long T0 = (T * blockIdx.x) / W, T1 = (T * (blockIdx.x + 1)) / W;
-    if (T1 <= T0) return;
+    const bool dyn = P.dyn_counter != nullptr && nw == 1;
+    // static share: an equal cut of the first Ts tiles; the rest is claimed chunk by chunk by whoever finishes first
+    // (waves do not finish together: HBM channel and XCD placement make equal tile counts take unequal time)
+    const long long Ts = dyn ? T - (T * P.dyn_pct) / 100 : T;
+    long long T0 = (Ts * blockIdx.x) / W, T1 = (Ts * (blockIdx.x + 1)) / W;
+    if (!dyn && T1 <= T0) return;
+    const long long wc0 = P.wave_clock ? wall_clock64() : 0;
     const int n_active = *P.n_active;
+    int pend_rec = -1, pend_old = -1, pend_cnt = 0;  // deferred header store of this lane's previous record
+    int dbg_comp = 0, dbg_app = 0, dbg_seg = 0;       // probe counters (QK_SCAN_WAVE_CLOCK)
+    for (;;) {
+    if (T1 > T0) {
     // 64-ary search for the partition containing tile T0: active[lo].toff <= T0 < active[lo+1].toff
     int lo = 0, hi = n_active;
     while (hi - lo > 1) {
@@ -471,7 +503,6 @@ __global__ __launch_bounds__(256) void k_scan(ScanParams P) {
     }
     int ai = lo;
     long long cur = T0;
-    int pend_rec = -1, pend_old = -1, pend_cnt = 0;  // deferred header store of this lane's previous record
 
     while (cur < T1) {
         // ---- segment = tiles [tl, tend) of item (p, qt) ---------------------------------------------------------
@@ -501,6 +532,7 @@ __global__ __launch_bounds__(256) void k_scan(ScanParams P) {
         if (QK_OPT_EARLY_REC && MODE == 0 && lane == 0) base_rec = atomicAdd(P.rec_counter, nq);
         uint32_t tau = 0xFFFFFFFFu;
         int cnt = 0;
+        dbg_seg++;
         float xnj = 0.0f;
         {
             // (a wave whose share is empty still issues the static loads: keep them inside the segment)
@@ -608,8 +640,10 @@ __global__ __launch_bounds__(256) void k_scan(ScanParams P) {
                                 my_id[slot] = idv[reg];
                             }
                             cnt += __popcll(gm);
+                            dbg_app += __popcll(m);
                             uint64_t need = __ballot(cnt > C - 4) & 0xFFFFull;
                             while (need) {
+                                dbg_comp++;
                                 const int jq = __ffsll((unsigned long long)need) - 1;
                                 need &= need - 1;
                                 const int n = __builtin_amdgcn_readlane(cnt, jq);
@@ -661,6 +695,7 @@ __global__ __launch_bounds__(256) void k_scan(ScanParams P) {
                 if (nw > 1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             }
             if (!QK_OPT_EARLY_LOAD) QK_LOAD(a0, y0, i00, i01);
+            // (a third tile buffer was measured at 4 waves per CU: 0.266 -> 0.294 ms, slower)
             for (int s = 0; s < nsteps; s += 2) {
                 QK_LOAD(a1, y1, i10, i11);
                 QK_STEP(a0, y0, i00, i01, true);
@@ -695,7 +730,14 @@ __global__ __launch_bounds__(256) void k_scan(ScanParams P) {
                         // the store of the previous head is deferred to the next emit (or kernel end) so that the
                         // wave does not stall on the exchange's round trip
                         if (pend_rec >= 0) P.rec_hdr[pend_rec] = make_int2(pend_old, pend_cnt);
-                        pend_old = atomicExch(&P.pair_head[mypair], myrec);
+                        // the first 31 records of a pair are listed in its slot line (the merge fetches them together,
+                        // no pointer chase); further ones are chained through pair_head
+                        const int slot = atomicAdd(&P.pair_slots[(int64_t)mypair * QK_SLOTS], 1);
+                        pend_old = -1;
+                        if (slot < QK_SLOTS - 1)
+                            P.pair_slots[(int64_t)mypair * QK_SLOTS + 1 + slot] = myrec;
+                        else
+                            pend_old = atomicExch(&P.pair_head[mypair], myrec);
                         pend_rec = myrec;
                         pend_cnt = cnt;
                         if (!QK_OPT_EARLY_REC) {
@@ -720,13 +762,31 @@ __global__ __launch_bounds__(256) void k_scan(ScanParams P) {
             }
         }
     }
+    }  // range
+        if (!dyn) break;
+        unsigned long long c = 0;
+        if (lane == 0) c = atomicAdd(P.dyn_counter, (unsigned long long)P.dyn_chunk);
+        c = __shfl(c, 0);
+        T0 = Ts + (long long)c;
+        if (T0 >= T) break;
+        T1 = min(T, T0 + P.dyn_chunk);
+    }
     if (pend_rec >= 0) P.rec_hdr[pend_rec] = make_int2(pend_old, pend_cnt);
+    if (P.wave_clock && lane == 0) {
+        long long *wcp = P.wave_clock + 8 * ((long long)blockIdx.x * nw + wv);
+        wcp[0] = wc0;
+        wcp[1] = wall_clock64();
+        wcp[2] = dbg_comp;
+        wcp[3] = dbg_app;
+        wcp[4] = dbg_seg;
+    }
 }
 
 // ---- merge kernel: one wave per query ---------------------------------------------------------------------
 struct MergeParams {
     int P;
     const int32_t *pair_head;
+    const int32_t *pair_slots;
     const int2 *rec_hdr;
     const uint32_t *rec_ord;
     const int64_t *rec_id;
@@ -749,46 +809,88 @@ __global__ __launch_bounds__(64) void k_merge(MergeParams M) {
     uint32_t *pool_ord = (uint32_t *)(smem + (size_t)Cm * 8);
     uint32_t tau = 0xFFFFFFFFu;
     int cnt = 0;
-    for (int r = 0; r < M.P; r++) {
-        int rec = M.pair_head[q * M.P + r];
-        while (rec >= 0 && rec < M.max_recs) {
-            // header and the first 64 entries are requested together (entries beyond the count are ignored)
-            const int2 hdr = M.rec_hdr[rec];
-            uint32_t o0 = 0xFFFFFFFFu;
-            int64_t d0 = -1;
+    // one record: header + first 64 entries are requested together (entries beyond the count are ignored)
+    auto fetch = [&](int rr, int2 &h, uint32_t &o, int64_t &dd) {
+        h = make_int2(-1, 0);
+        o = 0xFFFFFFFFu;
+        dd = -1;
+        if (rr >= 0 && rr < M.max_recs) {
+            h = M.rec_hdr[rr];
             if (lane < k) {
-                o0 = M.rec_ord[(int64_t)rec * k + lane];
-                d0 = M.rec_id[(int64_t)rec * k + lane];
+                o = M.rec_ord[(int64_t)rr * k + lane];
+                dd = M.rec_id[(int64_t)rr * k + lane];
             }
-            const int n = hdr.y;
-            for (int base = 0; base < n; base += 64) {
-                const int e = base + lane;
-                const bool has = e < n;
-                uint32_t o = o0;
-                int64_t dd = d0;
-                if (base > 0) {
-                    o = has ? M.rec_ord[(int64_t)rec * k + e] : 0xFFFFFFFFu;
-                    dd = has ? M.rec_id[(int64_t)rec * k + e] : -1;
-                }
-                const bool pass = has && o <= tau;
-                const uint64_t m = __ballot(pass);
-                if (m) {
-                    if (pass) {
-                        const int sl = cnt + __popcll(m & ((1ull << lane) - 1ull));
-                        pool_ord[sl] = o;
-                        pool_id[sl] = dd;
-                    }
-                    cnt += __popcll(m);
-                    if (cnt > Cm - 64) {  // (unsorted k best + their bound; the final compaction sorts)
-                        uint32_t kth;
-                        cnt = select_pool<MAXCH>(pool_ord, pool_id, cnt, k, lane, kth);
-                        if (cnt >= k) tau = min(tau, kth);
-                    }
-                }
-                // records are sorted ascending: once a valid lane fails the bound, the rest of the record fails too
-                if (__popcll(m) < min(64, n - base)) break;
+        }
+    };
+    auto consume = [&](int rec, const int2 hdr, const uint32_t o0, const int64_t d0) {
+        const int n = hdr.y;
+        // a full record is sorted and holds k entries: its k-th key bounds the answer before anything is pooled
+        if (n >= k && k <= 64) tau = min(tau, (uint32_t)__builtin_amdgcn_readlane(o0, k - 1));
+        for (int base = 0; base < n; base += 64) {
+            const int e = base + lane;
+            const bool has = e < n;
+            uint32_t o = o0;
+            int64_t dd = d0;
+            if (base > 0) {
+                o = has ? M.rec_ord[(int64_t)rec * k + e] : 0xFFFFFFFFu;
+                dd = has ? M.rec_id[(int64_t)rec * k + e] : -1;
             }
-            rec = hdr.x;
+            const bool pass = has && o <= tau;
+            const uint64_t m = __ballot(pass);
+            if (m) {
+                if (pass) {
+                    const int sl = cnt + __popcll(m & ((1ull << lane) - 1ull));
+                    pool_ord[sl] = o;
+                    pool_id[sl] = dd;
+                }
+                cnt += __popcll(m);
+                if (cnt > Cm - 64) {  // (unsorted k best + their bound; the final compaction sorts)
+                    uint32_t kth;
+                    cnt = select_pool<MAXCH>(pool_ord, pool_id, cnt, k, lane, kth);
+                    if (cnt >= k) tau = min(tau, kth);
+                }
+            }
+            // records are sorted ascending: once a valid lane fails the bound, the rest of the record fails too
+            if (__popcll(m) < min(64, n - base)) break;
+        }
+    };
+    for (int r = 0; r < M.P; r++) {
+        const int64_t pair = q * M.P + r;
+        // slot line of the pair: lane 0 = record count, lanes 1..31 = the first records
+        const int sv = lane < QK_SLOTS ? M.pair_slots[pair * QK_SLOTS + lane] : 0;
+        const int nrecs = __builtin_amdgcn_readlane(sv, 0);
+        const int ns = min(nrecs, QK_SLOTS - 1);
+        int2 hdr, nhdr;
+        uint32_t o0, no0;
+        int64_t d0, nd0;
+        int rec;
+        for (int g0 = 0; g0 < ns; g0 += 8) {
+            // eight listed records are requested before the first of them is merged: one memory round trip per group
+            int recs[8];
+            int2 hs[8];
+            uint32_t os[8];
+            int64_t ds[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                recs[i] = g0 + i < ns ? __shfl(sv, g0 + i + 1) : -1;
+                fetch(recs[i], hs[i], os[i], ds[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+                if (recs[i] >= 0 && recs[i] < M.max_recs) consume(recs[i], hs[i], os[i], ds[i]);
+        }
+        if (nrecs > QK_SLOTS - 1) {  // overflow: chained records (header names the next one)
+            rec = M.pair_head[pair];
+            fetch(rec, hdr, o0, d0);
+            while (rec >= 0 && rec < M.max_recs) {
+                const int nrec = hdr.x;
+                fetch(nrec, nhdr, no0, nd0);
+                consume(rec, hdr, o0, d0);
+                rec = nrec;
+                hdr = nhdr;
+                o0 = no0;
+                d0 = nd0;
+            }
         }
     }
     cnt = compact_pool<MAXCH>(pool_ord, pool_id, cnt, k, lane);
@@ -984,16 +1086,18 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
     const size_t lds_merge = (size_t)Cm * 12;
 
     const int num_cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
-    // persistent grid: as many single-wave workgroups as stay resident (LDS-limited; registers allow ~12 per CU)
-    // static tile partition => every wave must be resident at once.  Measured (bench.py / scan_probe.py): 8 per CU is best
-    // for long launches; when a wave would get fewer than ~160 tiles, 6 per CU wins (fewer, longer segments: less
-    // per-segment cost, fewer records to merge) -- 5.06 -> 5.5 TB/s on the bench configuration; 10+ lose bandwidth.
+    // persistent grid: as many single-wave workgroups as stay resident (LDS-limited; registers allow ~12 per CU); the tile
+    // partition is static, so every wave must be resident at once.  Measured (bench.py --nprobe 1/8/32, QK_SCAN_WAVE_CLOCK):
+    // long launches: 8 per CU (10+ lose bandwidth).  Short launches (a wave gets < ~160 tiles): 4 per CU = one wave per
+    // SIMD.  With 6 or 8 the waves of a CU finish between 65 % and 100 % of the kernel time (those that share a SIMD are
+    // slower, and the slowest wave of a static cut sets the time); with 4 they finish within 85-100 % and every query
+    // leaves fewer, longer records: bench configuration 0.276-0.297 ms (6 per CU) -> 0.264-0.268 ms (4 per CU).
     int waves_per_cu = nw * (int)std::max<size_t>(1, std::min<size_t>(8 / nw, (160 * 1024) / (lds_scan + 512)));
     {
         const int64_t npresent_e = std::max<int64_t>(1, s->nlist);
         const int64_t mean_tiles = std::max<int64_t>(1, (s->ntotal / npresent_e + 15) / 16);
         const int64_t tiles_est = std::max<int64_t>(1, npairs / 16 + std::min<int64_t>(npresent_e, npairs)) * mean_tiles;
-        if (nw == 1 && waves_per_cu > 6 && tiles_est < (int64_t)8 * num_cus * 160) waves_per_cu = 6;
+        if (nw == 1 && waves_per_cu > 4 && tiles_est < (int64_t)8 * num_cus * 160) waves_per_cu = 4;
     }
     if (const char *e = getenv("QK_SCAN_WAVES_PER_CU")) {  // probe override, read per call so one process can sweep it
         if (atoi(e) > 0) waves_per_cu = std::max(nw, atoi(e) / nw * nw);
@@ -1008,7 +1112,18 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
     const int64_t npresent = std::max<int64_t>(1, s->nlist);
     const int64_t items_bound = std::max<int64_t>(1, npairs / 16 + std::min<int64_t>(npresent, npairs));
     // (with nw waves per workgroup every segment is cut nw ways: nw records per pair and segment)
-    const int64_t max_recs = std::min<int64_t>(0x7FFFFFF0LL, nw * std::min<int64_t>(16 * (items_bound + n_wgs), npairs + 16 * n_wgs));
+    // ... plus one segment start per dynamic chunk (k_scan's dynamic tail, nw == 1)
+    int64_t dyn_ranges = 0;
+    {
+        const int pct = getenv("QK_SCAN_DYN_PCT") ? atoi(getenv("QK_SCAN_DYN_PCT")) : QK_DYN_PCT_DEFAULT;
+        const int chunk = std::max(1, getenv("QK_SCAN_DYN_CHUNK") ? atoi(getenv("QK_SCAN_DYN_CHUNK")) : QK_DYN_CHUNK_DEFAULT);
+        if (nw == 1 && pct > 0) {
+            const int64_t tiles_all = items_bound * ((std::max<int64_t>(1, s->max_size) + 15) / 16);
+            dyn_ranges = (tiles_all * std::min(90, pct) / 100) / chunk + 2;
+        }
+    }
+    const int64_t seg_starts = n_wgs + dyn_ranges;
+    const int64_t max_recs = std::min<int64_t>(0x7FFFFFF0LL, nw * std::min<int64_t>(16 * (items_bound + seg_starts), npairs + 16 * seg_starts));
 
     // ---- workspace ---------------------------------------------------------------------------------
     const int64_t np1 = std::max<int64_t>(npairs, 1);
@@ -1018,6 +1133,7 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
     add((size_t)(npids + 1) * sizeof(ActiveInfo) + 64);
     add((size_t)(npids + 1) * 4 + 64);
     add((size_t)np1 * 4 * 3);
+    add((size_t)np1 * QK_SLOTS * 4);
     add((size_t)Q * 4);
     add((size_t)max_recs * 8);
     add((size_t)max_recs * k * 4);
@@ -1041,11 +1157,12 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
     int32_t *grouped_q = (int32_t *)qk_ws_alloc(ctx, (size_t)np1 * 4 * 3);
     int32_t *grouped_pair = grouped_q + np1;
     int32_t *pair_head = grouped_pair + np1;
+    int32_t *pair_slots = (int32_t *)qk_ws_alloc(ctx, (size_t)np1 * QK_SLOTS * 4);
     uint32_t *gtau = (uint32_t *)(scal + 64);
     int2 *rec_hdr = (int2 *)qk_ws_alloc(ctx, (size_t)max_recs * 8);
     uint32_t *rec_ord = (uint32_t *)qk_ws_alloc(ctx, (size_t)max_recs * k * 4);
     int64_t *rec_id = (int64_t *)qk_ws_alloc(ctx, (size_t)max_recs * k * 8);
-    if (!g_cnt || !active || !g_qoff || !grouped_q || !gtau || !rec_hdr || !rec_ord || !rec_id)
+    if (!g_cnt || !active || !g_qoff || !grouped_q || !pair_slots || !gtau || !rec_hdr || !rec_ord || !rec_id)
         QK_FAIL(QK_ERR_OOM, "qk_scan: workspace exhausted");
 
     QK_TRY(pe.mark(0));
@@ -1068,6 +1185,7 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
     G.grouped_q = grouped_q;
     G.grouped_pair = grouped_pair;
     G.pair_head = pair_head;
+    G.pair_slots = pair_slots;
     G.gtau = gtau;
     static const int no_seed = getenv("QK_NO_SEED") ? atoi(getenv("QK_NO_SEED")) : 0;
     // (measured: for k > 64 a sample bound is far looser than the bound the pools reach by themselves -- no gain, and
@@ -1144,6 +1262,7 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
         sp.C = C;
         sp.metric = a.metric;
         sp.pair_head = pair_head;
+        sp.pair_slots = pair_slots;
         sp.rec_counter = rec_counter;
         sp.max_recs = (int32_t)max_recs;
         sp.rec_hdr = rec_hdr;
@@ -1159,14 +1278,61 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
         size_t lds_launch = lds_scan;
         if (wgs_per_cu == 4 || wgs_per_cu == 6 || wgs_per_cu == 8 || (nw > 1 && wgs_per_cu <= 2))
             lds_launch = std::max<size_t>(lds_scan, (size_t)(160 * 1024) / wgs_per_cu - 512);
+        // dynamic tail: measured wave end times spread over 65-100 % of the kernel with a purely static cut
+        static const int dyn_pct = getenv("QK_SCAN_DYN_PCT") ? atoi(getenv("QK_SCAN_DYN_PCT")) : QK_DYN_PCT_DEFAULT;
+        static const int dyn_chunk = getenv("QK_SCAN_DYN_CHUNK") ? atoi(getenv("QK_SCAN_DYN_CHUNK")) : QK_DYN_CHUNK_DEFAULT;
+        sp.dyn_counter = (nw == 1 && dyn_pct > 0) ? (unsigned long long *)(scal + 16) : nullptr;  // zeroed with the counters
+        sp.dyn_chunk = std::max(1, dyn_chunk);
+        sp.dyn_pct = std::min(90, std::max(0, dyn_pct));
+        static const bool probe_clock = getenv("QK_SCAN_WAVE_CLOCK") != nullptr;
+        static long long *d_clock = nullptr;
+        sp.wave_clock = nullptr;
+        if (probe_clock) {
+            if (!d_clock) QK_HIP(hipMalloc((void **)&d_clock, (size_t)1 << 20));
+            QK_HIP(hipMemsetAsync(d_clock, 0, (size_t)grid * nw * 64, st));
+            sp.wave_clock = d_clock;
+        }
         QK_TRY(launch_scan(DB, maxch, dim3((unsigned)grid), dim3(64 * nw), lds_launch, st, sp));
-    }
+        if (probe_clock) {  // debug probe: distribution of the waves' busy time (tail = what a dynamic split could recover)
+            std::vector<long long> h((size_t)grid * nw * 8);
+            QK_HIP(hipMemcpyAsync(h.data(), d_clock, h.size() * 8, hipMemcpyDeviceToHost, st));
+            QK_HIP(hipStreamSynchronize(st));
+            long long t0 = LLONG_MAX, t1 = 0;
+            const size_t nwv = h.size() / 8;
+            for (size_t i = 0; i < nwv; i++) {
+                if (h[8 * i + 1] == 0) continue;
+                t0 = std::min(t0, h[8 * i]);
+                t1 = std::max(t1, h[8 * i + 1]);
+            }
+            struct W { long long end, comp, app, seg; };
+            std::vector<W> ws;
+            double sum = 0;
+            for (size_t i = 0; i < nwv; i++) {
+                if (h[8 * i + 1] == 0) continue;
+                ws.push_back({h[8 * i + 1] - t0, h[8 * i + 2], h[8 * i + 3], h[8 * i + 4]});
+                sum += (double)(h[8 * i + 1] - t0);
+            }
+            std::sort(ws.begin(), ws.end(), [](const W &a, const W &b) { return a.end < b.end; });
+            if (!ws.empty()) {
+                const size_t n = ws.size();
+                fprintf(stderr, "[k_scan waves] n=%zu span=%lld ticks  end-time pct: p10=%lld p50=%lld p90=%lld p99=%lld max=%lld mean=%.0f (100 MHz ticks)\n",
+                        n, t1 - t0, ws[n / 10].end, ws[n / 2].end, ws[n * 9 / 10].end, ws[n * 99 / 100].end, ws.back().end, sum / n);
+                for (int dec = 0; dec < 10; dec++) {  // per decile of end time: mean compactions / appends / segment starts
+                    double c = 0, a_ = 0, sg = 0, e = 0;
+                    size_t lo = n * dec / 10, hi = n * (dec + 1) / 10;
+                    for (size_t i = lo; i < hi; i++) { c += ws[i].comp; a_ += ws[i].app; sg += ws[i].seg; e += ws[i].end; }
+                    const double m = (double)std::max<size_t>(1, hi - lo);
+                    fprintf(stderr, "   decile %d: end=%.0f compactions=%.1f appends=%.0f segments=%.2f\n", dec, e / m, c / m, a_ / m, sg / m);
+                }
+            }
+        }    }
     QK_TRY(pe.mark(2));
 
     // ---- merge ---------------------------------------------------------------------------------------------------
     MergeParams mp;
     mp.P = a.per_pair ? 1 : P;  // per_pair: every (query, list) pair is merged on its own
     mp.pair_head = pair_head;
+    mp.pair_slots = pair_slots;
     mp.rec_hdr = rec_hdr;
     mp.rec_ord = rec_ord;
     mp.rec_id = rec_id;

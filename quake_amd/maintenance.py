@@ -381,6 +381,10 @@ class MaintenancePolicy:
             elif size > p.min_partition_size:
                 if ce.compute_split_delta(size, hit_rate, total_partitions) < -p.split_threshold_ns:
                     to_split.append(pid)
+        if len(to_delete) >= total_partitions:
+            # (safety, not in the reference: a model that wants every partition gone would leave the vectors nowhere to
+            #  go -- the largest partition survives)
+            to_delete.remove(max(to_delete, key=lambda q_: sizes[q_]))
         t0 = time.perf_counter()
         if to_delete:
             idx._delete_partitions(to_delete, reassign=True)

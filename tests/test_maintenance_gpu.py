@@ -106,7 +106,7 @@ def test_device_profiled_cost_model():
     from quake_amd.maintenance import ListScanLatencyEstimator, MaintenanceCostEstimator, device_profile_fn
     lat = ListScanLatencyEstimator(32, [64, 1024, 16384], [1, 16], 2, profile_fn=device_profile_fn(32, 2))
     a, b, c = (lat.estimate_scan_latency(n, 10) for n in (64, 1024, 16384))
-    assert 0 < a and b > 0 and c > b  # scanning more rows costs more
+    assert a > 0 and b > 0 and c > 2 * a  # 256x more rows per pair cost clearly more (timing: keep the margin wide)
     est = MaintenanceCostEstimator(32, 0.9, 10, latency_estimator=lat)
     assert np.isfinite(est.compute_split_delta(8000, 0.5, 100))
 
