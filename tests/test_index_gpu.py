@@ -262,3 +262,70 @@ def test_recall_vs_recall_target(quake):  # search_recall_tests.cpp:284-309 Reca
     sp.recall_target = -1.0
     rn = idx.search(q, sp)
     np.testing.assert_array_equal(rb.ids.numpy(), rn.ids.numpy())
+
+
+def test_repeated_build_search(quake):  # quake_index.cpp:322-362 RepeatedBuildSearchTest
+    g = torch.Generator().manual_seed(41)
+    x = torch.randn(10000, 32, generator=g)
+    ids = torch.arange(1000, 11000)
+    q = torch.randn(100, 32, generator=g)
+    first = None
+    for _ in range(5):
+        idx = quake.QuakeIndex()
+        p = quake.IndexBuildParams()
+        p.nlist, p.metric, p.niter = 16, "l2", 3
+        idx.build(x, ids, p)
+        sp = quake.SearchParams()
+        sp.k, sp.nprobe = 10, 4
+        r = idx.search(q, sp)
+        assert tuple(r.ids.shape) == (100, 10)
+        if first is None:
+            first = r.ids.clone()
+        else:
+            assert torch.equal(first, r.ids)  # same data, same seed: the build is deterministic
+        del idx
+
+
+def test_rapid_add_remove_add(quake):  # quake_index.cpp:400-443 RapidAddRemoveAddTest
+    g = torch.Generator().manual_seed(42)
+    idx = quake.QuakeIndex()
+    p = quake.IndexBuildParams()
+    p.nlist = 2
+    idx.build(torch.randn(1000, 16, generator=g), torch.arange(1000), p)
+    for i in range(1, 10):
+        av = torch.randn(1000, 16, generator=g)
+        ai = torch.arange(i * 1000, (i + 1) * 1000)
+        assert idx.add(av, ai).n_vectors == 1000
+        assert idx.remove(ai[:500]).n_vectors == 500
+        assert idx.add(av[:500], ai[:500]).n_vectors == 500
+        sp = quake.SearchParams()
+        sp.k = 2
+        r = idx.search(torch.randn(5, 16, generator=g), sp)
+        assert tuple(r.ids.shape) == (5, 2)
+    assert idx.ntotal() == 10000
+    # every vector is where its id says (exact self-search over both partitions)
+    sp = quake.SearchParams()
+    sp.k, sp.nprobe = 1, 2
+    r = idx.search(av[:50], sp)
+    assert torch.equal(r.ids.reshape(-1), ai[:50])
+
+
+def test_search_add_remove_maintenance_loop(quake):  # quake_index.cpp:482-529 SearchAddRemoveMaintenanceTest
+    g = torch.Generator().manual_seed(43)
+    n = 100000
+    idx = quake.QuakeIndex()
+    p = quake.IndexBuildParams()
+    p.nlist, p.metric, p.niter = 100, "l2", 3
+    idx.build(torch.randn(n, 16, generator=g), torch.arange(n), p)
+    for i in range(30):
+        q = torch.randn(100, 16, generator=g) * 0.1
+        sp = quake.SearchParams()
+        sp.nprobe, sp.k = 1, 5
+        r = idx.search(q, sp)
+        assert tuple(r.ids.shape) == (100, 5)
+        ai = torch.arange(i * 10 + n, i * 10 + n + 10)
+        assert idx.add(torch.randn(10, 16, generator=g), ai).n_vectors == 10
+        assert idx.remove(ai[:5]).n_vectors == 5
+        t = idx.maintenance()  # hits are not tracked by default: the window never fills (maintenance_policies.cpp:36-41)
+        assert t.n_splits == 0 and t.n_deletes == 0
+    assert idx.ntotal() == n + 30 * 5
