@@ -122,6 +122,7 @@ struct GroupParams {
     int64_t *n_rows_unique;  // [1] sum of sizes of active partitions (algorithmic bytes / (d*4))
     int32_t *grouped_q;   // [npairs] query of each grouped entry
     int32_t *grouped_pair;// [npairs] pair index (q*P + r) of each grouped entry
+    int qgroup;           // query tiles that share one pass over a partition (k_scan's query-sharing workgroups), >= 1
     int32_t *pair_head;   // [npairs] head of the record chain of each pair (-1 = none)
     int32_t *pair_slots;  // [npairs][32]: {record count, first 31 record ids} -- what the merge reads in ONE load; later
                           // records of the pair go to the chain
@@ -168,6 +169,17 @@ __device__ __forceinline__ T block_exscan_1024(T v, T *s_wave /*[16]*/, T *total
     return wpre + inc - v;
 }
 
+// length of a partition in the work sequence.  G = 1: (query tiles) x (row tiles).  G > 1 (query-sharing workgroups): a pass
+// over the row tiles serves up to G query tiles; a pass with q' = 1, 2 or 4 (rounded up) query tiles keeps q' of the G waves
+// busy per tile cut, so it weighs q' units per row tile -- the sequence is measured in workgroup time, which is what the
+// static cut has to balance.
+__device__ __forceinline__ long long seq_weight(int cnt_q, int size_p, int G) {
+    const int nqt = (cnt_q + 15) >> 4, ntl = (size_p + 15) >> 4;
+    const int nfull = nqt / G, rem = nqt % G;
+    const int rp = rem == 0 ? 0 : rem <= 1 ? 1 : rem <= 2 ? 2 : 4;
+    return (long long)ntl * ((long long)nfull * G + rp);
+}
+
 // single workgroup of 1024 threads: exclusive scans over the partitions.  Also clears the per-call counters.
 __global__ __launch_bounds__(1024) void k_group_scan(GroupParams G) {
     __shared__ long long s_w[48];
@@ -182,7 +194,7 @@ __global__ __launch_bounds__(1024) void k_group_scan(GroupParams G) {
             int sz = G.pt_size[p];
             sq += c;
             sa += 1;
-            stl += (long long)((c + 15) >> 4) * ((sz + 15) >> 4);
+            stl += seq_weight(c, sz, G.qgroup);
             sr += sz;
         }
     }
@@ -259,7 +271,7 @@ __global__ __launch_bounds__(1024) void k_group_scan(GroupParams G) {
             G.active[aa] = inf;
             aq += c;
             aa += 1;
-            at += (long long)((c + 15) >> 4) * ((G.pt_size[p] + 15) >> 4);
+            at += seq_weight(c, G.pt_size[p], G.qgroup);
         }
     }
 }
@@ -412,6 +424,10 @@ struct ScanParams {
     // dyn_chunk tiles through this counter once a wave has finished its static share (nullptr: all static)
     unsigned long long *dyn_counter;
     int dyn_chunk, dyn_pct;
+    // query-sharing workgroups (narrow rows, many queries per partition): the nw waves of a workgroup walk the SAME tiles
+    // of a partition at the same time, each with its own 16-query tile and pools in LDS, so that a partition probed by up
+    // to 16*nw queries is fetched from HBM once (the later waves hit in L2).  0: waves split the tiles instead.
+    int qshare;
     long long *wave_clock;  // probe (QK_SCAN_WAVE_CLOCK): [waves][2] start / end of every wave in wall_clock64 ticks, or nullptr
 };
 
@@ -452,7 +468,9 @@ __device__ __forceinline__ float4 qk_ld_stream(const float4 *p) {
 #endif
 }
 
-// MODE 0 = product; 1 = skip the top-k epilogue; 2 = loads only (probe variants for bandwidth attribution, QK_SCAN_MODE)
+// MODE 0 = product; 1 = skip the top-k epilogue; 2 = loads only (probe variants for bandwidth attribution, QK_SCAN_MODE);
+// 3 = product with query-sharing workgroups (ScanParams::qshare) -- a compile-time variant: the extra branches cost the
+// plain path 8 % when they were decided at run time
 template <int DB, int MAXCH, int MODE = 0>
 __global__ __launch_bounds__(256) void k_scan(ScanParams P) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -464,8 +482,12 @@ __global__ __launch_bounds__(256) void k_scan(ScanParams P) {
     const int j = lane & 15, g = lane >> 4;
     const int nblk = P.nblk, C = P.C, k = P.k;
     const bool l2 = P.metric == QK_METRIC_L2;
-    float4 *qs = (float4 *)smem;                                               // [nblk*64], shared by the workgroup
-    unsigned char *pool_base = smem + (size_t)nblk * 1024 + (size_t)wv * 16 * C * 12;
+    constexpr bool qshare = MODE == 3;
+    constexpr bool PRODUCT = MODE == 0 || MODE == 3;
+    const size_t per_wave = (size_t)nblk * 1024 + (size_t)16 * C * 12;  // qshare: every wave owns a query tile + pools
+    float4 *qs = (float4 *)(smem + (qshare ? wv * per_wave : 0));             // [nblk*64] (shared by the workgroup unless qshare)
+    unsigned char *pool_base = qshare ? smem + wv * per_wave + (size_t)nblk * 1024
+                                      : smem + (size_t)nblk * 1024 + (size_t)wv * 16 * C * 12;
     int64_t *pool_id = (int64_t *)pool_base;                                   // [16][C]
     uint32_t *pool_ord = (uint32_t *)(pool_base + (size_t)16 * C * 8);         // [16][C]
     uint32_t *my_ord = pool_ord + j * C;
@@ -513,23 +535,59 @@ __global__ __launch_bounds__(256) void k_scan(ScanParams P) {
         const int ntl = (size_p + 15) >> 4;
         const int cnt_p = inf.cnt;
         const int nqt = (cnt_p + 15) >> 4;
+        const int G = qshare ? nw : 1;           // query tiles per pass over the partition
+        const int ngrp = (nqt + G - 1) / G;      // passes (items) of this partition
         const long long local = cur - base;
-        const int qt = (int)(local / ntl);
-        const int tl_wg = (int)(local - (long long)qt * ntl);
-        const int tend_wg = (int)min((long long)ntl, (long long)tl_wg + (T1 - cur));
-        cur += tend_wg - tl_wg;
-        // this wave's contiguous share of the segment (the whole of it when nw == 1)
-        const int tl = tl_wg + (int)(((long long)(tend_wg - tl_wg) * wv) / nw);
-        const int tend = tl_wg + (int)(((long long)(tend_wg - tl_wg) * (wv + 1)) / nw);
-        if (qt == nqt - 1 && tend_wg == ntl) ai++;  // item sequence of this partition exhausted
-        const int nq = min(16, cnt_p - 16 * qt);
+        // position inside the partition's weighted sequence (seq_weight): full passes weigh G units per row tile, the last
+        // pass q' = 1, 2 or 4; a row tile belongs to the range that holds its first unit
+        const int nfull = nqt / G;
+        const long long wfull = (long long)ntl * G;
+        int grp, wq;
+        long long off;
+        if (local < nfull * wfull) {
+            grp = (int)(local / wfull);
+            off = local - grp * wfull;
+            wq = G;
+        } else {
+            grp = nfull;
+            off = local - nfull * wfull;
+            const int rem = nqt - nfull * G;
+            wq = rem <= 1 ? 1 : rem <= 2 ? 2 : 4;
+        }
+        const long long off_end = min((long long)ntl * wq, off + (T1 - cur));
+        const int tl_wg = (int)((off + wq - 1) / wq);
+        const int tend_wg = (int)((off_end + wq - 1) / wq);
+        cur += off_end - off;
+        if (tend_wg <= tl_wg) {  // a range boundary inside one row tile's units: nothing starts here
+            if (grp == ngrp - 1 && off_end == (long long)ntl * wq) ai++;
+            continue;
+        }
+        // this wave's query tile and its contiguous share of the segment's tiles:
+        //   split mode (wide rows) / nw == 1: one query tile, the tiles are cut nw ways;
+        //   qshare: the nq_g query tiles of the pass go to waves 0..nq_g-1 (rounded up to a power of two); when the pass
+        //   has fewer query tiles than waves, the spare waves take a second / third / fourth cut of the tiles
+        int qt = grp, part = wv, parts = nw;
+        bool idle = false;
+        if (qshare) {
+            const int nq_g = min(G, nqt - grp * G);
+            const int nq_p = nq_g <= 1 ? 1 : nq_g <= 2 ? 2 : 4;
+            parts = max(1, nw / nq_p);
+            const int ql = wv % nq_p;
+            part = wv / nq_p;
+            idle = ql >= nq_g || part >= parts;
+            qt = grp * G + min(ql, nq_g - 1);
+        }
+        const int tl = idle ? tend_wg : tl_wg + (int)(((long long)(tend_wg - tl_wg) * part) / parts);
+        const int tend = idle ? tend_wg : tl_wg + (int)(((long long)(tend_wg - tl_wg) * (part + 1)) / parts);
+        if (grp == ngrp - 1 && off_end == (long long)ntl * wq) ai++;  // item sequence of this partition exhausted
+        const int nq = idle ? 0 : min(16, cnt_p - 16 * qt);
         const int gidx = inf.qoff + 16 * qt + j;
         // grouped entry of this lane's query + record slots for the segment: issued FIRST so that they return first
         // (loads complete in order); the first tile's loads go out right behind them and fly under the query staging
         const int myq = (j < nq) ? P.grouped_q[gidx] : -1;
         const int mypair = (j < nq) ? P.grouped_pair[gidx] : -1;
         int base_rec = 0;
-        if (QK_OPT_EARLY_REC && MODE == 0 && lane == 0) base_rec = atomicAdd(P.rec_counter, nq);
+        if (QK_OPT_EARLY_REC && PRODUCT && lane == 0) base_rec = atomicAdd(P.rec_counter, nq);
         uint32_t tau = 0xFFFFFFFFu;
         int cnt = 0;
         dbg_seg++;
@@ -561,8 +619,12 @@ __global__ __launch_bounds__(256) void k_scan(ScanParams P) {
 #define QK_LOAD(A, Y, I0, I1)                                         \
     {                                                                 \
         const float4 *pp_ = src + (int64_t)lS * (DB * 64);            \
-        _Pragma("unroll") for (int b_ = 0; b_ < DB; b_++)             \
-            A[b_] = qk_ld_stream(pp_ + b_ * 64);                      \
+        if (qshare) { /* the other waves of the workgroup read the same tile: keep it cacheable */ \
+            _Pragma("unroll") for (int b_ = 0; b_ < DB; b_++) A[b_] = pp_[b_ * 64];      \
+        } else {                                                      \
+            _Pragma("unroll") for (int b_ = 0; b_ < DB; b_++)         \
+                A[b_] = qk_ld_stream(pp_ + b_ * 64);                  \
+        }                                                             \
         Y = nsrc[(int64_t)ltile * 4];                                 \
         I0 = isrc[(int64_t)ltile * 8];                                \
         I1 = isrc[(int64_t)ltile * 8 + 1];                            \
@@ -594,7 +656,7 @@ __global__ __launch_bounds__(256) void k_scan(ScanParams P) {
         }                                                                                                  \
         if (++dch == ncd) {                                                                                \
             dch = 0;                                                                                       \
-            if (MODE == 0) {                                                                               \
+            if (PRODUCT) {                                                                                 \
                 epilogue(tile, LIVE, Y, I0, I1);                                                           \
             } else {                                                                                       \
                 probe_sink += acc[0] + acc[1] + acc[2] + acc[3] + Y.x + (float)I0.x + (float)I1.x;         \
@@ -677,8 +739,9 @@ __global__ __launch_bounds__(256) void k_scan(ScanParams P) {
                 if (P.gtau) tau = ~__hip_atomic_load(&P.gtau[qsafe], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (l2) xnj = P.xn[qsafe];
                 // LDS only (no vmcnt wait: the first tile stays in flight): every wave has left the previous tile
-                if (nw > 1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-                for (int cb0 = wv * DB; cb0 < nblk; cb0 += nw * DB) {
+                const bool coop = nw > 1 && !qshare;  // split mode: one query tile staged by all waves, fenced by barriers
+                if (coop) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                for (int cb0 = coop ? wv * DB : 0; cb0 < nblk; cb0 += coop ? nw * DB : DB) {
                     float4 qv[DB];
 #pragma unroll
                     for (int b = 0; b < DB; b++) qv[b] = qsrc[(cb0 + b) * 4];
@@ -692,7 +755,7 @@ __global__ __launch_bounds__(256) void k_scan(ScanParams P) {
                     tau = 0xFFFFFFFFu;
                     xnj = 0.0f;
                 }
-                if (nw > 1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                if (coop) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             }
             if (!QK_OPT_EARLY_LOAD) QK_LOAD(a0, y0, i00, i01);
             // (a third tile buffer was measured at 4 waves per CU: 0.266 -> 0.294 ms, slower)
@@ -706,7 +769,7 @@ __global__ __launch_bounds__(256) void k_scan(ScanParams P) {
             }
 #undef QK_LOAD
 #undef QK_STEP
-            if (MODE != 0 && probe_sink == 12345.678f) my_ord[0] = 1;  // keep the probe's loads alive
+            if (!PRODUCT && probe_sink == 12345.678f) my_ord[0] = 1;  // keep the probe's loads alive
         }
         // ---- segment end: final compaction (sorts, caps at k), publish bound, emit records ---------------------------
         {
@@ -999,7 +1062,23 @@ static int launch_scan_t(dim3 grid, dim3 block, size_t lds, hipStream_t st, cons
     return QK_OK;
 }
 
+template <int DB, int MAXCH>
+static int launch_scan_qs(dim3 grid, dim3 block, size_t lds, hipStream_t st, const ScanParams &sp) {
+    QK_HIP(hipFuncSetAttribute((const void *)k_scan<DB, MAXCH, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_scan<DB, MAXCH, 3>), grid, block, lds, st, sp);
+    return QK_OK;
+}
+// the (DB, MAXCH) combinations the query-sharing variant is compiled for (narrow rows, k <= 100)
+static bool have_scan_qs(int db, int maxch) { return (db == 8 || db == 4 || db == 2) && (maxch == 1 || maxch == 2 || maxch == 4); }
+
 static int launch_scan(int db, int maxch, dim3 grid, dim3 block, size_t lds, hipStream_t st, const ScanParams &sp) {
+    if (sp.qshare) {
+#define QK_CASEQ(D, M) \
+    if (db == D && maxch == M) return launch_scan_qs<D, M>(grid, block, lds, st, sp);
+        QK_CASEQ(2, 1) QK_CASEQ(2, 2) QK_CASEQ(2, 4) QK_CASEQ(4, 1) QK_CASEQ(4, 2) QK_CASEQ(4, 4) QK_CASEQ(8, 1) QK_CASEQ(8, 2) QK_CASEQ(8, 4)
+#undef QK_CASEQ
+        QK_FAIL(QK_ERR_UNSUPPORTED, "no query-sharing scan kernel for DB=%d MAXCH=%d", db, maxch);
+    }
     static const int probe_mode = getenv("QK_SCAN_MODE") ? atoi(getenv("QK_SCAN_MODE")) : 0;
     if (probe_mode == 1 && db == 8 && maxch == 1) {
         QK_HIP(hipFuncSetAttribute((const void *)k_scan<8, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1079,8 +1158,26 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
             if ((w == 1 || w == 2 || w == 4) && waves_for(w, C) > 0) nw = w;
         }
     }
+    // query-sharing workgroups: narrow rows and many queries per probed partition (a partition is otherwise streamed once
+    // per 16-query tile).  The host only knows the average (pairs per present list); a batch whose queries cluster on few
+    // partitions is hotter than that, so the threshold is low.
+    int qshare = 0;
+    {
+        // measured (bench.py --nprobe 8 / 32, 1024 queries, 4096 lists): 0.589 -> 0.551 ms and 1.394 -> 1.109 ms
+        static const int qs_min = getenv("QK_SCAN_QSHARE_MIN") ? atoi(getenv("QK_SCAN_QSHARE_MIN")) : 2;
+        const int64_t present = std::max<int64_t>(1, std::min<int64_t>(s->nlist, std::max<int64_t>(npairs, 1)));
+        const int64_t per_list = npairs / present;
+        const size_t per_wave = q_bytes + (size_t)16 * C * 12;
+        if (nw == 1 && !a.per_pair && qs_min > 0 && per_list >= qs_min && have_scan_qs(DB, pick_maxch(C))) {
+            const int w = 4 * per_wave + 512 <= 160 * 1024 ? 4 : 2 * per_wave + 512 <= 160 * 1024 ? 2 : 1;
+            if (w > 1) {
+                nw = w;
+                qshare = 1;
+            }
+        }
+    }
     const int maxch = pick_maxch(C);
-    const size_t lds_scan = q_bytes + (size_t)nw * 16 * C * 12;
+    const size_t lds_scan = qshare ? (size_t)nw * (q_bytes + (size_t)16 * C * 12) : q_bytes + (size_t)nw * 16 * C * 12;
     const int Cm = qk_round_up(k + 64, 64);
     const int maxch_m = Cm <= 128 ? 2 : Cm <= 256 ? 4 : Cm <= 512 ? 8 : 16;
     const size_t lds_merge = (size_t)Cm * 12;
@@ -1104,7 +1201,7 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
     }
     // wide rows (d >= 256: the LDS query tile leaves room for <= 4 waves per CU): 16 blocks = 16 KB per load step, so
     // that the few resident waves still keep enough bytes in flight to cover the HBM latency
-    if (nblk % 16 == 0 && waves_per_cu <= 4 && !getenv("QK_SCAN_NO_DB16")) DB = 16;
+    if (nblk % 16 == 0 && waves_per_cu <= 4 && !qshare && !getenv("QK_SCAN_NO_DB16")) DB = 16;
     const int wgs_per_cu = waves_per_cu / nw;
     const int64_t n_wgs = (int64_t)num_cus * wgs_per_cu;
     const int64_t n_waves = n_wgs * nw;
@@ -1185,6 +1282,7 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
     G.grouped_q = grouped_q;
     G.grouped_pair = grouped_pair;
     G.pair_head = pair_head;
+    G.qgroup = qshare ? nw : 1;
     G.pair_slots = pair_slots;
     G.gtau = gtau;
     static const int no_seed = getenv("QK_NO_SEED") ? atoi(getenv("QK_NO_SEED")) : 0;
@@ -1262,6 +1360,7 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
         sp.C = C;
         sp.metric = a.metric;
         sp.pair_head = pair_head;
+        sp.qshare = qshare;
         sp.pair_slots = pair_slots;
         sp.rec_counter = rec_counter;
         sp.max_recs = (int32_t)max_recs;
