@@ -1169,7 +1169,11 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
         const int64_t per_list = npairs / present;
         const size_t per_wave = q_bytes + (size_t)16 * C * 12;
         if (nw == 1 && !a.per_pair && qs_min > 0 && per_list >= qs_min && have_scan_qs(DB, pick_maxch(C))) {
-            const int w = 4 * per_wave + 512 <= 160 * 1024 ? 4 : 2 * per_wave + 512 <= 160 * 1024 ? 2 : 1;
+            // 2 waves per workgroup for moderately hot batches, 4 from ~6 queries per list on (measured: nprobe 8 -> 0.524 vs
+            // 0.534 ms with 2 vs 4; nprobe 32 -> 1.199 vs 1.073 ms)
+            static const int w_env = getenv("QK_SCAN_QSHARE_NW") ? atoi(getenv("QK_SCAN_QSHARE_NW")) : 0;
+            const int w_want = w_env ? w_env : (per_list >= 6 ? 4 : 2);
+            const int w = (w_want >= 4 && 4 * per_wave + 512 <= 160 * 1024) ? 4 : 2 * per_wave + 512 <= 160 * 1024 ? 2 : 1;
             if (w > 1) {
                 nw = w;
                 qshare = 1;
