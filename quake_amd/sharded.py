@@ -59,6 +59,16 @@ class GpuEngine:
     def merge(self, ids, keys):
         return self.ctx.merge_topk(ids, keys, self.metric)
 
+    def assign(self, x):
+        """nearest list (global number) of every vector: the k = 1 parent search of PartitionManager::add"""
+        return self.ctx.coarse(self.parent, x, 1, self.metric)[0].reshape(-1)
+
+    def add_local(self, ids, x, assign):
+        self.store.add_batch(ids, x, assign)
+
+    def remove_local(self, ids):
+        return self.store.remove_ids(ids)
+
 
 class ShardedIndex:
     """search() = sharded coarse + all-gather(pids) + local scan + all-gather(top-k) + merge.
@@ -128,3 +138,28 @@ class ShardedIndex:
         g_ids = self._gather("_g_ids", ids, torch.int64)
         g_keys = self._gather("_g_keys", keys, torch.float32)
         return self.engine.merge(g_ids, g_keys)
+
+    # -- dynamic updates (partition_manager.cpp:123-320), sharded: the batch is known to every rank (like the queries), each
+    # rank applies the part that concerns the lists it owns; no collective is needed.  Maintenance (split / delete) changes
+    # the replicated centroids and is not sharded here.
+    def add(self, x, ids, lists_per_rank=None):
+        """x [n, d], ids [n] on every rank.  Returns the number of vectors this rank stored."""
+        import torch
+        assign = self.engine.assign(x)
+        a = assign.cpu().numpy() if torch.is_tensor(assign) else np.asarray(assign)
+        own = np.array([owner_of_list(p, self.world, lists_per_rank) == self.rank for p in a], dtype=bool)
+        if not own.any():
+            return 0
+        sel = np.nonzero(own)[0]
+        if torch.is_tensor(x):
+            st = torch.as_tensor(sel, device=x.device)
+            self.engine.add_local(torch.as_tensor(ids).to(x.device)[st].contiguous(), x[st].contiguous(), assign[st].contiguous())
+        else:
+            self.engine.add_local(np.asarray(ids)[sel], np.asarray(x)[sel], a[sel])
+        return int(own.sum())
+
+    def remove(self, ids):
+        """ids on every rank; a rank removes the ones it holds.  Returns how many this rank removed."""
+        import torch
+        h = ids.cpu().numpy() if torch.is_tensor(ids) else np.asarray(ids)
+        return int(self.engine.remove_local(np.ascontiguousarray(h, dtype=np.int64)))

@@ -42,6 +42,31 @@ class OracleEngine:
                                                               O.ip(q[a], self.v[r]))
         return oi, key
 
+    def assign(self, x):
+        import oracle as O
+        return O.coarse(x, self.c, None, 1, self.metric)[0].reshape(-1)
+
+    def add_local(self, ids, x, assign):
+        # append to the owned lists in input order (IndexPartition::append), keeping the CSR arrays of this double in step
+        nlist = self.o.shape[0] - 1
+        for p in range(nlist):
+            m = assign == p
+            if not m.any():
+                continue
+            at = int(self.o[p + 1])
+            self.v = np.concatenate([self.v[:at], x[m], self.v[at:]])
+            self.i = np.concatenate([self.i[:at], ids[m], self.i[at:]])
+            self.o[p + 1:] += int(m.sum())
+
+    def remove_local(self, ids):
+        keep = ~np.isin(self.i, ids)
+        removed = int((~keep).sum())
+        nlist = self.o.shape[0] - 1
+        sizes = np.array([keep[self.o[p]:self.o[p + 1]].sum() for p in range(nlist)])
+        self.v, self.i = self.v[keep], self.i[keep]
+        self.o = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+        return removed
+
     def merge(self, ids, keys):
         ids = ids.numpy() if torch.is_tensor(ids) else ids
         keys = keys.numpy() if torch.is_tensor(keys) else keys
@@ -89,6 +114,26 @@ def _worker(rank, world, port, metric, ret):
             assert gi.shape == (per, k)
             assert (gi == fi[sl]).all(), (rank, nprobe, k)
             assert (gd.view(np.uint32) == fd[sl].view(np.uint32)).all(), (rank, nprobe, k)
+        # dynamic updates: every rank gets the batch, each applies what it owns; the union behaves like one index
+        rng = np.random.default_rng(9)
+        nx = (ivf["x"][rng.integers(0, 6000, 40)] + 0.01 * rng.standard_normal((40, 24))).astype(np.float32)
+        nid = np.arange(100000, 100040, dtype=np.int64)
+        n_add = idx.add(nx, nid)
+        rm = np.concatenate([ivf["ids"][:30], nid[:5]])
+        n_rm = idx.remove(rm)
+        tot = torch.tensor([n_add, n_rm])
+        dist.all_reduce(tot)
+        assert tot.tolist() == [40, 35], tot
+        # reference: the same mutations on the unsharded CSR
+        full = OracleEngine(ivf["centroids"], ivf["vecs"].copy(), ivf["ids"].copy(), ivf["offsets"].copy(), metric)
+        full.add_local(nid, nx, full.assign(nx))
+        full.remove_local(rm)
+        for nprobe, k in [(4, 10), (16, 20)]:
+            gi, gd = idx.search(q, nprobe, k)
+            fi, fd = O.search(q, ivf["centroids"], full.v, full.i, full.o, nprobe, k, metric, batched_scan=True)
+            # (append order inside a list differs between the sharded stores and the single store only across lists,
+            #  never inside one list, so even the tie order is the same)
+            assert (gi == fi).all(), (rank, nprobe, k)
         ret[rank] = "ok"
     finally:
         dist.destroy_process_group()
