@@ -46,6 +46,8 @@ typedef enum {
 #define QK_MEM_HOST 0
 #define QK_MEM_DEVICE 1
 #define QK_MAX_K 448 /* largest k / nprobe of the fused LDS top-k: pool capacity k+64 <= 512 (reference: 8192, list_scanning.h:39) */
+#define QK_MAX_NPROBE 4096 /* largest nprobe / number of APS candidate partitions: the coarse step selects them with a
+                              * bisection select + sort beyond QK_MAX_K (flat parent index) */
 
 typedef struct qk_ctx qk_ctx;     /* device + stream + scratch workspace                     */
 typedef struct qk_store qk_store; /* device mirror of faiss::DynamicInvertedLists (one level) */

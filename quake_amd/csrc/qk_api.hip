@@ -61,7 +61,7 @@ int run_search(qk_ctx *ctx, qk_store *parent, qk_store *s, const float *x, int64
     if (use_parent) {
         if (parent->d != d) QK_FAIL(QK_ERR_INVALID, "parent store dimension %d != store dimension %d", parent->d, d);
         kk = (int)std::min<int64_t>(nprobe, parent->ntotal);  // query_coordinator.cpp:641
-        if (kk > QK_MAX_K) QK_FAIL(QK_ERR_UNSUPPORTED, "nprobe=%d exceeds QK_MAX_K=%d", kk, QK_MAX_K);
+        if (kk > QK_MAX_NPROBE) QK_FAIL(QK_ERR_UNSUPPORTED, "nprobe=%d exceeds QK_MAX_NPROBE=%d", kk, QK_MAX_NPROBE);
     }
     const int Ps = coarse_only ? 0 : (use_parent ? kk : P);
     const int kout = coarse_only ? kk : k;

@@ -388,7 +388,7 @@ extern "C" int qk_search_aps(qk_ctx *ctx, qk_store *parent, qk_store *s, const f
     if (M < 1) M = 1;
     M = (int)std::min<int64_t>(M, parent->ntotal);
     if (M < 2) QK_FAIL(QK_ERR_INVALID, "Boundary distances must have at least 2 partitions to create an estimate.");  // geometry.h:350
-    if (M > QK_MAX_K) QK_FAIL(QK_ERR_UNSUPPORTED, "qk_search_aps: %d candidate partitions exceed QK_MAX_K=%d", M, QK_MAX_K);
+    if (M > QK_MAX_NPROBE) QK_FAIL(QK_ERR_UNSUPPORTED, "qk_search_aps: %d candidate partitions exceed QK_MAX_NPROBE=%d", M, QK_MAX_NPROBE);
     hipStream_t st = ctx->stream;
     const int CH = std::min(APS_CH, M);
 

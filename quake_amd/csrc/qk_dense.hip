@@ -237,6 +237,131 @@ __global__ __launch_bounds__(64) void k_select_rows(SelectParams S) {
     }
 }
 
+
+// ---- large-k selection (448 < k <= QK_MAX_NPROBE): the coarse step with nprobe / APS candidate counts beyond the LDS pools ----
+// One workgroup of 256 threads per query over its key row (L2-resident):
+//   1. T = k-th smallest key by bisection on the 32 key bits (one counting pass over the row per bit);
+//   2. if more rows tie on T than are needed, I = the id that cuts them, by bisection on the id bits;
+//   3. the k survivors ((key, id) < (T, I]) are gathered into LDS and bitonic-sorted under the total order (key, id).
+// Exact under the same (key, id) order as every other selection in the library; cost ~ (32 + 63) passes over 4*n bytes.
+struct SelectLargeParams {
+    const uint32_t *D;   // [Q][ld] keys
+    int64_t ld;
+    int nrows;
+    const int64_t *ids;  // arena ids + row_off
+    int k;               // <= QK_MAX_NPROBE
+    int kp;              // next power of two >= k
+    int metric;
+    int sqrt_l2;
+    int64_t *out_ids;
+    float *out_dist;
+};
+
+__device__ __forceinline__ int block_sum_256(int v, int *s_red) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+    __syncthreads();
+    if (lane == 0) s_red[wave] = v;
+    __syncthreads();
+    return s_red[0] + s_red[1] + s_red[2] + s_red[3];
+}
+
+__global__ __launch_bounds__(256) void k_select_rows_large(SelectLargeParams S) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    __shared__ int s_red[4];
+    __shared__ int s_cnt;
+    const int tid = threadIdx.x;
+    const int64_t q = blockIdx.x;
+    const int k = S.k, kp = S.kp, n = S.nrows;
+    uint32_t *e_ord = (uint32_t *)smem;                     // [kp]
+    int64_t *e_id = (int64_t *)(smem + (size_t)kp * 4);     // [kp]
+    const uint32_t *row = S.D + q * S.ld;
+    const int kk = min(k, n);  // fewer rows than k: everything is kept, the rest is padding
+    // 1. k-th smallest key
+    uint32_t T = 0;
+    for (int b = 31; b >= 0; b--) {
+        const uint32_t tr = T | (1u << b);
+        int c = 0;
+        for (int i = tid; i < n; i += 256) c += row[i] < tr ? 1 : 0;
+        if (block_sum_256(c, s_red) < kk) T = tr;
+    }
+    int c_lt = 0, c_eq = 0;
+    for (int i = tid; i < n; i += 256) {
+        const uint32_t v = row[i];
+        c_lt += v < T ? 1 : 0;
+        c_eq += v == T ? 1 : 0;
+    }
+    c_lt = block_sum_256(c_lt, s_red);
+    c_eq = block_sum_256(c_eq, s_red);
+    const int need = kk - c_lt;  // ties on T to take, 1 <= need <= c_eq (0 when kk == 0)
+    // 2. id cut among the ties (ids are unique and non-negative)
+    int64_t I = INT64_MAX;
+    if (need < c_eq) {
+        uint64_t Iu = 0;
+        for (int b = 62; b >= 0; b--) {
+            const uint64_t tr = Iu | (1ull << b);
+            int c = 0;
+            for (int i = tid; i < n; i += 256) c += (row[i] == T && (uint64_t)S.ids[i] < tr) ? 1 : 0;
+            if (block_sum_256(c, s_red) < need) Iu = tr;
+        }
+        I = (int64_t)Iu;  // the need-th smallest tied id
+    }
+    // 3. gather + sort
+    if (tid == 0) s_cnt = 0;
+    for (int i = tid; i < kp; i += 256) {
+        e_ord[i] = 0xFFFFFFFFu;
+        e_id[i] = INT64_MAX;
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += 256) {
+        const uint32_t v = row[i];
+        if (v < T || (v == T && need > 0 && S.ids[i] <= I)) {
+            const int sl = atomicAdd(&s_cnt, 1);
+            if (sl < kp) {
+                e_ord[sl] = v;
+                e_id[sl] = S.ids[i];
+            }
+        }
+    }
+    __syncthreads();
+    for (int size = 2; size <= kp; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int i = tid; i < (kp >> 1); i += 256) {
+                const int lo = 2 * i - (i & (stride - 1));  // index of the lower element of the pair
+                const int hi = lo + stride;
+                const bool up = (lo & size) == 0;
+                const uint32_t a = e_ord[lo], b = e_ord[hi];
+                const int64_t ia = e_id[lo], ib = e_id[hi];
+                const bool gt = a > b || (a == b && ia > ib);
+                if (gt == up) {
+                    e_ord[lo] = b;
+                    e_ord[hi] = a;
+                    e_id[lo] = ib;
+                    e_id[hi] = ia;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int e = tid; e < k; e += 256) {
+        int64_t oid = -1;
+        float od = S.metric == QK_METRIC_IP ? -INFINITY : INFINITY;
+        if (e < kk) {
+            oid = e_id[e];
+            const uint32_t o = e_ord[e];
+            if (S.metric == QK_METRIC_L2) {
+                const float d2 = __uint_as_float(o);
+                od = S.sqrt_l2 ? sqrtf(d2) : d2;
+            } else {
+                od = ip_from_ord(o);
+            }
+        }
+        S.out_ids[q * k + e] = oid;
+        if (S.out_dist) S.out_dist[q * k + e] = od;
+    }
+}
+
 template <int DB, int NQ>
 static int launch_dense_t(hipStream_t st, dim3 grid, size_t lds, const DenseParams &dp) {
     QK_HIP(hipFuncSetAttribute((const void *)k_dense_ord<DB, NQ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -261,7 +386,8 @@ int qk_dense_device(qk_ctx *ctx, qk_store *s, int64_t list_no, const qk_scan_arg
     if (lds > 160 * 1024) QK_FAIL(QK_ERR_UNSUPPORTED, "dense scan: d=%d too large for the LDS query tile", s->d);
     const int64_t ld = qk_round_up64(std::max(nrows, 1), 16);
     const int Cm = qk_round_up(k + 64, 64);
-    if (Cm > 1024) QK_FAIL(QK_ERR_UNSUPPORTED, "dense scan: k=%d too large", k);
+    const bool large_k = Cm > 1024;  // beyond the LDS pool machinery: bisection select + sort (k_select_rows_large)
+    if (k > QK_MAX_NPROBE) QK_FAIL(QK_ERR_UNSUPPORTED, "dense scan: k=%d exceeds QK_MAX_NPROBE=%d", k, QK_MAX_NPROBE);
     const int mc = Cm <= 128 ? 2 : Cm <= 256 ? 4 : Cm <= 512 ? 8 : 16;
     // query batching keeps the key matrix under 1 GiB
     int64_t qb = std::max<int64_t>(NQ * 16, ((int64_t)1 << 30) / (ld * 4));
@@ -316,6 +442,25 @@ int qk_dense_device(qk_ctx *ctx, qk_store *s, int64_t list_no, const qk_scan_arg
         sp.sqrt_l2 = a.sqrt_l2 ? 1 : 0;
         sp.out_ids = a.out_ids + q0 * k;
         sp.out_dist = a.out_dist ? a.out_dist + q0 * k : nullptr;
+        if (large_k) {
+            SelectLargeParams lp;
+            lp.D = D;
+            lp.ld = ld;
+            lp.nrows = nrows;
+            lp.ids = s->ids + pt.row_off;
+            lp.k = k;
+            int kp = 1;
+            while (kp < k) kp <<= 1;
+            lp.kp = kp;
+            lp.metric = a.metric;
+            lp.sqrt_l2 = a.sqrt_l2 ? 1 : 0;
+            lp.out_ids = a.out_ids + q0 * k;
+            lp.out_dist = a.out_dist ? a.out_dist + q0 * k : nullptr;
+            const size_t lds_l = (size_t)kp * 12;
+            QK_HIP(hipFuncSetAttribute((const void *)k_select_rows_large, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_l));
+            hipLaunchKernelGGL(k_select_rows_large, dim3((unsigned)nq), dim3(256), lds_l, st, lp);
+            continue;
+        }
         const size_t lds_s = (size_t)Cm * 12;
         switch (mc) {
             case 2: hipLaunchKernelGGL((k_select_rows<2>), dim3((unsigned)nq), dim3(64), lds_s, st, sp); break;

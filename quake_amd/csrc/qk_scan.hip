@@ -1106,11 +1106,14 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
     const int k = a.k;
     if (Q <= 0) return QK_OK;
     if (k <= 0) QK_FAIL(QK_ERR_INVALID, "qk_scan: k must be positive");
-    if (k > QK_MAX_K) QK_FAIL(QK_ERR_UNSUPPORTED, "qk_scan: k=%d exceeds QK_MAX_K=%d", k, QK_MAX_K);
+    // beyond the LDS pools only the one-list (flat / parent index) form is available: k_select_rows_large
+    const bool one_list = a.all_lists && s->nlist == 1;
+    if (k > QK_MAX_K && !(one_list && k <= QK_MAX_NPROBE))
+        QK_FAIL(QK_ERR_UNSUPPORTED, "qk_scan: k=%d exceeds QK_MAX_K=%d", k, QK_MAX_K);
     QK_TRY(qk_store_sync_table(s));
     const int npids = (int)s->parts.size();
     // dense form: every query against ONE list (the parent / flat index of query_coordinator.cpp:624-626,644)
-    if (a.all_lists && s->nlist == 1 && Q >= 32) {
+    if (one_list && (Q >= 32 || k > QK_MAX_K)) {
         for (int64_t p = 0; p < npids; p++)
             if (s->parts[p].present) return qk_dense_device(ctx, s, p, a, timing, ev_base);
     }

@@ -68,3 +68,16 @@ def test_aps_device_tensors_and_errors(ctx):
         ctx.search_aps(parent, s, q, 10, "l2", 0.9, initial_search_fraction=0.02)
     with pytest.raises(QuakeHipError):
         ctx.search_aps(None, s, q, 10, "l2", 0.9)
+
+
+def test_aps_many_candidates(ctx):
+    """M = nlist * initial_search_fraction beyond QK_MAX_K: candidates come from the large-k selection."""
+    ivf = make_ivf(40000, 16, 1200, seed=15)
+    q = make_queries(48, 16, seed=16, like=ivf["x"])
+    parent, s = build_stores(ctx, ivf)
+    gi, gd, gn = ctx.search_aps(parent, s, q, 10, "l2", 0.9, initial_search_fraction=0.5)  # M = 600
+    oi, od, on = O.search_aps(q, ivf["centroids"], ivf["vecs"], ivf["ids"], ivf["offsets"], 10, "l2", 0.9,
+                              initial_search_fraction=0.5, expanded=True, num_threads=8)
+    np.testing.assert_array_equal(gn, on)
+    np.testing.assert_array_equal(gi, oi)
+    np.testing.assert_array_equal(gd.view(np.uint32), od.view(np.uint32))

@@ -171,3 +171,46 @@ def test_wide_rows_shared_query_tile(ctx, d, metric):
         oi, od = O.batched_serial_scan(q, vecs, ivf["ids"], off, pids, k, metric)
         np.testing.assert_array_equal(gi, oi)
         np.testing.assert_array_equal(gd.view(np.uint32), od.view(np.uint32))
+
+
+def test_large_nprobe_selection(ctx):
+    """nprobe / candidate counts beyond QK_MAX_K (up to QK_MAX_NPROBE) go through k_select_rows_large: bisection on the key
+    bits, id cut among ties, bitonic sort.  Exact (key, id) order vs the oracle, duplicated centroids included."""
+    from quake_amd._lib import QK_MAX_K, QK_MAX_NPROBE, QuakeHipError
+    from quake_amd.capi import Store
+    rng = np.random.default_rng(51)
+    nl, d = 3000, 32
+    c = rng.standard_normal((nl, d)).astype(np.float32)
+    c[100:160] = c[40:100]   # exact duplicates: equal keys, order decided by id
+    c[2000:2400] = c[1000]   # 400-way tie
+    parent = Store(ctx, d)
+    parent.build_csr(np.array([0, nl], np.int64), np.arange(nl, dtype=np.int64), c)
+    for Q in (3, 70):
+        x = rng.standard_normal((Q, d)).astype(np.float32)
+        x[0] = c[1000]
+        for metric in ("l2", "ip"):
+            for kk in (QK_MAX_K + 1, 1000, 2999, 3000):
+                gp, gd = ctx.coarse(parent, x, kk, metric)
+                op, od = O.coarse(x, c, None, kk, metric)
+                np.testing.assert_array_equal(gp, op)
+                np.testing.assert_array_equal(gd.view(np.uint32), od.view(np.uint32))
+    # more candidates than rows: padded with -1 like every other entry point
+    gp, gd = ctx.coarse(parent, x[:2], 3500, "l2")
+    assert gp.shape[1] == 3000  # kk = min(nprobe, ntotal)
+    # the whole search with nprobe > QK_MAX_K, and the flat index with k > QK_MAX_K
+    ivf = make_ivf(30000, 16, 600, seed=52)
+    pq, s = build_stores(ctx, ivf)
+    q = make_queries(40, 16, seed=53, like=ivf["x"])
+    gi, gd = ctx.search(pq, s, q, 500, 10, "l2")
+    oi, od = O.search(q, ivf["centroids"], ivf["vecs"], ivf["ids"], ivf["offsets"], 500, 10, "l2", batched_scan=True)
+    np.testing.assert_array_equal(gi, oi)
+    np.testing.assert_array_equal(gd.view(np.uint32), od.view(np.uint32))
+    flat = Store(ctx, 16)
+    flat.build_csr(np.array([0, 5000], np.int64), ivf["ids"][:5000], ivf["vecs"][:5000])
+    gi, gd = ctx.search(None, flat, q, 1, 1000, "l2")
+    oi, od = O.batched_serial_scan(q, ivf["vecs"][:5000], ivf["ids"][:5000], np.array([0, 5000], np.int64),
+                                   np.zeros((40, 1), np.int64), 1000, "l2")
+    np.testing.assert_array_equal(gi, oi)
+    np.testing.assert_array_equal(gd.view(np.uint32), od.view(np.uint32))
+    with pytest.raises(QuakeHipError):
+        ctx.coarse(parent, x, QK_MAX_NPROBE + 1, "l2") if nl > QK_MAX_NPROBE else ctx.search(None, flat, q, 1, QK_MAX_NPROBE + 1, "l2")
