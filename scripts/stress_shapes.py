@@ -1,3 +1,5 @@
+"""Unusual shapes through qk_search (huge batches, k = 448, d = 2048, nprobe > QK_MAX_K, one query over 2048 partitions):
+sanity against GPU brute force.  python scripts/stress_shapes.py"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
