@@ -236,6 +236,86 @@ static int check_list(qk_store *s, int64_t list_no, const char *who) {
     return QK_OK;
 }
 
+
+// ---- arena compaction: live extents copied into a new arena, abandoned ones dropped --------------------------------------
+struct CompactMove {
+    int64_t old_off, new_off;  // first row (multiple of 16)
+    int64_t size;              // valid rows
+};
+// one workgroup per live partition
+__global__ __launch_bounds__(256) void k_compact_copy(const CompactMove *__restrict__ mv, int dpad, const float4 *__restrict__ ovecs,
+                                                      const float *__restrict__ onorms, const int64_t *__restrict__ oids,
+                                                      float4 *__restrict__ nvecs, float *__restrict__ nnorms, int64_t *__restrict__ nids) {
+    const CompactMove m = mv[blockIdx.x];
+    const int64_t tiles = (m.size + 15) >> 4;
+    const int64_t n4 = tiles * 16 * (dpad / 4);  // float4 per extent in use (tile-major: whole tiles)
+    const float4 *src = ovecs + m.old_off * (dpad / 4);
+    float4 *dst = nvecs + m.new_off * (dpad / 4);
+    for (int64_t i = threadIdx.x; i < n4; i += blockDim.x) dst[i] = src[i];
+    for (int64_t i = threadIdx.x; i < m.size; i += blockDim.x) {
+        nnorms[m.new_off + i] = onorms[m.old_off + i];
+        nids[m.new_off + i] = oids[m.old_off + i];
+    }
+}
+
+// Rebuild the arena with every present partition (its capacity kept) laid out back to back, `last` (if >= 0) at the very
+// end so that it can grow in place, and room for `extra_rows` more.  Called when a partition has to move and a quarter or
+// more of the arena is abandoned extents: under skewed inserts the bump pointer would otherwise run through 10x the live
+// data (every doubling of a hot partition leaves its old extent behind).
+static int compact_arena(qk_store *s, int64_t extra_rows, int64_t last) {
+    qk_ctx *c = s->ctx;
+    std::vector<CompactMove> mv;
+    std::vector<int64_t> order;
+    for (size_t pi = 0; pi < s->parts.size(); pi++)
+        if (s->parts[pi].present && (int64_t)pi != last) order.push_back((int64_t)pi);
+    if (last >= 0 && last < (int64_t)s->parts.size() && s->parts[(size_t)last].present) order.push_back(last);
+    int64_t live_cap = 0;
+    for (int64_t pi : order) live_cap += s->parts[(size_t)pi].cap;
+    int64_t ncap = qk_round_up64(std::max<int64_t>(live_cap + extra_rows + live_cap / 4, 1024), 16);
+    float *nv = nullptr, *nn = nullptr;
+    int64_t *ni = nullptr;
+    if (hipMalloc((void **)&nv, (size_t)ncap * s->dpad * sizeof(float)) != hipSuccess ||
+        hipMalloc((void **)&nn, (size_t)ncap * sizeof(float)) != hipSuccess ||
+        hipMalloc((void **)&ni, (size_t)ncap * sizeof(int64_t)) != hipSuccess) {
+        if (nv) hipFree(nv);
+        if (nn) hipFree(nn);
+        if (ni) hipFree(ni);
+        QK_FAIL(QK_ERR_OOM, "store arena compaction: allocation failed for %lld rows x %d dims", (long long)ncap, s->dpad);
+    }
+    QK_HIP(hipMemsetAsync(nv, 0, (size_t)ncap * s->dpad * sizeof(float), c->stream));
+    QK_HIP(hipMemsetAsync(nn, 0, (size_t)ncap * sizeof(float), c->stream));
+    QK_HIP(hipMemsetAsync(ni, 0xFF, (size_t)ncap * sizeof(int64_t), c->stream));
+    int64_t at = 0;
+    std::vector<int64_t> new_off(order.size());
+    for (size_t i = 0; i < order.size(); i++) {
+        const qk_part &p = s->parts[(size_t)order[i]];
+        new_off[i] = at;
+        if (p.size > 0) mv.push_back({p.row_off, at, p.size});
+        at += p.cap;
+    }
+    if (!mv.empty()) {
+        const size_t bytes = mv.size() * sizeof(CompactMove);
+        QK_TRY(qk_stage_reserve(c, bytes));
+        QK_HIP(hipMemcpyAsync(c->stage, mv.data(), bytes, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(k_compact_copy, dim3((unsigned)mv.size()), dim3(256), 0, c->stream, (const CompactMove *)c->stage, s->dpad,
+                           (const float4 *)s->vecs, s->norms, s->ids, (float4 *)nv, nn, ni);
+        QK_HIP(hipGetLastError());
+    }
+    QK_HIP(hipStreamSynchronize(c->stream));  // (also keeps the pageable `mv` alive for the copy)
+    if (s->vecs) hipFree(s->vecs);
+    if (s->norms) hipFree(s->norms);
+    if (s->ids) hipFree(s->ids);
+    s->vecs = nv;
+    s->norms = nn;
+    s->ids = ni;
+    s->cap_rows = ncap;
+    for (size_t i = 0; i < order.size(); i++) s->parts[(size_t)order[i]].row_off = new_off[i];
+    s->used_rows = at;
+    s->dead_rows = 0;
+    s->table_dirty = true;
+    return QK_OK;
+}
+
 // make sure partition `p` can take `extra` more rows; relocates the extent (amortised doubling, like
 // IndexPartition::ensure_capacity index_partition.cpp:247-255) when it does not fit
 static int ensure_part_capacity(qk_store *s, qk_part &p, int64_t extra) {
@@ -243,6 +323,9 @@ static int ensure_part_capacity(qk_store *s, qk_part &p, int64_t extra) {
     if (need <= p.cap) return QK_OK;
     qk_ctx *c = s->ctx;
     int64_t ncap = qk_round_up64(std::max<int64_t>(need, p.cap * 2), 16);
+    // the arena would have to grow although a quarter of it is abandoned extents: compact instead (p goes last)
+    if (s->used_rows + ncap > s->cap_rows && s->dead_rows * 4 >= s->cap_rows && s->dead_rows >= 1024)
+        QK_TRY(compact_arena(s, ncap, (int64_t)(&p - s->parts.data())));
     // extent at the very end of the arena can grow in place
     if (p.cap > 0 && p.row_off + p.cap == s->used_rows) {
         QK_TRY(qk_store_reserve_rows(s, ncap - p.cap));

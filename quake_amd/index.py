@@ -141,6 +141,66 @@ class SearchResult:  # common.h:243-247
 _CONTEXTS = {}
 
 
+class _ResidentIds:
+    """PartitionManager::resident_ids_ (partition_manager.h): which vector ids are in the index.  A byte map indexed by id
+    (ids are < INT_MAX, partition_manager.cpp:150-153) so that batches are checked with numpy instead of per-id lookups;
+    ids beyond 2^28 (a 256 MB map) switch to a plain set."""
+    LIMIT = 1 << 28
+
+    def __init__(self):
+        self._map = np.zeros(0, np.bool_)
+        self._set = None
+
+    def _to_set(self):
+        self._set = set(np.nonzero(self._map)[0].tolist())
+        self._map = np.zeros(0, np.bool_)
+
+    def any_present(self, ids):
+        if self._set is not None:
+            return any(v in self._set for v in ids.tolist())
+        ids = ids[(ids >= 0) & (ids < self._map.shape[0])]
+        return bool(self._map[ids].any()) if ids.size else False
+
+    def all_present(self, ids):
+        if ids.size == 0:
+            return True
+        if self._set is not None:
+            return all(v in self._set for v in ids.tolist())
+        if int(ids.max()) >= self._map.shape[0] or int(ids.min()) < 0:
+            return False
+        return bool(self._map[ids].all())
+
+    def update(self, ids):
+        ids = np.asarray(list(ids) if not isinstance(ids, np.ndarray) else ids, dtype=np.int64).reshape(-1)
+        if not ids.size:
+            return
+        if self._set is None and int(ids.max()) >= self.LIMIT:
+            self._to_set()
+        if self._set is not None:
+            self._set.update(ids.tolist())
+            return
+        m = int(ids.max())
+        if m >= self._map.shape[0]:
+            new = np.zeros(min(self.LIMIT, max(m + 1, 2 * self._map.shape[0], 1024)), np.bool_)
+            new[:self._map.shape[0]] = self._map
+            self._map = new
+        self._map[ids] = True
+
+    def discard_all(self, ids):
+        if self._set is not None:
+            self._set.difference_update(ids.tolist())
+        else:
+            self._map[ids] = False
+
+    def __contains__(self, v):
+        if self._set is not None:
+            return v in self._set
+        return 0 <= v < self._map.shape[0] and bool(self._map[v])
+
+    def __len__(self):
+        return len(self._set) if self._set is not None else int(self._map.sum())
+
+
 def _context(device=0):
     """the per-device context, bound to torch's CURRENT stream of that device: device tensors handed in were produced on
     it and the tensors handed back are consumed on it, so the library's work has to be ordered with it"""
@@ -171,7 +231,7 @@ class QuakeIndex:
         self._device = int(device)
         self._has_ctx = False
         self._store = None
-        self._resident = set()   # PartitionManager::resident_ids_
+        self._resident = _ResidentIds()   # PartitionManager::resident_ids_
         self._next_pid = 0       # PartitionManager::curr_partition_id_
         self._d = 0
 
@@ -237,7 +297,8 @@ class QuakeIndex:
             self.parent = None
             info.n_clusters = 1
             self._next_pid = 1
-        self._resident = set(ids.reshape(-1).tolist())
+        self._resident = _ResidentIds()
+        self._resident.update(ids.reshape(-1).cpu().numpy().astype(np.int64))
         self.initialize_maintenance_policy(MaintenancePolicyParams())
         info.total_time_us = _us(t_total)
         return info
@@ -336,15 +397,16 @@ class QuakeIndex:
             return info
         if x.dim() != 2:
             raise RuntimeError("[PartitionManager] add: 'vectors' must be 2D [N, dim].")
-        idl = ids.reshape(-1).tolist()
-        if max(idl) > INT32_MAX:
+        idn = ids.reshape(-1).cpu().numpy().astype(np.int64)
+        if int(idn.max()) > INT32_MAX:
             raise RuntimeError("[PartitionManager] add: vector_ids must be less than INT_MAX.")
-        if len(set(idl)) != n:
+        if int(idn.min()) < 0:
+            raise RuntimeError("[PartitionManager] add: vector_ids must be non-negative (-1 marks an empty result slot).")
+        if np.unique(idn).shape[0] != n:
             raise RuntimeError("[PartitionManager] add: vector_ids must be unique.")
-        for v in idl:
-            if v in self._resident:
-                raise RuntimeError("[PartitionManager] init_partitions: vector ID already exists in the index.")
-        self._resident.update(idl)
+        if self._resident.any_present(idn):
+            raise RuntimeError("[PartitionManager] init_partitions: vector ID already exists in the index.")
+        self._resident.update(idn)
         info.input_validation_time_us = _us(t0)
         t0 = time.perf_counter()
         xd = self._to_dev(x, torch.float32)
@@ -369,14 +431,13 @@ class QuakeIndex:
         if ids.shape[0] == 0:
             return info
         t0 = time.perf_counter()
-        idl = ids.reshape(-1).tolist()
-        for v in idl:
-            if v not in self._resident:
-                raise RuntimeError("[PartitionManager] remove: vector ID does not exist in the index.")
-            self._resident.discard(v)
+        idn = ids.reshape(-1).cpu().numpy().astype(np.int64)
+        if not self._resident.all_present(idn):
+            raise RuntimeError("[PartitionManager] remove: vector ID does not exist in the index.")
+        self._resident.discard_all(idn)
         info.input_validation_time_us = _us(t0)
         t0 = time.perf_counter()
-        self._store.remove_ids(np.asarray(idl, dtype=np.int64))
+        self._store.remove_ids(idn)
         info.modify_time_us = _us(t0)
         return info
 
@@ -549,7 +610,7 @@ class QuakeIndex:
         self._has_ctx = True
         self._d = int(d)
         self._store = capi.Store(self._ctx, int(d))
-        self._resident = set()
+        self._resident = _ResidentIds()
         for i in range(nparts):
             size = int(offs[i + 1] - offs[i])
             if size % rec != 0:
@@ -560,7 +621,7 @@ class QuakeIndex:
             self._store.add_list(int(pids[i]))
             if nv:
                 self._store.add_entries(int(pids[i]), ids.copy(), vecs.copy())
-            self._resident.update(ids.tolist())
+            self._resident.update(ids.astype(np.int64))
         self._next_pid = (int(pids.max()) + 1) if nparts else 0
         pdir = os.path.join(dir_path, "parent")
         if os.path.isdir(pdir):

@@ -241,6 +241,12 @@ class DynamicWorkloadGenerator:
         return self.runbook
 
 
+def _sync():
+    """operations are enqueued on the GPU: a latency is only attributable to its operation between two synchronisations"""
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+
+
 class WorkloadEvaluator:
     def __init__(self, workload_dir, output_dir, base_vectors_path=None):
         self.workload_dir = Path(workload_dir)
@@ -282,13 +288,16 @@ class WorkloadEvaluator:
             ids = torch.load(self.operations_dir / f"{op_id}.pt", weights_only=True)
             mean_recall = None
             maint = None
+            _sync()
             if typ == "insert":
                 t0 = time.time()
                 index.add(base[ids], ids=ids, num_threads=16)
+                _sync()
                 op_time = time.time() - t0
             elif typ == "delete":
                 t0 = time.time()
                 index.remove(ids)
+                _sync()
                 op_time = time.time() - t0
             else:
                 gt = torch.load(self.operations_dir / f"{op_id}_gt_ids.pt", weights_only=True)
@@ -298,12 +307,14 @@ class WorkloadEvaluator:
                     pred = index.search(q, **search_params).ids
                 else:
                     pred = torch.cat([index.search(q[i:i + 1], **search_params).ids for i in range(q.shape[0])])
+                _sync()
                 op_time = time.time() - t0
                 mean_recall = compute_recall(pred.cpu(), gt, search_params["k"]).mean().item()
                 self.runbook["operations"][op_id]["recall"] = mean_recall
             if do_maintenance:
                 t0 = time.time()
                 maint = index.maintenance()
+                _sync()
                 maint_ms = (time.time() - t0) * 1e3
             rec = {"operation_number": int(op_id), "operation_type": typ, "latency_ms": op_time * 1000, "recall": mean_recall,
                    "n_resident": op.get("n_resident")}

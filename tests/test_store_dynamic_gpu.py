@@ -117,3 +117,48 @@ def test_mutation_stream_matches_host_model_and_oracle(ctx):
     oi, od = O.batched_serial_scan(q, vecs[order], ids[order], dense_offs, pids, 10, "l2")
     np.testing.assert_array_equal(gi, oi)
     np.testing.assert_array_equal(gd.view(np.uint32), od.view(np.uint32))
+
+
+def test_skewed_inserts_compact_the_arena(ctx):
+    """Every doubling of a hot partition abandons its old extent; once a quarter of the arena is abandoned the store compacts
+    instead of growing (qk_store.hip compact_arena).  Contents, order and search results must be unaffected, and the arena
+    must stay within a small multiple of the live data."""
+    from quake_amd.capi import Store
+    d, nlist = 24, 12
+    ivf = make_ivf(6000, d, nlist, seed=61)
+    s = Store(ctx, d)
+    s.build_csr(ivf["offsets"], ivf["ids"], ivf["vecs"])
+    model = HostModel(ivf)
+    rng = np.random.default_rng(62)
+    next_id = 100000
+    for step in range(60):  # hot lists 2 and 7 get almost everything, in growing batches
+        n = int(rng.integers(200, 1500))
+        p = 2 if step % 3 else 7
+        vecs = rng.standard_normal((n, d)).astype(np.float32)
+        ids = np.arange(next_id, next_id + n, dtype=np.int64)
+        next_id += n
+        if step % 4 == 0:  # batched form, a few rows for other lists too
+            assign = np.full(n, p, np.int64)
+            assign[::50] = rng.integers(0, nlist, assign[::50].shape[0])
+            s.add_batch(ids, vecs, assign)
+            for q_ in range(nlist):
+                m = assign == q_
+                if m.any():
+                    model.add(q_, ids[m], vecs[m])
+        else:
+            s.add_entries(p, ids, vecs)
+            model.add(p, ids, vecs)
+        if step % 7 == 6:
+            kill = rng.choice(np.array(model.parts[p][0]), 300, replace=False)
+            s.remove_ids(kill)
+            model.remove(kill)
+    check_equal(s, model, d)
+    live_bytes = s.ntotal() * d * 4
+    assert s.device_bytes() < 4.5 * live_bytes, (s.device_bytes(), live_bytes)  # bump-only growth would be >> 10x here
+    keys, (vecs, ids_, offsets) = model.csr(d)
+    q = make_queries(30, d, seed=63, like=ivf["x"])
+    pids = np.tile(np.arange(nlist, dtype=np.int64), (30, 1))
+    gi, gd = ctx.scan(s, q, pids, 10, "l2")
+    oi, od = O.batched_serial_scan(q, vecs, ids_, offsets, pids, 10, "l2")
+    np.testing.assert_array_equal(gi, oi)
+    np.testing.assert_array_equal(gd.view(np.uint32), od.view(np.uint32))
