@@ -362,6 +362,188 @@ __global__ __launch_bounds__(256) void k_select_rows_large(SelectLargeParams S) 
     }
 }
 
+
+// ---- fused argmin: the coarse step with nprobe = 1 (and PartitionManager::add's k = 1 parent search) -------------------------
+// Same decomposition as k_dense_ord, but nothing is materialised: every lane keeps the best (key, row) of the rows it sees for
+// each of its NQ queries, the workgroup reduces them and folds its candidate into best64[q] = (key << 32 | id) with one
+// atomicMin per query -- the (key, id) total order as an integer order (ids < 2^32, checked by the host).  Two rows with the
+// same key are ordered by id right away (the two ids are loaded then: an exact tie is rare).
+struct ArgminParams {
+    const float4 *vecs;
+    const float *norms;
+    const int64_t *ids;  // arena ids + row_off
+    int64_t row_off;
+    int nrows;
+    int nblk;
+    const float4 *xq4;
+    const float *xn;
+    int64_t Q;
+    int metric;
+    int tiles_per_wg;
+    unsigned long long *best64;  // [Q], preset to ~0
+};
+
+template <int DB, int NQ>
+__global__ __launch_bounds__(256) void k_dense_argmin(ArgminParams P) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 15, g = lane >> 4;
+    const int nblk = P.nblk;
+    const bool l2 = P.metric == QK_METRIC_L2;
+    float4 *qs = (float4 *)smem;                               // [NQ][nblk*64]
+    float *xn_s = (float *)(smem + (size_t)NQ * nblk * 1024);  // [NQ*16]
+    unsigned long long *red = (unsigned long long *)(xn_s + NQ * 16);  // [4][NQ*16]
+    const int64_t q_base = (int64_t)blockIdx.x * (NQ * 16);
+
+    for (int t = wave; t < NQ * nblk; t += 4) {
+        const int nq = t / nblk, cb = t - nq * nblk;
+        const int64_t row = q_base + nq * 16 + j;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < P.Q) v = P.xq4[(row * nblk + cb) * 4 + g];
+        qs[(size_t)nq * nblk * 64 + cb * 64 + lane] = v;
+    }
+    if (tid < NQ * 16) {
+        const int64_t row = q_base + tid;
+        xn_s[tid] = (row < P.Q && l2) ? P.xn[row] : 0.0f;
+    }
+    __syncthreads();
+    float xnj[NQ];
+    uint32_t best_ord[NQ];
+    int best_row[NQ];
+#pragma unroll
+    for (int nq = 0; nq < NQ; nq++) {
+        xnj[nq] = xn_s[nq * 16 + j];
+        best_ord[nq] = 0xFFFFFFFFu;
+        best_row[nq] = -1;
+    }
+    const int ntile_all = (P.nrows + 15) >> 4;
+    const int wg_t0 = blockIdx.y * P.tiles_per_wg;
+    const int wg_t1 = min(ntile_all, wg_t0 + P.tiles_per_wg);
+    const int tpw = (wg_t1 - wg_t0 + 3) >> 2;
+    const int t0 = wg_t0 + wave * tpw, t1 = min(wg_t1, t0 + tpw);
+    const int ncd = nblk / DB;
+    if (t1 > t0) {
+        const int64_t tile_abs0 = (P.row_off >> 4) + t0;
+        const float4 *src = P.vecs + tile_abs0 * nblk * 64 + lane;
+        const float4 *nsrc = (const float4 *)(P.norms + (tile_abs0 << 4)) + g;
+        const int nsteps = (t1 - t0) * ncd;
+        float4 a0[DB], a1[DB];
+        float4 yn_cur = make_float4(0.f, 0.f, 0.f, 0.f), yn_next = yn_cur;
+        f32x4 acc[NQ];
+        int dch = 0, tile = t0, ldch = 0, ltile = 0;
+#define AM_LOAD(A, S)                                                 \
+    {                                                                 \
+        const float4 *pp_ = src + (int64_t)(S) * (DB * 64);           \
+        _Pragma("unroll") for (int b_ = 0; b_ < DB; b_++) A[b_] = pp_[b_ * 64]; \
+        if (ldch == 0) {                                              \
+            if (l2) yn_next = nsrc[(int64_t)ltile * 4];               \
+            ltile++;                                                  \
+        }                                                             \
+        if (++ldch == ncd) ldch = 0;                                  \
+    }
+#define AM_STEP(A)                                                                                           \
+    {                                                                                                        \
+        if (dch == 0) {                                                                                      \
+            _Pragma("unroll") for (int nq_ = 0; nq_ < NQ; nq_++) acc[nq_] = (f32x4){0.f, 0.f, 0.f, 0.f};     \
+        }                                                                                                    \
+        _Pragma("unroll") for (int b_ = 0; b_ < DB; b_++) {                                                  \
+            _Pragma("unroll") for (int nq_ = 0; nq_ < NQ; nq_++) {                                           \
+                const float4 bq_ = qs[(size_t)nq_ * nblk * 64 + (dch * DB + b_) * 64 + lane];                \
+                acc[nq_] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[b_].x, bq_.x, acc[nq_], 0, 0, 0);          \
+                acc[nq_] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[b_].y, bq_.y, acc[nq_], 0, 0, 0);          \
+                acc[nq_] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[b_].z, bq_.z, acc[nq_], 0, 0, 0);          \
+                acc[nq_] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[b_].w, bq_.w, acc[nq_], 0, 0, 0);          \
+            }                                                                                                \
+        }                                                                                                    \
+        if (++dch == ncd) {                                                                                  \
+            dch = 0;                                                                                         \
+            const float yv_[4] = {yn_cur.x, yn_cur.y, yn_cur.z, yn_cur.w};                                   \
+            const int row0_ = (tile << 4) + 4 * g;                                                           \
+            _Pragma("unroll") for (int nq_ = 0; nq_ < NQ; nq_++) {                                           \
+                _Pragma("unroll") for (int reg_ = 0; reg_ < 4; reg_++) {                                     \
+                    const float v_ = acc[nq_][reg_];                                                         \
+                    const uint32_t k_ = l2 ? ord_from_l2(l2_expanded(xnj[nq_], yv_[reg_], v_)) : ord_from_ip(v_); \
+                    const int r_ = row0_ + reg_;                                                             \
+                    if (r_ < P.nrows) {                                                                      \
+                        if (k_ < best_ord[nq_]) {                                                            \
+                            best_ord[nq_] = k_;                                                              \
+                            best_row[nq_] = r_;                                                              \
+                        } else if (k_ == best_ord[nq_] && best_row[nq_] >= 0 && P.ids[r_] < P.ids[best_row[nq_]]) { \
+                            best_row[nq_] = r_;                                                              \
+                        }                                                                                    \
+                    }                                                                                        \
+                }                                                                                            \
+            }                                                                                                \
+            yn_cur = yn_next;                                                                                \
+            tile++;                                                                                          \
+        }                                                                                                    \
+    }
+        AM_LOAD(a0, 0);
+        yn_cur = yn_next;
+        int s = 0;
+        while (s < nsteps) {
+            if (s + 1 < nsteps) AM_LOAD(a1, s + 1);
+            AM_STEP(a0);
+            s++;
+            if (s >= nsteps) break;
+            if (s + 1 < nsteps) AM_LOAD(a0, s + 1);
+            AM_STEP(a1);
+            s++;
+        }
+#undef AM_LOAD
+#undef AM_STEP
+    }
+    // lane -> (key << 32 | id); min over the 4 row groups of the wave, the 4 waves, then the workgroups
+#pragma unroll
+    for (int nq = 0; nq < NQ; nq++) {
+        unsigned long long v = ~0ull;
+        if (best_row[nq] >= 0) v = ((unsigned long long)best_ord[nq] << 32) | (unsigned long long)(uint32_t)P.ids[best_row[nq]];
+        unsigned long long o = __shfl_xor(v, 16);
+        v = o < v ? o : v;
+        o = __shfl_xor(v, 32);
+        v = o < v ? o : v;
+        if (g == 0) red[wave * (NQ * 16) + nq * 16 + j] = v;
+    }
+    __syncthreads();
+    if (tid < NQ * 16) {
+        unsigned long long v = red[tid];
+#pragma unroll
+        for (int w = 1; w < 4; w++) {
+            const unsigned long long o = red[w * (NQ * 16) + tid];
+            v = o < v ? o : v;
+        }
+        const int64_t q = q_base + tid;
+        if (q < P.Q && v != ~0ull) atomicMin(&P.best64[q], v);
+    }
+}
+
+__global__ void k_argmin_finish(const unsigned long long *best64, int64_t Q, int metric, int sqrt_l2, int64_t *out_ids, float *out_dist) {
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= Q) return;
+    const unsigned long long v = best64[q];
+    int64_t oid = -1;
+    float od = metric == QK_METRIC_IP ? -INFINITY : INFINITY;
+    if (v != ~0ull) {
+        oid = (int64_t)(v & 0xFFFFFFFFull);
+        const uint32_t o = (uint32_t)(v >> 32);
+        if (metric == QK_METRIC_L2) {
+            const float d2 = __uint_as_float(o);
+            od = sqrt_l2 ? sqrtf(d2) : d2;
+        } else {
+            od = ip_from_ord(o);
+        }
+    }
+    out_ids[q] = oid;
+    if (out_dist) out_dist[q] = od;
+}
+
+template <int DB, int NQ>
+static int launch_argmin_t(hipStream_t st, dim3 grid, size_t lds, const ArgminParams &ap) {
+    QK_HIP(hipFuncSetAttribute((const void *)k_dense_argmin<DB, NQ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_dense_argmin<DB, NQ>), grid, dim3(256), lds, st, ap);
+    return QK_OK;
+}
+
 template <int DB, int NQ>
 static int launch_dense_t(hipStream_t st, dim3 grid, size_t lds, const DenseParams &dp) {
     QK_HIP(hipFuncSetAttribute((const void *)k_dense_ord<DB, NQ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -384,6 +566,58 @@ int qk_dense_device(qk_ctx *ctx, qk_store *s, int64_t list_no, const qk_scan_arg
     while (NQ > 1 && (size_t)NQ * nblk * 1024 > 64 * 1024) NQ >>= 1;
     const size_t lds = (size_t)NQ * nblk * 1024 + (size_t)NQ * 16 * 4 + 64;
     if (lds > 160 * 1024) QK_FAIL(QK_ERR_UNSUPPORTED, "dense scan: d=%d too large for the LDS query tile", s->d);
+    if (k == 1 && nrows > 0 && s->max_id_seen < ((int64_t)1 << 32) && s->min_id_seen >= 0 && !getenv("QK_NO_ARGMIN")) {
+        // nprobe = 1 / nearest centroid: fused argmin, no key matrix
+        const size_t lds_a = lds + (size_t)4 * NQ * 16 * 8;
+        QK_TRY(qk_ws_reserve(ctx, (size_t)Q * 8 + 4096));
+        unsigned long long *best64 = (unsigned long long *)qk_ws_alloc(ctx, (size_t)Q * 8);
+        if (!best64) QK_FAIL(QK_ERR_OOM, "dense argmin: workspace exhausted");
+        const int num_cus_a = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
+        QK_TRY(pe.mark(0));
+        QK_TRY(pe.mark(1));
+        QK_HIP(hipMemsetAsync(best64, 0xFF, (size_t)Q * 8, st));
+        ArgminParams ap;
+        ap.vecs = (const float4 *)s->vecs;
+        ap.norms = s->norms;
+        ap.ids = s->ids + pt.row_off;
+        ap.row_off = pt.row_off;
+        ap.nrows = nrows;
+        ap.nblk = nblk;
+        ap.xq4 = a.xq4;
+        ap.xn = a.xn;
+        ap.Q = Q;
+        ap.metric = a.metric;
+        ap.best64 = best64;
+        const int64_t qgroups = (Q + NQ * 16 - 1) / (NQ * 16);
+        const int ntile = (nrows + 15) / 16;
+        // two workgroups per CU, at least 8 row tiles each (the query tile staging costs about as much as 8 tiles)
+        const int64_t want_chunks = std::max<int64_t>(1, ((int64_t)2 * num_cus_a + qgroups - 1) / qgroups);
+        int tiles_per_wg = (int)std::max<int64_t>(8, (ntile + want_chunks - 1) / want_chunks);
+        tiles_per_wg = qk_round_up(tiles_per_wg, 4);
+        ap.tiles_per_wg = tiles_per_wg;
+        const int rchunks = std::max(1, (ntile + tiles_per_wg - 1) / tiles_per_wg);
+        dim3 grid((unsigned)qgroups, (unsigned)rchunks);
+#define AM_CASE(D_, N_) \
+    if (DB == D_ && NQ == N_) QK_TRY((launch_argmin_t<D_, N_>(st, grid, lds_a, ap)));
+        AM_CASE(8, 4) AM_CASE(8, 2) AM_CASE(8, 1) AM_CASE(4, 4) AM_CASE(4, 2) AM_CASE(4, 1)
+        AM_CASE(2, 4) AM_CASE(2, 2) AM_CASE(2, 1) AM_CASE(1, 4) AM_CASE(1, 2) AM_CASE(1, 1)
+#undef AM_CASE
+        QK_TRY(pe.mark(2));
+        hipLaunchKernelGGL(k_argmin_finish, dim3((unsigned)((Q + 255) / 256)), dim3(256), 0, st, best64, Q, a.metric, a.sqrt_l2 ? 1 : 0,
+                           a.out_ids, a.out_dist);
+        QK_HIP(hipGetLastError());
+        QK_TRY(pe.mark(3));
+        if (timing) {
+            QK_TRY(qk_pinned_reserve(ctx, 64));
+            int32_t *hs = (int32_t *)ctx->pinned;
+            QK_HIP(hipStreamSynchronize(st));
+            hs[0] = 1;
+            hs[1] = 0;
+            int64_t rows = nrows;
+            memcpy(hs + 2, &rows, sizeof(rows));
+        }
+        return QK_OK;
+    }
     const int64_t ld = qk_round_up64(std::max(nrows, 1), 16);
     const int Cm = qk_round_up(k + 64, 64);
     const bool large_k = Cm > 1024;  // beyond the LDS pool machinery: bisection select + sort (k_select_rows_large)

@@ -230,6 +230,13 @@ void qk_store_ensure_index(qk_store *s) {
     s->index_valid = true;
 }
 
+static void note_ids(qk_store *s, const int64_t *ids, int64_t n) {
+    for (int64_t i = 0; i < n; i++) {
+        if (ids[i] > s->max_id_seen) s->max_id_seen = ids[i];
+        if (ids[i] < s->min_id_seen) s->min_id_seen = ids[i];
+    }
+}
+
 static int check_list(qk_store *s, int64_t list_no, const char *who) {
     if (list_no < 0 || list_no >= (int64_t)s->parts.size() || !s->parts[list_no].present)
         QK_FAIL(QK_ERR_NOT_FOUND, "List does not exist in %s (list %lld)", who, (long long)list_no);
@@ -452,6 +459,7 @@ int qk_store_add_entries(qk_store *s, int64_t list_no, int64_t n, const int64_t 
     }
     QK_TRY(qk_launch_ingest(c, (const float *)dv, (const int64_t *)di, n, s->d, s->nblk, s->vecs, s->norms, s->ids, p.row_off + p.size));
     QK_HIP(hipStreamSynchronize(c->stream));  // staging buffer / caller memory reusable on return
+    note_ids(s, p.ids.data() + old, n);
     if (s->index_valid)
         for (int64_t i = 0; i < n; i++) s->id_to_list[p.ids[old + i]] = (int32_t)list_no;
     p.size += n;
@@ -494,6 +502,7 @@ int qk_store_build_csr(qk_store *s, int64_t nlist, const int64_t *offsets, const
         hid = host_ids.data();
     }
     for (int64_t p = 0; p < nlist; p++) s->parts[p].ids.assign(hid + offsets[p], hid + offsets[p + 1]);
+    note_ids(s, hid, total);
     if (total > 0) {
         // CSR tables on the device
         int64_t *d_offsets = nullptr, *d_part_row = nullptr;
@@ -701,6 +710,8 @@ int qk_store_add_batch(qk_store *s, int64_t n, const int64_t *ids, const float *
         qk_part &p = s->parts[(size_t)h_assign[i]];
         rows[i] = p.row_off + p.size;
         p.ids.push_back(h_ids[i]);
+        if (h_ids[i] > s->max_id_seen) s->max_id_seen = h_ids[i];
+        if (h_ids[i] < s->min_id_seen) s->min_id_seen = h_ids[i];
         p.size++;
         if (s->index_valid) s->id_to_list[h_ids[i]] = (int32_t)h_assign[i];
     }
