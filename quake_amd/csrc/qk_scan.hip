@@ -122,6 +122,8 @@ struct GroupParams {
     int64_t *n_rows_unique;  // [1] sum of sizes of active partitions (algorithmic bytes / (d*4))
     int32_t *grouped_q;   // [npairs] query of each grouped entry
     int32_t *grouped_pair;// [npairs] pair index (q*P + r) of each grouped entry
+    int32_t *act_list;    // [min(npids, npairs)] partitions with at least one probing query, in first-hit order (k_group_count)
+    int32_t *n_act;       // its length (zeroed per call)
     int qgroup;           // query tiles that share one pass over a partition (k_scan's query-sharing workgroups), >= 1
     int32_t *pair_head;   // [npairs] head of the record chain of each pair (-1 = none)
     int32_t *pair_slots;  // [npairs][32]: {record count, first 31 record ids} -- what the merge reads in ONE load; later
@@ -141,7 +143,9 @@ __global__ void k_group_count(GroupParams G) {
     G.pair_head[i] = -1;
     G.pair_slots[i * QK_SLOTS] = 0;
     int p = pair_pid(G, i);
-    if (p >= 0) atomicAdd(&G.g_cnt[p], 1);
+    // the first query to reach a partition lists it: the scan below walks the probed partitions only, not all of them
+    // (a rank of an N-GPU index sees N x 4096 list numbers, 1/N of the batch's queries land on its own)
+    if (p >= 0 && atomicAdd(&G.g_cnt[p], 1) == 0) G.act_list[atomicAdd(G.n_act, 1)] = p;
 }
 
 // block-wide exclusive scan of one value per thread (1024 threads = 16 waves); returns the exclusive prefix, *total
@@ -184,19 +188,19 @@ __device__ __forceinline__ long long seq_weight(int cnt_q, int size_p, int G) {
 __global__ __launch_bounds__(1024) void k_group_scan(GroupParams G) {
     __shared__ long long s_w[48];
     const int tid = threadIdx.x;
-    const int per = (G.npids + 1023) / 1024;
-    const int b = tid * per, e = min(G.npids, b + per);
+    const int n_act = *G.n_act;
+    const int per = (n_act + 1023) / 1024;
+    const int b = tid * per, e = min(n_act, b + per);
     int sq = 0, sa = 0;
     long long stl = 0, sr = 0;
-    for (int p = b; p < e; p++) {
-        int c = G.g_cnt[p];
-        if (c > 0) {
-            int sz = G.pt_size[p];
-            sq += c;
-            sa += 1;
-            stl += seq_weight(c, sz, G.qgroup);
-            sr += sz;
-        }
+    for (int i = b; i < e; i++) {
+        const int p = G.act_list[i];
+        const int c = G.g_cnt[p];
+        const int sz = G.pt_size[p];
+        sq += c;
+        sa += 1;
+        stl += seq_weight(c, sz, G.qgroup);
+        sr += sz;
     }
     // three scans behind ONE pair of barriers: (active count | grouped-query count) packed in 64 bits (both < 2^31, so
     // the halves never carry into each other), tiles, rows (total only)
@@ -257,22 +261,21 @@ __global__ __launch_bounds__(1024) void k_group_scan(GroupParams G) {
         *G.n_tiles = tt;
         *G.n_rows_unique = tr;
     }
-    for (int p = b; p < e; p++) {
+    for (int i = b; i < e; i++) {
+        const int p = G.act_list[i];
+        const int c = G.g_cnt[p];
         G.g_qoff[p] = (int)aq;
-        int c = G.g_cnt[p];
-        if (c > 0) {
-            ActiveInfo inf;
-            inf.toff = at;
-            inf.row_off = G.pt_off[p];
-            inf.p = p;
-            inf.size = G.pt_size[p];
-            inf.cnt = c;
-            inf.qoff = (int)aq;
-            G.active[aa] = inf;
-            aq += c;
-            aa += 1;
-            at += seq_weight(c, G.pt_size[p], G.qgroup);
-        }
+        ActiveInfo inf;
+        inf.toff = at;
+        inf.row_off = G.pt_off[p];
+        inf.p = p;
+        inf.size = G.pt_size[p];
+        inf.cnt = c;
+        inf.qoff = (int)aq;
+        G.active[aa] = inf;
+        aq += c;
+        aa += 1;
+        at += seq_weight(c, G.pt_size[p], G.qgroup);
     }
 }
 
@@ -1238,6 +1241,7 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
     add((size_t)(npids + 1) * 4 + 64);
     add((size_t)np1 * 4 * 3);
     add((size_t)np1 * QK_SLOTS * 4);
+    add((size_t)(std::min<int64_t>(npids, np1) + 1) * 4 + 64);
     add((size_t)Q * 4);
     add((size_t)max_recs * 8);
     add((size_t)max_recs * k * 4);
@@ -1262,11 +1266,12 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
     int32_t *grouped_pair = grouped_q + np1;
     int32_t *pair_head = grouped_pair + np1;
     int32_t *pair_slots = (int32_t *)qk_ws_alloc(ctx, (size_t)np1 * QK_SLOTS * 4);
+    int32_t *act_list = (int32_t *)qk_ws_alloc(ctx, (size_t)(std::min<int64_t>(npids, np1) + 1) * 4 + 64);
     uint32_t *gtau = (uint32_t *)(scal + 64);
     int2 *rec_hdr = (int2 *)qk_ws_alloc(ctx, (size_t)max_recs * 8);
     uint32_t *rec_ord = (uint32_t *)qk_ws_alloc(ctx, (size_t)max_recs * k * 4);
     int64_t *rec_id = (int64_t *)qk_ws_alloc(ctx, (size_t)max_recs * k * 8);
-    if (!g_cnt || !active || !g_qoff || !grouped_q || !pair_slots || !gtau || !rec_hdr || !rec_ord || !rec_id)
+    if (!g_cnt || !active || !g_qoff || !grouped_q || !pair_slots || !act_list || !gtau || !rec_hdr || !rec_ord || !rec_id)
         QK_FAIL(QK_ERR_OOM, "qk_scan: workspace exhausted");
 
     QK_TRY(pe.mark(0));
@@ -1290,6 +1295,8 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
     G.grouped_pair = grouped_pair;
     G.pair_head = pair_head;
     G.qgroup = qshare ? nw : 1;
+    G.act_list = act_list;
+    G.n_act = scal + 6;  // zeroed with the other counters
     G.pair_slots = pair_slots;
     G.gtau = gtau;
     static const int no_seed = getenv("QK_NO_SEED") ? atoi(getenv("QK_NO_SEED")) : 0;
