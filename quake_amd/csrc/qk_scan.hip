@@ -137,15 +137,18 @@ __device__ __forceinline__ int pair_pid(const GroupParams &G, int64_t i) {
     return G.pt_size[p] > 0 ? (int)p : -1;
 }
 
-__global__ void k_group_count(GroupParams G) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= G.npairs) return;
+__device__ __forceinline__ void group_count_one(const GroupParams &G, int64_t i) {
     G.pair_head[i] = -1;
     G.pair_slots[i * QK_SLOTS] = 0;
     int p = pair_pid(G, i);
     // the first query to reach a partition lists it: the scan below walks the probed partitions only, not all of them
     // (a rank of an N-GPU index sees N x 4096 list numbers, 1/N of the batch's queries land on its own)
     if (p >= 0 && atomicAdd(&G.g_cnt[p], 1) == 0) G.act_list[atomicAdd(G.n_act, 1)] = p;
+}
+
+__global__ void k_group_count(GroupParams G) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < G.npairs) group_count_one(G, i);
 }
 
 // block-wide exclusive scan of one value per thread (1024 threads = 16 waves); returns the exclusive prefix, *total
@@ -184,18 +187,18 @@ __device__ __forceinline__ long long seq_weight(int cnt_q, int size_p, int G) {
     return (long long)ntl * ((long long)nfull * G + rp);
 }
 
-// single workgroup of 1024 threads: exclusive scans over the partitions.  Also clears the per-call counters.
-__global__ __launch_bounds__(1024) void k_group_scan(GroupParams G) {
-    __shared__ long long s_w[48];
+// single workgroup of 1024 threads: exclusive scans over the probed partitions
+__device__ __forceinline__ void group_scan_body(const GroupParams &G, long long *s_w /*[48] LDS*/) {
     const int tid = threadIdx.x;
-    const int n_act = *G.n_act;
+    // (agent-scope loads: in the single-kernel form the counters were just written with atomics by this workgroup)
+    const int n_act = __hip_atomic_load(G.n_act, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int per = (n_act + 1023) / 1024;
     const int b = tid * per, e = min(n_act, b + per);
     int sq = 0, sa = 0;
     long long stl = 0, sr = 0;
     for (int i = b; i < e; i++) {
         const int p = G.act_list[i];
-        const int c = G.g_cnt[p];
+        const int c = __hip_atomic_load(&G.g_cnt[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int sz = G.pt_size[p];
         sq += c;
         sa += 1;
@@ -263,7 +266,7 @@ __global__ __launch_bounds__(1024) void k_group_scan(GroupParams G) {
     }
     for (int i = b; i < e; i++) {
         const int p = G.act_list[i];
-        const int c = G.g_cnt[p];
+        const int c = __hip_atomic_load(&G.g_cnt[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         G.g_qoff[p] = (int)aq;
         ActiveInfo inf;
         inf.toff = at;
@@ -279,15 +282,35 @@ __global__ __launch_bounds__(1024) void k_group_scan(GroupParams G) {
     }
 }
 
-__global__ void k_group_scatter(GroupParams G) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= G.npairs) return;
+__global__ __launch_bounds__(1024) void k_group_scan(GroupParams G) {
+    __shared__ long long s_w[48];
+    group_scan_body(G, s_w);
+}
+
+__device__ __forceinline__ void group_scatter_one(const GroupParams &G, int64_t i) {
     int p = pair_pid(G, i);
     if (p >= 0) {
         int pos = atomicAdd(&G.g_cursor[p], 1);
         G.grouped_q[G.g_qoff[p] + pos] = (int32_t)(i / G.P);
         G.grouped_pair[G.g_qoff[p] + pos] = (int32_t)i;
     }
+}
+
+__global__ void k_group_scatter(GroupParams G) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < G.npairs) group_scatter_one(G, i);
+}
+
+// count + scan + scatter in ONE workgroup for small batches (<= QK_GROUP_SMALL pairs): two launches and two dependent
+// kernel boundaries less (bench configuration: 3 kernels, 20 us -> 1 kernel)
+constexpr int QK_GROUP_SMALL = 8192;
+__global__ __launch_bounds__(1024) void k_group_small(GroupParams G) {
+    __shared__ long long s_w[48];
+    for (int64_t i = threadIdx.x; i < G.npairs; i += 1024) group_count_one(G, i);
+    __syncthreads();
+    group_scan_body(G, s_w);
+    __syncthreads();
+    for (int64_t i = threadIdx.x; i < G.npairs; i += 1024) group_scatter_one(G, i);
 }
 
 // ---- bound seeding ---------------------------------------------------------------------------------------
@@ -1337,9 +1360,14 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
         else
             hipLaunchKernelGGL((k_seed_tau<8>), sg, dim3(64), 0, st, sd);
     }
-    if (npairs > 0) hipLaunchKernelGGL(k_group_count, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, st, G);
-    hipLaunchKernelGGL(k_group_scan, dim3(1), dim3(1024), 0, st, G);
-    if (npairs > 0) hipLaunchKernelGGL(k_group_scatter, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, st, G);
+    static const bool no_small = getenv("QK_NO_GROUP_SMALL") != nullptr;
+    if (npairs <= QK_GROUP_SMALL && !no_small) {
+        hipLaunchKernelGGL(k_group_small, dim3(1), dim3(1024), 0, st, G);
+    } else {
+        if (npairs > 0) hipLaunchKernelGGL(k_group_count, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, st, G);
+        hipLaunchKernelGGL(k_group_scan, dim3(1), dim3(1024), 0, st, G);
+        if (npairs > 0) hipLaunchKernelGGL(k_group_scatter, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, st, G);
+    }
     QK_TRY(pe.mark(1));
 
     // ---- scan ------------------------------------------------------------------------------------------------
