@@ -8,6 +8,8 @@
 //                       NQ*16 queries staged in LDS per workgroup, list rows streamed as A operands   -> MFMA-bound
 //   k_select_rows<MAXCH> one wave per query: threshold-filter + rank-compaction top-k over its key row -> L2/HBM-bound
 #include "qk_internal.h"
+
+#include <hipcub/hipcub.hpp>
 #include "qk_device.h"
 
 #include <algorithm>
@@ -257,6 +259,34 @@ struct SelectLargeParams {
     float *out_dist;
 };
 
+// key / id source of one query for select_large
+struct RowSrc {  // one list: keys in a row of the key matrix, ids in arena order
+    const uint32_t *row;
+    const int64_t *ids;
+    int n;
+    __device__ __forceinline__ uint32_t key(int i) const { return row[i]; }
+    __device__ __forceinline__ int64_t id(int i) const { return ids[i]; }
+};
+struct PairSrc {  // several lists: the query's keys are the concatenation of its P lists (qk_widek_device)
+    const uint32_t *row;       // keys + pair_base[q*P]
+    const int64_t *pbase;      // pair_base + q*P  (P + 1 entries, absolute)
+    const int64_t *pids;       // pids + q*P, or nullptr (pair r -> list r)
+    const int64_t *pt_off;
+    const int64_t *ids;        // arena ids
+    int P, n;
+    __device__ __forceinline__ uint32_t key(int i) const { return row[i]; }
+    __device__ __forceinline__ int64_t id(int i) const {
+        const int64_t pos = pbase[0] + i;
+        int lo = 0, hi = P;  // pbase[lo] <= pos < pbase[hi]
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (pbase[mid] <= pos) lo = mid; else hi = mid;
+        }
+        const int64_t pid = pids ? pids[lo] : lo;
+        return ids[pt_off[pid] + (pos - pbase[lo])];
+    }
+};
+
 __device__ __forceinline__ int block_sum_256(int v, int *s_red) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -267,28 +297,25 @@ __device__ __forceinline__ int block_sum_256(int v, int *s_red) {
     return s_red[0] + s_red[1] + s_red[2] + s_red[3];
 }
 
-__global__ __launch_bounds__(256) void k_select_rows_large(SelectLargeParams S) {
-    extern __shared__ __align__(16) unsigned char smem[];
-    __shared__ int s_red[4];
-    __shared__ int s_cnt;
+template <class Src>
+__device__ __forceinline__ void select_large(const Src &src, int k, int kp, int metric, int sqrt_l2, int64_t *out_ids, float *out_dist,
+                                             unsigned char *smem, int *s_red, int *s_cnt) {
     const int tid = threadIdx.x;
-    const int64_t q = blockIdx.x;
-    const int k = S.k, kp = S.kp, n = S.nrows;
+    const int n = src.n;
     uint32_t *e_ord = (uint32_t *)smem;                     // [kp]
     int64_t *e_id = (int64_t *)(smem + (size_t)kp * 4);     // [kp]
-    const uint32_t *row = S.D + q * S.ld;
     const int kk = min(k, n);  // fewer rows than k: everything is kept, the rest is padding
     // 1. k-th smallest key
     uint32_t T = 0;
     for (int b = 31; b >= 0; b--) {
         const uint32_t tr = T | (1u << b);
         int c = 0;
-        for (int i = tid; i < n; i += 256) c += row[i] < tr ? 1 : 0;
+        for (int i = tid; i < n; i += 256) c += src.key(i) < tr ? 1 : 0;
         if (block_sum_256(c, s_red) < kk) T = tr;
     }
     int c_lt = 0, c_eq = 0;
     for (int i = tid; i < n; i += 256) {
-        const uint32_t v = row[i];
+        const uint32_t v = src.key(i);
         c_lt += v < T ? 1 : 0;
         c_eq += v == T ? 1 : 0;
     }
@@ -302,25 +329,28 @@ __global__ __launch_bounds__(256) void k_select_rows_large(SelectLargeParams S) 
         for (int b = 62; b >= 0; b--) {
             const uint64_t tr = Iu | (1ull << b);
             int c = 0;
-            for (int i = tid; i < n; i += 256) c += (row[i] == T && (uint64_t)S.ids[i] < tr) ? 1 : 0;
+            for (int i = tid; i < n; i += 256) c += (src.key(i) == T && (uint64_t)src.id(i) < tr) ? 1 : 0;
             if (block_sum_256(c, s_red) < need) Iu = tr;
         }
         I = (int64_t)Iu;  // the need-th smallest tied id
     }
     // 3. gather + sort
-    if (tid == 0) s_cnt = 0;
+    if (tid == 0) *s_cnt = 0;
     for (int i = tid; i < kp; i += 256) {
         e_ord[i] = 0xFFFFFFFFu;
         e_id[i] = INT64_MAX;
     }
     __syncthreads();
     for (int i = tid; i < n; i += 256) {
-        const uint32_t v = row[i];
-        if (v < T || (v == T && need > 0 && S.ids[i] <= I)) {
-            const int sl = atomicAdd(&s_cnt, 1);
-            if (sl < kp) {
-                e_ord[sl] = v;
-                e_id[sl] = S.ids[i];
+        const uint32_t v = src.key(i);
+        if (v < T || (v == T && need > 0)) {
+            const int64_t vid = src.id(i);
+            if (v < T || vid <= I) {
+                const int sl = atomicAdd(s_cnt, 1);
+                if (sl < kp) {
+                    e_ord[sl] = v;
+                    e_id[sl] = vid;
+                }
             }
         }
     }
@@ -346,22 +376,74 @@ __global__ __launch_bounds__(256) void k_select_rows_large(SelectLargeParams S) 
     }
     for (int e = tid; e < k; e += 256) {
         int64_t oid = -1;
-        float od = S.metric == QK_METRIC_IP ? -INFINITY : INFINITY;
+        float od = metric == QK_METRIC_IP ? -INFINITY : INFINITY;
         if (e < kk) {
             oid = e_id[e];
             const uint32_t o = e_ord[e];
-            if (S.metric == QK_METRIC_L2) {
+            if (metric == QK_METRIC_L2) {
                 const float d2 = __uint_as_float(o);
-                od = S.sqrt_l2 ? sqrtf(d2) : d2;
+                od = sqrt_l2 ? sqrtf(d2) : d2;
             } else {
                 od = ip_from_ord(o);
             }
         }
-        S.out_ids[q * k + e] = oid;
-        if (S.out_dist) S.out_dist[q * k + e] = od;
+        out_ids[e] = oid;
+        if (out_dist) out_dist[e] = od;
     }
 }
 
+__global__ __launch_bounds__(256) void k_select_rows_large(SelectLargeParams S) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    __shared__ int s_red[4];
+    __shared__ int s_cnt;
+    const int64_t q = blockIdx.x;
+    RowSrc src;
+    src.row = S.D + q * S.ld;
+    src.ids = S.ids;
+    src.n = S.nrows;
+    select_large(src, S.k, S.kp, S.metric, S.sqrt_l2, S.out_ids + q * S.k, S.out_dist ? S.out_dist + q * S.k : nullptr, smem, s_red, &s_cnt);
+}
+
+// ---- wide k over several lists (QK_MAX_K < k <= QK_MAX_WIDE_K) ------------------------------------------------------------
+// qk_scan_device in key-emission mode writes every (pair, row) key; here: list sizes per pair, their prefix sums, and the
+// exact selection over each query's concatenated key segments.
+struct WideKParams {
+    const uint32_t *keys;
+    const int64_t *pair_base;  // [npairs + 1]
+    const int64_t *pids;       // [Q][P] or nullptr
+    const int64_t *pt_off;
+    const int64_t *ids;
+    int P, k, kp, metric, sqrt_l2;
+    int64_t *out_ids;
+    float *out_dist;
+};
+
+__global__ void k_pair_sizes(const int64_t *pids, int64_t npairs, int P, const int32_t *pt_size, int npids, int64_t *sizes) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > npairs) return;
+    int64_t sz = 0;
+    if (i < npairs) {
+        const int64_t p = pids ? pids[i] : (i % P);
+        if (p >= 0 && p < npids && pt_size[p] > 0) sz = pt_size[p];
+    }
+    sizes[i] = sz;  // sizes[npairs] = 0: the exclusive scan then ends with the total
+}
+
+__global__ __launch_bounds__(256) void k_select_pairs_large(WideKParams W) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    __shared__ int s_red[4];
+    __shared__ int s_cnt;
+    const int64_t q = blockIdx.x;
+    PairSrc src;
+    src.pbase = W.pair_base + q * W.P;
+    src.row = W.keys + src.pbase[0];
+    src.pids = W.pids ? W.pids + q * W.P : nullptr;
+    src.pt_off = W.pt_off;
+    src.ids = W.ids;
+    src.P = W.P;
+    src.n = (int)(src.pbase[W.P] - src.pbase[0]);
+    select_large(src, W.k, W.kp, W.metric, W.sqrt_l2, W.out_ids + q * W.k, W.out_dist ? W.out_dist + q * W.k : nullptr, smem, s_red, &s_cnt);
+}
 
 // ---- fused argmin: the coarse step with nprobe = 1 (and PartitionManager::add's k = 1 parent search) -------------------------
 // Same decomposition as k_dense_ord, but nothing is materialised: every lane keeps the best (key, row) of the rows it sees for
@@ -714,6 +796,75 @@ int qk_dense_device(qk_ctx *ctx, qk_store *s, int64_t list_no, const qk_scan_arg
         hs[1] = 0;
         int64_t rows = nrows;
         memcpy(hs + 2, &rows, sizeof(rows));
+    }
+    return QK_OK;
+}
+
+int qk_widek_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *timing, int ev_base) {
+    const int64_t Q = a.Q;
+    const int k = a.k;
+    if (k > QK_MAX_WIDE_K) QK_FAIL(QK_ERR_UNSUPPORTED, "qk_scan: k=%d exceeds %d", k, QK_MAX_WIDE_K);
+    QK_TRY(qk_store_sync_table(s));
+    const int npids = (int)s->parts.size();
+    const int P = a.all_lists ? npids : a.P;
+    if (P <= 0 || npids <= 0) QK_FAIL(QK_ERR_INVALID, "qk_scan: no lists to scan");
+    hipStream_t st = ctx->stream;
+    int kp = 1;
+    while (kp < k) kp <<= 1;
+    // queries per pass: the keys of one pass stay under 2^29 (2 GiB)
+    const int64_t per_query_ub = std::max<int64_t>(1, (int64_t)P * std::max<int64_t>(1, s->max_size));
+    const int64_t qc = std::max<int64_t>(1, std::min<int64_t>(Q, ((int64_t)1 << 29) / per_query_ub));
+    if (per_query_ub > ((int64_t)1 << 30)) QK_FAIL(QK_ERR_UNSUPPORTED, "qk_scan: k=%d with %d lists per query is too large", k, P);
+    const int nblk = s->nblk;
+    for (int64_t q0 = 0; q0 < Q; q0 += qc) {
+        const int64_t nq = std::min(qc, Q - q0);
+        const int64_t npairs = nq * P;
+        size_t cub_bytes = 0;
+        hipcub::DeviceScan::ExclusiveSum(nullptr, cub_bytes, (int64_t *)nullptr, (int64_t *)nullptr, (int)(npairs + 1), st);
+        auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+        const size_t o_sizes = 0, o_base = al((size_t)(npairs + 1) * 8), o_cub = o_base + al((size_t)(npairs + 1) * 8);
+        const size_t o_keys = o_cub + al(cub_bytes);
+        const size_t need = o_keys + (size_t)nq * per_query_ub * 4 + 256;
+        QK_TRY(qk_aps_reserve(ctx, need));  // (the scan below recycles ctx->ws; this buffer survives it)
+        char *B = ctx->aps;
+        int64_t *sizes = (int64_t *)(B + o_sizes), *pair_base = (int64_t *)(B + o_base);
+        uint32_t *keys = (uint32_t *)(B + o_keys);
+        const int64_t *pids = a.pids ? a.pids + q0 * P : nullptr;
+        hipLaunchKernelGGL(k_pair_sizes, dim3((unsigned)((npairs + 256) / 256)), dim3(256), 0, st, pids, npairs, P, s->d_size, npids, sizes);
+        QK_HIP(hipcub::DeviceScan::ExclusiveSum((void *)(B + o_cub), cub_bytes, sizes, pair_base, (int)(npairs + 1), st));
+        qk_scan_args e = a;
+        e.x = a.x + q0 * s->d;
+        e.xq4 = a.xq4 + q0 * nblk * 4;
+        e.xn = a.xn + q0;
+        e.Q = nq;
+        e.pids = pids;
+        e.key_out = keys;
+        e.pair_base = pair_base;
+        e.out_ids = nullptr;
+        e.out_dist = nullptr;
+        QK_TRY(qk_scan_device(ctx, s, e, nullptr, ev_base));
+        WideKParams w;
+        w.keys = keys;
+        w.pair_base = pair_base;
+        w.pids = pids;
+        w.pt_off = s->d_off;
+        w.ids = s->ids;
+        w.P = P;
+        w.k = k;
+        w.kp = kp;
+        w.metric = a.metric;
+        w.sqrt_l2 = a.sqrt_l2 ? 1 : 0;
+        w.out_ids = a.out_ids + q0 * k;
+        w.out_dist = a.out_dist ? a.out_dist + q0 * k : nullptr;
+        const size_t lds = (size_t)kp * 12;
+        QK_HIP(hipFuncSetAttribute((const void *)k_select_pairs_large, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_select_pairs_large, dim3((unsigned)nq), dim3(256), lds, st, w);
+        QK_HIP(hipGetLastError());
+    }
+    if (timing) {
+        QK_TRY(qk_pinned_reserve(ctx, 64));
+        QK_HIP(hipStreamSynchronize(st));
+        memset(ctx->pinned, 0, 32);
     }
     return QK_OK;
 }

@@ -151,6 +151,9 @@ struct qk_scan_args {
     bool per_pair = false;       // keep the P results of a query apart: out_* are [Q*P][k], one top-k per (query, list)
     // per_pair only: [Q] initial bound per query as ~ord (0 = none): entries worse than it are dropped in every list
     const uint32_t *tau_init = nullptr;
+    // key emission (internal, the k > QK_MAX_K path): no top-k, every (pair, row) key is written to key_out[pair_base[pair] + row]
+    uint32_t *key_out = nullptr;
+    const int64_t *pair_base = nullptr;
     const float4 *xq4 = nullptr;  // [Q][nblk][4] fragment-ordered queries (qk_prep_queries), required
     const float *xn = nullptr;    // [Q] squared norms, required
 };
@@ -161,6 +164,9 @@ int qk_merge_topk_device(qk_ctx *ctx, const int64_t *in_ids, const float *in_key
 int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *timing, int ev_base);
 // dense form (every query x one list, Q large): distance matrix on MFMA + per-query select.  qk_dense.hip
 int qk_dense_device(qk_ctx *ctx, qk_store *s, int64_t list_no, const qk_scan_args &a, qk_timing *timing, int ev_base);
+// k > QK_MAX_K over several lists: emit every key (qk_scan_device in emission mode), then exact selection per query.  qk_dense.hip
+int qk_widek_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *timing, int ev_base);
+constexpr int QK_MAX_WIDE_K = 4096;
 
 // phase events of one pipeline run: per-call mode (ctx->ev[ev_base..]) and/or deferred mode (parked in the ctx)
 struct qk_phase_events {

@@ -454,6 +454,9 @@ struct ScanParams {
     // of a partition at the same time, each with its own 16-query tile and pools in LDS, so that a partition probed by up
     // to 16*nw queries is fetched from HBM once (the later waves hit in L2).  0: waves split the tiles instead.
     int qshare;
+    // key emission (MODE 4, k > QK_MAX_K): no top-k at all, every (pair, row) key goes to key_out[pair_base[pair] + row]
+    uint32_t *key_out;
+    const int64_t *pair_base;
     long long *wave_clock;  // probe (QK_SCAN_WAVE_CLOCK): [waves][2] start / end of every wave in wall_clock64 ticks, or nullptr
 };
 
@@ -510,6 +513,7 @@ __global__ __launch_bounds__(256) void k_scan(ScanParams P) {
     const bool l2 = P.metric == QK_METRIC_L2;
     constexpr bool qshare = MODE == 3;
     constexpr bool PRODUCT = MODE == 0 || MODE == 3;
+    constexpr bool EMIT = MODE == 4;  // wide-k path: keys out, selection happens in k_select_rows_large afterwards
     const size_t per_wave = (size_t)nblk * 1024 + (size_t)16 * C * 12;  // qshare: every wave owns a query tile + pools
     float4 *qs = (float4 *)(smem + (qshare ? wv * per_wave : 0));             // [nblk*64] (shared by the workgroup unless qshare)
     unsigned char *pool_base = qshare ? smem + wv * per_wave + (size_t)nblk * 1024
@@ -682,7 +686,7 @@ __global__ __launch_bounds__(256) void k_scan(ScanParams P) {
         }                                                                                                  \
         if (++dch == ncd) {                                                                                \
             dch = 0;                                                                                       \
-            if (PRODUCT) {                                                                                 \
+            if (PRODUCT || EMIT) {                                                                         \
                 epilogue(tile, LIVE, Y, I0, I1);                                                           \
             } else {                                                                                       \
                 probe_sink += acc[0] + acc[1] + acc[2] + acc[3] + Y.x + (float)I0.x + (float)I1.x;         \
@@ -695,6 +699,18 @@ __global__ __launch_bounds__(256) void k_scan(ScanParams P) {
                 const int row0 = tl_ << 4;
                 const float yv[4] = {yn.x, yn.y, yn.z, yn.w};
                 const int64_t idv[4] = {ia.x, ia.y, ib.x, ib.y};
+                if (EMIT) {
+                    if (live && myq >= 0) {
+                        uint32_t *dst = P.key_out + P.pair_base[mypair] + row0 + 4 * g;
+#pragma unroll
+                        for (int reg = 0; reg < 4; reg++) {
+                            const float v = acc[reg];
+                            if (row0 + 4 * g + reg < size_p)
+                                dst[reg] = l2 ? ord_from_l2(l2_expanded(xnj, yv[reg], v)) : ord_from_ip(v);
+                        }
+                    }
+                    return;
+                }
                 // every 8 tiles pick up bounds published by other waves working on the same query (only when queries
                 // probe more than one partition: gtau is null otherwise).  Measured (scan_probe.py, 10M x 128, P=32)
                 // against a per-tile plain (L1-stale) load, a per-tile sc1 load in the prefetch stream and an
@@ -1097,7 +1113,21 @@ static int launch_scan_qs(dim3 grid, dim3 block, size_t lds, hipStream_t st, con
 // the (DB, MAXCH) combinations the query-sharing variant is compiled for (narrow rows, k <= 100)
 static bool have_scan_qs(int db, int maxch) { return (db == 8 || db == 4 || db == 2) && (maxch == 1 || maxch == 2 || maxch == 4); }
 
+template <int DB>
+static int launch_scan_emit(dim3 grid, dim3 block, size_t lds, hipStream_t st, const ScanParams &sp) {
+    QK_HIP(hipFuncSetAttribute((const void *)k_scan<DB, 1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_scan<DB, 1, 4>), grid, block, lds, st, sp);
+    return QK_OK;
+}
+
 static int launch_scan(int db, int maxch, dim3 grid, dim3 block, size_t lds, hipStream_t st, const ScanParams &sp) {
+    if (sp.key_out) {
+        if (db == 1) return launch_scan_emit<1>(grid, block, lds, st, sp);
+        if (db == 2) return launch_scan_emit<2>(grid, block, lds, st, sp);
+        if (db == 4) return launch_scan_emit<4>(grid, block, lds, st, sp);
+        if (db == 8) return launch_scan_emit<8>(grid, block, lds, st, sp);
+        return launch_scan_emit<16>(grid, block, lds, st, sp);
+    }
     if (sp.qshare) {
 #define QK_CASEQ(D, M) \
     if (db == D && maxch == M) return launch_scan_qs<D, M>(grid, block, lds, st, sp);
@@ -1129,13 +1159,18 @@ static int pick_maxch(int cap) { return cap <= 64 ? 1 : cap <= 128 ? 2 : cap <= 
 
 int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *timing, int ev_base) {
     const int64_t Q = a.Q;
-    const int k = a.k;
+    const bool emit = a.key_out != nullptr;  // key emission for qk_widek_device: no top-k, k plays no role here
+    const int k = emit ? 1 : a.k;
     if (Q <= 0) return QK_OK;
     if (k <= 0) QK_FAIL(QK_ERR_INVALID, "qk_scan: k must be positive");
-    // beyond the LDS pools only the one-list (flat / parent index) form is available: k_select_rows_large
-    const bool one_list = a.all_lists && s->nlist == 1;
-    if (k > QK_MAX_K && !(one_list && k <= QK_MAX_NPROBE))
-        QK_FAIL(QK_ERR_UNSUPPORTED, "qk_scan: k=%d exceeds QK_MAX_K=%d", k, QK_MAX_K);
+    // beyond the LDS pools: one list (flat / parent index) -> k_select_rows_large; several lists -> every key is emitted and
+    // selected afterwards (qk_widek_device)
+    const bool one_list = a.all_lists && s->nlist == 1 && !emit;
+    if (k > QK_MAX_K && !one_list) {
+        if (a.per_pair) QK_FAIL(QK_ERR_UNSUPPORTED, "qk_scan: k=%d exceeds QK_MAX_K=%d", k, QK_MAX_K);
+        return qk_widek_device(ctx, s, a, timing, ev_base);
+    }
+    if (k > QK_MAX_NPROBE) QK_FAIL(QK_ERR_UNSUPPORTED, "qk_scan: k=%d exceeds %d", k, QK_MAX_NPROBE);
     QK_TRY(qk_store_sync_table(s));
     const int npids = (int)s->parts.size();
     // dense form: every query against ONE list (the parent / flat index of query_coordinator.cpp:624-626,644)
@@ -1147,7 +1182,7 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
     }
     const int P = a.all_lists ? npids : a.P;
     // per-pair results: a bound learnt in one list must not prune another list's own top-k
-    const bool share_tau = a.share_tau && !a.per_pair;
+    const bool share_tau = a.share_tau && !a.per_pair && !emit;
     hipStream_t st = ctx->stream;
     const bool tm = ctx->timing && (timing || a.record_events);
     qk_phase_events pe;
@@ -1199,7 +1234,7 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
         const int64_t present = std::max<int64_t>(1, std::min<int64_t>(s->nlist, std::max<int64_t>(npairs, 1)));
         const int64_t per_list = npairs / present;
         const size_t per_wave = q_bytes + (size_t)16 * C * 12;
-        if (nw == 1 && !a.per_pair && qs_min > 0 && per_list >= qs_min && have_scan_qs(DB, pick_maxch(C))) {
+        if (nw == 1 && !a.per_pair && !emit && qs_min > 0 && per_list >= qs_min && have_scan_qs(DB, pick_maxch(C))) {
             // 2 waves per workgroup for moderately hot batches, 4 from ~6 queries per list on (measured: nprobe 8 -> 0.524 vs
             // 0.534 ms with 2 vs 4; nprobe 32 -> 1.199 vs 1.073 ms)
             static const int w_env = getenv("QK_SCAN_QSHARE_NW") ? atoi(getenv("QK_SCAN_QSHARE_NW")) : 0;
@@ -1405,6 +1440,8 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
         sp.metric = a.metric;
         sp.pair_head = pair_head;
         sp.qshare = qshare;
+        sp.key_out = a.key_out;
+        sp.pair_base = a.pair_base;
         sp.pair_slots = pair_slots;
         sp.rec_counter = rec_counter;
         sp.max_recs = (int32_t)max_recs;
@@ -1471,6 +1508,10 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
         }    }
     QK_TRY(pe.mark(2));
 
+    if (emit) {  // the caller selects from the emitted keys
+        QK_TRY(pe.mark(3));
+        return QK_OK;
+    }
     // ---- merge ---------------------------------------------------------------------------------------------------
     MergeParams mp;
     mp.P = a.per_pair ? 1 : P;  // per_pair: every (query, list) pair is merged on its own

@@ -132,7 +132,8 @@ def test_large_flat_list_vs_torch_bruteforce(ctx):
 
 
 def test_large_k_and_limits(ctx):
-    """k up to QK_MAX_K goes through the multi-chunk pools; beyond it the call fails loudly (no silent truncation)."""
+    """k up to QK_MAX_K goes through the multi-chunk pools, up to 4096 through key emission + selection; beyond that the call
+    fails loudly (no silent truncation)."""
     from quake_amd._lib import QK_MAX_K, QuakeHipError
     ivf = make_ivf(6000, 48, 6, seed=31)
     q = make_queries(40, 48, seed=32, like=ivf["x"])
@@ -142,8 +143,29 @@ def test_large_k_and_limits(ctx):
         oi, od = O.search(q, ivf["centroids"], ivf["vecs"], ivf["ids"], ivf["offsets"], 6, k, "l2", batched_scan=True)
         np.testing.assert_array_equal(gi, oi)
         np.testing.assert_array_equal(gd.view(np.uint32), od.view(np.uint32))
+    # beyond QK_MAX_K the keys are emitted and selected afterwards (k_scan MODE 4 + k_select_pairs_large): same answers
+    for k, metric_ in ((QK_MAX_K + 1, "l2"), (1000, "l2"), (777, "ip"), (4096, "l2")):
+        iv = make_ivf(6000, 48, 6, seed=33, metric=metric_)
+        vecs = iv["vecs"].copy()
+        a0, a1 = int(iv["offsets"][1]), int(iv["offsets"][2])
+        vecs[a0 + 50:a0 + 100] = vecs[a0:a0 + 50]  # duplicates inside a list: ties ordered by id
+        from quake_amd.capi import Store
+        sw = Store(ctx, 48)
+        sw.build_csr(iv["offsets"], iv["ids"], vecs)
+        qq = make_queries(9, 48, seed=34, like=iv["x"], metric=metric_)
+        rng = np.random.default_rng(35)
+        pids = np.stack([rng.permutation(6)[:4] for _ in range(9)]).astype(np.int64)
+        pids[2, 1] = -1
+        gi, gd = ctx.scan(sw, qq, pids, k, metric_)
+        oi, od = O.batched_serial_scan(qq, vecs, iv["ids"], iv["offsets"], pids, k, metric_)
+        np.testing.assert_array_equal(gi, oi)
+        np.testing.assert_array_equal(gd.view(np.uint32), od.view(np.uint32))
+    gi, gd = ctx.search(parent, s, q, 6, 2000, "l2")  # through the whole search, every list probed
+    oi, od = O.search(q, ivf["centroids"], ivf["vecs"], ivf["ids"], ivf["offsets"], 6, 2000, "l2", batched_scan=True)
+    np.testing.assert_array_equal(gi, oi)
+    np.testing.assert_array_equal(gd.view(np.uint32), od.view(np.uint32))
     with pytest.raises(QuakeHipError):
-        ctx.search(parent, s, q, 6, QK_MAX_K + 1, "l2")
+        ctx.search(parent, s, q, 6, 4097, "l2")
 
 
 @pytest.mark.parametrize("d,metric", [(768, "ip"), (768, "l2"), (1024, "l2"), (512, "ip")])
