@@ -930,7 +930,7 @@ __global__ __launch_bounds__(64) void k_merge(MergeParams M) {
     auto consume = [&](int rec, const int2 hdr, const uint32_t o0, const int64_t d0) {
         const int n = hdr.y;
         // a full record is sorted and holds k entries: its k-th key bounds the answer before anything is pooled
-        if (n >= k && k <= 64) tau = min(tau, (uint32_t)__builtin_amdgcn_readlane(o0, k - 1));
+        if (n >= k) tau = min(tau, k <= 64 ? (uint32_t)__builtin_amdgcn_readlane(o0, k - 1) : M.rec_ord[(int64_t)rec * k + k - 1]);
         for (int base = 0; base < n; base += 64) {
             const int e = base + lane;
             const bool has = e < n;
