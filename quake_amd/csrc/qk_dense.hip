@@ -159,11 +159,14 @@ __global__ __launch_bounds__(64) void k_select_rows(SelectParams S) {
     const uint32_t *row = S.D + q * S.ld;
     uint32_t tau = 0xFFFFFFFFu;
     int cnt = 0;
-    // pass 1: a bound without any top-k bookkeeping.  Every lane keeps the minimum of the keys it sees; the k-th smallest
-    // of the 64 lane minima has at least k keys <= it, so it bounds the k-th best overall (k <= 64).  Without it the
-    // first 64+ keys all pass (tau = inf) and the pool is compacted several times per query.
-    if (k <= 64) {
-        uint32_t lmin = 0xFFFFFFFFu;
+    // pass 1: a bound without any top-k bookkeeping.  Every lane keeps the m = ceil(k/64) smallest keys it sees; the k-th
+    // smallest of those 64*m values has at least k keys <= it, so it bounds the k-th best overall.  Without it the first keys
+    // all pass (tau = inf) and the pool is compacted over and over (k = 81: 199 us per launch instead of ~15).
+    if (k <= 512) {  // (this kernel serves k up to 960; beyond 8 values per lane it starts without a bound)
+        const int m = (k + 63) >> 6;  // 1..8
+        uint32_t lm[8];
+#pragma unroll
+        for (int t = 0; t < 8; t++) lm[t] = 0xFFFFFFFFu;
         for (int base = 0; base < S.nrows; base += 1024) {
             uint4 kv4[4];
 #pragma unroll
@@ -173,15 +176,42 @@ __global__ __launch_bounds__(64) void k_select_rows(SelectParams S) {
                 if (r0 < S.nrows) kv4[u] = *(const uint4 *)(row + r0);
             }
 #pragma unroll
-            for (int u = 0; u < 4; u++) lmin = min(lmin, min(min(kv4[u].x, kv4[u].y), min(kv4[u].z, kv4[u].w)));
+            for (int u = 0; u < 4; u++) {
+                const uint32_t kk4[4] = {kv4[u].x, kv4[u].y, kv4[u].z, kv4[u].w};
+#pragma unroll
+                for (int c4 = 0; c4 < 4; c4++) {
+                    uint32_t v = kk4[c4];
+                    if (m == 1) {
+                        lm[0] = min(lm[0], v);
+                    } else {
+#pragma unroll
+                        for (int t = 0; t < 8; t++) {  // sorted insertion into lm[0..m)
+                            if (t < m) {
+                                const uint32_t lo = min(lm[t], v);
+                                v = max(lm[t], v);
+                                lm[t] = lo;
+                            }
+                        }
+                    }
+                }
+            }
         }
-        int rk = 0;
-        for (int t = 0; t < 64; t++) {
-            const uint32_t ot = __builtin_amdgcn_readlane(lmin, t);
-            rk += (ot < lmin || (ot == lmin && t < lane)) ? 1 : 0;
+        // rank of every kept value among the 64*m under (value, slot, lane); the one with rank k-1 is the bound
+        uint32_t bound = 0xFFFFFFFFu;
+        for (int t = 0; t < m; t++) {
+            const uint32_t mine = t == 0 ? lm[0] : t == 1 ? lm[1] : t == 2 ? lm[2] : t == 3 ? lm[3] : t == 4 ? lm[4] : t == 5 ? lm[5] : t == 6 ? lm[6] : lm[7];
+            int rk = 0;
+            for (int tt = 0; tt < m; tt++) {
+                const uint32_t theirs = tt == 0 ? lm[0] : tt == 1 ? lm[1] : tt == 2 ? lm[2] : tt == 3 ? lm[3] : tt == 4 ? lm[4] : tt == 5 ? lm[5] : tt == 6 ? lm[6] : lm[7];
+                for (int l = 0; l < 64; l++) {
+                    const uint32_t ot = __builtin_amdgcn_readlane(theirs, l);
+                    rk += (ot < mine || (ot == mine && (tt < t || (tt == t && l < lane)))) ? 1 : 0;
+                }
+            }
+            const uint64_t mk = __ballot(rk == k - 1);
+            if (mk) bound = __builtin_amdgcn_readlane(mine, __ffsll((unsigned long long)mk) - 1);
         }
-        const uint64_t mk = __ballot(rk == k - 1);
-        tau = __builtin_amdgcn_readlane(lmin, __ffsll((unsigned long long)mk) - 1);
+        tau = bound;
     }
     // 4 keys per lane per load (16 B), 4 loads in flight: 1024 rows per wave step
     for (int base = 0; base < S.nrows; base += 1024) {
@@ -212,9 +242,10 @@ __global__ __launch_bounds__(64) void k_select_rows(SelectParams S) {
                         pool_id[sl] = S.ids[r];
                     }
                     cnt += __popcll(m);
-                    if (cnt > Cm - 64) {
-                        cnt = compact_pool<MAXCH>(pool_ord, pool_id, cnt, k, lane);
-                        if (cnt >= k) tau = min(tau, pool_ord[k - 1]);
+                    if (cnt > Cm - 64) {  // (unsorted k best + their bound; the final compaction sorts)
+                        uint32_t kth;
+                        cnt = select_pool<MAXCH>(pool_ord, pool_id, cnt, k, lane, kth);
+                        if (cnt >= k) tau = min(tau, kth);
                     }
                 }
             }

@@ -16,7 +16,7 @@ for nl in (4096, 8192, 16384, 32768, 65536):
     c = torch.randn(nl, d, generator=g, device=dev)
     parent = Store(ctx, d)
     parent.build_csr(np.array([0, nl], np.int64), torch.arange(nl, device=dev), c)
-    for nprobe in (1, 32):
+    for nprobe in (1, 32, 100, 400):
         for _ in range(3):
             ctx.coarse(parent, q, nprobe, "l2")
         torch.cuda.synchronize()
