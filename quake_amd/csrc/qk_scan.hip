@@ -800,7 +800,10 @@ __global__ __launch_bounds__(256) void k_scan(ScanParams P) {
                 if (coop) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             }
             if (!QK_OPT_EARLY_LOAD) QK_LOAD(a0, y0, i00, i01);
-            // (a third tile buffer was measured at 4 waves per CU: 0.266 -> 0.294 ms, slower)
+            // (a third tile buffer was measured twice at 4 waves per CU: 0.265 -> 0.296 ms, slower, with counted vmcnt waits in
+            //  the ISA; at 3 waves per CU it makes no difference.  Probe modes on the bench configuration: loads only 0.229 ms,
+            //  + MFMA 0.236 ms, + top-k 0.265 ms at any of 4 / 6 / 8 waves per CU -- the gap to the stream is the top-k path
+            //  (cold starts after the seed bound, segment-end compaction and record emission), not latency hiding.)
             for (int s = 0; s < nsteps; s += 2) {
                 QK_LOAD(a1, y1, i10, i11);
                 QK_STEP(a0, y0, i00, i01, true);
@@ -1384,7 +1387,9 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
         sd.metric = a.metric;
         sd.gtau = gtau;
         sd.seed_ranks = std::min(2, G.P);
-        // (a side stream + fork/join events was measured slower than running it in line: 45 vs 40 us group phase)
+        // (a side stream + fork/join events was measured slower than running it in line: 45 vs 40 us group phase.
+        //  Larger samples -- 128 / 256 rows, scalar or on MFMA with all tile loads in flight -- take 6-12 us off k_scan and
+        //  add 10-40 us here: the kernel is a chain of five dependent memory round trips, not arithmetic.)
         const dim3 sg((unsigned)(Q * sd.seed_ranks));
         if (k <= 64)
             hipLaunchKernelGGL((k_seed_tau<1>), sg, dim3(64), 0, st, sd);
