@@ -537,6 +537,7 @@ __global__ __launch_bounds__(256) void k_scan(ScanParams P) {
     const int n_active = *P.n_active;
     int pend_rec = -1, pend_old = -1, pend_cnt = 0;  // deferred header store of this lane's previous record
     int dbg_comp = 0, dbg_app = 0, dbg_seg = 0;       // probe counters (QK_SCAN_WAVE_CLOCK)
+    long long dbg_t_end = 0, dbg_t_stage = 0;         // probe: ticks spent in segment ends / query staging
     for (;;) {
     if (T1 > T0) {
     // 64-ary search for the partition containing tile T0: active[lo].toff <= T0 < active[lo+1].toff
@@ -775,6 +776,7 @@ __global__ __launch_bounds__(256) void k_scan(ScanParams P) {
 
             if (QK_OPT_EARLY_LOAD) QK_LOAD(a0, y0, i00, i01);
             // ---- query tile -> LDS in B-operand lane order (wave-private), while the first tile is in flight --------
+            const long long dbg_s0 = P.wave_clock ? wall_clock64() : 0;
             {
                 const int qsafe = myq >= 0 ? myq : 0;
                 const float4 *qsrc = P.xq4 + (int64_t)qsafe * nblk * 4 + g;
@@ -799,6 +801,7 @@ __global__ __launch_bounds__(256) void k_scan(ScanParams P) {
                 }
                 if (coop) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             }
+            if (P.wave_clock) dbg_t_stage += wall_clock64() - dbg_s0;
             if (!QK_OPT_EARLY_LOAD) QK_LOAD(a0, y0, i00, i01);
             // (a third tile buffer was measured twice at 4 waves per CU: 0.265 -> 0.296 ms, slower, with counted vmcnt waits in
             //  the ISA; at 3 waves per CU it makes no difference.  Probe modes on the bench configuration: loads only 0.229 ms,
@@ -817,6 +820,7 @@ __global__ __launch_bounds__(256) void k_scan(ScanParams P) {
             if (!PRODUCT && probe_sink == 12345.678f) my_ord[0] = 1;  // keep the probe's loads alive
         }
         // ---- segment end: final compaction (sorts, caps at k), publish bound, emit records ---------------------------
+        const long long dbg_e0 = P.wave_clock ? wall_clock64() : 0;
         {
             uint64_t need = __ballot(cnt > 0) & 0xFFFFull;
             while (need) {
@@ -869,6 +873,7 @@ __global__ __launch_bounds__(256) void k_scan(ScanParams P) {
                 }
             }
         }
+        if (P.wave_clock) dbg_t_end += wall_clock64() - dbg_e0;
     }
     }  // range
         if (!dyn) break;
@@ -887,6 +892,8 @@ __global__ __launch_bounds__(256) void k_scan(ScanParams P) {
         wcp[2] = dbg_comp;
         wcp[3] = dbg_app;
         wcp[4] = dbg_seg;
+        wcp[5] = dbg_t_end;
+        wcp[6] = dbg_t_stage;
     }
 }
 
@@ -1489,12 +1496,12 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
                 t0 = std::min(t0, h[8 * i]);
                 t1 = std::max(t1, h[8 * i + 1]);
             }
-            struct W { long long end, comp, app, seg; };
+            struct W { long long end, comp, app, seg, tend, tstage; };
             std::vector<W> ws;
             double sum = 0;
             for (size_t i = 0; i < nwv; i++) {
                 if (h[8 * i + 1] == 0) continue;
-                ws.push_back({h[8 * i + 1] - t0, h[8 * i + 2], h[8 * i + 3], h[8 * i + 4]});
+                ws.push_back({h[8 * i + 1] - t0, h[8 * i + 2], h[8 * i + 3], h[8 * i + 4], h[8 * i + 5], h[8 * i + 6]});
                 sum += (double)(h[8 * i + 1] - t0);
             }
             std::sort(ws.begin(), ws.end(), [](const W &a, const W &b) { return a.end < b.end; });
@@ -1503,11 +1510,11 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
                 fprintf(stderr, "[k_scan waves] n=%zu span=%lld ticks  end-time pct: p10=%lld p50=%lld p90=%lld p99=%lld max=%lld mean=%.0f (100 MHz ticks)\n",
                         n, t1 - t0, ws[n / 10].end, ws[n / 2].end, ws[n * 9 / 10].end, ws[n * 99 / 100].end, ws.back().end, sum / n);
                 for (int dec = 0; dec < 10; dec++) {  // per decile of end time: mean compactions / appends / segment starts
-                    double c = 0, a_ = 0, sg = 0, e = 0;
+                    double c = 0, a_ = 0, sg = 0, e = 0, te = 0, tsg = 0;
                     size_t lo = n * dec / 10, hi = n * (dec + 1) / 10;
-                    for (size_t i = lo; i < hi; i++) { c += ws[i].comp; a_ += ws[i].app; sg += ws[i].seg; e += ws[i].end; }
+                    for (size_t i = lo; i < hi; i++) { c += ws[i].comp; a_ += ws[i].app; sg += ws[i].seg; e += ws[i].end; te += ws[i].tend; tsg += ws[i].tstage; }
                     const double m = (double)std::max<size_t>(1, hi - lo);
-                    fprintf(stderr, "   decile %d: end=%.0f compactions=%.1f appends=%.0f segments=%.2f\n", dec, e / m, c / m, a_ / m, sg / m);
+                    fprintf(stderr, "   decile %d: end=%.0f compactions=%.1f appends=%.0f segments=%.2f seg_end_ticks=%.0f staging_ticks=%.0f\n", dec, e / m, c / m, a_ / m, sg / m, te / m, tsg / m);
                 }
             }
         }    }
