@@ -832,24 +832,25 @@ __global__ __launch_bounds__(256) void k_scan(ScanParams P) {
             }
             const uint64_t have = __ballot(cnt > 0) & 0xFFFFull;
             if (have) {
-                // record slots were reserved at segment start (base_rec .. base_rec + nq): no atomic round trip here
+                // the two atomics of an emission -- a slot in the pair's line, record numbers for the segment -- do not depend
+                // on each other: both are issued before either result is awaited (one round trip instead of two)
+                int slot = -1;
+                if (lane < 16 && cnt > 0) slot = atomicAdd(&P.pair_slots[(int64_t)mypair * QK_SLOTS], 1);
                 if (!QK_OPT_EARLY_REC && lane == 0) base_rec = atomicAdd(P.rec_counter, nq);
                 const int rec0 = __builtin_amdgcn_readfirstlane(base_rec);
                 int myrec = -1;
                 if (lane < 16 && cnt > 0) {
                     myrec = rec0 + lane;
+                    // the first 31 records of a pair are listed in its slot line (the merge fetches them together, no
+                    // pointer chase); further ones are chained through pair_head.  (max_recs is an upper bound of the
+                    // records a launch can emit; a slot taken for a record beyond it reads as "none")
+                    if (slot < QK_SLOTS - 1) P.pair_slots[(int64_t)mypair * QK_SLOTS + 1 + slot] = myrec < P.max_recs ? myrec : -1;
                     if (myrec < P.max_recs) {
                         // the store of the previous head is deferred to the next emit (or kernel end) so that the
                         // wave does not stall on the exchange's round trip
                         if (pend_rec >= 0) P.rec_hdr[pend_rec] = make_int2(pend_old, pend_cnt);
-                        // the first 31 records of a pair are listed in its slot line (the merge fetches them together,
-                        // no pointer chase); further ones are chained through pair_head
-                        const int slot = atomicAdd(&P.pair_slots[(int64_t)mypair * QK_SLOTS], 1);
                         pend_old = -1;
-                        if (slot < QK_SLOTS - 1)
-                            P.pair_slots[(int64_t)mypair * QK_SLOTS + 1 + slot] = myrec;
-                        else
-                            pend_old = atomicExch(&P.pair_head[mypair], myrec);
+                        if (slot >= QK_SLOTS - 1) pend_old = atomicExch(&P.pair_head[mypair], myrec);
                         pend_rec = myrec;
                         pend_cnt = cnt;
                         if (!QK_OPT_EARLY_REC) {
