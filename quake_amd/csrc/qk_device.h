@@ -27,7 +27,17 @@ __device__ __forceinline__ float l2_expanded(float xn, float yn, float ip) {
 // ---- LDS pool compaction (the TopkBuffer::flush of this design) ------------------------------------
 // Keeps the k best of n entries under the total order (ord, id, position) and leaves them sorted in [0,k).
 template <int MAXCH>
+__device__ __forceinline__ int select_core(uint32_t *ord, int64_t *id, int n, int k, int lane, uint32_t &kth);
+
+template <int MAXCH>
 __device__ __forceinline__ int compact_pool(uint32_t *ord, int64_t *id, int n, int k, int lane) {
+    // wider than one wave: the rank sort below costs n x MAXCH; cut to the k survivors first (bisection select, measured
+    // 2.2 us against 17 us for ranking 192 entries) -- unless a tie on the k-th key needs the full order
+    if (MAXCH > 1) {
+        n = __builtin_amdgcn_readfirstlane(n);
+        uint32_t kth_;
+        if (n > k && select_core<MAXCH>(ord, id, n, k, lane, kth_) == k) n = k;
+    }
     uint32_t o[MAXCH];
     int64_t d[MAXCH];
     int rk[MAXCH];
@@ -93,13 +103,9 @@ __device__ __forceinline__ int compact_pool(uint32_t *ord, int64_t *id, int n, i
 // A tie on the key that straddles the cut needs the (id, position) order: that case falls back to compact_pool.  The
 // segment-end compaction always goes through compact_pool, so records leave the kernel sorted under the total order.
 template <int MAXCH>
-__device__ __forceinline__ int select_pool(uint32_t *ord, int64_t *id, int n, int k, int lane, uint32_t &kth) {
-    n = __builtin_amdgcn_readfirstlane(n);
-    if (n <= k) {
-        const int nn = compact_pool<MAXCH>(ord, id, n, k, lane);
-        kth = nn >= k ? ord[k - 1] : 0xFFFFFFFFu;
-        return nn;
-    }
+__device__ __forceinline__ int select_core(uint32_t *ord, int64_t *id, int n, int k, int lane, uint32_t &kth) {
+    // (n > k; returns k with the survivors packed into [0, k), or -1 with the pool untouched when several entries share the
+    //  k-th key -- that cut needs the (id, position) order)
     uint32_t o[MAXCH];
     int64_t d[MAXCH];
 #pragma unroll
@@ -121,11 +127,7 @@ __device__ __forceinline__ int select_pool(uint32_t *ord, int64_t *id, int n, in
     int c_le = 0;
 #pragma unroll
     for (int i = 0; i < MAXCH; i++) c_le += __popcll(__ballot(o[i] <= T));
-    if (c_le != k) {  // several entries share the k-th key
-        const int nn = compact_pool<MAXCH>(ord, id, n, k, lane);
-        kth = ord[k - 1];
-        return nn;
-    }
+    if (c_le != k) return -1;  // several entries share the k-th key
     int base = 0;
 #pragma unroll
     for (int i = 0; i < MAXCH; i++) {
@@ -140,4 +142,13 @@ __device__ __forceinline__ int select_pool(uint32_t *ord, int64_t *id, int n, in
     }
     kth = T;
     return k;
+}
+
+template <int MAXCH>
+__device__ __forceinline__ int select_pool(uint32_t *ord, int64_t *id, int n, int k, int lane, uint32_t &kth) {
+    n = __builtin_amdgcn_readfirstlane(n);
+    if (n > k && select_core<MAXCH>(ord, id, n, k, lane, kth) == k) return k;
+    const int nn = compact_pool<MAXCH>(ord, id, n, k, lane);  // n <= k, or a tie on the k-th key
+    kth = nn >= k ? ord[k - 1] : 0xFFFFFFFFu;
+    return nn;
 }
