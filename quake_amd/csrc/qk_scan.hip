@@ -124,6 +124,7 @@ struct GroupParams {
     int32_t *grouped_pair;// [npairs] pair index (q*P + r) of each grouped entry
     int32_t *act_list;    // [min(npids, npairs)] partitions with at least one probing query, in first-hit order (k_group_count)
     int32_t *n_act;       // its length (zeroed per call)
+    int seg_ovh;          // sequence units charged for the start of a pass (see seq_weight)
     int qgroup;           // query tiles that share one pass over a partition (k_scan's query-sharing workgroups), >= 1
     int32_t *pair_head;   // [npairs] head of the record chain of each pair (-1 = none)
     int32_t *pair_slots;  // [npairs][32]: {record count, first 31 record ids} -- what the merge reads in ONE load; later
@@ -180,11 +181,14 @@ __device__ __forceinline__ T block_exscan_1024(T v, T *s_wave /*[16]*/, T *total
 // over the row tiles serves up to G query tiles; a pass with q' = 1, 2 or 4 (rounded up) query tiles keeps q' of the G waves
 // busy per tile cut, so it weighs q' units per row tile -- the sequence is measured in workgroup time, which is what the
 // static cut has to balance.
-__device__ __forceinline__ long long seq_weight(int cnt_q, int size_p, int G) {
+__device__ __forceinline__ long long seq_weight(int cnt_q, int size_p, int G, int ovh) {
     const int nqt = (cnt_q + 15) >> 4, ntl = (size_p + 15) >> 4;
     const int nfull = nqt / G, rem = nqt % G;
     const int rp = rem == 0 ? 0 : rem <= 1 ? 1 : rem <= 2 ? 2 : 4;
-    return (long long)ntl * ((long long)nfull * G + rp);
+    // + ovh units in front of every pass: what starting a segment costs (query staging, cold start of the pools, record
+    // emission).  Every wave of the workgroup pays it at the same time whatever the width of the pass, so it is a constant
+    // number of units (steps x waves) -- a range that holds more pass starts gets fewer row tiles
+    return (long long)ntl * ((long long)nfull * G + rp) + (long long)ovh * (nfull + (rem > 0 ? 1 : 0));
 }
 
 // single workgroup of 1024 threads: exclusive scans over the probed partitions
@@ -202,7 +206,7 @@ __device__ __forceinline__ void group_scan_body(const GroupParams &G, long long 
         const int sz = G.pt_size[p];
         sq += c;
         sa += 1;
-        stl += seq_weight(c, sz, G.qgroup);
+        stl += seq_weight(c, sz, G.qgroup, G.seg_ovh);
         sr += sz;
     }
     // three scans behind ONE pair of barriers: (active count | grouped-query count) packed in 64 bits (both < 2^31, so
@@ -278,7 +282,7 @@ __device__ __forceinline__ void group_scan_body(const GroupParams &G, long long 
         G.active[aa] = inf;
         aq += c;
         aa += 1;
-        at += seq_weight(c, G.pt_size[p], G.qgroup);
+        at += seq_weight(c, G.pt_size[p], G.qgroup, G.seg_ovh);
     }
 }
 
@@ -454,6 +458,7 @@ struct ScanParams {
     // of a partition at the same time, each with its own 16-query tile and pools in LDS, so that a partition probed by up
     // to 16*nw queries is fetched from HBM once (the later waves hit in L2).  0: waves split the tiles instead.
     int qshare;
+    int seg_ovh;  // as GroupParams::seg_ovh
     // key emission (MODE 4, k > QK_MAX_K): no top-k at all, every (pair, row) key goes to key_out[pair_base[pair] + row]
     uint32_t *key_out;
     const int64_t *pair_base;
@@ -572,7 +577,8 @@ __global__ __launch_bounds__(256) void k_scan(ScanParams P) {
         // position inside the partition's weighted sequence (seq_weight): full passes weigh G units per row tile, the last
         // pass q' = 1, 2 or 4; a row tile belongs to the range that holds its first unit
         const int nfull = nqt / G;
-        const long long wfull = (long long)ntl * G;
+        const int ovh = P.seg_ovh;  // units in front of every pass that stand for the cost of starting it (no row tiles)
+        const long long wfull = (long long)ntl * G + ovh;
         int grp, wq;
         long long off;
         if (local < nfull * wfull) {
@@ -585,12 +591,13 @@ __global__ __launch_bounds__(256) void k_scan(ScanParams P) {
             const int rem = nqt - nfull * G;
             wq = rem <= 1 ? 1 : rem <= 2 ? 2 : 4;
         }
-        const long long off_end = min((long long)ntl * wq, off + (T1 - cur));
-        const int tl_wg = (int)((off + wq - 1) / wq);
-        const int tend_wg = (int)((off_end + wq - 1) / wq);
+        const long long pass_len = (long long)ntl * wq + ovh;
+        const long long off_end = min(pass_len, off + (T1 - cur));
+        const int tl_wg = (int)((max(0ll, off - ovh) + wq - 1) / wq);
+        const int tend_wg = (int)((max(0ll, off_end - ovh) + wq - 1) / wq);
         cur += off_end - off;
-        if (tend_wg <= tl_wg) {  // a range boundary inside one row tile's units: nothing starts here
-            if (grp == ngrp - 1 && off_end == (long long)ntl * wq) ai++;
+        if (tend_wg <= tl_wg) {  // a range boundary inside one row tile's units or inside the start charge: nothing here
+            if (grp == ngrp - 1 && off_end == pass_len) ai++;
             continue;
         }
         // this wave's query tile and its contiguous share of the segment's tiles:
@@ -610,7 +617,7 @@ __global__ __launch_bounds__(256) void k_scan(ScanParams P) {
         }
         const int tl = idle ? tend_wg : tl_wg + (int)(((long long)(tend_wg - tl_wg) * part) / parts);
         const int tend = idle ? tend_wg : tl_wg + (int)(((long long)(tend_wg - tl_wg) * (part + 1)) / parts);
-        if (grp == ngrp - 1 && off_end == (long long)ntl * wq) ai++;  // item sequence of this partition exhausted
+        if (grp == ngrp - 1 && off_end == pass_len) ai++;  // item sequence of this partition exhausted
         const int nq = idle ? 0 : min(16, cnt_p - 16 * qt);
         const int gidx = inf.qoff + 16 * qt + j;
         // grouped entry of this lane's query + record slots for the segment: issued FIRST so that they return first
@@ -1382,7 +1389,18 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
     G.grouped_q = grouped_q;
     G.grouped_pair = grouped_pair;
     G.pair_head = pair_head;
+    // start charge of a pass in the static cut: QK_SCAN_SEG_OVH row-tile steps of a d = 128 tile (8 KB), scaled to the
+    // tile of this index, times the waves of a workgroup (they all pay it at once).  Measured (10M x 128, batch 10000):
+    // nprobe 32 +11 %, nprobe 8 +1 % with 8 steps; nothing beyond noise for one-wave workgroups (nprobe 1) or wide rows,
+    // where the charge stays off unless QK_SCAN_SEG_OVH_ALL=1.
+    static const int seg_ovh_env = getenv("QK_SCAN_SEG_OVH") ? atoi(getenv("QK_SCAN_SEG_OVH")) : 8;
+    static const bool seg_ovh_all = getenv("QK_SCAN_SEG_OVH_ALL") && atoi(getenv("QK_SCAN_SEG_OVH_ALL")) != 0;
+    const int64_t tile_bytes = 64 * (int64_t)s->dpad;
+    const int seg_ovh = (seg_ovh_env <= 0 || !(qshare || seg_ovh_all))
+                            ? 0
+                            : (int)std::max<int64_t>(1, ((int64_t)seg_ovh_env * 8192 + tile_bytes / 2) / tile_bytes) * nw;
     G.qgroup = qshare ? nw : 1;
+    G.seg_ovh = seg_ovh;
     G.act_list = act_list;
     G.n_act = scal + 6;  // zeroed with the other counters
     G.pair_slots = pair_slots;
@@ -1470,6 +1488,7 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
         sp.metric = a.metric;
         sp.pair_head = pair_head;
         sp.qshare = qshare;
+        sp.seg_ovh = seg_ovh;
         sp.key_out = a.key_out;
         sp.pair_base = a.pair_base;
         sp.pair_slots = pair_slots;
