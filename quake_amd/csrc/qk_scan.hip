@@ -33,6 +33,7 @@
 #include <algorithm>
 #include <climits>
 #include <cstdlib>
+#include <cstring>
 
 // ---- query preparation -----------------------------------------------------------------------------
 // xq4[(q*nblk + c)*4 + g] = {x[q][16c+g], x[q][16c+g+4], x[q][16c+g+8], x[q][16c+g+12]}  (B-operand order)
@@ -1525,7 +1526,16 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
         if (probe_clock) {  // debug probe: distribution of the waves' busy time (tail = what a dynamic split could recover)
             std::vector<long long> h((size_t)grid * nw * 8);
             QK_HIP(hipMemcpyAsync(h.data(), d_clock, h.size() * 8, hipMemcpyDeviceToHost, st));
+            int32_t hscal[8];
+            QK_HIP(hipMemcpyAsync(hscal, scal, sizeof(hscal), hipMemcpyDeviceToHost, st));
             QK_HIP(hipStreamSynchronize(st));
+            {
+                int64_t units, rows;
+                std::memcpy(&units, hscal + 4, 8);
+                std::memcpy(&rows, hscal + 2, 8);
+                fprintf(stderr, "[k_scan launch] grid=%lld nw=%d qshare=%d seg_ovh=%d active=%d records=%d unique_rows=%lld sequence_units=%lld\n",
+                        (long long)grid, nw, (int)qshare, seg_ovh, hscal[0], hscal[1], (long long)rows, (long long)units);
+            }
             long long t0 = LLONG_MAX, t1 = 0;
             const size_t nwv = h.size() / 8;
             for (size_t i = 0; i < nwv; i++) {
