@@ -481,6 +481,12 @@ struct ScanParams {
 // Dynamic tail.  Measured on the bench configuration (QK_SCAN_DYN_PCT / QK_SCAN_DYN_CHUNK sweeps): 20 % in 16-tile chunks
 // takes 5-12 % off k_scan at 6 or 8 waves per CU, but every chunk is a segment and leaves a record per live query, and
 // k_merge pays it back (+10 us); at 4 waves per CU the static cut is already balanced.  Off by default.
+// Also measured and dropped: tail stealing (the last 6-20 % of every wave's share guarded by claim bits; the owner goes on
+// inside its segment, idle waves take unreached tails): parity held and k_merge stayed at 0.010 ms, but k_scan went
+// 0.263 -> 0.268 (20 %) .. 0.297 ms (6 %): a stolen piece costs its work plus a segment start, a single bit says nothing
+// about how far behind the owner is, and late steals end after the owner would have.  The wave end times (mean 0.227 ms,
+// max 0.26 ms) follow the appends a range happens to see (80 vs 190 per wave between the fastest and slowest decile) and
+// the XCD (workgroups with blockIdx % 8 in {1, 6, 7} end 3 % later) -- neither is known when the cut is made.
 #define QK_DYN_PCT_DEFAULT 0     // share of the tile sequence handed out dynamically (0 = static cut only)
 #endif
 #ifndef QK_DYN_CHUNK_DEFAULT
@@ -1542,6 +1548,22 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
                 if (h[8 * i + 1] == 0) continue;
                 t0 = std::min(t0, h[8 * i]);
                 t1 = std::max(t1, h[8 * i + 1]);
+            }
+            if (nw == 1) {  // mean end time by XCD (workgroups go round-robin over the 8 XCDs) and the slowest workgroups
+                double xs[8] = {0}, xn[8] = {0};
+                std::vector<std::pair<long long, int>> byend;
+                for (size_t i = 0; i < nwv; i++) {
+                    if (h[8 * i + 1] == 0) continue;
+                    xs[i & 7] += (double)(h[8 * i + 1] - t0);
+                    xn[i & 7] += 1;
+                    byend.push_back({h[8 * i + 1] - t0, (int)i});
+                }
+                fprintf(stderr, "[k_scan xcd] mean end by blockIdx%%8:");
+                for (int x = 0; x < 8; x++) fprintf(stderr, " %.0f", xs[x] / std::max(1.0, xn[x]));
+                std::sort(byend.begin(), byend.end());
+                fprintf(stderr, "\n[k_scan slowest]");
+                for (size_t i = byend.size() >= 24 ? byend.size() - 24 : 0; i < byend.size(); i++) fprintf(stderr, " %d", byend[i].second);
+                fprintf(stderr, "\n");
             }
             struct W { long long end, comp, app, seg, tend, tstage; };
             std::vector<W> ws;
