@@ -82,7 +82,9 @@ QK_API int qk_ctx_set_null_stream(qk_ctx *ctx);
 QK_API int qk_ctx_synchronize(qk_ctx *ctx);
 /* hipEvent timing of the phases, recorded on the context's stream around the kernels:
  *   0 off; 1 per call (the qk_timing* passed to qk_scan/qk_search is filled, which synchronises the stream);
- *   2 deferred (no synchronisation inside the calls; qk_ctx_read_timing sums everything recorded since the last read). */
+ *   2 deferred (no synchronisation inside the calls; qk_ctx_read_timing sums everything recorded since the last read);
+ *   3 deferred, scan kernel only: one event pair per call around the partition-scan kernel (an event record costs the stream
+ *     a few microseconds; the 8 of mode 2 add ~10 % to a 0.35 ms search). */
 QK_API int qk_ctx_set_timing(qk_ctx *ctx, int mode);
 /* Synchronises, then returns the SUM of the phase durations over the calls recorded in deferred mode and their count. */
 QK_API int qk_ctx_read_timing(qk_ctx *ctx, qk_timing *sum, int64_t *calls);

@@ -107,7 +107,8 @@ class Context:
             check(self.lib.qk_ctx_set_stream(self.h, C.c_void_p(int(hip_stream))))
 
     def set_timing(self, mode=1):
-        """0 off, 1 per-call (synchronising), 2 deferred (read with read_timing())."""
+        """0 off, 1 per-call (synchronising), 2 deferred (read with read_timing()), 3 deferred with one event pair around
+        the scan kernel only (what bench.py keeps on inside its timed region)."""
         check(self.lib.qk_ctx_set_timing(self.h, int(mode)))
 
     def read_timing(self):

@@ -81,6 +81,7 @@ int qk_ctx_set_timing(qk_ctx *c, int enabled) {
 
 static float elapsed_or_zero(hipEvent_t a, hipEvent_t b) {
     float ms = 0.f;
+    if (!a || !b) return 0.f;
     if (hipEventElapsedTime(&ms, a, b) != hipSuccess) return 0.f;
     return ms;
 }
@@ -99,7 +100,8 @@ int qk_ctx_read_timing(qk_ctx *c, qk_timing *sum, int64_t *calls) {
     }
     for (size_t i = 0; i + 1 < c->ev_pending_coarse.size(); i += 2)
         sum->coarse_ms += elapsed_or_zero(c->ev_pending_coarse[i], c->ev_pending_coarse[i + 1]);
-    for (auto e : c->ev_pending) c->ev_free.push_back(e);
+    for (auto e : c->ev_pending)
+        if (e) c->ev_free.push_back(e);
     for (auto e : c->ev_pending_coarse) c->ev_free.push_back(e);
     c->ev_pending.clear();
     c->ev_pending_coarse.clear();

@@ -68,7 +68,7 @@ struct qk_ctx {
     size_t qprep_cap = 0;
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     // deferred timing (qk_ctx_set_timing(ctx, 2)): per-call event quads, read back by qk_ctx_read_timing
-    int timing_mode = 0;  // 0 off, 1 per call (sync), 2 deferred
+    int timing_mode = 0;  // 0 off, 1 per call (sync), 2 deferred, 3 deferred + scan kernel only
     std::vector<hipEvent_t> ev_free;
     std::vector<hipEvent_t> ev_pending;  // groups of 4: group start, scan start, scan end, merge end
     std::vector<hipEvent_t> ev_pending_coarse;  // groups of 2: coarse start, coarse end
@@ -172,15 +172,20 @@ constexpr int QK_MAX_WIDE_K = 4096;
 struct qk_phase_events {
     qk_ctx *ctx = nullptr;
     bool tm = false, dtm = false;
+    bool scan_only = false;  // timing mode 3: one event pair around the scan kernel, nothing else (every event record costs
+                             // the stream a few microseconds: 8 per search are 10 % of a 0.35 ms step)
     int ev_base = 0;
     hipEvent_t dev[4] = {nullptr, nullptr, nullptr, nullptr};
     int begin(qk_ctx *c, bool per_call, int base) {
         ctx = c;
         tm = per_call;
-        dtm = c->timing_mode == 2;
+        dtm = c->timing_mode == 2 || c->timing_mode == 3;
+        scan_only = c->timing_mode == 3;
         ev_base = base;
+        if (scan_only && base != 4) dtm = false;
         if (dtm) {
             for (int i = 0; i < 4; i++) {
+                if (scan_only && (i == 0 || i == 3)) continue;
                 if (!c->ev_free.empty()) {
                     dev[i] = c->ev_free.back();
                     c->ev_free.pop_back();
@@ -193,7 +198,7 @@ struct qk_phase_events {
     }
     int mark(int i) {
         if (tm) QK_HIP(hipEventRecord(ctx->ev[ev_base + i], ctx->stream));
-        if (dtm) QK_HIP(hipEventRecord(dev[i], ctx->stream));
+        if (dtm && dev[i]) QK_HIP(hipEventRecord(dev[i], ctx->stream));
         if (dtm && i == 3) {
             if (ev_base == 4) {
                 for (int t = 0; t < 4; t++) ctx->ev_pending.push_back(dev[t]);

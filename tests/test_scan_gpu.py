@@ -236,3 +236,26 @@ def test_large_nprobe_selection(ctx):
     np.testing.assert_array_equal(gd.view(np.uint32), od.view(np.uint32))
     with pytest.raises(QuakeHipError):
         ctx.coarse(parent, x, QK_MAX_NPROBE + 1, "l2") if nl > QK_MAX_NPROBE else ctx.search(None, flat, q, 1, QK_MAX_NPROBE + 1, "l2")
+
+
+def test_deferred_timing_modes(ctx):
+    """qk_ctx_set_timing 2 (events around every phase) and 3 (one pair around the scan kernel): summed by
+    qk_ctx_read_timing without a synchronisation inside the calls; results are unaffected."""
+    import torch
+    ivf = make_ivf(20000, 32, 32, seed=21)
+    q = torch.from_numpy(make_queries(64, 32, seed=22, like=ivf["x"])).cuda()
+    parent, s = build_stores(ctx, ivf)
+    ref_i, ref_d = ctx.search(parent, s, q, 4, 10, "l2")
+    for mode in (2, 3):
+        ctx.set_timing(mode)
+        for _ in range(3):
+            gi, gd = ctx.search(parent, s, q, 4, 10, "l2")
+        t = ctx.read_timing()
+        ctx.set_timing(0)
+        assert t["calls"] == 3 and t["scan_ms"] > 0.0
+        if mode == 3:
+            assert t["group_ms"] == 0.0 and t["merge_ms"] == 0.0 and t["coarse_ms"] == 0.0
+        else:
+            assert t["group_ms"] > 0.0 and t["coarse_ms"] > 0.0
+        assert torch.equal(gi, ref_i) and torch.equal(gd, ref_d)
+    assert ctx.read_timing()["calls"] == 0
