@@ -927,10 +927,13 @@ struct MergeParams {
     int64_t *out_ids;   // [Q][k]
     float *out_dist;    // [Q][k] or nullptr
     int sqrt_l2;        // 1: output sqrt(d2) (search results); 0: squared (merge key of the sharded path)
+    long long *clock;   // probe (QK_MERGE_CLOCK): [Q][8] wall_clock64 ticks of the phases of every wave, or nullptr
 };
 
 template <int MAXCH>
 __global__ __launch_bounds__(64) void k_merge(MergeParams M) {
+    long long ck[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // start, slot line, fetch, bound, consume, final sort, end; [7] = records
+    if (M.clock) ck[0] = wall_clock64();
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = threadIdx.x;
     const int64_t q = blockIdx.x;
@@ -1007,6 +1010,10 @@ __global__ __launch_bounds__(64) void k_merge(MergeParams M) {
         const int sv = lane < QK_SLOTS ? M.pair_slots[pair * QK_SLOTS + lane] : 0;
         const int nrecs = __builtin_amdgcn_readlane(sv, 0);
         const int ns = min(nrecs, QK_SLOTS - 1);
+        if (M.clock) {
+            ck[1] = wall_clock64();
+            ck[7] += nrecs;
+        }
         int2 hdr, nhdr;
         uint32_t o0, no0;
         int64_t d0, nd0;
@@ -1021,6 +1028,41 @@ __global__ __launch_bounds__(64) void k_merge(MergeParams M) {
             for (int i = 0; i < 8; i++) {
                 recs[i] = g0 + i < ns ? __shfl(sv, g0 + i + 1) : -1;
                 fetch2(recs[i], hs[i], os[i], ds[i], os1[i], ds1[i], oks[i]);
+            }
+            // If pooling the group as it comes would overflow the pool (every overflow costs a select_pool, 2-11 us at k = 100),
+            // first take the exact k-th smallest of the keys just fetched -- bisection over the 16 key registers, ~1.5 us --
+            // as the bound: then at most k entries (+ ties) of the whole group pass.  (The first 128 entries of a record
+            // are in registers; the k-th smallest of any >= k fetched keys is an upper bound of the answer's k-th key.)
+            {
+                if (M.clock) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    ck[2] = wall_clock64();
+                }
+                int nv[8], tot = 0;
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const bool ok = recs[i] >= 0 && recs[i] < M.max_recs;
+                    nv[i] = ok ? min(min(__builtin_amdgcn_readfirstlane(hs[i].y), k), 128) : 0;
+                    tot += nv[i];
+                }
+                if (tot >= k && cnt + tot > Cm - 64) {
+                    uint32_t m0[8], m1[8];
+#pragma unroll
+                    for (int i = 0; i < 8; i++) {
+                        m0[i] = lane < nv[i] ? os[i] : 0xFFFFFFFFu;
+                        m1[i] = lane + 64 < nv[i] ? os1[i] : 0xFFFFFFFFu;
+                    }
+                    uint32_t T = 0;  // the largest value with fewer than k keys below it = the k-th smallest key
+                    for (int b = 31; b >= 0; b--) {
+                        const uint32_t tr = T | (1u << b);
+                        int c = 0;
+#pragma unroll
+                        for (int i = 0; i < 8; i++) c += __popcll(__ballot(m0[i] < tr)) + __popcll(__ballot(m1[i] < tr));
+                        if (c < k) T = tr;
+                    }
+                    tau = min(tau, T);
+                }
+                if (M.clock) ck[3] = wall_clock64();
             }
 #pragma unroll
             for (int i = 0; i < 8; i++)
@@ -1040,7 +1082,9 @@ __global__ __launch_bounds__(64) void k_merge(MergeParams M) {
             }
         }
     }
+    if (M.clock) ck[4] = wall_clock64();
     cnt = compact_pool<MAXCH>(pool_ord, pool_id, cnt, k, lane);
+    if (M.clock) ck[5] = wall_clock64();
     for (int e = lane; e < k; e += 64) {
         int64_t oid = -1;
         float od = M.metric == QK_METRIC_IP ? -INFINITY : INFINITY;
@@ -1056,6 +1100,205 @@ __global__ __launch_bounds__(64) void k_merge(MergeParams M) {
         }
         M.out_ids[q * k + e] = oid;
         if (M.out_dist) M.out_dist[q * k + e] = od;
+    }
+    if (M.clock && lane == 0) {
+        ck[6] = wall_clock64();
+        for (int i = 0; i < 8; i++) M.clock[q * 8 + i] = ck[i];
+    }
+}
+
+// ---- merge kernel for wide k: one workgroup of 4 waves per query ------------------------------------------------
+// k_merge is one wave per query: its selects and rank sorts are chains of dependent readlane / ballot steps, and with one wave
+// per SIMD nothing hides them (QK_MERGE_CLOCK, k = 100, 5 records per query: bound 13 us + final sort 12-32 us of a 50 us
+// launch).  Here the records of a query are pooled in LDS by 256 threads -- bounded by the smallest k-th key of the full
+// records -- and the pool is sorted under the (key, id) order by a bitonic network; whenever the next round of records might
+// not fit, the pool is cut back to its k best first.
+#define QK_MW_CAP 2048
+__device__ __forceinline__ void mw_sort(uint32_t *keys, int64_t *ids, int n_pad, int tid) {
+    for (int size = 2; size <= n_pad; size <<= 1) {
+        for (int ls = 31 - __builtin_clz(size) - 1; ls >= 0; ls--) {
+            const int stride = 1 << ls;
+            for (int t = tid; t < (n_pad >> 1); t += 256) {
+                const int lo = ((t >> ls) << (ls + 1)) + (t & (stride - 1));
+                const int hi = lo + stride;
+                const bool up = (lo & size) == 0;  // ascending block
+                const uint32_t ka = keys[lo], kb = keys[hi];
+                const int64_t ia = ids[lo], ib = ids[hi];
+                const bool a_gt_b = ka > kb || (ka == kb && ia > ib);
+                if (a_gt_b == up) {
+                    keys[lo] = kb;
+                    keys[hi] = ka;
+                    ids[lo] = ib;
+                    ids[hi] = ia;
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_merge_wide(MergeParams M) {
+    __shared__ int64_t s_ids[QK_MW_CAP];
+    __shared__ uint32_t s_keys[QK_MW_CAP];
+    __shared__ int s_rec[256], s_recn[256];
+    __shared__ int s_cnt, s_nrec, s_chain;
+    __shared__ uint32_t s_tau;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t q = blockIdx.x;
+    const int k = M.k;
+    long long ck[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // probe: start, record list, bound, entries pooled, -, sorted, end; [7] = records
+    if (M.clock) ck[0] = wall_clock64();
+    if (tid == 0) {
+        s_cnt = 0;
+        s_tau = 0xFFFFFFFFu;
+    }
+    // keep the k best of the pool, sorted; the k-th key becomes the bound
+    auto cut = [&]() {
+        __syncthreads();
+        const int cnt = s_cnt;
+        int n_pad = 64;
+        while (n_pad < cnt) n_pad <<= 1;
+        for (int t = cnt + tid; t < n_pad; t += 256) {
+            s_keys[t] = 0xFFFFFFFFu;
+            s_ids[t] = LLONG_MAX;
+        }
+        __syncthreads();
+        mw_sort(s_keys, s_ids, n_pad, tid);
+        if (tid == 0) {
+            const int nn = min(cnt, k);
+            s_cnt = nn;
+            if (nn >= k) s_tau = min(s_tau, s_keys[k - 1]);
+        }
+        __syncthreads();
+    };
+    // pool the records listed in s_rec[0 .. s_nrec)
+    auto pool_records = [&]() {
+        __syncthreads();
+        const int nrec = s_nrec;
+        if (M.clock) {
+            ck[1] = wall_clock64();
+            ck[7] += nrec;
+        }
+        // bound: the k-th key of every full record
+        for (int i = tid; i < nrec; i += 256) {
+            const int rec = s_rec[i];
+            const uint32_t kth = M.rec_ord[(int64_t)rec * k + k - 1];  // (requested with the header; meaningful for a full record)
+            const int n = min(M.rec_hdr[rec].y, k);
+            s_recn[i] = n;
+            if (n >= k) atomicMin(&s_tau, kth);
+        }
+        __syncthreads();
+        if (M.clock) ck[2] = wall_clock64();
+        const int per_round = max(1, (QK_MW_CAP - k) / k);  // records that fit next to k kept entries
+        for (int r0 = 0; r0 < nrec; r0 += per_round) {
+            const int r1 = min(nrec, r0 + per_round);
+            if (s_cnt + (r1 - r0) * k > QK_MW_CAP) cut();  // (uniform: s_cnt is read after a barrier)
+            const uint32_t tau = s_tau;
+            for (int i = r0 + wave; i < r1; i += 4) {  // one wave per record; records are sorted, so a wave stops at the bound
+                const int rec = s_rec[i], n = s_recn[i];
+                // the first two chunks are requested together (k <= 128: the whole record in one round trip)
+                uint32_t oA = 0xFFFFFFFFu, oB = 0xFFFFFFFFu;
+                int64_t dA = -1, dB = -1;
+                if (lane < n) {
+                    oA = M.rec_ord[(int64_t)rec * k + lane];
+                    dA = M.rec_id[(int64_t)rec * k + lane];
+                }
+                if (lane + 64 < n) {
+                    oB = M.rec_ord[(int64_t)rec * k + lane + 64];
+                    dB = M.rec_id[(int64_t)rec * k + lane + 64];
+                }
+                for (int base = 0; base < n; base += 64) {
+                    const int e = base + lane;
+                    uint32_t o = base == 0 ? oA : oB;
+                    int64_t dd = base == 0 ? dA : dB;
+                    if (base >= 128) {
+                        o = 0xFFFFFFFFu;
+                        dd = -1;
+                        if (e < n) {
+                            o = M.rec_ord[(int64_t)rec * k + e];
+                            dd = M.rec_id[(int64_t)rec * k + e];
+                        }
+                    }
+                    const bool pass = e < n && o <= tau;
+                    const uint64_t m = __ballot(pass);
+                    if (m) {
+                        int slot0 = 0;
+                        if (lane == 0) slot0 = atomicAdd(&s_cnt, __popcll(m));
+                        slot0 = __builtin_amdgcn_readfirstlane(slot0);
+                        if (pass) {
+                            const int sl = slot0 + __popcll(m & ((1ull << lane) - 1ull));
+                            s_keys[sl] = o;
+                            s_ids[sl] = dd;
+                        }
+                    }
+                    if (__popcll(m) < min(64, n - base)) break;
+                }
+            }
+            __syncthreads();
+        }
+    };
+    for (int r0 = 0; r0 < M.P; r0 += 8) {
+        // slot lines of 8 pairs: entry 0 = record count, entries 1..31 = the first records
+        if (tid == 0) {
+            s_nrec = 0;
+            s_chain = 0;
+        }
+        __syncthreads();
+        const int pr = tid >> 5, sl = tid & 31;
+        const bool pv = r0 + pr < M.P;
+        const int64_t pair = q * M.P + r0 + pr;
+        const int sv = pv ? M.pair_slots[pair * QK_SLOTS + sl] : 0;
+        const int nrecs = __shfl(sv, lane & 32);
+        if (pv && sl >= 1 && sl - 1 < min(nrecs, QK_SLOTS - 1) && sv >= 0 && sv < M.max_recs) s_rec[atomicAdd(&s_nrec, 1)] = sv;
+        if (pv && sl == 0 && nrecs > QK_SLOTS - 1) atomicOr(&s_chain, 1 << pr);
+        pool_records();
+        // overflow chains (more than 31 records of one pair): walked by one thread, pooled 256 at a time
+        int chain = s_chain;
+        while (chain) {
+            const int pc = __ffs(chain) - 1;
+            chain &= chain - 1;
+            int rec = M.pair_head[q * M.P + r0 + pc];
+            while (rec >= 0 && rec < M.max_recs) {
+                __syncthreads();
+                if (tid == 0) {
+                    int n = 0;
+                    while (rec >= 0 && rec < M.max_recs && n < 256) {
+                        s_rec[n++] = rec;
+                        rec = M.rec_hdr[rec].x;
+                    }
+                    s_nrec = n;
+                    s_chain = rec;
+                }
+                __syncthreads();
+                rec = s_chain;
+                pool_records();
+            }
+        }
+        __syncthreads();
+    }
+    if (M.clock) ck[3] = ck[4] = wall_clock64();
+    cut();
+    if (M.clock) ck[5] = wall_clock64();
+    const int cnt = s_cnt;
+    for (int e = tid; e < k; e += 256) {
+        int64_t oid = -1;
+        float od = M.metric == QK_METRIC_IP ? -INFINITY : INFINITY;
+        if (e < cnt) {
+            oid = s_ids[e];
+            const uint32_t o = s_keys[e];
+            if (M.metric == QK_METRIC_L2) {
+                const float d2 = __uint_as_float(o);
+                od = M.sqrt_l2 ? sqrtf(d2) : d2;
+            } else {
+                od = ip_from_ord(o);
+            }
+        }
+        M.out_ids[q * k + e] = oid;
+        if (M.out_dist) M.out_dist[q * k + e] = od;
+    }
+    if (M.clock && tid == 0) {
+        ck[6] = wall_clock64();
+        for (int i = 0; i < 8; i++) M.clock[q * 8 + i] = ck[i];
     }
 }
 
@@ -1609,6 +1852,17 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
     mp.out_dist = a.out_dist;
     mp.sqrt_l2 = a.sqrt_l2 ? 1 : 0;
     const dim3 mgrid((unsigned)(a.per_pair ? Q * P : Q));
+    static const bool merge_clock = getenv("QK_MERGE_CLOCK") != nullptr;
+    static long long *d_mclock = nullptr;
+    mp.clock = nullptr;
+    if (merge_clock && (int64_t)mgrid.x * 64 <= ((int64_t)1 << 24)) {
+        if (!d_mclock) QK_HIP(hipMalloc((void **)&d_mclock, (size_t)1 << 24));
+        mp.clock = d_mclock;
+    }
+    static const int merge_wide_min_k = getenv("QK_MERGE_WIDE_MIN_K") ? atoi(getenv("QK_MERGE_WIDE_MIN_K")) : 33;
+    if (k >= merge_wide_min_k) {
+        hipLaunchKernelGGL(k_merge_wide, mgrid, dim3(256), 0, st, mp);
+    } else
     switch (maxch_m) {
         case 2: hipLaunchKernelGGL((k_merge<2>), mgrid, dim3(64), lds_merge, st, mp); break;
         case 4: hipLaunchKernelGGL((k_merge<4>), mgrid, dim3(64), lds_merge, st, mp); break;
@@ -1616,6 +1870,32 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
         default: hipLaunchKernelGGL((k_merge<16>), mgrid, dim3(64), lds_merge, st, mp); break;
     }
     QK_HIP(hipGetLastError());
+    if (mp.clock) {  // debug probe: where a merge wave spends its time (mean / max over the queries, 100 MHz ticks)
+        std::vector<long long> h((size_t)mgrid.x * 8);
+        QK_HIP(hipMemcpyAsync(h.data(), d_mclock, h.size() * 8, hipMemcpyDeviceToHost, st));
+        QK_HIP(hipStreamSynchronize(st));
+        const char *names[6] = {"slot line", "fetch", "bound", "consume", "final sort", "output"};
+        long long t0 = LLONG_MAX, t1 = 0;
+        double mean[6] = {0}, recs = 0;
+        long long mx[6] = {0}, mxrec = 0;
+        for (size_t i = 0; i < (size_t)mgrid.x; i++) {
+            const long long *c = &h[8 * i];
+            t0 = std::min(t0, c[0]);
+            t1 = std::max(t1, c[6]);
+            long long prev = c[0];
+            for (int ph = 0; ph < 6; ph++) {
+                const long long cur = c[ph + 1] ? c[ph + 1] : prev;
+                mean[ph] += (double)(cur - prev);
+                mx[ph] = std::max(mx[ph], cur - prev);
+                prev = cur;
+            }
+            recs += (double)c[7];
+            mxrec = std::max(mxrec, c[7]);
+        }
+        fprintf(stderr, "[k_merge waves] n=%u span=%lld ticks, records per query mean=%.1f max=%lld;", mgrid.x, t1 - t0, recs / mgrid.x, mxrec);
+        for (int ph = 0; ph < 6; ph++) fprintf(stderr, " %s mean=%.0f max=%lld;", names[ph], mean[ph] / mgrid.x, mx[ph]);
+        fprintf(stderr, "\n");
+    }
     QK_TRY(pe.mark(3));
     if (timing) {
         // device scalars come back through pinned memory; the caller synchronises before reading them

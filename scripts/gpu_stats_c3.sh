@@ -10,7 +10,7 @@ import csv, glob
 f = glob.glob("$OUT/**/*kernel_stats.csv", recursive=True)[0]
 for r in csv.DictReader(open(f)):
     n = r["Name"]
-    if any(t in n for t in ("k_scan", "k_merge", "k_group", "k_seed", "k_dense", "k_select", "k_prep", "k_argmin")):
+    if any(t in n for t in ("k_scan", "k_merge", "k_group", "k_seed", "k_dense", "k_select", "k_prep", "k_argmin", "k_merge_wide")):
         print(f"{n[:44]:44s} calls={r['Calls']:>4s} avg_us={float(r['AverageNs'])/1e3:9.2f} min_us={float(r['MinNs'])/1e3:9.2f} max_us={float(r['MaxNs'])/1e3:9.2f}")
 PY
 find $OUT -name "*kernel_trace.csv" -delete
