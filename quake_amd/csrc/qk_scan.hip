@@ -1141,8 +1141,8 @@ __global__ __launch_bounds__(256) void k_merge_wide(MergeParams M) {
     __shared__ int64_t s_ids[QK_MW_CAP];
     __shared__ uint32_t s_keys[QK_MW_CAP];
     __shared__ int s_rec[256], s_recn[256];
-    __shared__ int s_cnt, s_nrec, s_chain;
-    __shared__ uint32_t s_tau;
+    __shared__ int s_cnt, s_nrec, s_chain, s_qual;
+    __shared__ uint32_t s_tau, s_b2;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t q = blockIdx.x;
     const int k = M.k;
@@ -1173,20 +1173,34 @@ __global__ __launch_bounds__(256) void k_merge_wide(MergeParams M) {
     };
     // pool the records listed in s_rec[0 .. s_nrec)
     auto pool_records = [&]() {
+        if (tid == 0) {
+            s_qual = 0;
+            s_b2 = 0;
+        }
         __syncthreads();
         const int nrec = s_nrec;
         if (M.clock) {
             ck[1] = wall_clock64();
             ck[7] += nrec;
         }
-        // bound: the k-th key of every full record
+        // bounds (records are sorted): the k-th key of every full record; and, with c = ceil(k / records), the largest c-th key
+        // -- the first c entries of every record are >= k entries that do not exceed it.  The second one is what keeps the
+        // pool near k entries when a partition was cut into several segments (each record then holds the best of a part)
+        const int c2 = nrec > 0 ? (k + nrec - 1) / nrec : k;
         for (int i = tid; i < nrec; i += 256) {
             const int rec = s_rec[i];
             const uint32_t kth = M.rec_ord[(int64_t)rec * k + k - 1];  // (requested with the header; meaningful for a full record)
+            const uint32_t cth = M.rec_ord[(int64_t)rec * k + c2 - 1];
             const int n = min(M.rec_hdr[rec].y, k);
             s_recn[i] = n;
             if (n >= k) atomicMin(&s_tau, kth);
+            if (n >= c2) {
+                atomicAdd(&s_qual, 1);
+                atomicMax(&s_b2, cth);
+            }
         }
+        __syncthreads();
+        if (tid == 0 && (long long)s_qual * c2 >= k) s_tau = min(s_tau, s_b2);
         __syncthreads();
         if (M.clock) ck[2] = wall_clock64();
         const int per_round = max(1, (QK_MW_CAP - k) / k);  // records that fit next to k kept entries
