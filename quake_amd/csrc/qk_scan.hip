@@ -34,6 +34,7 @@
 #include <climits>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 
 // ---- query preparation -----------------------------------------------------------------------------
 // xq4[(q*nblk + c)*4 + g] = {x[q][16c+g], x[q][16c+g+4], x[q][16c+g+8], x[q][16c+g+12]}  (B-operand order)
@@ -455,6 +456,8 @@ struct ScanParams {
     // dyn_chunk tiles through this counter once a wave has finished its static share (nullptr: all static)
     unsigned long long *dyn_counter;
     int dyn_chunk, dyn_pct;
+    int pack;      // > 1: independent one-wave workgroups bundled per hardware workgroup (see k_scan)
+    int pack_lds;  // LDS bytes of each bundled wave
     // query-sharing workgroups (narrow rows, many queries per partition): the nw waves of a workgroup walk the SAME tiles
     // of a partition at the same time, each with its own 16-query tile and pools in LDS, so that a partition probed by up
     // to 16*nw queries is fetched from HBM once (the later waves hit in L2).  0: waves split the tiles instead.
@@ -519,7 +522,13 @@ __global__ __launch_bounds__(256) void k_scan(ScanParams P) {
     // wave keeps its own pools and emits its own records.  nw > 1 is chosen by the host for wide rows, where a
     // wave-private query tile (1 KiB per 16 columns) would leave room for only 2-3 waves per CU.
     const int lane = threadIdx.x & 63;
-    const int wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    // P.pack > 1: the hardware workgroup is a bundle of `pack` INDEPENDENT one-wave workgroups of the cut (own query tile, own
+    // pools, own range; no barrier anywhere on that path).  The dispatcher spreads the waves of one workgroup over the SIMDs
+    // of a CU, which it does not do for single-wave workgroups: QK_SCAN_WAVE_CLOCK showed 57 SIMDs holding two of the 1024
+    // waves (and 57 none) on some launches, and those 114 waves set the kernel time (0.26 -> 0.31 ms).
+    const int wv_phys = threadIdx.x >> 6;
+    const int pack = P.pack;
+    const int wv = pack > 1 ? 0 : wv_phys, nw = pack > 1 ? 1 : (int)(blockDim.x >> 6);
     const int j = lane & 15, g = lane >> 4;
     const int nblk = P.nblk, C = P.C, k = P.k;
     const bool l2 = P.metric == QK_METRIC_L2;
@@ -527,9 +536,10 @@ __global__ __launch_bounds__(256) void k_scan(ScanParams P) {
     constexpr bool PRODUCT = MODE == 0 || MODE == 3;
     constexpr bool EMIT = MODE == 4;  // wide-k path: keys out, selection happens in k_select_rows_large afterwards
     const size_t per_wave = (size_t)nblk * 1024 + (size_t)16 * C * 12;  // qshare: every wave owns a query tile + pools
-    float4 *qs = (float4 *)(smem + (qshare ? wv * per_wave : 0));             // [nblk*64] (shared by the workgroup unless qshare)
-    unsigned char *pool_base = qshare ? smem + wv * per_wave + (size_t)nblk * 1024
-                                      : smem + (size_t)nblk * 1024 + (size_t)wv * 16 * C * 12;
+    unsigned char *smem_w = smem + (pack > 1 ? (size_t)wv_phys * P.pack_lds : 0);
+    float4 *qs = (float4 *)(smem_w + (qshare ? wv * per_wave : 0));           // [nblk*64] (shared by the workgroup unless qshare)
+    unsigned char *pool_base = qshare ? smem_w + wv * per_wave + (size_t)nblk * 1024
+                                      : smem_w + (size_t)nblk * 1024 + (size_t)wv * 16 * C * 12;
     int64_t *pool_id = (int64_t *)pool_base;                                   // [16][C]
     uint32_t *pool_ord = (uint32_t *)(pool_base + (size_t)16 * C * 8);         // [16][C]
     uint32_t *my_ord = pool_ord + j * C;
@@ -538,12 +548,13 @@ __global__ __launch_bounds__(256) void k_scan(ScanParams P) {
 
     // ---- this wave's contiguous share of the global tile sequence ------------------------------------------
     const long long T = *P.n_tiles;
-    const long long W = gridDim.x;
+    const long long W = pack > 1 ? (long long)gridDim.x * pack : (long long)gridDim.x;
+    const long long vblock = pack > 1 ? (long long)blockIdx.x * pack + wv_phys : (long long)blockIdx.x;
     const bool dyn = P.dyn_counter != nullptr && nw == 1;
     // static share: an equal cut of the first Ts tiles; the rest is claimed chunk by chunk by whoever finishes first
     // (waves do not finish together: HBM channel and XCD placement make equal tile counts take unequal time)
     const long long Ts = dyn ? T - (T * P.dyn_pct) / 100 : T;
-    long long T0 = (Ts * blockIdx.x) / W, T1 = (Ts * (blockIdx.x + 1)) / W;
+    long long T0 = (Ts * vblock) / W, T1 = (Ts * (vblock + 1)) / W;
     if (!dyn && T1 <= T0) return;
     const long long wc0 = P.wave_clock ? wall_clock64() : 0;
     const int n_active = *P.n_active;
@@ -901,7 +912,7 @@ __global__ __launch_bounds__(256) void k_scan(ScanParams P) {
     }
     if (pend_rec >= 0) P.rec_hdr[pend_rec] = make_int2(pend_old, pend_cnt);
     if (P.wave_clock && lane == 0) {
-        long long *wcp = P.wave_clock + 8 * ((long long)blockIdx.x * nw + wv);
+        long long *wcp = P.wave_clock + 8 * (pack > 1 ? vblock : (long long)blockIdx.x * nw + wv);
         wcp[0] = wc0;
         wcp[1] = wall_clock64();
         wcp[2] = dbg_comp;
@@ -909,6 +920,10 @@ __global__ __launch_bounds__(256) void k_scan(ScanParams P) {
         wcp[4] = dbg_seg;
         wcp[5] = dbg_t_end;
         wcp[6] = dbg_t_stage;
+        // where the wave ran: HW_ID (simd [5:4], cu [11:8], sh [12], se [15:13]) and XCC_ID [3:0]
+        const unsigned hw = __builtin_amdgcn_s_getreg((4) | (0 << 6) | ((32 - 1) << 11));
+        const unsigned xcc = __builtin_amdgcn_s_getreg((20) | (0 << 6) | ((4 - 1) << 11));
+        wcp[7] = ((long long)xcc << 32) | hw;
     }
 }
 
@@ -1777,17 +1792,27 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
         sp.dyn_counter = (nw == 1 && dyn_pct > 0) ? (unsigned long long *)(scal + 16) : nullptr;  // zeroed with the counters
         sp.dyn_chunk = std::max(1, dyn_chunk);
         sp.dyn_pct = std::min(90, std::max(0, dyn_pct));
+        // single-wave workgroups are bundled four to a hardware workgroup: one wave per SIMD, guaranteed (see k_scan)
+        static const bool no_pack = getenv("QK_SCAN_NO_PACK") != nullptr;
+        const bool pack4 = nw == 1 && !qshare && !no_pack && (wgs_per_cu == 4 || wgs_per_cu == 8) && lds_launch % 16 == 0;
+        sp.pack = pack4 ? 4 : 1;
+        sp.pack_lds = (int)lds_launch;
+        const int wpw = pack4 ? 4 : nw;  // waves per hardware workgroup
+        if (pack4) {
+            grid = (grid + 3) / 4;
+            lds_launch *= 4;
+        }
         static const bool probe_clock = getenv("QK_SCAN_WAVE_CLOCK") != nullptr;
         static long long *d_clock = nullptr;
         sp.wave_clock = nullptr;
         if (probe_clock) {
             if (!d_clock) QK_HIP(hipMalloc((void **)&d_clock, (size_t)1 << 20));
-            QK_HIP(hipMemsetAsync(d_clock, 0, (size_t)grid * nw * 64, st));
+            QK_HIP(hipMemsetAsync(d_clock, 0, (size_t)grid * wpw * 64, st));
             sp.wave_clock = d_clock;
         }
-        QK_TRY(launch_scan(DB, maxch, dim3((unsigned)grid), dim3(64 * nw), lds_launch, st, sp));
+        QK_TRY(launch_scan(DB, maxch, dim3((unsigned)grid), dim3(64 * wpw), lds_launch, st, sp));
         if (probe_clock) {  // debug probe: distribution of the waves' busy time (tail = what a dynamic split could recover)
-            std::vector<long long> h((size_t)grid * nw * 8);
+            std::vector<long long> h((size_t)grid * wpw * 8);
             QK_HIP(hipMemcpyAsync(h.data(), d_clock, h.size() * 8, hipMemcpyDeviceToHost, st));
             int32_t hscal[8];
             QK_HIP(hipMemcpyAsync(hscal, scal, sizeof(hscal), hipMemcpyDeviceToHost, st));
@@ -1796,8 +1821,11 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
                 int64_t units, rows;
                 std::memcpy(&units, hscal + 4, 8);
                 std::memcpy(&rows, hscal + 2, 8);
-                fprintf(stderr, "[k_scan launch] grid=%lld nw=%d qshare=%d seg_ovh=%d active=%d records=%d unique_rows=%lld sequence_units=%lld\n",
-                        (long long)grid, nw, (int)qshare, seg_ovh, hscal[0], hscal[1], (long long)rows, (long long)units);
+                fprintf(stderr, "[k_scan launch] pack=%d grid=%lld nw=%d qshare=%d seg_ovh=%d active=%d records=%d unique_rows=%lld sequence_units=%lld\n",
+                        sp.pack, (long long)grid, nw, (int)qshare, seg_ovh, hscal[0], hscal[1], (long long)rows, (long long)units);
+                fprintf(stderr, "[k_scan params] DB=%d maxch=%d C=%d k=%d lds=%zu max_recs=%lld gtau=%d refresh=%d publish=%d npairs=%lld Q=%lld ws=%p vecs=%p\n",
+                        DB, maxch, sp.C, sp.k, lds_launch, (long long)max_recs, sp.gtau != nullptr, sp.tau_refresh, sp.tau_publish,
+                        (long long)npairs, (long long)Q, (void *)g_cnt, (void *)sp.vecs);
             }
             long long t0 = LLONG_MAX, t1 = 0;
             const size_t nwv = h.size() / 8;
@@ -1806,21 +1834,49 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
                 t0 = std::min(t0, h[8 * i]);
                 t1 = std::max(t1, h[8 * i + 1]);
             }
-            if (nw == 1) {  // mean end time by XCD (workgroups go round-robin over the 8 XCDs) and the slowest workgroups
+            if (wpw == 1 || sp.pack > 1) {  // mean end time by XCD (workgroups go round-robin over the 8 XCDs) and the slowest workgroups
                 double xs[8] = {0}, xn[8] = {0};
                 std::vector<std::pair<long long, int>> byend;
                 for (size_t i = 0; i < nwv; i++) {
                     if (h[8 * i + 1] == 0) continue;
-                    xs[i & 7] += (double)(h[8 * i + 1] - t0);
-                    xn[i & 7] += 1;
+                    xs[(i / wpw) & 7] += (double)(h[8 * i + 1] - t0);
+                    xn[(i / wpw) & 7] += 1;
                     byend.push_back({h[8 * i + 1] - t0, (int)i});
                 }
                 fprintf(stderr, "[k_scan xcd] mean end by blockIdx%%8:");
                 for (int x = 0; x < 8; x++) fprintf(stderr, " %.0f", xs[x] / std::max(1.0, xn[x]));
                 std::sort(byend.begin(), byend.end());
-                fprintf(stderr, "\n[k_scan slowest]");
-                for (size_t i = byend.size() >= 24 ? byend.size() - 24 : 0; i < byend.size(); i++) fprintf(stderr, " %d", byend[i].second);
+                fprintf(stderr, "\n[k_scan slowest] workgroup:start+duration");
+                for (size_t i = byend.size() >= 24 ? byend.size() - 24 : 0; i < byend.size(); i++) {
+                    const int w = byend[i].second;
+                    fprintf(stderr, " %d:%lld+%lld(c%lld a%lld s%lld e%lld q%lld)", w, h[8 * (size_t)w] - t0, h[8 * (size_t)w + 1] - h[8 * (size_t)w],
+                            h[8 * (size_t)w + 2], h[8 * (size_t)w + 3], h[8 * (size_t)w + 4], h[8 * (size_t)w + 5], h[8 * (size_t)w + 6]);
+                }
                 fprintf(stderr, "\n");
+                // placement: waves per (xcc, se, sh, cu, simd); how many of the slowest 10 % share their SIMD with another wave
+                auto place = [&](int w, bool with_simd) {
+                    const unsigned long long v = (unsigned long long)h[8 * (size_t)w + 7];
+                    const unsigned hw = (unsigned)(v & 0xFFFFFFFFu), xcc = (unsigned)(v >> 32) & 15u;
+                    const unsigned simd = (hw >> 4) & 3u, cu = (hw >> 8) & 15u, sh = (hw >> 12) & 1u, se = (hw >> 13) & 7u;
+                    return (((((xcc * 8 + se) * 2 + sh) * 16 + cu) * 4) + (with_simd ? simd : 0)) * 2 + (with_simd ? 1 : 0);
+                };
+                std::map<unsigned, int> per_simd, per_cu;
+                for (auto &e : byend) {
+                    per_simd[place(e.second, true)]++;
+                    per_cu[place(e.second, false)]++;
+                }
+                int hist_simd[8] = {0}, hist_cu[16] = {0};
+                for (auto &kv : per_simd) hist_simd[std::min(kv.second, 7)]++;
+                for (auto &kv : per_cu) hist_cu[std::min(kv.second, 15)]++;
+                fprintf(stderr, "[k_scan placement] SIMDs holding 1/2/3/4 waves: %d %d %d %d; CUs holding 1..8 waves:", hist_simd[1], hist_simd[2], hist_simd[3], hist_simd[4]);
+                for (int c = 1; c <= 8; c++) fprintf(stderr, " %d", hist_cu[c]);
+                int slow_shared = 0, slow_n = 0, fast_shared = 0, fast_n = 0;
+                for (size_t i = 0; i < byend.size(); i++) {
+                    const bool shared = per_simd[place(byend[i].second, true)] > 1;
+                    if (i >= byend.size() - byend.size() / 10) { slow_n++; slow_shared += shared; }
+                    else { fast_n++; fast_shared += shared; }
+                }
+                fprintf(stderr, "; waves sharing a SIMD: %d of the slowest %d, %d of the other %d\n", slow_shared, slow_n, fast_shared, fast_n);
             }
             struct W { long long end, comp, app, seg, tend, tstage; };
             std::vector<W> ws;

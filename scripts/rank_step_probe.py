@@ -61,6 +61,11 @@ out = {"N": N, "step_ms_without_collectives": round(timeit(step), 4),
        "coarse_ms": round(timeit(lambda: ctx.coarse(parent, q_all[:per], 1, "l2")), 4)}
 pl = ctx.coarse(parent, q_all[:per], 1, "l2")[0]
 pids = torch.cat([pl] + [pl + nlist * (r + 1) for r in range(N - 1)], 0).contiguous()
+if os.environ.get("PROBE_REMOTE") == "skip":      # remote pairs marked "skip" instead of naming an empty list
+    pids = torch.cat([pl] + [torch.full_like(pl, -1) for r in range(N - 1)], 0).contiguous()
+if os.environ.get("PROBE_REMOTE") == "first":     # the local queries last in the batch
+    pids = torch.cat([pl + nlist * (r + 1) for r in range(N - 1)] + [pl], 0).contiguous()
+    q_all = torch.cat([q_all[per:], q_all[:per]], 0).contiguous()
 out["scan_ms"] = round(timeit(lambda: ctx.scan_into(store, q_all, pids, k, "l2", (out_i, out_d))), 4)
 out["merge_ms"] = round(timeit(lambda: ctx.merge_topk(out_i.view(N, per, k), out_d.view(N, per, k), "l2")), 4)
 print(json.dumps(out), flush=True)
