@@ -44,6 +44,8 @@ int qk_ctx_destroy(qk_ctx *c) {
     if (c->qprep) hipFree(c->qprep);
     if (c->aps) hipFree(c->aps);
     if (c->pinned) hipHostFree(c->pinned);
+    if (c->xcd_host) hipHostFree(c->xcd_host);
+    if (c->xcd_ev) hipEventDestroy(c->xcd_ev);
     for (auto &e : c->ev)
         if (e) hipEventDestroy(e);
     for (auto e : c->ev_free) hipEventDestroy(e);

@@ -76,6 +76,19 @@ struct qk_ctx {
     // state of an adaptive (recall-target) search: survives the scan calls of its rounds, which recycle `ws`
     char *aps = nullptr;
     size_t aps_cap = 0;
+    // XCD balance of the partition scan (qk_scan.hip): relative speed of the 8 workgroup classes blockIdx % 8 per store,
+    // learned from the wave times of sampled launches (the physical placement of an arena makes some XCDs stream it up to
+    // 25 % slower than others); one sample in flight at a time
+    struct xcd_state {
+        double w[8] = {1, 1, 1, 1, 1, 1, 1, 1};
+        long long launches = 0;
+    };
+    std::unordered_map<uint64_t, xcd_state> xcd;  // by store uid
+    unsigned long long *xcd_host = nullptr;       // pinned [16]: ticks per class, waves per class
+    hipEvent_t xcd_ev = nullptr;
+    bool xcd_pending = false;
+    uint64_t xcd_key = 0;
+    double xcd_wsnap[8] = {1, 1, 1, 1, 1, 1, 1, 1};
 };
 
 int qk_ws_reserve(qk_ctx *ctx, size_t bytes);          // make sure the workspace can hold `bytes` (may sync+realloc)
@@ -95,6 +108,7 @@ struct qk_part {
 
 struct qk_store {
     qk_ctx *ctx = nullptr;
+    uint64_t uid = 0;  // unique per store object of the process
     int d = 0;
     int dpad = 0;  // d rounded up to 16
     int nblk = 0;  // dpad / 16

@@ -458,6 +458,11 @@ struct ScanParams {
     int dyn_chunk, dyn_pct;
     int pack;      // > 1: independent one-wave workgroups bundled per hardware workgroup (see k_scan)
     int pack_lds;  // LDS bytes of each bundled wave
+    // XCD balance: hardware workgroup u belongs to class u % 8 (workgroups go round-robin over the XCDs); its share of the cut
+    // is proportional to xcd_w[class] (1024 = average); xcd_stat [16] collects ticks and waves per class (nullptr: not sampled)
+    int xcd_on;
+    int xcd_w[8];
+    unsigned long long *xcd_stat;
     // query-sharing workgroups (narrow rows, many queries per partition): the nw waves of a workgroup walk the SAME tiles
     // of a partition at the same time, each with its own 16-query tile and pools in LDS, so that a partition probed by up
     // to 16*nw queries is fetched from HBM once (the later waves hit in L2).  0: waves split the tiles instead.
@@ -555,8 +560,22 @@ __global__ __launch_bounds__(256) void k_scan(ScanParams P) {
     // (waves do not finish together: HBM channel and XCD placement make equal tile counts take unequal time)
     const long long Ts = dyn ? T - (T * P.dyn_pct) / 100 : T;
     long long T0 = (Ts * vblock) / W, T1 = (Ts * (vblock + 1)) / W;
+    if (P.xcd_on && !dyn) {
+        // weighted cut: the split points are f(a) = T a / total for cumulative weights a; a wave's end is its successor's start
+        const int np = pack > 1 ? pack : 1;
+        long long pre[9];
+        pre[0] = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) pre[i + 1] = pre[i] + P.xcd_w[i];
+        const long long u = blockIdx.x, gu = gridDim.x;
+        const long long total = ((gu >> 3) * pre[8] + pre[gu & 7]) * np;
+        const long long a0 = ((u >> 3) * pre[8] + pre[u & 7]) * np + (long long)P.xcd_w[u & 7] * (pack > 1 ? wv_phys : 0);
+        const long long a1 = a0 + P.xcd_w[u & 7];
+        T0 = a0 <= 0 ? 0 : (long long)((double)T * (double)a0 / (double)total);
+        T1 = a1 >= total ? T : (long long)((double)T * (double)a1 / (double)total);
+    }
     if (!dyn && T1 <= T0) return;
-    const long long wc0 = P.wave_clock ? wall_clock64() : 0;
+    const long long wc0 = (P.wave_clock || P.xcd_stat) ? wall_clock64() : 0;
     const int n_active = *P.n_active;
     int pend_rec = -1, pend_old = -1, pend_cnt = 0;  // deferred header store of this lane's previous record
     int dbg_comp = 0, dbg_app = 0, dbg_seg = 0;       // probe counters (QK_SCAN_WAVE_CLOCK)
@@ -911,6 +930,10 @@ __global__ __launch_bounds__(256) void k_scan(ScanParams P) {
         T1 = min(T, T0 + P.dyn_chunk);
     }
     if (pend_rec >= 0) P.rec_hdr[pend_rec] = make_int2(pend_old, pend_cnt);
+    if (P.xcd_stat && lane == 0 && (nw == 1 || wv == 0)) {
+        atomicAdd(&P.xcd_stat[blockIdx.x & 7], (unsigned long long)(wall_clock64() - wc0));
+        atomicAdd(&P.xcd_stat[8 + (blockIdx.x & 7)], 1ull);
+    }
     if (P.wave_clock && lane == 0) {
         long long *wcp = P.wave_clock + 8 * (pack > 1 ? vblock : (long long)blockIdx.x * nw + wv);
         wcp[0] = wc0;
@@ -1574,10 +1597,11 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
     // slower, and the slowest wave of a static cut sets the time); with 4 they finish within 85-100 % and every query
     // leaves fewer, longer records: bench configuration 0.276-0.297 ms (6 per CU) -> 0.264-0.268 ms (4 per CU).
     int waves_per_cu = nw * (int)std::max<size_t>(1, std::min<size_t>(8 / nw, (160 * 1024) / (lds_scan + 512)));
+    int64_t tiles_est;
     {
         const int64_t npresent_e = std::max<int64_t>(1, s->nlist);
         const int64_t mean_tiles = std::max<int64_t>(1, (s->ntotal / npresent_e + 15) / 16);
-        const int64_t tiles_est = std::max<int64_t>(1, npairs / 16 + std::min<int64_t>(npresent_e, npairs)) * mean_tiles;
+        tiles_est = std::max<int64_t>(1, npairs / 16 + std::min<int64_t>(npresent_e, npairs)) * mean_tiles;
         if (nw == 1 && waves_per_cu > 4 && tiles_est < (int64_t)8 * num_cus * 160) waves_per_cu = 4;
     }
     if (const char *e = getenv("QK_SCAN_WAVES_PER_CU")) {  // probe override, read per call so one process can sweep it
@@ -1802,6 +1826,49 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
             grid = (grid + 3) / 4;
             lds_launch *= 4;
         }
+        // ---- XCD balance (see qk_ctx::xcd_state) ---------------------------------------------------------------------------
+        static const int xcd_adapt = getenv("QK_SCAN_XCD_ADAPT") ? atoi(getenv("QK_SCAN_XCD_ADAPT")) : 1;
+        if (ctx->xcd_pending && hipEventQuery(ctx->xcd_ev) == hipSuccess) {  // a finished sample: speed = share / time
+            ctx->xcd_pending = false;
+            qk_ctx::xcd_state &xs = ctx->xcd[ctx->xcd_key];
+            double sp8[8], mean = 0;
+            int nz = 0;
+            for (int c = 0; c < 8; c++) {
+                const double cnt = (double)ctx->xcd_host[8 + c], ticks = (double)ctx->xcd_host[c];
+                sp8[c] = (cnt > 0 && ticks > 0) ? ctx->xcd_wsnap[c] / (ticks / cnt) : 0.0;
+                if (sp8[c] > 0) {
+                    mean += sp8[c];
+                    nz++;
+                }
+            }
+            if (nz == 8) {
+                mean /= 8;
+                double sum = 0;
+                for (int c = 0; c < 8; c++) {
+                    const double target = std::min(1.7, std::max(0.3, sp8[c] / mean));
+                    xs.w[c] = 0.5 * xs.w[c] + 0.5 * target;
+                    sum += xs.w[c];
+                }
+                for (int c = 0; c < 8; c++) xs.w[c] *= 8.0 / sum;
+            }
+        }
+        sp.xcd_on = 0;
+        sp.xcd_stat = nullptr;
+        for (int c = 0; c < 8; c++) sp.xcd_w[c] = 1024;
+        if (xcd_adapt && sp.dyn_counter == nullptr && grid >= 64 && tiles_est >= (int64_t)grid * wpw * 32) {
+            qk_ctx::xcd_state &xs = ctx->xcd[s->uid];
+            sp.xcd_on = 1;
+            for (int c = 0; c < 8; c++) sp.xcd_w[c] = std::max(1, (int)(xs.w[c] * 1024.0 + 0.5));
+            const long long nl = xs.launches++;
+            const bool sample = !ctx->xcd_pending && (nl < 16 || (nl & 63) == 0);
+            if (sample) {
+                if (!ctx->xcd_host) QK_HIP(hipHostMalloc((void **)&ctx->xcd_host, 16 * sizeof(unsigned long long)));
+                if (!ctx->xcd_ev) QK_HIP(hipEventCreateWithFlags(&ctx->xcd_ev, hipEventDisableTiming));
+                sp.xcd_stat = (unsigned long long *)(scal + 32);  // zeroed with the counters
+                ctx->xcd_key = s->uid;
+                for (int c = 0; c < 8; c++) ctx->xcd_wsnap[c] = sp.xcd_w[c] / 1024.0;
+            }
+        }
         static const bool probe_clock = getenv("QK_SCAN_WAVE_CLOCK") != nullptr;
         static long long *d_clock = nullptr;
         sp.wave_clock = nullptr;
@@ -1811,6 +1878,11 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
             sp.wave_clock = d_clock;
         }
         QK_TRY(launch_scan(DB, maxch, dim3((unsigned)grid), dim3(64 * wpw), lds_launch, st, sp));
+        if (sp.xcd_stat) {
+            QK_HIP(hipMemcpyAsync(ctx->xcd_host, sp.xcd_stat, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+            QK_HIP(hipEventRecord(ctx->xcd_ev, st));
+            ctx->xcd_pending = true;
+        }
         if (probe_clock) {  // debug probe: distribution of the waves' busy time (tail = what a dynamic split could recover)
             std::vector<long long> h((size_t)grid * wpw * 8);
             QK_HIP(hipMemcpyAsync(h.data(), d_clock, h.size() * 8, hipMemcpyDeviceToHost, st));
@@ -1823,6 +1895,8 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
                 std::memcpy(&rows, hscal + 2, 8);
                 fprintf(stderr, "[k_scan launch] pack=%d grid=%lld nw=%d qshare=%d seg_ovh=%d active=%d records=%d unique_rows=%lld sequence_units=%lld\n",
                         sp.pack, (long long)grid, nw, (int)qshare, seg_ovh, hscal[0], hscal[1], (long long)rows, (long long)units);
+                fprintf(stderr, "[k_scan xcd weights] on=%d %d %d %d %d %d %d %d %d\n", sp.xcd_on, sp.xcd_w[0], sp.xcd_w[1], sp.xcd_w[2], sp.xcd_w[3],
+                        sp.xcd_w[4], sp.xcd_w[5], sp.xcd_w[6], sp.xcd_w[7]);
                 fprintf(stderr, "[k_scan params] DB=%d maxch=%d C=%d k=%d lds=%zu max_recs=%lld gtau=%d refresh=%d publish=%d npairs=%lld Q=%lld ws=%p vecs=%p\n",
                         DB, maxch, sp.C, sp.k, lds_launch, (long long)max_recs, sp.gtau != nullptr, sp.tau_refresh, sp.tau_publish,
                         (long long)npairs, (long long)Q, (void *)g_cnt, (void *)sp.vecs);
@@ -1834,7 +1908,7 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
                 t0 = std::min(t0, h[8 * i]);
                 t1 = std::max(t1, h[8 * i + 1]);
             }
-            if (wpw == 1 || sp.pack > 1) {  // mean end time by XCD (workgroups go round-robin over the 8 XCDs) and the slowest workgroups
+            {  // mean end time by XCD (workgroups go round-robin over the 8 XCDs) and the slowest workgroups
                 double xs[8] = {0}, xn[8] = {0};
                 std::vector<std::pair<long long, int>> byend;
                 for (size_t i = 0; i < nwv; i++) {

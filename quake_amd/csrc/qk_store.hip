@@ -6,6 +6,7 @@
 // layout is NOT the reference's row-major malloc array: it is the MFMA-fragment tile-major layout
 // described in qk_internal.h / DESIGN.md section 4, plus a per-row squared norm.
 #include "qk_internal.h"
+#include <atomic>
 
 #include <algorithm>
 #include <cstring>
@@ -373,8 +374,10 @@ extern "C" {
 int qk_store_create(qk_ctx *ctx, int d, qk_store **out) {
     if (!ctx || !out) QK_FAIL(QK_ERR_INVALID, "qk_store_create: null argument");
     if (d <= 0) QK_FAIL(QK_ERR_INVALID, "qk_store_create: d must be positive (got %d)", d);
+    static std::atomic<uint64_t> next_uid{1};
     qk_store *s = new qk_store();
     s->ctx = ctx;
+    s->uid = next_uid.fetch_add(1);
     s->d = d;
     s->dpad = qk_round_up(d, 16);
     s->nblk = s->dpad / 16;
