@@ -1067,40 +1067,11 @@ __global__ __launch_bounds__(64) void k_merge(MergeParams M) {
                 recs[i] = g0 + i < ns ? __shfl(sv, g0 + i + 1) : -1;
                 fetch2(recs[i], hs[i], os[i], ds[i], os1[i], ds1[i], oks[i]);
             }
-            // If pooling the group as it comes would overflow the pool (every overflow costs a select_pool, 2-11 us at k = 100),
-            // first take the exact k-th smallest of the keys just fetched -- bisection over the 16 key registers, ~1.5 us --
-            // as the bound: then at most k entries (+ ties) of the whole group pass.  (The first 128 entries of a record
-            // are in registers; the k-th smallest of any >= k fetched keys is an upper bound of the answer's k-th key.)
-            {
-                if (M.clock) {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    ck[2] = wall_clock64();
-                }
-                int nv[8], tot = 0;
-#pragma unroll
-                for (int i = 0; i < 8; i++) {
-                    const bool ok = recs[i] >= 0 && recs[i] < M.max_recs;
-                    nv[i] = ok ? min(min(__builtin_amdgcn_readfirstlane(hs[i].y), k), 128) : 0;
-                    tot += nv[i];
-                }
-                if (tot >= k && cnt + tot > Cm - 64) {
-                    uint32_t m0[8], m1[8];
-#pragma unroll
-                    for (int i = 0; i < 8; i++) {
-                        m0[i] = lane < nv[i] ? os[i] : 0xFFFFFFFFu;
-                        m1[i] = lane + 64 < nv[i] ? os1[i] : 0xFFFFFFFFu;
-                    }
-                    uint32_t T = 0;  // the largest value with fewer than k keys below it = the k-th smallest key
-                    for (int b = 31; b >= 0; b--) {
-                        const uint32_t tr = T | (1u << b);
-                        int c = 0;
-#pragma unroll
-                        for (int i = 0; i < 8; i++) c += __popcll(__ballot(m0[i] < tr)) + __popcll(__ballot(m1[i] < tr));
-                        if (c < k) T = tr;
-                    }
-                    tau = min(tau, T);
-                }
-                if (M.clock) ck[3] = wall_clock64();
+            // (an exact bound from the fetched keys -- bisection over the key registers -- was tried here: 13 us per use in
+            //  this one-wave kernel, more than the select_pool calls it saves at k <= 32; wide k goes to k_merge_wide)
+            if (M.clock) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                ck[2] = ck[3] = wall_clock64();
             }
 #pragma unroll
             for (int i = 0; i < 8; i++)
