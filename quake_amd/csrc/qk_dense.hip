@@ -685,10 +685,16 @@ int qk_dense_device(qk_ctx *ctx, qk_store *s, int64_t list_no, const qk_scan_arg
         QK_TRY(qk_ws_reserve(ctx, (size_t)Q * 8 + 4096));
         unsigned long long *best64 = (unsigned long long *)qk_ws_alloc(ctx, (size_t)Q * 8);
         if (!best64) QK_FAIL(QK_ERR_OOM, "dense argmin: workspace exhausted");
+        // the prep kernel of this batch left a ready-made "nothing yet" array (first use only)
+        const bool preinit = ctx->qprep_best64 && ctx->qprep_best64_n == Q;
+        if (preinit) {
+            best64 = ctx->qprep_best64;
+            ctx->qprep_best64_n = 0;
+        }
         const int num_cus_a = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
         QK_TRY(pe.mark(0));
         QK_TRY(pe.mark(1));
-        QK_HIP(hipMemsetAsync(best64, 0xFF, (size_t)Q * 8, st));
+        if (!preinit) QK_HIP(hipMemsetAsync(best64, 0xFF, (size_t)Q * 8, st));
         ArgminParams ap;
         ap.vecs = (const float4 *)s->vecs;
         ap.norms = s->norms;

@@ -41,7 +41,8 @@
 // xn[q] = canonical squared norm (k-ordered fmaf chain).  One workgroup = 16 queries staged through LDS so that the
 // global reads are coalesced and the 16 serial norm chains run out of LDS.
 __global__ __launch_bounds__(256) void k_prep_queries(const float *__restrict__ x, int64_t Q, int d, int nblk,
-                                                      float4 *__restrict__ xq4, float *__restrict__ xn) {
+                                                      float4 *__restrict__ xq4, float *__restrict__ xn,
+                                                      unsigned long long *__restrict__ best64) {
     extern __shared__ float sq[];  // [16][d+1]
     const int ldq = d + 1;
     const int64_t q0 = (int64_t)blockIdx.x * 16;
@@ -68,12 +69,15 @@ __global__ __launch_bounds__(256) void k_prep_queries(const float *__restrict__ 
         float acc = 0.0f;
         for (int k = 0; k < d; k++) acc = __fmaf_rn(s[k], s[k], acc);
         xn[q0 + threadIdx.x] = acc;
+        best64[q0 + threadIdx.x] = ~0ull;  // "nothing yet" for the nearest-centroid kernel (k_dense_argmin): saves its memset
     }
 }
 
 int qk_prep_queries(qk_ctx *ctx, const float *x, int64_t Q, int d, const float4 **xq4, const float **xn) {
     const int dpad = qk_round_up(d, 16), nblk = dpad / 16;
-    size_t need = (((size_t)Q * dpad * 4 + 255) & ~(size_t)255) + (size_t)Q * 4 + 256;
+    const size_t off_n = ((size_t)Q * dpad * 4 + 255) & ~(size_t)255;
+    const size_t off_b = (off_n + (size_t)Q * 4 + 255) & ~(size_t)255;
+    size_t need = off_b + (size_t)Q * 8 + 256;
     if (need > ctx->qprep_cap) {
         QK_HIP(hipStreamSynchronize(ctx->stream));
         if (ctx->qprep) QK_HIP(hipFree(ctx->qprep));
@@ -83,12 +87,14 @@ int qk_prep_queries(qk_ctx *ctx, const float *x, int64_t Q, int d, const float4 
         ctx->qprep_cap = need + need / 4;
     }
     float4 *q4 = (float4 *)ctx->qprep;
-    float *n = (float *)(ctx->qprep + (((size_t)Q * dpad * 4 + 255) & ~(size_t)255));
+    float *n = (float *)(ctx->qprep + off_n);
+    ctx->qprep_best64 = (unsigned long long *)(ctx->qprep + off_b);
+    ctx->qprep_best64_n = Q;  // initialised for Q queries; the first nearest-centroid launch consumes it
     const size_t lds = (size_t)16 * (d + 1) * 4;
     if (lds > 160 * 1024) QK_FAIL(QK_ERR_UNSUPPORTED, "d=%d too large for the query prep kernel", d);
     if (lds > 48 * 1024)
         QK_HIP(hipFuncSetAttribute((const void *)k_prep_queries, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_prep_queries, dim3((unsigned)((Q + 15) / 16)), dim3(256), lds, ctx->stream, x, Q, d, nblk, q4, n);
+    hipLaunchKernelGGL(k_prep_queries, dim3((unsigned)((Q + 15) / 16)), dim3(256), lds, ctx->stream, x, Q, d, nblk, q4, n, ctx->qprep_best64);
     QK_HIP(hipGetLastError());
     *xq4 = q4;
     *xn = n;
