@@ -97,6 +97,7 @@ int run_search(qk_ctx *ctx, qk_store *parent, qk_store *s, const float *x, int64
     const float4 *xq4 = nullptr;
     const float *xn = nullptr;
     QK_TRY(qk_prep_queries(ctx, sv.x, Q, d, &xq4, &xn));
+    const unsigned long long *packed = nullptr;
     // ---- coarse --------------------------------------------------------------------------------------
     if (use_parent && kk <= 0 && coarse_only) return QK_OK;
     if (use_parent && kk > 0) {
@@ -111,6 +112,7 @@ int run_search(qk_ctx *ctx, qk_store *parent, qk_store *s, const float *x, int64
         ca.out_ids = coarse_only ? sv.out_ids : (int64_t *)sv.pids;
         ca.out_dist = coarse_only ? sv.out_dist : nullptr;
         ca.record_events = timing != nullptr;
+        if (!coarse_only && kk == 1 && k <= QK_MAX_K) ca.packed_out = &packed;  // nprobe = 1: see qk_scan_args::pids_packed
         QK_TRY(qk_scan_device(ctx, parent, ca, coarse_only ? timing : nullptr, 0));
     }
     // ---- scan ------------------------------------------------------------------------------------------
@@ -129,6 +131,10 @@ int run_search(qk_ctx *ctx, qk_store *parent, qk_store *s, const float *x, int64
         } else {
             sa.pids = sv.pids;
             sa.P = Ps;
+            if (packed) {
+                sa.pids = nullptr;
+                sa.pids_packed = packed;
+            }
         }
         sa.sqrt_l2 = !ctx->squared_l2;
         if (use_parent && kk <= 0) {  // empty parent: nothing to probe -> padding only

@@ -722,8 +722,12 @@ int qk_dense_device(qk_ctx *ctx, qk_store *s, int64_t list_no, const qk_scan_arg
         AM_CASE(2, 4) AM_CASE(2, 2) AM_CASE(2, 1) AM_CASE(1, 4) AM_CASE(1, 2) AM_CASE(1, 1)
 #undef AM_CASE
         QK_TRY(pe.mark(2));
-        hipLaunchKernelGGL(k_argmin_finish, dim3((unsigned)((Q + 255) / 256)), dim3(256), 0, st, best64, Q, a.metric, a.sqrt_l2 ? 1 : 0,
-                           a.out_ids, a.out_dist);
+        if (a.packed_out && preinit) {
+            *a.packed_out = best64;  // lives in the query prep buffer: valid until the next batch is prepared
+        } else {
+            hipLaunchKernelGGL(k_argmin_finish, dim3((unsigned)((Q + 255) / 256)), dim3(256), 0, st, best64, Q, a.metric,
+                               a.sqrt_l2 ? 1 : 0, a.out_ids, a.out_dist);
+        }
         QK_HIP(hipGetLastError());
         QK_TRY(pe.mark(3));
         if (timing) {

@@ -170,6 +170,11 @@ struct qk_scan_args {
     // key emission (internal, the k > QK_MAX_K path): no top-k, every (pair, row) key is written to key_out[pair_base[pair] + row]
     uint32_t *key_out = nullptr;
     const int64_t *pair_base = nullptr;
+    // nearest-list shortcut (nprobe = 1): the coarse stage hands over k_dense_argmin's result array as it is -- key << 32 | list
+    // number per query, ~0 = none -- and the grouping / seeding kernels read the list number from it (P = 1, pids unused);
+    // the conversion kernel and its launch boundary are skipped.  packed_out: filled by the coarse stage when it can do so.
+    const unsigned long long *pids_packed = nullptr;
+    const unsigned long long **packed_out = nullptr;
     const float4 *xq4 = nullptr;  // [Q][nblk][4] fragment-ordered queries (qk_prep_queries), required
     const float *xn = nullptr;    // [Q] squared norms, required
 };

@@ -116,6 +116,7 @@ struct __align__(16) ActiveInfo {
 
 struct GroupParams {
     const int64_t *pids;  // [Q*P] or nullptr (all_lists: pair i -> list i % P)
+    const unsigned long long *pids_packed;  // [Q] (P = 1) or nullptr
     int64_t npairs;
     int P;
     const int32_t *pt_size;
@@ -141,7 +142,13 @@ struct GroupParams {
 };
 
 __device__ __forceinline__ int pair_pid(const GroupParams &G, int64_t i) {
-    int64_t p = G.pids ? G.pids[i] : (i % G.P);
+    int64_t p;
+    if (G.pids_packed) {  // nearest-list result of k_dense_argmin (qk_scan_args::pids_packed)
+        const unsigned long long v = G.pids_packed[i];
+        p = v == ~0ull ? -1 : (int64_t)(v & 0xFFFFFFFFull);
+    } else {
+        p = G.pids ? G.pids[i] : (i % G.P);
+    }
     if (p < 0 || p >= G.npids) return -1;
     return G.pt_size[p] > 0 ? (int)p : -1;
 }
@@ -332,6 +339,7 @@ __global__ __launch_bounds__(1024) void k_group_small(GroupParams G) {
 // removes most of the cold-start appends/compactions (the slow path of the scan epilogue).
 struct SeedParams {
     const int64_t *pids;  // [Q*P] or nullptr (pair i -> list i % P)
+    const unsigned long long *pids_packed;  // [Q] (P = 1) or nullptr
     int64_t npairs;
     int P;
     const int32_t *pt_size;
@@ -358,7 +366,13 @@ __global__ __launch_bounds__(64) void k_seed_tau(SeedParams S) {
     const int rr = blockIdx.x % S.seed_ranks;
     if (rr >= S.P) return;
     const int64_t pair = qq * S.P + rr;
-    int64_t p = S.pids ? S.pids[pair] : (pair % S.P);
+    int64_t p;
+    if (S.pids_packed) {
+        const unsigned long long v = S.pids_packed[pair];
+        p = v == ~0ull ? -1 : (int64_t)(v & 0xFFFFFFFFull);
+    } else {
+        p = S.pids ? S.pids[pair] : (pair % S.P);
+    }
     if (p < 0 || p >= S.npids) return;
     const int size_p = S.pt_size[p];
     if (size_p < S.k) return;  // fewer than k rows: no bound from this partition
@@ -1654,6 +1668,7 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
     QK_HIP(hipMemsetAsync(g_cnt, 0, zero_bytes, st));
     GroupParams G;
     G.pids = a.all_lists ? nullptr : a.pids;
+    G.pids_packed = a.all_lists ? nullptr : a.pids_packed;
     G.npairs = npairs;
     G.P = std::max(P, 1);
     G.pt_size = s->d_size;
@@ -1695,6 +1710,7 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
         // sample goes into gtau[q]
         SeedParams sd;
         sd.pids = G.pids;
+        sd.pids_packed = G.pids_packed;
         sd.npairs = npairs;
         sd.P = G.P;
         sd.pt_size = s->d_size;
