@@ -153,13 +153,19 @@ __device__ __forceinline__ int pair_pid(const GroupParams &G, int64_t i) {
     return G.pt_size[p] > 0 ? (int)p : -1;
 }
 
-__device__ __forceinline__ void group_count_one(const GroupParams &G, int64_t i) {
+// returns the partition of the pair (-1: none) and, in *pos, how many queries reached it before this one
+__device__ __forceinline__ int group_count_one(const GroupParams &G, int64_t i, int *pos = nullptr) {
     G.pair_head[i] = -1;
     G.pair_slots[i * QK_SLOTS] = 0;
     int p = pair_pid(G, i);
     // the first query to reach a partition lists it: the scan below walks the probed partitions only, not all of them
     // (a rank of an N-GPU index sees N x 4096 list numbers, 1/N of the batch's queries land on its own)
-    if (p >= 0 && atomicAdd(&G.g_cnt[p], 1) == 0) G.act_list[atomicAdd(G.n_act, 1)] = p;
+    if (p >= 0) {
+        const int old = atomicAdd(&G.g_cnt[p], 1);
+        if (old == 0) G.act_list[atomicAdd(G.n_act, 1)] = p;
+        if (pos) *pos = old;
+    }
+    return p;
 }
 
 __global__ void k_group_count(GroupParams G) {
@@ -325,11 +331,28 @@ __global__ void k_group_scatter(GroupParams G) {
 constexpr int QK_GROUP_SMALL = 8192;
 __global__ __launch_bounds__(1024) void k_group_small(GroupParams G) {
     __shared__ long long s_w[48];
-    for (int64_t i = threadIdx.x; i < G.npairs; i += 1024) group_count_one(G, i);
+    // partition and arrival rank of this thread's pairs stay in registers: the scatter below needs neither the list numbers
+    // again nor a second round of atomics (three dependent memory round trips less in a kernel that is nothing but those)
+    int pp[QK_GROUP_SMALL / 1024], pos[QK_GROUP_SMALL / 1024];
+#pragma unroll
+    for (int jj = 0; jj < QK_GROUP_SMALL / 1024; jj++) {
+        const int64_t i = threadIdx.x + 1024 * (int64_t)jj;
+        pp[jj] = -1;
+        pos[jj] = 0;
+        if (i < G.npairs) pp[jj] = group_count_one(G, i, &pos[jj]);
+    }
     __syncthreads();
     group_scan_body(G, s_w);
     __syncthreads();
-    for (int64_t i = threadIdx.x; i < G.npairs; i += 1024) group_scatter_one(G, i);
+#pragma unroll
+    for (int jj = 0; jj < QK_GROUP_SMALL / 1024; jj++) {
+        const int64_t i = threadIdx.x + 1024 * (int64_t)jj;
+        if (pp[jj] >= 0) {
+            const int at = G.g_qoff[pp[jj]] + pos[jj];
+            G.grouped_q[at] = (int32_t)(i / G.P);
+            G.grouped_pair[at] = (int32_t)i;
+        }
+    }
 }
 
 // ---- bound seeding ---------------------------------------------------------------------------------------
