@@ -327,8 +327,10 @@ __global__ void k_group_scatter(GroupParams G) {
 }
 
 // count + scan + scatter in ONE workgroup for small batches (<= QK_GROUP_SMALL pairs): two launches and two dependent
-// kernel boundaries less (bench configuration: 3 kernels, 20 us -> 1 kernel)
-constexpr int QK_GROUP_SMALL = 8192;
+// kernel boundaries less.  Measured (bench.py --nprobe 1/2/3/4/8 = 1024 ... 8192 pairs, group phase): 31 / 40 / 45 / 51 /
+// 72 us against 31 / 37 / 38 / 38 / 44 us for the three kernels -- the single workgroup wins only where launch latency is
+// all there is (a 1-query search: 10 pairs), so it serves batches up to 1024 pairs.
+constexpr int QK_GROUP_SMALL = 1024;
 __global__ __launch_bounds__(1024) void k_group_small(GroupParams G) {
     __shared__ long long s_w[48];
     // partition and arrival rank of this thread's pairs stay in registers: the scatter below needs neither the list numbers
