@@ -91,13 +91,19 @@ __global__ __launch_bounds__(256) void k_dense_ord(DenseParams P) {
             _Pragma("unroll") for (int nq_ = 0; nq_ < NQ; nq_++) acc[nq_] = (f32x4){0.f, 0.f, 0.f, 0.f};     \
         }                                                                                                    \
         _Pragma("unroll") for (int b_ = 0; b_ < DB; b_++) {                                                  \
-            _Pragma("unroll") for (int nq_ = 0; nq_ < NQ; nq_++) {                                           \
-                const float4 bq_ = qs[(size_t)nq_ * nblk * 64 + (dch * DB + b_) * 64 + lane];                \
-                acc[nq_] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[b_].x, bq_.x, acc[nq_], 0, 0, 0);          \
-                acc[nq_] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[b_].y, bq_.y, acc[nq_], 0, 0, 0);          \
-                acc[nq_] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[b_].z, bq_.z, acc[nq_], 0, 0, 0);          \
-                acc[nq_] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[b_].w, bq_.w, acc[nq_], 0, 0, 0);          \
-            }                                                                                                \
+            /* operands of the NQ query tiles first, then each k-step across the NQ independent accumulators */ \
+            /* (an accumulator still sees its own k-steps in order: same bits)                                */ \
+            float4 bq_[NQ];                                                                                  \
+            _Pragma("unroll") for (int nq_ = 0; nq_ < NQ; nq_++)                                             \
+                bq_[nq_] = qs[(size_t)nq_ * nblk * 64 + (dch * DB + b_) * 64 + lane];                        \
+            _Pragma("unroll") for (int nq_ = 0; nq_ < NQ; nq_++)                                             \
+                acc[nq_] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[b_].x, bq_[nq_].x, acc[nq_], 0, 0, 0);     \
+            _Pragma("unroll") for (int nq_ = 0; nq_ < NQ; nq_++)                                             \
+                acc[nq_] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[b_].y, bq_[nq_].y, acc[nq_], 0, 0, 0);     \
+            _Pragma("unroll") for (int nq_ = 0; nq_ < NQ; nq_++)                                             \
+                acc[nq_] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[b_].z, bq_[nq_].z, acc[nq_], 0, 0, 0);     \
+            _Pragma("unroll") for (int nq_ = 0; nq_ < NQ; nq_++)                                             \
+                acc[nq_] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[b_].w, bq_[nq_].w, acc[nq_], 0, 0, 0);     \
         }                                                                                                    \
         if (++dch == ncd) {                                                                                  \
             dch = 0;                                                                                         \
@@ -560,13 +566,19 @@ __global__ __launch_bounds__(256) void k_dense_argmin(ArgminParams P) {
             _Pragma("unroll") for (int nq_ = 0; nq_ < NQ; nq_++) acc[nq_] = (f32x4){0.f, 0.f, 0.f, 0.f};     \
         }                                                                                                    \
         _Pragma("unroll") for (int b_ = 0; b_ < DB; b_++) {                                                  \
-            _Pragma("unroll") for (int nq_ = 0; nq_ < NQ; nq_++) {                                           \
-                const float4 bq_ = qs[(size_t)nq_ * nblk * 64 + (dch * DB + b_) * 64 + lane];                \
-                acc[nq_] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[b_].x, bq_.x, acc[nq_], 0, 0, 0);          \
-                acc[nq_] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[b_].y, bq_.y, acc[nq_], 0, 0, 0);          \
-                acc[nq_] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[b_].z, bq_.z, acc[nq_], 0, 0, 0);          \
-                acc[nq_] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[b_].w, bq_.w, acc[nq_], 0, 0, 0);          \
-            }                                                                                                \
+            /* operands of the NQ query tiles first, then each k-step across the NQ independent accumulators */ \
+            /* (an accumulator still sees its own k-steps in order: same bits)                                */ \
+            float4 bq_[NQ];                                                                                  \
+            _Pragma("unroll") for (int nq_ = 0; nq_ < NQ; nq_++)                                             \
+                bq_[nq_] = qs[(size_t)nq_ * nblk * 64 + (dch * DB + b_) * 64 + lane];                        \
+            _Pragma("unroll") for (int nq_ = 0; nq_ < NQ; nq_++)                                             \
+                acc[nq_] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[b_].x, bq_[nq_].x, acc[nq_], 0, 0, 0);     \
+            _Pragma("unroll") for (int nq_ = 0; nq_ < NQ; nq_++)                                             \
+                acc[nq_] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[b_].y, bq_[nq_].y, acc[nq_], 0, 0, 0);     \
+            _Pragma("unroll") for (int nq_ = 0; nq_ < NQ; nq_++)                                             \
+                acc[nq_] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[b_].z, bq_[nq_].z, acc[nq_], 0, 0, 0);     \
+            _Pragma("unroll") for (int nq_ = 0; nq_ < NQ; nq_++)                                             \
+                acc[nq_] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[b_].w, bq_[nq_].w, acc[nq_], 0, 0, 0);     \
         }                                                                                                    \
         if (++dch == ncd) {                                                                                  \
             dch = 0;                                                                                         \
@@ -577,13 +589,14 @@ __global__ __launch_bounds__(256) void k_dense_argmin(ArgminParams P) {
                     const float v_ = acc[nq_][reg_];                                                         \
                     const uint32_t k_ = l2 ? ord_from_l2(l2_expanded(xnj[nq_], yv_[reg_], v_)) : ord_from_ip(v_); \
                     const int r_ = row0_ + reg_;                                                             \
-                    if (r_ < P.nrows) {                                                                      \
-                        if (k_ < best_ord[nq_]) {                                                            \
-                            best_ord[nq_] = k_;                                                              \
-                            best_row[nq_] = r_;                                                              \
-                        } else if (k_ == best_ord[nq_] && best_row[nq_] >= 0 && P.ids[r_] < P.ids[best_row[nq_]]) { \
-                            best_row[nq_] = r_;                                                              \
-                        }                                                                                    \
+                    /* straight-line update; an exact key tie (rare) is settled by the smaller id behind one uniform branch */ \
+                    const bool ok_ = r_ < P.nrows;                                                           \
+                    const bool lt_ = ok_ && k_ < best_ord[nq_];                                              \
+                    const bool eq_ = ok_ && k_ == best_ord[nq_] && best_row[nq_] >= 0;                       \
+                    best_ord[nq_] = lt_ ? k_ : best_ord[nq_];                                                \
+                    best_row[nq_] = lt_ ? r_ : best_row[nq_];                                                \
+                    if (__ballot(eq_)) {                                                                     \
+                        if (eq_ && P.ids[r_] < P.ids[best_row[nq_]]) best_row[nq_] = r_;                     \
                     }                                                                                        \
                 }                                                                                            \
             }                                                                                                \
