@@ -1791,7 +1791,9 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
         sp.active = active;
         sp.n_tiles = n_tiles;
         sp.gtau = share_tau ? gtau : nullptr;
+        static const int force_refresh = getenv("QK_SCAN_TAU_REFRESH") ? atoi(getenv("QK_SCAN_TAU_REFRESH")) : -1;
         sp.tau_refresh = P > 1 ? 1 : 0;  // one partition per query: the seed is all there is to share
+        if (force_refresh >= 0) sp.tau_refresh = force_refresh;
         sp.tau_publish = 1;
         if (!share_tau && a.tau_init) {  // caller-provided per-query bound (same ~bound format), never updated here
             sp.gtau = const_cast<uint32_t *>(a.tau_init);
