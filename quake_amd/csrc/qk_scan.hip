@@ -42,11 +42,11 @@
 // global reads are coalesced and the 16 serial norm chains run out of LDS.
 __global__ __launch_bounds__(256) void k_prep_queries(const float *__restrict__ x, int64_t Q, int d, int nblk,
                                                       float4 *__restrict__ xq4, float *__restrict__ xn,
-                                                      unsigned long long *__restrict__ best64) {
-    extern __shared__ float sq[];  // [16][d+1]
+                                                      unsigned long long *__restrict__ best64, int qpw) {
+    extern __shared__ float sq[];  // [qpw][d+1]
     const int ldq = d + 1;
-    const int64_t q0 = (int64_t)blockIdx.x * 16;
-    const int nq = (int)min((int64_t)16, Q - q0);
+    const int64_t q0 = (int64_t)blockIdx.x * qpw;
+    const int nq = (int)min((int64_t)qpw, Q - q0);
     for (int i = threadIdx.x; i < nq * d; i += 256) {
         int r = i / d, c = i - r * d;
         sq[r * ldq + c] = x[(q0 + r) * d + c];
@@ -90,11 +90,15 @@ int qk_prep_queries(qk_ctx *ctx, const float *x, int64_t Q, int d, const float4 
     float *n = (float *)(ctx->qprep + off_n);
     ctx->qprep_best64 = (unsigned long long *)(ctx->qprep + off_b);
     ctx->qprep_best64_n = Q;  // initialised for Q queries; the first nearest-centroid launch consumes it
-    const size_t lds = (size_t)16 * (d + 1) * 4;
+    // queries per workgroup: 16, fewer when that would leave most of the chip idle (1024 x 768: 64 workgroups took 16 us)
+    int qpw = 16;
+    while (qpw > 2 && (Q + qpw - 1) / qpw < 2 * (int64_t)std::max(1, ctx->prop.multiProcessorCount) && (int64_t)qpw * d > 1024) qpw >>= 1;
+    const size_t lds = (size_t)qpw * (d + 1) * 4;
     if (lds > 160 * 1024) QK_FAIL(QK_ERR_UNSUPPORTED, "d=%d too large for the query prep kernel", d);
     if (lds > 48 * 1024)
         QK_HIP(hipFuncSetAttribute((const void *)k_prep_queries, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_prep_queries, dim3((unsigned)((Q + 15) / 16)), dim3(256), lds, ctx->stream, x, Q, d, nblk, q4, n, ctx->qprep_best64);
+    hipLaunchKernelGGL(k_prep_queries, dim3((unsigned)((Q + qpw - 1) / qpw)), dim3(256), lds, ctx->stream, x, Q, d, nblk, q4, n,
+                       ctx->qprep_best64, qpw);
     QK_HIP(hipGetLastError());
     *xq4 = q4;
     *xn = n;
