@@ -84,6 +84,7 @@ struct qk_ctx {
     struct xcd_state {
         double w[8] = {1, 1, 1, 1, 1, 1, 1, 1};
         long long launches = 0;
+        int samples = 0;  // samples folded in so far
     };
     std::unordered_map<uint64_t, xcd_state> xcd;  // by store uid
     unsigned long long *xcd_host = nullptr;       // pinned [16]: ticks per class, waves per class

@@ -1874,6 +1874,7 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
                     sum += xs.w[c];
                 }
                 for (int c = 0; c < 8; c++) xs.w[c] *= 8.0 / sum;
+                xs.samples++;
             }
         }
         sp.xcd_on = 0;
@@ -1884,7 +1885,7 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
             sp.xcd_on = 1;
             for (int c = 0; c < 8; c++) sp.xcd_w[c] = std::max(1, (int)(xs.w[c] * 1024.0 + 0.5));
             const long long nl = xs.launches++;
-            const bool sample = !ctx->xcd_pending && (nl < 16 || (nl & 63) == 0);
+            const bool sample = !ctx->xcd_pending && (xs.samples < 8 || (nl & 63) == 0);  // 8 completed samples, then 1 in 64
             if (sample) {
                 if (!ctx->xcd_host) QK_HIP(hipHostMalloc((void **)&ctx->xcd_host, 16 * sizeof(unsigned long long)));
                 if (!ctx->xcd_ev) QK_HIP(hipEventCreateWithFlags(&ctx->xcd_ev, hipEventDisableTiming));
