@@ -526,14 +526,14 @@ __global__ __launch_bounds__(256) void k_dense_argmin(ArgminParams P) {
         xn_s[tid] = (row < P.Q && l2) ? P.xn[row] : 0.0f;
     }
     __syncthreads();
+    // running minimum per (lane, query) of key << 32 | id -- the (key, id) order as ONE integer order (ids < 2^32 here), so
+    // the update is a 64-bit compare and two selects; the ids of a lane's 4 rows travel with the tile like the norms do
     float xnj[NQ];
-    uint32_t best_ord[NQ];
-    int best_row[NQ];
+    unsigned long long best[NQ];
 #pragma unroll
     for (int nq = 0; nq < NQ; nq++) {
         xnj[nq] = xn_s[nq * 16 + j];
-        best_ord[nq] = 0xFFFFFFFFu;
-        best_row[nq] = -1;
+        best[nq] = ~0ull;
     }
     const int ntile_all = (P.nrows + 15) >> 4;
     const int wg_t0 = blockIdx.y * P.tiles_per_wg;
@@ -545,6 +545,8 @@ __global__ __launch_bounds__(256) void k_dense_argmin(ArgminParams P) {
         const int64_t tile_abs0 = (P.row_off >> 4) + t0;
         const float4 *src = P.vecs + tile_abs0 * nblk * 64 + lane;
         const float4 *nsrc = (const float4 *)(P.norms + (tile_abs0 << 4)) + g;
+        const longlong2 *isrc = (const longlong2 *)(P.ids + ((int64_t)t0 << 4)) + 2 * g;  // +8 longlong2 per tile (ids of the list)
+        longlong2 ia_cur = {0, 0}, ib_cur = {0, 0}, ia_next = {0, 0}, ib_next = {0, 0};
         const int nsteps = (t1 - t0) * ncd;
         float4 a0[DB], a1[DB];
         float4 yn_cur = make_float4(0.f, 0.f, 0.f, 0.f), yn_next = yn_cur;
@@ -556,6 +558,8 @@ __global__ __launch_bounds__(256) void k_dense_argmin(ArgminParams P) {
         _Pragma("unroll") for (int b_ = 0; b_ < DB; b_++) A[b_] = pp_[b_ * 64]; \
         if (ldch == 0) {                                              \
             if (l2) yn_next = nsrc[(int64_t)ltile * 4];               \
+            ia_next = isrc[(int64_t)ltile * 8];                       \
+            ib_next = isrc[(int64_t)ltile * 8 + 1];                   \
             ltile++;                                                  \
         }                                                             \
         if (++ldch == ncd) ldch = 0;                                  \
@@ -583,29 +587,27 @@ __global__ __launch_bounds__(256) void k_dense_argmin(ArgminParams P) {
         if (++dch == ncd) {                                                                                  \
             dch = 0;                                                                                         \
             const float yv_[4] = {yn_cur.x, yn_cur.y, yn_cur.z, yn_cur.w};                                   \
+            const uint32_t iv_[4] = {(uint32_t)ia_cur.x, (uint32_t)ia_cur.y, (uint32_t)ib_cur.x, (uint32_t)ib_cur.y}; \
             const int row0_ = (tile << 4) + 4 * g;                                                           \
             _Pragma("unroll") for (int nq_ = 0; nq_ < NQ; nq_++) {                                           \
                 _Pragma("unroll") for (int reg_ = 0; reg_ < 4; reg_++) {                                     \
                     const float v_ = acc[nq_][reg_];                                                         \
                     const uint32_t k_ = l2 ? ord_from_l2(l2_expanded(xnj[nq_], yv_[reg_], v_)) : ord_from_ip(v_); \
-                    const int r_ = row0_ + reg_;                                                             \
-                    /* straight-line update; an exact key tie (rare) is settled by the smaller id behind one uniform branch */ \
-                    const bool ok_ = r_ < P.nrows;                                                           \
-                    const bool lt_ = ok_ && k_ < best_ord[nq_];                                              \
-                    const bool eq_ = ok_ && k_ == best_ord[nq_] && best_row[nq_] >= 0;                       \
-                    best_ord[nq_] = lt_ ? k_ : best_ord[nq_];                                                \
-                    best_row[nq_] = lt_ ? r_ : best_row[nq_];                                                \
-                    if (__ballot(eq_)) {                                                                     \
-                        if (eq_ && P.ids[r_] < P.ids[best_row[nq_]]) best_row[nq_] = r_;                     \
-                    }                                                                                        \
+                    const unsigned long long c_ = ((unsigned long long)k_ << 32) | iv_[reg_];                \
+                    const bool lt_ = row0_ + reg_ < P.nrows && c_ < best[nq_];                               \
+                    best[nq_] = lt_ ? c_ : best[nq_];                                                        \
                 }                                                                                            \
             }                                                                                                \
             yn_cur = yn_next;                                                                                \
+            ia_cur = ia_next;                                                                                \
+            ib_cur = ib_next;                                                                                \
             tile++;                                                                                          \
         }                                                                                                    \
     }
         AM_LOAD(a0, 0);
         yn_cur = yn_next;
+        ia_cur = ia_next;
+        ib_cur = ib_next;
         int s = 0;
         while (s < nsteps) {
             if (s + 1 < nsteps) AM_LOAD(a1, s + 1);
@@ -622,8 +624,7 @@ __global__ __launch_bounds__(256) void k_dense_argmin(ArgminParams P) {
     // lane -> (key << 32 | id); min over the 4 row groups of the wave, the 4 waves, then the workgroups
 #pragma unroll
     for (int nq = 0; nq < NQ; nq++) {
-        unsigned long long v = ~0ull;
-        if (best_row[nq] >= 0) v = ((unsigned long long)best_ord[nq] << 32) | (unsigned long long)(uint32_t)P.ids[best_row[nq]];
+        unsigned long long v = best[nq];
         unsigned long long o = __shfl_xor(v, 16);
         v = o < v ? o : v;
         o = __shfl_xor(v, 32);
