@@ -550,6 +550,9 @@ struct ScanParams {
 #define QK_DYN_CHUNK_DEFAULT 16  // tiles per dynamic chunk
 #endif
 
+#ifndef QK_OPT_SELECT1
+#define QK_OPT_SELECT1 1      // in-loop compaction of one-wave pools (k <= 36) by bisection select instead of the rank sort
+#endif
 #ifndef QK_OPT_NT
 #define QK_OPT_NT 1           // non-temporal loads for the streamed partition rows (measured: loads-only 5.74 -> 6.44 TB/s)
 #endif
@@ -847,7 +850,7 @@ __global__ __launch_bounds__(256) void k_scan(ScanParams P) {
                                 const int n = __builtin_amdgcn_readlane(cnt, jq);
                                 uint32_t kth;
                                 int nn;
-                                if (MAXCH > 1) {
+                                if (MAXCH > 1 || QK_OPT_SELECT1) {
                                     nn = select_pool<MAXCH>(pool_ord + jq * C, pool_id + jq * C, n, k, lane, kth);
                                 } else {
                                     nn = compact_pool<MAXCH>(pool_ord + jq * C, pool_id + jq * C, n, k, lane);
