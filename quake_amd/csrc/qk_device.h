@@ -37,6 +37,10 @@ __device__ __forceinline__ int compact_pool(uint32_t *ord, int64_t *id, int n, i
         n = __builtin_amdgcn_readfirstlane(n);
         uint32_t kth_;
         if (n > k && select_core<MAXCH>(ord, id, n, k, lane, kth_) == k) n = k;
+    } else {  // one wave wide: worth it when the rank loop below would run over many more entries than survive
+        n = __builtin_amdgcn_readfirstlane(n);
+        uint32_t kth_;
+        if (n > 2 * k + 4 && select_core<MAXCH>(ord, id, n, k, lane, kth_) == k) n = k;
     }
     uint32_t o[MAXCH];
     int64_t d[MAXCH];
