@@ -1556,7 +1556,8 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
     // pool capacity per query: k + slack, limited by LDS (one wave per workgroup, 160 KiB max)
     const size_t lds_budget = 160 * 1024 - 64;
     const size_t q_bytes = (size_t)nblk * 1024;
-    int C = qk_round_up(k + std::max(28, std::min(k, 64)), 4);
+    static const int slack_min = getenv("QK_SCAN_SLACK") ? std::max(4, atoi(getenv("QK_SCAN_SLACK"))) : 28;
+    int C = qk_round_up(k + std::max(slack_min, std::min(k, 64)), 4);
     while ((size_t)16 * C * 12 + q_bytes > lds_budget && C > k + 4) C -= 4;
     if ((size_t)16 * C * 12 + q_bytes > lds_budget || C < k + 4 || C > 512)
         QK_FAIL(QK_ERR_UNSUPPORTED, "qk_scan: k=%d with d=%d does not fit the LDS top-k pools", k, s->d);
