@@ -473,6 +473,81 @@ __global__ __launch_bounds__(64) void k_seed_tau(SeedParams S) {
     if (lane == 0 && bound != 0xFFFFFFFFu) atomicMax(&S.gtau[q], ~bound);  // gtau holds ~bound: 0 = no bound yet
 }
 
+// exact key of one sampled row (row `lrow` of the partition that starts at arena row `row_base`) for the query xq: the
+// arithmetic of the MFMA path -- one k-ordered fmaf chain; the query values are broadcast with v_readlane
+__device__ __forceinline__ uint32_t seed_row_key(const SeedParams &S, const float *xq, float xnq, int64_t row_base, int lrow, int lane) {
+    const int64_t row = row_base + lrow;
+    const int64_t tile = row >> 4;
+    const int r = (int)(row & 15);
+    const float yn = S.norms[row];
+    float acc = 0.0f;
+    // 8 blocks (128 columns) at a time: the 32 float4 of the lane's row and the 128 query values (2 per lane,
+    // broadcast with v_readlane) are requested together, then one k-ordered fmaf chain -- the arithmetic of the MFMA path
+    for (int c0 = 0; c0 < S.nblk; c0 += 8) {
+        float4 v[8][4];
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            const int cc = min(c0 + c, S.nblk - 1);
+            const float4 *blk = S.vecs + (tile * S.nblk + cc) * 64 + r;
+#pragma unroll
+            for (int g = 0; g < 4; g++) v[c][g] = blk[g * 16];
+        }
+        const int colA = c0 * 16 + lane, colB = c0 * 16 + 64 + lane;
+        const float xa = colA < S.d ? xq[colA] : 0.0f;
+        const float xb = colB < S.d ? xq[colB] : 0.0f;
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            if (c0 + c < S.nblk) {
+                const float e[16] = {v[c][0].x, v[c][1].x, v[c][2].x, v[c][3].x, v[c][0].y, v[c][1].y, v[c][2].y, v[c][3].y,
+                                     v[c][0].z, v[c][1].z, v[c][2].z, v[c][3].z, v[c][0].w, v[c][1].w, v[c][2].w, v[c][3].w};
+#pragma unroll
+                for (int t = 0; t < 16; t++) {
+                    const int cl = c * 16 + t;  // column within this group of 128
+                    // (the builtin is typed int -> int: move the bits, not the value)
+                    const float xv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cl < 64 ? xa : xb), cl & 63));
+                    acc = __fmaf_rn(e[t], xv, acc);  // padded columns: e[t] == 0 and xv == 0 -> acc unchanged
+                }
+            }
+        }
+    }
+    return S.metric == QK_METRIC_L2 ? ord_from_l2(l2_expanded(xnq, yn, acc)) : ord_from_ip(acc);
+}
+
+// W waves per (query, partition) pair, 64 W sampled rows, one memory round trip deep like the one-wave kernel: the bound is the
+// k-th smallest of 4x as many rows (k = 10: the 4 % quantile of the partition instead of the 16 % one), so k_scan starts
+// every segment with fewer appends and compactions.  Keys meet in LDS; every thread ranks its own.
+template <int W>
+__global__ __launch_bounds__(64 * W) void k_seed_tau_wg(SeedParams S) {
+    __shared__ uint32_t s_key[64 * W];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t qq = blockIdx.x / S.seed_ranks;
+    const int rr = blockIdx.x % S.seed_ranks;
+    if (rr >= S.P) return;
+    const int64_t pair = qq * S.P + rr;
+    int64_t p;
+    if (S.pids_packed) {
+        const unsigned long long v = S.pids_packed[pair];
+        p = v == ~0ull ? -1 : (int64_t)(v & 0xFFFFFFFFull);
+    } else {
+        p = S.pids ? S.pids[pair] : (pair % S.P);
+    }
+    if (p < 0 || p >= S.npids) return;
+    const int size_p = S.pt_size[p];
+    if (size_p < S.k) return;  // (uniform over the workgroup: nobody reaches the barrier)
+    const int n = min(size_p, 64 * W);
+    const int mine = wv * 64 + lane;
+    uint32_t key = seed_row_key(S, S.x + qq * S.d, S.xn[qq], S.pt_off[p], min(mine, n - 1), lane);
+    if (mine >= n) key = 0xFFFFFFFFu;
+    s_key[threadIdx.x] = key;
+    __syncthreads();
+    int rk = 0;
+    for (int t = 0; t < 64 * W; t++) {
+        const uint32_t ot = s_key[t];
+        rk += (ot < key || (ot == key && t < (int)threadIdx.x)) ? 1 : 0;
+    }
+    if (rk == S.k - 1 && key != 0xFFFFFFFFu) atomicMax(&S.gtau[qq], ~key);  // gtau holds ~bound: 0 = no bound yet
+}
+
 // ---- the scan kernel ---------------------------------------------------------------------------------
 struct ScanParams {
     const float4 *vecs;
@@ -1763,7 +1838,15 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
         //  Larger samples -- 128 / 256 rows, scalar or on MFMA with all tile loads in flight -- take 6-12 us off k_scan and
         //  add 10-40 us here: the kernel is a chain of five dependent memory round trips, not arithmetic.)
         const dim3 sg((unsigned)(Q * sd.seed_ranks));
-        if (k <= 64)
+        // (QK_SEED_WAVES = 2 / 4: 128 / 256-row samples at the latency of the 64-row one.  Measured on the bench: k_scan 0.254 ->
+        //  0.248 / 0.240 ms, this kernel 10 -> 17 / 30 us -- a 256-row sample of 1024 partitions is 134 MB of reads, 9 % of what
+        //  the scan streams.  One for one again; the default stays at 64 rows.)
+        static const int seed_waves = getenv("QK_SEED_WAVES") ? atoi(getenv("QK_SEED_WAVES")) : 1;
+        if (k <= 64 && seed_waves == 4)
+            hipLaunchKernelGGL((k_seed_tau_wg<4>), sg, dim3(256), 0, st, sd);
+        else if (k <= 64 && seed_waves == 2)
+            hipLaunchKernelGGL((k_seed_tau_wg<2>), sg, dim3(128), 0, st, sd);
+        else if (k <= 64)
             hipLaunchKernelGGL((k_seed_tau<1>), sg, dim3(64), 0, st, sd);
         else if (k <= 128)
             hipLaunchKernelGGL((k_seed_tau<2>), sg, dim3(64), 0, st, sd);
