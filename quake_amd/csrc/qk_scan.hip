@@ -1939,7 +1939,9 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
         }
         // ---- XCD balance (see qk_ctx::xcd_state) ---------------------------------------------------------------------------
         static const int xcd_adapt = getenv("QK_SCAN_XCD_ADAPT") ? atoi(getenv("QK_SCAN_XCD_ADAPT")) : 1;
-        if (ctx->xcd_pending && hipEventQuery(ctx->xcd_ev) == hipSuccess) {  // a finished sample: speed = share / time
+        const bool xcd_ready = ctx->xcd_pending && hipEventQuery(ctx->xcd_ev) == hipSuccess;
+        if (ctx->xcd_pending && !xcd_ready) (void)hipGetLastError();  // "not ready" is not an error: keep it out of the later checks
+        if (xcd_ready) {  // a finished sample: speed = share / time
             ctx->xcd_pending = false;
             qk_ctx::xcd_state &xs = ctx->xcd[ctx->xcd_key];
             double sp8[8], mean = 0;
