@@ -307,7 +307,7 @@ def main():
                         f"batch={Q} queries, k={k}, nprobe={nprobe} "
                         f"(BASELINE.json configs[{2 if (metric == 'ip' and d == 768) else 1}] per GPU)",
             "nvec_per_gpu": n, "dim": d, "metric_type": metric, "nlist_per_gpu": nlist, "batch": Q, "k": k, "nprobe": nprobe,
-            "recall_at_k": round(recall, 4), "recall_sweep": sweep,
+            "recall_at_k": round(recall, 4), "recall_sweep": sweep, "settle_steps": max(args.settle, 0),
             "sharding": ("lists by number across ranks, centroids replicated; all-gather of the probed-list ids, local scan, "
                          "all-to-all of the per-rank top-k, merge on the rank that owns the query") if world > 1 else "single GPU",
         },
