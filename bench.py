@@ -5,18 +5,29 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json configs[1], SURVEY.md section 8d "C2"): synthetic 10M x 128 f32 Gaussian mixture (4096 centres
-~N(0,1), within-cluster sigma 0.3), L2, nlist=4096 built with the GPU k-means, batch of 1024 queries, k=10.
-One "step" = one qk_search() of the whole batch (coarse + partition scan + merge) with queries, index and outputs
-resident in HBM.  nprobe = the smallest of {1,2,4,...,64} reaching recall@10 >= 0.9 against exact brute force.
-N > 1: weak scaling -- every rank owns its own 10M-vector shard (4096 lists, cluster-sharded by list number), the
-batch is N*1024 queries, centroids are replicated, each rank scans the probed lists it owns and the per-rank top-k
-are all-gathered over RCCL and merged.
+Headline workload (BASELINE.json configs[1], SURVEY.md section 8d "C2"): synthetic 10M x 128 f32 Gaussian mixture (4096
+centres ~N(0,1), within-cluster sigma 0.3), L2, nlist=4096 built with the GPU k-means, batches of 1024 queries, k=10.
+One "step" = one qk_search() of a whole batch (coarse + partition scan + merge) with queries, index and outputs resident
+in HBM; the timed region rotates over 4 different query batches.  nprobe = the smallest of {1,2,4,...,64} reaching
+recall@10 >= 0.9 against exact brute force.
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (k_scan, HBM-bound): algorithmic bytes per
-launch (sum over unique probed partitions of n_p*d*4) / the kernel's mean duration measured with HIP events recorded
-on the launch stream inside the timed region.  `cpu_baseline` times oracle/ (the CPU port of the reference path) on
-the host cores on a bounded sample of the same queries.
+Next to the headline line the same JSON object carries (N = 1 only, `--no-extra` skips them):
+  workloads.hard      the same corpus shape with within-cluster sigma 1.0: components overlap, so the recall target
+                      NEEDS nprobe >= 8 -- the regime where a probed partition is shared by many queries of the batch;
+                      reported with its own `roofline` (unique bytes / k_scan time)
+  workloads.configs0  BASELINE.json configs[0] shape on the S-SIFT stand-in (1M x 128 integer-valued f32,
+                      nlist=1024, nprobe=10, k=10, batch=1): GPU single-query rate beside the CPU port on ONE thread (the
+                      reference default: num_workers=0, num_threads=1, common.h:73,175), same ids
+
+N > 1 (BASELINE.json configs[3] shape, one rank per GPU): the corpus is 12.5M vectors per rank, ONE global k-means over
+all ranks (local assign + accumulate, all-reduce of sums and counts per iteration: quake_amd/sharded.py) produces
+nlist = 8192*N global centroids, replicated; list p lives on rank p % N; the batch is 512*N queries; every rank computes
+the coarse step, scans the probed lists it owns and the per-rank top-k meet in one all-to-all + merge.
+
+`roofline` is for the dominant kernel (k_scan, HBM-bound): algorithmic bytes per launch (sum over unique probed
+partitions of n_p*d*4) / the kernel's mean duration measured with HIP events recorded on the launch stream inside the
+timed region.  `cpu_baseline` times oracle/ (the CPU port of the reference path) on the host cores on a bounded sample
+of the same queries; the ids of the bench batch must equal the batched oracle's, bit for bit, or the run fails.
 """
 import argparse
 import json
@@ -31,6 +42,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+METRIC_NAME = "queries/sec at recall@10≥0.9 (SIFT1M, k=10); 1/2/4/8 GPU"
+N_BATCHES = 4  # query batches the timed region rotates over
 
 
 def log(*a):
@@ -38,13 +51,15 @@ def log(*a):
         print("[bench]", *a, file=sys.stderr, flush=True)
 
 
-def gen_mixture(n, d, ncent, seed, device, sigma=0.3, chunk=1 << 20, unit=False):
+# ---- synthetic corpora ---------------------------------------------------------------------------
+def gen_mixture(n, d, ncent, seed, device, sigma=0.3, chunk=1 << 20, unit=False, cent=None):
     g = torch.Generator(device=device).manual_seed(seed)
-    cent = torch.randn(ncent, d, generator=g, device=device)
+    if cent is None:
+        cent = torch.randn(ncent, d, generator=g, device=device)
     x = torch.empty(n, d, device=device)
     for i0 in range(0, n, chunk):
         m = min(chunk, n - i0)
-        a = torch.randint(0, ncent, (m,), generator=g, device=device)
+        a = torch.randint(0, cent.shape[0], (m,), generator=g, device=device)
         v = cent[a] + sigma * torch.randn(m, d, generator=g, device=device)
         x[i0:i0 + m] = torch.nn.functional.normalize(v, dim=1) if unit else v
     return x, cent
@@ -55,6 +70,22 @@ def gen_queries(nq, cent_all, seed, device, sigma=0.3, unit=False):
     a = torch.randint(0, cent_all.shape[0], (nq,), generator=g, device=device)
     v = cent_all[a] + sigma * torch.randn(nq, cent_all.shape[1], generator=g, device=device)
     return (torch.nn.functional.normalize(v, dim=1) if unit else v).contiguous()
+
+
+def gen_ssift(n, device, seed=1234, d=128, ncomp=1024, sigma=25.0, cent=None, chunk=1 << 20):
+    """S-SIFT, the stand-in for SIFT1M: integer-valued f32 in [0, 218] drawn from a 1024-component Gaussian
+    mixture (centres ~U[20,120]^d, sigma 25, clipped, rounded).  Every fp32 partial sum of a distance is an exact integer
+    (< 2^24), so the direct and the expanded L2 forms agree bit for bit."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    if cent is None:
+        cent = 20.0 + 100.0 * torch.rand(ncomp, d, generator=g, device=device)
+    x = torch.empty(n, d, device=device)
+    for i0 in range(0, n, chunk):
+        m = min(chunk, n - i0)
+        a = torch.randint(0, cent.shape[0], (m,), generator=g, device=device)
+        v = cent[a] + sigma * torch.randn(m, d, generator=g, device=device)
+        x[i0:i0 + m] = torch.clamp(torch.round(v), 0.0, 218.0)
+    return x, cent
 
 
 def brute_force_topk(q, x, k, id_base=0, chunk=1 << 20, metric="l2"):
@@ -80,6 +111,402 @@ def recall_at_k(ids, gt, k):
     return hit.mean().item()
 
 
+# ---- single-GPU index build (untimed) -------------------------------------------------------------------------------------
+def build_single(ctx, dev, x, nlist, metric, niter, keep_host):
+    """k-means on the GPU, vectors bucketed by list, device store + flat parent over the centroids."""
+    from quake_amd.capi import Store
+    n, d = x.shape
+    t0 = time.time()
+    centroids, assign, _ = ctx.kmeans(x, nlist, metric, niter=niter, seed=1234)
+    torch.cuda.synchronize()
+    t_kmeans = time.time() - t0
+    order = torch.argsort(assign, stable=True)
+    counts = torch.bincount(assign, minlength=nlist).cpu().numpy().astype(np.int64)
+    ids_sorted = order.contiguous()
+    x_sorted = x[order].contiguous()
+    del order, assign
+    offsets = np.zeros(nlist + 1, np.int64)
+    offsets[1:] = np.cumsum(counts)
+    store = Store(ctx, d)
+    store.build_csr(offsets, ids_sorted, x_sorted)
+    parent = Store(ctx, d)
+    parent.build_csr(np.array([0, nlist], np.int64), torch.arange(nlist, device=dev), centroids.contiguous())
+    torch.cuda.synchronize()
+    host = None
+    if keep_host:
+        host = (x_sorted.cpu().numpy(), ids_sorted.cpu().numpy(), offsets.copy(), centroids.cpu().numpy())
+    log(f"index: {n}x{d} nlist={nlist} k-means {t_kmeans:.2f}s, list sizes min/mean/max = "
+        f"{counts.min()}/{counts.mean():.0f}/{counts.max()}, arena {store.device_bytes() / 1e9:.2f} GB")
+    return dict(parent=parent, store=store, host=host, kmeans_s=t_kmeans, counts=counts)
+
+
+def pick_nprobe(step, batches, gts, k, target, fixed, recall_fn):
+    """smallest nprobe of {1,2,4,...,64} whose recall@k over the batches reaches the target (or the fixed one)."""
+    sweep = []
+
+    def rec(p):
+        r = 0.0
+        for b in range(len(batches)):
+            ri, _ = step(p, b)
+            torch.cuda.synchronize()
+            r += recall_fn(ri, b)
+        return r / len(batches)
+
+    nprobe = fixed
+    if nprobe <= 0:
+        for p in (1, 2, 4, 8, 16, 32, 64):
+            r = rec(p)
+            sweep.append((p, round(r, 4)))
+            if r >= target:
+                nprobe = p
+                break
+        if nprobe <= 0:
+            nprobe = 64
+    return nprobe, rec(nprobe), sweep
+
+
+def timed_region(ctx, step, nprobe, steps, warmup, settle, dist, dev):
+    """settle + warmup untimed, then EXACTLY `steps` steps between barrier + synchronize; one HIP event pair per step around
+    the scan kernel (timing mode 3).  Returns (elapsed seconds max over ranks, scan-kernel event sums, phase sums)."""
+    ctx.set_timing(0)
+    for i in range(max(settle, 0)):
+        step(nprobe, i % N_BATCHES)
+    for i in range(warmup):
+        step(nprobe, i % N_BATCHES)
+    ctx.set_timing(3)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(nprobe, i % N_BATCHES)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    ev = ctx.read_timing()
+    ctx.set_timing(2)  # phase breakdown: a short untimed pass with events around every phase
+    for i in range(min(steps, 20)):
+        step(nprobe, i % N_BATCHES)
+    torch.cuda.synchronize()
+    ev_ph = ctx.read_timing()
+    ctx.set_timing(0)
+    if dist is not None:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = tt.item()
+    return elapsed, ev, ev_ph
+
+
+def roofline_of(scan_bytes, ev, traffic=None):
+    scan_ms = ev["scan_ms"] / max(ev["calls"], 1)
+    achieved = scan_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
+    return {
+        "kernel": "k_scan", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+        "algorithmic_bytes_per_launch": int(scan_bytes), "kernel_ms_avg": round(scan_ms, 5), "launches": ev["calls"],
+    }
+
+
+def phases_of(ev_ph):
+    c = max(ev_ph["calls"], 1)
+    return {"coarse": round(ev_ph["coarse_ms"] / c, 4), "group": round(ev_ph["group_ms"] / c, 4),
+            "scan": round(ev_ph["scan_ms"] / c, 4), "merge": round(ev_ph["merge_ms"] / c, 4),
+            "note": "separate untimed pass with events around every phase"}
+
+
+def committed_traffic(name, n, d, k, nprobe):
+    """HBM bytes per k_scan launch from the committed rocprofv3 PMC pass of this command (profiles/<name>), if it matches
+    the configuration that just ran; a PMC pass cannot run inside this process."""
+    path = os.path.join(ROOT, "profiles", name)
+    if not os.path.exists(path):
+        return None
+    try:
+        pj = json.load(open(path))
+        if pj.get("nvec") == n and pj.get("nprobe") == nprobe and pj.get("dim", 128) == d and pj.get("k", 10) == k:
+            return pj.get("traffic_bytes_per_launch")
+    except Exception:
+        pass
+    return None
+
+
+def run_single_workload(ctx, dev, args, name, sigma, fixed_nprobe, steps, warmup, settle, cpu_seconds, traffic_file=None):
+    """Build, sweep nprobe, time, verify against the oracle.  Returns the result dict of one single-GPU workload."""
+    n, d, nlist, k, Q, metric = args.nvec, args.dim, args.nlist, args.k, args.batch, args.metric
+    unit = metric == "ip"
+    t0 = time.time()
+    x, cent_true = gen_mixture(n, d, nlist, seed=1, device=dev, sigma=sigma, unit=unit)
+    torch.cuda.synchronize()
+    log(f"[{name}] generated {n}x{d} (sigma {sigma}) in {time.time() - t0:.1f}s")
+    want_cpu = not args.no_cpu
+    idx = build_single(ctx, dev, x, nlist, metric, args.niter, keep_host=want_cpu)
+    parent, store = idx["parent"], idx["store"]
+    batches = [gen_queries(Q, cent_true, seed=2 + b, device=dev, sigma=sigma, unit=unit) for b in range(N_BATCHES)]
+    t0 = time.time()
+    gts = [brute_force_topk(q, x, k, metric=metric)[0] for q in batches]
+    torch.cuda.synchronize()
+    log(f"[{name}] brute-force ground truth of {N_BATCHES} batches {time.time() - t0:.2f}s")
+    del x
+    out_i = torch.empty((Q, k), dtype=torch.int64, device=dev)
+    out_d = torch.empty((Q, k), dtype=torch.float32, device=dev)
+
+    def step(nprobe, b):
+        return ctx.search(parent, store, batches[b], nprobe, k, metric, out=(out_i, out_d))
+
+    nprobe, recall, sweep = pick_nprobe(step, batches, gts, k, args.recall_target, fixed_nprobe,
+                                        lambda ri, b: recall_at_k(ri, gts[b], k))
+    log(f"[{name}] nprobe={nprobe} recall@{k}={recall:.4f} sweep={sweep}")
+    ctx.set_timing(1)
+    _, _, tinfo = ctx.search(parent, store, batches[0], nprobe, k, metric, timing=True)
+    log(f"[{name}] phases (ms):", {kk: round(v, 4) if isinstance(v, float) else v for kk, v in tinfo.items()})
+    elapsed, ev, ev_ph = timed_region(ctx, step, nprobe, steps, warmup, settle, None, dev)
+    # algorithmic bytes: mean over the rotated batches (each launch reports the unique rows it scanned)
+    scan_bytes = 0
+    ctx.set_timing(1)
+    for b in range(N_BATCHES):
+        scan_bytes += int(ctx.search(parent, store, batches[b], nprobe, k, metric, timing=True)[2]["scan_bytes"])
+    ctx.set_timing(0)
+    scan_bytes //= N_BATCHES
+    res = {
+        "value": round(Q * steps / elapsed, 1), "unit": "queries/s", "ms_per_step": round(1e3 * elapsed / steps, 4),
+        "steps": steps, "warmup": warmup,
+        "config": {
+            "workload": f"Synthetic {n // 1_000_000}M x {d} f32 {metric.upper()} {'unit-norm ' if unit else ''}Gaussian mixture "
+                        f"(sigma {sigma}), nlist={nlist}, batch={Q} queries, k={k}, nprobe={nprobe}",
+            "nvec": n, "dim": d, "metric_type": metric, "nlist": nlist, "batch": Q, "k": k, "nprobe": nprobe, "sigma": sigma,
+            "recall_at_k": round(recall, 4), "recall_sweep": sweep, "settle_steps": max(settle, 0),
+            "query_batches_rotated": N_BATCHES,
+        },
+        "roofline": roofline_of(scan_bytes, ev, committed_traffic(traffic_file, n, d, k, nprobe) if traffic_file else None),
+        "phases_ms": phases_of(ev_ph),
+        "build": {"kmeans_s": round(idx["kmeans_s"], 2), "niter": args.niter},
+    }
+    # ---- parity + CPU baseline: the oracle port on the host cores (test infrastructure used as checker / timed port) ----
+    if want_cpu:
+        import oracle as O
+        hv, hi, ho, hc = idx["host"]
+        qh = batches[0].cpu().numpy()
+        gi0, gd0 = step(nprobe, 0)
+        torch.cuda.synchronize()
+        gi0, gd0 = gi0.cpu().numpy(), gd0.cpu().numpy()
+        cores = O.max_threads()
+
+        def time_cpu(batched, budget, threads, nq):
+            t, nn, reps, ids, dist = 0.0, 0, 0, None, None
+            while reps == 0 or (t < budget and reps < 10000):
+                t1 = time.perf_counter()
+                ids, dist = O.search(qh[:nq], hc, hv, hi, ho, nprobe, k, metric, batched_scan=batched, num_threads=threads)
+                t += time.perf_counter() - t1
+                nn += nq
+                reps += 1
+            return nn / t, nn, reps, t, ids, dist
+
+        qps_b, n_b, reps_b, t_b, ids_b, dist_b = time_cpu(True, cpu_seconds * 0.35, cores, Q)
+        # parity at the bench size: the canonical (batched, expanded-form) oracle must give the SAME bits as the GPU
+        same_ids = float((ids_b == gi0).mean())
+        same_dist = float((dist_b.view(np.uint32) == gd0.view(np.uint32)).mean())
+        if same_ids != 1.0 or same_dist != 1.0:
+            raise SystemExit(f"[{name}] PARITY FAILURE at the bench size: ids equal {same_ids:.6f}, distance bits equal "
+                             f"{same_dist:.6f} (HIP qk_search vs oracle batched_serial_scan)")
+        qps_s, n_s, reps_s, t_s, ids_s, _ = time_cpu(False, cpu_seconds * 0.35, cores, Q)
+        n1 = max(8, min(Q, int(qps_s / max(cores, 1) * cpu_seconds * 0.3) or 8))  # a few seconds on one thread
+        qps_1, _, _, t_1, _, _ = time_cpu(False, 0.0, 1, n1)
+        best_batched = qps_b > qps_s
+        res["cpu_baseline"] = {
+            "value": round(max(qps_b, qps_s), 1), "unit": "queries/s", "cores": cores, "kind": "port",
+            "sample": f"the {Q}-query bench batch 0 replayed {reps_b if best_batched else reps_s}x, same index/nprobe/k, oracle "
+                      f"search() = coarse + {'batched_serial_scan' if best_batched else 'serial_scan'} semantics on {cores} "
+                      f"threads, {t_b if best_batched else t_s:.1f}s (the faster of the reference's two scan variants); "
+                      f"single thread: {n1} queries in {t_1:.1f}s",
+            "serial_scan_qps": round(qps_s, 1), "batched_scan_qps": round(qps_b, 1),
+            "single_thread_qps": round(qps_1, 1), "threads_speedup": round(max(qps_b, qps_s) / max(qps_1, 1e-9), 1),
+            "ids_equal_to_gpu_frac": same_ids, "distance_bits_equal_to_gpu_frac": same_dist,
+            "ids_equal_serial_direct_form_frac": round(float((ids_s == gi0).mean()), 5),
+        }
+        res["speedup_vs_cpu"] = round(res["value"] / res["cpu_baseline"]["value"], 1)
+    store.close()
+    parent.close()
+    del idx, batches, gts
+    torch.cuda.empty_cache()
+    return res
+
+
+def run_configs0(ctx, dev, args):
+    """BASELINE.json configs[0] shape on S-SIFT: 1M x 128, nlist=1024, nprobe=10, k=10, L2, batch = 1."""
+    n, d, nlist, nprobe, k, nq = 1_000_000, 128, 1024, 10, 10, 1000
+    x, cent = gen_ssift(n, dev, seed=1234)
+    q, _ = gen_ssift(nq, dev, seed=4321, cent=cent)
+    idx = build_single(ctx, dev, x, nlist, "l2", args.niter, keep_host=not args.no_cpu)
+    parent, store = idx["parent"], idx["store"]
+    gt, _ = brute_force_topk(q, x, k)
+    del x
+    out_i = torch.empty((1, k), dtype=torch.int64, device=dev)
+    out_d = torch.empty((1, k), dtype=torch.float32, device=dev)
+    qs = [q[i:i + 1].contiguous() for i in range(nq)]
+    ids_all = torch.empty((nq, k), dtype=torch.int64, device=dev)
+    for i in range(nq):  # warm-up pass, also the answers
+        ctx.search(parent, store, qs[i], nprobe, k, "l2", out=(ids_all[i:i + 1], out_d))
+    torch.cuda.synchronize()
+    recall = recall_at_k(ids_all, gt, k)
+    # (a) back-to-back single-query searches, device buffers, one synchronisation at the end: launch throughput
+    t0 = time.perf_counter()
+    for i in range(nq):
+        ctx.search(parent, store, qs[i], nprobe, k, "l2", out=(out_i, out_d))
+    torch.cuda.synchronize()
+    t_pipe = time.perf_counter() - t0
+    # (b) one query at a time, synchronised: latency as a caller sees it
+    lat = []
+    for i in range(min(nq, 200)):
+        t1 = time.perf_counter()
+        ctx.search(parent, store, qs[i], nprobe, k, "l2", out=(out_i, out_d))
+        torch.cuda.synchronize()
+        lat.append(time.perf_counter() - t1)
+    lat = np.array(lat) * 1e6
+    # (c) whole 1000-query batch in one call
+    ob_i = torch.empty((nq, k), dtype=torch.int64, device=dev)
+    ob_d = torch.empty((nq, k), dtype=torch.float32, device=dev)
+    for _ in range(3):
+        ctx.search(parent, store, q, nprobe, k, "l2", out=(ob_i, ob_d))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        ctx.search(parent, store, q, nprobe, k, "l2", out=(ob_i, ob_d))
+    torch.cuda.synchronize()
+    t_batch = (time.perf_counter() - t0) / 20
+    res = {
+        "config": {"workload": "S-SIFT (SIFT1M stand-in) 1M x 128 integer-valued f32 L2, nlist=1024, nprobe=10, k=10, batch=1 "
+                               "(BASELINE.json configs[0])", "recall_at_k": round(recall, 4), "queries": nq},
+        "value": round(nq / t_pipe, 1), "unit": "queries/s",
+        "note": "batch=1 searches issued back to back on one stream (device buffers), one synchronisation at the end",
+        "latency_us_synchronised": {"p50": round(float(np.percentile(lat, 50)), 1), "p99": round(float(np.percentile(lat, 99)), 1)},
+        "batch_1000_qps": round(nq / t_batch, 1),
+    }
+    if not args.no_cpu:
+        import oracle as O
+        hv, hi, ho, hc = idx["host"]
+        qh = q.cpu().numpy()
+        # the reference default: serial_scan, one query per call, ONE thread
+        t0 = time.perf_counter()
+        cpu_ids = np.empty((nq, k), np.int64)
+        for i in range(nq):
+            cpu_ids[i], _ = O.search(qh[i:i + 1], hc, hv, hi, ho, nprobe, k, "l2", batched_scan=False, num_threads=1)
+        t_cpu = time.perf_counter() - t0
+        same = float((cpu_ids == ids_all.cpu().numpy()).mean())
+        same_b = float((cpu_ids == ob_i.cpu().numpy()).mean())
+        if same != 1.0 or same_b != 1.0:
+            raise SystemExit(f"[configs0] PARITY FAILURE: batch=1 ids equal {same:.6f}, batch=1000 ids equal {same_b:.6f} "
+                             f"(HIP vs oracle serial_scan, integer data)")
+        res["cpu_baseline"] = {"value": round(nq / t_cpu, 1), "unit": "queries/s", "cores": 1, "kind": "port",
+                               "sample": f"the same {nq} queries, one search() call per query, serial_scan semantics, 1 thread, "
+                                         f"{t_cpu:.1f}s", "ids_equal_to_gpu_frac": same}
+        res["speedup_vs_cpu"] = round(res["value"] / res["cpu_baseline"]["value"], 1)
+    store.close()
+    parent.close()
+    torch.cuda.empty_cache()
+    return res
+
+
+# ---- N > 1: BASELINE.json configs[3] shape --------------------------------------------------------------------------------
+def run_sharded(ctx, dev, args, dist, rank, world):
+    from quake_amd.capi import Store
+    from quake_amd.sharded import GpuEngine, ShardedIndex, sharded_kmeans
+    n, d, k, metric = args.nvec_sharded, args.dim, args.k, args.metric
+    nlist_g = args.nlist_sharded * world
+    Q = args.batch_sharded * world
+    unit = metric == "ip"
+    # the SAME mixture on every rank (nlist_g components), a different draw per rank
+    g0 = torch.Generator(device=dev).manual_seed(1)
+    cent_true = torch.randn(nlist_g, d, generator=g0, device=dev)
+    x, _ = gen_mixture(n, d, nlist_g, seed=1000 + rank, device=dev, unit=unit, cent=cent_true)
+    id_base = rank * n
+    torch.cuda.synchronize()
+    t0 = time.time()
+    centroids, assign = sharded_kmeans(ctx, dist, x, nlist_g, metric, niter=args.niter, seed=1234, rank=rank, world=world)
+    torch.cuda.synchronize()
+    t_kmeans = time.time() - t0
+    log(f"sharded k-means over {world} ranks: {n * world} vectors, nlist={nlist_g}, niter={args.niter}: {t_kmeans:.2f}s")
+    # route every vector to the owner of its list (list p lives on rank p % world): one all-to-all of rows + ids
+    t0 = time.time()
+    owner = assign % world
+    order = torch.argsort(owner, stable=True)
+    send_counts = torch.bincount(owner, minlength=world)
+    recv_counts = torch.empty_like(send_counts)
+    dist.all_to_all_single(recv_counts, send_counts)
+    sc, rc = send_counts.tolist(), recv_counts.tolist()
+    xs, as_, is_ = x[order].contiguous(), assign[order].contiguous(), (order + id_base).contiguous()
+    del x, order, owner
+    nr = int(sum(rc))
+    xr = torch.empty((nr, d), device=dev)
+    ar = torch.empty((nr,), dtype=torch.int64, device=dev)
+    ir = torch.empty((nr,), dtype=torch.int64, device=dev)
+    dist.all_to_all_single(xr, xs, rc, sc)
+    dist.all_to_all_single(ar, as_, rc, sc)
+    dist.all_to_all_single(ir, is_, rc, sc)
+    del xs, as_, is_
+    o2 = torch.argsort(ar, stable=True)
+    counts = torch.bincount(ar, minlength=nlist_g).cpu().numpy().astype(np.int64)
+    offsets = np.zeros(nlist_g + 1, np.int64)
+    offsets[1:] = np.cumsum(counts)
+    x_local, ids_local = xr[o2].contiguous(), ir[o2].contiguous()
+    del xr, ar, ir, o2
+    store = Store(ctx, d)
+    store.build_csr(offsets, ids_local, x_local)
+    parent = Store(ctx, d)
+    parent.build_csr(np.array([0, nlist_g], np.int64), torch.arange(nlist_g, device=dev), centroids.contiguous())
+    torch.cuda.synchronize()
+    own = counts[counts > 0]
+    log(f"rank 0 holds {int(counts.sum())} vectors in {len(own)} lists after the exchange ({time.time() - t0:.1f}s), "
+        f"arena {store.device_bytes() / 1e9:.2f} GB")
+    batches = [gen_queries(Q, cent_true, seed=2 + b, device=dev, unit=unit) for b in range(N_BATCHES)]
+    per = Q // world
+    gts = []
+    for q in batches:  # exact ground truth: local brute force, all-gather, merge
+        gi, gd2 = brute_force_topk(q, x_local, k, metric=metric)
+        gi = torch.where(gi >= 0, ids_local[gi.clamp(min=0)], gi)
+        gl_i = [torch.empty_like(gi) for _ in range(world)]
+        gl_d = [torch.empty_like(gd2) for _ in range(world)]
+        dist.all_gather(gl_i, gi)
+        dist.all_gather(gl_d, gd2)
+        ci, cd = torch.cat(gl_i, 1), torch.cat(gl_d, 1)
+        _, j = torch.topk(cd, k, dim=1, largest=False)
+        gts.append(torch.gather(ci, 1, j)[rank * per:(rank + 1) * per])
+    del x_local
+    out_i = torch.empty((per, k), dtype=torch.int64, device=dev)
+    out_d = torch.empty((per, k), dtype=torch.float32, device=dev)
+    sharded = ShardedIndex(GpuEngine(ctx, parent, store, metric), dist, world, rank, result="owner")
+
+    def step(nprobe, b):
+        return sharded.search(batches[b], nprobe, k, out=(out_i, out_d))
+
+    def rec(ri, b):
+        r = torch.tensor([recall_at_k(ri, gts[b], k)], device=dev, dtype=torch.float64)
+        dist.all_reduce(r, op=dist.ReduceOp.SUM)
+        return r.item() / world
+
+    nprobe, recall, sweep = pick_nprobe(step, batches, gts, k, args.recall_target, args.nprobe, rec)
+    log(f"nprobe={nprobe} recall@{k}={recall:.4f} sweep={sweep}")
+    elapsed, ev, ev_ph = timed_region(ctx, step, nprobe, args.steps, args.warmup, args.settle, dist, dev)
+    ctx.set_timing(1)
+    sb = torch.tensor([float(sharded.engine.last_scan_bytes(batches[0], nprobe, k))], device=dev, dtype=torch.float64)
+    ctx.set_timing(0)
+    return {
+        "value": round(Q * args.steps / elapsed, 1), "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+        "config": {
+            "workload": f"Synthetic {n * world // 1_000_000}M x {d} f32 {metric.upper()} Gaussian mixture, nlist={nlist_g} "
+                        f"(one k-means over all ranks), lists sharded by number over {world} ranks, batch={Q} queries, k={k}, "
+                        f"nprobe={nprobe} (BASELINE.json configs[3] shape: 12.5M vectors, 8192 lists and 512 queries per GPU)",
+            "nvec_per_gpu": n, "dim": d, "metric_type": metric, "nlist": nlist_g, "batch": Q, "k": k, "nprobe": nprobe,
+            "recall_at_k": round(recall, 4), "recall_sweep": sweep, "settle_steps": max(args.settle, 0),
+            "query_batches_rotated": N_BATCHES,
+            "sharding": "list p on rank p % N, centroids replicated; every rank computes the coarse step, scans the probed "
+                        "lists it owns; all-to-all of the per-rank top-k, merge on the rank that owns the query",
+        },
+        "roofline": roofline_of(int(sb.item()), ev),
+        "phases_ms": phases_of(ev_ph),
+        "build": {"sharded_kmeans_s": round(t_kmeans, 2), "niter": args.niter},
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -87,17 +514,23 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--settle", type=int, default=200,
                     help="untimed steps before the warmup (the first ~100 steps after the build run at lower clocks)")
-    ap.add_argument("--nvec", type=int, default=10_000_000, help="vectors per GPU")
+    ap.add_argument("--nvec", type=int, default=10_000_000, help="vectors (single GPU)")
     ap.add_argument("--dim", type=int, default=128)
-    ap.add_argument("--nlist", type=int, default=4096, help="lists per GPU")
-    ap.add_argument("--batch", type=int, default=1024, help="queries per GPU per step")
+    ap.add_argument("--nlist", type=int, default=4096, help="lists (single GPU)")
+    ap.add_argument("--batch", type=int, default=1024, help="queries per step (single GPU)")
+    ap.add_argument("--nvec-sharded", type=int, default=12_500_000, help="vectors per GPU when N > 1 (configs[3]: 100M / 8)")
+    ap.add_argument("--nlist-sharded", type=int, default=8192, help="lists per GPU when N > 1 (configs[3]: 65536 / 8)")
+    ap.add_argument("--batch-sharded", type=int, default=512, help="queries per GPU per step when N > 1 (configs[3]: 4096 / 8)")
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--metric", choices=("l2", "ip"), default="l2",
                     help="ip: unit-norm mixture (embedding-like), BASELINE.json configs[2] with --dim 768 --k 100")
+    ap.add_argument("--sigma", type=float, default=0.3, help="within-cluster sigma of the headline mixture")
+    ap.add_argument("--hard-sigma", type=float, default=1.0, help="sigma of the second workload (overlapping components)")
     ap.add_argument("--nprobe", type=int, default=0, help="0 = sweep for recall@k >= target")
     ap.add_argument("--recall-target", type=float, default=0.9)
     ap.add_argument("--niter", type=int, default=5)
-    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline legs (and the oracle parity check)")
+    ap.add_argument("--no-extra", action="store_true", help="headline workload only")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
 
@@ -121,258 +554,41 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    from quake_amd.capi import Context, Store
+    from quake_amd.capi import Context
     ctx = Context(dev_index)
     # the library runs on torch's current stream, so that it is ordered with torch / torch.distributed work
     # (QUAKE_BENCH_STREAM=private: A/B against the context's own non-blocking stream, single GPU only)
     if not (os.environ.get("QUAKE_BENCH_STREAM") == "private" and world == 1):
         ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-    info = ctx.device_info()
-    log("device", info)
-
-    n, d, nlist, k = args.nvec, args.dim, args.nlist, args.k
-    Q = args.batch * world
+    log("device", ctx.device_info())
     t_all = time.time()
 
-    # ---- corpus shard + index build (untimed) -------------------------------------------------------------
-    t0 = time.time()
-    metric = args.metric
-    unit = metric == "ip"
-    x, cent_true = gen_mixture(n, d, nlist, seed=1 + 100 * rank, device=dev, unit=unit)
-    torch.cuda.synchronize()
-    log(f"generated {n}x{d} shard in {time.time() - t0:.1f}s")
-    t0 = time.time()
-    centroids, assign, _ = ctx.kmeans(x, nlist, metric, niter=args.niter, seed=1234)
-    torch.cuda.synchronize()
-    t_kmeans = time.time() - t0
-    log(f"k-means nlist={nlist} niter={args.niter}: {t_kmeans:.2f}s")
-    order = torch.argsort(assign, stable=True)
-    counts = torch.bincount(assign, minlength=nlist).cpu().numpy().astype(np.int64)
-    id_base = rank * n
-    ids_sorted = (order + id_base).contiguous()
-    x_sorted = x[order].contiguous()
-    del order, assign
-    nlist_g = nlist * world
-    offsets = np.zeros(nlist_g + 1, np.int64)
-    offsets[rank * nlist + 1:(rank + 1) * nlist + 1] = np.cumsum(counts)
-    offsets[(rank + 1) * nlist + 1:] = offsets[(rank + 1) * nlist]
-    store = Store(ctx, d)
-    t0 = time.time()
-    store.build_csr(offsets, ids_sorted, x_sorted)
-    torch.cuda.synchronize()
-    log(f"store upload {time.time() - t0:.2f}s, sizes min/mean/max = {counts.min()}/{counts.mean():.0f}/{counts.max()}, "
-        f"arena {store.device_bytes() / 1e9:.2f} GB")
-    host_csr = None
-    if rank == 0 and world == 1 and not args.no_cpu:
-        host_csr = (x_sorted.cpu().numpy(), ids_sorted.cpu().numpy(), offsets.copy(), centroids.cpu().numpy())
-    del x_sorted, ids_sorted
-    # replicated centroids (parent index over all ranks' lists)
-    if world > 1:
-        cl = [torch.empty_like(centroids) for _ in range(world)]
-        dist.all_gather(cl, centroids.contiguous())
-        cent_all = torch.cat(cl, 0)
-        tl = [torch.empty_like(cent_true) for _ in range(world)]
-        dist.all_gather(tl, cent_true.contiguous())
-        cent_true_all = torch.cat(tl, 0)
+    if world == 1:
+        main_res = run_single_workload(ctx, dev, args, "headline", args.sigma, args.nprobe, args.steps, args.warmup, args.settle,
+                                       args.cpu_seconds, traffic_file="r02_pmc_k_scan.json")
+        cfg_no = 2 if (args.metric == "ip" and args.dim == 768) else 1
+        main_res["config"]["workload"] += f" (BASELINE.json configs[{cfg_no}])"
+        main_res["config"]["sharding"] = "single GPU"
     else:
-        cent_all, cent_true_all = centroids, cent_true
-    parent = Store(ctx, d)
-    parent.build_csr(np.array([0, nlist_g], np.int64), torch.arange(nlist_g, device=dev), cent_all.contiguous())
-
-    # ---- queries + exact ground truth --------------------------------------------------------------------------
-    q = gen_queries(Q, cent_true_all, seed=2, device=dev, unit=unit)
-    t0 = time.time()
-    gi, gd2 = brute_force_topk(q, x, k, id_base=id_base, metric=metric)
-    if world > 1:
-        gl_i = [torch.empty_like(gi) for _ in range(world)]
-        gl_d = [torch.empty_like(gd2) for _ in range(world)]
-        dist.all_gather(gl_i, gi)
-        dist.all_gather(gl_d, gd2)
-        ci, cd = torch.cat(gl_i, 1), torch.cat(gl_d, 1)
-        _, j = torch.topk(cd, k, dim=1, largest=False)
-        gi = torch.gather(ci, 1, j)
-    torch.cuda.synchronize()
-    log(f"brute-force ground truth {time.time() - t0:.2f}s")
-    del x
-
-    out_i = torch.empty((Q, k), dtype=torch.int64, device=dev)
-    out_d = torch.empty((Q, k), dtype=torch.float32, device=dev)
-    sharded = None
-    if world > 1:
-        # ranks exchange the merge key (squared distance) with one all-gather over RCCL; sqrt after the merge
-        from quake_amd.sharded import GpuEngine, ShardedIndex
-        sharded = ShardedIndex(GpuEngine(ctx, parent, store, metric), dist, world, rank, result="owner")
-
-    def step(nprobe):
-        if sharded is not None:
-            return sharded.search(q, nprobe, k, out=(out_i, out_d))
-        return ctx.search(parent, store, q, nprobe, k, metric, out=(out_i, out_d))
-
-    def batch_recall(ri):
-        """recall@k of the batch: with N ranks every rank holds the answer of its slice of the queries."""
-        if sharded is None:
-            return recall_at_k(ri, gi, k)
-        per = Q // world
-        r = torch.tensor([recall_at_k(ri, gi[rank * per:(rank + 1) * per], k)], device=dev, dtype=torch.float64)
-        dist.all_reduce(r, op=dist.ReduceOp.SUM)
-        return r.item() / world
-
-    # ---- nprobe: smallest reaching the recall target ----------------------------------------------------------------
-    sweep = []
-    nprobe = args.nprobe
-    if nprobe <= 0:
-        for p in (1, 2, 4, 8, 16, 32, 64):
-            ri, _ = step(p)
-            torch.cuda.synchronize()
-            r = batch_recall(ri)
-            sweep.append((p, round(r, 4)))
-            if r >= args.recall_target:
-                nprobe = p
-                break
-        if nprobe <= 0:
-            nprobe = 64
-    ri, rd = step(nprobe)
-    torch.cuda.synchronize()
-    recall = batch_recall(ri)
-    log(f"nprobe={nprobe} recall@{k}={recall:.4f} sweep={sweep}")
-
-    # per-call phase breakdown + algorithmic bytes (one synchronising call, outside the timed region)
-    ctx.set_timing(1)
-    _, _, tinfo = ctx.search(parent, store, q, nprobe, k, metric, timing=True)
-    scan_bytes = int(tinfo["scan_bytes"])
-    log("phases (ms):", {kk: round(v, 4) if isinstance(v, float) else v for kk, v in tinfo.items()})
-
-    # ---- timed region -------------------------------------------------------------------------------------------------
-    ctx.set_timing(0)
-    for _ in range(max(args.settle, 0)):
-        step(nprobe)
-    for _ in range(args.warmup):
-        step(nprobe)
-    # one HIP event pair per step around the scan kernel, recorded on the launch stream, read after the region (mode 2 --
-    # events around every phase -- costs the step ~10 %: it is used for the phase breakdown below, outside the region)
-    ctx.set_timing(3)
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(nprobe)
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    ev = ctx.read_timing()
-    ctx.set_timing(2)  # phase breakdown: a short untimed pass with events around every phase
-    for _ in range(min(args.steps, 20)):
-        step(nprobe)
-    torch.cuda.synchronize()
-    ev_ph = ctx.read_timing()
-    ctx.set_timing(0)
-    if dist is not None:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = tt.item()
-    ms_per_step = 1e3 * elapsed / args.steps
-    qps = Q * args.steps / elapsed
-    scan_ms = ev["scan_ms"] / max(ev["calls"], 1)
-    achieved = scan_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
-
-    # measured HBM traffic of k_scan from the committed rocprofv3 PMC pass of this same command, if present
-    traffic = None
-    pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_k_scan.json")
-    if os.path.exists(pmc_path) and world == 1:
-        try:
-            pj = json.load(open(pmc_path))
-            if pj.get("nvec") == n and pj.get("nprobe") == nprobe and pj.get("dim", 128) == d and pj.get("k", 10) == k:
-                traffic = pj.get("traffic_bytes_per_launch")
-        except Exception:
-            traffic = None
+        main_res = run_sharded(ctx, dev, args, dist, rank, world)
 
     result = {
-        "metric": "queries/sec at recall@10\u22650.9 (SIFT1M, k=10); 1/2/4/8 GPU",
-        "value": round(qps, 1),
-        "unit": "queries/s",
-        "n_gpus": world,
-        "steps": args.steps,
-        "warmup": args.warmup,
-        "ms_per_step": round(ms_per_step, 4),
-        "higher_is_better": True,
-        "scaling": "weak",
-        "vs_baseline": None,
-        "dtype": "f32",
-        "data": "synthetic",
-        "config": {
-            "workload": f"Synthetic {n * world // 1_000_000}M x {d} f32 {metric.upper()} "
-                        f"{'unit-norm ' if unit else ''}Gaussian mixture, nlist={nlist_g}, "
-                        f"batch={Q} queries, k={k}, nprobe={nprobe} "
-                        f"(BASELINE.json configs[{2 if (metric == 'ip' and d == 768) else 1}] per GPU)",
-            "nvec_per_gpu": n, "dim": d, "metric_type": metric, "nlist_per_gpu": nlist, "batch": Q, "k": k, "nprobe": nprobe,
-            "recall_at_k": round(recall, 4), "recall_sweep": sweep, "settle_steps": max(args.settle, 0),
-            "sharding": ("lists by number across ranks, centroids replicated; all-gather of the probed-list ids, local scan, "
-                         "all-to-all of the per-rank top-k, merge on the rank that owns the query") if world > 1 else "single GPU",
-        },
-        "roofline": {
-            "kernel": "k_scan",
-            "bound": "hbm",
-            "achieved": round(achieved, 1),
-            "peak": HBM_PEAK_GBS,
-            "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": traffic,
-            "algorithmic_bytes_per_launch": scan_bytes,
-            "kernel_ms_avg": round(scan_ms, 5),
-            "launches": ev["calls"],
-        },
-        "phases_ms": {"coarse": round(ev_ph["coarse_ms"] / max(ev_ph["calls"], 1), 4),
-                      "group": round(ev_ph["group_ms"] / max(ev_ph["calls"], 1), 4),
-                      "scan": round(ev_ph["scan_ms"] / max(ev_ph["calls"], 1), 4),
-                      "merge": round(ev_ph["merge_ms"] / max(ev_ph["calls"], 1), 4),
-                      "note": "separate untimed pass with events around every phase"},
-        "build": {"kmeans_s": round(t_kmeans, 2), "niter": args.niter},
+        "metric": METRIC_NAME, "value": main_res["value"], "unit": "queries/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": main_res["ms_per_step"], "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": main_res["config"],
+        "roofline": main_res["roofline"], "phases_ms": main_res["phases_ms"], "build": main_res["build"],
     }
-
-    # ---- CPU baseline: the oracle port on the host cores, bounded sample (rank 0, N=1 only) ---------------------------
-    if host_csr is not None:
-        import oracle as O
-        hv, hi, ho, hc = host_csr
-        qh = q.cpu().numpy()
-        cores = O.max_threads()
-        # bounded sample: the bench batch is replayed until ~cpu_seconds of host work have been timed, for both of the
-        # reference's scan variants (serial_scan = its default, batched_serial_scan = SearchParams::batched_scan);
-        # the faster one is reported as the baseline
-        def time_cpu(batched, budget):
-            t, n, reps, ids = 0.0, 0, 0, None
-            while t < budget and reps < 10000:
-                t0 = time.perf_counter()
-                ids, _ = O.search(qh, hc, hv, hi, ho, nprobe, k, metric, batched_scan=batched, num_threads=cores)
-                t += time.perf_counter() - t0
-                n += Q
-                reps += 1
-            return n / t, n, reps, t, ids
-
-        qps_serial, ns_s, reps_s, t_s, ci_ = time_cpu(False, args.cpu_seconds * 0.6)
-        qps_batched, ns_b, reps_b, t_b, _ = time_cpu(True, args.cpu_seconds * 0.4)
-        best_batched = qps_batched > qps_serial
-        cpu_qps = max(qps_serial, qps_batched)
-        ns, reps, t_cpu = (ns_b, reps_b, t_b) if best_batched else (ns_s, reps_s, t_s)
-        n1 = max(1, min(Q, int(3.0 * qps_serial / max(cores, 1) * 4) or 1))  # a few seconds single-threaded
-        t0 = time.perf_counter()
-        O.search(qh[:n1], hc, hv, hi, ho, nprobe, k, metric, batched_scan=False, num_threads=1)
-        t_cpu1 = time.perf_counter() - t0
-        # the CPU path returns the same neighbours (direct-form L2 vs expanded: ids equal unless near-tied)
-        same = float((ci_ == ri.cpu().numpy()).mean())
-        result["cpu_baseline"] = {
-            "value": round(cpu_qps, 1), "unit": "queries/s", "cores": cores, "kind": "port",
-            "sample": f"the {Q}-query bench batch replayed {reps}x ({ns} queries), same index/nprobe/k, oracle search() = "
-                      f"coarse + {'batched_serial_scan' if best_batched else 'serial_scan'} semantics on {cores} threads, "
-                      f"{t_cpu:.1f}s (the faster of the reference's two scan variants)",
-            "serial_scan_qps": round(qps_serial, 1), "batched_scan_qps": round(qps_batched, 1),
-            "single_thread_qps": round(n1 / t_cpu1, 1),
-            "ids_equal_to_gpu_frac": round(same, 5),
-        }
-        result["speedup_vs_cpu"] = round(qps / cpu_qps, 1)
-    elif world == 1:
-        result["cpu_baseline"] = None
+    if world == 1:
+        result["cpu_baseline"] = main_res.get("cpu_baseline")
+        if "speedup_vs_cpu" in main_res:
+            result["speedup_vs_cpu"] = main_res["speedup_vs_cpu"]
+        if not args.no_extra:
+            extra = {}
+            hard_steps = max(20, min(args.steps, 100))
+            extra["hard"] = run_single_workload(ctx, dev, args, "hard", args.hard_sigma, 0, hard_steps, min(args.warmup, 10),
+                                                min(args.settle, 50), args.cpu_seconds * 0.5, traffic_file="r02_pmc_k_scan_hard.json")
+            extra["configs0"] = run_configs0(ctx, dev, args)
+            result["workloads"] = extra
 
     log(f"total bench wall {time.time() - t_all:.1f}s")
     if rank == 0:

@@ -188,6 +188,18 @@ QK_API int qk_store_refine_lists(qk_store *s, const int64_t *list_nos, int64_t m
 QK_API int qk_kmeans(qk_ctx *ctx, float *x, int64_t n, int d, int64_t m, int metric, int niter, uint64_t seed,
                      float *centroids, int64_t *assign, int mem);
 
+/* The pieces of kmeans() a multi-GPU build needs between its collectives (local assign + local partial sums,
+ * all-reduce of [m][d] sums + [m] counts per iteration; quake_amd/sharded.py):
+ *   qk_normalize_rows   x /= ||x|| row by row, canonical norm (clustering.cpp:25-26,59-60), in place
+ *   qk_kmeans_update    centroids = sums / counts for non-empty clusters, previous centroid kept for empty ones, then the
+ *                       empty-cluster split of faiss::Clustering restated deterministically (largest cluster first, pair
+ *                       perturbed by 1 +/- 1/1024); counts are updated by the split
+ *   qk_rand_perm        first m entries of the splitmix64 Fisher-Yates permutation of [0, n) (host array out): the
+ *                       subsample / initial centroids of qk_kmeans */
+QK_API int qk_normalize_rows(qk_ctx *ctx, float *x, int64_t n, int d, int mem);
+QK_API int qk_kmeans_update(qk_ctx *ctx, const float *sums, int64_t *counts, int64_t m, int d, float *centroids, int mem);
+QK_API int qk_rand_perm(int64_t n, int64_t m, uint64_t seed, int64_t *perm_out_host);
+
 #ifdef __cplusplus
 }
 #endif

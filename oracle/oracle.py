@@ -19,7 +19,7 @@ METRIC_L2 = 1  # faiss::METRIC_L2
 __all__ = [
     "METRIC_IP", "METRIC_L2", "build", "lib", "metric_code", "ip", "l2sqr_direct", "row_norms", "TopkBuffer",
     "scan_list", "batched_scan_list", "serial_scan", "batched_serial_scan", "coarse", "search", "rand_perm",
-    "kmeans_assign", "kmeans_accumulate", "kmeans", "kmeans_refine_partitions", "recall", "csr_from_partitions",
+    "kmeans_assign", "kmeans_accumulate", "kmeans", "kmeans_update", "normalize_rows", "kmeans_refine_partitions", "recall", "csr_from_partitions",
     "max_threads", "incomplete_beta", "incomplete_beta_table", "incomplete_beta_lookup", "log_cap_volume", "recall_profile",
     "boundary_distances", "search_aps",
 ]
@@ -76,6 +76,8 @@ def lib():
         L.qo_kmeans_accumulate.argtypes = [_f32p, C.c_int64, C.c_int, _i64p, C.c_int64, _f32p, _i64p]
         L.qo_kmeans_finalize.argtypes = [_f32p, _i64p, C.c_int64, C.c_int, C.c_int, _f32p]
         L.qo_normalize_rows.argtypes = [_f32p, C.c_int64, C.c_int]
+        L.qo_kmeans_update.restype = C.c_int
+        L.qo_kmeans_update.argtypes = [_f32p, _i64p, C.c_int64, C.c_int, _f32p]
         L.qo_kmeans.argtypes = [_f32p, C.c_int64, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_uint64, C.c_int, _f32p,
                                 _i64p]
         L.qo_kmeans_refine_partitions.argtypes = [_f32p, C.c_int64, C.c_int, _f32p, _i64p, _i64p, C.c_int, C.c_int,
@@ -292,6 +294,21 @@ def kmeans_accumulate(x, assign, m):
     counts = np.empty(m, np.int64)
     lib().qo_kmeans_accumulate(_pf(x), n, d, _pi(assign), m, _pf(sums), _pi(counts))
     return sums, counts
+
+
+def kmeans_update(sums, counts, centroids):
+    """centroids = sums / counts (empty clusters keep theirs), then the deterministic empty-cluster split; returns
+    (centroids, counts) -- new arrays."""
+    sums, counts, c = _f32(sums), _i64(counts).copy(), _f32(centroids).copy()
+    m, d = c.shape
+    lib().qo_kmeans_update(_pf(sums), _pi(counts), m, d, _pf(c))
+    return c, counts
+
+
+def normalize_rows(x):
+    x = _f32(x).copy()
+    lib().qo_normalize_rows(_pf(x), x.shape[0], x.shape[1])
+    return x
 
 
 def kmeans(x, m, metric, niter=5, seed=1234, num_threads=0):

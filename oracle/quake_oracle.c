@@ -139,10 +139,38 @@ static void topk_init(qo_topk *t, int k, int desc, int cap) {
     }
 }
 
-/* flush(): list_scanning.h:151-173.  partial_sort keeping k, or full sort of curr (<= k) entries. */
+/* flush(): list_scanning.h:151-173.  std::partial_sort keeping k (heap select over the first k, then sort_heap),
+ * or a full sort of curr (<= k) entries.  The comparator is the total order (key, id), so the result does not depend
+ * on the algorithm; the heap form is what makes a flush of 8192 candidates cost O(n log k) like the reference's. */
+static inline int pair_less(const qo_pair *p, const qo_pair *q, int desc) {
+    if (p->v != q->v) return desc ? p->v > q->v : p->v < q->v;
+    return p->id < q->id;
+}
+static inline void heap_sift_down(qo_pair *h, int n, int i, int desc) { /* max-heap under pair_less */
+    qo_pair x = h[i];
+    for (;;) {
+        int c = 2 * i + 1;
+        if (c >= n) break;
+        if (c + 1 < n && pair_less(&h[c], &h[c + 1], desc)) c++;
+        if (!pair_less(&x, &h[c], desc)) break;
+        h[i] = h[c];
+        i = c;
+    }
+    h[i] = x;
+}
 static void topk_flush(qo_topk *t) {
+    const int n = t->curr, k = t->k, desc = t->desc;
+    if (n > k && k > 0) {
+        qo_pair *h = t->buf;
+        for (int i = k / 2 - 1; i >= 0; i--) heap_sift_down(h, k, i, desc);
+        for (int i = k; i < n; i++)
+            if (pair_less(&h[i], &h[0], desc)) {
+                h[0] = h[i];
+                heap_sift_down(h, k, 0, desc);
+            }
+        t->curr = k;
+    }
     qsort(t->buf, (size_t)t->curr, sizeof(qo_pair), t->desc ? cmp_desc : cmp_asc);
-    if (t->curr > t->k) t->curr = t->k;
 }
 
 /* add(): list_scanning.h:117-122 */
@@ -296,8 +324,8 @@ QO_API void qo_scan_list_fast(const float *q, const float *vecs, const int64_t *
  *   the per-query buffers with batch_add.  squared_domain as in qo_scan_list (the reference sqrt()s
  *   before batch_add, list_scanning.h:353-357).
  * ---------------------------------------------------------------------------------------------- */
-static void batched_values(const float *queries, const float *qnorm, int nq, const float *vecs, int n, int d, int metric,
-                           float *out /* [nq][n] */) {
+static void batched_values(const float *queries, const float *qnorm, int nq, const float *vecs, const float *ynorm, int n, int d,
+                           int metric, float *out /* [nq][n] */) {
     /* blocks of 8 queries, transposed to [d][8] so that 8 chains run in one AVX register */
     float *xT = (float *)aligned_alloc(32, sizeof(float) * 8 * (size_t)d);
     for (int q0 = 0; q0 < nq; q0 += 8) {
@@ -311,7 +339,7 @@ static void batched_values(const float *queries, const float *qnorm, int nq, con
             if (metric == QO_METRIC_IP) {
                 for (int j = 0; j < nb; j++) out[(size_t)(q0 + j) * n + l] = ip[j];
             } else {
-                float yn = qo_ip(y, y, d);
+                const float yn = ynorm[l]; /* = qo_ip(y, y, d), computed once per list by the caller */
                 for (int j = 0; j < nb; j++) out[(size_t)(q0 + j) * n + l] = l2sqr_expanded(qnorm[q0 + j], yn, ip[j]);
             }
         }
@@ -326,7 +354,11 @@ QO_API void qo_batched_scan_list(const float *queries, const float *vecs, const 
     int k_max = k < n ? k : n; /* list_scanning.h:327-328 */
     int desc = metric == QO_METRIC_IP;
     float *qnorm = (float *)malloc(sizeof(float) * (size_t)nq);
-    if (metric == QO_METRIC_L2) qo_row_norms(queries, nq, d, qnorm);
+    float *ynorm = (float *)malloc(sizeof(float) * (size_t)n);
+    if (metric == QO_METRIC_L2) {
+        qo_row_norms(queries, nq, d, qnorm);
+        qo_row_norms(vecs, n, d, ynorm);
+    }
     enum { QB = 64 };
     float *vals = (float *)malloc(sizeof(float) * (size_t)QB * (size_t)n);
     qo_topk local;
@@ -335,7 +367,7 @@ QO_API void qo_batched_scan_list(const float *queries, const float *vecs, const 
     int64_t *oi = (int64_t *)malloc(sizeof(int64_t) * (size_t)k_max);
     for (int q0 = 0; q0 < nq; q0 += QB) {
         int nb = nq - q0 < QB ? nq - q0 : QB;
-        batched_values(queries + (size_t)q0 * d, qnorm + q0, nb, vecs, n, d, metric, vals);
+        batched_values(queries + (size_t)q0 * d, qnorm + q0, nb, vecs, ynorm, n, d, metric, vals);
         for (int j = 0; j < nb; j++) {
             local.curr = 0;
             for (int l = 0; l < n; l++) topk_add(&local, vals[(size_t)j * n + l], ids ? ids[l] : (int64_t)l);
@@ -353,6 +385,7 @@ QO_API void qo_batched_scan_list(const float *queries, const float *vecs, const 
     free(local.buf);
     free(vals);
     free(qnorm);
+    free(ynorm);
 }
 
 /* ------------------------------------------------------------------------------------------------
@@ -447,7 +480,11 @@ QO_API void qo_batched_serial_scan(const float *x, int64_t nq, const float *vecs
 #endif
     }
     /* the merge into global buffers is order-independent under the (key,id) total order, so the
-     * parallel loop only needs mutual exclusion per query (the reference holds a mutex, :133) */
+     * parallel loop only needs mutual exclusion per query (the reference holds a mutex per buffer, :133) */
+#ifdef _OPENMP
+    omp_lock_t *qlock = (omp_lock_t *)malloc(sizeof(omp_lock_t) * (size_t)(nq > 0 ? nq : 1));
+    for (int64_t q = 0; q < nq; q++) omp_init_lock(&qlock[q]);
+#endif
 #pragma omp parallel for num_threads(num_threads) schedule(dynamic, 1)
     for (int64_t p = 0; p < nlist; p++) {
         int64_t g0 = cnt[p], g1 = cnt[p + 1];
@@ -472,8 +509,13 @@ QO_API void qo_batched_serial_scan(const float *x, int64_t nq, const float *vecs
                 v[i] = local[j]->buf[i].v;
                 id[i] = local[j]->buf[i].id;
             }
-#pragma omp critical(qo_global_merge)
+#ifdef _OPENMP
+            omp_set_lock(&qlock[grouped[g0 + j]]);
+#endif
             topk_batch_add(global[grouped[g0 + j]], v, id, m);
+#ifdef _OPENMP
+            omp_unset_lock(&qlock[grouped[g0 + j]]);
+#endif
             free(v);
             free(id);
             qo_topk_destroy(local[j]);
@@ -485,6 +527,10 @@ QO_API void qo_batched_serial_scan(const float *x, int64_t nq, const float *vecs
         emit_result(global[q], k, metric, out_ids + q * k, out_dist + q * k);
         qo_topk_destroy(global[q]);
     }
+#ifdef _OPENMP
+    for (int64_t q = 0; q < nq; q++) omp_destroy_lock(&qlock[q]);
+    free(qlock);
+#endif
     free(global);
     free(cnt);
     free(grouped);
@@ -498,19 +544,43 @@ QO_API int qo_coarse(const float *x, int64_t nq, const float *centroids, const i
                      int nprobe, int metric, int num_threads, int64_t *out_pids, float *out_cdist) {
     int kk = nprobe < nlist ? nprobe : (int)nlist;
     if (kk <= 0) return 0;
-    int64_t offsets[2] = {0, nlist};
-    int64_t *zero = (int64_t *)calloc((size_t)(nq > 0 ? nq : 1), sizeof(int64_t));
-    float *dist = out_cdist ? out_cdist : (float *)malloc(sizeof(float) * (size_t)(nq > 0 ? nq : 1) * (size_t)kk);
-    int64_t *own_ids = NULL;
-    if (!centroid_ids) {
-        own_ids = (int64_t *)calloc((size_t)nlist, sizeof(int64_t));
-        for (int64_t i = 0; i < nlist; i++) own_ids[i] = i;
-        centroid_ids = own_ids;
+    if (num_threads <= 0) {
+#ifdef _OPENMP
+        num_threads = omp_get_max_threads();
+#else
+        num_threads = 1;
+#endif
     }
-    qo_batched_serial_scan(x, nq, centroids, centroid_ids, offsets, 1, d, zero, 1, kk, metric, num_threads, out_pids, dist);
-    if (!out_cdist) free(dist);
-    free(own_ids);
-    free(zero);
+    /* One partition (the parent's centroid list), every query probes it: the batched scan of that single group
+     * (batched_serial_scan :723-761 -> batched_scan_list -> knn_L2sqr / knn_inner_product).  FAISS's knn_* is OpenMP-parallel
+     * over query blocks [FAISS-upstream]; so is this loop (blocks of 8 queries = one AVX register of chains).  Each query's
+     * result is its local top-kk under the (key, id) order -- the same as pushing it through the global buffer. */
+    const int n = (int)nlist;
+    float *ynorm = (float *)malloc(sizeof(float) * (size_t)n);
+    if (metric == QO_METRIC_L2) qo_row_norms(centroids, n, d, ynorm);
+#pragma omp parallel num_threads(num_threads)
+    {
+        float *vals = (float *)malloc(sizeof(float) * 8 * (size_t)n);
+        float *dtmp = (float *)malloc(sizeof(float) * (size_t)kk);
+        qo_topk local;
+        topk_init(&local, kk, metric == QO_METRIC_IP, kk * 10 > 8192 ? kk * 10 : 8192);
+#pragma omp for schedule(dynamic, 1)
+        for (int64_t q0 = 0; q0 < nq; q0 += 8) {
+            const int nb = (int)(nq - q0 < 8 ? nq - q0 : 8);
+            float qn[8];
+            if (metric == QO_METRIC_L2) qo_row_norms(x + q0 * d, nb, d, qn);
+            batched_values(x + q0 * d, qn, nb, centroids, ynorm, n, d, metric, vals);
+            for (int j = 0; j < nb; j++) {
+                local.curr = 0;
+                for (int l = 0; l < n; l++) topk_add(&local, vals[(size_t)j * n + l], centroid_ids ? centroid_ids[l] : (int64_t)l);
+                emit_result(&local, kk, metric, out_pids + (q0 + j) * kk, out_cdist ? out_cdist + (q0 + j) * kk : dtmp);
+            }
+        }
+        free(local.buf);
+        free(dtmp);
+        free(vals);
+    }
+    free(ynorm);
     return kk;
 }
 
@@ -683,6 +753,13 @@ static int split_empty(float *c, int64_t *counts, int64_t m, int d) {
         nsplit++;
     }
     return nsplit;
+}
+
+/* mean update + empty-cluster split of one Lloyd iteration, given (global) sums and counts -- what every rank of a
+ * multi-GPU build runs after the all-reduce (quake_amd/sharded.py) and what qo_kmeans runs per iteration */
+QO_API int qo_kmeans_update(const float *sums, int64_t *counts, int64_t m, int d, float *c) {
+    qo_kmeans_finalize(sums, counts, m, d, 1, c);
+    return split_empty(c, counts, m, d);
 }
 
 static void normalize_rows(float *x, int64_t n, int d) {

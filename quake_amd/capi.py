@@ -222,6 +222,22 @@ class Context:
         check(self.lib.qk_kmeans_accumulate(self.h, _ptr(x), n, d, _ptr(assign), m, _ptr(sums), _ptr(counts), mem))
         return sums, counts
 
+    def normalize_rows(self, x):
+        """x /= ||x|| row by row, in place (canonical norm); returns x."""
+        check(self.lib.qk_normalize_rows(self.h, _ptr(x), x.shape[0], x.shape[1], _mem_of(x)))
+        return x
+
+    def kmeans_update(self, sums, counts, centroids):
+        """mean update + empty-cluster split of one Lloyd iteration; `centroids` and `counts` are updated in place."""
+        m, d = centroids.shape
+        check(self.lib.qk_kmeans_update(self.h, _ptr(sums), _ptr(counts), m, d, _ptr(centroids), _mem_of(sums, counts, centroids)))
+        return centroids, counts
+
+    def rand_perm(self, n, m, seed):
+        out = np.empty(min(int(n), int(m)), np.int64)
+        check(self.lib.qk_rand_perm(int(n), int(m), int(seed), _ptr(out)))
+        return out
+
     def kmeans(self, x, m, metric, niter=5, seed=1234):
         """Returns (centroids, assign, x_used); x_used is the (IP-normalised) copy the caller should store."""
         x = _f32(x)

@@ -22,7 +22,7 @@ int finish_timing(qk_ctx *ctx, qk_store *s, qk_timing *t, bool have_coarse, int 
     QK_HIP(hipStreamSynchronize(ctx->stream));
     const int32_t *hs = (const int32_t *)ctx->pinned;
     t->n_items = hs[0];  // active partitions
-    t->partitions_scanned = hs[1];  // records emitted
+    t->partitions_scanned = hs[7];  // (query, partition) pairs that reached a present, non-empty partition
     int64_t rows_unique;
     memcpy(&rows_unique, hs + 2, sizeof(int64_t));
     t->scan_bytes = rows_unique * (int64_t)s->d * 4;

@@ -750,6 +750,8 @@ int qk_dense_device(qk_ctx *ctx, qk_store *s, int64_t list_no, const qk_scan_arg
             QK_HIP(hipStreamSynchronize(st));
             hs[0] = 1;
             hs[1] = 0;
+        hs[7] = (int32_t)std::min<int64_t>(Q, INT32_MAX);  // every query scans the one list
+            hs[7] = (int32_t)std::min<int64_t>(Q, INT32_MAX);  // every query scans the one list
             int64_t rows = nrows;
             memcpy(hs + 2, &rows, sizeof(rows));
         }
@@ -849,6 +851,7 @@ int qk_dense_device(qk_ctx *ctx, qk_store *s, int64_t list_no, const qk_scan_arg
         QK_HIP(hipStreamSynchronize(st));
         hs[0] = 1;
         hs[1] = 0;
+        hs[7] = (int32_t)std::min<int64_t>(Q, INT32_MAX);  // every query scans the one list
         int64_t rows = nrows;
         memcpy(hs + 2, &rows, sizeof(rows));
     }
@@ -871,6 +874,15 @@ int qk_widek_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *
     const int64_t qc = std::max<int64_t>(1, std::min<int64_t>(Q, ((int64_t)1 << 29) / per_query_ub));
     if (per_query_ub > ((int64_t)1 << 30)) QK_FAIL(QK_ERR_UNSUPPORTED, "qk_scan: k=%d with %d lists per query is too large", k, P);
     const int nblk = s->nblk;
+    // per-call phase events of THIS pipeline (the inner qk_scan_device runs without a qk_timing, so it records none):
+    // [0,1) pair sizes + offsets of the first pass, [1,2) key emission passes, [2,3) the last selection.  Deferred modes
+    // are served by the inner call's own scan-kernel events.
+    qk_phase_events pe;
+    pe.ctx = ctx;
+    pe.tm = ctx->timing && (timing || a.record_events);
+    pe.dtm = false;
+    pe.ev_base = ev_base;
+    QK_TRY(pe.mark(0));
     for (int64_t q0 = 0; q0 < Q; q0 += qc) {
         const int64_t nq = std::min(qc, Q - q0);
         const int64_t npairs = nq * P;
@@ -887,6 +899,7 @@ int qk_widek_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *
         const int64_t *pids = a.pids ? a.pids + q0 * P : nullptr;
         hipLaunchKernelGGL(k_pair_sizes, dim3((unsigned)((npairs + 256) / 256)), dim3(256), 0, st, pids, npairs, P, s->d_size, npids, sizes);
         QK_HIP(hipcub::DeviceScan::ExclusiveSum((void *)(B + o_cub), cub_bytes, sizes, pair_base, (int)(npairs + 1), st));
+        if (q0 == 0) QK_TRY(pe.mark(1));
         qk_scan_args e = a;
         e.x = a.x + q0 * s->d;
         e.xq4 = a.xq4 + q0 * nblk * 4;
@@ -897,7 +910,9 @@ int qk_widek_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *
         e.pair_base = pair_base;
         e.out_ids = nullptr;
         e.out_dist = nullptr;
+        e.record_events = false;
         QK_TRY(qk_scan_device(ctx, s, e, nullptr, ev_base));
+        if (q0 + qc >= Q) QK_TRY(pe.mark(2));
         WideKParams w;
         w.keys = keys;
         w.pair_base = pair_base;
@@ -916,6 +931,7 @@ int qk_widek_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *
         hipLaunchKernelGGL(k_select_pairs_large, dim3((unsigned)nq), dim3(256), lds, st, w);
         QK_HIP(hipGetLastError());
     }
+    QK_TRY(pe.mark(3));
     if (timing) {
         QK_TRY(qk_pinned_reserve(ctx, 64));
         QK_HIP(hipStreamSynchronize(st));

@@ -681,4 +681,67 @@ int qk_kmeans(qk_ctx *ctx, float *x, int64_t n, int d, int64_t m, int metric, in
     return QK_OK;
 }
 
+int qk_normalize_rows(qk_ctx *ctx, float *x, int64_t n, int d, int mem) {
+    if (!ctx || !x) QK_FAIL(QK_ERR_INVALID, "qk_normalize_rows: null argument");
+    if (n < 0 || d <= 0) QK_FAIL(QK_ERR_INVALID, "qk_normalize_rows: bad sizes");
+    if (n == 0) return QK_OK;
+    QK_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    KmScratch ks;
+    float *dx = x;
+    if (mem == QK_MEM_HOST) {
+        QK_TRY(ks.alloc(&dx, (size_t)n * d));
+        QK_HIP(hipMemcpyAsync(dx, x, (size_t)n * d * 4, hipMemcpyHostToDevice, st));
+    }
+    hipLaunchKernelGGL(k_normalize_rows, dim3(km_grid(n, 256)), dim3(256), 0, st, dx, n, d);
+    QK_HIP(hipGetLastError());
+    if (mem == QK_MEM_HOST) {
+        QK_HIP(hipMemcpyAsync(x, dx, (size_t)n * d * 4, hipMemcpyDeviceToHost, st));
+        QK_HIP(hipStreamSynchronize(st));  // scratch is freed on return
+    }
+    return QK_OK;
+}
+
+int qk_kmeans_update(qk_ctx *ctx, const float *sums, int64_t *counts, int64_t m, int d, float *centroids, int mem) {
+    if (!ctx || !sums || !counts || !centroids) QK_FAIL(QK_ERR_INVALID, "qk_kmeans_update: null argument");
+    if (m <= 0 || d <= 0) QK_FAIL(QK_ERR_INVALID, "qk_kmeans_update: bad sizes");
+    QK_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    std::vector<int64_t> hcounts((size_t)m);
+    if (mem == QK_MEM_HOST) {
+        // host data: the whole update is m*d divisions -- same expressions as the kernel
+        for (int64_t j = 0; j < m; j++) {
+            if (counts[j] == 0) continue;
+            const float cnt = (float)counts[j];
+            for (int k = 0; k < d; k++) centroids[j * d + k] = sums[j * d + k] / cnt;
+        }
+        split_empty_host(centroids, counts, m, d);
+        return QK_OK;
+    }
+    hipLaunchKernelGGL(k_finalize_centroids, dim3(km_grid(m * d, 256)), dim3(256), 0, st, sums, counts, m, d, 1, centroids);
+    QK_HIP(hipGetLastError());
+    QK_HIP(hipMemcpyAsync(hcounts.data(), counts, (size_t)m * 8, hipMemcpyDeviceToHost, st));
+    QK_HIP(hipStreamSynchronize(st));
+    bool any_empty = false;
+    for (int64_t j = 0; j < m && !any_empty; j++) any_empty = hcounts[j] == 0;
+    if (any_empty) {
+        std::vector<float> hc((size_t)m * d);
+        QK_HIP(hipMemcpyAsync(hc.data(), centroids, (size_t)m * d * 4, hipMemcpyDeviceToHost, st));
+        QK_HIP(hipStreamSynchronize(st));
+        split_empty_host(hc.data(), hcounts.data(), m, d);
+        QK_HIP(hipMemcpyAsync(centroids, hc.data(), (size_t)m * d * 4, hipMemcpyHostToDevice, st));
+        QK_HIP(hipMemcpyAsync(counts, hcounts.data(), (size_t)m * 8, hipMemcpyHostToDevice, st));
+        QK_HIP(hipStreamSynchronize(st));
+    }
+    return QK_OK;
+}
+
+int qk_rand_perm(int64_t n, int64_t m, uint64_t seed, int64_t *perm_out_host) {
+    if (n < 0 || m < 0 || !perm_out_host) QK_FAIL(QK_ERR_INVALID, "qk_rand_perm: bad arguments");
+    std::vector<int64_t> p;
+    rand_perm_prefix(n, m, seed, p);
+    memcpy(perm_out_host, p.data(), p.size() * sizeof(int64_t));
+    return QK_OK;
+}
+
 }  // extern "C"

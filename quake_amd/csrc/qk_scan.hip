@@ -143,6 +143,7 @@ struct GroupParams {
     int32_t *pair_slots;  // [npairs][32]: {record count, first 31 record ids} -- what the merge reads in ONE load; later
                           // records of the pair go to the chain
     uint32_t *gtau;       // [Q] per-query shared bound, reset here
+    int32_t *n_pairs_live; // [1] (query, partition) pairs that reach a present, non-empty partition (qk_timing::partitions_scanned)
 };
 
 __device__ __forceinline__ int pair_pid(const GroupParams &G, int64_t i) {
@@ -292,6 +293,7 @@ __device__ __forceinline__ void group_scan_body(const GroupParams &G, long long 
         G.active[ta] = sent;
         *G.n_tiles = tt;
         *G.n_rows_unique = tr;
+        *G.n_pairs_live = (int)tq;
     }
     for (int i = b; i < e; i++) {
         const int p = G.act_list[i];
@@ -1755,7 +1757,7 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
     int32_t *scal = g_cursor + npids;
     ActiveInfo *active = (ActiveInfo *)qk_ws_alloc(ctx, (size_t)(npids + 1) * sizeof(ActiveInfo) + 64);
     int32_t *g_qoff = (int32_t *)qk_ws_alloc(ctx, (size_t)(npids + 1) * 4 + 64);
-    // scal layout (int32 units): [0] n_active, [1] rec_counter, [2..3] n_rows_unique (i64), [4..5] n_tiles (i64)
+    // scal layout (int32 units): [0] n_active, [1] rec_counter, [2..3] n_rows_unique (i64), [4..5] n_tiles (i64), [6] n_act, [7] live pairs
     int32_t *n_active = scal, *rec_counter = scal + 1;
     int64_t *n_rows_unique = (int64_t *)(scal + 2);
     int64_t *n_tiles = (int64_t *)(scal + 4);
@@ -1806,6 +1808,7 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
     G.seg_ovh = seg_ovh;
     G.act_list = act_list;
     G.n_act = scal + 6;  // zeroed with the other counters
+    G.n_pairs_live = scal + 7;
     G.pair_slots = pair_slots;
     G.gtau = gtau;
     static const int no_seed = getenv("QK_NO_SEED") ? atoi(getenv("QK_NO_SEED")) : 0;

@@ -44,17 +44,22 @@ class GpuEngine:
 
     def __init__(self, ctx, parent, store, metric):
         self.ctx, self.parent, self.store, self.metric = ctx, parent, store, metric
-        ctx.set_squared_l2(True)  # ranks exchange the merge key; sqrt happens after the merge
 
     def coarse(self, q, nprobe):
         """[n, nprobe] global partition numbers for a slice of the batch (replicated centroids)."""
         return self.ctx.coarse(self.parent, q, nprobe, self.metric)[0]
 
     def scan(self, q, pids, k, out=None):
-        """local top-k over the probed lists this rank owns: (ids [Q,k], merge keys [Q,k])."""
-        if out is not None:
-            return self.ctx.scan_into(self.store, q, pids, k, self.metric, out)
-        return self.ctx.scan(self.store, q, pids, k, self.metric)
+        """local top-k over the probed lists this rank owns: (ids [Q,k], merge keys [Q,k]).  Ranks exchange the merge key
+        (squared L2 / dot; sqrt happens after the merge): the context returns squared distances for THIS call only, so a
+        context shared with plain searches keeps returning sqrt distances there."""
+        self.ctx.set_squared_l2(True)
+        try:
+            if out is not None:
+                return self.ctx.scan_into(self.store, q, pids, k, self.metric, out)
+            return self.ctx.scan(self.store, q, pids, k, self.metric)
+        finally:
+            self.ctx.set_squared_l2(False)
 
     def merge(self, ids, keys):
         return self.ctx.merge_topk(ids, keys, self.metric)
@@ -68,6 +73,102 @@ class GpuEngine:
 
     def remove_local(self, ids):
         return self.store.remove_ids(ids)
+
+    def last_scan_bytes(self, q, nprobe, k):
+        """algorithmic bytes of this rank's partition scan for the batch q (one synchronising call; bench.py's roofline)"""
+        pids = self.coarse(q, nprobe)
+        return int(self.ctx.scan(self.store, q, pids, k, self.metric, timing=True)[2]["scan_bytes"])
+
+
+# ---- k-means across shards (SURVEY 8e) ------------------------------------------------------------------------------------
+def _all_gather_cat(dist, world, t):
+    """[n, ...] per rank -> [world * n, ...] on every rank, rank order (staged through the host when gloo is handed a
+    device tensor: the functional tests run two ranks on one GPU)."""
+    import torch
+    stage = t.is_cuda and str(dist.get_backend()).lower() == "gloo"
+    src = t.contiguous().cpu() if stage else t.contiguous()
+    out = torch.empty((world * src.shape[0],) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+    dist.all_gather_into_tensor(out.view(world * src.shape[0], -1) if src.dim() > 1 else out, src.view(src.shape[0], -1) if src.dim() > 1 else src)
+    return out.to(t.device) if stage else out
+
+
+def _reduce_partials(dist, world, sums, counts, ordered=True):
+    """global sums / counts from the per-rank partials.  ordered: the partials are all-gathered and added in RANK ORDER on
+    every rank -- a fixed fp32 summation order, so every rank (and a single-process restatement) gets the same bits; else one
+    all-reduce (the order is the collective's: deterministic per topology, not specified)."""
+    import torch
+    if dist is None or world == 1:
+        return sums, counts
+    ts = sums if torch.is_tensor(sums) else torch.from_numpy(sums)
+    tc = counts if torch.is_tensor(counts) else torch.from_numpy(counts)
+    if ordered:
+        gs = _all_gather_cat(dist, world, ts).view((world,) + tuple(ts.shape))
+        gc = _all_gather_cat(dist, world, tc).view((world,) + tuple(tc.shape))
+        s = gs[0].clone()
+        for r in range(1, world):
+            s += gs[r]
+        c = gc.sum(0)
+    else:
+        s, c = ts.clone(), tc.clone()
+        dist.all_reduce(s)
+        dist.all_reduce(c)
+    return (s, c) if torch.is_tensor(sums) else (s.numpy(), c.numpy())
+
+
+def sharded_kmeans(eng, dist, x, m, metric, niter=5, seed=1234, rank=0, world=1, ordered=True):
+    """kmeans() (clustering.cpp:13-97) over a corpus split across ranks: every rank holds x [n_r, d] (equal n_r), the result
+    is ONE set of m centroids, identical on every rank, and the assignment of the local rows.
+
+    Per Lloyd iteration: local nearest-centroid assignment and local per-centroid partial sums / counts (the MFMA assign
+    and the segmented accumulate of the single-GPU build), then the [m, d] sums and [m] counts are reduced over the ranks
+     and every rank applies the same mean update + empty-cluster split.  Training subsample (FAISS: at most 256
+    points per centroid) and initial centroids come from each rank's own splitmix64 permutation (seed + rank): rank r
+    trains on the first 256*m/world rows of it and contributes centroid slots [r*m/world, (r+1)*m/world).  With world = 1
+    this is exactly qk_kmeans.
+
+    eng: the per-rank arithmetic -- quake_amd.capi.Context (libquake_hip.so), or any object with normalize_rows,
+    rand_perm, kmeans_assign, kmeans_accumulate, kmeans_update (the gloo tests inject an oracle-backed one).
+    Returns (centroids [m, d], assign [n_r])."""
+    import torch
+    is_t = torch.is_tensor(x)
+    n, d = x.shape
+    if m % world != 0:
+        raise ValueError("the number of centroids must be a multiple of the number of ranks")
+    m_r = m // world
+    if m_r > n:
+        raise ValueError("fewer local vectors than centroid slots per rank")
+    if metric == "ip":
+        x = eng.normalize_rows(x)
+    max_pts = 256
+    sub = n * world > max_pts * m
+    ntrain = (max_pts * m) // world if sub else n
+    perm = eng.rand_perm(n, ntrain if sub else m_r, seed + rank)
+    if is_t:
+        perm_t = torch.from_numpy(perm).to(x.device)
+        xt = x[perm_t[:ntrain]].contiguous() if sub else x
+        c_local = x[perm_t[:m_r]].contiguous()
+    else:
+        xt = np.ascontiguousarray(x[perm[:ntrain]]) if sub else x
+        c_local = np.ascontiguousarray(x[perm[:m_r]])
+    if dist is not None and world > 1:
+        call = _all_gather_cat(dist, world, c_local if is_t else torch.from_numpy(c_local))
+        c = call if is_t else call.numpy()
+    else:
+        c = c_local.clone() if is_t else c_local.copy()
+    for _ in range(niter):
+        a, _v = eng.kmeans_assign(xt, c, metric)
+        sums, counts = eng.kmeans_accumulate(xt, a, m)
+        sums, counts = _reduce_partials(dist, world, sums, counts, ordered)
+        c, _ = eng.kmeans_update(sums, counts, c)
+    if metric == "ip":
+        c = eng.normalize_rows(c)
+    assign, _v = eng.kmeans_assign(x, c, metric)
+    return c, assign
+
+
+class _Done:
+    def wait(self):
+        return True
 
 
 class ShardedIndex:
@@ -89,11 +190,23 @@ class ShardedIndex:
         self.result = result
         self._g_ids = self._g_keys = self._g_pids = None
         self._x_ids = self._x_keys = None
+        # gloo (two ranks sharing one GPU in the functional tests) has no device all-to-all: stage through the host there
+        self._stage_host = False
+        if dist is not None and self.world > 1:
+            try:
+                self._stage_host = str(dist.get_backend()).lower() == "gloo"
+            except Exception:
+                self._stage_host = False
 
     def _exchange(self, buf_name, t):
         """all-to-all of [G, per, k] blocks: block j goes to rank j; returns [G(source), per, k]."""
         import torch
         t = t if torch.is_tensor(t) else torch.from_numpy(np.ascontiguousarray(t))
+        if self._stage_host and t.is_cuda:
+            h = t.contiguous().cpu()
+            hb = torch.empty_like(h)
+            self.dist.all_to_all_single(hb.view(-1), h.view(-1))
+            return hb.to(t.device), _Done()
         buf = getattr(self, buf_name)
         if buf is None or tuple(buf.shape) != tuple(t.shape) or buf.device != t.device or buf.dtype != t.dtype:
             buf = torch.empty_like(t)
@@ -104,6 +217,11 @@ class ShardedIndex:
         import torch
         t = t if torch.is_tensor(t) else torch.from_numpy(np.ascontiguousarray(t))
         shape = (self.world,) + tuple(t.shape)
+        if self._stage_host and t.is_cuda:
+            h = t.contiguous().cpu()
+            hb = torch.empty(shape, dtype=dtype)
+            self.dist.all_gather_into_tensor(hb.view(-1, h.shape[-1]), h)
+            return hb.to(t.device)
         buf = getattr(self, buf_name)
         if buf is None or tuple(buf.shape) != shape or buf.device != t.device:
             buf = torch.empty(shape, dtype=dtype, device=t.device)

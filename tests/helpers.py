@@ -69,3 +69,29 @@ def brute_force(x, ids, q, k, metric):
     dist = np.sqrt(np.take_along_axis(key, top, 1)) if metric == "l2" else -np.take_along_axis(key, top, 1)
     gaps = np.diff(kv, axis=1)
     return out_ids, dist.astype(np.float32), gaps
+
+
+def sharded_kmeans_reference(O, shards, m, metric, niter=5, seed=1234):
+    """Single-process restatement of quake_amd.sharded.sharded_kmeans with the oracle's pieces: per-shard assignment and
+    partial sums, partials added in rank order, one mean update + empty-cluster split per iteration.  Returns
+    (centroids, [assign of shard r])."""
+    world = len(shards)
+    xs = [O.normalize_rows(x) if metric == "ip" else np.ascontiguousarray(x, np.float32) for x in shards]
+    n = xs[0].shape[0]
+    m_r = m // world
+    sub = n * world > 256 * m
+    ntrain = (256 * m) // world if sub else n
+    perms = [O.rand_perm(n, ntrain if sub else m_r, seed + r) for r in range(world)]
+    xt = [np.ascontiguousarray(x[p[:ntrain]]) if sub else x for x, p in zip(xs, perms)]
+    c = np.concatenate([x[p[:m_r]] for x, p in zip(xs, perms)], 0)
+    for _ in range(niter):
+        s = cnt = None
+        for r in range(world):
+            a, _ = O.kmeans_assign(xt[r], c, metric)
+            ps, pc = O.kmeans_accumulate(xt[r], a, m)
+            s = ps if s is None else s + ps
+            cnt = pc if cnt is None else cnt + pc
+        c, _ = O.kmeans_update(s, cnt, c)
+    if metric == "ip":
+        c = O.normalize_rows(c)
+    return c, [O.kmeans_assign(x, c, metric)[0] for x in xs]

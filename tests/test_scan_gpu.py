@@ -168,6 +168,28 @@ def test_large_k_and_limits(ctx):
         ctx.search(parent, s, q, 6, 4097, "l2")
 
 
+def test_wide_k_with_timing_on_a_fresh_context():
+    """k > QK_MAX_K with a qk_timing requested as the FIRST call of a context (what QuakeIndex.search always does): the wide-k
+    pipeline records its own phase events, so the timings are real and the call does not fail on never-recorded events."""
+    from quake_amd.capi import Context
+    c = Context(0)
+    c.set_timing(1)
+    ivf = make_ivf(6000, 48, 6, seed=36)
+    q = make_queries(12, 48, seed=37, like=ivf["x"])
+    parent, s = build_stores(c, ivf)
+    gi, gd, t = c.search(parent, s, q, 4, 1000, "l2", timing=True)
+    oi, od = O.search(q, ivf["centroids"], ivf["vecs"], ivf["ids"], ivf["offsets"], 4, 1000, "l2", batched_scan=True)
+    np.testing.assert_array_equal(gi, oi)
+    np.testing.assert_array_equal(gd.view(np.uint32), od.view(np.uint32))
+    for f in ("coarse_ms", "group_ms", "scan_ms", "merge_ms", "total_ms"):
+        assert 0.0 <= t[f] < 1000.0, (f, t[f])
+    assert t["total_ms"] >= t["scan_ms"] > 0.0
+    # and the pair count of a plain search is the number of (query, partition) pairs that reached a non-empty list
+    gi, gd, t = c.search(parent, s, q, 4, 10, "l2", timing=True)
+    assert t["partitions_scanned"] == 12 * 4
+    c.close()
+
+
 @pytest.mark.parametrize("d,metric", [(768, "ip"), (768, "l2"), (1024, "l2"), (512, "ip")])
 def test_wide_rows_shared_query_tile(ctx, d, metric):
     """d >= 512: several waves of a workgroup share one LDS query tile and split each segment (k_scan nw = 2/4), pools

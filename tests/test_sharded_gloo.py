@@ -150,6 +150,77 @@ def test_sharded_search_equals_unsharded(metric):
     assert ret.get(0) == "ok" and ret.get(1) == "ok"
 
 
+class OracleKmeans:
+    """test double for the per-rank k-means arithmetic (the product engine is quake_amd.capi.Context)"""
+
+    def normalize_rows(self, x):
+        import oracle as O
+        return O.normalize_rows(x)
+
+    def rand_perm(self, n, m, seed):
+        import oracle as O
+        return O.rand_perm(n, m, seed)
+
+    def kmeans_assign(self, x, c, metric):
+        import oracle as O
+        return O.kmeans_assign(x, c, metric)
+
+    def kmeans_accumulate(self, x, a, m):
+        import oracle as O
+        return O.kmeans_accumulate(x, a, m)
+
+    def kmeans_update(self, sums, counts, c):
+        import oracle as O
+        return O.kmeans_update(sums, counts, c)
+
+
+def _kmeans_shards(metric, n=3000, d=12, seed=21):
+    rng = np.random.default_rng(seed)
+    cent = rng.standard_normal((8, d)).astype(np.float32)
+    return [(cent[rng.integers(0, 8, n)] + 0.4 * rng.standard_normal((n, d))).astype(np.float32) for _ in range(2)]
+
+
+def _kmeans_worker(rank, world, port, metric, m, ordered, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import oracle as O
+        from helpers import sharded_kmeans_reference
+        from quake_amd.sharded import sharded_kmeans
+        shards = _kmeans_shards(metric)
+        c, a = sharded_kmeans(OracleKmeans(), dist, shards[rank], m, metric, niter=4, seed=77, rank=rank, world=world, ordered=ordered)
+        rc, ra = sharded_kmeans_reference(O, shards, m, metric, niter=4, seed=77)
+        assert (c.view(np.uint32) == rc.view(np.uint32)).all(), rank  # same centroids on every rank, bit for bit
+        assert (a == ra[rank]).all(), rank
+        ret[rank] = "ok"
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("metric,m,ordered", [("l2", 16, True), ("ip", 16, True), ("l2", 8, False), ("l2", 2000, True)])
+def test_sharded_kmeans_world2(metric, m, ordered):
+    """cross-shard Lloyd (local assign + partial sums, reduction of [m,d] sums and [m] counts per iteration): both ranks end
+    with the centroids of the single-process restatement.  m = 2000 > n/256 exercises the no-subsample branch with
+    empty clusters (the split rule); ordered=False is the plain all-reduce (two ranks: a + b == b + a)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_kmeans_worker, args=(2, port, metric, m, ordered, ret), nprocs=2, join=True)
+    assert ret.get(0) == "ok" and ret.get(1) == "ok"
+
+
+def test_sharded_kmeans_world1_is_plain_kmeans():
+    import oracle as O
+    from quake_amd.sharded import sharded_kmeans
+    x = _kmeans_shards("l2")[0]
+    c, a = sharded_kmeans(OracleKmeans(), None, x, 16, "l2", niter=3, seed=5)
+    rc, ra, _ = O.kmeans(x, 16, "l2", niter=3, seed=5)
+    assert (c.view(np.uint32) == rc.view(np.uint32)).all() and (a == ra).all()
+
+
 def test_shard_offsets_block_and_mod():
     from quake_amd.sharded import shard_offsets
     off = np.array([0, 3, 3, 10, 12], np.int64)

@@ -1,5 +1,11 @@
-"""GpuEngine + ShardedIndex on one GPU (world = 1): the product engine behind the sharded orchestration -- search, and the
-sharded add / remove with device tensors -- against the plain C-ABI calls on an identical store."""
+"""GpuEngine + ShardedIndex: the product engine behind the sharded orchestration -- search, the sharded add / remove with
+device tensors and the cross-shard k-means -- against the plain C-ABI calls on an identical store.  world = 1 in process,
+and world = 2 as two PROCESSES sharing GPU 0 over gloo (RCCL refuses two ranks on one device; the collectives are staged
+through the host there, everything else is the product path with device tensors)."""
+import os
+import socket
+import sys
+
 import numpy as np
 import pytest
 import torch
@@ -7,6 +13,7 @@ import torch
 from helpers import make_ivf, make_queries
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_gpu_engine_world1_search_add_remove():
@@ -26,8 +33,7 @@ def test_gpu_engine_world1_search_add_remove():
     idx = ShardedIndex(GpuEngine(ctx, parent, stores[0], "l2"), None, 1, 0)
     qd = torch.from_numpy(q).cuda()
     gi, gd = idx.search(qd, 4, 10)
-    ctx.set_squared_l2(False)
-    ri, rd = ctx.search(parent, stores[1], qd, 4, 10, "l2")
+    ri, rd = ctx.search(parent, stores[1], qd, 4, 10, "l2")  # (the engine's squared-distance mode does not leak into the context)
     torch.cuda.synchronize()
     np.testing.assert_array_equal(gi.cpu().numpy(), ri.cpu().numpy())
     np.testing.assert_array_equal(gd.cpu().numpy(), rd.cpu().numpy())
@@ -42,11 +48,91 @@ def test_gpu_engine_world1_search_add_remove():
     assert idx.remove(torch.from_numpy(rm).cuda()) == 150
     assert stores[1].remove_ids(rm) == 150
     assert stores[0].ntotal() == stores[1].ntotal() == 20000 + 300 - 150
-    ctx.set_squared_l2(True)
     gi, gd = idx.search(qd, 24, 10)
-    ctx.set_squared_l2(False)
     ri, rd = ctx.search(parent, stores[1], qd, 24, 10, "l2")
     torch.cuda.synchronize()
     np.testing.assert_array_equal(gi.cpu().numpy(), ri.cpu().numpy())
     np.testing.assert_array_equal(gd.cpu().numpy(), rd.cpu().numpy())
+    ctx.close()
+
+
+def _world2_worker(rank, world, port, metric, ret):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import oracle as O
+        from helpers import make_ivf, make_queries, sharded_kmeans_reference
+        from quake_amd.capi import Context, Store
+        from quake_amd.sharded import GpuEngine, ShardedIndex, shard_offsets, sharded_kmeans
+        torch.cuda.set_device(0)
+        ctx = Context(0)
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        d, nlist = 64, 48
+        ivf = make_ivf(60000, d, nlist, seed=81, metric=metric, empty=(5,))
+        q = make_queries(128, d, seed=82, like=ivf["x"], metric=metric)
+        qd = torch.from_numpy(q).cuda()
+        # unsharded reference on the same GPU through the plain C ABI
+        full = Store(ctx, d)
+        full.build_csr(ivf["offsets"], ivf["ids"], ivf["vecs"])
+        parent = Store(ctx, d)
+        parent.build_csr(np.array([0, nlist], np.int64), np.arange(nlist, dtype=np.int64), ivf["centroids"])
+        # this rank's half of the lists (list p on rank p % 2)
+        lo, rows = shard_offsets(ivf["offsets"], rank, world)
+        mine = Store(ctx, d)
+        mine.build_csr(lo, ivf["ids"][rows], ivf["vecs"][rows])
+        eng = GpuEngine(ctx, parent, mine, metric)
+        per = q.shape[0] // world
+        for nprobe, k in [(1, 10), (8, 10), (48, 100)]:
+            ri, rd = ctx.search(parent, full, qd, nprobe, k, metric)
+            gi, gd = ShardedIndex(eng, dist, world, rank, result="all").search(qd, nprobe, k)
+            torch.cuda.synchronize()
+            assert torch.equal(gi, ri), (rank, nprobe, k, "all")
+            assert torch.equal(gd.view(torch.int32), rd.view(torch.int32)), (rank, nprobe, k, "all")
+            oi, od = ShardedIndex(eng, dist, world, rank, result="owner").search(qd, nprobe, k)
+            torch.cuda.synchronize()
+            sl = slice(rank * per, (rank + 1) * per)
+            assert torch.equal(oi, ri[sl]) and torch.equal(od.view(torch.int32), rd[sl].view(torch.int32)), (rank, nprobe, k, "owner")
+        # cross-shard k-means on the product engine: both ranks end with the centroids of the single-process restatement
+        rng = np.random.default_rng(83)
+        cent = rng.standard_normal((32, d)).astype(np.float32)
+        shards = [(cent[rng.integers(0, 32, 20000)] + 0.4 * rng.standard_normal((20000, d))).astype(np.float32) for _ in range(world)]
+        c, a = sharded_kmeans(ctx, dist, torch.from_numpy(shards[rank]).cuda(), 64, metric, niter=3, seed=9, rank=rank, world=world)
+        rc, ra = sharded_kmeans_reference(O, shards, 64, metric, niter=3, seed=9)
+        assert (c.cpu().numpy().view(np.uint32) == rc.view(np.uint32)).all(), rank
+        assert (a.cpu().numpy() == ra[rank]).all(), rank
+        ret[rank] = "ok"
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("metric", ["l2", "ip"])
+def test_gpu_engine_world2_processes(metric):
+    """two ranks, two processes, one GPU: GpuEngine + the real collectives (gloo) -- sharded search equals the unsharded
+    qk_search bit for bit in both result layouts; sharded k-means equals its single-process restatement."""
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_world2_worker, args=(2, port, metric, ret), nprocs=2, join=True)
+    assert ret.get(0) == "ok" and ret.get(1) == "ok"
+
+
+def test_sharded_kmeans_world1_equals_qk_kmeans():
+    from quake_amd.capi import Context
+    from quake_amd.sharded import sharded_kmeans
+    ctx = Context(0)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    for metric, n, m in [("l2", 50000, 64), ("ip", 30000, 200)]:  # 50000 > 256*64: the subsample branch; 30000 < 256*200: all rows
+        x = torch.randn(n, 48, generator=g, device="cuda")
+        rc, ra, _ = ctx.kmeans(x, m, metric, niter=3, seed=11)
+        c, a = sharded_kmeans(ctx, None, x.clone(), m, metric, niter=3, seed=11)
+        torch.cuda.synchronize()
+        assert torch.equal(c.view(torch.int32), rc.view(torch.int32)) and torch.equal(a, ra), metric
     ctx.close()
