@@ -12,9 +12,10 @@ in HBM; the timed region rotates over 4 different query batches.  nprobe = the s
 recall@10 >= 0.9 against exact brute force.
 
 Next to the headline line the same JSON object carries (N = 1 only, `--no-extra` skips them):
-  workloads.hard      the same corpus shape with within-cluster sigma 1.0: components overlap, so the recall target
-                      NEEDS nprobe >= 8 -- the regime where a probed partition is shared by many queries of the batch;
-                      reported with its own `roofline` (unique bytes / k_scan time)
+  workloads.hard      the same sizes on a corpus WITHOUT cluster structure (x = zA + noise, latent dimension 10: a smooth
+                      low-intrinsic-dimension density like SIFT / embeddings): the recall target NEEDS nprobe >> 1 -- the
+                      regime where a probed partition is shared by many queries of the batch; reported with its own
+                      `roofline` (unique bytes / k_scan time)
   workloads.configs0  BASELINE.json configs[0] shape on the S-SIFT stand-in (1M x 128 integer-valued f32,
                       nlist=1024, nprobe=10, k=10, batch=1): GPU single-query rate beside the CPU port on ONE thread (the
                       reference default: num_workers=0, num_threads=1, common.h:73,175), same ids
@@ -70,6 +71,22 @@ def gen_queries(nq, cent_all, seed, device, sigma=0.3, unit=False):
     a = torch.randint(0, cent_all.shape[0], (nq,), generator=g, device=device)
     v = cent_all[a] + sigma * torch.randn(nq, cent_all.shape[1], generator=g, device=device)
     return (torch.nn.functional.normalize(v, dim=1) if unit else v).contiguous()
+
+
+def gen_manifold(n, d, seed, device, latent=10, noise=0.05, basis=None, chunk=1 << 20):
+    """Low-intrinsic-dimension corpus: x = z A + noise, z ~ N(0, I_latent), A a fixed [latent, d] basis.  No cluster structure for
+    k-means to find: the lists are Voronoi cells of a smooth density, a query's neighbours straddle several cells and the
+    recall target needs nprobe >> 1 -- the regime real embedding / SIFT-like data put an IVF index in."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    if basis is None:
+        gb = torch.Generator(device=device).manual_seed(777)
+        basis = torch.randn(latent, d, generator=gb, device=device) / (latent ** 0.5)
+    x = torch.empty(n, d, device=device)
+    for i0 in range(0, n, chunk):
+        m = min(chunk, n - i0)
+        z = torch.randn(m, basis.shape[0], generator=g, device=device)
+        x[i0:i0 + m] = z @ basis + noise * torch.randn(m, d, generator=g, device=device)
+    return x, basis
 
 
 def gen_ssift(n, device, seed=1234, d=128, ncomp=1024, sigma=25.0, cent=None, chunk=1 << 20):
@@ -154,14 +171,14 @@ def pick_nprobe(step, batches, gts, k, target, fixed, recall_fn):
 
     nprobe = fixed
     if nprobe <= 0:
-        for p in (1, 2, 4, 8, 16, 32, 64):
+        for p in (1, 2, 4, 8, 16, 32, 64, 128):
             r = rec(p)
             sweep.append((p, round(r, 4)))
             if r >= target:
                 nprobe = p
                 break
         if nprobe <= 0:
-            nprobe = 64
+            nprobe = 128
     return nprobe, rec(nprobe), sweep
 
 
@@ -230,18 +247,28 @@ def committed_traffic(name, n, d, k, nprobe):
     return None
 
 
-def run_single_workload(ctx, dev, args, name, sigma, fixed_nprobe, steps, warmup, settle, cpu_seconds, traffic_file=None):
-    """Build, sweep nprobe, time, verify against the oracle.  Returns the result dict of one single-GPU workload."""
+def run_single_workload(ctx, dev, args, name, sigma, fixed_nprobe, steps, warmup, settle, cpu_seconds, traffic_file=None,
+                        manifold=0):
+    """Build, sweep nprobe, time, verify against the oracle.  Returns the result dict of one single-GPU workload.
+    manifold > 0: the low-intrinsic-dimension corpus (gen_manifold, latent dimension `manifold`) instead of the mixture."""
     n, d, nlist, k, Q, metric = args.nvec, args.dim, args.nlist, args.k, args.batch, args.metric
     unit = metric == "ip"
     t0 = time.time()
-    x, cent_true = gen_mixture(n, d, nlist, seed=1, device=dev, sigma=sigma, unit=unit)
+    if manifold:
+        x, basis = gen_manifold(n, d, seed=1, device=dev, latent=manifold)
+        desc = f"x = zA + noise, latent dimension {manifold}"
+    else:
+        x, cent_true = gen_mixture(n, d, nlist, seed=1, device=dev, sigma=sigma, unit=unit)
+        desc = f"Gaussian mixture (sigma {sigma})"
     torch.cuda.synchronize()
-    log(f"[{name}] generated {n}x{d} (sigma {sigma}) in {time.time() - t0:.1f}s")
+    log(f"[{name}] generated {n}x{d} ({desc}) in {time.time() - t0:.1f}s")
     want_cpu = not args.no_cpu
     idx = build_single(ctx, dev, x, nlist, metric, args.niter, keep_host=want_cpu)
     parent, store = idx["parent"], idx["store"]
-    batches = [gen_queries(Q, cent_true, seed=2 + b, device=dev, sigma=sigma, unit=unit) for b in range(N_BATCHES)]
+    if manifold:
+        batches = [gen_manifold(Q, d, seed=2 + b, device=dev, latent=manifold, basis=basis)[0] for b in range(N_BATCHES)]
+    else:
+        batches = [gen_queries(Q, cent_true, seed=2 + b, device=dev, sigma=sigma, unit=unit) for b in range(N_BATCHES)]
     t0 = time.time()
     gts = [brute_force_topk(q, x, k, metric=metric)[0] for q in batches]
     torch.cuda.synchronize()
@@ -271,9 +298,10 @@ def run_single_workload(ctx, dev, args, name, sigma, fixed_nprobe, steps, warmup
         "value": round(Q * steps / elapsed, 1), "unit": "queries/s", "ms_per_step": round(1e3 * elapsed / steps, 4),
         "steps": steps, "warmup": warmup,
         "config": {
-            "workload": f"Synthetic {n // 1_000_000}M x {d} f32 {metric.upper()} {'unit-norm ' if unit else ''}Gaussian mixture "
-                        f"(sigma {sigma}), nlist={nlist}, batch={Q} queries, k={k}, nprobe={nprobe}",
-            "nvec": n, "dim": d, "metric_type": metric, "nlist": nlist, "batch": Q, "k": k, "nprobe": nprobe, "sigma": sigma,
+            "workload": f"Synthetic {n // 1_000_000}M x {d} f32 {metric.upper()} {'unit-norm ' if unit else ''}{desc}, "
+                        f"nlist={nlist}, batch={Q} queries, k={k}, nprobe={nprobe}",
+            "nvec": n, "dim": d, "metric_type": metric, "nlist": nlist, "batch": Q, "k": k, "nprobe": nprobe,
+            "sigma": None if manifold else sigma, "latent_dim": manifold or None,
             "recall_at_k": round(recall, 4), "recall_sweep": sweep, "settle_steps": max(settle, 0),
             "query_batches_rotated": N_BATCHES,
         },
@@ -291,11 +319,12 @@ def run_single_workload(ctx, dev, args, name, sigma, fixed_nprobe, steps, warmup
         gi0, gd0 = gi0.cpu().numpy(), gd0.cpu().numpy()
         cores = O.max_threads()
 
-        def time_cpu(batched, budget, threads, nq):
+        def time_cpu(batched, budget, threads, nq, fast=1):
             t, nn, reps, ids, dist = 0.0, 0, 0, None, None
             while reps == 0 or (t < budget and reps < 10000):
                 t1 = time.perf_counter()
-                ids, dist = O.search(qh[:nq], hc, hv, hi, ho, nprobe, k, metric, batched_scan=batched, num_threads=threads)
+                ids, dist = O.search(qh[:nq], hc, hv, hi, ho, nprobe, k, metric, batched_scan=batched, num_threads=threads,
+                                     fast=fast)
                 t += time.perf_counter() - t1
                 nn += nq
                 reps += 1
@@ -308,9 +337,11 @@ def run_single_workload(ctx, dev, args, name, sigma, fixed_nprobe, steps, warmup
         if same_ids != 1.0 or same_dist != 1.0:
             raise SystemExit(f"[{name}] PARITY FAILURE at the bench size: ids equal {same_ids:.6f}, distance bits equal "
                              f"{same_dist:.6f} (HIP qk_search vs oracle batched_serial_scan)")
-        qps_s, n_s, reps_s, t_s, ids_s, _ = time_cpu(False, cpu_seconds * 0.35, cores, Q)
+        # serial_scan timed with FAISS's way of computing a row (SIMD over the dimensions, lane partial sums: fast=2) -- not the
+        # canonical summation order, so its ids may differ on near-ties; it is the timed port, never the checker
+        qps_s, n_s, reps_s, t_s, ids_s, _ = time_cpu(False, cpu_seconds * 0.35, cores, Q, fast=2)
         n1 = max(8, min(Q, int(qps_s / max(cores, 1) * cpu_seconds * 0.3) or 8))  # a few seconds on one thread
-        qps_1, _, _, t_1, _, _ = time_cpu(False, 0.0, 1, n1)
+        qps_1, _, _, t_1, _, _ = time_cpu(False, 0.0, 1, n1, fast=2)
         best_batched = qps_b > qps_s
         res["cpu_baseline"] = {
             "value": round(max(qps_b, qps_s), 1), "unit": "queries/s", "cores": cores, "kind": "port",
@@ -321,7 +352,7 @@ def run_single_workload(ctx, dev, args, name, sigma, fixed_nprobe, steps, warmup
             "serial_scan_qps": round(qps_s, 1), "batched_scan_qps": round(qps_b, 1),
             "single_thread_qps": round(qps_1, 1), "threads_speedup": round(max(qps_b, qps_s) / max(qps_1, 1e-9), 1),
             "ids_equal_to_gpu_frac": same_ids, "distance_bits_equal_to_gpu_frac": same_dist,
-            "ids_equal_serial_direct_form_frac": round(float((ids_s == gi0).mean()), 5),
+            "ids_equal_serial_lane_sum_frac": round(float((ids_s == gi0).mean()), 5),
         }
         res["speedup_vs_cpu"] = round(res["value"] / res["cpu_baseline"]["value"], 1)
     store.close()
@@ -389,7 +420,7 @@ def run_configs0(ctx, dev, args):
         t0 = time.perf_counter()
         cpu_ids = np.empty((nq, k), np.int64)
         for i in range(nq):
-            cpu_ids[i], _ = O.search(qh[i:i + 1], hc, hv, hi, ho, nprobe, k, "l2", batched_scan=False, num_threads=1)
+            cpu_ids[i], _ = O.search(qh[i:i + 1], hc, hv, hi, ho, nprobe, k, "l2", batched_scan=False, num_threads=1, fast=2)
         t_cpu = time.perf_counter() - t0
         same = float((cpu_ids == ids_all.cpu().numpy()).mean())
         same_b = float((cpu_ids == ob_i.cpu().numpy()).mean())
@@ -525,7 +556,8 @@ def main():
     ap.add_argument("--metric", choices=("l2", "ip"), default="l2",
                     help="ip: unit-norm mixture (embedding-like), BASELINE.json configs[2] with --dim 768 --k 100")
     ap.add_argument("--sigma", type=float, default=0.3, help="within-cluster sigma of the headline mixture")
-    ap.add_argument("--hard-sigma", type=float, default=1.0, help="sigma of the second workload (overlapping components)")
+    ap.add_argument("--hard-latent", type=int, default=10, help="latent dimension of the second workload's corpus (gen_manifold)")
+    ap.add_argument("--manifold", type=int, default=0, help="headline corpus = gen_manifold with this latent dimension (probe)")
     ap.add_argument("--nprobe", type=int, default=0, help="0 = sweep for recall@k >= target")
     ap.add_argument("--recall-target", type=float, default=0.9)
     ap.add_argument("--niter", type=int, default=5)
@@ -565,7 +597,7 @@ def main():
 
     if world == 1:
         main_res = run_single_workload(ctx, dev, args, "headline", args.sigma, args.nprobe, args.steps, args.warmup, args.settle,
-                                       args.cpu_seconds, traffic_file="r02_pmc_k_scan.json")
+                                       args.cpu_seconds, traffic_file="r02_pmc_k_scan.json", manifold=args.manifold)
         cfg_no = 2 if (args.metric == "ip" and args.dim == 768) else 1
         main_res["config"]["workload"] += f" (BASELINE.json configs[{cfg_no}])"
         main_res["config"]["sharding"] = "single GPU"
@@ -585,8 +617,9 @@ def main():
         if not args.no_extra:
             extra = {}
             hard_steps = max(20, min(args.steps, 100))
-            extra["hard"] = run_single_workload(ctx, dev, args, "hard", args.hard_sigma, 0, hard_steps, min(args.warmup, 10),
-                                                min(args.settle, 50), args.cpu_seconds * 0.5, traffic_file="r02_pmc_k_scan_hard.json")
+            extra["hard"] = run_single_workload(ctx, dev, args, "hard", 0.0, 0, hard_steps, min(args.warmup, 10),
+                                                min(args.settle, 50), args.cpu_seconds * 0.5, traffic_file="r02_pmc_k_scan_hard.json",
+                                                manifold=args.hard_latent)
             extra["configs0"] = run_configs0(ctx, dev, args)
             result["workloads"] = extra
 

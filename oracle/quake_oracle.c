@@ -46,6 +46,7 @@
 #include <math.h>
 #include <float.h>
 #include <immintrin.h>
+#include <malloc.h>
 #ifdef _OPENMP
 #include <omp.h>
 #endif
@@ -54,6 +55,14 @@
 #define QO_METRIC_L2 1 /* faiss::METRIC_L2 */
 
 #define QO_API __attribute__((visibility("default")))
+
+/* The per-query / per-partition scratch of this file (8192-entry buffers, value blocks) is 128 KB - 1 MB: exactly glibc's
+ * default mmap threshold, so every malloc/free became an mmap/munmap under the process-wide mm lock and 128 threads ran
+ * 5x faster than one (BENCH r02a).  Serve those blocks from the per-thread arenas instead. */
+__attribute__((constructor)) static void qo_init_allocator(void) {
+    mallopt(M_MMAP_THRESHOLD, 1 << 30);
+    mallopt(M_TRIM_THRESHOLD, 1 << 30);
+}
 
 /* ------------------------------------------------------------------------------------------------
  * Distance primitives (canonical k-ordered fmaf chains)
@@ -303,6 +312,35 @@ static void row_values_fast(const float *q, const float *vecs, int n, int d, int
     }
 }
 
+/* fast == 2, TIMING ONLY: SIMD across the dimensions of ONE row with 8 lane-wise partial sums and a horizontal add -- what
+ * FAISS's AVX2 fvec_L2sqr / fvec_inner_product do [FAISS-upstream].  Not the canonical order (last-bit differences), so this
+ * form is never used as the checker; bench.py's cpu_baseline times it as "the reference's way of computing a row". */
+static inline float hsum8(__m256 v) {
+    __m128 lo = _mm256_castps256_ps128(v), hi = _mm256_extractf128_ps(v, 1);
+    lo = _mm_add_ps(lo, hi);
+    lo = _mm_hadd_ps(lo, lo);
+    lo = _mm_hadd_ps(lo, lo);
+    return _mm_cvtss_f32(lo);
+}
+static void scan_list_lanes(const float *q, const float *vecs, const int64_t *ids, int n, int d, qo_topk *buf, int metric) {
+    const int d8 = d & ~7;
+    for (int l = 0; l < n; l++) {
+        const float *y = vecs + (size_t)l * d;
+        __m256 acc = _mm256_setzero_ps();
+        if (metric == QO_METRIC_IP) {
+            for (int k = 0; k < d8; k += 8) acc = _mm256_fmadd_ps(_mm256_loadu_ps(q + k), _mm256_loadu_ps(y + k), acc);
+        } else {
+            for (int k = 0; k < d8; k += 8) {
+                __m256 t = _mm256_sub_ps(_mm256_loadu_ps(q + k), _mm256_loadu_ps(y + k));
+                acc = _mm256_fmadd_ps(t, t, acc);
+            }
+        }
+        float v = hsum8(acc);
+        for (int k = d8; k < d; k++) v += metric == QO_METRIC_IP ? q[k] * y[k] : (q[k] - y[k]) * (q[k] - y[k]);
+        topk_add(buf, v, ids ? ids[l] : (int64_t)l);
+    }
+}
+
 /* bit-identical to qo_scan_list(..., squared_domain=1) but SIMD across rows */
 static void scan_list_fast(const float *q, const float *vecs, const int64_t *ids, int n, int d, qo_topk *buf, int metric) {
     enum { BLK = 1024 };
@@ -428,21 +466,28 @@ QO_API void qo_serial_scan(const float *x, int64_t nq, const float *vecs, const 
         num_threads = 1;
 #endif
     }
-#pragma omp parallel for num_threads(num_threads) schedule(static)
-    for (int64_t q = 0; q < nq; q++) {
+    /* one TopkBuffer per thread, re-armed per query (the reference constructs a fresh one per query, :517: same contents) */
+#pragma omp parallel num_threads(num_threads)
+    {
         qo_topk buf;
         topk_init(&buf, k, metric == QO_METRIC_IP, 8192 > k ? 8192 : k); /* :517 */
-        for (int p = 0; p < P; p++) {
-            int64_t pi = pids[q * P + p];
-            if (pi < 0 || pi >= nlist) continue;
-            int64_t o = offsets[pi];
-            int n = (int)(offsets[pi + 1] - o);
-            if (fast)
-                scan_list_fast(x + q * d, vecs + o * d, ids + o, n, d, &buf, metric);
-            else
-                qo_scan_list(x + q * d, vecs + o * d, ids + o, n, d, &buf, metric, 1);
+#pragma omp for schedule(dynamic, 1)
+        for (int64_t q = 0; q < nq; q++) {
+            buf.curr = 0;
+            for (int p = 0; p < P; p++) {
+                int64_t pi = pids[q * P + p];
+                if (pi < 0 || pi >= nlist) continue;
+                int64_t o = offsets[pi];
+                int n = (int)(offsets[pi + 1] - o);
+                if (fast == 2)
+                    scan_list_lanes(x + q * d, vecs + o * d, ids + o, n, d, &buf, metric);
+                else if (fast)
+                    scan_list_fast(x + q * d, vecs + o * d, ids + o, n, d, &buf, metric);
+                else
+                    qo_scan_list(x + q * d, vecs + o * d, ids + o, n, d, &buf, metric, 1);
+            }
+            emit_result(&buf, k, metric, out_ids + q * k, out_dist + q * k);
         }
-        emit_result(&buf, k, metric, out_ids + q * k, out_dist + q * k);
         free(buf.buf);
     }
 }

@@ -68,6 +68,7 @@ struct qk_ctx {
     size_t qprep_cap = 0;
     unsigned long long *qprep_best64 = nullptr;  // [Q] set to ~0 by the prep kernel; valid while qprep_best64_n == Q
     int64_t qprep_best64_n = 0;
+    const float4 *qprep_xp4 = nullptr;  // [Q][dpad/4] row-major zero-padded copy of the batch at the head of qprep (qk_scan_rl.hip)
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     // deferred timing (qk_ctx_set_timing(ctx, 2)): per-call event quads, read back by qk_ctx_read_timing
     int timing_mode = 0;  // 0 off, 1 per call (sync), 2 deferred, 3 deferred + scan kernel only

@@ -29,6 +29,7 @@
 #include <vector>
 #include <climits>
 #include "qk_device.h"
+#include "qk_scan_types.h"
 
 #include <algorithm>
 #include <climits>
@@ -42,7 +43,8 @@
 // global reads are coalesced and the 16 serial norm chains run out of LDS.
 __global__ __launch_bounds__(256) void k_prep_queries(const float *__restrict__ x, int64_t Q, int d, int nblk,
                                                       float4 *__restrict__ xq4, float *__restrict__ xn,
-                                                      unsigned long long *__restrict__ best64, int qpw) {
+                                                      unsigned long long *__restrict__ best64, int qpw,
+                                                      float4 *__restrict__ xp4) {
     extern __shared__ float sq[];  // [qpw][d+1]
     const int ldq = d + 1;
     const int64_t q0 = (int64_t)blockIdx.x * qpw;
@@ -63,6 +65,15 @@ __global__ __launch_bounds__(256) void k_prep_queries(const float *__restrict__ 
         v.z = col + 8 < d ? s[col + 8] : 0.0f;
         v.w = col + 12 < d ? s[col + 12] : 0.0f;
         xq4[(q0 + r) * nblk * 4 + rem] = v;
+        // row-major copy padded to 16 columns (natural column order, four columns per float4): the B operand source of the
+        // row-per-lane scan (qk_scan_rl.hip)
+        const int c4 = 4 * rem;
+        float4 w;
+        w.x = c4 < d ? s[c4] : 0.0f;
+        w.y = c4 + 1 < d ? s[c4 + 1] : 0.0f;
+        w.z = c4 + 2 < d ? s[c4 + 2] : 0.0f;
+        w.w = c4 + 3 < d ? s[c4 + 3] : 0.0f;
+        xp4[(q0 + r) * nblk * 4 + rem] = w;
     }
     if (threadIdx.x < nq) {
         const float *s = sq + threadIdx.x * ldq;
@@ -77,7 +88,8 @@ int qk_prep_queries(qk_ctx *ctx, const float *x, int64_t Q, int d, const float4 
     const int dpad = qk_round_up(d, 16), nblk = dpad / 16;
     const size_t off_n = ((size_t)Q * dpad * 4 + 255) & ~(size_t)255;
     const size_t off_b = (off_n + (size_t)Q * 4 + 255) & ~(size_t)255;
-    size_t need = off_b + (size_t)Q * 8 + 256;
+    const size_t off_p = (off_b + (size_t)Q * 8 + 255) & ~(size_t)255;
+    size_t need = off_p + (size_t)Q * dpad * 4 + 256;
     if (need > ctx->qprep_cap) {
         QK_HIP(hipStreamSynchronize(ctx->stream));
         if (ctx->qprep) QK_HIP(hipFree(ctx->qprep));
@@ -90,6 +102,7 @@ int qk_prep_queries(qk_ctx *ctx, const float *x, int64_t Q, int d, const float4 
     float *n = (float *)(ctx->qprep + off_n);
     ctx->qprep_best64 = (unsigned long long *)(ctx->qprep + off_b);
     ctx->qprep_best64_n = Q;  // initialised for Q queries; the first nearest-centroid launch consumes it
+    ctx->qprep_xp4 = (const float4 *)(ctx->qprep + off_p);
     // queries per workgroup: 16, fewer when that would leave most of the chip idle (1024 x 768: 64 workgroups took 16 us)
     int qpw = 16;
     while (qpw > 2 && (Q + qpw - 1) / qpw < 2 * (int64_t)std::max(1, ctx->prop.multiProcessorCount) && (int64_t)qpw * d > 1024) qpw >>= 1;
@@ -98,25 +111,12 @@ int qk_prep_queries(qk_ctx *ctx, const float *x, int64_t Q, int d, const float4 
     if (lds > 48 * 1024)
         QK_HIP(hipFuncSetAttribute((const void *)k_prep_queries, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_prep_queries, dim3((unsigned)((Q + qpw - 1) / qpw)), dim3(256), lds, ctx->stream, x, Q, d, nblk, q4, n,
-                       ctx->qprep_best64, qpw);
+                       ctx->qprep_best64, qpw, (float4 *)(ctx->qprep + off_p));
     QK_HIP(hipGetLastError());
     *xq4 = q4;
     *xn = n;
     return QK_OK;
 }
-
-constexpr int QK_SLOTS = 32;  // ints per pair slot line: count + 31 record ids
-
-// ---- grouping ---------------------------------------------------------------------------------------
-// everything a wave needs to start on an active partition, in one 32-byte load
-struct __align__(16) ActiveInfo {
-    long long toff;     // first tile of this partition's items in the global tile sequence
-    long long row_off;  // first arena row
-    int p;              // list number
-    int size;           // rows
-    int cnt;            // queries probing it
-    int qoff;           // offset of its group in grouped_q / grouped_pair
-};
 
 struct GroupParams {
     const int64_t *pids;  // [Q*P] or nullptr (all_lists: pair i -> list i % P)
@@ -143,6 +143,8 @@ struct GroupParams {
     int32_t *pair_slots;  // [npairs][32]: {record count, first 31 record ids} -- what the merge reads in ONE load; later
                           // records of the pair go to the chain
     uint32_t *gtau;       // [Q] per-query shared bound, reset here
+    int rl;               // 1: the sequence is measured in the units of the row-per-lane scan (rl_part_len), else seq_weight
+    RlCost rlc;
     int32_t *n_pairs_live; // [1] (query, partition) pairs that reach a present, non-empty partition (qk_timing::partitions_scanned)
 };
 
@@ -232,7 +234,7 @@ __device__ __forceinline__ void group_scan_body(const GroupParams &G, long long 
         const int sz = G.pt_size[p];
         sq += c;
         sa += 1;
-        stl += seq_weight(c, sz, G.qgroup, G.seg_ovh);
+        stl += G.rl ? rl_part_len(c, sz, G.rlc) : seq_weight(c, sz, G.qgroup, G.seg_ovh);
         sr += sz;
     }
     // three scans behind ONE pair of barriers: (active count | grouped-query count) packed in 64 bits (both < 2^31, so
@@ -309,7 +311,7 @@ __device__ __forceinline__ void group_scan_body(const GroupParams &G, long long 
         G.active[aa] = inf;
         aq += c;
         aa += 1;
-        at += seq_weight(c, G.pt_size[p], G.qgroup, G.seg_ovh);
+        at += G.rl ? rl_part_len(c, G.pt_size[p], G.rlc) : seq_weight(c, G.pt_size[p], G.qgroup, G.seg_ovh);
     }
 }
 
@@ -551,55 +553,6 @@ __global__ __launch_bounds__(64 * W) void k_seed_tau_wg(SeedParams S) {
 }
 
 // ---- the scan kernel ---------------------------------------------------------------------------------
-struct ScanParams {
-    const float4 *vecs;
-    const float *norms;
-    const int64_t *ids;
-    const int64_t *pt_off;
-    const int32_t *pt_size;
-    int nblk;
-    const float4 *xq4;
-    const float *xn;
-    const int32_t *grouped_q;
-    const int32_t *grouped_pair;
-    const int32_t *n_active;
-    const ActiveInfo *active;
-    const int64_t *n_tiles;
-    uint32_t *gtau;  // [Q] shared running bound per query stored as ~bound (0 = none, so one memset clears it), or nullptr
-    int tau_refresh;  // re-read gtau every 8 tiles (only useful when a query probes several partitions)
-    int tau_publish;  // waves publish their bound into gtau (0: gtau is a read-only initial bound, qk_scan_args::tau_init)
-    int k;
-    int C;  // pool capacity per query; k <= C - 4
-    int metric;
-    int32_t *pair_head;
-    int32_t *pair_slots;
-    int32_t *rec_counter;
-    int32_t max_recs;
-    int2 *rec_hdr;       // [max_recs] {next record of the pair (-1 = end), entry count}
-    uint32_t *rec_ord;   // [max_recs][k]
-    int64_t *rec_id;     // [max_recs][k]
-    // dynamic tail (one wave per workgroup only): the last dyn_tiles_pct % of the tile sequence is handed out in chunks of
-    // dyn_chunk tiles through this counter once a wave has finished its static share (nullptr: all static)
-    unsigned long long *dyn_counter;
-    int dyn_chunk, dyn_pct;
-    int pack;      // > 1: independent one-wave workgroups bundled per hardware workgroup (see k_scan)
-    int pack_lds;  // LDS bytes of each bundled wave
-    // XCD balance: hardware workgroup u belongs to class u % 8 (workgroups go round-robin over the XCDs); its share of the cut
-    // is proportional to xcd_w[class] (1024 = average); xcd_stat [16] collects ticks and waves per class (nullptr: not sampled)
-    int xcd_on;
-    int xcd_w[8];
-    unsigned long long *xcd_stat;
-    // query-sharing workgroups (narrow rows, many queries per partition): the nw waves of a workgroup walk the SAME tiles
-    // of a partition at the same time, each with its own 16-query tile and pools in LDS, so that a partition probed by up
-    // to 16*nw queries is fetched from HBM once (the later waves hit in L2).  0: waves split the tiles instead.
-    int qshare;
-    int seg_ovh;  // as GroupParams::seg_ovh
-    // key emission (MODE 4, k > QK_MAX_K): no top-k at all, every (pair, row) key goes to key_out[pair_base[pair] + row]
-    uint32_t *key_out;
-    const int64_t *pair_base;
-    long long *wave_clock;  // probe (QK_SCAN_WAVE_CLOCK): [waves][2] start / end of every wave in wall_clock64 ticks, or nullptr
-};
-
 // Compile-time experiment switches (scripts/scan_ab.sh builds one library per combination)
 #ifndef QK_OPT_EARLY_LOAD
 #define QK_OPT_EARLY_LOAD 1   // first tile's loads before the query staging
@@ -1534,6 +1487,10 @@ int qk_merge_topk_device(qk_ctx *ctx, const int64_t *in_ids, const float *in_key
 }
 
 // ---- host orchestration -------------------------------------------------------------------------------------
+// row-per-lane form (qk_scan_rl.hip)
+size_t qk_scan_rl_lds_per_wave(int nblk, int C);
+int qk_launch_scan_rl(int nblk, dim3 grid, size_t lds, hipStream_t st, const ScanParams &sp);
+
 template <int DB, int MAXCH>
 static int launch_scan_t(dim3 grid, dim3 block, size_t lds, hipStream_t st, const ScanParams &sp) {
     QK_HIP(hipFuncSetAttribute((const void *)k_scan<DB, MAXCH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1684,8 +1641,33 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
             }
         }
     }
+    // Row-per-lane form (qk_scan_rl.hip, v_mfma_f32_4x4x1_16b_f32: 64 rows x 4 queries per instruction): narrow rows, k <= 32,
+    // whole prepared batch.  The matrix work follows the live queries in steps of 4 and a pass over a partition serves up to
+    // 32 queries from one read of its rows -- the regime where several queries of the batch probe the same partition.
+    bool use_rl = false;
+    RlCost rlc{12, 6, 2, 24};
+    {
+        static const int rl_env = getenv("QK_SCAN_RL") ? atoi(getenv("QK_SCAN_RL")) : -1;  // -1 auto, 0 never, 1 whenever supported
+        static const int rl_min = getenv("QK_SCAN_RL_MIN") ? atoi(getenv("QK_SCAN_RL_MIN")) : 2;
+        static const int rl_h0 = getenv("QK_SCAN_RL_H0") ? atoi(getenv("QK_SCAN_RL_H0")) : 12;
+        static const int rl_h1 = getenv("QK_SCAN_RL_H1") ? atoi(getenv("QK_SCAN_RL_H1")) : 6;
+        static const int rl_e = getenv("QK_SCAN_RL_E") ? atoi(getenv("QK_SCAN_RL_E")) : 2;
+        static const int rl_ovh = getenv("QK_SCAN_RL_OVH") ? atoi(getenv("QK_SCAN_RL_OVH")) : 24;
+        rlc = RlCost{std::max(1, rl_h0), std::max(1, rl_h1), std::max(0, rl_e), std::max(0, rl_ovh)};
+        const int64_t present = std::max<int64_t>(1, std::min<int64_t>(s->nlist, std::max<int64_t>(npairs, 1)));
+        const int64_t per_list = npairs / present;
+        const bool rl_ok = nblk <= 8 && k <= 32 && !a.per_pair && !emit && npairs > 0 && ctx->qprep_xp4 != nullptr &&
+                           a.xq4 == (const float4 *)ctx->qprep;
+        use_rl = rl_ok && (rl_env == 1 || (rl_env < 0 && per_list >= rl_min));
+        if (use_rl) {
+            nw = 1;
+            qshare = 0;
+            C = std::min(64, qk_round_up(k + 32, 4));
+        }
+    }
     const int maxch = pick_maxch(C);
-    const size_t lds_scan = qshare ? (size_t)nw * (q_bytes + (size_t)16 * C * 12) : q_bytes + (size_t)nw * 16 * C * 12;
+    const size_t lds_scan = use_rl ? ((qk_scan_rl_lds_per_wave(nblk, C) + 15) & ~(size_t)15)
+                            : qshare ? (size_t)nw * (q_bytes + (size_t)16 * C * 12) : q_bytes + (size_t)nw * 16 * C * 12;
     const int Cm = qk_round_up(k + 64, 64);
     const int maxch_m = Cm <= 128 ? 2 : Cm <= 256 ? 4 : Cm <= 512 ? 8 : 16;
     const size_t lds_merge = (size_t)Cm * 12;
@@ -1708,9 +1690,10 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
     if (const char *e = getenv("QK_SCAN_WAVES_PER_CU")) {  // probe override, read per call so one process can sweep it
         if (atoi(e) > 0) waves_per_cu = std::max(nw, atoi(e) / nw * nw);
     }
+    if (use_rl) waves_per_cu = 4;  // one wave per SIMD: 256+ registers of row data per wave
     // wide rows (d >= 256: the LDS query tile leaves room for <= 4 waves per CU): 16 blocks = 16 KB per load step, so
     // that the few resident waves still keep enough bytes in flight to cover the HBM latency
-    if (nblk % 16 == 0 && waves_per_cu <= 4 && !qshare && !getenv("QK_SCAN_NO_DB16")) DB = 16;
+    if (nblk % 16 == 0 && waves_per_cu <= 4 && !qshare && !use_rl && !getenv("QK_SCAN_NO_DB16")) DB = 16;
     const int wgs_per_cu = waves_per_cu / nw;
     const int64_t n_wgs = (int64_t)num_cus * wgs_per_cu;
     const int64_t n_waves = n_wgs * nw;
@@ -1729,7 +1712,10 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
         }
     }
     const int64_t seg_starts = n_wgs + dyn_ranges;
-    const int64_t max_recs = std::min<int64_t>(0x7FFFFFF0LL, nw * std::min<int64_t>(16 * (items_bound + seg_starts), npairs + 16 * seg_starts));
+    // (row-per-lane form: a segment emits one record per live query of its pass; every range boundary inside a pass adds at
+    //  most QK_RL_QB records)
+    const int64_t max_recs = use_rl ? std::min<int64_t>(0x7FFFFFF0LL, npairs + (int64_t)QK_RL_QB * (n_waves + 1))
+                                    : std::min<int64_t>(0x7FFFFFF0LL, nw * std::min<int64_t>(16 * (items_bound + seg_starts), npairs + 16 * seg_starts));
 
     // ---- workspace ---------------------------------------------------------------------------------
     const int64_t np1 = std::max<int64_t>(npairs, 1);
@@ -1801,11 +1787,14 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
     static const int seg_ovh_env = getenv("QK_SCAN_SEG_OVH") ? atoi(getenv("QK_SCAN_SEG_OVH")) : 8;
     static const bool seg_ovh_all = getenv("QK_SCAN_SEG_OVH_ALL") && atoi(getenv("QK_SCAN_SEG_OVH_ALL")) != 0;
     const int64_t tile_bytes = 64 * (int64_t)s->dpad;
-    const int seg_ovh = (seg_ovh_env <= 0 || !(qshare || seg_ovh_all))
+    const int seg_ovh = use_rl ? rlc.ovh
+                        : (seg_ovh_env <= 0 || !(qshare || seg_ovh_all))
                             ? 0
                             : (int)std::max<int64_t>(1, ((int64_t)seg_ovh_env * 8192 + tile_bytes / 2) / tile_bytes) * nw;
     G.qgroup = qshare ? nw : 1;
     G.seg_ovh = seg_ovh;
+    G.rl = use_rl ? 1 : 0;
+    G.rlc = rlc;
     G.act_list = act_list;
     G.n_act = scal + 6;  // zeroed with the other counters
     G.n_pairs_live = scal + 7;
@@ -1906,6 +1895,12 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
         sp.pair_head = pair_head;
         sp.qshare = qshare;
         sp.seg_ovh = seg_ovh;
+        sp.xp4 = ctx->qprep_xp4;
+        sp.rl_h0 = rlc.h0;
+        sp.rl_h1 = rlc.h1;
+        sp.rl_e = rlc.e;
+        static const int rl_probe = getenv("QK_SCAN_RL_PROBE") ? atoi(getenv("QK_SCAN_RL_PROBE")) : 0;
+        sp.rl_probe = rl_probe;
         sp.key_out = a.key_out;
         sp.pair_base = a.pair_base;
         sp.pair_slots = pair_slots;
@@ -1927,12 +1922,12 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
         // dynamic tail: measured wave end times spread over 65-100 % of the kernel with a purely static cut
         static const int dyn_pct = getenv("QK_SCAN_DYN_PCT") ? atoi(getenv("QK_SCAN_DYN_PCT")) : QK_DYN_PCT_DEFAULT;
         static const int dyn_chunk = getenv("QK_SCAN_DYN_CHUNK") ? atoi(getenv("QK_SCAN_DYN_CHUNK")) : QK_DYN_CHUNK_DEFAULT;
-        sp.dyn_counter = (nw == 1 && dyn_pct > 0) ? (unsigned long long *)(scal + 16) : nullptr;  // zeroed with the counters
+        sp.dyn_counter = (nw == 1 && dyn_pct > 0 && !use_rl) ? (unsigned long long *)(scal + 16) : nullptr;  // zeroed with the counters
         sp.dyn_chunk = std::max(1, dyn_chunk);
         sp.dyn_pct = std::min(90, std::max(0, dyn_pct));
         // single-wave workgroups are bundled four to a hardware workgroup: one wave per SIMD, guaranteed (see k_scan)
         static const bool no_pack = getenv("QK_SCAN_NO_PACK") != nullptr;
-        const bool pack4 = nw == 1 && !qshare && !no_pack && (wgs_per_cu == 4 || wgs_per_cu == 8) && lds_launch % 16 == 0;
+        const bool pack4 = use_rl || (nw == 1 && !qshare && !no_pack && (wgs_per_cu == 4 || wgs_per_cu == 8) && lds_launch % 16 == 0);
         sp.pack = pack4 ? 4 : 1;
         sp.pack_lds = (int)lds_launch;
         const int wpw = pack4 ? 4 : nw;  // waves per hardware workgroup
@@ -1994,7 +1989,10 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
             QK_HIP(hipMemsetAsync(d_clock, 0, (size_t)grid * wpw * 64, st));
             sp.wave_clock = d_clock;
         }
-        QK_TRY(launch_scan(DB, maxch, dim3((unsigned)grid), dim3(64 * wpw), lds_launch, st, sp));
+        if (use_rl)
+            QK_TRY(qk_launch_scan_rl(nblk, dim3((unsigned)grid), lds_launch, st, sp));
+        else
+            QK_TRY(launch_scan(DB, maxch, dim3((unsigned)grid), dim3(64 * wpw), lds_launch, st, sp));
         if (sp.xcd_stat) {
             QK_HIP(hipMemcpyAsync(ctx->xcd_host, sp.xcd_stat, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
             QK_HIP(hipEventRecord(ctx->xcd_ev, st));

@@ -1,0 +1,419 @@
+// qk_scan_rl.hip -- the partition scan in ROW-PER-LANE form: v_mfma_f32_4x4x1_16b_f32, 64 rows x 4 queries per instruction.
+//
+// Same contract as k_scan (qk_scan.hip): distance of every (query, probed partition) pair's rows on k-ordered fp32 chains +
+// fused top-k, records chained to the pair, merged by k_merge.  Replaces scan_list / batched_scan_list + TopkBuffer
+// (src/cpp/include/list_scanning.h:41-204,241-366) inside serial_scan / batched_serial_scan
+// (src/cpp/src/query_coordinator.cpp:471-611,675-799).
+//
+// Why a second form.  k_scan feeds 16 rows x 16 queries to v_mfma_f32_16x16x4_f32: a partition probed by q queries of the
+// batch costs ceil(q/16) full MFMA tiles per 16 rows whatever q is.  With realistic nprobe (8-32) a probed partition is
+// shared by 5-20 queries of a 1024-query batch, 40 % of the query slots are live, and the launch turns MFMA-bound while
+// streaming every shared partition once per 16-query tile.  Here the 16 blocks of the 4x4x1 form are
+// 16 row groups of 4 rows against the SAME 4 queries: one instruction = 64 rows x 4 queries x 1 column at the same
+// 64 FLOP/clk/SIMD, so the matrix work follows the live queries in steps of 4 and a pass over a partition serves up to
+// QK_RL_QB = 32 queries from ONE read of its rows.  k = 1 per instruction: the accumulator chain is literally
+// acc = fma(row[k], query[k], acc) in column order -- the canonical arithmetic, bit-identical to k_scan.
+//
+// Operand layout (scripts/micro/mfma_4x4x1.hip prints it from the hardware):
+//   A: lane l holds the value of ROW l of the 64-row chunk (block l/4, row l%4 of the block)
+//   B: lane l holds the value of query (l % 4) of the group, the same for all 16 blocks
+//   D: lane 4b + j, register i = row 4b + i x query j
+// Rows come straight from the tile-major arena: lane l = (tile l/16 of the chunk, row l%16) loads, for every 16-column block c
+// and k-slice g, the float4 {columns 16c+g, +4, +8, +12} -- 4 x 256 contiguous bytes per instruction -- and element t of it
+// is the A operand of column 16c + 4t + g.  Queries are staged per pass in LDS as [group][4 columns][query] float4 (one
+// conflict-free ds_read_b128 per 4 MFMAs).
+#include "qk_internal.h"
+#include "qk_device.h"
+#include "qk_scan_types.h"
+
+#include <algorithm>
+
+__device__ __forceinline__ float4 rl_ld_nt(const float4 *p) {
+    const f32x4 t = __builtin_nontemporal_load((const f32x4 *)p);
+    return make_float4(t[0], t[1], t[2], t[3]);
+}
+__device__ __forceinline__ float f4c(const float4 &v, int t) { return t == 0 ? v.x : t == 1 ? v.y : t == 2 ? v.z : v.w; }
+
+// NB = 16-column blocks per row (d <= 128).  One hardware workgroup = 4 independent waves (own range, own LDS, no barrier).
+template <int NB>
+__global__ __launch_bounds__(256) void k_scan_rl(ScanParams P) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    constexpr int NKK = NB * 4;        // float4 (4 consecutive columns) per padded row
+    constexpr int QB = QK_RL_QB;       // query slots per pass
+    constexpr int NG = QB / 4;         // groups per pass
+    const int lane = threadIdx.x & 63, wvp = threadIdx.x >> 6;
+    const int j = lane & 3, b4 = lane >> 2;   // D: lane 4*b4 + j, register i = row 4*b4 + i x query j of the group
+    const int tq = lane >> 4, r = lane & 15;  // A: lane = row of the chunk = (tile tq, row r)
+    const int C = P.C, k = P.k;
+    const bool l2 = P.metric == QK_METRIC_L2;
+    unsigned char *sm = smem + (size_t)wvp * P.pack_lds;
+    float4 *sB = (float4 *)sm;                                            // [NG][NKK][4]
+    int64_t *pool_id = (int64_t *)(sm + (size_t)NG * NKK * 4 * 16);       // [QB][C]
+    uint32_t *pool_ord = (uint32_t *)((unsigned char *)pool_id + (size_t)QB * C * 8);  // [QB][C]
+    int *s_q = (int *)(pool_ord + (size_t)QB * C);                        // per slot: query, pair, bound, pool fill, |x|^2
+    int *s_pair = s_q + QB;
+    uint32_t *s_tau = (uint32_t *)(s_pair + QB);
+    int *s_cnt = (int *)(s_tau + QB);
+    float *s_xn = (float *)(s_cnt + QB);
+
+    // ---- this wave's contiguous share of the work sequence (units of RlCost; XCD-weighted like k_scan's) -----------------
+    const long long T = *P.n_tiles;
+    const long long W = (long long)gridDim.x * 4;
+    const long long vblock = (long long)blockIdx.x * 4 + wvp;
+    long long T0 = (T * vblock) / W, T1 = (T * (vblock + 1)) / W;
+    if (P.xcd_on) {
+        long long pre[9];
+        pre[0] = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) pre[i + 1] = pre[i] + P.xcd_w[i];
+        const long long u = blockIdx.x, gu = gridDim.x;
+        const long long total = ((gu >> 3) * pre[8] + pre[gu & 7]) * 4;
+        const long long a0 = ((u >> 3) * pre[8] + pre[u & 7]) * 4 + (long long)P.xcd_w[u & 7] * wvp;
+        const long long a1 = a0 + P.xcd_w[u & 7];
+        T0 = a0 <= 0 ? 0 : (long long)((double)T * (double)a0 / (double)total);
+        T1 = a1 >= total ? T : (long long)((double)T * (double)a1 / (double)total);
+    }
+    if (T1 <= T0) return;
+    const long long wc0 = (P.xcd_stat || P.wave_clock) ? wall_clock64() : 0;
+    int dbg_comp = 0, dbg_app = 0, dbg_seg = 0;  // probe counters (QK_SCAN_WAVE_CLOCK)
+    long long dbg_t_end = 0, dbg_t_stage = 0, dbg_gc = 0;
+    const RlCost rc{P.rl_h0, P.rl_h1, P.rl_e, P.seg_ovh};
+    const int n_active = *P.n_active;
+    // 64-ary search for the partition that holds unit T0: active[lo].toff <= T0 < active[lo+1].toff
+    int lo = 0, hi = n_active;
+    while (hi - lo > 1) {
+        const int span = hi - lo;
+        const int step = (span + 63) >> 6;
+        const int probe = min(lo + (lane + 1) * step, hi);
+        const bool gt = (probe >= hi) || (P.active[probe].toff > T0);
+        const uint64_t m = __ballot(gt);
+        const int first = __ffsll((unsigned long long)m) - 1;
+        const int nlo = min(lo + first * step, hi - 1);
+        const int nhi = min(lo + (first + 1) * step, hi);
+        lo = nlo;
+        hi = nhi;
+    }
+    int ai = lo;
+    long long cur = T0;
+
+    while (cur < T1) {
+        // ---- segment = chunks [ch0, ch1) of pass b over partition active[ai] ---------------------------------------------
+        const ActiveInfo inf = P.active[ai];
+        const int size_p = inf.size, cnt_p = inf.cnt;
+        const int nch = (size_p + 63) >> 6, ntl = (size_p + 15) >> 4;
+        const int nqb = (cnt_p + QB - 1) / QB;
+        const int g_last = (cnt_p - QB * (nqb - 1) + 3) >> 2;
+        const long long local = cur - inf.toff;
+        int b = 0, w;
+        long long boff = 0, blen;
+        for (;;) {
+            w = rl_w(b == nqb - 1 ? g_last : NG, b == 0, rc);
+            blen = rc.ovh + (long long)nch * w;
+            if (b >= nqb - 1 || local < boff + blen) break;
+            boff += blen;
+            b++;
+        }
+        const long long off = local - boff;
+        const long long off_end = min(blen, off + (T1 - cur));
+        // a chunk belongs to the range that holds its first unit
+        const int ch0 = (int)((max(0ll, off - rc.ovh) + w - 1) / w);
+        const int ch1 = (int)((max(0ll, off_end - rc.ovh) + w - 1) / w);
+        cur += off_end - off;
+        if (b >= nqb - 1 && off_end == blen) ai++;  // partition exhausted
+        if (ch1 <= ch0) continue;
+
+        const int nq = min(QB, cnt_p - QB * b);
+        const int ng = (nq + 3) >> 2;
+        const int gidx = inf.qoff + QB * b + lane;
+        // lanes 0..31 own the slot of their number: query and pair of the slot (requested first, they return first)
+        const int myq = (lane < nq) ? P.grouped_q[gidx] : -1;
+        const int mypair = (lane < nq) ? P.grouped_pair[gidx] : -1;
+        const int64_t tile_p0 = inf.row_off >> 4;
+        const bool keep_cached = nqb > 1;  // later passes re-read the rows: leave them in L2 / Infinity Cache
+
+        float4 a0[NB * 4], a1[NB * 4];
+        float4 y0, y1;
+        longlong2 i00, i01, i10, i11;
+        int lch = ch0;  // next chunk to load
+#define RL_LOAD(A, Y, I0, I1)                                                                         \
+    {                                                                                                 \
+        const int64_t ta_ = tile_p0 + min(4 * lch + tq, ntl - 1);                                     \
+        const float4 *src_ = P.vecs + ta_ * (NB * 64) + r;                                            \
+        if (keep_cached) {                                                                            \
+            _Pragma("unroll") for (int c_ = 0; c_ < NB; c_++)                                         \
+                _Pragma("unroll") for (int g_ = 0; g_ < 4; g_++) A[c_ * 4 + g_] = src_[c_ * 64 + g_ * 16]; \
+        } else {                                                                                      \
+            _Pragma("unroll") for (int c_ = 0; c_ < NB; c_++)                                         \
+                _Pragma("unroll") for (int g_ = 0; g_ < 4; g_++) A[c_ * 4 + g_] = rl_ld_nt(src_ + c_ * 64 + g_ * 16); \
+        }                                                                                             \
+        const int64_t tn_ = tile_p0 + min(4 * lch + (b4 >> 2), ntl - 1);                              \
+        Y = *((const float4 *)(P.norms + (tn_ << 4)) + (b4 & 3));                                     \
+        const longlong2 *ip_ = (const longlong2 *)(P.ids + (tn_ << 4)) + 2 * (b4 & 3);                \
+        I0 = ip_[0];                                                                                  \
+        I1 = ip_[1];                                                                                  \
+        lch++;                                                                                        \
+    }
+        RL_LOAD(a0, y0, i00, i01);
+        dbg_seg++;
+        const long long dbg_s0 = P.wave_clock ? wall_clock64() : 0;
+
+        // ---- stage the pass: per-slot state + the B operands of its queries, while the first chunk is in flight ----------
+        {
+            float4 qv[NG][(NKK + 15) / 16];
+#pragma unroll
+            for (int g = 0; g < NG; g++) {
+                if (g < ng) {
+                    const int qsl = __shfl(myq, 4 * g + j);
+                    const float4 *qsrc = P.xp4 + (int64_t)max(qsl, 0) * NKK;
+#pragma unroll
+                    for (int it = 0; it < (NKK + 15) / 16; it++) {
+                        const int kk = b4 + 16 * it;
+                        qv[g][it] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (kk < NKK && qsl >= 0) qv[g][it] = qsrc[kk];
+                    }
+                }
+            }
+            if (lane < QB) {
+                const int qs = max(myq, 0);
+                uint32_t t0 = 0xFFFFFFFFu;
+                if (P.gtau && myq >= 0) t0 = ~__hip_atomic_load(&P.gtau[qs], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s_q[lane] = myq;
+                s_pair[lane] = mypair;
+                s_tau[lane] = t0;
+                s_cnt[lane] = 0;
+                s_xn[lane] = (l2 && myq >= 0) ? P.xn[qs] : 0.0f;
+            }
+#pragma unroll
+            for (int g = 0; g < NG; g++) {
+                if (g < ng) {
+#pragma unroll
+                    for (int it = 0; it < (NKK + 15) / 16; it++) {
+                        const int kk = b4 + 16 * it;
+                        if (kk < NKK) sB[(g * NKK + kk) * 4 + j] = qv[g][it];
+                    }
+                }
+            }
+        }
+
+        if (P.wave_clock) dbg_t_stage += wall_clock64() - dbg_s0;
+
+        // ---- fused top-k of one group's 64 x 4 results ---------------------------------------------------------------------
+        auto epilogue = [&](int g, const f32x4 acc, int ch, const float4 yn, const longlong2 ia, const longlong2 ib) {
+            const int s = 4 * g + j;
+            const bool live = s < nq;
+            const float xnj = s_xn[s];
+            uint32_t tau = s_tau[s];
+            const float yv[4] = {yn.x, yn.y, yn.z, yn.w};
+            const int64_t idv[4] = {ia.x, ia.y, ib.x, ib.y};
+            const int row0 = 64 * ch + 4 * b4;
+            uint32_t ordv[4];
+            bool anyp = false;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const bool valid = live && (row0 + i < size_p);
+                const float v = acc[i];
+                const uint32_t o = l2 ? ord_from_l2(l2_expanded(xnj, yv[i], v)) : ord_from_ip(v);
+                ordv[i] = valid ? o : 0xFFFFFFFFu;
+                anyp |= valid && o <= tau && o != 0xFFFFFFFFu;
+            }
+            // steady state: nothing beats the running k-th best -> one ballot, one branch per group and chunk
+            if (__ballot(anyp)) {
+                int cnt = s_cnt[s];
+                uint32_t *my_ord = pool_ord + s * C;
+                int64_t *my_id = pool_id + s * C;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const uint32_t ord = ordv[i];
+                    const bool pass = ord != 0xFFFFFFFFu && ord <= tau;
+                    const uint64_t m = __ballot(pass);
+                    if (m) {
+                        const uint64_t gm = m & (0x1111111111111111ull << j);  // the lanes of this lane's query
+                        if (pass) {
+                            const int slot = cnt + __popcll(gm & ((1ull << lane) - 1ull));
+                            my_ord[slot] = ord;
+                            my_id[slot] = idv[i];
+                        }
+                        cnt += __popcll(gm);
+                        dbg_app += __popcll(m);
+                        uint64_t need = __ballot(cnt > C - 16) & 0xFull;  // one lane per query of the group
+                        while (need) {
+                            dbg_comp++;
+                            const int jq = __ffsll((unsigned long long)need) - 1;
+                            need &= need - 1;
+                            const int n = __builtin_amdgcn_readlane(cnt, jq);
+                            uint32_t kth;
+                            const int nn = select_pool<1>(pool_ord + (4 * g + jq) * C, pool_id + (4 * g + jq) * C, n, k, lane, kth);
+                            if (j == jq) {
+                                cnt = nn;
+                                if (nn >= k) {
+                                    tau = min(tau, kth);
+                                    if (P.gtau && P.tau_publish && b4 == 0) atomicMax(&P.gtau[s_q[s]], ~tau);
+                                }
+                            }
+                        }
+                    }
+                }
+                if (b4 == 0) {
+                    s_cnt[s] = cnt;
+                    s_tau[s] = tau;
+                }
+            }
+        };
+
+// (the B operands of step kk + 1 are requested before the 8 MFMAs of step kk: the ds_read latency hides under them)
+#define RL_STEP(A, Y, I0, I1, CH)                                                                                     \
+    {                                                                                                                 \
+        for (int g0_ = 0; g0_ < ng; g0_ += 2) {                                                                       \
+            dbg_gc++;                                                                                                 \
+            f32x4 acc0_ = {0.f, 0.f, 0.f, 0.f}, acc1_ = {0.f, 0.f, 0.f, 0.f};                                         \
+            const float4 *b0_ = sB + (size_t)g0_ * NKK * 4 + j;                                                       \
+            const float4 *b1_ = (g0_ + 1 < ng) ? b0_ + NKK * 4 : b0_;                                                 \
+            float4 qa_[2], qb_[2];                                                                                    \
+            qa_[0] = b0_[0];                                                                                          \
+            qb_[0] = b1_[0];                                                                                          \
+            if (!(P.rl_probe & 2))                                                                                    \
+            _Pragma("unroll") for (int kk_ = 0; kk_ < NKK; kk_++) {                                                   \
+                if (kk_ + 1 < NKK) {                                                                                  \
+                    qa_[(kk_ + 1) & 1] = b0_[(kk_ + 1) * 4];                                                          \
+                    qb_[(kk_ + 1) & 1] = b1_[(kk_ + 1) * 4];                                                          \
+                }                                                                                                     \
+                __builtin_amdgcn_sched_barrier(0); /* keep the reads above the MFMAs (the scheduler sinks them otherwise) */ \
+                const float4 q0_ = qa_[kk_ & 1], q1_ = qb_[kk_ & 1];                                                  \
+                const int c_ = kk_ >> 2, t_ = kk_ & 3;                                                                \
+                acc0_ = __builtin_amdgcn_mfma_f32_4x4x1f32(f4c(A[c_ * 4 + 0], t_), q0_.x, acc0_, 0, 0, 0);            \
+                acc1_ = __builtin_amdgcn_mfma_f32_4x4x1f32(f4c(A[c_ * 4 + 0], t_), q1_.x, acc1_, 0, 0, 0);            \
+                acc0_ = __builtin_amdgcn_mfma_f32_4x4x1f32(f4c(A[c_ * 4 + 1], t_), q0_.y, acc0_, 0, 0, 0);            \
+                acc1_ = __builtin_amdgcn_mfma_f32_4x4x1f32(f4c(A[c_ * 4 + 1], t_), q1_.y, acc1_, 0, 0, 0);            \
+                acc0_ = __builtin_amdgcn_mfma_f32_4x4x1f32(f4c(A[c_ * 4 + 2], t_), q0_.z, acc0_, 0, 0, 0);            \
+                acc1_ = __builtin_amdgcn_mfma_f32_4x4x1f32(f4c(A[c_ * 4 + 2], t_), q1_.z, acc1_, 0, 0, 0);            \
+                acc0_ = __builtin_amdgcn_mfma_f32_4x4x1f32(f4c(A[c_ * 4 + 3], t_), q0_.w, acc0_, 0, 0, 0);            \
+                acc1_ = __builtin_amdgcn_mfma_f32_4x4x1f32(f4c(A[c_ * 4 + 3], t_), q1_.w, acc1_, 0, 0, 0);            \
+            }                                                                                                         \
+            if (P.rl_probe & 2) { acc0_[0] += A[0].x + A[NB * 4 - 1].w; acc1_[1] += A[NB * 2].y; }                    \
+            if (!(P.rl_probe & 1)) {                                                                                  \
+                epilogue(g0_, acc0_, CH, Y, I0, I1);                                                                  \
+                if (g0_ + 1 < ng) epilogue(g0_ + 1, acc1_, CH, Y, I0, I1);                                            \
+            } else if (acc0_[0] + acc1_[1] + Y.x + (float)I0.x + (float)I1.y == 12345.678f) {                         \
+                s_cnt[0] = 1;                                                                                         \
+            }                                                                                                         \
+        }                                                                                                             \
+    }
+
+        // Every load below is unconditional inside its block (counted s_waitcnt vmcnt(N): the next chunk stays in flight under
+        // the MFMA chains of the current one) and no chunk is requested twice: the steady loop needs two more chunks after the
+        // one it computes; the last one or two chunks are peeled.
+        const bool refresh = P.gtau != nullptr && P.tau_refresh != 0 && lane < QB && myq >= 0;
+        int ch = ch0;
+        while (ch + 2 < ch1) {
+            // bounds published by other waves working on the same queries: one load for all 32 slots, requested BEFORE the
+            // next chunk's loads so that consuming it does not drain them
+            uint32_t tref = 0xFFFFFFFFu;
+            if (refresh) tref = ~__hip_atomic_load(&P.gtau[myq], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            RL_LOAD(a1, y1, i10, i11);
+            if (refresh) s_tau[lane] = min(s_tau[lane], tref);
+            RL_STEP(a0, y0, i00, i01, ch);
+            RL_LOAD(a0, y0, i00, i01);
+            RL_STEP(a1, y1, i10, i11, ch + 1);
+            ch += 2;
+        }
+        if (ch + 1 < ch1) {
+            RL_LOAD(a1, y1, i10, i11);
+            RL_STEP(a0, y0, i00, i01, ch);
+            RL_STEP(a1, y1, i10, i11, ch + 1);
+        } else {
+            RL_STEP(a0, y0, i00, i01, ch);
+        }
+#undef RL_LOAD
+#undef RL_STEP
+
+        // ---- segment end: sort every non-empty pool, publish its bound, emit it as a record of its pair -------------------
+        const long long dbg_e0 = P.wave_clock ? wall_clock64() : 0;
+        {
+            int cntl = lane < QB ? s_cnt[lane] : 0;
+            uint64_t need = __ballot(cntl > 0);
+            while (need) {
+                const int sq = __ffsll((unsigned long long)need) - 1;
+                need &= need - 1;
+                const int n = __builtin_amdgcn_readlane(cntl, sq);
+                const int nn = compact_pool<1>(pool_ord + sq * C, pool_id + sq * C, n, k, lane);
+                if (lane == sq) cntl = nn;
+            }
+            const uint64_t have = __ballot(cntl > 0);
+            if (have) {
+                // slot in the pair's line and record numbers of the segment: independent atomics, one round trip
+                int slot = -1, base_rec = 0;
+                if (cntl > 0) slot = atomicAdd(&P.pair_slots[(int64_t)mypair * QK_SLOTS], 1);
+                if (lane == 0) base_rec = atomicAdd(P.rec_counter, nq);
+                const int rec0 = __builtin_amdgcn_readfirstlane(base_rec);
+                int myrec = -1;
+                if (cntl > 0) {
+                    myrec = rec0 + lane;
+                    if (slot < QK_SLOTS - 1) P.pair_slots[(int64_t)mypair * QK_SLOTS + 1 + slot] = myrec < P.max_recs ? myrec : -1;
+                    if (myrec < P.max_recs) {
+                        int old = -1;
+                        if (slot >= QK_SLOTS - 1) old = atomicExch(&P.pair_head[mypair], myrec);  // beyond the line: chained
+                        P.rec_hdr[myrec] = make_int2(old, cntl);
+                        if (P.gtau && P.tau_publish && cntl >= k) atomicMax(&P.gtau[myq], ~pool_ord[lane * C + k - 1]);
+                    }
+                }
+                uint64_t todo = have;
+                while (todo) {
+                    const int sq = __ffsll((unsigned long long)todo) - 1;
+                    todo &= todo - 1;
+                    const int n = __builtin_amdgcn_readlane(cntl, sq);
+                    const int rec = __builtin_amdgcn_readlane(myrec, sq);
+                    if (rec < P.max_recs)
+                        for (int e = lane; e < n; e += 64) {
+                            P.rec_ord[(int64_t)rec * k + e] = pool_ord[sq * C + e];
+                            P.rec_id[(int64_t)rec * k + e] = pool_id[sq * C + e];
+                        }
+                }
+            }
+        }
+        if (P.wave_clock) dbg_t_end += wall_clock64() - dbg_e0;
+    }
+    if (P.xcd_stat && lane == 0) {
+        atomicAdd(&P.xcd_stat[blockIdx.x & 7], (unsigned long long)(wall_clock64() - wc0));
+        atomicAdd(&P.xcd_stat[8 + (blockIdx.x & 7)], 1ull);
+    }
+    if (P.wave_clock && lane == 0) {
+        long long *wcp = P.wave_clock + 8 * vblock;
+        wcp[0] = wc0;
+        wcp[1] = wall_clock64();
+        wcp[2] = dbg_comp;
+        wcp[3] = dbg_app;
+        wcp[4] = dbg_seg;
+        wcp[5] = dbg_t_end;
+        wcp[6] = dbg_gc;  // (group-pair x chunk) steps instead of the staging ticks k_scan reports here
+        const unsigned hw = __builtin_amdgcn_s_getreg((4) | (0 << 6) | ((32 - 1) << 11));
+        const unsigned xcc = __builtin_amdgcn_s_getreg((20) | (0 << 6) | ((4 - 1) << 11));
+        wcp[7] = ((long long)xcc << 32) | hw;
+    }
+}
+
+// ---- host side ---------------------------------------------------------------------------------------------------------
+size_t qk_scan_rl_lds_per_wave(int nblk, int C) {
+    return (size_t)(QK_RL_QB / 4) * nblk * 4 * 4 * 16 + (size_t)QK_RL_QB * C * 12 + (size_t)QK_RL_QB * 4 * 5;
+}
+
+template <int NB>
+static int launch_rl_t(dim3 grid, size_t lds, hipStream_t st, const ScanParams &sp) {
+    QK_HIP(hipFuncSetAttribute((const void *)k_scan_rl<NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_scan_rl<NB>), grid, dim3(256), lds, st, sp);
+    return QK_OK;
+}
+
+// grid = hardware workgroups of 4 independent waves; lds = 4 x sp.pack_lds
+int qk_launch_scan_rl(int nblk, dim3 grid, size_t lds, hipStream_t st, const ScanParams &sp) {
+    switch (nblk) {
+        case 1: return launch_rl_t<1>(grid, lds, st, sp);
+        case 2: return launch_rl_t<2>(grid, lds, st, sp);
+        case 3: return launch_rl_t<3>(grid, lds, st, sp);
+        case 4: return launch_rl_t<4>(grid, lds, st, sp);
+        case 5: return launch_rl_t<5>(grid, lds, st, sp);
+        case 6: return launch_rl_t<6>(grid, lds, st, sp);
+        case 7: return launch_rl_t<7>(grid, lds, st, sp);
+        case 8: return launch_rl_t<8>(grid, lds, st, sp);
+    }
+    QK_FAIL(QK_ERR_UNSUPPORTED, "row-per-lane scan: d > 128 (nblk=%d)", nblk);
+}

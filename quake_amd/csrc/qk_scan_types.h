@@ -1,0 +1,95 @@
+// qk_scan_types.h -- structures shared by the partition-scan kernels (qk_scan.hip, qk_scan_rl.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+constexpr int QK_SLOTS = 32;  // ints per pair slot line: count + 31 record ids
+
+// ---- grouping ---------------------------------------------------------------------------------------
+// everything a wave needs to start on an active partition, in one 32-byte load
+struct __align__(16) ActiveInfo {
+    long long toff;     // first tile of this partition's items in the global tile sequence
+    long long row_off;  // first arena row
+    int p;              // list number
+    int size;           // rows
+    int cnt;            // queries probing it
+    int qoff;           // offset of its group in grouped_q / grouped_pair
+};
+
+struct ScanParams {
+    const float4 *vecs;
+    const float *norms;
+    const int64_t *ids;
+    const int64_t *pt_off;
+    const int32_t *pt_size;
+    int nblk;
+    const float4 *xq4;
+    const float *xn;
+    const int32_t *grouped_q;
+    const int32_t *grouped_pair;
+    const int32_t *n_active;
+    const ActiveInfo *active;
+    const int64_t *n_tiles;
+    uint32_t *gtau;  // [Q] shared running bound per query stored as ~bound (0 = none, so one memset clears it), or nullptr
+    int tau_refresh;  // re-read gtau every 8 tiles (only useful when a query probes several partitions)
+    int tau_publish;  // waves publish their bound into gtau (0: gtau is a read-only initial bound, qk_scan_args::tau_init)
+    int k;
+    int C;  // pool capacity per query; k <= C - 4
+    int metric;
+    int32_t *pair_head;
+    int32_t *pair_slots;
+    int32_t *rec_counter;
+    int32_t max_recs;
+    int2 *rec_hdr;       // [max_recs] {next record of the pair (-1 = end), entry count}
+    uint32_t *rec_ord;   // [max_recs][k]
+    int64_t *rec_id;     // [max_recs][k]
+    // dynamic tail (one wave per workgroup only): the last dyn_tiles_pct % of the tile sequence is handed out in chunks of
+    // dyn_chunk tiles through this counter once a wave has finished its static share (nullptr: all static)
+    unsigned long long *dyn_counter;
+    int dyn_chunk, dyn_pct;
+    int pack;      // > 1: independent one-wave workgroups bundled per hardware workgroup (see k_scan)
+    int pack_lds;  // LDS bytes of each bundled wave
+    // XCD balance: hardware workgroup u belongs to class u % 8 (workgroups go round-robin over the XCDs); its share of the cut
+    // is proportional to xcd_w[class] (1024 = average); xcd_stat [16] collects ticks and waves per class (nullptr: not sampled)
+    int xcd_on;
+    int xcd_w[8];
+    unsigned long long *xcd_stat;
+    // query-sharing workgroups (narrow rows, many queries per partition): the nw waves of a workgroup walk the SAME tiles
+    // of a partition at the same time, each with its own 16-query tile and pools in LDS, so that a partition probed by up
+    // to 16*nw queries is fetched from HBM once (the later waves hit in L2).  0: waves split the tiles instead.
+    int qshare;
+    int seg_ovh;  // as GroupParams::seg_ovh
+    // key emission (MODE 4, k > QK_MAX_K): no top-k at all, every (pair, row) key goes to key_out[pair_base[pair] + row]
+    uint32_t *key_out;
+    const int64_t *pair_base;
+    long long *wave_clock;  // probe (QK_SCAN_WAVE_CLOCK): [waves][2] start / end of every wave in wall_clock64 ticks, or nullptr
+    // row-per-lane scan (qk_scan_rl.hip)
+    const float4 *xp4;  // [Q][dpad/4] row-major zero-padded queries
+    int rl_h0, rl_h1, rl_e;  // cost model of the work sequence (RlCost; ovh = seg_ovh)
+    int rl_probe;            // probe (QK_SCAN_RL_PROBE): bit 0 = no top-k epilogue, bit 1 = no MFMA chains (attribution only)
+};
+
+// ---- row-per-lane scan (qk_scan_rl.hip): cost model of the work sequence ----------------------------------------------------
+// A partition probed by cnt queries is scanned in passes of up to QK_RL_QB queries (QK_RL_QB / 4 groups of 4: one
+// v_mfma_f32_4x4x1_16b_f32 serves 64 rows x 4 queries).  A pass walks the partition in chunks of 64 rows; a chunk of a pass
+// with g groups weighs max(h, g + e) units -- h stands for streaming the chunk (h0: from HBM, first pass; h1: later passes
+// find it in L2 / Infinity Cache), g for its MFMA chains -- and every pass starts with `ovh` units (query staging, record
+// emission).  The grouping stage lays the partitions end to end in these units and k_scan_rl cuts the sequence statically.
+constexpr int QK_RL_QB = 32;
+struct RlCost {
+    int h0, h1, e, ovh;
+};
+__host__ __device__ inline int rl_w(int g, bool first, const RlCost &c) {
+    const int h = first ? c.h0 : c.h1, v = g + c.e;
+    return v > h ? v : h;
+}
+__host__ __device__ inline long long rl_part_len(int cnt, int size, const RlCost &c) {
+    const long long nch = (size + 63) >> 6;
+    const int nqb = (cnt + QK_RL_QB - 1) / QK_RL_QB;
+    const int g_last = (cnt - QK_RL_QB * (nqb - 1) + 3) >> 2;
+    if (nqb <= 1) return c.ovh + nch * rl_w(g_last, true, c);
+    return (long long)nqb * c.ovh +
+           nch * ((long long)rl_w(QK_RL_QB / 4, true, c) + (long long)(nqb - 2) * rl_w(QK_RL_QB / 4, false, c) + rl_w(g_last, false, c));
+}
+
+

@@ -1,5 +1,5 @@
 """BASELINE.json configs[4] at single-GPU scale: a dynamic workload (interleaved add / remove / search with maintenance =
-split + delete + k-means refine) replayed on the device index, written with the harness of quake_amd/workload.py.
+split + delete + k-means refine) replayed on the device index with the harness of quake_amd/workload.py (generate_workload / replay_workload).
     python scripts/dynamic_workload.py [n_base] [dim] [n_ops]
 Prints one JSON summary line (per-operation-type latency, recall, partitions over time) and keeps the per-operation records
 (and the runbook)
@@ -11,8 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench as B
 import quake_amd as quake
-from quake_amd.workload import DynamicWorkloadGenerator, WorkloadEvaluator
-from quake_amd.wrapper import QuakeWrapper
+from quake_amd.workload import WorkloadSpec, generate_workload, replay_workload
 
 
 def main():
@@ -30,24 +29,22 @@ def main():
     q = B.gen_queries(20000, cent, seed=2, device=dev)
     x, q = x.cpu(), q.cpu()
     t0 = time.time()
-    gen = DynamicWorkloadGenerator(workload_dir=os.path.join(out, "w"), base_vectors=x, metric="l2", insert_ratio=0.3,
-                                   delete_ratio=0.2, query_ratio=0.5, update_batch_size=max(n // 100, 100),
-                                   query_batch_size=1024, number_of_operations=n_ops, initial_size=n // 2,
-                                   cluster_size=2500, cluster_sample_distribution="skewed", queries=q,
-                                   query_cluster_sample_distribution="skewed", seed=1738)
-    rb = gen.generate_workload()
+    spec = WorkloadSpec(metric="l2", insert_ratio=0.3, delete_ratio=0.2, query_ratio=0.5, update_batch_size=max(n // 100, 100),
+                        query_batch_size=1024, number_of_operations=n_ops, initial_size=n // 2, cluster_size=2500,
+                        cluster_sample_distribution="skewed", query_cluster_sample_distribution="skewed", seed=1738)
+    rb = generate_workload(os.path.join(out, "w"), x, spec, queries=q)
     t_gen = time.time() - t0
     results = {}
     for name, maint in (("warmup", False), ("static_partitions", False), ("with_maintenance", True)):
-        ev = WorkloadEvaluator(os.path.join(out, "w"), os.path.join(out, name))
         mp = quake.MaintenancePolicyParams()
         mp.window_size = 2048
         mp.refinement_radius = 8
         mp.refinement_iterations = 2
         t0 = time.time()
-        res = ev.evaluate_workload(name=name, index=QuakeWrapper(), build_params={"nc": (n // 2) // 2500, "metric": "l2"},
-                                   search_params={"k": 10, "nprobe": 8}, do_maintenance=maint, m_params=mp if maint else None,
-                                   batch=True)
+        sp = quake.SearchParams()
+        sp.k, sp.nprobe = 10, 8
+        res = replay_workload(os.path.join(out, "w"), os.path.join(out, name), name, nlist=(n // 2) // 2500, search_params=sp,
+                              maintenance_params=mp if maint else None)
         wall = time.time() - t0
 
         def mean(key, typ):

@@ -2,6 +2,7 @@
 workload harness (generator + evaluator) behaves like the reference's (test/python/test_workload_generator.py:69-114;
 test/cpp/maintenance.cpp spirit: after maintenance the index answers exactly and its bookkeeping is consistent)."""
 import json
+import os
 
 import numpy as np
 import pytest
@@ -113,48 +114,62 @@ def test_device_profiled_cost_model():
     assert np.isfinite(est.compute_split_delta(8000, 0.5, 100))
 
 
-def test_workload_generation_and_evaluation(tmp_path):  # test_workload_generator.py:28-114
-    from quake_amd.workload import DynamicWorkloadGenerator, UniformSampler, WorkloadEvaluator
-    from quake_amd.wrapper import QuakeWrapper
+def test_workload_generation_and_evaluation(tmp_path):  # cf. test/python/test_workload_generator.py:28-114
+    """runbook schema (the on-disk contract shared with the reference's harness), determinism of the seeded stream, and a
+    replay with maintenance on: the index follows the runbook's resident set, exhaustive probing finds everything."""
+    from quake_amd.workload import ClusterWalk, WorkloadSpec, generate_workload, replay_workload
     import quake_amd as quake
     torch.manual_seed(0)
     base = torch.randn(1000, 16)
     queries = torch.randn(100, 16)
     wdir = tmp_path / "workload"
-    gen = DynamicWorkloadGenerator(workload_dir=wdir, base_vectors=base, metric="l2", insert_ratio=0.3, delete_ratio=0.2,
-                                   query_ratio=0.5, update_batch_size=20, query_batch_size=10, number_of_operations=10,
-                                   initial_size=200, cluster_size=50, cluster_sample_distribution="uniform",
-                                   queries=queries, seed=1738)
-    gen.sampler = UniformSampler()
-    gen.generate_workload()
+    spec = WorkloadSpec(metric="l2", insert_ratio=0.3, delete_ratio=0.2, query_ratio=0.5, update_batch_size=20, query_batch_size=10,
+                        number_of_operations=10, initial_size=200, cluster_size=50, seed=1738)
+    rb = generate_workload(wdir, base, spec, queries=queries)
     assert (wdir / "runbook.json").exists() and (wdir / "operations").exists()
-    rb = json.load(open(wdir / "runbook.json"))
-    assert "initialize" in rb and "operations" in rb and "parameters" in rb and "summary" in rb
+    assert rb == json.load(open(wdir / "runbook.json"), object_pairs_hook=lambda kv: {(int(k) if k.isdigit() else k): v for k, v in kv})
+    assert set(rb) == {"parameters", "initialize", "operations", "summary"}
+    with open(os.path.join(os.path.dirname(__file__), "golden", "runbook_schema.json")) as f:
+        schema = json.load(f)
+    assert sorted(rb["parameters"]) == sorted(schema["parameters"])  # the reference's parameter block, key for key
     assert len(rb["operations"]) <= 10
     for i, op in rb["operations"].items():
+        assert set(op) <= set(schema["operation"]) and {"type", "sample_size", "n_resident"} <= set(op)
         assert op["type"] in ("insert", "delete", "query") and op["sample_size"] > 0 and op["n_resident"] > 0
         assert (wdir / "operations" / f"{i}.pt").exists()
         if op["type"] == "query":
             gt = torch.load(wdir / "operations" / f"{i}_gt_ids.pt", weights_only=True)
             assert gt.shape == (op["sample_size"], 100) and "gt_time" in op
     s = rb["summary"]
+    assert sorted(s) == sorted(schema["summary"])
     assert s["n_inserts"] + s["n_deletes"] + s["n_queries"] == s["n_operations"] == len(rb["operations"])
-    # same seed -> same operation stream
-    gen2 = DynamicWorkloadGenerator(workload_dir=tmp_path / "w2", base_vectors=base, metric="l2", insert_ratio=0.3,
-                                    delete_ratio=0.2, query_ratio=0.5, update_batch_size=20, query_batch_size=10,
-                                    number_of_operations=10, initial_size=200, cluster_size=50,
-                                    cluster_sample_distribution="uniform", queries=queries, seed=1738)
-    rb2 = gen2.generate_workload()
+    # same seed -> same operation stream and the same ids
+    rb2 = generate_workload(tmp_path / "w2", base, spec, queries=queries)
     assert [o["type"] for o in rb2["operations"].values()] == [o["type"] for o in rb["operations"].values()]
+    for i in rb["operations"]:
+        assert torch.equal(torch.load(wdir / "operations" / f"{i}.pt", weights_only=True),
+                           torch.load(tmp_path / "w2" / "operations" / f"{i}.pt", weights_only=True))
+    with pytest.raises(ValueError):
+        WorkloadSpec(insert_ratio=0.5, delete_ratio=0.5, query_ratio=0.5).check()
 
-    ev = WorkloadEvaluator(workload_dir=wdir, output_dir=wdir)
+    sp = quake.SearchParams()
+    sp.k, sp.nprobe = 5, 10
     mp = quake.MaintenancePolicyParams()
     mp.window_size = 20
-    res = ev.evaluate_workload(name="quake_test", index=QuakeWrapper(), build_params={"nc": 10, "metric": "l2"},
-                               search_params={"k": 5, "nprobe": 10}, do_maintenance=True, m_params=mp, batch=True)
+    res = replay_workload(wdir, wdir, "quake_test", nlist=10, search_params=sp, maintenance_params=mp)
     assert isinstance(res, list) and len(res) == len(rb["operations"])
+    assert json.load(open(wdir / "quake_test_results.json")) == res
     for r in res:
         assert r["latency_ms"] >= 0 and r["n_total"] == r["n_resident"]  # the index tracks the runbook's resident set
         if r["operation_type"] == "query":
-            assert 0.0 <= r["recall"] <= 1.0
             assert r["recall"] >= 0.99  # nprobe = nlist: exhaustive
+
+    # skewed sampling: consecutive draws come from neighbouring clusters and empty the nearest cluster first
+    cent = torch.tensor([[0.0, 0.0], [1.0, 0.0], [5.0, 0.0], [9.0, 0.0]])
+    cluster_of = torch.tensor([0] * 5 + [1] * 5 + [2] * 5 + [3] * 5)
+    torch.manual_seed(3)
+    walk = ClusterWalk(cluster_of, cent)
+    root0 = walk.root
+    got = walk(torch.arange(20), 7)
+    assert got.shape[0] == 7 and (cluster_of[got] == root0).sum() == 5  # the whole root cluster, then its neighbour
+    assert walk.root != root0
