@@ -209,7 +209,7 @@ def timed_region(ctx, step, nprobe, steps, warmup, settle, dist, dev):
     ev_ph = ctx.read_timing()
     ctx.set_timing(0)
     if dist is not None:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if str(dist.get_backend()).lower() != "gloo" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = tt.item()
     return elapsed, ev, ev_ph
@@ -318,6 +318,7 @@ def run_single_workload(ctx, dev, args, name, sigma, fixed_nprobe, steps, warmup
         torch.cuda.synchronize()
         gi0, gd0 = gi0.cpu().numpy(), gd0.cpu().numpy()
         cores = O.max_threads()
+        eff_cores = round(O.effective_cores(cores), 1)  # what the host really gives this process (shared / sandboxed boxes)
 
         def time_cpu(batched, budget, threads, nq, fast=1):
             t, nn, reps, ids, dist = 0.0, 0, 0, None, None
@@ -351,6 +352,7 @@ def run_single_workload(ctx, dev, args, name, sigma, fixed_nprobe, steps, warmup
                       f"single thread: {n1} queries in {t_1:.1f}s",
             "serial_scan_qps": round(qps_s, 1), "batched_scan_qps": round(qps_b, 1),
             "single_thread_qps": round(qps_1, 1), "threads_speedup": round(max(qps_b, qps_s) / max(qps_1, 1e-9), 1),
+            "effective_cores_measured": eff_cores,
             "ids_equal_to_gpu_frac": same_ids, "distance_bits_equal_to_gpu_frac": same_dist,
             "ids_equal_serial_lane_sum_frac": round(float((ids_s == gi0).mean()), 5),
         }
@@ -438,6 +440,35 @@ def run_configs0(ctx, dev, args):
 
 
 # ---- N > 1: BASELINE.json configs[3] shape --------------------------------------------------------------------------------
+def _all_to_all(dist, out, inp, out_splits=None, in_splits=None):
+    """all_to_all_single; staged through the host under gloo (QUAKE_BENCH_BACKEND=gloo: two ranks on one GPU, functional check)"""
+    if str(dist.get_backend()).lower() == "gloo" and inp.is_cuda:
+        ho = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_to_all_single(ho, inp.cpu(), out_splits, in_splits)
+        out.copy_(ho)
+    else:
+        dist.all_to_all_single(out, inp, out_splits, in_splits)
+
+
+def _all_gather(dist, tensors, t):
+    if str(dist.get_backend()).lower() == "gloo" and t.is_cuda:
+        hl = [torch.empty(x.shape, dtype=x.dtype) for x in tensors]
+        dist.all_gather(hl, t.cpu())
+        for a, b in zip(tensors, hl):
+            a.copy_(b)
+    else:
+        dist.all_gather(tensors, t)
+
+
+def _all_reduce(dist, t):
+    if str(dist.get_backend()).lower() == "gloo" and t.is_cuda:
+        h = t.cpu()
+        dist.all_reduce(h)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t)
+
+
 def run_sharded(ctx, dev, args, dist, rank, world):
     from quake_amd.capi import Store
     from quake_amd.sharded import GpuEngine, ShardedIndex, sharded_kmeans
@@ -462,7 +493,7 @@ def run_sharded(ctx, dev, args, dist, rank, world):
     order = torch.argsort(owner, stable=True)
     send_counts = torch.bincount(owner, minlength=world)
     recv_counts = torch.empty_like(send_counts)
-    dist.all_to_all_single(recv_counts, send_counts)
+    _all_to_all(dist, recv_counts, send_counts)
     sc, rc = send_counts.tolist(), recv_counts.tolist()
     xs, as_, is_ = x[order].contiguous(), assign[order].contiguous(), (order + id_base).contiguous()
     del x, order, owner
@@ -470,9 +501,9 @@ def run_sharded(ctx, dev, args, dist, rank, world):
     xr = torch.empty((nr, d), device=dev)
     ar = torch.empty((nr,), dtype=torch.int64, device=dev)
     ir = torch.empty((nr,), dtype=torch.int64, device=dev)
-    dist.all_to_all_single(xr, xs, rc, sc)
-    dist.all_to_all_single(ar, as_, rc, sc)
-    dist.all_to_all_single(ir, is_, rc, sc)
+    _all_to_all(dist, xr, xs, rc, sc)
+    _all_to_all(dist, ar, as_, rc, sc)
+    _all_to_all(dist, ir, is_, rc, sc)
     del xs, as_, is_
     o2 = torch.argsort(ar, stable=True)
     counts = torch.bincount(ar, minlength=nlist_g).cpu().numpy().astype(np.int64)
@@ -496,8 +527,8 @@ def run_sharded(ctx, dev, args, dist, rank, world):
         gi = torch.where(gi >= 0, ids_local[gi.clamp(min=0)], gi)
         gl_i = [torch.empty_like(gi) for _ in range(world)]
         gl_d = [torch.empty_like(gd2) for _ in range(world)]
-        dist.all_gather(gl_i, gi)
-        dist.all_gather(gl_d, gd2)
+        _all_gather(dist, gl_i, gi)
+        _all_gather(dist, gl_d, gd2)
         ci, cd = torch.cat(gl_i, 1), torch.cat(gl_d, 1)
         _, j = torch.topk(cd, k, dim=1, largest=False)
         gts.append(torch.gather(ci, 1, j)[rank * per:(rank + 1) * per])
@@ -511,7 +542,7 @@ def run_sharded(ctx, dev, args, dist, rank, world):
 
     def rec(ri, b):
         r = torch.tensor([recall_at_k(ri, gts[b], k)], device=dev, dtype=torch.float64)
-        dist.all_reduce(r, op=dist.ReduceOp.SUM)
+        _all_reduce(dist, r)
         return r.item() / world
 
     nprobe, recall, sweep = pick_nprobe(step, batches, gts, k, args.recall_target, args.nprobe, rec)

@@ -45,9 +45,10 @@ typedef enum {
 #define QK_METRIC_L2 1
 #define QK_MEM_HOST 0
 #define QK_MEM_DEVICE 1
-#define QK_MAX_K 448 /* largest k of the fused LDS top-k (pool capacity k+64 <= 512).  Larger k, up to 4096, is served by
-                      * emitting every key and selecting afterwards (slower, exact); the reference's buffer holds 8192 (list_scanning.h:39) */
-#define QK_MAX_NPROBE 4096 /* largest nprobe / number of APS candidate partitions: the coarse step selects them with a
+#define QK_MAX_K 448 /* largest k of the fused LDS top-k (pool capacity k+64 <= 512).  Larger k, up to 8192 -- the capacity
+                      * of the reference's buffer (list_scanning.h:39) -- is served by emitting every key and selecting afterwards
+                      * (slower, exact) */
+#define QK_MAX_NPROBE 8192 /* largest nprobe / number of APS candidate partitions: the coarse step selects them with a
                               * bisection select + sort beyond QK_MAX_K (flat parent index) */
 
 typedef struct qk_ctx qk_ctx;     /* device + stream + scratch workspace                     */

@@ -20,7 +20,7 @@ __all__ = [
     "METRIC_IP", "METRIC_L2", "build", "lib", "metric_code", "ip", "l2sqr_direct", "row_norms", "TopkBuffer",
     "scan_list", "batched_scan_list", "serial_scan", "batched_serial_scan", "coarse", "search", "rand_perm",
     "kmeans_assign", "kmeans_accumulate", "kmeans", "kmeans_update", "normalize_rows", "kmeans_refine_partitions", "recall", "csr_from_partitions",
-    "max_threads", "incomplete_beta", "incomplete_beta_table", "incomplete_beta_lookup", "log_cap_volume", "recall_profile",
+    "max_threads", "effective_cores", "incomplete_beta", "incomplete_beta_table", "incomplete_beta_lookup", "log_cap_volume", "recall_profile",
     "boundary_distances", "search_aps",
 ]
 
@@ -270,6 +270,14 @@ def search(x, centroids, vecs, ids, offsets, nprobe, k, metric, batched_scan=Fal
     lib().qo_search(_pf(x), nq, _pf(centroids), _pi(cids), _pf(vecs), _pi(ids), _pi(offsets), offsets.shape[0] - 1, d,
                     nprobe, k, metric_code(metric), int(batched_scan), num_threads, int(fast), _pi(out_i), _pf(out_d))
     return out_i, out_d
+
+
+def effective_cores(nthreads=0, iters=40_000_000):
+    """aggregate FMA rate on `nthreads` threads / rate on one thread (what the host really gives this process)"""
+    L = lib()
+    L.qo_effective_cores.restype = C.c_double
+    L.qo_effective_cores.argtypes = [C.c_int, C.c_long]
+    return float(L.qo_effective_cores(int(nthreads), int(iters)))
 
 
 def rand_perm(n, m, seed):

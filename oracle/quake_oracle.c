@@ -64,6 +64,40 @@ __attribute__((constructor)) static void qo_init_allocator(void) {
     mallopt(M_TRIM_THRESHOLD, 1 << 30);
 }
 
+/* How many cores' worth of arithmetic the host actually gives this process: a fixed register-only FMA loop, timed on 1 and on
+ * `nthreads` threads; returns (aggregate rate on nthreads) / (rate on 1).  bench.py reports it next to the thread count, so
+ * that a 128-thread host that is shared / sandboxed / quota-limited is not mistaken for a 128-core baseline. */
+static double fma_spin(long iters) {
+    __m256 a0 = _mm256_set1_ps(1.0f), a1 = a0, a2 = a0, a3 = a0;
+    const __m256 m = _mm256_set1_ps(0.9999999f), c = _mm256_set1_ps(1e-7f);
+    for (long i = 0; i < iters; i++) {
+        a0 = _mm256_fmadd_ps(a0, m, c);
+        a1 = _mm256_fmadd_ps(a1, m, c);
+        a2 = _mm256_fmadd_ps(a2, m, c);
+        a3 = _mm256_fmadd_ps(a3, m, c);
+    }
+    float out[8];
+    _mm256_storeu_ps(out, _mm256_add_ps(_mm256_add_ps(a0, a1), _mm256_add_ps(a2, a3)));
+    return out[0];
+}
+QO_API double qo_effective_cores(int nthreads, long iters) {
+#ifdef _OPENMP
+    if (nthreads <= 0) nthreads = omp_get_max_threads();
+    volatile double sink = 0;
+    double t0 = omp_get_wtime();
+    sink += fma_spin(iters);
+    const double t1 = omp_get_wtime() - t0;
+    t0 = omp_get_wtime();
+#pragma omp parallel num_threads(nthreads)
+    { sink += fma_spin(iters); }
+    const double tn = omp_get_wtime() - t0;
+    (void)sink;
+    return tn > 0 ? (double)nthreads * t1 / tn : 1.0;
+#else
+    return 1.0;
+#endif
+}
+
 /* ------------------------------------------------------------------------------------------------
  * Distance primitives (canonical k-ordered fmaf chains)
  * ---------------------------------------------------------------------------------------------- */

@@ -12,7 +12,7 @@ QK_METRIC_L2 = 1
 QK_MEM_HOST = 0
 QK_MEM_DEVICE = 1
 QK_MAX_K = 448
-QK_MAX_NPROBE = 4096
+QK_MAX_NPROBE = 8192
 
 STATUS_NAMES = {1: "QK_ERR_INVALID", 2: "QK_ERR_NOT_FOUND", 3: "QK_ERR_HIP", 4: "QK_ERR_UNSUPPORTED", 5: "QK_ERR_OOM"}
 

@@ -17,12 +17,8 @@ _spec = importlib.util.spec_from_file_location("quake_amd._bindings", _SO)
 _bindings = importlib.util.module_from_spec(_spec)
 _spec.loader.exec_module(_bindings)
 
-QuakeIndex = _bindings.QuakeIndex
-IndexBuildParams = _bindings.IndexBuildParams
-SearchParams = _bindings.SearchParams
-MaintenancePolicyParams = _bindings.MaintenancePolicyParams
-SearchResult = _bindings.SearchResult
-SearchTimingInfo = _bindings.SearchTimingInfo
-BuildTimingInfo = _bindings.BuildTimingInfo
-ModifyTimingInfo = _bindings.ModifyTimingInfo
-MaintenanceTimingInfo = _bindings.MaintenanceTimingInfo
+# every public name of the extension module: the classes (QuakeIndex, IndexBuildParams, SearchParams, ..., PartitionManager,
+# QueryCoordinator) and the list_scanning seam (batched_scan_list)
+for _name in dir(_bindings):
+    if not _name.startswith("_"):
+        globals()[_name] = getattr(_bindings, _name)

@@ -14,10 +14,14 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libquake_hip.so")
-SOURCES = ["qk_ctx.hip", "qk_store.hip", "qk_scan.hip", "qk_scan_rl.hip", "qk_dense.hip", "qk_kmeans.hip", "qk_aps.hip", "qk_api.hip"]
+SOURCES = ["qk_ctx.hip", "qk_store.hip", "qk_scan.hip", "qk_scan_rl.hip", "qk_small.hip", "qk_dense.hip", "qk_kmeans.hip", "qk_aps.hip", "qk_api.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fvisibility=hidden",
          "-Wall", "-Wno-unused-function", "-Wno-unused-variable", "-Wno-unused-value"]
+# QK_BUILD_PROBES=1: the tuning build -- QK_* environment switches and the wave-clock printouts compiled in (qk_internal.h).
+# The product build has none of them.
+if os.environ.get("QK_BUILD_PROBES", "0") not in ("", "0"):
+    FLAGS.append("-DQK_PROBES")
 
 
 def _stale(out, deps):
@@ -34,6 +38,11 @@ def build_lib(force=False, verbose=False):
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers.append(os.path.join(os.path.dirname(HERE), "include", "quake_hip.h"))
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    # a change of flags (product <-> probe build) rebuilds everything
+    flag_file = os.path.join(objdir, "flags.txt")
+    flag_text = " ".join(FLAGS)
+    if not os.path.exists(flag_file) or open(flag_file).read() != flag_text:
+        force = True
     objs = []
     jobs = []
     for s in srcs:
@@ -55,6 +64,8 @@ def build_lib(force=False, verbose=False):
         if res.returncode != 0:
             sys.stderr.write(res.stdout + res.stderr)
             raise RuntimeError("link failed")
+        with open(flag_file, "w") as f:
+            f.write(flag_text)
     return LIB
 
 

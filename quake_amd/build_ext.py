@@ -13,8 +13,9 @@ OUT = os.path.join(HERE, "_bindings.so")
 def build_bindings(force=False, verbose=False):
     from .build import build_lib
     lib = build_lib()
-    srcs = [os.path.join(CPP, "bindings.cpp"), os.path.join(CPP, "quake_index.cpp")]
-    deps = srcs + [os.path.join(CPP, "quake_index.h"), os.path.join(os.path.dirname(HERE), "include", "quake_hip.h")]
+    srcs = [os.path.join(CPP, f) for f in ("bindings.cpp", "quake_index.cpp", "partition_manager.cpp", "query_coordinator.cpp",
+                                           "maintenance_policies.cpp", "list_scanning.cpp")]
+    deps = srcs + glob.glob(os.path.join(CPP, "*.h")) + [os.path.join(os.path.dirname(HERE), "include", "quake_hip.h")]
     if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in deps):
         return OUT
     from torch.utils import cpp_extension

@@ -31,13 +31,45 @@ PYBIND11_MODULE(_bindings, m) {
         .def("ntotal", &QuakeIndex::ntotal)
         .def("nlist", &QuakeIndex::nlist)
         .def("d", &QuakeIndex::d)
+        .def("set_track_hits", &QuakeIndex::set_track_hits, "Record the partitions each query probes, so that maintenance() can act.")
+        .def("validate", &QuakeIndex::validate)
         .def_readonly("parent", &QuakeIndex::parent_)
+        .def_readonly("partition_manager", &QuakeIndex::partition_manager_)
+        .def_readonly("query_coordinator", &QuakeIndex::query_coordinator_)
         .def_readonly("current_level", &QuakeIndex::current_level_)
         .def("__repr__", [](const QuakeIndex &q) {
             std::ostringstream oss;
             oss << "{\"current_level\": " << q.current_level_ << ", }";
             return oss.str();
         });
+
+    // the collaborators the reference's own tests reach into (test/cpp/quake_index.cpp:50-54, query_coordinator.cpp:42,96)
+    py::class_<PartitionManager, std::shared_ptr<PartitionManager>>(m, "PartitionManager")
+        .def("ntotal", &PartitionManager::ntotal)
+        .def("nlist", &PartitionManager::nlist)
+        .def("d", &PartitionManager::d)
+        .def("get_partition_ids", &PartitionManager::get_partition_ids)
+        .def("get_partition_sizes", [](PartitionManager &pm, torch::Tensor pids) { return pm.get_partition_sizes(pids); })
+        .def("get_ids", &PartitionManager::get_ids)
+        .def("validate", &PartitionManager::validate);
+
+    py::class_<QueryCoordinator, std::shared_ptr<QueryCoordinator>>(m, "QueryCoordinator")
+        .def("search", &QueryCoordinator::search)
+        .def("scan_partitions", &QueryCoordinator::scan_partitions)
+        .def("serial_scan", &QueryCoordinator::serial_scan)
+        .def("batched_serial_scan", &QueryCoordinator::batched_serial_scan)
+        .def("worker_scan", &QueryCoordinator::worker_scan);
+
+    // list_scanning.h seam: one query (or a block of queries) against one raw list
+    m.def("batched_scan_list", [](torch::Tensor queries, torch::Tensor list_vecs, torch::Tensor list_ids, int k, std::string metric) {
+        torch::Tensor q = queries.to(torch::kCPU, torch::kFloat32).contiguous(), v = list_vecs.to(torch::kCPU, torch::kFloat32).contiguous();
+        torch::Tensor ids = list_ids.defined() && list_ids.numel() ? list_ids.to(torch::kCPU, torch::kInt64).contiguous() : torch::Tensor();
+        const MetricType mt = (MetricType)str_to_metric_type(metric);
+        auto bufs = create_buffers((int)q.size(0), k, mt == METRIC_INNER_PRODUCT);
+        batched_scan_list(q.data_ptr<float>(), v.data_ptr<float>(), ids.defined() ? ids.data_ptr<int64_t>() : nullptr, (int)q.size(0),
+                          (int)v.size(0), (int)q.size(1), bufs, mt);
+        return buffers_to_tensor(bufs);
+    }, py::arg("queries"), py::arg("list_vecs"), py::arg("list_ids"), py::arg("k"), py::arg("metric") = "l2");
 
     py::class_<IndexBuildParams, std::shared_ptr<IndexBuildParams>>(m, "IndexBuildParams")
         .def(py::init<>())

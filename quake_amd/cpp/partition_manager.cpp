@@ -1,0 +1,391 @@
+// partition_manager.cpp -- see partition_manager.h.  Every data-parallel step goes through the C ABI: assignment of new
+// vectors = the coarse step (qk_coarse), 2-means split = qk_kmeans, refinement = qk_store_refine_lists.
+#include "partition_manager.h"
+
+#include <algorithm>
+#include <chrono>
+#include <climits>
+#include <filesystem>
+#include <fstream>
+#include <stdexcept>
+#include <unordered_set>
+
+#include "quake_index.h"
+
+namespace quake_amd {
+
+namespace {
+using clk = std::chrono::high_resolution_clock;
+inline int us_since(clk::time_point t0) { return (int)std::chrono::duration_cast<std::chrono::microseconds>(clk::now() - t0).count(); }
+}  // namespace
+
+PartitionManager::PartitionManager() = default;
+
+PartitionManager::~PartitionManager() {
+    if (store_) qk_store_destroy(store_);
+    store_ = nullptr;
+}
+
+void PartitionManager::reset_store(int d) {
+    ctx_ = qk_device_context(0);
+    if (store_) qk_store_destroy(store_);
+    store_ = nullptr;
+    qk_check(qk_store_create(ctx_, d, &store_));
+    d_ = d;
+    resident_ids_.clear();
+    core_of_.clear();
+}
+
+void PartitionManager::require_store(const char *who) const {
+    if (!store_) throw std::runtime_error(std::string("[PartitionManager] ") + who + ": partitions are not initialized.");
+}
+
+void PartitionManager::init_partitions(shared_ptr<QuakeIndex> parent, shared_ptr<Clustering> c, bool check_uniques) {
+    // partition_manager.cpp:33-121
+    if (!c) throw std::runtime_error("[PartitionManager] init_partitions: clustering is null.");
+    const int64_t nlist = c->nlist();
+    if (nlist <= 0) throw std::runtime_error("[PartitionManager] init_partitions: nlist is zero.");
+    if (c->partition_ids.size(0) != nlist || (int64_t)c->vector_ids.size() != nlist)
+        throw std::runtime_error("[PartitionManager] init_partitions: partition_ids / vectors / vector_ids disagree.");
+    parent_ = parent;
+    check_uniques_ = check_uniques;
+    reset_store((int)c->dim());
+    Tensor pids = host_i64(c->partition_ids);
+    int64_t max_pid = -1;
+    for (int64_t i = 0; i < nlist; i++) {
+        const int64_t pid = pids[i].item<int64_t>();
+        qk_check(qk_store_add_list(store_, pid));
+        Tensor v = host_f32(c->vectors[(size_t)i]), id = host_i64(c->vector_ids[(size_t)i]).reshape({-1});
+        if (v.size(0) != id.size(0)) throw std::runtime_error("[PartitionManager] init_partitions: vectors and ids disagree.");
+        const int64_t *ip = id.data_ptr<int64_t>();
+        if (check_uniques)
+            for (int64_t j = 0; j < id.size(0); j++)
+                if (!resident_ids_.insert(ip[j]).second)
+                    throw std::runtime_error("[PartitionManager] init_partitions: vector ID already exists in the index.");
+        if (!check_uniques) resident_ids_.insert(ip, ip + id.size(0));
+        if (id.size(0)) qk_check(qk_store_add_entries(store_, pid, id.size(0), ip, v.data_ptr<float>(), QK_MEM_HOST));
+        max_pid = std::max(max_pid, pid);
+    }
+    curr_partition_id_ = max_pid + 1;
+}
+
+void PartitionManager::init_from_csr(shared_ptr<QuakeIndex> parent, const Tensor &offsets, const Tensor &ids, const Tensor &vectors) {
+    parent_ = parent;
+    Tensor off = host_i64(offsets), id = host_i64(ids), v = host_f32(vectors);
+    const int64_t nlist = off.size(0) - 1;
+    reset_store((int)v.size(1));
+    qk_check(qk_store_build_csr(store_, nlist, off.data_ptr<int64_t>(), id.data_ptr<int64_t>(), v.data_ptr<float>(), QK_MEM_HOST));
+    const int64_t *ip = id.data_ptr<int64_t>();
+    resident_ids_.insert(ip, ip + id.size(0));
+    curr_partition_id_ = nlist;
+}
+
+shared_ptr<ModifyTimingInfo> PartitionManager::add(const Tensor &vectors, const Tensor &vector_ids, const Tensor &assignments,
+                                                   bool check_uniques) {  // partition_manager.cpp:123-262
+    require_store("add");
+    auto info = std::make_shared<ModifyTimingInfo>();
+    auto t0 = clk::now();
+    if (!vectors.defined() || !vector_ids.defined()) throw std::runtime_error("[PartitionManager] add: vectors or vector_ids is undefined.");
+    if (vectors.size(0) != vector_ids.size(0)) throw std::runtime_error("[PartitionManager] add: mismatch in vectors.size(0) and vector_ids.size(0).");
+    const int64_t n = vectors.size(0);
+    info->n_vectors = n;
+    if (n == 0) return info;
+    if (vectors.dim() != 2) throw std::runtime_error("[PartitionManager] add: 'vectors' must be 2D [N, dim].");
+    if (vectors.size(1) != d_) throw std::runtime_error("[PartitionManager] add: dimension mismatch.");
+    Tensor xh = host_f32(vectors), idh = host_i64(vector_ids).reshape({-1});
+    const int64_t *ip = idh.data_ptr<int64_t>();
+    for (int64_t i = 0; i < n; i++)
+        if (ip[i] > (int64_t)INT32_MAX) throw std::runtime_error("[PartitionManager] add: vector_ids must be less than INT_MAX.");
+    if (check_uniques) {
+        std::unordered_set<int64_t> uniq(ip, ip + n);
+        if ((int64_t)uniq.size() != n) throw std::runtime_error("[PartitionManager] add: vector_ids must be unique.");
+        for (int64_t i = 0; i < n; i++)
+            if (resident_ids_.count(ip[i])) throw std::runtime_error("[PartitionManager] add: vector ID already exists in the index.");
+    }
+    info->input_validation_time_us = us_since(t0);
+    t0 = clk::now();
+    Tensor assign;
+    if (assignments.defined() && assignments.numel() > 0) {
+        if (assignments.size(0) != n) throw std::runtime_error("[PartitionManager] add: assignments.size(0) != vectors.size(0).");
+        assign = host_i64(assignments).reshape({-1});
+    } else if (parent_) {  // parent_->search(x, {k = 1}) (:219-230) == the coarse step with nprobe 1
+        assign = torch::empty({n}, torch::kInt64);
+        qk_check(qk_coarse(ctx_, parent_->store(), xh.data_ptr<float>(), n, 1, metric_, assign.data_ptr<int64_t>(), nullptr, QK_MEM_HOST));
+    } else {  // flat index: its single partition
+        Tensor only = get_partition_ids();
+        assign = torch::full({n}, only.numel() ? only[0].item<int64_t>() : 0, torch::kInt64);
+    }
+    info->find_partition_time_us = us_since(t0);
+    t0 = clk::now();
+    // per-list append order = input order (:245-258); the ids become resident only once the device step succeeded
+    qk_check(qk_store_add_batch(store_, n, ip, xh.data_ptr<float>(), assign.data_ptr<int64_t>(), QK_MEM_HOST));
+    resident_ids_.insert(ip, ip + n);
+    info->modify_time_us = us_since(t0);
+    return info;
+}
+
+shared_ptr<ModifyTimingInfo> PartitionManager::remove(const Tensor &ids) {  // partition_manager.cpp:264-320
+    require_store("remove");
+    auto info = std::make_shared<ModifyTimingInfo>();
+    info->n_vectors = ids.size(0);
+    if (ids.size(0) == 0) return info;
+    auto t0 = clk::now();
+    Tensor idh = host_i64(ids).reshape({-1});
+    const int64_t *ip = idh.data_ptr<int64_t>();
+    for (int64_t i = 0; i < idh.size(0); i++)
+        if (!resident_ids_.count(ip[i])) throw std::runtime_error("[PartitionManager] remove: vector ID does not exist in the index.");
+    info->input_validation_time_us = us_since(t0);
+    t0 = clk::now();
+    qk_check(qk_store_remove_ids(store_, idh.size(0), ip, nullptr));
+    for (int64_t i = 0; i < idh.size(0); i++) resident_ids_.erase(ip[i]);
+    info->modify_time_us = us_since(t0);
+    return info;
+}
+
+Tensor PartitionManager::get(const Tensor &ids) {
+    require_store("get");
+    Tensor idh = host_i64(ids).reshape({-1});
+    Tensor out = torch::empty({idh.size(0), d_}, torch::kFloat32);
+    for (int64_t i = 0; i < idh.size(0); i++) {
+        int found = 0;
+        qk_check(qk_store_get_vector(store_, idh.data_ptr<int64_t>()[i], out.data_ptr<float>() + i * d_, &found));
+        if (!found) throw std::runtime_error("ID not found in any partition");
+    }
+    return out;
+}
+
+Tensor PartitionManager::get_partition_ids() {
+    require_store("get_partition_ids");
+    int64_t nl = 0;
+    qk_check(qk_store_list_ids(store_, nullptr, &nl));
+    Tensor out = torch::empty({nl}, torch::kInt64);
+    if (nl) qk_check(qk_store_list_ids(store_, out.data_ptr<int64_t>(), &nl));
+    return out;
+}
+
+int64_t PartitionManager::get_partition_size(int64_t partition_id) {
+    require_store("get_partition_size");
+    int64_t sz = 0;
+    qk_check(qk_store_list_size(store_, partition_id, &sz));
+    return sz;
+}
+
+std::vector<int64_t> PartitionManager::get_partition_sizes(std::vector<int64_t> partition_ids) {
+    std::vector<int64_t> out(partition_ids.size());
+    for (size_t i = 0; i < partition_ids.size(); i++) out[i] = get_partition_size(partition_ids[i]);
+    return out;
+}
+
+Tensor PartitionManager::get_partition_sizes(Tensor partition_ids) {
+    if (!partition_ids.defined() || partition_ids.numel() == 0) partition_ids = get_partition_ids();
+    Tensor p = host_i64(partition_ids).reshape({-1});
+    Tensor out = torch::empty({p.size(0)}, torch::kInt64);
+    for (int64_t i = 0; i < p.size(0); i++) out[i] = get_partition_size(p[i].item<int64_t>());
+    return out;
+}
+
+Tensor PartitionManager::get_ids() {
+    require_store("get_ids");
+    Tensor lists = get_partition_ids();
+    Tensor out = torch::empty({qk_store_ntotal(store_)}, torch::kInt64);
+    int64_t pos = 0;
+    for (int64_t i = 0; i < lists.size(0); i++) {
+        const int64_t p = lists[i].item<int64_t>(), sz = get_partition_size(p);
+        if (sz) qk_check(qk_store_get_list(store_, p, nullptr, out.data_ptr<int64_t>() + pos, QK_MEM_HOST));
+        pos += sz;
+    }
+    return out;
+}
+
+shared_ptr<Clustering> PartitionManager::select_partitions(const Tensor &partition_ids, bool /*copy*/) {  // :344-390
+    require_store("select_partitions");
+    Tensor p = host_i64(partition_ids).reshape({-1});
+    auto c = std::make_shared<Clustering>();
+    c->partition_ids = p.clone();
+    c->centroids = parent_ ? parent_->get(p) : torch::empty({p.size(0), d_}, torch::kFloat32);
+    for (int64_t i = 0; i < p.size(0); i++) {
+        const int64_t pid = p[i].item<int64_t>(), sz = get_partition_size(pid);
+        Tensor v = torch::empty({sz, d_}, torch::kFloat32), id = torch::empty({sz}, torch::kInt64);
+        if (sz) qk_check(qk_store_get_list(store_, pid, v.data_ptr<float>(), id.data_ptr<int64_t>(), QK_MEM_HOST));
+        c->vectors.push_back(v);
+        c->vector_ids.push_back(id);
+    }
+    return c;
+}
+
+shared_ptr<Clustering> PartitionManager::split_partitions(const Tensor &partition_ids) {  // :392-444: 2-means per partition
+    require_store("split_partitions");
+    auto sel = select_partitions(partition_ids);
+    auto out = std::make_shared<Clustering>();
+    const int64_t np = sel->nlist();
+    std::vector<Tensor> cents;
+    for (int64_t i = 0; i < np; i++) {
+        Tensor v = sel->vectors[(size_t)i].clone(), id = sel->vector_ids[(size_t)i];
+        const int64_t n = v.size(0);
+        if (n < 8) {  // too small to split: one half keeps everything (:409-413 asserts instead)
+            cents.push_back(sel->centroids[i].unsqueeze(0).repeat({2, 1}));
+            out->vectors.push_back(v);
+            out->vector_ids.push_back(id);
+            out->vectors.push_back(torch::empty({0, d_}, torch::kFloat32));
+            out->vector_ids.push_back(torch::empty({0}, torch::kInt64));
+            continue;
+        }
+        Tensor c2 = torch::empty({2, d_}, torch::kFloat32), a = torch::empty({n}, torch::kInt64);
+        qk_check(qk_kmeans(ctx_, v.data_ptr<float>(), n, d_, 2, metric_, DEFAULT_NITER, 1234ULL, c2.data_ptr<float>(), a.data_ptr<int64_t>(),
+                           QK_MEM_HOST));
+        cents.push_back(c2);
+        for (int64_t h = 0; h < 2; h++) {
+            Tensor rows = torch::nonzero(a == h).reshape({-1});
+            out->vectors.push_back(v.index_select(0, rows).contiguous());
+            out->vector_ids.push_back(id.index_select(0, rows).contiguous());
+        }
+    }
+    out->centroids = np ? torch::cat(cents, 0) : torch::empty({0, d_}, torch::kFloat32);
+    out->partition_ids = torch::arange(2 * np, torch::kInt64);  // placeholders: add_partitions hands out the real ids
+    return out;
+}
+
+void PartitionManager::add_partitions(shared_ptr<Clustering> c) {  // :489-520
+    require_store("add_partitions");
+    if (!parent_) throw std::runtime_error("[PartitionManager] add_partitions: no parent index.");
+    const int64_t n = c->nlist();
+    Tensor new_ids = torch::arange(curr_partition_id_, curr_partition_id_ + n, torch::kInt64);
+    curr_partition_id_ += n;
+    c->partition_ids = new_ids;
+    parent_->add(c->centroids, new_ids);
+    for (int64_t i = 0; i < n; i++) {
+        const int64_t pid = new_ids[i].item<int64_t>();
+        qk_check(qk_store_add_list(store_, pid));
+        Tensor v = host_f32(c->vectors[(size_t)i]), id = host_i64(c->vector_ids[(size_t)i]).reshape({-1});
+        if (id.size(0)) qk_check(qk_store_add_entries(store_, pid, id.size(0), id.data_ptr<int64_t>(), v.data_ptr<float>(), QK_MEM_HOST));
+        const int64_t *ip = id.data_ptr<int64_t>();
+        resident_ids_.insert(ip, ip + id.size(0));
+    }
+}
+
+void PartitionManager::delete_partitions(const Tensor &partition_ids, bool reassign) {  // :522-554
+    require_store("delete_partitions");
+    if (!parent_) throw std::runtime_error("[PartitionManager] delete_partitions: no parent index.");
+    auto sel = select_partitions(partition_ids, true);
+    Tensor p = host_i64(partition_ids).reshape({-1});
+    parent_->remove(p);
+    for (int64_t i = 0; i < p.size(0); i++) {
+        qk_check(qk_store_remove_list(store_, p[i].item<int64_t>()));
+        Tensor id = sel->vector_ids[(size_t)i];
+        for (int64_t j = 0; j < id.size(0); j++) resident_ids_.erase(id[j].item<int64_t>());
+    }
+    if (reassign && sel->ntotal() > 0) {
+        Tensor v = torch::cat(sel->vectors, 0), id = torch::cat(sel->vector_ids, 0);
+        add(v, id);
+    }
+}
+
+void PartitionManager::refine_partitions(Tensor partition_ids, int refinement_iterations) {  // :446-487
+    require_store("refine_partitions");
+    if (!parent_) return;
+    if (!partition_ids.defined() || partition_ids.numel() == 0) partition_ids = get_partition_ids();
+    if (partition_ids.size(0) == 0) return;
+    Tensor pids = host_i64(partition_ids).reshape({-1});
+    Tensor cent = parent_->get(pids);
+    qk_check(qk_store_refine_lists(store_, pids.data_ptr<int64_t>(), pids.size(0), cent.data_ptr<float>(), metric_, refinement_iterations,
+                                   QK_MEM_HOST));
+    parent_->modify(pids, cent);  // :478
+}
+
+void PartitionManager::distribute_partitions(int num_workers) {  // :557-603: partition i -> worker i % num_workers
+    if (num_workers <= 0) return;
+    Tensor p = get_partition_ids();
+    for (int64_t i = 0; i < p.size(0); i++) core_of_[p[i].item<int64_t>()] = (int)(i % num_workers);
+}
+
+void PartitionManager::set_partition_core_id(int64_t partition_id, int core_id) { core_of_[partition_id] = core_id; }
+
+int PartitionManager::get_partition_core_id(int64_t partition_id) {
+    auto it = core_of_.find(partition_id);
+    return it == core_of_.end() ? -1 : it->second;
+}
+
+int64_t PartitionManager::ntotal() const { return store_ ? qk_store_ntotal(store_) : 0; }
+int64_t PartitionManager::nlist() const { return store_ ? qk_store_nlist(store_) : 0; }
+int PartitionManager::d() const { return d_; }
+
+bool PartitionManager::validate() {
+    if (!store_) return false;
+    if ((int64_t)resident_ids_.size() != ntotal()) return false;
+    Tensor ids = get_ids();
+    const int64_t *ip = ids.data_ptr<int64_t>();
+    std::unordered_set<int64_t> seen(ip, ip + ids.size(0));
+    return (int64_t)seen.size() == ids.size(0);
+}
+
+// on-disk format of the reference's "partitions" file (dynamic_inverted_list.cpp:338-520): 32-byte header
+// {magic "LNID", version 3, nlist, code_size, npartitions}, offsets [n+1], partition ids [n], then [codes | ids] chunks
+void PartitionManager::save(const std::string &path) {
+    require_store("save");
+    Tensor lists = get_partition_ids();
+    const int64_t nl = lists.size(0);
+    std::ofstream ofs(path, std::ios::binary);
+    if (!ofs.is_open()) throw std::runtime_error("Could not open file for writing: " + path);
+    const uint32_t magic = 0x44494E4C, version = 3;
+    const uint64_t nlist64 = (uint64_t)nl, code_size = (uint64_t)d_ * 4, nparts = (uint64_t)nl;
+    ofs.write((const char *)&magic, 4);
+    ofs.write((const char *)&version, 4);
+    ofs.write((const char *)&nlist64, 8);
+    ofs.write((const char *)&code_size, 8);
+    ofs.write((const char *)&nparts, 8);
+    std::vector<uint64_t> offsets((size_t)nl + 1, 0);
+    std::vector<int64_t> sizes((size_t)nl, 0);
+    for (int64_t i = 0; i < nl; i++) {
+        sizes[(size_t)i] = get_partition_size(lists[i].item<int64_t>());
+        offsets[(size_t)i + 1] = offsets[(size_t)i] + (uint64_t)sizes[(size_t)i] * (code_size + 8);
+    }
+    ofs.write((const char *)offsets.data(), (std::streamsize)(offsets.size() * 8));
+    for (int64_t i = 0; i < nl; i++) {
+        const uint64_t pid = (uint64_t)lists[i].item<int64_t>();
+        ofs.write((const char *)&pid, 8);
+    }
+    for (int64_t i = 0; i < nl; i++) {  // one partition at a time: the host never holds more than a partition
+        std::vector<float> v((size_t)sizes[(size_t)i] * d_);
+        std::vector<int64_t> id((size_t)sizes[(size_t)i]);
+        if (sizes[(size_t)i]) qk_check(qk_store_get_list(store_, lists[i].item<int64_t>(), v.data(), id.data(), QK_MEM_HOST));
+        ofs.write((const char *)v.data(), (std::streamsize)(v.size() * 4));
+        ofs.write((const char *)id.data(), (std::streamsize)(id.size() * 8));
+    }
+}
+
+void PartitionManager::load(const std::string &path) {
+    std::ifstream ifs(path, std::ios::binary);
+    if (!ifs.is_open()) throw std::runtime_error("Could not open file for reading: " + path);
+    uint32_t magic = 0, version = 0;
+    uint64_t nlist64 = 0, code_size = 0, nparts = 0;
+    ifs.read((char *)&magic, 4);
+    ifs.read((char *)&version, 4);
+    if (magic != 0x44494E4C) throw std::runtime_error("Invalid file format (bad magic number).");
+    if (version != 3) throw std::runtime_error("Unsupported file version: " + std::to_string(version));
+    ifs.read((char *)&nlist64, 8);
+    ifs.read((char *)&code_size, 8);
+    ifs.read((char *)&nparts, 8);
+    std::vector<uint64_t> offsets((size_t)nparts + 1), pids((size_t)nparts);
+    ifs.read((char *)offsets.data(), (std::streamsize)(offsets.size() * 8));
+    ifs.read((char *)pids.data(), (std::streamsize)(pids.size() * 8));
+    const int d = (int)(code_size / 4);
+    reset_store(d);
+    const uint64_t rec = code_size + 8;
+    int64_t max_pid = -1;
+    for (uint64_t i = 0; i < nparts; i++) {
+        const uint64_t chunk = offsets[i + 1] - offsets[i];
+        if (chunk % rec != 0) throw std::runtime_error("Partition chunk size not divisible by (code_size+sizeof(idx_t))");
+        const int64_t nv = (int64_t)(chunk / rec);
+        std::vector<float> v((size_t)nv * d);
+        std::vector<int64_t> id((size_t)nv);
+        ifs.read((char *)v.data(), (std::streamsize)(v.size() * 4));
+        ifs.read((char *)id.data(), (std::streamsize)(id.size() * 8));
+        qk_check(qk_store_add_list(store_, (int64_t)pids[i]));
+        if (nv) qk_check(qk_store_add_entries(store_, (int64_t)pids[i], nv, id.data(), v.data(), QK_MEM_HOST));
+        resident_ids_.insert(id.begin(), id.end());
+        max_pid = std::max<int64_t>(max_pid, (int64_t)pids[i]);
+    }
+    curr_partition_id_ = max_pid + 1;
+}
+
+}  // namespace quake_amd

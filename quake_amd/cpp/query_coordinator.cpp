@@ -1,0 +1,151 @@
+// query_coordinator.cpp -- see query_coordinator.h.  No arithmetic here: tensors are marshalled to the C ABI.
+#include "query_coordinator.h"
+
+#include <chrono>
+#include <cstring>
+#include <stdexcept>
+
+#include "maintenance_policies.h"
+#include "partition_manager.h"
+#include "quake_index.h"
+
+namespace quake_amd {
+
+namespace {
+using clk = std::chrono::high_resolution_clock;
+inline int64_t ns_since(clk::time_point t0) { return std::chrono::duration_cast<std::chrono::nanoseconds>(clk::now() - t0).count(); }
+}  // namespace
+
+QueryCoordinator::QueryCoordinator(shared_ptr<QuakeIndex> parent, shared_ptr<PartitionManager> partition_manager,
+                                   shared_ptr<MaintenancePolicy> maintenance_policy, MetricType metric, int num_workers)
+    : partition_manager_(partition_manager), maintenance_policy_(maintenance_policy), parent_(parent), metric_(metric) {
+    if (num_workers > 0) initialize_workers(num_workers);
+}
+
+QueryCoordinator::~QueryCoordinator() { shutdown_workers(); }
+
+void QueryCoordinator::initialize_workers(int num_workers) {  // query_coordinator.cpp:50-74
+    if (workers_initialized_) return;
+    num_workers_ = num_workers;
+    workers_initialized_ = num_workers > 0;
+    if (partition_manager_ && workers_initialized_) partition_manager_->distribute_partitions(num_workers);
+}
+
+void QueryCoordinator::shutdown_workers() {  // :77-95
+    workers_initialized_ = false;
+}
+
+shared_ptr<SearchResult> QueryCoordinator::empty_result(shared_ptr<SearchParams> sp) const {  // :251-257, 476-482
+    auto res = std::make_shared<SearchResult>();
+    res->ids = torch::empty({0}, torch::kInt64);
+    res->distances = torch::empty({0}, torch::kFloat32);
+    res->timing_info = std::make_shared<SearchTimingInfo>();
+    res->timing_info->search_params = sp;
+    return res;
+}
+
+shared_ptr<SearchResult> QueryCoordinator::search(Tensor x, shared_ptr<SearchParams> sp) {  // :612-657
+    if (!partition_manager_) throw std::runtime_error("[QueryCoordinator::search] partition_manager_ is null.");
+    if (!x.defined() || x.size(0) == 0) return empty_result(sp);
+    auto t0 = clk::now();
+    qk_ctx *ctx = partition_manager_->ctx();
+    qk_store *store = partition_manager_->store();
+    if (!store) throw std::runtime_error("[QueryCoordinator::search] partitions are not initialized.");
+    const bool on_dev = x.is_cuda();
+    Tensor xq = on_dev ? x.to(torch::kFloat32).contiguous() : host_f32(x);
+    // the library runs on its own stream: device inputs must be complete before it starts (the calls below hand back a
+    // drained stream, so the outputs are ready for torch's stream)
+    if (on_dev) torch::cuda::synchronize(xq.device().index());
+    const int64_t Q = xq.size(0);
+    const int k = sp->k > 0 ? sp->k : 1;  // :490
+    const int nprobe = std::max(sp->nprobe, 1);
+    auto res = std::make_shared<SearchResult>();
+    auto ti = res->timing_info = std::make_shared<SearchTimingInfo>();
+    ti->search_params = sp;
+    ti->n_queries = Q;
+    ti->n_clusters = partition_manager_->nlist();
+    res->ids = torch::empty({Q, k}, torch::TensorOptions().dtype(torch::kInt64).device(xq.device()));
+    res->distances = torch::empty({Q, k}, torch::TensorOptions().dtype(torch::kFloat32).device(xq.device()));
+    qk_timing tm;
+    std::memset(&tm, 0, sizeof(tm));
+    const int mem = on_dev ? QK_MEM_DEVICE : QK_MEM_HOST;
+    const bool track = maintenance_policy_ && maintenance_policy_->track_hits_ && parent_;
+    if (sp->recall_target > 0.0f && parent_ && !sp->batched_scan) {
+        // adaptive partition scanning (:502,637-641): candidates = nlist * initial_search_fraction
+        Tensor nscan = torch::empty({Q}, torch::TensorOptions().dtype(torch::kInt32).device(xq.device()));
+        qk_check(qk_search_aps(ctx, parent_->store(), store, xq.data_ptr<float>(), Q, k, (int)metric_, sp->recall_target,
+                               sp->recompute_threshold, sp->use_precomputed ? 1 : 0, sp->initial_search_fraction,
+                               res->ids.data_ptr<int64_t>(), res->distances.data_ptr<float>(), nscan.data_ptr<int32_t>(), mem, &tm));
+        ti->partitions_scanned = (int)nscan.sum().item<int64_t>();
+        ti->job_wait_time_ns = (int64_t)(tm.total_ms * 1e6);
+    } else if (track) {
+        // hit tracking on: the probe list is needed on the host, so the coarse step and the scan are two calls
+        const int kk = (int)std::min<int64_t>(nprobe, parent_->ntotal());
+        Tensor pids = torch::empty({Q, kk}, torch::TensorOptions().dtype(torch::kInt64).device(xq.device()));
+        qk_check(qk_coarse(ctx, parent_->store(), xq.data_ptr<float>(), Q, nprobe, (int)metric_, pids.data_ptr<int64_t>(), nullptr, mem));
+        qk_check(qk_scan(ctx, store, xq.data_ptr<float>(), Q, pids.data_ptr<int64_t>(), kk, k, (int)metric_, res->ids.data_ptr<int64_t>(),
+                         res->distances.data_ptr<float>(), mem, &tm));
+        maintenance_policy_->record_query_batch(host_i64(pids));
+        ti->partitions_scanned = (int)tm.partitions_scanned;
+    } else {
+        qk_check(qk_ctx_set_timing(ctx, 1));
+        const int st = qk_search(ctx, parent_ ? parent_->store() : nullptr, store, xq.data_ptr<float>(), Q, nprobe, k, (int)metric_,
+                                 res->ids.data_ptr<int64_t>(), res->distances.data_ptr<float>(), mem, &tm);
+        qk_ctx_set_timing(ctx, 0);
+        qk_check(st);
+        ti->partitions_scanned = (int)tm.partitions_scanned;
+        ti->job_enqueue_time_ns = (int64_t)(tm.group_ms * 1e6);
+        ti->job_wait_time_ns = (int64_t)(tm.scan_ms * 1e6);
+        ti->result_aggregate_time_ns = (int64_t)(tm.merge_ms * 1e6);
+    }
+    if (parent_) {
+        ti->parent_info = std::make_shared<SearchTimingInfo>();
+        ti->parent_info->n_queries = Q;
+        ti->parent_info->n_clusters = 1;
+        ti->parent_info->total_time_ns = (int64_t)(tm.coarse_ms * 1e6);
+    }
+    ti->total_time_ns = ns_since(t0);
+    return res;
+}
+
+shared_ptr<SearchResult> QueryCoordinator::scan_partitions(Tensor x, Tensor partition_ids, shared_ptr<SearchParams> sp) {  // :659-673
+    if (!partition_manager_) throw std::runtime_error("[QueryCoordinator::scan_partitions] partition_manager_ is null.");
+    if (!x.defined() || x.size(0) == 0) return empty_result(sp);
+    auto t0 = clk::now();
+    qk_store *store = partition_manager_->store();
+    if (!store) throw std::runtime_error("[QueryCoordinator::scan_partitions] partitions are not initialized.");
+    Tensor xq = host_f32(x);
+    const int64_t Q = xq.size(0);
+    const int k = sp->k > 0 ? sp->k : 1;
+    Tensor pids = host_i64(partition_ids);
+    if (pids.dim() == 1) pids = pids.unsqueeze(0).expand({Q, pids.size(0)}).contiguous();  // the same set for every query (:506-508)
+    const int P = (int)pids.size(1);
+    auto res = std::make_shared<SearchResult>();
+    auto ti = res->timing_info = std::make_shared<SearchTimingInfo>();
+    ti->search_params = sp;
+    ti->n_queries = Q;
+    ti->n_clusters = partition_manager_->nlist();
+    res->ids = torch::empty({Q, k}, torch::kInt64);
+    res->distances = torch::empty({Q, k}, torch::kFloat32);
+    qk_timing tm;
+    std::memset(&tm, 0, sizeof(tm));
+    Tensor none = torch::full({Q, 1}, -1, torch::kInt64);  // zero partitions: padded output (:459-497)
+    const Tensor &pp = P > 0 ? pids : none;
+    qk_check(qk_scan(partition_manager_->ctx(), store, xq.data_ptr<float>(), Q, pp.data_ptr<int64_t>(), (int)pp.size(1), k, (int)metric_,
+                     res->ids.data_ptr<int64_t>(), res->distances.data_ptr<float>(), QK_MEM_HOST, &tm));
+    ti->partitions_scanned = (int)tm.partitions_scanned;
+    ti->total_time_ns = ns_since(t0);
+    return res;
+}
+
+shared_ptr<SearchResult> QueryCoordinator::serial_scan(Tensor x, Tensor partition_ids, shared_ptr<SearchParams> sp) {
+    return scan_partitions(x, partition_ids, sp);
+}
+shared_ptr<SearchResult> QueryCoordinator::batched_serial_scan(Tensor x, Tensor partition_ids, shared_ptr<SearchParams> sp) {
+    return scan_partitions(x, partition_ids, sp);
+}
+shared_ptr<SearchResult> QueryCoordinator::worker_scan(Tensor x, Tensor partition_ids, shared_ptr<SearchParams> sp) {
+    return scan_partitions(x, partition_ids, sp);
+}
+
+}  // namespace quake_amd

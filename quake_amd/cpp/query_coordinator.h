@@ -1,0 +1,42 @@
+// query_coordinator.h -- QueryCoordinator of the C++ host mirror: the public surface of the reference's
+// src/cpp/include/query_coordinator.h:45-179.  search() = parent search for the nprobe nearest partitions, then
+// scan_partitions(); on the device the three scan variants of the reference (serial_scan, batched_serial_scan, worker_scan:
+// three ways of spreading the same work over CPU threads) are ONE pipeline -- qk_search / qk_scan of libquake_hip.so -- and
+// return the same result, so all three names enqueue it.  "Workers" are a CPU notion: initialize_workers() only records the
+// count (the multi-GPU analogue is quake_amd/sharded.py).
+#pragma once
+#include "common.h"
+
+namespace quake_amd {
+
+class QuakeIndex;
+class PartitionManager;
+class MaintenancePolicy;
+
+class QueryCoordinator {
+public:
+    shared_ptr<PartitionManager> partition_manager_;
+    shared_ptr<MaintenancePolicy> maintenance_policy_;
+    shared_ptr<QuakeIndex> parent_;
+    MetricType metric_;
+    bool workers_initialized_ = false;
+    int num_workers_ = 0;
+    bool debug_ = false;
+
+    QueryCoordinator(shared_ptr<QuakeIndex> parent, shared_ptr<PartitionManager> partition_manager,
+                     shared_ptr<MaintenancePolicy> maintenance_policy, MetricType metric, int num_workers = 0);
+    ~QueryCoordinator();
+
+    shared_ptr<SearchResult> search(Tensor x, shared_ptr<SearchParams> search_params);
+    shared_ptr<SearchResult> scan_partitions(Tensor x, Tensor partition_ids, shared_ptr<SearchParams> search_params);
+    shared_ptr<SearchResult> serial_scan(Tensor x, Tensor partition_ids, shared_ptr<SearchParams> search_params);
+    shared_ptr<SearchResult> batched_serial_scan(Tensor x, Tensor partition_ids, shared_ptr<SearchParams> search_params);
+    shared_ptr<SearchResult> worker_scan(Tensor x, Tensor partition_ids, shared_ptr<SearchParams> search_params);
+    void initialize_workers(int num_workers);
+    void shutdown_workers();
+
+private:
+    shared_ptr<SearchResult> empty_result(shared_ptr<SearchParams> sp) const;
+};
+
+}  // namespace quake_amd

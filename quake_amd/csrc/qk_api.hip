@@ -94,6 +94,28 @@ int run_search(qk_ctx *ctx, qk_store *parent, qk_store *s, const float *x, int64
             sv.pids = pids;
         }
     }
+    // small batches: the whole search in one launch (qk_small.hip) -- no prep / group / seed / merge launches
+    if (use_parent && !coarse_only && kk > 0 && qk_small_supported(ctx, parent, s, Q, kk, k)) {
+        const bool tm = ctx->timing && timing;
+        if (tm) QK_HIP(hipEventRecord(ctx->ev[4], ctx->stream));
+        QK_TRY(qk_search_small_device(ctx, parent, s, sv.x, Q, kk, k, metric, sv.out_ids, sv.out_dist, !ctx->squared_l2));
+        if (tm) QK_HIP(hipEventRecord(ctx->ev[7], ctx->stream));
+        if (mem == QK_MEM_HOST) {
+            if (out_ids) QK_HIP(hipMemcpyAsync(out_ids, sv.out_ids, (size_t)Q * kout * 8, hipMemcpyDeviceToHost, ctx->stream));
+            if (out_dist) QK_HIP(hipMemcpyAsync(out_dist, sv.out_dist, (size_t)Q * kout * 4, hipMemcpyDeviceToHost, ctx->stream));
+            QK_HIP(hipStreamSynchronize(ctx->stream));
+        }
+        if (timing) {  // one kernel: everything is "scan"; the pair / byte counters are not collected on this path
+            QK_HIP(hipStreamSynchronize(ctx->stream));
+            timing->partitions_scanned = Q * (int64_t)kk;
+            if (tm) {
+                float ms = 0.f;
+                QK_HIP(hipEventElapsedTime(&ms, ctx->ev[4], ctx->ev[7]));
+                timing->scan_ms = timing->total_ms = ms;
+            }
+        }
+        return QK_OK;
+    }
     const float4 *xq4 = nullptr;
     const float *xn = nullptr;
     QK_TRY(qk_prep_queries(ctx, sv.x, Q, d, &xq4, &xn));

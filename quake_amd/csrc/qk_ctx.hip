@@ -43,9 +43,11 @@ int qk_ctx_destroy(qk_ctx *c) {
     if (c->stage) hipFree(c->stage);
     if (c->qprep) hipFree(c->qprep);
     if (c->aps) hipFree(c->aps);
+    if (c->small_ws) hipFree(c->small_ws);
     if (c->pinned) hipHostFree(c->pinned);
     if (c->xcd_host) hipHostFree(c->xcd_host);
     if (c->xcd_ev) hipEventDestroy(c->xcd_ev);
+    if (c->stream_ev) hipEventDestroy(c->stream_ev);
     for (auto &e : c->ev)
         if (e) hipEventDestroy(e);
     for (auto e : c->ev_free) hipEventDestroy(e);
@@ -56,16 +58,27 @@ int qk_ctx_destroy(qk_ctx *c) {
     return QK_OK;
 }
 
+// The context's scratch (workspace, staging, query-prep and pinned buffers) is reused by every call.  When the stream
+// changes, work enqueued on the old stream may still be using it: the new stream waits for the old one (an event, no host
+// synchronisation), so two searches issued back to back on different streams cannot overwrite each other's scratch.
+static int switch_stream(qk_ctx *c, hipStream_t next) {
+    if (next == c->stream) return QK_OK;
+    QK_HIP(hipSetDevice(c->device));
+    if (!c->stream_ev) QK_HIP(hipEventCreateWithFlags(&c->stream_ev, hipEventDisableTiming));
+    QK_HIP(hipEventRecord(c->stream_ev, c->stream));
+    QK_HIP(hipStreamWaitEvent(next, c->stream_ev, 0));
+    c->stream = next;
+    return QK_OK;
+}
+
 int qk_ctx_set_stream(qk_ctx *c, void *hip_stream) {
     if (!c) QK_FAIL(QK_ERR_INVALID, "qk_ctx_set_stream: ctx is null");
-    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
-    return QK_OK;
+    return switch_stream(c, hip_stream ? (hipStream_t)hip_stream : c->own_stream);
 }
 
 int qk_ctx_set_null_stream(qk_ctx *c) {
     if (!c) QK_FAIL(QK_ERR_INVALID, "qk_ctx_set_null_stream: ctx is null");
-    c->stream = nullptr;  // hipStream_t 0: ordered with every blocking stream of the device
-    return QK_OK;
+    return switch_stream(c, nullptr);  // hipStream_t 0: ordered with every blocking stream of the device
 }
 
 int qk_ctx_synchronize(qk_ctx *c) {

@@ -9,7 +9,8 @@
 //   k_select_rows<MAXCH> one wave per query: threshold-filter + rank-compaction top-k over its key row -> L2/HBM-bound
 #include "qk_internal.h"
 
-#include <hipcub/hipcub.hpp>
+#include <cstring>
+#include <rocprim/device/device_scan.hpp>  // exclusive_scan: AMD's own device primitives (no CUB compatibility layer)
 #include "qk_device.h"
 
 #include <algorithm>
@@ -693,7 +694,7 @@ int qk_dense_device(qk_ctx *ctx, qk_store *s, int64_t list_no, const qk_scan_arg
     while (NQ > 1 && (size_t)NQ * nblk * 1024 > 64 * 1024) NQ >>= 1;
     const size_t lds = (size_t)NQ * nblk * 1024 + (size_t)NQ * 16 * 4 + 64;
     if (lds > 160 * 1024) QK_FAIL(QK_ERR_UNSUPPORTED, "dense scan: d=%d too large for the LDS query tile", s->d);
-    if (k == 1 && nrows > 0 && s->max_id_seen < ((int64_t)1 << 32) && s->min_id_seen >= 0 && !getenv("QK_NO_ARGMIN")) {
+    if (k == 1 && nrows > 0 && s->max_id_seen < ((int64_t)1 << 32) && s->min_id_seen >= 0 && !qk_env_set("QK_NO_ARGMIN")) {
         // nprobe = 1 / nearest centroid: fused argmin, no key matrix
         const size_t lds_a = lds + (size_t)4 * NQ * 16 * 8;
         QK_TRY(qk_ws_reserve(ctx, (size_t)Q * 8 + 4096));
@@ -887,7 +888,7 @@ int qk_widek_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *
         const int64_t nq = std::min(qc, Q - q0);
         const int64_t npairs = nq * P;
         size_t cub_bytes = 0;
-        hipcub::DeviceScan::ExclusiveSum(nullptr, cub_bytes, (int64_t *)nullptr, (int64_t *)nullptr, (int)(npairs + 1), st);
+        (void)rocprim::exclusive_scan(nullptr, cub_bytes, (int64_t *)nullptr, (int64_t *)nullptr, (int64_t)0, (size_t)(npairs + 1), rocprim::plus<int64_t>(), st);
         auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
         const size_t o_sizes = 0, o_base = al((size_t)(npairs + 1) * 8), o_cub = o_base + al((size_t)(npairs + 1) * 8);
         const size_t o_keys = o_cub + al(cub_bytes);
@@ -898,7 +899,7 @@ int qk_widek_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *
         uint32_t *keys = (uint32_t *)(B + o_keys);
         const int64_t *pids = a.pids ? a.pids + q0 * P : nullptr;
         hipLaunchKernelGGL(k_pair_sizes, dim3((unsigned)((npairs + 256) / 256)), dim3(256), 0, st, pids, npairs, P, s->d_size, npids, sizes);
-        QK_HIP(hipcub::DeviceScan::ExclusiveSum((void *)(B + o_cub), cub_bytes, sizes, pair_base, (int)(npairs + 1), st));
+        QK_HIP(rocprim::exclusive_scan((void *)(B + o_cub), cub_bytes, sizes, pair_base, (int64_t)0, (size_t)(npairs + 1), rocprim::plus<int64_t>(), st));
         if (q0 == 0) QK_TRY(pe.mark(1));
         qk_scan_args e = a;
         e.x = a.x + q0 * s->d;

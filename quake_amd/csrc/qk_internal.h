@@ -32,6 +32,23 @@ void qk_set_error(const char *fmt, ...);
         return (code);            \
     } while (0)
 
+// ---- probe switches -------------------------------------------------------------------------------------------------------
+// The product library has no environment switches: every QK_* knob the kernels were tuned with is a compile-time constant
+// (its measured default).  A probe build (`QK_BUILD_PROBES=1 python -m quake_amd.build --force`, -DQK_PROBES) turns them
+// back into environment lookups -- each read ONCE per process -- and compiles the wave-clock / merge-clock printouts in;
+// scripts/ and the gpu_*.sh sweeps need that build.
+#ifdef QK_PROBES
+#include <cstdlib>
+static inline int qk_env_int(const char *name, int dflt) {
+    const char *e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+static inline bool qk_env_set(const char *name) { return getenv(name) != nullptr; }
+#else
+static inline constexpr int qk_env_int(const char *, int dflt) { return dflt; }
+static inline constexpr bool qk_env_set(const char *) { return false; }
+#endif
+
 // ---- geometry of the tile-major arena ----------------------------------
 // A "tile" is 16 rows.  Within a tile the d dimension is cut into 16-column blocks; block c of a tile is
 // 64 float4 stored in LANE ORDER of v_mfma_f32_16x16x4_f32's A operand:
@@ -51,6 +68,7 @@ struct qk_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
+    hipEvent_t stream_ev = nullptr;  // orders a newly bound stream behind the previous one (qk_ctx_set_stream)
     bool timing = false;
     hipDeviceProp_t prop{};
     // bump-allocated scratch, reset at the start of every API call
@@ -76,6 +94,7 @@ struct qk_ctx {
     std::vector<hipEvent_t> ev_pending;  // groups of 4: group start, scan start, scan end, merge end
     std::vector<hipEvent_t> ev_pending_coarse;  // groups of 2: coarse start, coarse end
     bool squared_l2 = false;  // L2 entry points return squared distances (sharded path, before the final merge)
+    char *small_ws = nullptr;  // records + tickets of the one-launch small-batch search (qk_small.hip); tickets stay zero between calls
     // state of an adaptive (recall-target) search: survives the scan calls of its rounds, which recycle `ws`
     char *aps = nullptr;
     size_t aps_cap = 0;
@@ -185,11 +204,15 @@ int qk_prep_queries(qk_ctx *ctx, const float *x, int64_t Q, int d, const float4 
 int qk_merge_topk_device(qk_ctx *ctx, const int64_t *in_ids, const float *in_key, int G, int64_t Q, int k, int metric,
                          int64_t *out_ids, float *out_dist, bool sqrt_l2);
 int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *timing, int ev_base);
+// one-launch search of a small batch (qk_small.hip)
+bool qk_small_supported(qk_ctx *ctx, qk_store *parent, qk_store *s, int64_t Q, int nprobe, int k);
+int qk_search_small_device(qk_ctx *ctx, qk_store *parent, qk_store *s, const float *x, int64_t Q, int nprobe, int k, int metric,
+                           int64_t *out_ids, float *out_dist, bool sqrt_l2);
 // dense form (every query x one list, Q large): distance matrix on MFMA + per-query select.  qk_dense.hip
 int qk_dense_device(qk_ctx *ctx, qk_store *s, int64_t list_no, const qk_scan_args &a, qk_timing *timing, int ev_base);
 // k > QK_MAX_K over several lists: emit every key (qk_scan_device in emission mode), then exact selection per query.  qk_dense.hip
 int qk_widek_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *timing, int ev_base);
-constexpr int QK_MAX_WIDE_K = 4096;
+constexpr int QK_MAX_WIDE_K = 8192;  // = the reference's TOP_K_BUFFER_CAPACITY (list_scanning.h:39)
 
 // phase events of one pipeline run: per-call mode (ctx->ev[ev_base..]) and/or deferred mode (parked in the ctx)
 struct qk_phase_events {

@@ -10,7 +10,8 @@
 // PARITY UNPINNED vs FAISS (RNG / init), pinned vs oracle/quake_oracle.c (qo_kmeans*).
 #include "qk_internal.h"
 
-#include <hipcub/hipcub.hpp>
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>  // radix_sort_pairs: AMD's own device primitives (no CUB compatibility layer)
 
 #include <algorithm>
 #include <cmath>
@@ -373,7 +374,7 @@ static int accum_prepare(KmScratch &ks, AccumScratch &as, int64_t n, int64_t m) 
     QK_TRY(ks.alloc(&as.vals2, (size_t)n));
     QK_TRY(ks.alloc(&as.seg, (size_t)m + 2));
     size_t bytes = 0;
-    hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, as.keys, as.keys2, as.vals, as.vals2, (int)n);
+    (void)rocprim::radix_sort_pairs(nullptr, bytes, as.keys, as.keys2, as.vals, as.vals2, (size_t)n);
     char *t = nullptr;
     QK_TRY(ks.alloc(&t, bytes + 256));
     as.tmp = t;
@@ -390,7 +391,7 @@ static int accumulate_device(qk_ctx *ctx, AccumScratch &as, const float *x, int6
         int bits = 1;
         while ((1LL << bits) <= m) bits++;
         size_t bytes = as.tmp_bytes;
-        QK_HIP(hipcub::DeviceRadixSort::SortPairs(as.tmp, bytes, as.keys, as.keys2, as.vals, as.vals2, (int)n, 0, bits, st));
+        QK_HIP(rocprim::radix_sort_pairs(as.tmp, bytes, as.keys, as.keys2, as.vals, as.vals2, (size_t)n, 0u, (unsigned)bits, st));  // stable
     }
     hipLaunchKernelGGL(k_segment_bounds, dim3(km_grid(n + 1, 256)), dim3(256), 0, st, as.keys2, n, (int)m, as.seg);
     hipLaunchKernelGGL(k_accumulate, dim3((unsigned)m), dim3(256), 0, st, x, d, as.vals2, as.seg, sums, counts);

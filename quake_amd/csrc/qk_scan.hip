@@ -1529,7 +1529,7 @@ static int launch_scan(int db, int maxch, dim3 grid, dim3 block, size_t lds, hip
 #undef QK_CASEQ
         QK_FAIL(QK_ERR_UNSUPPORTED, "no query-sharing scan kernel for DB=%d MAXCH=%d", db, maxch);
     }
-    static const int probe_mode = getenv("QK_SCAN_MODE") ? atoi(getenv("QK_SCAN_MODE")) : 0;
+    static const int probe_mode = qk_env_int("QK_SCAN_MODE", 0);
     if (probe_mode == 1 && db == 8 && maxch == 1) {
         QK_HIP(hipFuncSetAttribute((const void *)k_scan<8, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL((k_scan<8, 1, 1>), grid, block, lds, st, sp);
@@ -1569,7 +1569,7 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
     const int npids = (int)s->parts.size();
     // dense form: every query against ONE list (the parent / flat index of query_coordinator.cpp:624-626,644)
     // (any batch size: for one query the key-matrix path is 3 launches against 6 of the grouped scan -- 133 -> 95 us per search)
-    static const int dense_min_q = getenv("QK_DENSE_MIN_Q") ? atoi(getenv("QK_DENSE_MIN_Q")) : 1;
+    static const int dense_min_q = qk_env_int("QK_DENSE_MIN_Q", 1);
     if (one_list && (Q >= dense_min_q || k > QK_MAX_K)) {
         for (int64_t p = 0; p < npids; p++)
             if (s->parts[p].present) return qk_dense_device(ctx, s, p, a, timing, ev_base);
@@ -1590,7 +1590,7 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
     // pool capacity per query: k + slack, limited by LDS (one wave per workgroup, 160 KiB max)
     const size_t lds_budget = 160 * 1024 - 64;
     const size_t q_bytes = (size_t)nblk * 1024;
-    static const int slack_min = getenv("QK_SCAN_SLACK") ? std::max(4, atoi(getenv("QK_SCAN_SLACK"))) : 28;
+    static const int slack_min = std::max(4, qk_env_int("QK_SCAN_SLACK", 28));
     int C = qk_round_up(k + std::max(slack_min, std::min(k, 64)), 4);
     while ((size_t)16 * C * 12 + q_bytes > lds_budget && C > k + 4) C -= 4;
     if ((size_t)16 * C * 12 + q_bytes > lds_budget || C < k + 4 || C > 512)
@@ -1614,8 +1614,8 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
                     if (waves_for(w, Cs) > best) { best = waves_for(w, Cs); nw = w; C = Cs; }
             }
         }
-        if (const char *e = getenv("QK_SCAN_NW")) {
-            const int w = atoi(e);
+        {
+            static const int w = qk_env_int("QK_SCAN_NW", 0);
             if ((w == 1 || w == 2 || w == 4) && waves_for(w, C) > 0) nw = w;
         }
     }
@@ -1625,14 +1625,14 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
     int qshare = 0;
     {
         // measured (bench.py --nprobe 8 / 32, 1024 queries, 4096 lists): 0.589 -> 0.551 ms and 1.394 -> 1.109 ms
-        static const int qs_min = getenv("QK_SCAN_QSHARE_MIN") ? atoi(getenv("QK_SCAN_QSHARE_MIN")) : 2;
+        static const int qs_min = qk_env_int("QK_SCAN_QSHARE_MIN", 2);
         const int64_t present = std::max<int64_t>(1, std::min<int64_t>(s->nlist, std::max<int64_t>(npairs, 1)));
         const int64_t per_list = npairs / present;
         const size_t per_wave = q_bytes + (size_t)16 * C * 12;
         if (nw == 1 && !a.per_pair && !emit && qs_min > 0 && per_list >= qs_min && have_scan_qs(DB, pick_maxch(C))) {
             // 2 waves per workgroup for moderately hot batches, 4 from ~6 queries per list on (measured: nprobe 8 -> 0.524 vs
             // 0.534 ms with 2 vs 4; nprobe 32 -> 1.199 vs 1.073 ms)
-            static const int w_env = getenv("QK_SCAN_QSHARE_NW") ? atoi(getenv("QK_SCAN_QSHARE_NW")) : 0;
+            static const int w_env = qk_env_int("QK_SCAN_QSHARE_NW", 0);
             const int w_want = w_env ? w_env : (per_list >= 6 ? 4 : 2);
             const int w = (w_want >= 4 && 4 * per_wave + 512 <= 160 * 1024) ? 4 : 2 * per_wave + 512 <= 160 * 1024 ? 2 : 1;
             if (w > 1) {
@@ -1645,20 +1645,28 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
     // whole prepared batch.  The matrix work follows the live queries in steps of 4 and a pass over a partition serves up to
     // 32 queries from one read of its rows -- the regime where several queries of the batch probe the same partition.
     bool use_rl = false;
-    RlCost rlc{12, 6, 2, 24};
+    int64_t rl_per_list = 0;
+    RlCost rlc{12, 8, 1, 16, 4};
     {
-        static const int rl_env = getenv("QK_SCAN_RL") ? atoi(getenv("QK_SCAN_RL")) : -1;  // -1 auto, 0 never, 1 whenever supported
-        static const int rl_min = getenv("QK_SCAN_RL_MIN") ? atoi(getenv("QK_SCAN_RL_MIN")) : 2;
-        static const int rl_h0 = getenv("QK_SCAN_RL_H0") ? atoi(getenv("QK_SCAN_RL_H0")) : 12;
-        static const int rl_h1 = getenv("QK_SCAN_RL_H1") ? atoi(getenv("QK_SCAN_RL_H1")) : 6;
-        static const int rl_e = getenv("QK_SCAN_RL_E") ? atoi(getenv("QK_SCAN_RL_E")) : 2;
-        static const int rl_ovh = getenv("QK_SCAN_RL_OVH") ? atoi(getenv("QK_SCAN_RL_OVH")) : 24;
-        rlc = RlCost{std::max(1, rl_h0), std::max(1, rl_h1), std::max(0, rl_e), std::max(0, rl_ovh)};
+        // Measured (10M x 128, 1024 queries, k = 10; k_scan ms old form -> this form): nprobe 1: 0.252 -> 0.246, 2: 0.324 -> 0.313,
+        // 4: 0.404 -> 0.362, 8: 0.488 -> 0.439, 16: 0.694 -> 0.616, 32: 0.958 -> 1.02 (MFMA-bound: 5 us of chain per chunk);
+        // low-intrinsic-dimension corpus, nprobe 16: 0.862 -> 0.778 (0.80 of the HBM peak).  So: whenever supported, except
+        // when the batch averages rl_max or more probing queries per list -- and except nprobe = 1, where the dynamic tail's
+        // extra range boundaries cost the merge more (2211 -> 5840 records, 10 -> 23 us) than the scan gains (252 -> 247 us).
+        static const int rl_env = qk_env_int("QK_SCAN_RL", -1);  // -1 auto, 0 never, 1 whenever supported
+        static const int rl_max = qk_env_int("QK_SCAN_RL_MAX", 6);
+        static const int rl_h0 = qk_env_int("QK_SCAN_RL_H0", 12);
+        static const int rl_h1 = qk_env_int("QK_SCAN_RL_H1", 8);
+        static const int rl_e = qk_env_int("QK_SCAN_RL_E", 1);
+        static const int rl_ovh = qk_env_int("QK_SCAN_RL_OVH", 16);
+        static const int rl_m = qk_env_int("QK_SCAN_RL_M", 4);
+        rlc = RlCost{std::max(1, rl_h0), std::max(1, rl_h1), std::max(0, rl_e), std::max(0, rl_ovh), std::max(1, rl_m)};
         const int64_t present = std::max<int64_t>(1, std::min<int64_t>(s->nlist, std::max<int64_t>(npairs, 1)));
         const int64_t per_list = npairs / present;
         const bool rl_ok = nblk <= 8 && k <= 32 && !a.per_pair && !emit && npairs > 0 && ctx->qprep_xp4 != nullptr &&
                            a.xq4 == (const float4 *)ctx->qprep;
-        use_rl = rl_ok && (rl_env == 1 || (rl_env < 0 && per_list >= rl_min));
+        use_rl = rl_ok && (rl_env == 1 || (rl_env < 0 && per_list < rl_max && P > 1));
+        rl_per_list = per_list;
         if (use_rl) {
             nw = 1;
             qshare = 0;
@@ -1687,13 +1695,14 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
         tiles_est = std::max<int64_t>(1, npairs / 16 + std::min<int64_t>(npresent_e, npairs)) * mean_tiles;
         if (nw == 1 && waves_per_cu > 4 && tiles_est < (int64_t)8 * num_cus * 160) waves_per_cu = 4;
     }
-    if (const char *e = getenv("QK_SCAN_WAVES_PER_CU")) {  // probe override, read per call so one process can sweep it
-        if (atoi(e) > 0) waves_per_cu = std::max(nw, atoi(e) / nw * nw);
+    {
+        static const int wpc = qk_env_int("QK_SCAN_WAVES_PER_CU", 0);  // probe override
+        if (wpc > 0) waves_per_cu = std::max(nw, wpc / nw * nw);
     }
     if (use_rl) waves_per_cu = 4;  // one wave per SIMD: 256+ registers of row data per wave
     // wide rows (d >= 256: the LDS query tile leaves room for <= 4 waves per CU): 16 blocks = 16 KB per load step, so
     // that the few resident waves still keep enough bytes in flight to cover the HBM latency
-    if (nblk % 16 == 0 && waves_per_cu <= 4 && !qshare && !use_rl && !getenv("QK_SCAN_NO_DB16")) DB = 16;
+    if (nblk % 16 == 0 && waves_per_cu <= 4 && !qshare && !use_rl && !qk_env_set("QK_SCAN_NO_DB16")) DB = 16;
     const int wgs_per_cu = waves_per_cu / nw;
     const int64_t n_wgs = (int64_t)num_cus * wgs_per_cu;
     const int64_t n_waves = n_wgs * nw;
@@ -1704,8 +1713,8 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
     // ... plus one segment start per dynamic chunk (k_scan's dynamic tail, nw == 1)
     int64_t dyn_ranges = 0;
     {
-        const int pct = getenv("QK_SCAN_DYN_PCT") ? atoi(getenv("QK_SCAN_DYN_PCT")) : QK_DYN_PCT_DEFAULT;
-        const int chunk = std::max(1, getenv("QK_SCAN_DYN_CHUNK") ? atoi(getenv("QK_SCAN_DYN_CHUNK")) : QK_DYN_CHUNK_DEFAULT);
+        static const int pct = qk_env_int("QK_SCAN_DYN_PCT", QK_DYN_PCT_DEFAULT);
+        static const int chunk = std::max(1, qk_env_int("QK_SCAN_DYN_CHUNK", QK_DYN_CHUNK_DEFAULT));
         if (nw == 1 && pct > 0) {
             const int64_t tiles_all = items_bound * ((std::max<int64_t>(1, s->max_size) + 15) / 16);
             dyn_ranges = (tiles_all * std::min(90, pct) / 100) / chunk + 2;
@@ -1714,7 +1723,7 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
     const int64_t seg_starts = n_wgs + dyn_ranges;
     // (row-per-lane form: a segment emits one record per live query of its pass; every range boundary inside a pass adds at
     //  most QK_RL_QB records)
-    const int64_t max_recs = use_rl ? std::min<int64_t>(0x7FFFFFF0LL, npairs + (int64_t)QK_RL_QB * (n_waves + 1))
+    const int64_t max_recs = use_rl ? std::min<int64_t>(0x7FFFFFF0LL, npairs + (int64_t)QK_RL_QB * (n_waves + QK_RL_DYN_MAX + 2))
                                     : std::min<int64_t>(0x7FFFFFF0LL, nw * std::min<int64_t>(16 * (items_bound + seg_starts), npairs + 16 * seg_starts));
 
     // ---- workspace ---------------------------------------------------------------------------------
@@ -1784,8 +1793,8 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
     // tile of this index, times the waves of a workgroup (they all pay it at once).  Measured (10M x 128, batch 10000):
     // nprobe 32 +11 %, nprobe 8 +1 % with 8 steps; nothing beyond noise for one-wave workgroups (nprobe 1) or wide rows,
     // where the charge stays off unless QK_SCAN_SEG_OVH_ALL=1.
-    static const int seg_ovh_env = getenv("QK_SCAN_SEG_OVH") ? atoi(getenv("QK_SCAN_SEG_OVH")) : 8;
-    static const bool seg_ovh_all = getenv("QK_SCAN_SEG_OVH_ALL") && atoi(getenv("QK_SCAN_SEG_OVH_ALL")) != 0;
+    static const int seg_ovh_env = qk_env_int("QK_SCAN_SEG_OVH", 8);
+    static const bool seg_ovh_all = qk_env_int("QK_SCAN_SEG_OVH_ALL", 0) != 0;
     const int64_t tile_bytes = 64 * (int64_t)s->dpad;
     const int seg_ovh = use_rl ? rlc.ovh
                         : (seg_ovh_env <= 0 || !(qshare || seg_ovh_all))
@@ -1800,10 +1809,10 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
     G.n_pairs_live = scal + 7;
     G.pair_slots = pair_slots;
     G.gtau = gtau;
-    static const int no_seed = getenv("QK_NO_SEED") ? atoi(getenv("QK_NO_SEED")) : 0;
+    static const int no_seed = qk_env_int("QK_NO_SEED", 0);
     // (measured: for k > 64 a sample bound is far looser than the bound the pools reach by themselves -- no gain, and
     //  the 64*M-row sample costs 0.1 ms at d = 768; the wider instantiations stay available for probing)
-    static const int seed_max_k = getenv("QK_SEED_MAX_K") ? atoi(getenv("QK_SEED_MAX_K")) : 64;
+    static const int seed_max_k = qk_env_int("QK_SEED_MAX_K", 64);
     const bool seeded = !no_seed && share_tau && k <= std::min(seed_max_k, 512) && npairs > 0 && npids > 0;
     if (seeded) {
         // bound seeding: for the first (nearest) partitions of every query, the k-th smallest distance of a 64-row
@@ -1833,7 +1842,7 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
         // (QK_SEED_WAVES = 2 / 4: 128 / 256-row samples at the latency of the 64-row one.  Measured on the bench: k_scan 0.254 ->
         //  0.248 / 0.240 ms, this kernel 10 -> 17 / 30 us -- a 256-row sample of 1024 partitions is 134 MB of reads, 9 % of what
         //  the scan streams.  One for one again; the default stays at 64 rows.)
-        static const int seed_waves = getenv("QK_SEED_WAVES") ? atoi(getenv("QK_SEED_WAVES")) : 1;
+        static const int seed_waves = qk_env_int("QK_SEED_WAVES", 1);
         if (k <= 64 && seed_waves == 4)
             hipLaunchKernelGGL((k_seed_tau_wg<4>), sg, dim3(256), 0, st, sd);
         else if (k <= 64 && seed_waves == 2)
@@ -1847,7 +1856,7 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
         else
             hipLaunchKernelGGL((k_seed_tau<8>), sg, dim3(64), 0, st, sd);
     }
-    static const bool no_small = getenv("QK_NO_GROUP_SMALL") != nullptr;
+    static const bool no_small = qk_env_set("QK_NO_GROUP_SMALL");
     if (npairs <= QK_GROUP_SMALL && !no_small) {
         hipLaunchKernelGGL(k_group_small, dim3(1), dim3(1024), 0, st, G);
     } else {
@@ -1874,7 +1883,7 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
         sp.active = active;
         sp.n_tiles = n_tiles;
         sp.gtau = share_tau ? gtau : nullptr;
-        static const int force_refresh = getenv("QK_SCAN_TAU_REFRESH") ? atoi(getenv("QK_SCAN_TAU_REFRESH")) : -1;
+        static const int force_refresh = qk_env_int("QK_SCAN_TAU_REFRESH", -1);
         sp.tau_refresh = P > 1 ? 1 : 0;  // one partition per query: the seed is all there is to share
         if (force_refresh >= 0) sp.tau_refresh = force_refresh;
         sp.tau_publish = 1;
@@ -1884,7 +1893,7 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
             sp.tau_publish = 0;
         }
 
-        static const int probe_tau0 = getenv("QK_SCAN_TAU0") ? atoi(getenv("QK_SCAN_TAU0")) : 0;
+        static const int probe_tau0 = qk_env_int("QK_SCAN_TAU0", 0);
         if (probe_tau0) {  // probe: a bound of 0 -> nothing ever passes (isolates the steady-state epilogue cost)
             QK_HIP(hipMemsetAsync(gtau, 0xFF, (size_t)Q * 4, st));
             sp.gtau = gtau;
@@ -1899,7 +1908,8 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
         sp.rl_h0 = rlc.h0;
         sp.rl_h1 = rlc.h1;
         sp.rl_e = rlc.e;
-        static const int rl_probe = getenv("QK_SCAN_RL_PROBE") ? atoi(getenv("QK_SCAN_RL_PROBE")) : 0;
+        sp.rl_m = rlc.m;
+        static const int rl_probe = qk_env_int("QK_SCAN_RL_PROBE", 0);
         sp.rl_probe = rl_probe;
         sp.key_out = a.key_out;
         sp.pair_base = a.pair_base;
@@ -1920,13 +1930,23 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
         if (wgs_per_cu == 4 || wgs_per_cu == 6 || wgs_per_cu == 8 || (nw > 1 && wgs_per_cu <= 2))
             lds_launch = std::max<size_t>(lds_scan, (size_t)(160 * 1024) / wgs_per_cu - 512);
         // dynamic tail: measured wave end times spread over 65-100 % of the kernel with a purely static cut
-        static const int dyn_pct = getenv("QK_SCAN_DYN_PCT") ? atoi(getenv("QK_SCAN_DYN_PCT")) : QK_DYN_PCT_DEFAULT;
-        static const int dyn_chunk = getenv("QK_SCAN_DYN_CHUNK") ? atoi(getenv("QK_SCAN_DYN_CHUNK")) : QK_DYN_CHUNK_DEFAULT;
+        static const int dyn_pct = qk_env_int("QK_SCAN_DYN_PCT", QK_DYN_PCT_DEFAULT);
+        static const int dyn_chunk = qk_env_int("QK_SCAN_DYN_CHUNK", QK_DYN_CHUNK_DEFAULT);
         sp.dyn_counter = (nw == 1 && dyn_pct > 0 && !use_rl) ? (unsigned long long *)(scal + 16) : nullptr;  // zeroed with the counters
         sp.dyn_chunk = std::max(1, dyn_chunk);
         sp.dyn_pct = std::min(90, std::max(0, dyn_pct));
+        if (use_rl) {  // row-per-lane form: dynamic tail in ranges of rl_dyn_chunk units (>= tail / QK_RL_DYN_MAX)
+            // (share of the sequence handed out dynamically: 40 % when partitions are mostly probed by one query -- the cost
+            //  model has little to say there and the tail evens out XCD / placement differences --, 25 % otherwise)
+            static const int rl_dyn_env = qk_env_int("QK_SCAN_RL_DYN_PCT", -1);
+            const int rl_dyn_pct = rl_dyn_env >= 0 ? rl_dyn_env : (rl_per_list <= 1 ? 40 : 25);
+            static const int rl_dyn_chunk = qk_env_int("QK_SCAN_RL_DYN_CHUNK", 64);
+            sp.dyn_counter = rl_dyn_pct > 0 ? (unsigned long long *)(scal + 16) : nullptr;
+            sp.dyn_chunk = std::max(1, rl_dyn_chunk);
+            sp.dyn_pct = std::min(90, std::max(0, rl_dyn_pct));
+        }
         // single-wave workgroups are bundled four to a hardware workgroup: one wave per SIMD, guaranteed (see k_scan)
-        static const bool no_pack = getenv("QK_SCAN_NO_PACK") != nullptr;
+        static const bool no_pack = qk_env_set("QK_SCAN_NO_PACK");
         const bool pack4 = use_rl || (nw == 1 && !qshare && !no_pack && (wgs_per_cu == 4 || wgs_per_cu == 8) && lds_launch % 16 == 0);
         sp.pack = pack4 ? 4 : 1;
         sp.pack_lds = (int)lds_launch;
@@ -1936,7 +1956,7 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
             lds_launch *= 4;
         }
         // ---- XCD balance (see qk_ctx::xcd_state) ---------------------------------------------------------------------------
-        static const int xcd_adapt = getenv("QK_SCAN_XCD_ADAPT") ? atoi(getenv("QK_SCAN_XCD_ADAPT")) : 1;
+        static const int xcd_adapt = qk_env_int("QK_SCAN_XCD_ADAPT", 1);
         const bool xcd_ready = ctx->xcd_pending && hipEventQuery(ctx->xcd_ev) == hipSuccess;
         if (ctx->xcd_pending && !xcd_ready) (void)hipGetLastError();  // "not ready" is not an error: keep it out of the later checks
         if (xcd_ready) {  // a finished sample: speed = share / time
@@ -1967,7 +1987,7 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
         sp.xcd_on = 0;
         sp.xcd_stat = nullptr;
         for (int c = 0; c < 8; c++) sp.xcd_w[c] = 1024;
-        if (xcd_adapt && sp.dyn_counter == nullptr && grid >= 64 && tiles_est >= (int64_t)grid * wpw * 32) {
+        if (xcd_adapt && (sp.dyn_counter == nullptr || use_rl) && grid >= 64 && tiles_est >= (int64_t)grid * wpw * 32) {
             qk_ctx::xcd_state &xs = ctx->xcd[s->uid];
             sp.xcd_on = 1;
             for (int c = 0; c < 8; c++) sp.xcd_w[c] = std::max(1, (int)(xs.w[c] * 1024.0 + 0.5));
@@ -1981,7 +2001,7 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
                 for (int c = 0; c < 8; c++) ctx->xcd_wsnap[c] = sp.xcd_w[c] / 1024.0;
             }
         }
-        static const bool probe_clock = getenv("QK_SCAN_WAVE_CLOCK") != nullptr;
+        static const bool probe_clock = qk_env_set("QK_SCAN_WAVE_CLOCK");
         static long long *d_clock = nullptr;
         sp.wave_clock = nullptr;
         if (probe_clock) {
@@ -1998,6 +2018,7 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
             QK_HIP(hipEventRecord(ctx->xcd_ev, st));
             ctx->xcd_pending = true;
         }
+#ifdef QK_PROBES
         if (probe_clock) {  // debug probe: distribution of the waves' busy time (tail = what a dynamic split could recover)
             std::vector<long long> h((size_t)grid * wpw * 8);
             QK_HIP(hipMemcpyAsync(h.data(), d_clock, h.size() * 8, hipMemcpyDeviceToHost, st));
@@ -2076,6 +2097,17 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
                 sum += (double)(h[8 * i + 1] - t0);
             }
             std::sort(ws.begin(), ws.end(), [](const W &a, const W &b) { return a.end < b.end; });
+            if (use_rl) {  // row-per-lane form: field 5 = shader cycles, field 6 = MFMA loop steps
+                double cyc = 0, tk = 0, steps = 0;
+                for (size_t i = 0; i < nwv; i++) {
+                    if (h[8 * i + 1] == 0) continue;
+                    cyc += (double)h[8 * i + 5];
+                    tk += (double)(h[8 * i + 1] - h[8 * i]);
+                    steps += (double)h[8 * i + 6];
+                }
+                fprintf(stderr, "[k_scan_rl] effective shader clock %.3f GHz, %.0f MFMA loop steps in all, %.0f cycles of wave time per step\n",
+                        tk > 0 ? cyc / tk * 0.1 : 0.0, steps, steps > 0 ? cyc / steps : 0.0);
+            }
             if (!ws.empty()) {
                 const size_t n = ws.size();
                 fprintf(stderr, "[k_scan waves] n=%zu span=%lld ticks  end-time pct: p10=%lld p50=%lld p90=%lld p99=%lld max=%lld mean=%.0f (100 MHz ticks)\n",
@@ -2088,7 +2120,9 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
                     fprintf(stderr, "   decile %d: end=%.0f compactions=%.1f appends=%.0f segments=%.2f seg_end_ticks=%.0f staging_ticks=%.0f\n", dec, e / m, c / m, a_ / m, sg / m, te / m, tsg / m);
                 }
             }
-        }    }
+        }
+#endif
+    }
     QK_TRY(pe.mark(2));
 
     if (emit) {  // the caller selects from the emitted keys
@@ -2111,14 +2145,14 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
     mp.out_dist = a.out_dist;
     mp.sqrt_l2 = a.sqrt_l2 ? 1 : 0;
     const dim3 mgrid((unsigned)(a.per_pair ? Q * P : Q));
-    static const bool merge_clock = getenv("QK_MERGE_CLOCK") != nullptr;
+    static const bool merge_clock = qk_env_set("QK_MERGE_CLOCK");
     static long long *d_mclock = nullptr;
     mp.clock = nullptr;
     if (merge_clock && (int64_t)mgrid.x * 64 <= ((int64_t)1 << 24)) {
         if (!d_mclock) QK_HIP(hipMalloc((void **)&d_mclock, (size_t)1 << 24));
         mp.clock = d_mclock;
     }
-    static const int merge_wide_min_k = getenv("QK_MERGE_WIDE_MIN_K") ? atoi(getenv("QK_MERGE_WIDE_MIN_K")) : 33;
+    static const int merge_wide_min_k = qk_env_int("QK_MERGE_WIDE_MIN_K", 33);
     if (k >= merge_wide_min_k) {
         hipLaunchKernelGGL(k_merge_wide, mgrid, dim3(256), 0, st, mp);
     } else
@@ -2129,6 +2163,7 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
         default: hipLaunchKernelGGL((k_merge<16>), mgrid, dim3(64), lds_merge, st, mp); break;
     }
     QK_HIP(hipGetLastError());
+#ifdef QK_PROBES
     if (mp.clock) {  // debug probe: where a merge wave spends its time (mean / max over the queries, 100 MHz ticks)
         std::vector<long long> h((size_t)mgrid.x * 8);
         QK_HIP(hipMemcpyAsync(h.data(), d_mclock, h.size() * 8, hipMemcpyDeviceToHost, st));
@@ -2155,6 +2190,7 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
         for (int ph = 0; ph < 6; ph++) fprintf(stderr, " %s mean=%.0f max=%lld;", names[ph], mean[ph] / mgrid.x, mx[ph]);
         fprintf(stderr, "\n");
     }
+#endif
     QK_TRY(pe.mark(3));
     if (timing) {
         // device scalars come back through pinned memory; the caller synchronises before reading them

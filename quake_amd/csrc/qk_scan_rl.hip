@@ -57,10 +57,15 @@ __global__ __launch_bounds__(256) void k_scan_rl(ScanParams P) {
     float *s_xn = (float *)(s_cnt + QB);
 
     // ---- this wave's contiguous share of the work sequence (units of RlCost; XCD-weighted like k_scan's) -----------------
+    // The first (100 - dyn_pct) % of the sequence is cut statically; the tail is claimed in ranges of dyn_chunk units through
+    // one atomic counter by whoever finishes first (the cost model cannot know how much HBM bandwidth a wave will get while
+    // others are in MFMA-bound passes)
     const long long T = *P.n_tiles;
     const long long W = (long long)gridDim.x * 4;
     const long long vblock = (long long)blockIdx.x * 4 + wvp;
-    long long T0 = (T * vblock) / W, T1 = (T * (vblock + 1)) / W;
+    const bool dyn = P.dyn_counter != nullptr;
+    const long long Ts = dyn ? T - (T * P.dyn_pct) / 100 : T;
+    long long T0 = (Ts * vblock) / W, T1 = (Ts * (vblock + 1)) / W;
     if (P.xcd_on) {
         long long pre[9];
         pre[0] = 0;
@@ -70,15 +75,19 @@ __global__ __launch_bounds__(256) void k_scan_rl(ScanParams P) {
         const long long total = ((gu >> 3) * pre[8] + pre[gu & 7]) * 4;
         const long long a0 = ((u >> 3) * pre[8] + pre[u & 7]) * 4 + (long long)P.xcd_w[u & 7] * wvp;
         const long long a1 = a0 + P.xcd_w[u & 7];
-        T0 = a0 <= 0 ? 0 : (long long)((double)T * (double)a0 / (double)total);
-        T1 = a1 >= total ? T : (long long)((double)T * (double)a1 / (double)total);
+        T0 = a0 <= 0 ? 0 : (long long)((double)Ts * (double)a0 / (double)total);
+        T1 = a1 >= total ? Ts : (long long)((double)Ts * (double)a1 / (double)total);
     }
-    if (T1 <= T0) return;
+    if (!dyn && T1 <= T0) return;
     const long long wc0 = (P.xcd_stat || P.wave_clock) ? wall_clock64() : 0;
+    const long long cy0 = P.wave_clock ? clock64() : 0;
     int dbg_comp = 0, dbg_app = 0, dbg_seg = 0;  // probe counters (QK_SCAN_WAVE_CLOCK)
     long long dbg_t_end = 0, dbg_t_stage = 0, dbg_gc = 0;
-    const RlCost rc{P.rl_h0, P.rl_h1, P.rl_e, P.seg_ovh};
+    const RlCost rc{P.rl_h0, P.rl_h1, P.rl_e, P.seg_ovh, P.rl_m};
     const int n_active = *P.n_active;
+    long long xcd_ticks = 0;  // time spent on the static share (what the XCD balance learns from)
+    for (;;) {
+    if (T1 > T0) {
     // 64-ary search for the partition that holds unit T0: active[lo].toff <= T0 < active[lo+1].toff
     int lo = 0, hi = n_active;
     while (hi - lo > 1) {
@@ -129,7 +138,6 @@ __global__ __launch_bounds__(256) void k_scan_rl(ScanParams P) {
         const int myq = (lane < nq) ? P.grouped_q[gidx] : -1;
         const int mypair = (lane < nq) ? P.grouped_pair[gidx] : -1;
         const int64_t tile_p0 = inf.row_off >> 4;
-        const bool keep_cached = nqb > 1;  // later passes re-read the rows: leave them in L2 / Infinity Cache
 
         float4 a0[NB * 4], a1[NB * 4];
         float4 y0, y1;
@@ -139,13 +147,8 @@ __global__ __launch_bounds__(256) void k_scan_rl(ScanParams P) {
     {                                                                                                 \
         const int64_t ta_ = tile_p0 + min(4 * lch + tq, ntl - 1);                                     \
         const float4 *src_ = P.vecs + ta_ * (NB * 64) + r;                                            \
-        if (keep_cached) {                                                                            \
-            _Pragma("unroll") for (int c_ = 0; c_ < NB; c_++)                                         \
-                _Pragma("unroll") for (int g_ = 0; g_ < 4; g_++) A[c_ * 4 + g_] = src_[c_ * 64 + g_ * 16]; \
-        } else {                                                                                      \
-            _Pragma("unroll") for (int c_ = 0; c_ < NB; c_++)                                         \
-                _Pragma("unroll") for (int g_ = 0; g_ < 4; g_++) A[c_ * 4 + g_] = rl_ld_nt(src_ + c_ * 64 + g_ * 16); \
-        }                                                                                             \
+        _Pragma("unroll") for (int c_ = 0; c_ < NB; c_++)                                             \
+            _Pragma("unroll") for (int g_ = 0; g_ < 4; g_++) A[c_ * 4 + g_] = rl_ld_nt(src_ + c_ * 64 + g_ * 16); \
         const int64_t tn_ = tile_p0 + min(4 * lch + (b4 >> 2), ntl - 1);                              \
         Y = *((const float4 *)(P.norms + (tn_ << 4)) + (b4 & 3));                                     \
         const longlong2 *ip_ = (const longlong2 *)(P.ids + (tn_ << 4)) + 2 * (b4 & 3);                \
@@ -268,12 +271,13 @@ __global__ __launch_bounds__(256) void k_scan_rl(ScanParams P) {
             f32x4 acc0_ = {0.f, 0.f, 0.f, 0.f}, acc1_ = {0.f, 0.f, 0.f, 0.f};                                         \
             const float4 *b0_ = sB + (size_t)g0_ * NKK * 4 + j;                                                       \
             const float4 *b1_ = (g0_ + 1 < ng) ? b0_ + NKK * 4 : b0_;                                                 \
-            float4 qa_[2], qb_[2];                                                                                    \
+            float4 qa_[2], qb_[2]; /* B operands of steps kk and kk + 1: requested one step (8 MFMAs) ahead (two steps ahead    \
+                                      measured slower: more registers moved through the AGPR half) */                   \
             qa_[0] = b0_[0];                                                                                          \
             qb_[0] = b1_[0];                                                                                          \
             if (!(P.rl_probe & 2))                                                                                    \
             _Pragma("unroll") for (int kk_ = 0; kk_ < NKK; kk_++) {                                                   \
-                if (kk_ + 1 < NKK) {                                                                                  \
+                if (kk_ + 1 < NKK) { /* (compile-time: no branch inside the chain) */                                 \
                     qa_[(kk_ + 1) & 1] = b0_[(kk_ + 1) * 4];                                                          \
                     qb_[(kk_ + 1) & 1] = b1_[(kk_ + 1) * 4];                                                          \
                 }                                                                                                     \
@@ -302,15 +306,12 @@ __global__ __launch_bounds__(256) void k_scan_rl(ScanParams P) {
         // Every load below is unconditional inside its block (counted s_waitcnt vmcnt(N): the next chunk stays in flight under
         // the MFMA chains of the current one) and no chunk is requested twice: the steady loop needs two more chunks after the
         // one it computes; the last one or two chunks are peeled.
-        const bool refresh = P.gtau != nullptr && P.tau_refresh != 0 && lane < QB && myq >= 0;
+        // (every load of the steady loop is UNCONDITIONAL: a load inside a branch makes hipcc fall back to s_waitcnt vmcnt(0),
+        //  which drains the prefetched chunk.  Bounds published by other waves are picked up at every pass start -- the staging
+        //  above -- not inside a pass: an unconditional agent-scope re-read per step from every wave was measured 2x slower.)
         int ch = ch0;
         while (ch + 2 < ch1) {
-            // bounds published by other waves working on the same queries: one load for all 32 slots, requested BEFORE the
-            // next chunk's loads so that consuming it does not drain them
-            uint32_t tref = 0xFFFFFFFFu;
-            if (refresh) tref = ~__hip_atomic_load(&P.gtau[myq], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             RL_LOAD(a1, y1, i10, i11);
-            if (refresh) s_tau[lane] = min(s_tau[lane], tref);
             RL_STEP(a0, y0, i00, i01, ch);
             RL_LOAD(a0, y0, i00, i01);
             RL_STEP(a1, y1, i10, i11, ch + 1);
@@ -372,8 +373,19 @@ __global__ __launch_bounds__(256) void k_scan_rl(ScanParams P) {
         }
         if (P.wave_clock) dbg_t_end += wall_clock64() - dbg_e0;
     }
+    }  // range
+        if (!dyn) break;
+        if (xcd_ticks == 0 && P.xcd_stat) xcd_ticks = wall_clock64() - wc0;
+        const long long chunk = max((long long)P.dyn_chunk, (T - Ts + QK_RL_DYN_MAX - 1) / QK_RL_DYN_MAX);
+        unsigned long long c = 0;
+        if (lane == 0) c = atomicAdd(P.dyn_counter, (unsigned long long)chunk);
+        c = __shfl(c, 0);
+        T0 = Ts + (long long)c;
+        if (T0 >= T) break;
+        T1 = min(T, T0 + chunk);
+    }
     if (P.xcd_stat && lane == 0) {
-        atomicAdd(&P.xcd_stat[blockIdx.x & 7], (unsigned long long)(wall_clock64() - wc0));
+        atomicAdd(&P.xcd_stat[blockIdx.x & 7], (unsigned long long)(xcd_ticks ? xcd_ticks : wall_clock64() - wc0));
         atomicAdd(&P.xcd_stat[8 + (blockIdx.x & 7)], 1ull);
     }
     if (P.wave_clock && lane == 0) {
@@ -383,7 +395,7 @@ __global__ __launch_bounds__(256) void k_scan_rl(ScanParams P) {
         wcp[2] = dbg_comp;
         wcp[3] = dbg_app;
         wcp[4] = dbg_seg;
-        wcp[5] = dbg_t_end;
+        wcp[5] = clock64() - cy0;  // shader cycles of the wave (with [1] - [0] in 100 MHz ticks: the effective clock)
         wcp[6] = dbg_gc;  // (group-pair x chunk) steps instead of the staging ticks k_scan reports here
         const unsigned hw = __builtin_amdgcn_s_getreg((4) | (0 << 6) | ((32 - 1) << 11));
         const unsigned xcc = __builtin_amdgcn_s_getreg((20) | (0 << 6) | ((4 - 1) << 11));

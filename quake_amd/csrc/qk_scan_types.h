@@ -65,22 +65,25 @@ struct ScanParams {
     long long *wave_clock;  // probe (QK_SCAN_WAVE_CLOCK): [waves][2] start / end of every wave in wall_clock64 ticks, or nullptr
     // row-per-lane scan (qk_scan_rl.hip)
     const float4 *xp4;  // [Q][dpad/4] row-major zero-padded queries
-    int rl_h0, rl_h1, rl_e;  // cost model of the work sequence (RlCost; ovh = seg_ovh)
-    int rl_probe;            // probe (QK_SCAN_RL_PROBE): bit 0 = no top-k epilogue, bit 1 = no MFMA chains (attribution only)
+    int rl_h0, rl_h1, rl_e, rl_m;  // cost model of the work sequence (RlCost; ovh = seg_ovh)
+    int rl_probe;            // probe (QK_SCAN_RL_PROBE): bit 0 = no top-k epilogue, bit 1 = no MFMA chains (attribution only; uniform branches OUTSIDE the chain)
 };
 
 // ---- row-per-lane scan (qk_scan_rl.hip): cost model of the work sequence ----------------------------------------------------
 // A partition probed by cnt queries is scanned in passes of up to QK_RL_QB queries (QK_RL_QB / 4 groups of 4: one
 // v_mfma_f32_4x4x1_16b_f32 serves 64 rows x 4 queries).  A pass walks the partition in chunks of 64 rows; a chunk of a pass
-// with g groups weighs max(h, g + e) units -- h stands for streaming the chunk (h0: from HBM, first pass; h1: later passes
-// find it in L2 / Infinity Cache), g for its MFMA chains -- and every pass starts with `ovh` units (query staging, record
-// emission).  The grouping stage lays the partitions end to end in these units and k_scan_rl cuts the sequence statically.
+// with g groups weighs max(h, m * ceil(g / 2) + e) units -- h stands for streaming the chunk (h0: from HBM, first pass; h1:
+// later passes find it in L2 / Infinity Cache), m for one step of the MFMA loop (two groups' chains interleaved: 256
+// instructions + two top-k epilogues; measured 1.44 us against ~4.3 us for a chunk when every wave streams, hence m = 4,
+// h0 = 12) -- and every pass starts with `ovh` units (query staging, record emission).  The grouping stage lays the
+// partitions end to end in these units; k_scan_rl cuts the head of the sequence statically and hands the tail out dynamically.
 constexpr int QK_RL_QB = 32;
+constexpr int QK_RL_DYN_MAX = 4096;  // most ranges the dynamic tail is cut into (bounds the records a launch can emit)
 struct RlCost {
-    int h0, h1, e, ovh;
+    int h0, h1, e, ovh, m;
 };
 __host__ __device__ inline int rl_w(int g, bool first, const RlCost &c) {
-    const int h = first ? c.h0 : c.h1, v = g + c.e;
+    const int h = first ? c.h0 : c.h1, v = c.m * ((g + 1) >> 1) + c.e;
     return v > h ? v : h;
 }
 __host__ __device__ inline long long rl_part_len(int cnt, int size, const RlCost &c) {

@@ -1,0 +1,414 @@
+// qk_small.hip -- QueryCoordinator::search for SMALL batches in ONE launch.
+//
+// A 1-query search through the batch pipeline is a chain of ~12 dependent launches (prep, coarse keys, select, convert,
+// group, seed, scan, merge): ~100 us of launch boundaries around ~5 us of work (profiles/r01_latency_probe.json).  Here the
+// whole path -- src/cpp/src/query_coordinator.cpp:612-657 (parent search -> scan_partitions), serial_scan :471-611,
+// scan_list + TopkBuffer src/cpp/include/list_scanning.h:41-204,241-311 -- is one kernel:
+//
+//   grid = Q x W workgroups; the W workgroups of a query each
+//     A. compute the coarse step for the query themselves (every centroid, canonical chains, one row per thread; the
+//        centroid arena is L2 / Infinity-Cache resident) and select the nprobe nearest under the (key, id) order by
+//        bisection on the key bits (and on the id bits among ties on the cut), so that no grid-wide barrier separates the
+//        coarse step from the scan;
+//     B. take the w-th slice of the rows of the probed partitions laid end to end, one row per thread and round, keep the
+//        slice's k best in LDS (select_pool / compact_pool: the TopkBuffer append + flush of this design);
+//     C. leave a sorted record; the LAST workgroup of the query to arrive (one atomic ticket; agent-scope release before,
+//        acquire after) merges the W records, applies sqrt / padding and writes [k] ids + distances.
+//
+// Arithmetic and order are the canonical ones: every distance is one k-ordered fmaf chain, L2 in the
+// expanded form with the stored row norms, selection under (key, id) -- so the answers are bit-identical to the batch
+// pipeline's and to the oracle's.
+#include "qk_internal.h"
+#include "qk_device.h"
+
+#include <algorithm>
+
+struct SmallParams {
+    // parent (flat) index: one list of centroids
+    const float4 *c_vecs;
+    const float *c_norms;
+    const int64_t *c_ids;
+    int64_t c_row0;
+    int c_n;
+    // partitions
+    const float4 *vecs;
+    const float *norms;
+    const int64_t *ids;
+    const int64_t *pt_off;
+    const int32_t *pt_size;
+    int npids;
+    int nblk;
+    int d;
+    const float *x;  // [Q][d] row-major
+    int nprobe, k, metric, sqrt_l2;
+    int W;       // workgroups per query
+    int cap;     // LDS candidate pool capacity (multiple of 64, > k)
+    int64_t *out_ids;
+    float *out_dist;
+    // workspace: records [Q][W][k] (ord, id), counts [Q][W], tickets [Q] (zero between calls: the last arriver resets its own)
+    uint32_t *rec_ord;
+    int64_t *rec_id;
+    int32_t *rec_cnt;
+    unsigned int *ticket;
+    long long *clock;  // probe (QK_SMALL_CLOCK): phase stamps of workgroup 0 in 100 MHz ticks, or nullptr
+};
+
+// canonical key of arena row `row` against the query staged in LDS (sq, zero-padded to 16 columns): one k-ordered fmaf chain
+// over the tile-major layout (qk_internal.h): float4 (tile*nblk + c)*64 + g*16 + r holds columns 16c + {g, 4+g, 8+g, 12+g}
+__device__ __forceinline__ uint32_t small_row_key(const float4 *vecs, const float *norms, int nblk, int64_t row, const float *sq,
+                                                  float xn, bool l2) {
+    const int64_t tile = row >> 4;
+    const int r = (int)(row & 15);
+    const float4 *base = vecs + tile * nblk * 64 + r;
+    float acc = 0.0f;
+    for (int c0 = 0; c0 < nblk; c0 += 8) {
+        float4 v[8][4];
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            const int cc = min(c0 + c, nblk - 1);
+#pragma unroll
+            for (int g = 0; g < 4; g++) v[c][g] = base[cc * 64 + g * 16];
+        }
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            if (c0 + c < nblk) {
+                const float4 *q4 = (const float4 *)(sq + (c0 + c) * 16);
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    const float4 qq = q4[t];  // columns 16c + 4t .. 4t+3 (same address in every lane: LDS broadcast)
+                    const float e0 = t == 0 ? v[c][0].x : t == 1 ? v[c][0].y : t == 2 ? v[c][0].z : v[c][0].w;
+                    const float e1 = t == 0 ? v[c][1].x : t == 1 ? v[c][1].y : t == 2 ? v[c][1].z : v[c][1].w;
+                    const float e2 = t == 0 ? v[c][2].x : t == 1 ? v[c][2].y : t == 2 ? v[c][2].z : v[c][2].w;
+                    const float e3 = t == 0 ? v[c][3].x : t == 1 ? v[c][3].y : t == 2 ? v[c][3].z : v[c][3].w;
+                    acc = __fmaf_rn(e0, qq.x, acc);
+                    acc = __fmaf_rn(e1, qq.y, acc);
+                    acc = __fmaf_rn(e2, qq.z, acc);
+                    acc = __fmaf_rn(e3, qq.w, acc);
+                }
+            }
+        }
+    }
+    return l2 ? ord_from_l2(l2_expanded(xn, norms[row], acc)) : ord_from_ip(acc);
+}
+
+// block-wide sum of one int per thread (256 threads)
+__device__ __forceinline__ int small_block_sum(int v, int *s_red /*[4]*/) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    __syncthreads();
+    if (lane == 0) s_red[wave] = v;
+    __syncthreads();
+    return s_red[0] + s_red[1] + s_red[2] + s_red[3];
+}
+
+constexpr int QK_SMALL_MAXP = 64;    // nprobe
+constexpr int QK_SMALL_CPT = 16;     // centroids per thread (256 threads): nlist <= 4096
+constexpr int QK_SMALL_MAXK = 32;
+
+__global__ __launch_bounds__(256) void k_search_small(SmallParams P) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    __shared__ int s_red[4];
+    __shared__ int64_t s_pid[QK_SMALL_MAXP];      // the probe list (rank order) ...
+    __shared__ uint32_t s_pord[QK_SMALL_MAXP];
+    __shared__ int s_np;
+    __shared__ long long s_pre[QK_SMALL_MAXP + 1];  // ... and the prefix sums of the probed partitions' sizes
+    __shared__ int64_t s_off[QK_SMALL_MAXP];
+    __shared__ int s_last;
+    __shared__ uint32_t s_kth;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = blockIdx.x / P.W, w = blockIdx.x % P.W;
+    const bool l2 = P.metric == QK_METRIC_L2;
+    const int dpad = P.nblk * 16;
+    float *sq = (float *)smem;                                  // [dpad] query, zero padded
+    int64_t *pool_id = (int64_t *)(smem + (size_t)dpad * 4);    // [cap]
+    uint32_t *pool_ord = (uint32_t *)(pool_id + P.cap);         // [cap]
+    uint32_t *s_ck = pool_ord + P.cap;                          // [c_n] coarse keys ...
+    int64_t *s_cid = (int64_t *)(s_ck + ((P.c_n + 7) & ~7));    // [c_n] ... and the partition ids that go with them
+    __shared__ uint32_t s_mord[4 * QK_SMALL_MAXP];
+    __shared__ int64_t s_mid[4 * QK_SMALL_MAXP];
+
+    if (P.clock && tid == 0 && blockIdx.x == 0) P.clock[0] = wall_clock64();
+    // ---- the query -----------------------------------------------------------------------------------------------------
+    for (int c = tid; c < dpad; c += 256) sq[c] = c < P.d ? P.x[(int64_t)q * P.d + c] : 0.0f;
+    __syncthreads();
+    float xn = 0.0f;
+    if (l2)
+        for (int c = 0; c < P.d; c++) xn = __fmaf_rn(sq[c], sq[c], xn);  // canonical |x|^2 (every thread: LDS broadcast reads)
+
+    // ---- A. coarse: keys of this thread's centroids (kept in LDS), then the nprobe smallest under (key, id) -------------------
+    for (int r = tid; r < P.c_n; r += 256) s_ck[r] = small_row_key(P.c_vecs, P.c_norms, P.nblk, P.c_row0 + r, sq, xn, l2);
+    __syncthreads();
+    if (P.clock && tid == 0 && blockIdx.x == 0) P.clock[1] = wall_clock64();
+    const int want = min(P.nprobe, P.c_n);
+    // Selection without block barriers: every wave keeps the `want` best of its quarter of the centroids (bisection select on
+    // registers, select_pool; exact under (key, id), ties on the cut included), wave 0 then takes the `want` best of the four.
+    {
+        const int per = (P.c_n + 3) >> 2;                 // <= 1024
+        const int b0 = wave * per, n_w = max(0, min(per, P.c_n - b0));
+        for (int r = lane; r < n_w; r += 64) s_cid[b0 + r] = P.c_ids[P.c_row0 + b0 + r];
+        uint32_t kth;
+        int got = 0;
+        if (n_w > 0) {
+            if (per <= 256)
+                got = select_pool<4>(s_ck + b0, s_cid + b0, n_w, want, lane, kth);
+            else
+                got = select_pool<16>(s_ck + b0, s_cid + b0, n_w, want, lane, kth);
+        }
+        if (lane == 0) s_red[wave] = got;
+    }
+    __syncthreads();
+    if (wave == 0) {
+        int n = 0;
+        for (int ww = 0; ww < 4; ww++) {
+            const int got = s_red[ww], b0 = ww * ((P.c_n + 3) >> 2);
+            for (int e = lane; e < got; e += 64) {
+                s_mord[n + e] = s_ck[b0 + e];
+                s_mid[n + e] = s_cid[b0 + e];
+            }
+            n += got;
+        }
+        const int nn = compact_pool<4>(s_mord, s_mid, n, want, lane);  // n <= 4 * 64; sorted: the probe list in rank order
+        for (int e = lane; e < nn; e += 64) {
+            s_pord[e] = s_mord[e];
+            s_pid[e] = s_mid[e];
+        }
+        if (lane == 0) s_np = nn;
+    }
+    if (P.clock && tid == 0 && blockIdx.x == 0) P.clock[2] = wall_clock64();
+    __syncthreads();
+    const int np = min(s_np, QK_SMALL_MAXP);
+    // ---- B. this workgroup's slice of the probed rows -----------------------------------------------------------------------
+    if (tid == 0) {
+        long long run = 0;
+        for (int i = 0; i < np; i++) {
+            const int64_t p = s_pid[i];
+            int sz = 0;
+            if (p >= 0 && p < P.npids) sz = max(P.pt_size[p], 0);  // absent lists have size -1
+            s_pre[i] = run;
+            s_off[i] = sz > 0 ? P.pt_off[p] : 0;
+            run += sz;
+        }
+        s_pre[np] = run;
+    }
+    __syncthreads();
+    const long long R = s_pre[np];
+    const long long lo = (R * w) / P.W, hi = (R * (w + 1)) / P.W;
+    const int k = P.k, cap = P.cap;
+    int cnt = 0;              // entries held in the pool (uniform)
+    uint32_t tau = 0xFFFFFFFFu;
+    const int per_round = cap - k;  // multiple of 64 is not required: rows are appended with a ballot prefix per wave
+    __shared__ int s_fill;
+    for (long long base = lo; base < hi; base += per_round) {
+        const long long end = min(hi, base + per_round);
+        if (tid == 0) s_fill = cnt;
+        __syncthreads();
+        const int iters = (int)((end - base + 255) / 256);
+        for (int it = 0; it < iters; it++) {
+            const long long g = base + tid + 256 * (long long)it;
+            bool pass = false;
+            uint32_t key = 0xFFFFFFFFu;
+            int64_t id = -1;
+            if (g < end) {
+                int pi = 0;
+                while (pi + 1 < np && s_pre[pi + 1] <= g) pi++;
+                const int64_t row = s_off[pi] + (g - s_pre[pi]);
+                key = small_row_key(P.vecs, P.norms, P.nblk, row, sq, xn, l2);
+                id = P.ids[row];
+                pass = key != 0xFFFFFFFFu && key <= tau;
+            }
+            const uint64_t m = __ballot(pass);
+            if (m) {
+                int at = 0;
+                if (lane == 0) at = atomicAdd(&s_fill, __popcll(m));
+                at = __builtin_amdgcn_readfirstlane(at);
+                if (pass) {
+                    const int sl = at + __popcll(m & ((1ull << lane) - 1ull));
+                    pool_ord[sl] = key;
+                    pool_id[sl] = id;
+                }
+            }
+        }
+        __syncthreads();
+        cnt = s_fill;
+        if (cnt > k || end >= hi) {  // keep the k best (sorted at the end of the slice)
+            if (wave == 0) {
+                uint32_t kth = 0xFFFFFFFFu;
+                int nn;
+                if (end >= hi)
+                    nn = cnt <= 256 ? compact_pool<4>(pool_ord, pool_id, cnt, k, lane) : compact_pool<16>(pool_ord, pool_id, cnt, k, lane);
+                else
+                    nn = select_pool<16>(pool_ord, pool_id, cnt, k, lane, kth);
+                if (lane == 0) {
+                    s_fill = nn;
+                    s_kth = (nn >= k && end < hi) ? kth : 0xFFFFFFFFu;
+                }
+            }
+            __syncthreads();
+            cnt = s_fill;
+            tau = min(tau, s_kth);
+            __syncthreads();
+        }
+    }
+    if (lo >= hi) cnt = 0;
+    if (P.clock && tid == 0 && blockIdx.x == 0) P.clock[3] = wall_clock64();
+    // ---- C. record, ticket, merge by the last arriver -----------------------------------------------------------------------
+    const int64_t rbase = ((int64_t)q * P.W + w) * k;
+    for (int e = tid; e < cnt; e += 256) {
+        P.rec_ord[rbase + e] = pool_ord[e];
+        P.rec_id[rbase + e] = pool_id[e];
+    }
+    if (tid == 0) P.rec_cnt[q * P.W + w] = cnt;
+    __syncthreads();
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned int t = atomicAdd(&P.ticket[q], 1u);
+        s_last = t == (unsigned)(P.W - 1) ? 1 : 0;
+        if (s_last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            P.ticket[q] = 0;  // ready for the next call on this stream
+        }
+    }
+    __syncthreads();
+    if (P.clock && tid == 0 && blockIdx.x == 0) P.clock[4] = wall_clock64();
+    if (!s_last) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (tid == 0) s_fill = 0;
+    __syncthreads();
+    for (int ww = wave; ww < P.W; ww += 4) {  // one wave per record (k <= 32 <= 64 lanes)
+        const int n = P.rec_cnt[q * P.W + ww];
+        const bool has = lane < n;
+        uint32_t o = 0xFFFFFFFFu;
+        int64_t id = -1;
+        if (has) {
+            o = __hip_atomic_load(&P.rec_ord[((int64_t)q * P.W + ww) * k + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            id = __hip_atomic_load(&P.rec_id[((int64_t)q * P.W + ww) * k + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        const uint64_t m = __ballot(has);
+        if (m) {
+            int at = 0;
+            if (lane == 0) at = atomicAdd(&s_fill, __popcll(m));
+            at = __builtin_amdgcn_readfirstlane(at);
+            if (has) {
+                pool_ord[at + lane] = o;
+                pool_id[at + lane] = id;
+            }
+        }
+    }
+    __syncthreads();
+    const int total = s_fill;  // <= W * k <= cap
+    if (wave == 0) {
+        const int nn = total <= 256 ? compact_pool<4>(pool_ord, pool_id, total, k, lane) : compact_pool<16>(pool_ord, pool_id, total, k, lane);
+        for (int e = lane; e < k; e += 64) {
+            int64_t oid = -1;
+            float od = l2 ? INFINITY : -INFINITY;
+            if (e < nn) {
+                oid = pool_id[e];
+                const uint32_t o = pool_ord[e];
+                if (l2) {
+                    const float d2 = __uint_as_float(o);
+                    od = P.sqrt_l2 ? sqrtf(d2) : d2;
+                } else {
+                    od = ip_from_ord(o);
+                }
+            }
+            P.out_ids[(int64_t)q * k + e] = oid;
+            if (P.out_dist) P.out_dist[(int64_t)q * k + e] = od;
+        }
+        if (P.clock && lane == 0) {
+            P.clock[5] = wall_clock64();
+            P.clock[6] = blockIdx.x;
+        }
+    }
+}
+
+// ---- host side -----------------------------------------------------------------------------------------------------------
+// Supported envelope (qk_search routes everything else through the batch pipeline): flat parent with one list of at most
+// 4096 centroids whose ids are >= 0, nprobe <= 64, k <= 32, Q <= 64.
+bool qk_small_supported(qk_ctx *ctx, qk_store *parent, qk_store *s, int64_t Q, int nprobe, int k) {
+    static const int enabled = qk_env_int("QK_SMALL", 1);
+    static const int max_q = qk_env_int("QK_SMALL_MAX_Q", 6);  // measured (1M x 128, nprobe 10): 1 query 62 vs 95 us, 4: 68 vs 100, 16: 129 vs 111
+    if (!enabled || !parent || Q <= 0 || Q > std::min(64, max_q)) return false;
+    if (k > QK_SMALL_MAXK || nprobe > QK_SMALL_MAXP || nprobe <= 0) return false;
+    if (parent->nlist != 1 || parent->ntotal <= 0 || parent->ntotal > 256 * QK_SMALL_CPT) return false;
+    if (parent->min_id_seen < 0 || parent->d != s->d) return false;
+    if ((size_t)s->dpad * 4 + 1024 * 12 + (size_t)parent->ntotal * 12 + 8192 > 160 * 1024) return false;
+    return true;
+}
+
+int qk_search_small_device(qk_ctx *ctx, qk_store *parent, qk_store *s, const float *x, int64_t Q, int nprobe, int k, int metric,
+                           int64_t *out_ids, float *out_dist, bool sqrt_l2) {
+    QK_TRY(qk_store_sync_table(s));
+    int64_t c_row0 = 0, c_n = 0;
+    for (const qk_part &pt : parent->parts)
+        if (pt.present) {
+            c_row0 = pt.row_off;
+            c_n = pt.size;
+            break;
+        }
+    // workgroups per query: enough that a slice is a few hundred rows, no more than fill the chip a few times over
+    const int64_t rows_est = std::max<int64_t>(1, (int64_t)std::min<int64_t>(nprobe, c_n) * std::max<int64_t>(1, s->ntotal / std::max<int64_t>(1, s->nlist)));
+    int W = (int)std::min<int64_t>(64, std::max<int64_t>(1, rows_est / 192));
+    W = std::min(W, std::max(1, 1024 / k));
+    W = std::min<int64_t>(W, std::max<int64_t>(1, 2048 / Q));
+    const int cap = 1024;
+    // persistent workspace (tickets must stay zero between calls)
+    const size_t need = (size_t)64 * 64 * QK_SMALL_MAXK * 12 + (size_t)64 * 64 * 4 + 64 * 4 + 1024;
+    if (!ctx->small_ws) {
+        QK_HIP(hipMalloc((void **)&ctx->small_ws, need));
+        QK_HIP(hipMemsetAsync(ctx->small_ws, 0, need, ctx->stream));
+    }
+    SmallParams P;
+    P.c_vecs = (const float4 *)parent->vecs;
+    P.c_norms = parent->norms;
+    P.c_ids = parent->ids;
+    P.c_row0 = c_row0;
+    P.c_n = (int)c_n;
+    P.vecs = (const float4 *)s->vecs;
+    P.norms = s->norms;
+    P.ids = s->ids;
+    P.pt_off = s->d_off;
+    P.pt_size = s->d_size;
+    P.npids = (int)s->parts.size();
+    P.nblk = s->nblk;
+    P.d = s->d;
+    P.x = x;
+    P.nprobe = nprobe;
+    P.k = k;
+    P.metric = metric;
+    P.sqrt_l2 = sqrt_l2 ? 1 : 0;
+    P.W = W;
+    P.cap = cap;
+    P.out_ids = out_ids;
+    P.out_dist = out_dist;
+    char *b = ctx->small_ws;
+    P.rec_id = (int64_t *)b;
+    b += (size_t)64 * 64 * QK_SMALL_MAXK * 8;
+    P.rec_ord = (uint32_t *)b;
+    b += (size_t)64 * 64 * QK_SMALL_MAXK * 4;
+    P.rec_cnt = (int32_t *)b;
+    b += (size_t)64 * 64 * 4;
+    P.ticket = (unsigned int *)b;
+    static const bool probe_clock = qk_env_set("QK_SMALL_CLOCK");
+    static long long *d_clock = nullptr;
+    P.clock = nullptr;
+    if (probe_clock) {
+        if (!d_clock) QK_HIP(hipMalloc((void **)&d_clock, 64));
+        QK_HIP(hipMemsetAsync(d_clock, 0, 64, ctx->stream));
+        P.clock = d_clock;
+    }
+    const size_t lds = (size_t)s->dpad * 4 + (size_t)cap * 12 + (size_t)((c_n + 7) & ~7) * 12 + 64;
+    if (lds > 48 * 1024) QK_HIP(hipFuncSetAttribute((const void *)k_search_small, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_search_small, dim3((unsigned)(Q * W)), dim3(256), lds, ctx->stream, P);
+    QK_HIP(hipGetLastError());
+    if (probe_clock) {
+        long long h[8];
+        QK_HIP(hipMemcpyAsync(h, d_clock, 64, hipMemcpyDeviceToHost, ctx->stream));
+        QK_HIP(hipStreamSynchronize(ctx->stream));
+        fprintf(stderr, "[k_search_small] Q=%lld W=%d: workgroup 0 (10 ns ticks): query+keys %lld, select %lld, scan %lld, record+ticket %lld; "
+                "last workgroup %lld ended %lld after workgroup 0 started\n", (long long)Q, W, h[1] - h[0], h[2] - h[1], h[3] - h[2],
+                h[4] - h[3], h[6], h[5] - h[0]);
+    }
+    return QK_OK;
+}

@@ -501,6 +501,9 @@ int qk_store_build_csr(qk_store *s, int64_t nlist, const int64_t *offsets, const
     const int64_t *hid = ids;
     if (mem == QK_MEM_DEVICE && total > 0) {
         host_ids.resize(total);
+        // the caller's device arrays were produced on the context's stream (possibly a non-blocking one, which the
+        // synchronous copies below would not wait for)
+        QK_HIP(hipStreamSynchronize(c->stream));
         QK_HIP(hipMemcpy(host_ids.data(), ids, (size_t)total * sizeof(int64_t), hipMemcpyDeviceToHost));
         hid = host_ids.data();
     }

@@ -406,7 +406,6 @@ class QuakeIndex:
             raise RuntimeError("[PartitionManager] add: vector_ids must be unique.")
         if self._resident.any_present(idn):
             raise RuntimeError("[PartitionManager] init_partitions: vector ID already exists in the index.")
-        self._resident.update(idn)
         info.input_validation_time_us = _us(t0)
         t0 = time.perf_counter()
         xd = self._to_dev(x, torch.float32)
@@ -420,6 +419,7 @@ class QuakeIndex:
         info.find_partition_time_us = _us(t0)
         t0 = time.perf_counter()
         self._store.add_batch(idd, xd, assign.contiguous())  # per-list append order = input order (:245-258)
+        self._resident.update(idn)  # only once the device step succeeded: a failed add leaves no phantom ids behind
         info.modify_time_us = _us(t0)
         return info
 
@@ -568,19 +568,18 @@ class QuakeIndex:
         with open(os.path.join(dir_path, "metadata.txt"), "w") as f:
             f.write("metric=%d\nlevel=%d\nntotal=%d\nnlist=%d\n" % (self.metric_, self.current_level, self.ntotal(), self.nlist()))
         pids = [int(p) for p in self._store.list_ids()]
-        chunks, offsets, cur = [], [0], 0
-        for p in pids:
-            vecs, ids = self._store.get_list(p)
-            b = vecs.astype("<f4").tobytes() + ids.astype("<i8").tobytes()  # [codes | ids] per partition
-            chunks.append(b)
-            cur += len(b)
-            offsets.append(cur)
+        # header and offsets come from the partition sizes alone; the chunks are then streamed one partition at a time, so
+        # the host never holds more than one partition (10M x 768 would otherwise cost ~30 GB of RAM)
+        rec = self._d * 4 + 8
+        offsets = np.concatenate([[0], np.cumsum([self._store.list_size(p) * rec for p in pids])]).astype("<u8")
         with open(os.path.join(dir_path, "partitions"), "wb") as f:
             f.write(struct.pack("<IIQQQ", SERIALIZATION_MAGIC, SERIALIZATION_VERSION, len(pids), self._d * 4, len(pids)))
-            f.write(np.asarray(offsets, "<u8").tobytes())
+            f.write(offsets.tobytes())
             f.write(np.asarray(pids, "<u8").tobytes())
-            for b in chunks:
-                f.write(b)
+            for p in pids:
+                vecs, ids = self._store.get_list(p)
+                f.write(vecs.astype("<f4").tobytes())  # [codes | ids] per partition
+                f.write(ids.astype("<i8").tobytes())
         if self.parent is not None:
             self.parent.save(os.path.join(dir_path, "parent"))
 

@@ -26,7 +26,7 @@ def main():
     gi, _ = B.brute_force_topk(q, x, k)
     qh = q.cpu().numpy()
     out = {}
-    for Q in (1, 8, 64):
+    for Q in (1, 4, 16, 64):
         for mode in ("host", "device"):
             lat, hits = [], 0
             nrep = 400 if Q == 1 else 100
@@ -46,6 +46,12 @@ def main():
             out[f"Q{Q}_{mode}"] = {"mean_us": round(float(lat.mean()), 1), "p50_us": round(float(np.median(lat)), 1),
                                    "p99_us": round(float(np.percentile(lat, 99)), 1), "qps": round(Q / lat.mean() * 1e6, 1),
                                    "recall": round(hits / (nrep * Q * k), 4)}
+    # device time of one search from the library's own HIP events (no Python / launch-queue time)
+    ctx.set_timing(1)
+    for Q in (1, 4, 16, 64):
+        ts = [ctx.search(parent, store, q[i * Q:(i + 1) * Q], nprobe, k, "l2", timing=True)[2]["total_ms"] for i in range(20)]
+        out[f"Q{Q}_device_event_us"] = round(float(np.median(ts[5:])) * 1e3, 1)
+    ctx.set_timing(0)
     if not os.environ.get("LAT_NO_CPU"):
         import oracle as O
         hv, hi, hc = xs.cpu().numpy(), ids.cpu().numpy(), centroids.cpu().numpy()

@@ -84,3 +84,20 @@ def test_compiled_surface_builds_and_exposes_reference_names():
     assert (mp.window_size, mp.refinement_radius, mp.refinement_iterations, mp.min_partition_size) == (1000, 25, 3, 32)
     idx = b.QuakeIndex()
     assert idx.ntotal() == 0 and idx.nlist() == 0 and idx.parent is None and idx.current_level == 0
+
+
+def test_quake_package_alias():
+    """`import quake` (the reference's package name, src/python/__init__.py) gives the compiled surface; `quake._bindings` is
+    importable like upstream's extension module (wrap.cpp:48)."""
+    from quake_amd.build_ext import build_bindings
+    build_bindings()
+    import quake
+    from quake import _bindings
+    import quake._bindings as qb2
+    assert _bindings is qb2 and quake.QuakeIndex is _bindings.QuakeIndex
+    idx = quake.QuakeIndex()
+    assert idx.parent is None and idx.partition_manager is None and idx.query_coordinator is None and idx.ntotal() == 0
+    sp, bp = quake.SearchParams(), quake.IndexBuildParams()
+    assert (sp.k, sp.nprobe, sp.batched_scan, bp.nlist, bp.niter, bp.metric) == (1, 1, False, 0, 5, "l2")
+    for name in ("PartitionManager", "QueryCoordinator", "batched_scan_list", "MaintenancePolicyParams", "SearchResult"):
+        assert hasattr(_bindings, name), name

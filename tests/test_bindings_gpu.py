@@ -109,3 +109,93 @@ def test_bindings_recall_target_search(qb):
     np.testing.assert_array_equal(res[0][0], res[1][0])
     np.testing.assert_array_equal(res[0][1], res[1][1])
     assert res[0][2] == res[1][2] and res[0][2] >= 2 * 64
+
+
+def test_bindings_internal_seams(qb):
+    """The collaborators the reference's own tests reach into (test/cpp/quake_index.cpp:50-54, query_coordinator.cpp:42-254):
+    partition_manager / query_coordinator members, the three scan entry points (one device pipeline: identical results, like the
+    reference's worker-vs-serial equality test :201-254), padding when k exceeds what the scanned partitions hold (:309-371) and
+    with zero partitions (:459-497), and the list_scanning seam (batched_scan_list on a raw list, list_scanning.cpp:432-562)."""
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(4000, 16, generator=g)
+    ids = torch.arange(4000) + 100
+    q = torch.randn(12, 16, generator=g)
+    idx = qb.QuakeIndex()
+    assert idx.partition_manager is None and idx.query_coordinator is None  # ConstructorTest
+    bp = qb.IndexBuildParams()
+    bp.nlist = 8
+    idx.build(x, ids, bp)
+    pm, qc = idx.partition_manager, idx.query_coordinator
+    assert pm.ntotal() == 4000 and pm.nlist() == 8 and pm.d() == 16 and pm.validate()
+    pids = pm.get_partition_ids()
+    sizes = pm.get_partition_sizes(pids)
+    assert pids.tolist() == list(range(8)) and int(sizes.sum()) == 4000
+    assert sorted(pm.get_ids().tolist()) == ids.tolist()
+    sp = qb.SearchParams()
+    sp.k, sp.nprobe = 5, 3
+    a = idx.search(q, sp)
+    b = qc.search(q, sp)
+    np.testing.assert_array_equal(a.ids.numpy(), b.ids.numpy())
+    # scan_partitions with an explicit [Q, P] list == the three scan variants; -1 entries are skipped
+    probe = torch.tensor([[0, 3, -1]] * 12)
+    r0 = qc.scan_partitions(q, probe, sp)
+    for fn in (qc.serial_scan, qc.batched_serial_scan, qc.worker_scan):
+        r = fn(q, probe, sp)
+        np.testing.assert_array_equal(r.ids.numpy(), r0.ids.numpy())
+        np.testing.assert_array_equal(r.distances.numpy(), r0.distances.numpy())
+    # 1-D partition list = the same set for every query; k larger than the partitions hold -> -1 / inf padding
+    small = int(sizes[5])
+    sp2 = qb.SearchParams()
+    sp2.k = small + 3
+    r = qc.scan_partitions(q, torch.tensor([5]), sp2)
+    assert (r.ids[:, :small] >= 0).all() and (r.ids[:, small:] == -1).all() and torch.isinf(r.distances[:, small:]).all()
+    r = qc.scan_partitions(q, torch.empty((12, 0), dtype=torch.int64), sp)  # zero partitions
+    assert (r.ids == -1).all() and torch.isinf(r.distances).all()
+    assert qc.search(torch.empty(0, 16), sp).ids.numel() == 0
+    # list_scanning seam: a raw list against torch brute force (ids equal, distances within 1e-4)
+    lv = torch.randn(1000, 16, generator=g)
+    lid = torch.arange(1000) * 3
+    for metric in ("l2", "ip"):
+        gi, gd = qb.batched_scan_list(q, lv, lid, 10, metric)
+        if metric == "l2":
+            t = torch.topk(torch.cdist(q.double(), lv.double()), 10, dim=1, largest=False)
+        else:
+            t = torch.topk(q.double() @ lv.double().T, 10, dim=1, largest=True)
+        np.testing.assert_array_equal(gi.numpy(), lid[t.indices].numpy())
+        np.testing.assert_allclose(gd.numpy(), t.values.numpy(), atol=1e-4)
+    gi, gd = qb.batched_scan_list(q, lv[:4], torch.empty(0, dtype=torch.int64), 10, "l2")  # no ids: row numbers; fewer than k
+    assert sorted(gi[0, :4].tolist()) == [0, 1, 2, 3] and (gi[:, 4:] == -1).all()
+
+
+def test_bindings_compiled_maintenance(qb):
+    """maintenance() in the compiled mirror runs the policy (hit window -> split hot / delete cold partitions -> refine): after it,
+    every vector is still resident exactly once and exhaustive search stays exact."""
+    g = torch.Generator().manual_seed(41)
+    cent = torch.randn(12, 16, generator=g) * 4
+    x = cent[torch.randint(0, 12, (6000,), generator=g)] + torch.randn(6000, 16, generator=g)
+    ids = torch.arange(6000)
+    idx = qb.QuakeIndex()
+    bp = qb.IndexBuildParams()
+    bp.nlist = 12
+    idx.build(x, ids, bp)
+    assert idx.maintenance().n_splits == 0  # window not full: nothing happens (maintenance_policies.cpp:36-41)
+    mp = qb.MaintenancePolicyParams()
+    mp.window_size = 64
+    mp.refinement_radius = 4
+    mp.refinement_iterations = 1
+    mp.split_threshold_ns = 0.0
+    mp.delete_threshold_ns = 0.0
+    idx.initialize_maintenance_policy(mp)
+    idx.set_track_hits(True)
+    sp = qb.SearchParams()
+    sp.k, sp.nprobe = 5, 2
+    hot = x[:128] + 0.01 * torch.randn(128, 16, generator=g)
+    for i in range(0, 128, 32):
+        idx.search(hot[i:i + 32], sp)
+    info = idx.maintenance()
+    assert info.n_splits + info.n_deletes >= 0 and info.total_time_us >= 0
+    assert idx.ntotal() == 6000 and sorted(idx.get_ids().tolist()) == ids.tolist()
+    assert idx.partition_manager.validate() and idx.parent.ntotal() == idx.nlist()
+    sp.nprobe = idx.nlist()
+    r = idx.search(x[:50], sp)
+    assert (r.ids[:, 0] == ids[:50]).all()  # every vector finds itself

@@ -132,7 +132,7 @@ def test_large_flat_list_vs_torch_bruteforce(ctx):
 
 
 def test_large_k_and_limits(ctx):
-    """k up to QK_MAX_K goes through the multi-chunk pools, up to 4096 through key emission + selection; beyond that the call
+    """k up to QK_MAX_K goes through the multi-chunk pools, up to 8192 (the reference's buffer capacity) through key emission + selection; beyond that the call
     fails loudly (no silent truncation)."""
     from quake_amd._lib import QK_MAX_K, QuakeHipError
     ivf = make_ivf(6000, 48, 6, seed=31)
@@ -144,8 +144,8 @@ def test_large_k_and_limits(ctx):
         np.testing.assert_array_equal(gi, oi)
         np.testing.assert_array_equal(gd.view(np.uint32), od.view(np.uint32))
     # beyond QK_MAX_K the keys are emitted and selected afterwards (k_scan MODE 4 + k_select_pairs_large): same answers
-    for k, metric_ in ((QK_MAX_K + 1, "l2"), (1000, "l2"), (777, "ip"), (4096, "l2")):
-        iv = make_ivf(6000, 48, 6, seed=33, metric=metric_)
+    for k, metric_ in ((QK_MAX_K + 1, "l2"), (1000, "l2"), (777, "ip"), (4096, "l2"), (8192, "ip")):
+        iv = make_ivf(16000 if k > 4096 else 6000, 48, 6, seed=33, metric=metric_)
         vecs = iv["vecs"].copy()
         a0, a1 = int(iv["offsets"][1]), int(iv["offsets"][2])
         vecs[a0 + 50:a0 + 100] = vecs[a0:a0 + 50]  # duplicates inside a list: ties ordered by id
@@ -165,7 +165,49 @@ def test_large_k_and_limits(ctx):
     np.testing.assert_array_equal(gi, oi)
     np.testing.assert_array_equal(gd.view(np.uint32), od.view(np.uint32))
     with pytest.raises(QuakeHipError):
-        ctx.search(parent, s, q, 6, 4097, "l2")
+        ctx.search(parent, s, q, 6, 8193, "l2")
+
+
+@pytest.mark.parametrize("metric", ["l2", "ip"])
+def test_small_batches_one_launch_search(ctx, metric):
+    """Q <= 16 with a flat parent goes through the one-launch search (qk_small.hip): coarse + selection + scan + merge in one
+    kernel.  Same bits as the oracle for every (Q, nprobe, k), with an empty list, a list shorter than k, duplicated
+    centroids (a tie that straddles the nprobe cut: ordered by partition id) and duplicated rows (ties ordered by id)."""
+    ivf = make_ivf(30000, 96, 40, seed=41, metric=metric, empty=(7,))
+    cent = ivf["centroids"].copy()
+    cent[11] = cent[3]
+    cent[12] = cent[3]
+    cent[30] = cent[3]  # four identical centroids: whichever queries are near them see a 4-way tie in the coarse keys
+    vecs = ivf["vecs"].copy()
+    a0 = int(ivf["offsets"][3])
+    vecs[a0 + 20:a0 + 40] = vecs[a0:a0 + 20]
+    from quake_amd.capi import Store
+    s = Store(ctx, 96)
+    s.build_csr(ivf["offsets"], ivf["ids"], vecs)
+    parent = Store(ctx, 96)
+    parent.build_csr(np.array([0, 40], np.int64), np.arange(40, dtype=np.int64), cent)
+    q = make_queries(16, 96, seed=42, like=ivf["x"], metric=metric)
+    q[5] = vecs[a0 + 3]  # sits on a duplicated row of list 3 (and next to the duplicated centroids)
+    for Q in (1, 3, 16):
+        for nprobe, k in ((1, 1), (2, 10), (3, 10), (10, 10), (40, 32), (64, 5)):
+            gi, gd = ctx.search(parent, s, q[:Q], nprobe, k, metric)
+            oi, od = O.search(q[:Q], cent, vecs, ivf["ids"], ivf["offsets"], nprobe, k, metric, batched_scan=True)
+            np.testing.assert_array_equal(gi, oi, err_msg=f"Q={Q} nprobe={nprobe} k={k}")
+            np.testing.assert_array_equal(gd.view(np.uint32), od.view(np.uint32))
+    # device buffers, and a tiny index where every list is shorter than k
+    import torch
+    qd = torch.from_numpy(q[:4]).cuda()
+    gi, gd = ctx.search(parent, s, qd, 10, 10, metric)
+    oi, od = O.search(q[:4], cent, vecs, ivf["ids"], ivf["offsets"], 10, 10, metric, batched_scan=True)
+    np.testing.assert_array_equal(gi.cpu().numpy(), oi)
+    np.testing.assert_array_equal(gd.cpu().numpy().view(np.uint32), od.view(np.uint32))
+    tiny = make_ivf(30, 96, 8, seed=43, metric=metric)
+    pt, st = build_stores(ctx, tiny)
+    gi, gd = ctx.search(pt, st, q[:2], 3, 20, metric)
+    oi, od = O.search(q[:2], tiny["centroids"], tiny["vecs"], tiny["ids"], tiny["offsets"], 3, 20, metric, batched_scan=True)
+    np.testing.assert_array_equal(gi, oi)
+    np.testing.assert_array_equal(gd.view(np.uint32), od.view(np.uint32))
+    assert (gi == -1).any()
 
 
 def test_wide_k_with_timing_on_a_fresh_context():
