@@ -533,8 +533,10 @@ def run_sharded(ctx, dev, args, dist, rank, world):
         _, j = torch.topk(cd, k, dim=1, largest=False)
         gts.append(torch.gather(ci, 1, j)[rank * per:(rank + 1) * per])
     del x_local
-    out_i = torch.empty((per, k), dtype=torch.int64, device=dev)
-    out_d = torch.empty((per, k), dtype=torch.float32, device=dev)
+    # scratch of the LOCAL scan (every rank scans the whole batch against the lists it owns: [Q, k]); the merged answer of
+    # this rank's slice comes back from search() as [Q / N, k]
+    out_i = torch.empty((Q, k), dtype=torch.int64, device=dev)
+    out_d = torch.empty((Q, k), dtype=torch.float32, device=dev)
     sharded = ShardedIndex(GpuEngine(ctx, parent, store, metric), dist, world, rank, result="owner")
 
     def step(nprobe, b):

@@ -60,6 +60,7 @@ __device__ __forceinline__ uint32_t small_row_key(const float4 *vecs, const floa
     const int64_t tile = row >> 4;
     const int r = (int)(row & 15);
     const float4 *base = vecs + tile * nblk * 64 + r;
+    const float yn = l2 ? norms[row] : 0.0f;  // requested with the row data, not after the chain
     float acc = 0.0f;
     for (int c0 = 0; c0 < nblk; c0 += 8) {
         float4 v[8][4];
@@ -88,7 +89,48 @@ __device__ __forceinline__ uint32_t small_row_key(const float4 *vecs, const floa
             }
         }
     }
-    return l2 ? ord_from_l2(l2_expanded(xn, norms[row], acc)) : ord_from_ip(acc);
+    return l2 ? ord_from_l2(l2_expanded(xn, yn, acc)) : ord_from_ip(acc);
+}
+
+// two rows at once (d <= 128 per pass: both rows' 32 float4 are requested before either chain starts)
+__device__ __forceinline__ void small_row_key2(const float4 *vecs, const float *norms, int nblk, int64_t rowa, int64_t rowb, const float *sq,
+                                               float xn, bool l2, uint32_t &ka, uint32_t &kb) {
+    const float4 *ba = vecs + (rowa >> 4) * nblk * 64 + (int)(rowa & 15);
+    const float4 *bb = vecs + (rowb >> 4) * nblk * 64 + (int)(rowb & 15);
+    const float yna = l2 ? norms[rowa] : 0.0f, ynb = l2 ? norms[rowb] : 0.0f;
+    float acca = 0.0f, accb = 0.0f;
+    for (int c0 = 0; c0 < nblk; c0 += 4) {
+        float4 va[4][4], vb[4][4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const int cc = min(c0 + c, nblk - 1);
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                va[c][g] = ba[cc * 64 + g * 16];
+                vb[c][g] = bb[cc * 64 + g * 16];
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            if (c0 + c < nblk) {
+                const float4 *q4 = (const float4 *)(sq + (c0 + c) * 16);
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    const float4 qq = q4[t];
+                    const float qv[4] = {qq.x, qq.y, qq.z, qq.w};
+#pragma unroll
+                    for (int g = 0; g < 4; g++) {
+                        const float ea = t == 0 ? va[c][g].x : t == 1 ? va[c][g].y : t == 2 ? va[c][g].z : va[c][g].w;
+                        const float eb = t == 0 ? vb[c][g].x : t == 1 ? vb[c][g].y : t == 2 ? vb[c][g].z : vb[c][g].w;
+                        acca = __fmaf_rn(ea, qv[g], acca);
+                        accb = __fmaf_rn(eb, qv[g], accb);
+                    }
+                }
+            }
+        }
+    }
+    ka = l2 ? ord_from_l2(l2_expanded(xn, yna, acca)) : ord_from_ip(acca);
+    kb = l2 ? ord_from_l2(l2_expanded(xn, ynb, accb)) : ord_from_ip(accb);
 }
 
 // block-wide sum of one int per thread (256 threads)
@@ -102,11 +144,72 @@ __device__ __forceinline__ int small_block_sum(int v, int *s_red /*[4]*/) {
     return s_red[0] + s_red[1] + s_red[2] + s_red[3];
 }
 
+constexpr int QK_SMALL_THREADS = 512;  // 8 waves: two per SIMD
+constexpr int QK_SMALL_NW = QK_SMALL_THREADS / 64;
+
+template <int MAXCH>
+__device__ __forceinline__ int small_select_t(uint32_t *ord, int64_t *id, int n, int k, int lane) {
+    uint32_t kth;
+    return select_pool<MAXCH>(ord, id, n, k, lane, kth);
+}
+__device__ __forceinline__ int small_select(uint32_t *ord, int64_t *id, int n, int k, int lane, int span) {
+    if (span <= 64) return small_select_t<1>(ord, id, n, k, lane);
+    if (span <= 128) return small_select_t<2>(ord, id, n, k, lane);
+    if (span <= 256) return small_select_t<4>(ord, id, n, k, lane);
+    if (span <= 512) return small_select_t<8>(ord, id, n, k, lane);
+    return small_select_t<16>(ord, id, n, k, lane);
+}
+__device__ __forceinline__ int small_sort(uint32_t *ord, int64_t *id, int n, int k, int lane) {
+    if (n <= 64) return compact_pool<1>(ord, id, n, k, lane);
+    if (n <= 128) return compact_pool<2>(ord, id, n, k, lane);
+    if (n <= 256) return compact_pool<4>(ord, id, n, k, lane);
+    return compact_pool<8>(ord, id, n, k, lane);
+}
+
+// The k best of the n entries (ord, id) in LDS, sorted under (key, id), left in [0, min(n, k)).  A single wave selecting among
+// hundreds of entries is a long serial chain of ballots (measured 6-10 us per use at 2.4 GHz); here every wave of the
+// workgroup selects inside its own chunk (<= 64 entries where possible: 32 ballots) and wave 0 merges the <= 8 k survivors.
+// Exact: selection and sort are select_pool / compact_pool (ties on the cut by id).  n <= 8192, k <= 64.  Uniform return value;
+// contains barriers.
+__device__ __forceinline__ int block_topk(uint32_t *ord, int64_t *id, int n, int k, uint32_t *tmp_ord, int64_t *tmp_id, int *s_got) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nchunks = max(1, min(QK_SMALL_NW, (n + 63) >> 6));
+    const int per = (n + nchunks - 1) / nchunks;
+    int got = 0;
+    if (wave < nchunks) {
+        const int b0 = wave * per, nw = max(0, min(per, n - b0));
+        if (nw > 0) got = small_select(ord + b0, id + b0, nw, k, lane, per);
+    }
+    if (lane == 0) s_got[wave] = got;
+    __syncthreads();
+    if (wave == 0) {
+        int m = 0;
+        for (int c = 0; c < nchunks; c++) {
+            const int g = s_got[c];
+            for (int e = lane; e < g; e += 64) {
+                tmp_ord[m + e] = ord[c * per + e];
+                tmp_id[m + e] = id[c * per + e];
+            }
+            m += g;
+        }
+        const int nn = small_sort(tmp_ord, tmp_id, m, k, lane);  // m <= 8 k <= 512
+        for (int e = lane; e < nn; e += 64) {
+            ord[e] = tmp_ord[e];
+            id[e] = tmp_id[e];
+        }
+        if (lane == 0) s_got[0] = nn;
+    }
+    __syncthreads();
+    const int res = s_got[0];
+    __syncthreads();
+    return res;
+}
+
 constexpr int QK_SMALL_MAXP = 64;    // nprobe
 constexpr int QK_SMALL_CPT = 16;     // centroids per thread (256 threads): nlist <= 4096
 constexpr int QK_SMALL_MAXK = 32;
 
-__global__ __launch_bounds__(256) void k_search_small(SmallParams P) {
+__global__ __launch_bounds__(QK_SMALL_THREADS) void k_search_small(SmallParams P) {
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ int s_red[4];
     __shared__ int64_t s_pid[QK_SMALL_MAXP];      // the probe list (rank order) ...
@@ -116,6 +219,7 @@ __global__ __launch_bounds__(256) void k_search_small(SmallParams P) {
     __shared__ int64_t s_off[QK_SMALL_MAXP];
     __shared__ int s_last;
     __shared__ uint32_t s_kth;
+    __shared__ int s_rcnt[65];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q = blockIdx.x / P.W, w = blockIdx.x % P.W;
     const bool l2 = P.metric == QK_METRIC_L2;
@@ -125,71 +229,80 @@ __global__ __launch_bounds__(256) void k_search_small(SmallParams P) {
     uint32_t *pool_ord = (uint32_t *)(pool_id + P.cap);         // [cap]
     uint32_t *s_ck = pool_ord + P.cap;                          // [c_n] coarse keys ...
     int64_t *s_cid = (int64_t *)(s_ck + ((P.c_n + 7) & ~7));    // [c_n] ... and the partition ids that go with them
-    __shared__ uint32_t s_mord[4 * QK_SMALL_MAXP];
-    __shared__ int64_t s_mid[4 * QK_SMALL_MAXP];
+    __shared__ uint32_t s_mord[QK_SMALL_NW * QK_SMALL_MAXP];  // block_topk scratch
+    __shared__ int64_t s_mid[QK_SMALL_NW * QK_SMALL_MAXP];
+    __shared__ int s_got[QK_SMALL_NW];
 
+    const long long cy0 = P.clock ? clock64() : 0;
     if (P.clock && tid == 0 && blockIdx.x == 0) P.clock[0] = wall_clock64();
     // ---- the query -----------------------------------------------------------------------------------------------------
-    for (int c = tid; c < dpad; c += 256) sq[c] = c < P.d ? P.x[(int64_t)q * P.d + c] : 0.0f;
+    for (int c = tid; c < dpad; c += QK_SMALL_THREADS) sq[c] = c < P.d ? P.x[(int64_t)q * P.d + c] : 0.0f;
     __syncthreads();
     float xn = 0.0f;
-    if (l2)
-        for (int c = 0; c < P.d; c++) xn = __fmaf_rn(sq[c], sq[c], xn);  // canonical |x|^2 (every thread: LDS broadcast reads)
+    if (l2) {  // canonical |x|^2, every thread for itself: broadcast ds_read_b128, four columns per read (padding columns are 0)
+        const float4 *sq4 = (const float4 *)sq;
+#pragma unroll 8
+        for (int c = 0; c < dpad / 4; c++) {
+            const float4 v = sq4[c];
+            xn = __fmaf_rn(v.x, v.x, xn);
+            xn = __fmaf_rn(v.y, v.y, xn);
+            xn = __fmaf_rn(v.z, v.z, xn);
+            xn = __fmaf_rn(v.w, v.w, xn);
+        }
+    }
 
     // ---- A. coarse: keys of this thread's centroids (kept in LDS), then the nprobe smallest under (key, id) -------------------
-    for (int r = tid; r < P.c_n; r += 256) s_ck[r] = small_row_key(P.c_vecs, P.c_norms, P.nblk, P.c_row0 + r, sq, xn, l2);
+    // (two centroid rows per thread in flight: the chain of one hides the load latency of the other)
+    for (int r = tid; r < P.c_n; r += 2 * QK_SMALL_THREADS) {
+        const int r2 = r + QK_SMALL_THREADS;
+        uint32_t k1, k2 = 0;
+        if (r2 < P.c_n) {
+            small_row_key2(P.c_vecs, P.c_norms, P.nblk, P.c_row0 + r, P.c_row0 + r2, sq, xn, l2, k1, k2);
+            s_ck[r2] = k2;
+        } else {
+            k1 = small_row_key(P.c_vecs, P.c_norms, P.nblk, P.c_row0 + r, sq, xn, l2);
+        }
+        s_ck[r] = k1;
+    }
     __syncthreads();
     if (P.clock && tid == 0 && blockIdx.x == 0) P.clock[1] = wall_clock64();
     const int want = min(P.nprobe, P.c_n);
-    // Selection without block barriers: every wave keeps the `want` best of its quarter of the centroids (bisection select on
-    // registers, select_pool; exact under (key, id), ties on the cut included), wave 0 then takes the `want` best of the four.
-    {
-        const int per = (P.c_n + 3) >> 2;                 // <= 1024
-        const int b0 = wave * per, n_w = max(0, min(per, P.c_n - b0));
-        for (int r = lane; r < n_w; r += 64) s_cid[b0 + r] = P.c_ids[P.c_row0 + b0 + r];
-        uint32_t kth;
-        int got = 0;
-        if (n_w > 0) {
-            if (per <= 256)
-                got = select_pool<4>(s_ck + b0, s_cid + b0, n_w, want, lane, kth);
-            else
-                got = select_pool<16>(s_ck + b0, s_cid + b0, n_w, want, lane, kth);
-        }
-        if (lane == 0) s_red[wave] = got;
-    }
+    // the `want` nearest under (key, partition id), in rank order
+    for (int r = tid; r < P.c_n; r += QK_SMALL_THREADS) s_cid[r] = P.c_ids[P.c_row0 + r];
     __syncthreads();
-    if (wave == 0) {
-        int n = 0;
-        for (int ww = 0; ww < 4; ww++) {
-            const int got = s_red[ww], b0 = ww * ((P.c_n + 3) >> 2);
-            for (int e = lane; e < got; e += 64) {
-                s_mord[n + e] = s_ck[b0 + e];
-                s_mid[n + e] = s_cid[b0 + e];
-            }
-            n += got;
+    {
+        const int nn = block_topk(s_ck, s_cid, P.c_n, want, s_mord, s_mid, s_got);
+        for (int e = tid; e < nn; e += QK_SMALL_THREADS) {
+            s_pord[e] = s_ck[e];
+            s_pid[e] = s_cid[e];
         }
-        const int nn = compact_pool<4>(s_mord, s_mid, n, want, lane);  // n <= 4 * 64; sorted: the probe list in rank order
-        for (int e = lane; e < nn; e += 64) {
-            s_pord[e] = s_mord[e];
-            s_pid[e] = s_mid[e];
-        }
-        if (lane == 0) s_np = nn;
+        if (tid == 0) s_np = nn;
     }
     if (P.clock && tid == 0 && blockIdx.x == 0) P.clock[2] = wall_clock64();
     __syncthreads();
     const int np = min(s_np, QK_SMALL_MAXP);
     // ---- B. this workgroup's slice of the probed rows -----------------------------------------------------------------------
-    if (tid == 0) {
-        long long run = 0;
-        for (int i = 0; i < np; i++) {
-            const int64_t p = s_pid[i];
-            int sz = 0;
-            if (p >= 0 && p < P.npids) sz = max(P.pt_size[p], 0);  // absent lists have size -1
-            s_pre[i] = run;
-            s_off[i] = sz > 0 ? P.pt_off[p] : 0;
-            run += sz;
+    if (tid < 64) {  // wave 0: sizes and offsets of the np <= 64 probed partitions in ONE round trip, then a wave prefix sum
+        int sz = 0;
+        int64_t off = 0;
+        if (tid < np) {
+            const int64_t p = s_pid[tid];
+            if (p >= 0 && p < P.npids) {
+                sz = max(P.pt_size[p], 0);  // absent lists have size -1
+                off = P.pt_off[p];
+            }
         }
-        s_pre[np] = run;
+        long long inc = sz;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const long long v = __shfl_up(inc, o);
+            if (lane >= o) inc += v;
+        }
+        if (tid < np) {
+            s_pre[tid] = inc - sz;
+            s_off[tid] = sz > 0 ? off : 0;
+        }
+        if (tid == max(np, 1) - 1) s_pre[np] = np > 0 ? inc : 0;
     }
     __syncthreads();
     const long long R = s_pre[np];
@@ -203,9 +316,9 @@ __global__ __launch_bounds__(256) void k_search_small(SmallParams P) {
         const long long end = min(hi, base + per_round);
         if (tid == 0) s_fill = cnt;
         __syncthreads();
-        const int iters = (int)((end - base + 255) / 256);
+        const int iters = (int)((end - base + QK_SMALL_THREADS - 1) / QK_SMALL_THREADS);
         for (int it = 0; it < iters; it++) {
-            const long long g = base + tid + 256 * (long long)it;
+            const long long g = base + tid + QK_SMALL_THREADS * (long long)it;
             bool pass = false;
             uint32_t key = 0xFFFFFFFFu;
             int64_t id = -1;
@@ -213,8 +326,8 @@ __global__ __launch_bounds__(256) void k_search_small(SmallParams P) {
                 int pi = 0;
                 while (pi + 1 < np && s_pre[pi + 1] <= g) pi++;
                 const int64_t row = s_off[pi] + (g - s_pre[pi]);
+                id = P.ids[row];  // (requested before the row data: one round trip, not two)
                 key = small_row_key(P.vecs, P.norms, P.nblk, row, sq, xn, l2);
-                id = P.ids[row];
                 pass = key != 0xFFFFFFFFu && key <= tau;
             }
             const uint64_t m = __ballot(pass);
@@ -231,22 +344,10 @@ __global__ __launch_bounds__(256) void k_search_small(SmallParams P) {
         }
         __syncthreads();
         cnt = s_fill;
-        if (cnt > k || end >= hi) {  // keep the k best (sorted at the end of the slice)
-            if (wave == 0) {
-                uint32_t kth = 0xFFFFFFFFu;
-                int nn;
-                if (end >= hi)
-                    nn = cnt <= 256 ? compact_pool<4>(pool_ord, pool_id, cnt, k, lane) : compact_pool<16>(pool_ord, pool_id, cnt, k, lane);
-                else
-                    nn = select_pool<16>(pool_ord, pool_id, cnt, k, lane, kth);
-                if (lane == 0) {
-                    s_fill = nn;
-                    s_kth = (nn >= k && end < hi) ? kth : 0xFFFFFFFFu;
-                }
-            }
-            __syncthreads();
-            cnt = s_fill;
-            tau = min(tau, s_kth);
+        __syncthreads();
+        if (cnt > k || end >= hi) {  // keep the k best, sorted; their k-th key bounds the next round
+            cnt = block_topk(pool_ord, pool_id, cnt, k, s_mord, s_mid, s_got);
+            if (cnt >= k) tau = min(tau, pool_ord[k - 1]);
             __syncthreads();
         }
     }
@@ -254,7 +355,7 @@ __global__ __launch_bounds__(256) void k_search_small(SmallParams P) {
     if (P.clock && tid == 0 && blockIdx.x == 0) P.clock[3] = wall_clock64();
     // ---- C. record, ticket, merge by the last arriver -----------------------------------------------------------------------
     const int64_t rbase = ((int64_t)q * P.W + w) * k;
-    for (int e = tid; e < cnt; e += 256) {
+    for (int e = tid; e < cnt; e += QK_SMALL_THREADS) {
         P.rec_ord[rbase + e] = pool_ord[e];
         P.rec_id[rbase + e] = pool_id[e];
     }
@@ -271,35 +372,39 @@ __global__ __launch_bounds__(256) void k_search_small(SmallParams P) {
         }
     }
     __syncthreads();
-    if (P.clock && tid == 0 && blockIdx.x == 0) P.clock[4] = wall_clock64();
+    if (P.clock && tid == 0 && blockIdx.x == 0) {
+        P.clock[4] = wall_clock64();
+        P.clock[7] = clock64() - cy0;
+    }
     if (!s_last) return;
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     if (tid == 0) s_fill = 0;
     __syncthreads();
-    for (int ww = wave; ww < P.W; ww += 4) {  // one wave per record (k <= 32 <= 64 lanes)
-        const int n = P.rec_cnt[q * P.W + ww];
-        const bool has = lane < n;
-        uint32_t o = 0xFFFFFFFFu;
-        int64_t id = -1;
-        if (has) {
-            o = __hip_atomic_load(&P.rec_ord[((int64_t)q * P.W + ww) * k + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            id = __hip_atomic_load(&P.rec_id[((int64_t)q * P.W + ww) * k + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // the W records: their counts in one round trip (threads 0..W-1), then every entry of every record in a second one
+    if (tid < P.W) s_rcnt[tid] = __hip_atomic_load(&P.rec_cnt[q * P.W + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int ww = 0; ww < P.W; ww++) {
+            const int c = s_rcnt[ww];
+            s_rcnt[ww] = run;
+            run += c;
         }
-        const uint64_t m = __ballot(has);
-        if (m) {
-            int at = 0;
-            if (lane == 0) at = atomicAdd(&s_fill, __popcll(m));
-            at = __builtin_amdgcn_readfirstlane(at);
-            if (has) {
-                pool_ord[at + lane] = o;
-                pool_id[at + lane] = id;
-            }
-        }
+        s_rcnt[P.W] = run;
+        s_fill = run;
+    }
+    __syncthreads();
+    for (int e = tid; e < s_rcnt[P.W]; e += QK_SMALL_THREADS) {
+        int ww = 0;
+        while (ww + 1 < P.W && s_rcnt[ww + 1] <= e) ww++;
+        const int64_t src = ((int64_t)q * P.W + ww) * k + (e - s_rcnt[ww]);
+        pool_ord[e] = __hip_atomic_load(&P.rec_ord[src], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        pool_id[e] = __hip_atomic_load(&P.rec_id[src], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
     const int total = s_fill;  // <= W * k <= cap
+    const int nn = block_topk(pool_ord, pool_id, total, k, s_mord, s_mid, s_got);
     if (wave == 0) {
-        const int nn = total <= 256 ? compact_pool<4>(pool_ord, pool_id, total, k, lane) : compact_pool<16>(pool_ord, pool_id, total, k, lane);
         for (int e = lane; e < k; e += 64) {
             int64_t oid = -1;
             float od = l2 ? INFINITY : -INFINITY;
@@ -331,7 +436,7 @@ bool qk_small_supported(qk_ctx *ctx, qk_store *parent, qk_store *s, int64_t Q, i
     static const int max_q = qk_env_int("QK_SMALL_MAX_Q", 6);  // measured (1M x 128, nprobe 10): 1 query 62 vs 95 us, 4: 68 vs 100, 16: 129 vs 111
     if (!enabled || !parent || Q <= 0 || Q > std::min(64, max_q)) return false;
     if (k > QK_SMALL_MAXK || nprobe > QK_SMALL_MAXP || nprobe <= 0) return false;
-    if (parent->nlist != 1 || parent->ntotal <= 0 || parent->ntotal > 256 * QK_SMALL_CPT) return false;
+    if (parent->nlist != 1 || parent->ntotal <= 0 || parent->ntotal > 256 * QK_SMALL_CPT) return false;  // <= 4096 centroids
     if (parent->min_id_seen < 0 || parent->d != s->d) return false;
     if ((size_t)s->dpad * 4 + 1024 * 12 + (size_t)parent->ntotal * 12 + 8192 > 160 * 1024) return false;
     return true;
@@ -400,15 +505,15 @@ int qk_search_small_device(qk_ctx *ctx, qk_store *parent, qk_store *s, const flo
     }
     const size_t lds = (size_t)s->dpad * 4 + (size_t)cap * 12 + (size_t)((c_n + 7) & ~7) * 12 + 64;
     if (lds > 48 * 1024) QK_HIP(hipFuncSetAttribute((const void *)k_search_small, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_search_small, dim3((unsigned)(Q * W)), dim3(256), lds, ctx->stream, P);
+    hipLaunchKernelGGL(k_search_small, dim3((unsigned)(Q * W)), dim3(QK_SMALL_THREADS), lds, ctx->stream, P);
     QK_HIP(hipGetLastError());
     if (probe_clock) {
         long long h[8];
         QK_HIP(hipMemcpyAsync(h, d_clock, 64, hipMemcpyDeviceToHost, ctx->stream));
         QK_HIP(hipStreamSynchronize(ctx->stream));
         fprintf(stderr, "[k_search_small] Q=%lld W=%d: workgroup 0 (10 ns ticks): query+keys %lld, select %lld, scan %lld, record+ticket %lld; "
-                "last workgroup %lld ended %lld after workgroup 0 started\n", (long long)Q, W, h[1] - h[0], h[2] - h[1], h[3] - h[2],
-                h[4] - h[3], h[6], h[5] - h[0]);
+                "last workgroup %lld ended %lld after workgroup 0 started; shader clock %.2f GHz\n", (long long)Q, W, h[1] - h[0], h[2] - h[1], h[3] - h[2],
+                h[4] - h[3], h[6], h[5] - h[0], h[4] > h[0] ? (double)h[7] / (double)(h[4] - h[0]) * 0.1 : 0.0);
     }
     return QK_OK;
 }
