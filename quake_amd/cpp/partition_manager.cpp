@@ -19,18 +19,27 @@ using clk = std::chrono::high_resolution_clock;
 inline int us_since(clk::time_point t0) { return (int)std::chrono::duration_cast<std::chrono::microseconds>(clk::now() - t0).count(); }
 }  // namespace
 
+size_t DynamicInvertedLists::list_size(size_t list_no) const {
+    int64_t sz = 0;
+    qk_check(qk_store_list_size(s_, (int64_t)list_no, &sz));
+    return (size_t)sz;
+}
+
 PartitionManager::PartitionManager() = default;
 
 PartitionManager::~PartitionManager() {
+    partition_store_ = nullptr;
     if (store_) qk_store_destroy(store_);
     store_ = nullptr;
 }
 
 void PartitionManager::reset_store(int d) {
     ctx_ = qk_device_context(0);
+    partition_store_ = nullptr;
     if (store_) qk_store_destroy(store_);
     store_ = nullptr;
     qk_check(qk_store_create(ctx_, d, &store_));
+    partition_store_ = std::make_shared<DynamicInvertedLists>(store_, (size_t)d * 4);
     d_ = d;
     resident_ids_.clear();
     core_of_.clear();

@@ -15,9 +15,24 @@ namespace quake_amd {
 
 class QuakeIndex;
 
+// What the reference exposes as PartitionManager::partition_store_ (faiss::DynamicInvertedLists, dynamic_inverted_list.h:25-33;
+// its tests read list sizes through it, test/cpp/partition_manager.cpp:203-248): here a read-only view of the device store.
+class DynamicInvertedLists {
+public:
+    explicit DynamicInvertedLists(qk_store *s, size_t code_size) : code_size(code_size), s_(s) {}
+    size_t list_size(size_t list_no) const;  // throws like the reference when the list does not exist (:68-74)
+    size_t ntotal() const { return (size_t)qk_store_ntotal(s_); }
+    size_t get_nlist() const { return (size_t)qk_store_nlist(s_); }
+    size_t code_size;  // bytes per vector (d * 4)
+
+private:
+    qk_store *s_;
+};
+
 class PartitionManager {
 public:
     shared_ptr<QuakeIndex> parent_ = nullptr;  // index over the centroids (partition_manager.h:27)
+    shared_ptr<DynamicInvertedLists> partition_store_ = nullptr;  // view of the device store (partition_manager.h:28)
     int64_t curr_partition_id_ = 0;            // next partition id to hand out
     bool debug_ = false;
     bool check_uniques_ = false;

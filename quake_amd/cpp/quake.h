@@ -4,7 +4,26 @@
 #pragma once
 #include "quake_index.h"
 
+#include <chrono>
+#include <string>
+#include <tuple>
+#include <unordered_map>
+#include <vector>
+
 using namespace quake_amd;  // the reference declares its classes at global scope
+// the unqualified std names the reference's common.h brings in (common.h:49-61)
+using std::make_shared;
+using std::shared_ptr;
+using std::size_t;
+using std::string;
+using std::tuple;
+using std::unordered_map;
+using std::vector;
+using std::chrono::duration_cast;
+using std::chrono::high_resolution_clock;
+using std::chrono::microseconds;
+using std::chrono::milliseconds;
+using std::chrono::nanoseconds;
 namespace faiss {
 using MetricType = quake_amd::MetricType;
 constexpr MetricType METRIC_INNER_PRODUCT = quake_amd::METRIC_INNER_PRODUCT;
