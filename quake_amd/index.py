@@ -192,6 +192,14 @@ class _ResidentIds:
         else:
             self._map[ids] = False
 
+    def discard_present(self, ids):
+        """forget the ids that are here, ignore the others (a shard is handed the whole remove batch)"""
+        if self._set is not None:
+            self._set.difference_update(ids.tolist())
+        else:
+            ids = ids[(ids >= 0) & (ids < self._map.shape[0])]
+            self._map[ids] = False
+
     def __contains__(self, v):
         if self._set is not None:
             return v in self._set
@@ -302,6 +310,36 @@ class QuakeIndex:
         self.initialize_maintenance_policy(MaintenancePolicyParams())
         info.total_time_us = _us(t_total)
         return info
+
+    @classmethod
+    def from_partitions(cls, centroids, offsets, ids, vecs, metric, device=0):
+        """An index over a clustering made elsewhere (a cross-shard k-means, a file): list p = rows [offsets[p], offsets[p+1])
+        of ids / vecs, centroid p = centroids[p].  The state after build(): parent over the centroids, partition ids
+        0..nlist-1, default maintenance policy (quake_index.cpp:29-90 minus the clustering)."""
+        self = cls(0, device)
+        bp = IndexBuildParams()
+        bp.metric = metric
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        bp.nlist = int(offsets.shape[0] - 1)
+        self.build_params_ = bp
+        self.metric_ = capi.metric_code(metric)
+        self._has_ctx = True
+        cd = self._to_dev(centroids, torch.float32)
+        self._d = int(cd.shape[1])
+        if bp.nlist != cd.shape[0]:
+            raise RuntimeError("[QuakeIndex::from_partitions] one centroid per list is required")
+        self._store = capi.Store(self._ctx, self._d)
+        idd = self._to_dev(ids, torch.int64)
+        self._store.build_csr(offsets, idd, self._to_dev(vecs, torch.float32))
+        self.parent = cls(1, device)
+        pp = IndexBuildParams()
+        pp.metric = metric
+        self.parent.build(cd, torch.arange(bp.nlist, dtype=torch.int64), pp)
+        self._next_pid = bp.nlist
+        self._resident = _ResidentIds()
+        self._resident.update(idd.cpu().numpy().astype(np.int64))
+        self.initialize_maintenance_policy(MaintenancePolicyParams())
+        return self
 
     # -- search (quake_index.cpp:93-99 -> query_coordinator.cpp:612-657) --------------------------------------------------
     def search(self, x, search_params):
@@ -495,6 +533,27 @@ class QuakeIndex:
 
     def _partition_sizes(self, pids):
         return [int(self._store.list_size(int(p))) for p in pids]
+
+    def _list_ids(self):
+        return [int(p) for p in self._store.list_ids()]
+
+    def _reassign_targets(self, pid):
+        """where would the vectors of partition `pid` go if it were deleted: the other partitions among every vector's two
+        nearest centroids and how many vectors name each (maintenance_policies.cpp:79-101).  -> (pids, counts) lists."""
+        vecs, _ = self._store.get_list(int(pid))
+        near, _ = self._ctx.coarse(self.parent._store, torch.from_numpy(vecs).cuda(self._device), 2, self.metric_)
+        flat = near.reshape(-1)
+        flat = flat[(flat != int(pid)) & (flat >= 0)]
+        uniq, counts = torch.unique(flat, return_counts=True)
+        return [int(v) for v in uniq.tolist()], [int(v) for v in counts.tolist()]
+
+    def _neighbour_partitions(self, pids, radius):
+        """the partitions whose centroids are among the `radius` nearest of each given partition's centroid, sorted
+        (maintenance_policies.cpp:187-202)."""
+        cent = self.parent.get(torch.tensor([int(p) for p in pids], dtype=torch.int64))
+        near, _ = self._ctx.coarse(self.parent._store, cent.cuda(self._device), int(radius), self.metric_)
+        out = torch.unique(near.reshape(-1))
+        return [int(v) for v in out[out != -1].tolist()]
 
     def _select_partitions(self, pids):  # partition_manager.cpp:344-390
         vecs, ids = [], []

@@ -351,7 +351,7 @@ class MaintenancePolicy:
             return info
         t_total = time.perf_counter()
         hits = tr.aggregated_hits()
-        all_pids = [int(v) for v in idx._store.list_ids()]
+        all_pids = [int(v) for v in idx._list_ids()]
         total_partitions = idx.nlist()
         scan_fraction = tr.get_current_scan_fraction()
         avg_size = idx.ntotal() // max(total_partitions, 1)
@@ -365,15 +365,10 @@ class MaintenancePolicy:
             if dd < -p.delete_threshold_ns:
                 if p.enable_delete_rejection and size > p.min_partition_size:
                     # where would its vectors go?  second-nearest centroid of every vector (:79-101)
-                    vecs, _ = idx._store.get_list(pid)
-                    near, _ = idx._ctx.coarse(idx.parent._store, torch.from_numpy(vecs).cuda(idx._device), 2, idx.metric_)
-                    flat = near.reshape(-1)
-                    flat = flat[flat != pid]
-                    uniq, counts = torch.unique(flat, return_counts=True)
-                    uniq = [int(v) for v in uniq.tolist()]
+                    uniq, counts = idx._reassign_targets(pid)
                     rs = idx._partition_sizes(uniq)
                     hr = [float(np.float32(hits.get(u, 0)) / np.float32(p.window_size)) for u in uniq]
-                    delta = ce.compute_delete_delta_w_reassign(size, hit_rate, total_partitions, counts.tolist(), rs, hr)
+                    delta = ce.compute_delete_delta_w_reassign(size, hit_rate, total_partitions, counts, rs, hr)
                     if delta < -p.delete_threshold_ns:
                         to_delete.append(pid)
                 else:
@@ -409,9 +404,5 @@ class MaintenancePolicy:
         idx, p = self.index_, self.params_
         if p.refinement_radius == 0:
             return
-        pid_t = torch.tensor(list(partition_ids), dtype=torch.int64)
-        cent = idx.parent.get(pid_t)
-        near, _ = idx._ctx.coarse(idx.parent._store, cent.cuda(idx._device), int(p.refinement_radius), idx.metric_)
-        refine = torch.unique(near.reshape(-1))
-        refine = refine[refine != -1].cpu()
+        refine = torch.tensor(idx._neighbour_partitions(list(partition_ids), int(p.refinement_radius)), dtype=torch.int64)
         idx.refine_partitions(refine, int(p.refinement_iterations))

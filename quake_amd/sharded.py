@@ -190,6 +190,7 @@ class ShardedIndex:
         self.result = result
         self._g_ids = self._g_keys = self._g_pids = None
         self._x_ids = self._x_keys = None
+        self.last_pids = None
         # gloo (two ranks sharing one GPU in the functional tests) has no device all-to-all: stage through the host there
         self._stage_host = False
         if dist is not None and self.world > 1:
@@ -234,7 +235,7 @@ class ShardedIndex:
         import torch
         Q = q.shape[0]
         if self.world == 1 or self.dist is None:
-            pids = self.engine.coarse(q, nprobe)
+            pids = self.last_pids = self.engine.coarse(q, nprobe)
             ids, keys = self.engine.scan(q, pids, k, out=out)
             return self.engine.merge(ids.reshape((1,) + tuple(ids.shape)), keys.reshape((1,) + tuple(keys.shape)))
         if Q % self.world != 0:
@@ -244,6 +245,7 @@ class ShardedIndex:
         pids = self._gather("_g_pids", pl, torch.int64).view(Q, -1)
         if not torch.is_tensor(q):
             pids = pids.numpy()
+        self.last_pids = pids  # [Q, nprobe] of the whole batch, on every rank: what hit tracking records
         ids, keys = self.engine.scan(q, pids, k, out=out)
         if self.result == "owner":
             ids = ids if torch.is_tensor(ids) else torch.from_numpy(np.ascontiguousarray(ids))
@@ -258,8 +260,8 @@ class ShardedIndex:
         return self.engine.merge(g_ids, g_keys)
 
     # -- dynamic updates (partition_manager.cpp:123-320), sharded: the batch is known to every rank (like the queries), each
-    # rank applies the part that concerns the lists it owns; no collective is needed.  Maintenance (split / delete) changes
-    # the replicated centroids and is not sharded here.
+    # rank applies the part that concerns the lists it owns; no collective is needed.  Maintenance (split / delete / refine) changes
+    # the replicated centroids: quake_amd/sharded_maintenance.py.
     def add(self, x, ids, lists_per_rank=None):
         """x [n, d], ids [n] on every rank.  Returns the number of vectors this rank stored."""
         import torch
