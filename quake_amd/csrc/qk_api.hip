@@ -118,7 +118,7 @@ int run_search(qk_ctx *ctx, qk_store *parent, qk_store *s, const float *x, int64
     }
     const float4 *xq4 = nullptr;
     const float *xn = nullptr;
-    QK_TRY(qk_prep_queries(ctx, sv.x, Q, d, &xq4, &xn));
+    QK_TRY(qk_prep_queries(ctx, sv.x, Q, d, &xq4, &xn, coarse_only ? 0 : qk_scan_zero_bytes((int64_t)s->parts.size(), Q)));
     const unsigned long long *packed = nullptr;
     // ---- coarse --------------------------------------------------------------------------------------
     if (use_parent && kk <= 0 && coarse_only) return QK_OK;

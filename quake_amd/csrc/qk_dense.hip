@@ -32,13 +32,15 @@ struct DenseParams {
     int tiles_per_wg;    // row tiles per workgroup (split over its 4 waves)
 };
 
-template <int DB, int NQ>
+// (L2 is a template parameter: with the metric as a runtime flag hipcc kept one uniform branch per result element in the
+//  epilogue -- 32 scalar branches per 16-row tile, each waiting on the VALU -- instead of unswitching the loop)
+template <int DB, int NQ, bool L2>
 __global__ __launch_bounds__(256) void k_dense_ord(DenseParams P) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, g = lane >> 4;
     const int nblk = P.nblk;
-    const bool l2 = P.metric == QK_METRIC_L2;
+    constexpr bool l2 = L2;
     float4 *qs = (float4 *)smem;                               // [NQ][nblk*64]
     float *xn_s = (float *)(smem + (size_t)NQ * nblk * 1024);  // [NQ*16]
     const int64_t q_base = (int64_t)blockIdx.x * (NQ * 16);
@@ -503,13 +505,13 @@ struct ArgminParams {
     unsigned long long *best64;  // [Q], preset to ~0
 };
 
-template <int DB, int NQ>
+template <int DB, int NQ, bool L2>
 __global__ __launch_bounds__(256) void k_dense_argmin(ArgminParams P) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, g = lane >> 4;
     const int nblk = P.nblk;
-    const bool l2 = P.metric == QK_METRIC_L2;
+    constexpr bool l2 = L2;
     float4 *qs = (float4 *)smem;                               // [NQ][nblk*64]
     float *xn_s = (float *)(smem + (size_t)NQ * nblk * 1024);  // [NQ*16]
     unsigned long long *red = (unsigned long long *)(xn_s + NQ * 16);  // [4][NQ*16]
@@ -595,7 +597,7 @@ __global__ __launch_bounds__(256) void k_dense_argmin(ArgminParams P) {
                     const float v_ = acc[nq_][reg_];                                                         \
                     const uint32_t k_ = l2 ? ord_from_l2(l2_expanded(xnj[nq_], yv_[reg_], v_)) : ord_from_ip(v_); \
                     const unsigned long long c_ = ((unsigned long long)k_ << 32) | iv_[reg_];                \
-                    const bool lt_ = row0_ + reg_ < P.nrows && c_ < best[nq_];                               \
+                    const bool lt_ = (row0_ + reg_ < P.nrows) & (c_ < best[nq_]);                            \
                     best[nq_] = lt_ ? c_ : best[nq_];                                                        \
                 }                                                                                            \
             }                                                                                                \
@@ -665,18 +667,26 @@ __global__ void k_argmin_finish(const unsigned long long *best64, int64_t Q, int
     if (out_dist) out_dist[q] = od;
 }
 
-template <int DB, int NQ>
-static int launch_argmin_t(hipStream_t st, dim3 grid, size_t lds, const ArgminParams &ap) {
-    QK_HIP(hipFuncSetAttribute((const void *)k_dense_argmin<DB, NQ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((k_dense_argmin<DB, NQ>), grid, dim3(256), lds, st, ap);
+template <int DB, int NQ, bool L2>
+static int launch_argmin_m(hipStream_t st, dim3 grid, size_t lds, const ArgminParams &ap) {
+    QK_HIP(hipFuncSetAttribute((const void *)k_dense_argmin<DB, NQ, L2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_dense_argmin<DB, NQ, L2>), grid, dim3(256), lds, st, ap);
     return QK_OK;
 }
+template <int DB, int NQ>
+static int launch_argmin_t(hipStream_t st, dim3 grid, size_t lds, const ArgminParams &ap) {
+    return ap.metric == QK_METRIC_L2 ? launch_argmin_m<DB, NQ, true>(st, grid, lds, ap) : launch_argmin_m<DB, NQ, false>(st, grid, lds, ap);
+}
 
+template <int DB, int NQ, bool L2>
+static int launch_dense_m(hipStream_t st, dim3 grid, size_t lds, const DenseParams &dp) {
+    QK_HIP(hipFuncSetAttribute((const void *)k_dense_ord<DB, NQ, L2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_dense_ord<DB, NQ, L2>), grid, dim3(256), lds, st, dp);
+    return QK_OK;
+}
 template <int DB, int NQ>
 static int launch_dense_t(hipStream_t st, dim3 grid, size_t lds, const DenseParams &dp) {
-    QK_HIP(hipFuncSetAttribute((const void *)k_dense_ord<DB, NQ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((k_dense_ord<DB, NQ>), grid, dim3(256), lds, st, dp);
-    return QK_OK;
+    return dp.metric == QK_METRIC_L2 ? launch_dense_m<DB, NQ, true>(st, grid, lds, dp) : launch_dense_m<DB, NQ, false>(st, grid, lds, dp);
 }
 
 int qk_dense_device(qk_ctx *ctx, qk_store *s, int64_t list_no, const qk_scan_args &a, qk_timing *timing, int ev_base) {
@@ -751,7 +761,6 @@ int qk_dense_device(qk_ctx *ctx, qk_store *s, int64_t list_no, const qk_scan_arg
             QK_HIP(hipStreamSynchronize(st));
             hs[0] = 1;
             hs[1] = 0;
-        hs[7] = (int32_t)std::min<int64_t>(Q, INT32_MAX);  // every query scans the one list
             hs[7] = (int32_t)std::min<int64_t>(Q, INT32_MAX);  // every query scans the one list
             int64_t rows = nrows;
             memcpy(hs + 2, &rows, sizeof(rows));

@@ -51,13 +51,14 @@ struct AssignParams {
 
 // One workgroup = NQ*16 rows of x (the MFMA "query" side, staged in LDS) against all centroids (streamed as A
 // operands from L2/HBM, split across the 4 waves), running (ord, index) argmin per row.
-template <int DB, int NQ>
+// (L2 = the metric at compile time: as a runtime flag it left a uniform branch per result element in the epilogue)
+template <int DB, int NQ, bool L2>
 __global__ __launch_bounds__(256) void k_assign(AssignParams P) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, g = lane >> 4;
     const int nblk = P.nblk, d = P.d;
-    const bool l2 = P.metric == QK_METRIC_L2;
+    constexpr bool l2 = L2;
     float4 *qs = (float4 *)smem;                                            // [NQ][nblk*64]
     float *xn_s = (float *)(smem + (size_t)NQ * nblk * 1024);               // [NQ*16]
     uint32_t *red_ord = (uint32_t *)(xn_s + NQ * 16);                       // [4][NQ*16]
@@ -316,11 +317,15 @@ struct KmScratch {  // device buffers owned by one qk_kmeans* call
     }
 };
 
+template <int DB, int NQ, bool L2>
+static int launch_assign_m(hipStream_t st, unsigned grid, size_t lds, const AssignParams &ap) {
+    QK_HIP(hipFuncSetAttribute((const void *)k_assign<DB, NQ, L2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_assign<DB, NQ, L2>), dim3(grid), dim3(256), lds, st, ap);
+    return QK_OK;
+}
 template <int DB, int NQ>
 static int launch_assign_t(hipStream_t st, unsigned grid, size_t lds, const AssignParams &ap) {
-    QK_HIP(hipFuncSetAttribute((const void *)k_assign<DB, NQ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((k_assign<DB, NQ>), dim3(grid), dim3(256), lds, st, ap);
-    return QK_OK;
+    return ap.metric == QK_METRIC_L2 ? launch_assign_m<DB, NQ, true>(st, grid, lds, ap) : launch_assign_m<DB, NQ, false>(st, grid, lds, ap);
 }
 
 // assign on device pointers; ctile/cnorm are scratch for the tile-major centroid copy (mt*16 rows)

@@ -44,8 +44,12 @@
 __global__ __launch_bounds__(256) void k_prep_queries(const float *__restrict__ x, int64_t Q, int d, int nblk,
                                                       float4 *__restrict__ xq4, float *__restrict__ xn,
                                                       unsigned long long *__restrict__ best64, int qpw,
-                                                      float4 *__restrict__ xp4) {
+                                                      float4 *__restrict__ xp4, uint4 *__restrict__ zero16, int64_t n_zero16) {
     extern __shared__ float sq[];  // [qpw][d+1]
+    // the scan's per-call state (counters, cursors, bounds) starts from zero: cleared here, by everybody, instead of a memset
+    // launch between the coarse step and the scan (6 us of the 0.31 ms bench step)
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_zero16; i += (int64_t)gridDim.x * 256)
+        zero16[i] = make_uint4(0u, 0u, 0u, 0u);
     const int ldq = d + 1;
     const int64_t q0 = (int64_t)blockIdx.x * qpw;
     const int nq = (int)min((int64_t)qpw, Q - q0);
@@ -84,12 +88,16 @@ __global__ __launch_bounds__(256) void k_prep_queries(const float *__restrict__ 
     }
 }
 
-int qk_prep_queries(qk_ctx *ctx, const float *x, int64_t Q, int d, const float4 **xq4, const float **xn) {
+size_t qk_scan_zero_bytes(int64_t npids, int64_t Q) { return (size_t)npids * 4 * 2 + 256 + (size_t)Q * 4; }
+
+int qk_prep_queries(qk_ctx *ctx, const float *x, int64_t Q, int d, const float4 **xq4, const float **xn, size_t zero_bytes) {
     const int dpad = qk_round_up(d, 16), nblk = dpad / 16;
     const size_t off_n = ((size_t)Q * dpad * 4 + 255) & ~(size_t)255;
     const size_t off_b = (off_n + (size_t)Q * 4 + 255) & ~(size_t)255;
     const size_t off_p = (off_b + (size_t)Q * 8 + 255) & ~(size_t)255;
-    size_t need = off_p + (size_t)Q * dpad * 4 + 256;
+    const size_t off_z = (off_p + (size_t)Q * dpad * 4 + 255) & ~(size_t)255;
+    const size_t zero_pad = (zero_bytes + 15) & ~(size_t)15;
+    size_t need = off_z + zero_pad + 256;
     if (need > ctx->qprep_cap) {
         QK_HIP(hipStreamSynchronize(ctx->stream));
         if (ctx->qprep) QK_HIP(hipFree(ctx->qprep));
@@ -103,6 +111,8 @@ int qk_prep_queries(qk_ctx *ctx, const float *x, int64_t Q, int d, const float4 
     ctx->qprep_best64 = (unsigned long long *)(ctx->qprep + off_b);
     ctx->qprep_best64_n = Q;  // initialised for Q queries; the first nearest-centroid launch consumes it
     ctx->qprep_xp4 = (const float4 *)(ctx->qprep + off_p);
+    ctx->qprep_zero = zero_bytes ? ctx->qprep + off_z : nullptr;
+    ctx->qprep_zero_bytes = zero_bytes;  // the first qk_scan_device of this batch that needs exactly this much consumes it
     // queries per workgroup: 16, fewer when that would leave most of the chip idle (1024 x 768: 64 workgroups took 16 us)
     int qpw = 16;
     while (qpw > 2 && (Q + qpw - 1) / qpw < 2 * (int64_t)std::max(1, ctx->prop.multiProcessorCount) && (int64_t)qpw * d > 1024) qpw >>= 1;
@@ -111,7 +121,7 @@ int qk_prep_queries(qk_ctx *ctx, const float *x, int64_t Q, int d, const float4 
     if (lds > 48 * 1024)
         QK_HIP(hipFuncSetAttribute((const void *)k_prep_queries, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_prep_queries, dim3((unsigned)((Q + qpw - 1) / qpw)), dim3(256), lds, ctx->stream, x, Q, d, nblk, q4, n,
-                       ctx->qprep_best64, qpw, (float4 *)(ctx->qprep + off_p));
+                       ctx->qprep_best64, qpw, (float4 *)(ctx->qprep + off_p), (uint4 *)(ctx->qprep + off_z), (int64_t)(zero_pad / 16));
     QK_HIP(hipGetLastError());
     *xq4 = q4;
     *xn = n;
@@ -339,7 +349,7 @@ __global__ void k_group_scatter(GroupParams G) {
 // 72 us against 31 / 37 / 38 / 38 / 44 us for the three kernels -- the single workgroup wins only where launch latency is
 // all there is (a 1-query search: 10 pairs), so it serves batches up to 1024 pairs.
 constexpr int QK_GROUP_SMALL = 1024;
-__global__ __launch_bounds__(1024) void k_group_small(GroupParams G) {
+__device__ __forceinline__ void group_small_body(const GroupParams &G) {
     __shared__ long long s_w[48];
     // partition and arrival rank of this thread's pairs stay in registers: the scatter below needs neither the list numbers
     // again nor a second round of atomics (three dependent memory round trips less in a kernel that is nothing but those)
@@ -364,6 +374,8 @@ __global__ __launch_bounds__(1024) void k_group_small(GroupParams G) {
         }
     }
 }
+
+__global__ __launch_bounds__(1024) void k_group_small(GroupParams G) { group_small_body(G); }
 
 // ---- bound seeding ---------------------------------------------------------------------------------------
 // One wave per (query, partition) pair: exact distances (same canonical chain as the MFMA path) from the query to the
@@ -392,11 +404,12 @@ struct SeedParams {
 
 // grid = Q * seed_ranks waves: wave w -> query w / seed_ranks, rank w % seed_ranks.  M rows per lane: the sample is the
 // first min(n_p, 64*M) rows, so that it can bound k <= 64*M.
-template <int M>
-__global__ __launch_bounds__(64) void k_seed_tau(SeedParams S) {
-    const int lane = threadIdx.x;
-    const int64_t qq = blockIdx.x / S.seed_ranks;
-    const int rr = blockIdx.x % S.seed_ranks;
+// CB = 16-column blocks requested per memory round trip (8: one trip for d <= 128, 128 VGPRs of row data; the fused
+// seed + group launch runs 1024-thread workgroups -- 128 VGPRs in all -- and takes two trips of 4)
+template <int M, int CB>
+__device__ __forceinline__ void seed_tau_body(const SeedParams &S, const int64_t w, const int lane) {
+    const int64_t qq = w / S.seed_ranks;
+    const int rr = (int)(w % S.seed_ranks);
     if (rr >= S.P) return;
     const int64_t pair = qq * S.P + rr;
     int64_t p;
@@ -425,10 +438,10 @@ __global__ __launch_bounds__(64) void k_seed_tau(SeedParams S) {
         float acc = 0.0f;
         // 8 blocks (128 columns) at a time: the 32 float4 of the lane's row and the 128 query values (2 per lane,
         // broadcast with v_readlane) are requested together, then one k-ordered fmaf chain -- the arithmetic of the MFMA path
-        for (int c0 = 0; c0 < S.nblk; c0 += 8) {
-            float4 v[8][4];
+        for (int c0 = 0; c0 < S.nblk; c0 += CB) {
+            float4 v[CB][4];
 #pragma unroll
-            for (int c = 0; c < 8; c++) {
+            for (int c = 0; c < CB; c++) {
                 const int cc = min(c0 + c, S.nblk - 1);
                 const float4 *blk = S.vecs + (tile * S.nblk + cc) * 64 + r;
 #pragma unroll
@@ -438,7 +451,7 @@ __global__ __launch_bounds__(64) void k_seed_tau(SeedParams S) {
             const float xa = colA < S.d ? xq[colA] : 0.0f;
             const float xb = colB < S.d ? xq[colB] : 0.0f;
 #pragma unroll
-            for (int c = 0; c < 8; c++) {
+            for (int c = 0; c < CB; c++) {
                 if (c0 + c < S.nblk) {
                     const float e[16] = {v[c][0].x, v[c][1].x, v[c][2].x, v[c][3].x, v[c][0].y, v[c][1].y, v[c][2].y, v[c][3].y,
                                          v[c][0].z, v[c][1].z, v[c][2].z, v[c][3].z, v[c][0].w, v[c][1].w, v[c][2].w, v[c][3].w};
@@ -476,6 +489,24 @@ __global__ __launch_bounds__(64) void k_seed_tau(SeedParams S) {
     }
     if (lane == 0 && bound != 0xFFFFFFFFu) atomicMax(&S.gtau[q], ~bound);  // gtau holds ~bound: 0 = no bound yet
 }
+
+template <int M>
+__global__ __launch_bounds__(64) void k_seed_tau(SeedParams S) {
+    seed_tau_body<M, 8>(S, blockIdx.x, threadIdx.x);
+}
+
+// Grouping and bound seeding of a small batch in ONE launch: both depend only on the probed-partition lists, neither on the
+// other.  Workgroup 0 is k_group_small, the others carry 16 seeding waves each (k <= 64: a 64-row sample per wave).  In line
+// the two kernels took 12.4 + 10.1 us of the 0.31 ms bench step.
+__global__ __launch_bounds__(1024) void k_group_seed(GroupParams G, SeedParams S, int64_t n_seed_waves) {
+    if (blockIdx.x == 0) {
+        group_small_body(G);
+        return;
+    }
+    const int64_t w = ((int64_t)blockIdx.x - 1) * 16 + (threadIdx.x >> 6);
+    if (w < n_seed_waves) seed_tau_body<1, 4>(S, w, threadIdx.x & 63);
+}
+
 
 // exact key of one sampled row (row `lrow` of the partition that starts at arena row `row_base`) for the query xq: the
 // arithmetic of the MFMA path -- one k-ordered fmaf chain; the query values are broadcast with v_readlane
@@ -602,7 +633,8 @@ __device__ __forceinline__ float4 qk_ld_stream(const float4 *p) {
 // MODE 0 = product; 1 = skip the top-k epilogue; 2 = loads only (probe variants for bandwidth attribution, QK_SCAN_MODE);
 // 3 = product with query-sharing workgroups (ScanParams::qshare) -- a compile-time variant: the extra branches cost the
 // plain path 8 % when they were decided at run time
-template <int DB, int MAXCH, int MODE = 0>
+// L2: the metric, compile-time as well -- as a runtime flag it left a uniform branch around every result element of the epilogue
+template <int DB, int MAXCH, int MODE, bool L2>
 __global__ __launch_bounds__(256) void k_scan(ScanParams P) {
     extern __shared__ __align__(16) unsigned char smem[];
     // nw waves per workgroup (1, 2 or 4) share ONE LDS query tile and split every segment's tiles between them; each
@@ -618,7 +650,7 @@ __global__ __launch_bounds__(256) void k_scan(ScanParams P) {
     const int wv = pack > 1 ? 0 : wv_phys, nw = pack > 1 ? 1 : (int)(blockDim.x >> 6);
     const int j = lane & 15, g = lane >> 4;
     const int nblk = P.nblk, C = P.C, k = P.k;
-    const bool l2 = P.metric == QK_METRIC_L2;
+    constexpr bool l2 = L2;
     constexpr bool qshare = MODE == 3;
     constexpr bool PRODUCT = MODE == 0 || MODE == 3;
     constexpr bool EMIT = MODE == 4;  // wide-k path: keys out, selection happens in k_select_rows_large afterwards
@@ -1491,27 +1523,33 @@ int qk_merge_topk_device(qk_ctx *ctx, const int64_t *in_ids, const float *in_key
 size_t qk_scan_rl_lds_per_wave(int nblk, int C);
 int qk_launch_scan_rl(int nblk, dim3 grid, size_t lds, hipStream_t st, const ScanParams &sp);
 
+template <int DB, int MAXCH, int MODE, bool L2>
+static int launch_scan_k(dim3 grid, dim3 block, size_t lds, hipStream_t st, const ScanParams &sp) {
+    QK_HIP(hipFuncSetAttribute((const void *)k_scan<DB, MAXCH, MODE, L2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_scan<DB, MAXCH, MODE, L2>), grid, block, lds, st, sp);
+    return QK_OK;
+}
+template <int DB, int MAXCH, int MODE>
+static int launch_scan_m(dim3 grid, dim3 block, size_t lds, hipStream_t st, const ScanParams &sp) {
+    return sp.metric == QK_METRIC_L2 ? launch_scan_k<DB, MAXCH, MODE, true>(grid, block, lds, st, sp)
+                                     : launch_scan_k<DB, MAXCH, MODE, false>(grid, block, lds, st, sp);
+}
+
 template <int DB, int MAXCH>
 static int launch_scan_t(dim3 grid, dim3 block, size_t lds, hipStream_t st, const ScanParams &sp) {
-    QK_HIP(hipFuncSetAttribute((const void *)k_scan<DB, MAXCH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((k_scan<DB, MAXCH>), grid, block, lds, st, sp);
-    return QK_OK;
+    return launch_scan_m<DB, MAXCH, 0>(grid, block, lds, st, sp);
 }
 
 template <int DB, int MAXCH>
 static int launch_scan_qs(dim3 grid, dim3 block, size_t lds, hipStream_t st, const ScanParams &sp) {
-    QK_HIP(hipFuncSetAttribute((const void *)k_scan<DB, MAXCH, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((k_scan<DB, MAXCH, 3>), grid, block, lds, st, sp);
-    return QK_OK;
+    return launch_scan_m<DB, MAXCH, 3>(grid, block, lds, st, sp);
 }
 // the (DB, MAXCH) combinations the query-sharing variant is compiled for (narrow rows, k <= 100)
 static bool have_scan_qs(int db, int maxch) { return (db == 8 || db == 4 || db == 2) && (maxch == 1 || maxch == 2 || maxch == 4); }
 
 template <int DB>
 static int launch_scan_emit(dim3 grid, dim3 block, size_t lds, hipStream_t st, const ScanParams &sp) {
-    QK_HIP(hipFuncSetAttribute((const void *)k_scan<DB, 1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((k_scan<DB, 1, 4>), grid, block, lds, st, sp);
-    return QK_OK;
+    return launch_scan_m<DB, 1, 4>(grid, block, lds, st, sp);
 }
 
 static int launch_scan(int db, int maxch, dim3 grid, dim3 block, size_t lds, hipStream_t st, const ScanParams &sp) {
@@ -1531,14 +1569,10 @@ static int launch_scan(int db, int maxch, dim3 grid, dim3 block, size_t lds, hip
     }
     static const int probe_mode = qk_env_int("QK_SCAN_MODE", 0);
     if (probe_mode == 1 && db == 8 && maxch == 1) {
-        QK_HIP(hipFuncSetAttribute((const void *)k_scan<8, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((k_scan<8, 1, 1>), grid, block, lds, st, sp);
-        return QK_OK;
+        return launch_scan_k<8, 1, 1, true>(grid, block, lds, st, sp);
     }
     if (probe_mode == 2 && db == 8 && maxch == 1) {
-        QK_HIP(hipFuncSetAttribute((const void *)k_scan<8, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((k_scan<8, 1, 2>), grid, block, lds, st, sp);
-        return QK_OK;
+        return launch_scan_k<8, 1, 2, true>(grid, block, lds, st, sp);
     }
 #define QK_CASE(D, M) \
     if (db == D && maxch == M) return launch_scan_t<D, M>(grid, block, lds, st, sp);
@@ -1745,9 +1779,12 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
     const float4 *xq4 = a.xq4;
     const float *xn = a.xn;
     if (!xq4 || !xn) QK_FAIL(QK_ERR_INVALID, "qk_scan: queries were not prepared");
-    // zeroed region: g_cnt [npids], g_cursor [npids], scal [64], gtau [Q]  (one memset per call)
-    const size_t zero_bytes = (size_t)npids * 4 * 2 + 256 + (size_t)Q * 4;
-    int32_t *g_cnt = (int32_t *)qk_ws_alloc(ctx, zero_bytes + 64);
+    // zeroed region: g_cnt [npids], g_cursor [npids], scal [64], gtau [Q]  (one memset per call -- or none: the query prep
+    // kernel of this batch leaves a zeroed region of the size it was told to, qk_prep_queries(..., zero_bytes))
+    const size_t zero_bytes = qk_scan_zero_bytes(npids, Q);
+    const bool prezeroed = ctx->qprep_zero && ctx->qprep_zero_bytes == zero_bytes && a.xq4 == (const float4 *)ctx->qprep;
+    int32_t *g_cnt = prezeroed ? (int32_t *)ctx->qprep_zero : (int32_t *)qk_ws_alloc(ctx, zero_bytes + 64);
+    if (prezeroed) ctx->qprep_zero_bytes = 0;  // consumed
     int32_t *g_cursor = g_cnt + npids;
     int32_t *scal = g_cursor + npids;
     ActiveInfo *active = (ActiveInfo *)qk_ws_alloc(ctx, (size_t)(npids + 1) * sizeof(ActiveInfo) + 64);
@@ -1770,7 +1807,7 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
 
     QK_TRY(pe.mark(0));
     // ---- grouping -----------------------------------------------------------------------------------------
-    QK_HIP(hipMemsetAsync(g_cnt, 0, zero_bytes, st));
+    if (!prezeroed) QK_HIP(hipMemsetAsync(g_cnt, 0, zero_bytes, st));
     GroupParams G;
     G.pids = a.all_lists ? nullptr : a.pids;
     G.pids_packed = a.all_lists ? nullptr : a.pids_packed;
@@ -1814,6 +1851,7 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
     //  the 64*M-row sample costs 0.1 ms at d = 768; the wider instantiations stay available for probing)
     static const int seed_max_k = qk_env_int("QK_SEED_MAX_K", 64);
     const bool seeded = !no_seed && share_tau && k <= std::min(seed_max_k, 512) && npairs > 0 && npids > 0;
+    bool fused_group = false;
     if (seeded) {
         // bound seeding: for the first (nearest) partitions of every query, the k-th smallest distance of a 64-row
         // sample goes into gtau[q]
@@ -1843,7 +1881,13 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
         //  0.248 / 0.240 ms, this kernel 10 -> 17 / 30 us -- a 256-row sample of 1024 partitions is 134 MB of reads, 9 % of what
         //  the scan streams.  One for one again; the default stays at 64 rows.)
         static const int seed_waves = qk_env_int("QK_SEED_WAVES", 1);
-        if (k <= 64 && seed_waves == 4)
+        static const bool no_small_f = qk_env_set("QK_NO_GROUP_SMALL");
+        static const bool no_fuse = qk_env_set("QK_NO_GROUP_SEED");
+        if (k <= 64 && seed_waves == 1 && npairs <= QK_GROUP_SMALL && !no_small_f && !no_fuse) {
+            const int64_t nsw = Q * sd.seed_ranks;
+            hipLaunchKernelGGL(k_group_seed, dim3((unsigned)(1 + (nsw + 15) / 16)), dim3(1024), 0, st, G, sd, nsw);
+            fused_group = true;
+        } else if (k <= 64 && seed_waves == 4)
             hipLaunchKernelGGL((k_seed_tau_wg<4>), sg, dim3(256), 0, st, sd);
         else if (k <= 64 && seed_waves == 2)
             hipLaunchKernelGGL((k_seed_tau_wg<2>), sg, dim3(128), 0, st, sd);
@@ -1857,7 +1901,9 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
             hipLaunchKernelGGL((k_seed_tau<8>), sg, dim3(64), 0, st, sd);
     }
     static const bool no_small = qk_env_set("QK_NO_GROUP_SMALL");
-    if (npairs <= QK_GROUP_SMALL && !no_small) {
+    if (fused_group) {
+        // grouped by workgroup 0 of k_group_seed
+    } else if (npairs <= QK_GROUP_SMALL && !no_small) {
         hipLaunchKernelGGL(k_group_small, dim3(1), dim3(1024), 0, st, G);
     } else {
         if (npairs > 0) hipLaunchKernelGGL(k_group_count, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, st, G);

@@ -14,14 +14,19 @@
 // QK_RL_QB = 32 queries from ONE read of its rows.  k = 1 per instruction: the accumulator chain is literally
 // acc = fma(row[k], query[k], acc) in column order -- the canonical arithmetic, bit-identical to k_scan.
 //
-// Operand layout (scripts/micro/mfma_4x4x1.hip prints it from the hardware):
-//   A: lane l holds the value of ROW l of the 64-row chunk (block l/4, row l%4 of the block)
-//   B: lane l holds the value of query (l % 4) of the group, the same for all 16 blocks
-//   D: lane 4b + j, register i = row 4b + i x query j
+// Operand layout (scripts/micro/mfma_4x4x1.hip prints it from the hardware and checks the chain against fmaf):
+//   D[lane 4b + j][register i] = A(lane 4b + i) * B(lane 4b + j); with CBSZ = 4 / ABID = n the A values of block n feed all
+//   16 blocks: D[lane l][register i] = A(lane 4n + i) * B(lane l).
+//   B: lane l holds the value of ROW l of the 64-row chunk, column k
+//   A: the four QUERIES of the group; lane (b, i) keeps q_i[16c + b] in register c, so that column k = 16c + n is the
+//      instruction (register c, ABID = n): a group's queries live in d/16 VGPRs and the inner loop reads no LDS at all
+//      (round 2, first form: queries as B operands re-read from LDS, one ds_read_b128 per 4 MFMAs -- 64 KB per wave and
+//      loop step, 77 % of the CU's LDS bandwidth with four waves: the loop step took 4700 cycles instead of 2700)
+//   D: lane l, register i = row l x query i of the group: a lane owns ONE row (its norm, its id) and four queries
 // Rows come straight from the tile-major arena: lane l = (tile l/16 of the chunk, row l%16) loads, for every 16-column block c
 // and k-slice g, the float4 {columns 16c+g, +4, +8, +12} -- 4 x 256 contiguous bytes per instruction -- and element t of it
-// is the A operand of column 16c + 4t + g.  Queries are staged per pass in LDS as [group][4 columns][query] float4 (one
-// conflict-free ds_read_b128 per 4 MFMAs).
+// is the B operand of column 16c + 4t + g.  Queries are staged per pass in LDS as [group][c][lane] floats (conflict-free
+// ds_read_b32, d/16 per group and chunk).
 #include "qk_internal.h"
 #include "qk_device.h"
 #include "qk_scan_types.h"
@@ -35,20 +40,21 @@ __device__ __forceinline__ float4 rl_ld_nt(const float4 *p) {
 __device__ __forceinline__ float f4c(const float4 &v, int t) { return t == 0 ? v.x : t == 1 ? v.y : t == 2 ? v.z : v.w; }
 
 // NB = 16-column blocks per row (d <= 128).  One hardware workgroup = 4 independent waves (own range, own LDS, no barrier).
-template <int NB>
+// (the metric is a template parameter: as a runtime flag it left uniform branches around every result element of the epilogue)
+template <int NB, bool L2>
 __global__ __launch_bounds__(256) void k_scan_rl(ScanParams P) {
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int NKK = NB * 4;        // float4 (4 consecutive columns) per padded row
     constexpr int QB = QK_RL_QB;       // query slots per pass
     constexpr int NG = QB / 4;         // groups per pass
     const int lane = threadIdx.x & 63, wvp = threadIdx.x >> 6;
-    const int j = lane & 3, b4 = lane >> 2;   // D: lane 4*b4 + j, register i = row 4*b4 + i x query j of the group
-    const int tq = lane >> 4, r = lane & 15;  // A: lane = row of the chunk = (tile tq, row r)
+    const int qi = lane & 3, b4 = lane >> 2;  // A: lane (block b4, query qi of the group) keeps q_qi[16c + b4] in register c
+    const int tq = lane >> 4, r = lane & 15;  // B / D: lane = row of the chunk = (tile tq, row r)
     const int C = P.C, k = P.k;
-    const bool l2 = P.metric == QK_METRIC_L2;
+    constexpr bool l2 = L2;
     unsigned char *sm = smem + (size_t)wvp * P.pack_lds;
-    float4 *sB = (float4 *)sm;                                            // [NG][NKK][4]
-    int64_t *pool_id = (int64_t *)(sm + (size_t)NG * NKK * 4 * 16);       // [QB][C]
+    float *sQ = (float *)sm;                                              // [NG][NB][64]
+    int64_t *pool_id = (int64_t *)(sm + (size_t)NG * NB * 64 * 4);        // [QB][C]
     uint32_t *pool_ord = (uint32_t *)((unsigned char *)pool_id + (size_t)QB * C * 8);  // [QB][C]
     int *s_q = (int *)(pool_ord + (size_t)QB * C);                        // per slot: query, pair, bound, pool fill, |x|^2
     int *s_pair = s_q + QB;
@@ -140,40 +146,36 @@ __global__ __launch_bounds__(256) void k_scan_rl(ScanParams P) {
         const int64_t tile_p0 = inf.row_off >> 4;
 
         float4 a0[NB * 4], a1[NB * 4];
-        float4 y0, y1;
-        longlong2 i00, i01, i10, i11;
+        float y0, y1;      // |row|^2 and id of this lane's row
+        int64_t i0, i1;
         int lch = ch0;  // next chunk to load
-#define RL_LOAD(A, Y, I0, I1)                                                                         \
+#define RL_LOAD(A, Y, I)                                                                              \
     {                                                                                                 \
         const int64_t ta_ = tile_p0 + min(4 * lch + tq, ntl - 1);                                     \
         const float4 *src_ = P.vecs + ta_ * (NB * 64) + r;                                            \
         _Pragma("unroll") for (int c_ = 0; c_ < NB; c_++)                                             \
             _Pragma("unroll") for (int g_ = 0; g_ < 4; g_++) A[c_ * 4 + g_] = rl_ld_nt(src_ + c_ * 64 + g_ * 16); \
-        const int64_t tn_ = tile_p0 + min(4 * lch + (b4 >> 2), ntl - 1);                              \
-        Y = *((const float4 *)(P.norms + (tn_ << 4)) + (b4 & 3));                                     \
-        const longlong2 *ip_ = (const longlong2 *)(P.ids + (tn_ << 4)) + 2 * (b4 & 3);                \
-        I0 = ip_[0];                                                                                  \
-        I1 = ip_[1];                                                                                  \
+        Y = P.norms[(ta_ << 4) + r];                                                                  \
+        I = P.ids[(ta_ << 4) + r];                                                                    \
         lch++;                                                                                        \
     }
-        RL_LOAD(a0, y0, i00, i01);
+        RL_LOAD(a0, y0, i0);
         dbg_seg++;
         const long long dbg_s0 = P.wave_clock ? wall_clock64() : 0;
 
-        // ---- stage the pass: per-slot state + the B operands of its queries, while the first chunk is in flight ----------
+        // ---- stage the pass: per-slot state + the A operands of its queries, while the first chunk is in flight ----------
         {
-            float4 qv[NG][(NKK + 15) / 16];
+            const float *xp = (const float *)P.xp4;
 #pragma unroll
             for (int g = 0; g < NG; g++) {
                 if (g < ng) {
-                    const int qsl = __shfl(myq, 4 * g + j);
-                    const float4 *qsrc = P.xp4 + (int64_t)max(qsl, 0) * NKK;
+                    const int qsl = __shfl(myq, 4 * g + qi);
+                    const float *qsrc = xp + (int64_t)max(qsl, 0) * (NKK * 4) + b4;
+                    float qv[NB];
 #pragma unroll
-                    for (int it = 0; it < (NKK + 15) / 16; it++) {
-                        const int kk = b4 + 16 * it;
-                        qv[g][it] = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if (kk < NKK && qsl >= 0) qv[g][it] = qsrc[kk];
-                    }
+                    for (int c = 0; c < NB; c++) qv[c] = qsl >= 0 ? qsrc[16 * c] : 0.0f;
+#pragma unroll
+                    for (int c = 0; c < NB; c++) sQ[(g * NB + c) * 64 + lane] = qv[c];
                 }
             }
             if (lane < QB) {
@@ -186,118 +188,112 @@ __global__ __launch_bounds__(256) void k_scan_rl(ScanParams P) {
                 s_cnt[lane] = 0;
                 s_xn[lane] = (l2 && myq >= 0) ? P.xn[qs] : 0.0f;
             }
-#pragma unroll
-            for (int g = 0; g < NG; g++) {
-                if (g < ng) {
-#pragma unroll
-                    for (int it = 0; it < (NKK + 15) / 16; it++) {
-                        const int kk = b4 + 16 * it;
-                        if (kk < NKK) sB[(g * NKK + kk) * 4 + j] = qv[g][it];
-                    }
-                }
-            }
         }
 
         if (P.wave_clock) dbg_t_stage += wall_clock64() - dbg_s0;
 
-        // ---- fused top-k of one group's 64 x 4 results ---------------------------------------------------------------------
-        auto epilogue = [&](int g, const f32x4 acc, int ch, const float4 yn, const longlong2 ia, const longlong2 ib) {
-            const int s = 4 * g + j;
-            const bool live = s < nq;
-            const float xnj = s_xn[s];
-            uint32_t tau = s_tau[s];
-            const float yv[4] = {yn.x, yn.y, yn.z, yn.w};
-            const int64_t idv[4] = {ia.x, ia.y, ib.x, ib.y};
-            const int row0 = 64 * ch + 4 * b4;
+        // ---- fused top-k of one group's 64 rows x 4 queries: lane = row, acc[i] = query i of the group ----------------------
+        auto epilogue = [&](int g, const f32x4 acc, int ch, const float yn, const int64_t idr) {
+            const bool rowvalid = 64 * ch + lane < size_p;
+            const float4 xn4 = *(const float4 *)(s_xn + 4 * g);
+            const uint4 tau4 = *(const uint4 *)(s_tau + 4 * g);
+            const float xnv[4] = {xn4.x, xn4.y, xn4.z, xn4.w};
+            const uint32_t tauv[4] = {tau4.x, tau4.y, tau4.z, tau4.w};
             uint32_t ordv[4];
             bool anyp = false;
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                const bool valid = live && (row0 + i < size_p);
-                const float v = acc[i];
-                const uint32_t o = l2 ? ord_from_l2(l2_expanded(xnj, yv[i], v)) : ord_from_ip(v);
-                ordv[i] = valid ? o : 0xFFFFFFFFu;
-                anyp |= valid && o <= tau && o != 0xFFFFFFFFu;
+                const uint32_t o = l2 ? ord_from_l2(l2_expanded(xnv[i], yn, acc[i])) : ord_from_ip(acc[i]);
+                // (slots beyond the pass's queries and rows beyond the partition never pass)
+                ordv[i] = (rowvalid && 4 * g + i < nq) ? o : 0xFFFFFFFFu;
+                anyp |= ordv[i] <= tauv[i] && ordv[i] != 0xFFFFFFFFu;
             }
             // steady state: nothing beats the running k-th best -> one ballot, one branch per group and chunk
             if (__ballot(anyp)) {
-                int cnt = s_cnt[s];
-                uint32_t *my_ord = pool_ord + s * C;
-                int64_t *my_id = pool_id + s * C;
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
+                    const int s = 4 * g + i;
                     const uint32_t ord = ordv[i];
+                    uint32_t tau = tauv[i];
                     const bool pass = ord != 0xFFFFFFFFu && ord <= tau;
                     const uint64_t m = __ballot(pass);
                     if (m) {
-                        const uint64_t gm = m & (0x1111111111111111ull << j);  // the lanes of this lane's query
-                        if (pass) {
-                            const int slot = cnt + __popcll(gm & ((1ull << lane) - 1ull));
-                            my_ord[slot] = ord;
-                            my_id[slot] = idv[i];
-                        }
-                        cnt += __popcll(gm);
+                        int cnt = s_cnt[s];  // wave-uniform
+                        uint32_t *my_ord = pool_ord + s * C;
+                        int64_t *my_id = pool_id + s * C;
                         dbg_app += __popcll(m);
-                        uint64_t need = __ballot(cnt > C - 16) & 0xFull;  // one lane per query of the group
-                        while (need) {
-                            dbg_comp++;
-                            const int jq = __ffsll((unsigned long long)need) - 1;
-                            need &= need - 1;
-                            const int n = __builtin_amdgcn_readlane(cnt, jq);
-                            uint32_t kth;
-                            const int nn = select_pool<1>(pool_ord + (4 * g + jq) * C, pool_id + (4 * g + jq) * C, n, k, lane, kth);
-                            if (j == jq) {
-                                cnt = nn;
-                                if (nn >= k) {
+                        // the pool has room for 32 more entries whenever it is at most k long: append by half waves
+#pragma unroll
+                        for (int h = 0; h < 2; h++) {
+                            const uint64_t mh = h ? (m & 0xFFFFFFFF00000000ull) : (m & 0xFFFFFFFFull);
+                            if (!mh) continue;
+                            if (pass && (lane >> 5) == h) {
+                                const int slot = cnt + __popcll(mh & ((1ull << lane) - 1ull));
+                                my_ord[slot] = ord;
+                                my_id[slot] = idr;
+                            }
+                            cnt += __popcll(mh);
+                            if (cnt > C - 32) {
+                                dbg_comp++;
+                                uint32_t kth;
+                                cnt = select_pool<1>(my_ord, my_id, cnt, k, lane, kth);
+                                if (cnt >= k) {
                                     tau = min(tau, kth);
-                                    if (P.gtau && P.tau_publish && b4 == 0) atomicMax(&P.gtau[s_q[s]], ~tau);
+                                    if (P.gtau && P.tau_publish && lane == 0) atomicMax(&P.gtau[s_q[s]], ~tau);
                                 }
                             }
                         }
+                        if (lane == 0) {
+                            s_cnt[s] = cnt;
+                            s_tau[s] = tau;
+                        }
                     }
-                }
-                if (b4 == 0) {
-                    s_cnt[s] = cnt;
-                    s_tau[s] = tau;
                 }
             }
         };
 
-// (the B operands of step kk + 1 are requested before the 8 MFMAs of step kk: the ds_read latency hides under them)
-#define RL_STEP(A, Y, I0, I1, CH)                                                                                     \
+// One loop step = two groups' chains interleaved over the chunk: 2 x 16 NB instructions, no LDS access inside; the A
+// registers of the NEXT pair are requested before the chains of this one.
+#define RL_MF1(A, c_, t_, g_)                                                                                             \
+    acc0_ = __builtin_amdgcn_mfma_f32_4x4x1f32(qa_[c_], f4c(A[(c_) * 4 + (g_)], t_), acc0_, 4, 4 * (t_) + (g_), 0);        \
+    acc1_ = __builtin_amdgcn_mfma_f32_4x4x1f32(qb_[c_], f4c(A[(c_) * 4 + (g_)], t_), acc1_, 4, 4 * (t_) + (g_), 0);
+#define RL_MF4(A, c_, t_) RL_MF1(A, c_, t_, 0) RL_MF1(A, c_, t_, 1) RL_MF1(A, c_, t_, 2) RL_MF1(A, c_, t_, 3)
+#define RL_MF16(A, c_) RL_MF4(A, c_, 0) RL_MF4(A, c_, 1) RL_MF4(A, c_, 2) RL_MF4(A, c_, 3)
+#define RL_STEP(A, Y, I, CH)                                                                                          \
     {                                                                                                                 \
+        float qa_[NB], qb_[NB], na_[NB], nb_[NB];                                                                     \
+        {                                                                                                             \
+            const float *p0_ = sQ + lane, *p1_ = sQ + (size_t)(ng > 1 ? 1 : 0) * NB * 64 + lane;                      \
+            _Pragma("unroll") for (int c_ = 0; c_ < NB; c_++) {                                                       \
+                na_[c_] = p0_[c_ * 64];                                                                               \
+                nb_[c_] = p1_[c_ * 64];                                                                               \
+            }                                                                                                         \
+        }                                                                                                             \
         for (int g0_ = 0; g0_ < ng; g0_ += 2) {                                                                       \
             dbg_gc++;                                                                                                 \
             f32x4 acc0_ = {0.f, 0.f, 0.f, 0.f}, acc1_ = {0.f, 0.f, 0.f, 0.f};                                         \
-            const float4 *b0_ = sB + (size_t)g0_ * NKK * 4 + j;                                                       \
-            const float4 *b1_ = (g0_ + 1 < ng) ? b0_ + NKK * 4 : b0_;                                                 \
-            float4 qa_[2], qb_[2]; /* B operands of steps kk and kk + 1: requested one step (8 MFMAs) ahead (two steps ahead    \
-                                      measured slower: more registers moved through the AGPR half) */                   \
-            qa_[0] = b0_[0];                                                                                          \
-            qb_[0] = b1_[0];                                                                                          \
-            if (!(P.rl_probe & 2))                                                                                    \
-            _Pragma("unroll") for (int kk_ = 0; kk_ < NKK; kk_++) {                                                   \
-                if (kk_ + 1 < NKK) { /* (compile-time: no branch inside the chain) */                                 \
-                    qa_[(kk_ + 1) & 1] = b0_[(kk_ + 1) * 4];                                                          \
-                    qb_[(kk_ + 1) & 1] = b1_[(kk_ + 1) * 4];                                                          \
-                }                                                                                                     \
-                __builtin_amdgcn_sched_barrier(0); /* keep the reads above the MFMAs (the scheduler sinks them otherwise) */ \
-                const float4 q0_ = qa_[kk_ & 1], q1_ = qb_[kk_ & 1];                                                  \
-                const int c_ = kk_ >> 2, t_ = kk_ & 3;                                                                \
-                acc0_ = __builtin_amdgcn_mfma_f32_4x4x1f32(f4c(A[c_ * 4 + 0], t_), q0_.x, acc0_, 0, 0, 0);            \
-                acc1_ = __builtin_amdgcn_mfma_f32_4x4x1f32(f4c(A[c_ * 4 + 0], t_), q1_.x, acc1_, 0, 0, 0);            \
-                acc0_ = __builtin_amdgcn_mfma_f32_4x4x1f32(f4c(A[c_ * 4 + 1], t_), q0_.y, acc0_, 0, 0, 0);            \
-                acc1_ = __builtin_amdgcn_mfma_f32_4x4x1f32(f4c(A[c_ * 4 + 1], t_), q1_.y, acc1_, 0, 0, 0);            \
-                acc0_ = __builtin_amdgcn_mfma_f32_4x4x1f32(f4c(A[c_ * 4 + 2], t_), q0_.z, acc0_, 0, 0, 0);            \
-                acc1_ = __builtin_amdgcn_mfma_f32_4x4x1f32(f4c(A[c_ * 4 + 2], t_), q1_.z, acc1_, 0, 0, 0);            \
-                acc0_ = __builtin_amdgcn_mfma_f32_4x4x1f32(f4c(A[c_ * 4 + 3], t_), q0_.w, acc0_, 0, 0, 0);            \
-                acc1_ = __builtin_amdgcn_mfma_f32_4x4x1f32(f4c(A[c_ * 4 + 3], t_), q1_.w, acc1_, 0, 0, 0);            \
+            _Pragma("unroll") for (int c_ = 0; c_ < NB; c_++) {                                                       \
+                qa_[c_] = na_[c_];                                                                                    \
+                qb_[c_] = nb_[c_];                                                                                    \
             }                                                                                                         \
-            if (P.rl_probe & 2) { acc0_[0] += A[0].x + A[NB * 4 - 1].w; acc1_[1] += A[NB * 2].y; }                    \
+            {                                                                                                         \
+                const int gn0_ = min(g0_ + 2, ng - 1), gn1_ = min(g0_ + 3, ng - 1);                                   \
+                const float *p0_ = sQ + (size_t)gn0_ * NB * 64 + lane, *p1_ = sQ + (size_t)gn1_ * NB * 64 + lane;     \
+                _Pragma("unroll") for (int c_ = 0; c_ < NB; c_++) {                                                   \
+                    na_[c_] = p0_[c_ * 64];                                                                           \
+                    nb_[c_] = p1_[c_ * 64];                                                                           \
+                }                                                                                                     \
+            }                                                                                                         \
+            if (!(P.rl_probe & 2)) {                                                                                  \
+                _Pragma("unroll") for (int c_ = 0; c_ < NB; c_++) { RL_MF16(A, c_) }                                  \
+            } else {                                                                                                  \
+                acc0_[0] += A[0].x + A[NB * 4 - 1].w + qa_[0];                                                        \
+                acc1_[1] += A[NB * 2].y + qb_[NB - 1];                                                                \
+            }                                                                                                         \
             if (!(P.rl_probe & 1)) {                                                                                  \
-                epilogue(g0_, acc0_, CH, Y, I0, I1);                                                                  \
-                if (g0_ + 1 < ng) epilogue(g0_ + 1, acc1_, CH, Y, I0, I1);                                            \
-            } else if (acc0_[0] + acc1_[1] + Y.x + (float)I0.x + (float)I1.y == 12345.678f) {                         \
+                epilogue(g0_, acc0_, CH, Y, I);                                                                       \
+                if (g0_ + 1 < ng) epilogue(g0_ + 1, acc1_, CH, Y, I);                                                 \
+            } else if (acc0_[0] + acc1_[1] + Y + (float)I == 12345.678f) {                                            \
                 s_cnt[0] = 1;                                                                                         \
             }                                                                                                         \
         }                                                                                                             \
@@ -311,21 +307,24 @@ __global__ __launch_bounds__(256) void k_scan_rl(ScanParams P) {
         //  above -- not inside a pass: an unconditional agent-scope re-read per step from every wave was measured 2x slower.)
         int ch = ch0;
         while (ch + 2 < ch1) {
-            RL_LOAD(a1, y1, i10, i11);
-            RL_STEP(a0, y0, i00, i01, ch);
-            RL_LOAD(a0, y0, i00, i01);
-            RL_STEP(a1, y1, i10, i11, ch + 1);
+            RL_LOAD(a1, y1, i1);
+            RL_STEP(a0, y0, i0, ch);
+            RL_LOAD(a0, y0, i0);
+            RL_STEP(a1, y1, i1, ch + 1);
             ch += 2;
         }
         if (ch + 1 < ch1) {
-            RL_LOAD(a1, y1, i10, i11);
-            RL_STEP(a0, y0, i00, i01, ch);
-            RL_STEP(a1, y1, i10, i11, ch + 1);
+            RL_LOAD(a1, y1, i1);
+            RL_STEP(a0, y0, i0, ch);
+            RL_STEP(a1, y1, i1, ch + 1);
         } else {
-            RL_STEP(a0, y0, i00, i01, ch);
+            RL_STEP(a0, y0, i0, ch);
         }
 #undef RL_LOAD
 #undef RL_STEP
+#undef RL_MF16
+#undef RL_MF4
+#undef RL_MF1
 
         // ---- segment end: sort every non-empty pool, publish its bound, emit it as a record of its pair -------------------
         const long long dbg_e0 = P.wave_clock ? wall_clock64() : 0;
@@ -405,14 +404,18 @@ __global__ __launch_bounds__(256) void k_scan_rl(ScanParams P) {
 
 // ---- host side ---------------------------------------------------------------------------------------------------------
 size_t qk_scan_rl_lds_per_wave(int nblk, int C) {
-    return (size_t)(QK_RL_QB / 4) * nblk * 4 * 4 * 16 + (size_t)QK_RL_QB * C * 12 + (size_t)QK_RL_QB * 4 * 5;
+    return (size_t)(QK_RL_QB / 4) * nblk * 64 * 4 + (size_t)QK_RL_QB * C * 12 + (size_t)QK_RL_QB * 4 * 5;
 }
 
+template <int NB, bool L2>
+static int launch_rl_m(dim3 grid, size_t lds, hipStream_t st, const ScanParams &sp) {
+    QK_HIP(hipFuncSetAttribute((const void *)k_scan_rl<NB, L2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_scan_rl<NB, L2>), grid, dim3(256), lds, st, sp);
+    return QK_OK;
+}
 template <int NB>
 static int launch_rl_t(dim3 grid, size_t lds, hipStream_t st, const ScanParams &sp) {
-    QK_HIP(hipFuncSetAttribute((const void *)k_scan_rl<NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((k_scan_rl<NB>), grid, dim3(256), lds, st, sp);
-    return QK_OK;
+    return sp.metric == QK_METRIC_L2 ? launch_rl_m<NB, true>(grid, lds, st, sp) : launch_rl_m<NB, false>(grid, lds, st, sp);
 }
 
 // grid = hardware workgroups of 4 independent waves; lds = 4 x sp.pack_lds

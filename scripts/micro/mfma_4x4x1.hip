@@ -17,6 +17,59 @@ __global__ void k_layout(float *out) {
     for (int i = 0; i < 4; i++) out[l * 4 + i] = acc[i];
 }
 
+// A-matrix broadcast (CBSZ = 4: the A block named by ABID feeds all 16 blocks)
+template <int ABID>
+__global__ void k_layout_bc(float *out) {
+    const int l = threadIdx.x;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    acc = __builtin_amdgcn_mfma_f32_4x4x1f32((float)(100 + l), (float)(1000 + l), acc, 4, ABID, 0);
+    for (int i = 0; i < 4; i++) out[l * 4 + i] = acc[i];
+}
+
+template <int C0>
+__device__ __forceinline__ void bc16(f32x4 &acc, const float qa, const float *row) {
+    acc = __builtin_amdgcn_mfma_f32_4x4x1f32(qa, row[C0 + 0], acc, 4, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_4x4x1f32(qa, row[C0 + 1], acc, 4, 1, 0);
+    acc = __builtin_amdgcn_mfma_f32_4x4x1f32(qa, row[C0 + 2], acc, 4, 2, 0);
+    acc = __builtin_amdgcn_mfma_f32_4x4x1f32(qa, row[C0 + 3], acc, 4, 3, 0);
+    acc = __builtin_amdgcn_mfma_f32_4x4x1f32(qa, row[C0 + 4], acc, 4, 4, 0);
+    acc = __builtin_amdgcn_mfma_f32_4x4x1f32(qa, row[C0 + 5], acc, 4, 5, 0);
+    acc = __builtin_amdgcn_mfma_f32_4x4x1f32(qa, row[C0 + 6], acc, 4, 6, 0);
+    acc = __builtin_amdgcn_mfma_f32_4x4x1f32(qa, row[C0 + 7], acc, 4, 7, 0);
+    acc = __builtin_amdgcn_mfma_f32_4x4x1f32(qa, row[C0 + 8], acc, 4, 8, 0);
+    acc = __builtin_amdgcn_mfma_f32_4x4x1f32(qa, row[C0 + 9], acc, 4, 9, 0);
+    acc = __builtin_amdgcn_mfma_f32_4x4x1f32(qa, row[C0 + 10], acc, 4, 10, 0);
+    acc = __builtin_amdgcn_mfma_f32_4x4x1f32(qa, row[C0 + 11], acc, 4, 11, 0);
+    acc = __builtin_amdgcn_mfma_f32_4x4x1f32(qa, row[C0 + 12], acc, 4, 12, 0);
+    acc = __builtin_amdgcn_mfma_f32_4x4x1f32(qa, row[C0 + 13], acc, 4, 13, 0);
+    acc = __builtin_amdgcn_mfma_f32_4x4x1f32(qa, row[C0 + 14], acc, 4, 14, 0);
+    acc = __builtin_amdgcn_mfma_f32_4x4x1f32(qa, row[C0 + 15], acc, 4, 15, 0);
+}
+
+// queries as the (broadcast) A operand: lane (b, i) register c holds q_i[16c + b]; rows as B, one row per lane:
+// D[lane l][vgpr i] = q_i . row_l, chain in column order
+__global__ void k_exact_bc(const float *rows /*[64][128]*/, const float *qs /*[4][128]*/, float *out_mfma, float *out_ref) {
+    const int l = threadIdx.x, b = l >> 2, i = l & 3;
+    float qa[8], row[128];
+    for (int c = 0; c < 8; c++) qa[c] = qs[i * 128 + 16 * c + b];
+    for (int k = 0; k < 128; k++) row[k] = rows[l * 128 + k];
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    bc16<0>(acc, qa[0], row);
+    bc16<16>(acc, qa[1], row);
+    bc16<32>(acc, qa[2], row);
+    bc16<48>(acc, qa[3], row);
+    bc16<64>(acc, qa[4], row);
+    bc16<80>(acc, qa[5], row);
+    bc16<96>(acc, qa[6], row);
+    bc16<112>(acc, qa[7], row);
+    for (int q = 0; q < 4; q++) {
+        out_mfma[l * 4 + q] = acc[q];
+        float r = 0.f;
+        for (int k = 0; k < 128; k++) r = __fmaf_rn(rows[l * 128 + k], qs[q * 128 + k], r);
+        out_ref[l * 4 + q] = r;
+    }
+}
+
 template <int CH, int KIND>
 __global__ __launch_bounds__(256) void k_rate(float *out, int iters, long long *clk) {
     const int l = threadIdx.x & 63;
@@ -31,6 +84,9 @@ __global__ __launch_bounds__(256) void k_rate(float *out, int iters, long long *
             for (int c = 0; c < CH; c++) {
                 if (KIND == 0)
                     acc[c] = __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, acc[c], 0, 0, 0);
+                else if (KIND == 2)
+                    acc[c] = (u & 1) ? __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, acc[c], 4, 5, 0)
+                                     : __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, acc[c], 4, 10, 0);
                 else
                     acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[c], 0, 0, 0);
             }
@@ -72,7 +128,7 @@ static void rate(const char *name, float *d_out, long long *d_clk) {
     float ms;
     hipEventElapsedTime(&ms, e0, e1);
     const double n_inst = (double)iters * 16 * CH;  // per wave
-    const double flop_per = KIND == 0 ? 512.0 : 2048.0;
+    const double flop_per = KIND == 1 ? 2048.0 : 512.0;
     const double tflops = n_inst * flop_per * blocks * 4 / (ms * 1e-3) / 1e12;
     // one wave per SIMD: ns per instruction per wave -> cycles at 2.4 GHz
     printf("%-28s chains=%d  %.3f ms  %.1f TFLOP/s  %.2f cycles/inst @2.4GHz\n", name, CH, ms, tflops, ms * 1e-3 / n_inst * 2.4e9);
@@ -106,6 +162,9 @@ int main() {
     rate<2, 0>("4x4x1_16b", d_out, d_clk);
     rate<4, 0>("4x4x1_16b", d_out, d_clk);
     rate<8, 0>("4x4x1_16b", d_out, d_clk);
+    rate<1, 2>("4x4x1_16b cbsz=4", d_out, d_clk);
+    rate<2, 2>("4x4x1_16b cbsz=4", d_out, d_clk);
+    rate<4, 2>("4x4x1_16b cbsz=4", d_out, d_clk);
     rate<1, 1>("16x16x4", d_out, d_clk);
     rate<2, 1>("16x16x4", d_out, d_clk);
     rate<4, 1>("16x16x4", d_out, d_clk);
@@ -136,5 +195,30 @@ int main() {
             bad += a != b;
         }
     printf("128-step 4x4x1 chain vs fmaf chain: %d of 256 results differ in bits\n", bad);
+    // (4) A broadcast: CBSZ = 4, ABID = n -> D[lane l][vgpr i] = A(lane 4n+i) * B(lane l)
+    {
+        bool ok = true;
+        for (int abid : {0, 5, 15}) {
+            if (abid == 0) hipLaunchKernelGGL(k_layout_bc<0>, dim3(1), dim3(64), 0, 0, d_out);
+            if (abid == 5) hipLaunchKernelGGL(k_layout_bc<5>, dim3(1), dim3(64), 0, 0, d_out);
+            if (abid == 15) hipLaunchKernelGGL(k_layout_bc<15>, dim3(1), dim3(64), 0, 0, d_out);
+            hipMemcpy(h.data(), d_out, 256 * 4, hipMemcpyDeviceToHost);
+            for (int l = 0; l < 64; l++)
+                for (int i = 0; i < 4; i++) {
+                    const float want = (float)(100 + 4 * abid + i) * (float)(1000 + l);
+                    if (h[l * 4 + i] != want) {
+                        if (ok) printf("  cbsz=4 abid=%d lane %d vgpr %d: got %.0f want %.0f\n", abid, l, i, h[l * 4 + i], want);
+                        ok = false;
+                    }
+                }
+        }
+        printf("CBSZ=4/ABID=n gives D[lane l][vgpr i] = A(lane 4n+i) * B(lane l): %s\n", ok ? "YES" : "NO");
+        hipLaunchKernelGGL(k_exact_bc, dim3(1), dim3(64), 0, 0, d_rows, d_qs, d_m, d_r);
+        hipMemcpy(hm.data(), d_m, 256 * 4, hipMemcpyDeviceToHost);
+        hipMemcpy(hr.data(), d_r, 256 * 4, hipMemcpyDeviceToHost);
+        int bad2 = 0;
+        for (int x = 0; x < 256; x++) bad2 += memcmp(&hm[x], &hr[x], 4) != 0;
+        printf("128-step broadcast-A chain (queries in 8 registers, rows as B) vs fmaf chain: %d of 256 results differ in bits\n", bad2);
+    }
     return 0;
 }
