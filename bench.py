@@ -215,11 +215,11 @@ def timed_region(ctx, step, nprobe, steps, warmup, settle, dist, dev):
     return elapsed, ev, ev_ph
 
 
-def roofline_of(scan_bytes, ev, traffic=None):
+def roofline_of(scan_bytes, ev, traffic=None, kernel="k_scan"):
     scan_ms = ev["scan_ms"] / max(ev["calls"], 1)
     achieved = scan_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
     return {
-        "kernel": "k_scan", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "kernel": kernel, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
         "algorithmic_bytes_per_launch": int(scan_bytes), "kernel_ms_avg": round(scan_ms, 5), "launches": ev["calls"],
     }
@@ -305,7 +305,8 @@ def run_single_workload(ctx, dev, args, name, sigma, fixed_nprobe, steps, warmup
             "recall_at_k": round(recall, 4), "recall_sweep": sweep, "settle_steps": max(settle, 0),
             "query_batches_rotated": N_BATCHES,
         },
-        "roofline": roofline_of(scan_bytes, ev, committed_traffic(traffic_file, n, d, k, nprobe) if traffic_file else None),
+        "roofline": roofline_of(scan_bytes, ev, committed_traffic(traffic_file, n, d, k, nprobe) if traffic_file else None,
+                                kernel=ctx.last_scan_kernel()),
         "phases_ms": phases_of(ev_ph),
         "build": {"kmeans_s": round(idx["kmeans_s"], 2), "niter": args.niter},
     }
@@ -565,7 +566,7 @@ def run_sharded(ctx, dev, args, dist, rank, world):
             "sharding": "list p on rank p % N, centroids replicated; every rank computes the coarse step, scans the probed "
                         "lists it owns; all-to-all of the per-rank top-k, merge on the rank that owns the query",
         },
-        "roofline": roofline_of(int(sb.item()), ev),
+        "roofline": roofline_of(int(sb.item()), ev, kernel=ctx.last_scan_kernel()),
         "phases_ms": phases_of(ev_ph),
         "build": {"sharded_kmeans_s": round(t_kmeans, 2), "niter": args.niter},
     }

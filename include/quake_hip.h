@@ -36,7 +36,9 @@ typedef enum {
     QK_OK = 0,
     QK_ERR_INVALID = 1,     /* bad argument (std::invalid_argument in the reference) */
     QK_ERR_NOT_FOUND = 2,   /* "List does not exist" (dynamic_inverted_list.cpp:71,79,87) */
-    QK_ERR_HIP = 3,         /* HIP runtime error */
+    QK_ERR_HIP = 3,         /* HIP runtime error; also: a scan launched earlier on the context had to drop result records
+                             * (its record buffer is sized by a host-side upper bound; the kernels raise a host-visible
+                             * flag if that bound is ever wrong) -- reported by the call that synchronises, or the next call */
     QK_ERR_UNSUPPORTED = 4, /* outside the implemented envelope (e.g. k > QK_MAX_K) */
     QK_ERR_OOM = 5
 } qk_status;
@@ -91,6 +93,9 @@ QK_API int qk_ctx_set_timing(qk_ctx *ctx, int mode);
 QK_API int qk_ctx_read_timing(qk_ctx *ctx, qk_timing *sum, int64_t *calls);
 /* Device properties the harness prints: CU count, clock (kHz), total HBM bytes, gcnArchName. */
 QK_API int qk_ctx_device_info(qk_ctx *ctx, int *num_cus, int *clock_khz, int64_t *hbm_bytes, char *arch, int arch_len);
+/* Name of the partition-scan kernel the last qk_scan / qk_search on this context launched ("k_scan", "k_scan (query-sharing)",
+ * "k_scan_rl", "k_search_small", "k_dense"; "" before the first call): what a harness labels its kernel timings with. */
+QK_API int qk_ctx_last_scan_kernel(qk_ctx *ctx, char *name, int name_len);
 
 /* ---- partition store ---------------------------------------------------------------------------
  * Replaces faiss::DynamicInvertedLists / IndexPartition as the thing the scan reads

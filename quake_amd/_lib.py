@@ -46,6 +46,7 @@ SIGNATURES = {
     "qk_ctx_set_squared_l2": (_int, [_vp, _int]),
     "qk_ctx_read_timing": (_int, [_vp, C.POINTER(QkTiming), C.POINTER(_i64)]),
     "qk_ctx_device_info": (_int, [_vp, C.POINTER(_int), C.POINTER(_int), C.POINTER(_i64), C.c_char_p, _int]),
+    "qk_ctx_last_scan_kernel": (_int, [_vp, C.c_char_p, _int]),
     "qk_store_create": (_int, [_vp, _int, C.POINTER(_vp)]),
     "qk_store_destroy": (_int, [_vp]),
     "qk_store_reset": (_int, [_vp]),

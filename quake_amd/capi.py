@@ -121,6 +121,12 @@ class Context:
     def set_squared_l2(self, on=True):
         check(self.lib.qk_ctx_set_squared_l2(self.h, int(bool(on))))
 
+    def last_scan_kernel(self):
+        """name of the partition-scan kernel the last scan / search on this context launched"""
+        buf = C.create_string_buffer(64)
+        check(self.lib.qk_ctx_last_scan_kernel(self.h, buf, 64))
+        return buf.value.decode()
+
     def device_info(self):
         cus, clk, hbm = C.c_int(), C.c_int(), C.c_int64()
         arch = C.create_string_buffer(64)

@@ -52,6 +52,7 @@ int check_metric(int metric) {
 // scan with every pointer in `mem`; parent == nullptr && pids == nullptr -> all lists
 int run_search(qk_ctx *ctx, qk_store *parent, qk_store *s, const float *x, int64_t Q, const int64_t *pids, int P, int nprobe,
                int k, int metric, int64_t *out_ids, float *out_dist, int mem, qk_timing *timing, bool coarse_only) {
+    QK_TRY(qk_check_overflow(ctx));  // a record-buffer overflow of an earlier launch is reported by the next call
     QK_HIP(hipSetDevice(ctx->device));
     if (timing) memset(timing, 0, sizeof(*timing));
     if (Q <= 0) return QK_OK;
@@ -97,8 +98,21 @@ int run_search(qk_ctx *ctx, qk_store *parent, qk_store *s, const float *x, int64
     // small batches: the whole search in one launch (qk_small.hip) -- no prep / group / seed / merge launches
     if (use_parent && !coarse_only && kk > 0 && qk_small_supported(ctx, parent, s, Q, kk, k)) {
         const bool tm = ctx->timing && timing;
+        // one event pair around the one kernel (an event record costs the stream a few microseconds): ev[4], ev[7] per call,
+        // the scan pair of a deferred group otherwise
+        qk_phase_events pe;
+        QK_TRY(pe.begin(ctx, false, 4));
+        for (int i : {0, 3})
+            if (pe.dev[i]) {
+                ctx->ev_free.push_back(pe.dev[i]);
+                pe.dev[i] = nullptr;
+            }
         if (tm) QK_HIP(hipEventRecord(ctx->ev[4], ctx->stream));
+        QK_TRY(pe.mark(1));
+        ctx->last_scan_kernel = "k_search_small";
         QK_TRY(qk_search_small_device(ctx, parent, s, sv.x, Q, kk, k, metric, sv.out_ids, sv.out_dist, !ctx->squared_l2));
+        QK_TRY(pe.mark(2));
+        QK_TRY(pe.mark(3));  // (no event of its own: parks the group)
         if (tm) QK_HIP(hipEventRecord(ctx->ev[7], ctx->stream));
         if (mem == QK_MEM_HOST) {
             if (out_ids) QK_HIP(hipMemcpyAsync(out_ids, sv.out_ids, (size_t)Q * kout * 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -172,6 +186,7 @@ int run_search(qk_ctx *ctx, qk_store *parent, qk_store *s, const float *x, int64
         QK_HIP(hipStreamSynchronize(ctx->stream));
     }
     if (timing) QK_TRY(finish_timing(ctx, coarse_only ? parent : s, timing, use_parent && !coarse_only, coarse_only ? 0 : 4));
+    if (timing || mem == QK_MEM_HOST) QK_TRY(qk_check_overflow(ctx));  // these paths have synchronised: report now
     return QK_OK;
 }
 

@@ -14,6 +14,14 @@ void qk_set_error(const char *fmt, ...) {
     va_end(ap);
 }
 
+int qk_check_overflow(qk_ctx *ctx) {
+    if (ctx && ctx->overflow_host && *(volatile int *)ctx->overflow_host) {
+        *(volatile int *)ctx->overflow_host = 0;
+        QK_FAIL(QK_ERR_HIP, "a scan launched on this context overflowed its record buffer: the results of that call are incomplete");
+    }
+    return QK_OK;
+}
+
 extern "C" {
 
 const char *qk_last_error(void) { return g_err; }
@@ -31,6 +39,9 @@ int qk_ctx_create(int device, qk_ctx **out) {
     QK_HIP(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
     for (auto &e : c->ev) QK_HIP(hipEventCreate(&e));
+    QK_HIP(hipHostMalloc((void **)&c->overflow_host, 64, hipHostMallocMapped));
+    *c->overflow_host = 0;
+    QK_HIP(hipHostGetDevicePointer((void **)&c->overflow_dev, c->overflow_host, 0));
     *out = c;
     return QK_OK;
 }
@@ -45,6 +56,7 @@ int qk_ctx_destroy(qk_ctx *c) {
     if (c->aps) hipFree(c->aps);
     if (c->small_ws) hipFree(c->small_ws);
     if (c->pinned) hipHostFree(c->pinned);
+    if (c->overflow_host) hipHostFree(c->overflow_host);
     if (c->xcd_host) hipHostFree(c->xcd_host);
     if (c->xcd_ev) hipEventDestroy(c->xcd_ev);
     if (c->stream_ev) hipEventDestroy(c->stream_ev);
@@ -84,7 +96,7 @@ int qk_ctx_set_null_stream(qk_ctx *c) {
 int qk_ctx_synchronize(qk_ctx *c) {
     if (!c) QK_FAIL(QK_ERR_INVALID, "qk_ctx_synchronize: ctx is null");
     QK_HIP(hipStreamSynchronize(c->stream));
-    return QK_OK;
+    return qk_check_overflow(c);
 }
 
 int qk_ctx_set_timing(qk_ctx *c, int enabled) {
@@ -120,6 +132,12 @@ int qk_ctx_read_timing(qk_ctx *c, qk_timing *sum, int64_t *calls) {
     for (auto e : c->ev_pending_coarse) c->ev_free.push_back(e);
     c->ev_pending.clear();
     c->ev_pending_coarse.clear();
+    return QK_OK;
+}
+
+int qk_ctx_last_scan_kernel(qk_ctx *c, char *name, int name_len) {
+    if (!c || !name || name_len <= 0) QK_FAIL(QK_ERR_INVALID, "qk_ctx_last_scan_kernel: bad arguments");
+    snprintf(name, (size_t)name_len, "%s", c->last_scan_kernel);
     return QK_OK;
 }
 

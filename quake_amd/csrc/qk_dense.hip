@@ -690,6 +690,7 @@ static int launch_dense_t(hipStream_t st, dim3 grid, size_t lds, const DensePara
 }
 
 int qk_dense_device(qk_ctx *ctx, qk_store *s, int64_t list_no, const qk_scan_args &a, qk_timing *timing, int ev_base) {
+    ctx->last_scan_kernel = "k_dense";
     const int64_t Q = a.Q;
     const int k = a.k;
     const qk_part &pt = s->parts[list_no];

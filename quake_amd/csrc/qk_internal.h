@@ -86,6 +86,9 @@ struct qk_ctx {
     size_t qprep_cap = 0;
     unsigned long long *qprep_best64 = nullptr;  // [Q] set to ~0 by the prep kernel; valid while qprep_best64_n == Q
     int64_t qprep_best64_n = 0;
+    const char *last_scan_kernel = "";  // form of the last scan launch (qk_ctx_last_scan_kernel)
+    int *overflow_host = nullptr;    // pinned, device-visible: a scan kernel sets it when its record buffer overflows
+    int *overflow_dev = nullptr;
     char *qprep_zero = nullptr;      // region cleared by the prep kernel for the scan of the same batch
     size_t qprep_zero_bytes = 0;     // its size; 0 once consumed
     const float4 *qprep_xp4 = nullptr;  // [Q][dpad/4] row-major zero-padded copy of the batch at the head of qprep (qk_scan_rl.hip)
@@ -205,6 +208,8 @@ struct qk_scan_args {
 // zero_bytes > 0: the kernel also clears that many bytes for the scan of this batch (qk_scan_zero_bytes)
 int qk_prep_queries(qk_ctx *ctx, const float *x, int64_t Q, int d, const float4 **xq4, const float **xn, size_t zero_bytes = 0);
 size_t qk_scan_zero_bytes(int64_t npids, int64_t Q);
+// fails (once) if a scan launched earlier on this context dropped records; called at API entry and after synchronising calls
+int qk_check_overflow(qk_ctx *ctx);
 int qk_merge_topk_device(qk_ctx *ctx, const int64_t *in_ids, const float *in_key, int G, int64_t Q, int k, int metric,
                          int64_t *out_ids, float *out_dist, bool sqrt_l2);
 int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *timing, int ev_base);

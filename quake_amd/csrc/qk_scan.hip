@@ -1003,6 +1003,7 @@ __global__ __launch_bounds__(256) void k_scan(ScanParams P) {
                     // pointer chase); further ones are chained through pair_head.  (max_recs is an upper bound of the
                     // records a launch can emit; a slot taken for a record beyond it reads as "none")
                     if (slot < QK_SLOTS - 1) P.pair_slots[(int64_t)mypair * QK_SLOTS + 1 + slot] = myrec < P.max_recs ? myrec : -1;
+                    if (myrec >= P.max_recs) *P.overflow = 1;  // never, if the host bound holds: the context reports it
                     if (myrec < P.max_recs) {
                         // the store of the previous head is deferred to the next emit (or kernel end) so that the
                         // wave does not stall on the exchange's round trip
@@ -1962,6 +1963,7 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
         sp.pair_slots = pair_slots;
         sp.rec_counter = rec_counter;
         sp.max_recs = (int32_t)max_recs;
+        sp.overflow = ctx->overflow_dev;
         sp.rec_hdr = rec_hdr;
         sp.rec_ord = rec_ord;
         sp.rec_id = rec_id;
@@ -2055,6 +2057,7 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
             QK_HIP(hipMemsetAsync(d_clock, 0, (size_t)grid * wpw * 64, st));
             sp.wave_clock = d_clock;
         }
+        ctx->last_scan_kernel = use_rl ? "k_scan_rl" : qshare ? "k_scan (query-sharing)" : "k_scan";
         if (use_rl)
             QK_TRY(qk_launch_scan_rl(nblk, dim3((unsigned)grid), lds_launch, st, sp));
         else

@@ -349,6 +349,7 @@ __global__ __launch_bounds__(256) void k_scan_rl(ScanParams P) {
                 if (cntl > 0) {
                     myrec = rec0 + lane;
                     if (slot < QK_SLOTS - 1) P.pair_slots[(int64_t)mypair * QK_SLOTS + 1 + slot] = myrec < P.max_recs ? myrec : -1;
+                    if (myrec >= P.max_recs) *P.overflow = 1;
                     if (myrec < P.max_recs) {
                         int old = -1;
                         if (slot >= QK_SLOTS - 1) old = atomicExch(&P.pair_head[mypair], myrec);  // beyond the line: chained

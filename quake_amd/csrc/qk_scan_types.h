@@ -40,6 +40,7 @@ struct ScanParams {
     int32_t *pair_slots;
     int32_t *rec_counter;
     int32_t max_recs;
+    int *overflow;       // host-mapped flag of the context: set when a record does not fit (max_recs is meant to be unreachable)
     int2 *rec_hdr;       // [max_recs] {next record of the pair (-1 = end), entry count}
     uint32_t *rec_ord;   // [max_recs][k]
     int64_t *rec_id;     // [max_recs][k]

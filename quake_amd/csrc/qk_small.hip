@@ -19,6 +19,8 @@
 // expanded form with the stored row norms, selection under (key, id) -- so the answers are bit-identical to the batch
 // pipeline's and to the oracle's.
 #include "qk_internal.h"
+
+#include <map>
 #include "qk_device.h"
 
 #include <algorithm>
@@ -50,6 +52,12 @@ struct SmallParams {
     int64_t *rec_id;
     int32_t *rec_cnt;
     unsigned int *ticket;
+    // split coarse step (batches of several queries): workgroup (q, w) computes the keys of its 1/W of the centroids, the W
+    // slices meet in ckeys [Q][c_n] behind a per-query arrival counter (all workgroups of the launch are co-resident: the host
+    // sizes the grid by the occupancy of this kernel)
+    int split;
+    uint32_t *ckeys;
+    unsigned int *arrive;  // [Q], zero between calls (reset with the ticket)
     long long *clock;  // probe (QK_SMALL_CLOCK): phase stamps of workgroup 0 in 100 MHz ticks, or nullptr
 };
 
@@ -205,6 +213,10 @@ __device__ __forceinline__ int block_topk(uint32_t *ord, int64_t *id, int n, int
     return res;
 }
 
+constexpr int QK_SMALL_MAXQ = 256;   // queries (workspace); the default envelope is QK_SMALL_MAXQ_DEFAULT
+constexpr int QK_SMALL_MAXQ_DEFAULT = 32;  // measured (1M x 128, nlist 1024, nprobe 10; device us, this kernel vs the batch pipeline):
+                                           // 1: 40 / -, 8: 51 / 123, 16: 66 / 126, 32: 98 / 134, 64: 153 / 144
+constexpr int QK_SMALL_MAXQW = 4096; // workgroups of one launch (records in the workspace)
 constexpr int QK_SMALL_MAXP = 64;    // nprobe
 constexpr int QK_SMALL_CPT = 16;     // centroids per thread (256 threads): nlist <= 4096
 constexpr int QK_SMALL_MAXK = 32;
@@ -253,18 +265,49 @@ __global__ __launch_bounds__(QK_SMALL_THREADS) void k_search_small(SmallParams P
 
     // ---- A. coarse: keys of this thread's centroids (kept in LDS), then the nprobe smallest under (key, id) -------------------
     // (two centroid rows per thread in flight: the chain of one hides the load latency of the other)
-    for (int r = tid; r < P.c_n; r += 2 * QK_SMALL_THREADS) {
-        const int r2 = r + QK_SMALL_THREADS;
-        uint32_t k1, k2 = 0;
-        if (r2 < P.c_n) {
-            small_row_key2(P.c_vecs, P.c_norms, P.nblk, P.c_row0 + r, P.c_row0 + r2, sq, xn, l2, k1, k2);
-            s_ck[r2] = k2;
-        } else {
-            k1 = small_row_key(P.c_vecs, P.c_norms, P.nblk, P.c_row0 + r, sq, xn, l2);
+    if (!P.split) {
+        // every workgroup of the query computes all the keys: no exchange, W x the L2 reads (fine for one or two queries)
+        for (int r = tid; r < P.c_n; r += 2 * QK_SMALL_THREADS) {
+            const int r2 = r + QK_SMALL_THREADS;
+            uint32_t k1, k2 = 0;
+            if (r2 < P.c_n) {
+                small_row_key2(P.c_vecs, P.c_norms, P.nblk, P.c_row0 + r, P.c_row0 + r2, sq, xn, l2, k1, k2);
+                s_ck[r2] = k2;
+            } else {
+                k1 = small_row_key(P.c_vecs, P.c_norms, P.nblk, P.c_row0 + r, sq, xn, l2);
+            }
+            s_ck[r] = k1;
         }
-        s_ck[r] = k1;
+        __syncthreads();
+    } else {
+        // this workgroup's 1/W of the centroids -> ckeys[q]; arrival counter; then everybody reads the whole key row.
+        // (redundant keys cost Q x W x c_n x d x 4 bytes of L2 reads: 8 queries x 52 workgroups x 512 KB = 213 MB, 72 us)
+        const int r0 = (int)(((long long)P.c_n * w) / P.W), r1 = (int)(((long long)P.c_n * (w + 1)) / P.W);
+        uint32_t *krow = P.ckeys + (int64_t)q * P.c_n;
+        for (int r = r0 + tid; r < r1; r += 2 * QK_SMALL_THREADS) {
+            const int r2 = r + QK_SMALL_THREADS;
+            uint32_t k1, k2 = 0;
+            if (r2 < r1) {
+                small_row_key2(P.c_vecs, P.c_norms, P.nblk, P.c_row0 + r, P.c_row0 + r2, sq, xn, l2, k1, k2);
+                __hip_atomic_store(&krow[r2], k2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                k1 = small_row_key(P.c_vecs, P.c_norms, P.nblk, P.c_row0 + r, sq, xn, l2);
+            }
+            __hip_atomic_store(&krow[r], k1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // the exchange runs on agent-scope atomics end to end (keys, counter, reads): no L2 write-back / invalidate.  (A release
+        // fence here, executed by all 8 waves of every workgroup, is a buffer_wbl2 each: the wait grew to 30-40 us.)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            atomicAdd(&P.arrive[q], 1u);
+            while (__hip_atomic_load(&P.arrive[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)P.W) __builtin_amdgcn_s_sleep(1);
+        }
+        __syncthreads();
+        for (int r = tid; r < P.c_n; r += QK_SMALL_THREADS)
+            s_ck[r] = __hip_atomic_load(&krow[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
     }
-    __syncthreads();
     if (P.clock && tid == 0 && blockIdx.x == 0) P.clock[1] = wall_clock64();
     const int want = min(P.nprobe, P.c_n);
     // the `want` nearest under (key, partition id), in rank order
@@ -369,6 +412,7 @@ __global__ __launch_bounds__(QK_SMALL_THREADS) void k_search_small(SmallParams P
         if (s_last) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             P.ticket[q] = 0;  // ready for the next call on this stream
+            if (P.split) P.arrive[q] = 0;  // (every workgroup of the query is past the arrival wait: it took a ticket)
         }
     }
     __syncthreads();
@@ -430,11 +474,11 @@ __global__ __launch_bounds__(QK_SMALL_THREADS) void k_search_small(SmallParams P
 
 // ---- host side -----------------------------------------------------------------------------------------------------------
 // Supported envelope (qk_search routes everything else through the batch pipeline): flat parent with one list of at most
-// 4096 centroids whose ids are >= 0, nprobe <= 64, k <= 32, Q <= 64.
+// 4096 centroids whose ids are >= 0, nprobe <= 64, k <= 32, Q <= 64 (QK_SMALL_MAXQ_DEFAULT).
 bool qk_small_supported(qk_ctx *ctx, qk_store *parent, qk_store *s, int64_t Q, int nprobe, int k) {
     static const int enabled = qk_env_int("QK_SMALL", 1);
-    static const int max_q = qk_env_int("QK_SMALL_MAX_Q", 6);  // measured (1M x 128, nprobe 10): 1 query 62 vs 95 us, 4: 68 vs 100, 16: 129 vs 111
-    if (!enabled || !parent || Q <= 0 || Q > std::min(64, max_q)) return false;
+    static const int max_q = qk_env_int("QK_SMALL_MAX_Q", QK_SMALL_MAXQ_DEFAULT);
+    if (!enabled || !parent || Q <= 0 || Q > std::min(QK_SMALL_MAXQ, max_q)) return false;
     if (k > QK_SMALL_MAXK || nprobe > QK_SMALL_MAXP || nprobe <= 0) return false;
     if (parent->nlist != 1 || parent->ntotal <= 0 || parent->ntotal > 256 * QK_SMALL_CPT) return false;  // <= 4096 centroids
     if (parent->min_id_seen < 0 || parent->d != s->d) return false;
@@ -458,8 +502,36 @@ int qk_search_small_device(qk_ctx *ctx, qk_store *parent, qk_store *s, const flo
     W = std::min(W, std::max(1, 1024 / k));
     W = std::min<int64_t>(W, std::max<int64_t>(1, 2048 / Q));
     const int cap = 1024;
-    // persistent workspace (tickets must stay zero between calls)
-    const size_t need = (size_t)64 * 64 * QK_SMALL_MAXK * 12 + (size_t)64 * 64 * 4 + 64 * 4 + 1024;
+    const size_t lds = (size_t)s->dpad * 4 + (size_t)cap * 12 + (size_t)((c_n + 7) & ~7) * 12 + 64;
+    if (lds > 48 * 1024) QK_HIP(hipFuncSetAttribute((const void *)k_search_small, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    // split coarse step: the workgroups of a query wait for each other, so the whole grid has to be resident at once
+    static const int split_env = qk_env_int("QK_SMALL_SPLIT", -1);  // -1 auto, 0 never, 1 always
+    static const int split_min_wgs = qk_env_int("QK_SMALL_SPLIT_MIN", 96);
+    int resident = 0;
+    {
+        static std::map<size_t, int> occ_cache;  // by LDS size (the only launch parameter occupancy depends on)
+        auto it = occ_cache.find(lds);
+        if (it == occ_cache.end()) {
+            int per_cu = 0;
+            QK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_search_small, QK_SMALL_THREADS, lds));
+            it = occ_cache.emplace(lds, per_cu * std::max(1, ctx->prop.multiProcessorCount)).first;
+        }
+        resident = it->second;
+    }
+    bool split = split_env == 1 || (split_env < 0 && Q * (int64_t)W >= split_min_wgs);
+    if (split) {
+        if (resident < Q) {
+            split = false;  // cannot even hold one workgroup per query: redundant keys
+        } else {
+            W = (int)std::min<int64_t>(W, resident / Q);
+        }
+    }
+    if (!split) W = std::min<int64_t>(W, std::max<int64_t>(1, QK_SMALL_MAXQW / Q));
+    // persistent workspace (tickets and arrival counters must stay zero between calls)
+    const size_t sz_rec_id = (size_t)QK_SMALL_MAXQW * QK_SMALL_MAXK * 8, sz_rec_ord = (size_t)QK_SMALL_MAXQW * QK_SMALL_MAXK * 4;
+    const size_t sz_cnt = (size_t)QK_SMALL_MAXQW * 4, sz_tick = (size_t)QK_SMALL_MAXQ * 4;
+    const size_t sz_keys = (size_t)QK_SMALL_MAXQ * 256 * QK_SMALL_CPT * 4;
+    const size_t need = sz_rec_id + sz_rec_ord + sz_cnt + 2 * sz_tick + sz_keys + 1024;
     if (!ctx->small_ws) {
         QK_HIP(hipMalloc((void **)&ctx->small_ws, need));
         QK_HIP(hipMemsetAsync(ctx->small_ws, 0, need, ctx->stream));
@@ -489,12 +561,17 @@ int qk_search_small_device(qk_ctx *ctx, qk_store *parent, qk_store *s, const flo
     P.out_dist = out_dist;
     char *b = ctx->small_ws;
     P.rec_id = (int64_t *)b;
-    b += (size_t)64 * 64 * QK_SMALL_MAXK * 8;
+    b += sz_rec_id;
     P.rec_ord = (uint32_t *)b;
-    b += (size_t)64 * 64 * QK_SMALL_MAXK * 4;
+    b += sz_rec_ord;
     P.rec_cnt = (int32_t *)b;
-    b += (size_t)64 * 64 * 4;
+    b += sz_cnt;
     P.ticket = (unsigned int *)b;
+    b += sz_tick;
+    P.arrive = (unsigned int *)b;
+    b += sz_tick;
+    P.ckeys = (uint32_t *)b;
+    P.split = split ? 1 : 0;
     static const bool probe_clock = qk_env_set("QK_SMALL_CLOCK");
     static long long *d_clock = nullptr;
     P.clock = nullptr;
@@ -503,8 +580,6 @@ int qk_search_small_device(qk_ctx *ctx, qk_store *parent, qk_store *s, const flo
         QK_HIP(hipMemsetAsync(d_clock, 0, 64, ctx->stream));
         P.clock = d_clock;
     }
-    const size_t lds = (size_t)s->dpad * 4 + (size_t)cap * 12 + (size_t)((c_n + 7) & ~7) * 12 + 64;
-    if (lds > 48 * 1024) QK_HIP(hipFuncSetAttribute((const void *)k_search_small, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_search_small, dim3((unsigned)(Q * W)), dim3(QK_SMALL_THREADS), lds, ctx->stream, P);
     QK_HIP(hipGetLastError());
     if (probe_clock) {

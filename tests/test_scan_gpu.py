@@ -170,8 +170,9 @@ def test_large_k_and_limits(ctx):
 
 @pytest.mark.parametrize("metric", ["l2", "ip"])
 def test_small_batches_one_launch_search(ctx, metric):
-    """Q <= 16 with a flat parent goes through the one-launch search (qk_small.hip): coarse + selection + scan + merge in one
-    kernel.  Same bits as the oracle for every (Q, nprobe, k), with an empty list, a list shorter than k, duplicated
+    """Q <= 32 with a flat parent goes through the one-launch search (qk_small.hip): coarse + selection + scan + merge in one
+    kernel -- with the coarse keys computed once per workgroup (one or two queries) or split across the workgroups of a query
+    behind an arrival counter (larger batches).  Same bits as the oracle for every (Q, nprobe, k), with an empty list, a list shorter than k, duplicated
     centroids (a tie that straddles the nprobe cut: ordered by partition id) and duplicated rows (ties ordered by id)."""
     ivf = make_ivf(30000, 96, 40, seed=41, metric=metric, empty=(7,))
     cent = ivf["centroids"].copy()
@@ -186,14 +187,23 @@ def test_small_batches_one_launch_search(ctx, metric):
     s.build_csr(ivf["offsets"], ivf["ids"], vecs)
     parent = Store(ctx, 96)
     parent.build_csr(np.array([0, 40], np.int64), np.arange(40, dtype=np.int64), cent)
-    q = make_queries(16, 96, seed=42, like=ivf["x"], metric=metric)
+    q = make_queries(32, 96, seed=42, like=ivf["x"], metric=metric)
     q[5] = vecs[a0 + 3]  # sits on a duplicated row of list 3 (and next to the duplicated centroids)
-    for Q in (1, 3, 16):
+    for Q in (1, 3, 8, 16, 32):
         for nprobe, k in ((1, 1), (2, 10), (3, 10), (10, 10), (40, 32), (64, 5)):
-            gi, gd = ctx.search(parent, s, q[:Q], nprobe, k, metric)
-            oi, od = O.search(q[:Q], cent, vecs, ivf["ids"], ivf["offsets"], nprobe, k, metric, batched_scan=True)
-            np.testing.assert_array_equal(gi, oi, err_msg=f"Q={Q} nprobe={nprobe} k={k}")
-            np.testing.assert_array_equal(gd.view(np.uint32), od.view(np.uint32))
+            for rep in range(2):  # the second call finds the arrival counters and tickets the first one left behind
+                gi, gd = ctx.search(parent, s, q[:Q], nprobe, k, metric)
+                assert ctx.last_scan_kernel() == "k_search_small"
+                oi, od = O.search(q[:Q], cent, vecs, ivf["ids"], ivf["offsets"], nprobe, k, metric, batched_scan=True)
+                np.testing.assert_array_equal(gi, oi, err_msg=f"Q={Q} nprobe={nprobe} k={k}")
+                np.testing.assert_array_equal(gd.view(np.uint32), od.view(np.uint32))
+    # deferred timing on this path: one event pair per call, all of it "scan"
+    ctx.set_timing(2)
+    for _ in range(3):
+        ctx.search(parent, s, q[:8], 10, 10, metric)
+    t = ctx.read_timing()
+    ctx.set_timing(0)
+    assert t["calls"] == 3 and t["scan_ms"] > 0.0 and t["coarse_ms"] == 0.0
     # device buffers, and a tiny index where every list is shorter than k
     import torch
     qd = torch.from_numpy(q[:4]).cuda()
