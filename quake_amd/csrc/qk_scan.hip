@@ -230,17 +230,21 @@ __device__ __forceinline__ long long seq_weight(int cnt_q, int size_p, int G, in
 }
 
 // single workgroup of 1024 threads: exclusive scans over the probed partitions
+// SAME_KERNEL: the counters were written with atomics by this very workgroup (single-kernel form) and are read back with agent-
+// scope loads, which go past the L2; behind a kernel boundary (three-kernel form) plain loads do, and hit in L2 -- the scan
+// kernel is a chain of dependent loads and nothing else (4096 active lists: 16 round trips per thread)
+template <bool SAME_KERNEL>
 __device__ __forceinline__ void group_scan_body(const GroupParams &G, long long *s_w /*[48] LDS*/) {
     const int tid = threadIdx.x;
     // (agent-scope loads: in the single-kernel form the counters were just written with atomics by this workgroup)
-    const int n_act = __hip_atomic_load(G.n_act, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int n_act = SAME_KERNEL ? __hip_atomic_load(G.n_act, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *G.n_act;
     const int per = (n_act + 1023) / 1024;
     const int b = tid * per, e = min(n_act, b + per);
     int sq = 0, sa = 0;
     long long stl = 0, sr = 0;
     for (int i = b; i < e; i++) {
         const int p = G.act_list[i];
-        const int c = __hip_atomic_load(&G.g_cnt[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int c = SAME_KERNEL ? __hip_atomic_load(&G.g_cnt[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : G.g_cnt[p];
         const int sz = G.pt_size[p];
         sq += c;
         sa += 1;
@@ -309,7 +313,7 @@ __device__ __forceinline__ void group_scan_body(const GroupParams &G, long long 
     }
     for (int i = b; i < e; i++) {
         const int p = G.act_list[i];
-        const int c = __hip_atomic_load(&G.g_cnt[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int c = SAME_KERNEL ? __hip_atomic_load(&G.g_cnt[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : G.g_cnt[p];
         G.g_qoff[p] = (int)aq;
         ActiveInfo inf;
         inf.toff = at;
@@ -327,7 +331,7 @@ __device__ __forceinline__ void group_scan_body(const GroupParams &G, long long 
 
 __global__ __launch_bounds__(1024) void k_group_scan(GroupParams G) {
     __shared__ long long s_w[48];
-    group_scan_body(G, s_w);
+    group_scan_body<false>(G, s_w);
 }
 
 __device__ __forceinline__ void group_scatter_one(const GroupParams &G, int64_t i) {
@@ -362,7 +366,7 @@ __device__ __forceinline__ void group_small_body(const GroupParams &G) {
         if (i < G.npairs) pp[jj] = group_count_one(G, i, &pos[jj]);
     }
     __syncthreads();
-    group_scan_body(G, s_w);
+    group_scan_body<true>(G, s_w);
     __syncthreads();
 #pragma unroll
     for (int jj = 0; jj < QK_GROUP_SMALL / 1024; jj++) {
@@ -1987,7 +1991,9 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
             // (share of the sequence handed out dynamically: 40 % when partitions are mostly probed by one query -- the cost
             //  model has little to say there and the tail evens out XCD / placement differences --, 25 % otherwise)
             static const int rl_dyn_env = qk_env_int("QK_SCAN_RL_DYN_PCT", -1);
-            const int rl_dyn_pct = rl_dyn_env >= 0 ? rl_dyn_env : (rl_per_list <= 1 ? 40 : 25);
+            // (small launches -- under 1024 pairs, a wave's static share is a chunk or two -- finish sooner without a tail to
+            //  claim: 64 queries x nprobe 10: scan 60 -> 55 us, 8 queries: 46 -> 25 us; from 2560 pairs on the tail pays)
+            const int rl_dyn_pct = rl_dyn_env >= 0 ? rl_dyn_env : (npairs < 1024 ? 0 : rl_per_list <= 1 ? 40 : 25);
             static const int rl_dyn_chunk = qk_env_int("QK_SCAN_RL_DYN_CHUNK", 64);
             sp.dyn_counter = rl_dyn_pct > 0 ? (unsigned long long *)(scal + 16) : nullptr;
             sp.dyn_chunk = std::max(1, rl_dyn_chunk);
