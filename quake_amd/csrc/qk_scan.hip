@@ -1702,14 +1702,17 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
         rlc = RlCost{std::max(1, rl_h0), std::max(1, rl_h1), std::max(0, rl_e), std::max(0, rl_ovh), std::max(1, rl_m)};
         const int64_t present = std::max<int64_t>(1, std::min<int64_t>(s->nlist, std::max<int64_t>(npairs, 1)));
         const int64_t per_list = npairs / present;
-        const bool rl_ok = nblk <= 8 && k <= 32 && !a.per_pair && !emit && npairs > 0 && ctx->qprep_xp4 != nullptr &&
+        const int C_rl = std::min(64, qk_round_up(k + 32, 4));
+        // (4 waves per CU, each with its own LDS copy of the pass's queries and 32 pools: d = 128 with k = 32 does not fit)
+        const bool rl_fits = 4 * ((qk_scan_rl_lds_per_wave(nblk, C_rl) + 15) & ~(size_t)15) <= (size_t)160 * 1024;
+        const bool rl_ok = nblk <= 8 && k <= 32 && rl_fits && !a.per_pair && !emit && npairs > 0 && ctx->qprep_xp4 != nullptr &&
                            a.xq4 == (const float4 *)ctx->qprep;
         use_rl = rl_ok && (rl_env == 1 || (rl_env < 0 && per_list < rl_max && P > 1));
         rl_per_list = per_list;
         if (use_rl) {
             nw = 1;
             qshare = 0;
-            C = std::min(64, qk_round_up(k + 32, 4));
+            C = C_rl;
         }
     }
     const int maxch = pick_maxch(C);
