@@ -430,7 +430,12 @@ int qk_store_remove_list(qk_store *s, int64_t list_no) {
     if (list_no < 0 || list_no >= (int64_t)s->parts.size() || !s->parts[list_no].present) return QK_OK;  // "Already doesn't exist"
     qk_part &p = s->parts[list_no];
     if (s->index_valid)
-        for (int64_t id : p.ids) s->id_to_list.erase(id);
+        for (int64_t id : p.ids) {
+            // only the entries that still name THIS list: while refine_lists replaces its lists one after the other, an id of
+            // this list's old contents may already live in (and be indexed under) a list replaced before it
+            auto it = s->id_to_list.find(id);
+            if (it != s->id_to_list.end() && it->second == (int32_t)list_no) s->id_to_list.erase(it);
+        }
     s->ntotal -= p.size;
     s->dead_rows += p.cap;
     p = qk_part();

@@ -365,9 +365,12 @@ class ShardedPartitions:
         # rows of a new list arrive in the order of the original concatenation: with one assignment pass that is the order a
         # single rank would append them in
         ra, rx, ri = self.comm.route_rows(dest, a, x, ids, key=seq)
-        for j, p in enumerate(pids):  # replace the partitions (:481-483)
+        # replace the partitions (:481-483): every old list goes before the first new row comes in (a row that changes lists
+        # must not be forgotten again when its old list is dropped)
+        for p in pids:
             self.local.remove_list(p)
             self.local.add_list(p)
+        for j, p in enumerate(pids):
             if self.owns(p):
                 sel = ra == j
                 self.local.add_entries(p, ri[sel], rx[sel])

@@ -162,3 +162,98 @@ def test_skewed_inserts_compact_the_arena(ctx):
     oi, od = O.batched_serial_scan(q, vecs, ids_, offsets, pids, 10, "l2")
     np.testing.assert_array_equal(gi, oi)
     np.testing.assert_array_equal(gd.view(np.uint32), od.view(np.uint32))
+
+
+def _search_equals_oracle(ctx, s, m, d, rng, metric, k):
+    keys, (vecs, ids, offs) = m.csr(d)
+    live = [p for p in keys]
+    sizes = {p: len(m.parts[p][0]) for p in keys}
+    top = max(keys) + 1
+    dense_offs = np.zeros(top + 1, np.int64)
+    for p in range(top):
+        dense_offs[p + 1] = dense_offs[p] + sizes.get(p, 0)
+    order = np.concatenate([np.arange(offs[keys.index(p)], offs[keys.index(p) + 1]) for p in range(top) if p in sizes] or
+                           [np.zeros(0, np.int64)]).astype(np.int64)
+    nq = int(rng.choice([1, 5, 40, 300]))
+    q = rng.standard_normal((nq, d)).astype(np.float32)
+    P = min(len(live), int(rng.choice([1, 3, 8])))
+    pids = np.stack([rng.permutation(np.array(live))[:P] for _ in range(nq)]).astype(np.int64)
+    gi, gd = ctx.scan(s, q, pids, k, metric)
+    oi, od = O.batched_serial_scan(q, vecs[order], ids[order], dense_offs, pids, k, metric)
+    np.testing.assert_array_equal(gi, oi)
+    np.testing.assert_array_equal(gd.view(np.uint32), od.view(np.uint32))
+
+
+@pytest.mark.parametrize("seed", list(range(6)))
+def test_random_mutation_streams(ctx, seed):
+    """40 random operations per stream -- per-list and batched appends, removals (resident and unknown ids), list drop /
+    creation, in-place refinement of random list subsets with 0-2 Lloyd iterations -- with the store compared to the host
+    model (contents AND row order) after every operation and a scan compared to the oracle every few operations."""
+    from quake_amd.capi import Store
+    rng = np.random.default_rng(900 + seed)
+    d = int(rng.choice([8, 40, 100, 128]))
+    nlist = int(rng.choice([3, 9, 30]))
+    metric = str(rng.choice(["l2", "ip"]))
+    ivf = make_ivf(int(rng.choice([50, 3000])), d, nlist, seed=901 + seed, metric=metric)
+    s = Store(ctx, d)
+    s.build_csr(ivf["offsets"], ivf["ids"], ivf["vecs"])
+    m = HostModel(ivf)
+    next_id, next_list = 10 ** 6, nlist
+    for step in range(40):
+        live = sorted(m.parts)
+        kind = int(rng.integers(0, 6))
+        if kind == 0 and live:
+            p = int(rng.choice(live))
+            n = int(rng.integers(1, 600))
+            v = rng.standard_normal((n, d)).astype(np.float32)
+            ids = np.arange(next_id, next_id + n, dtype=np.int64)
+            next_id += n
+            s.add_entries(p, ids, v)
+            m.add(p, ids, v)
+        elif kind == 1 and live:
+            n = int(rng.integers(1, 500))
+            v = rng.standard_normal((n, d)).astype(np.float32)
+            ids = np.arange(next_id, next_id + n, dtype=np.int64)
+            next_id += n
+            a = rng.choice(live, size=n).astype(np.int64)
+            s.add_batch(ids, v, a)
+            for i in range(n):
+                m.add(int(a[i]), ids[i:i + 1], v[i:i + 1])
+        elif kind == 2:
+            allids = np.concatenate([np.array(x[0], np.int64) for x in m.parts.values()] + [np.zeros(0, np.int64)])
+            if len(allids):
+                kill = rng.choice(allids, size=max(1, min(300, len(allids) // 3)), replace=False)
+                kill = np.concatenate([kill, np.array([10 ** 9 + step])])
+                assert s.remove_ids(kill) == len(kill) - 1
+                m.remove(kill)
+        elif kind == 3 and len(live) > 2:
+            p = int(rng.choice(live))
+            s.remove_list(p)
+            del m.parts[p]
+        elif kind == 4:
+            s.add_list(next_list)
+            m.parts[next_list] = ([], [])
+            next_list += 1
+        elif kind == 5 and len(live) >= 2:
+            sub = [int(p) for p in rng.permutation(live)[:int(rng.integers(2, min(len(live), 6) + 1))]]
+            if sum(len(m.parts[p][0]) for p in sub) == 0:
+                continue
+            cent = rng.standard_normal((len(sub), d)).astype(np.float32)
+            if metric == "ip":
+                cent /= np.linalg.norm(cent, axis=1, keepdims=True)
+            iters = int(rng.integers(0, 3))
+            pv = [np.array(m.parts[p][1], np.float32).reshape(-1, d) for p in sub]
+            pi = [np.array(m.parts[p][0], np.int64) for p in sub]
+            vecs, ids, offs = O.csr_from_partitions(pv, pi, d)
+            rc, rv, ri, ro = O.kmeans_refine_partitions(cent, vecs, ids, offs, metric, iters)
+            if np.isnan(rc).any():
+                continue  # an emptied cluster: the store refuses (QK_ERR_INVALID), covered in test_kmeans_gpu
+            gc = s.refine_lists(np.array(sub, np.int64), cent, metric, iters)
+            np.testing.assert_array_equal(np.asarray(gc).view(np.uint32), rc.view(np.uint32))
+            for j, p in enumerate(sub):
+                m.parts[p] = (list(ri[ro[j]:ro[j + 1]]), [v for v in rv[ro[j]:ro[j + 1]]])
+        assert s.ntotal() == sum(len(x[0]) for x in m.parts.values())
+        assert sorted(int(p) for p in s.list_ids()) == sorted(m.parts)
+        check_equal(s, m, d)
+        if step % 5 == 4 and m.parts and s.ntotal() > 0:
+            _search_equals_oracle(ctx, s, m, d, rng, metric, int(rng.choice([1, 10, 40])))
