@@ -1,0 +1,117 @@
+"""Random operation streams through BOTH mirrors of the reference API -- quake_amd.QuakeIndex (Python) and
+quake_amd.bindings.QuakeIndex (C++ / pybind11) -- side by side: build, add, remove, modify, search at random (nprobe, k),
+refine_partitions on random subsets, save -> load across the two mirrors.  After every operation the two indexes must agree
+(resident ids, partition numbers, search results bit for bit) and exhaustive probing must equal the oracle's flat search over
+the model of resident vectors."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def qb():
+    from quake_amd.build_ext import build_bindings
+    build_bindings()
+    import quake_amd.bindings as b
+    return b
+
+
+def _params(mod, **kw):
+    p = mod()
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("QK_RANDOM_STREAMS", "6")))))  # (a one-off run of 100 passed)
+def test_two_mirrors_and_the_model_agree(qb, seed, tmp_path):
+    import quake_amd as qp
+    rng = np.random.default_rng(300 + seed)
+    d = int(rng.choice([8, 32, 100]))
+    metric = str(rng.choice(["l2", "ip"]))
+    nlist = int(rng.choice([1, 4, 20]))
+    n0 = int(rng.choice([max(nlist * 8, 60), 2500]))
+    x = torch.from_numpy(rng.standard_normal((n0, d)).astype(np.float32))
+    ids = torch.from_numpy(rng.permutation(n0 * 3)[:n0].astype(np.int64))
+    a, b = qp.QuakeIndex(), qb.QuakeIndex()
+    a.build(x.clone(), ids.clone(), _params(qp.IndexBuildParams, nlist=nlist, metric=metric, niter=3))
+    b.build(x.clone(), ids.clone(), _params(qb.IndexBuildParams, nlist=nlist, metric=metric, niter=3))
+    # the model: id -> vector AS STORED (IP normalises at build; later adds are stored as given, clustering.cpp:25-26)
+    model = {int(i): a.get(torch.tensor([int(i)]))[0].numpy().copy() for i in ids.tolist()}
+    next_id = int(ids.max()) + 1
+
+    def agree(tag):
+        assert a.ntotal() == b.ntotal() == len(model), tag
+        assert a.nlist() == b.nlist(), tag
+        ia, ib = np.sort(a.get_ids().numpy()), np.sort(b.get_ids().numpy())
+        np.testing.assert_array_equal(ia, ib, err_msg=tag)
+        np.testing.assert_array_equal(ia, np.sort(np.array(list(model), np.int64)), err_msg=tag)
+
+    def search_both(tag):
+        nq = int(rng.choice([1, 3, 40, 200]))
+        q = torch.from_numpy(rng.standard_normal((nq, d)).astype(np.float32))
+        k = int(rng.choice([1, 10, 50]))
+        nprobe = int(rng.choice([1, 2, max(a.nlist(), 1)]))
+        ra = a.search(q, _params(qp.SearchParams, k=k, nprobe=nprobe, batched_scan=True))
+        rb = b.search(q, _params(qb.SearchParams, k=k, nprobe=nprobe, batched_scan=True))
+        np.testing.assert_array_equal(ra.ids.numpy(), rb.ids.numpy(), err_msg=tag)
+        np.testing.assert_array_equal(ra.distances.numpy().view(np.uint32), rb.distances.numpy().view(np.uint32), err_msg=tag)
+        if nprobe >= a.nlist():  # exhaustive: the flat search of the oracle over the model
+            mid = np.array(sorted(model), np.int64)
+            mv = np.stack([model[int(i)] for i in mid]).astype(np.float32)
+            oi, od = O.batched_serial_scan(q.numpy(), mv, mid, np.array([0, len(mid)], np.int64), np.zeros((nq, 1), np.int64), k, metric)
+            np.testing.assert_array_equal(ra.ids.numpy(), oi, err_msg=tag)
+            np.testing.assert_array_equal(ra.distances.numpy().view(np.uint32), od.view(np.uint32), err_msg=tag)
+
+    agree("build")
+    search_both("build")
+    for step in range(25):
+        kind = int(rng.integers(0, 6))
+        tag = f"seed {seed} step {step} kind {kind}"
+        if kind == 0:
+            n = int(rng.integers(1, 300))
+            v = torch.from_numpy(rng.standard_normal((n, d)).astype(np.float32))
+            i = torch.arange(next_id, next_id + n)
+            next_id += n
+            a.add(v.clone(), i.clone())
+            b.add(v.clone(), i.clone())
+            for jj in range(n):
+                model[int(i[jj])] = v[jj].numpy().copy()
+        elif kind == 1 and len(model) > 10:
+            kill = rng.choice(np.array(list(model), np.int64), size=min(len(model) // 4, 200), replace=False)
+            a.remove(torch.from_numpy(kill))
+            b.remove(torch.from_numpy(kill))
+            for i in kill.tolist():
+                del model[int(i)]
+        elif kind == 2 and len(model) > 4:
+            pick = rng.choice(np.array(list(model), np.int64), size=min(len(model), 20), replace=False)
+            v = torch.from_numpy(rng.standard_normal((len(pick), d)).astype(np.float32))
+            a.modify(torch.from_numpy(pick), v.clone())
+            b.modify(torch.from_numpy(pick), v.clone())
+            for jj, i in enumerate(pick.tolist()):
+                model[int(i)] = v[jj].numpy().copy()
+        elif kind == 3 and a.nlist() >= 2:
+            pids = a.parent.get_ids().numpy()
+            sub = torch.from_numpy(rng.permutation(pids)[:int(rng.integers(2, min(len(pids), 6) + 1))].astype(np.int64))
+            iters = int(rng.integers(0, 2))  # 0 / 1: assignment only, no emptied-cluster NaN
+            a.refine_partitions(sub.clone(), iters)
+            b.refine_partitions(sub.clone(), iters)
+        elif kind == 4:
+            da, db = str(tmp_path / f"a{step}"), str(tmp_path / f"b{step}")
+            a.save(da)
+            b.save(db)
+            a2, b2 = qp.QuakeIndex(), qb.QuakeIndex()
+            a2.load(db)  # each mirror reads what the other one wrote
+            b2.load(da)
+            a, b = a2, b2
+        else:
+            search_both(tag)
+        agree(tag)
+        if step % 4 == 3:
+            search_both(tag + " (periodic)")

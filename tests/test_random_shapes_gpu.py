@@ -136,3 +136,51 @@ def test_random_shape_kmeans_bit_exact(seed):
         np.testing.assert_array_equal(np.asarray(a), ra, err_msg=str(tag))
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("QK_RANDOM_APS", "16")))))
+def test_random_shape_aps_bit_exact(seed):
+    """recall-target search on random shapes: ids, distance bits AND the number of partitions each query visited equal the
+    oracle's walk"""
+    from quake_amd.capi import Context, Store
+    rng = np.random.default_rng(9000 + seed)
+    d = int(rng.choice([8, 33, 64, 128]))
+    nlist = int(rng.choice([8, 40, 200]))
+    n = int(rng.choice([2000, 30000]))
+    metric = str(rng.choice(["l2", "ip"]))
+    cent = rng.standard_normal((nlist, d)).astype(np.float32)
+    w = rng.random(nlist) ** 2 + 1e-3
+    assign = rng.choice(nlist, size=n, p=w / w.sum())
+    x = (cent[assign] + 0.6 * rng.standard_normal((n, d))).astype(np.float32)
+    if metric == "ip":
+        x /= np.linalg.norm(x, axis=1, keepdims=True)
+        cent /= np.linalg.norm(cent, axis=1, keepdims=True)
+    ids = rng.permutation(n).astype(np.int64)
+    order = np.argsort(assign, kind="stable")
+    vecs, aids = np.ascontiguousarray(x[order]), np.ascontiguousarray(ids[order])
+    offsets = np.zeros(nlist + 1, np.int64)
+    offsets[1:] = np.cumsum(np.bincount(assign, minlength=nlist))
+    Q = int(rng.choice([1, 9, 70, 300]))
+    q = (x[rng.integers(0, n, size=Q)] + 0.1 * rng.standard_normal((Q, d))).astype(np.float32)
+    k = int(rng.choice([1, 10, 60]))
+    rt = float(rng.choice([0.5, 0.8, 0.9, 0.99]))
+    frac = float(rng.choice([0.3, 0.6, 1.0]))
+    thr = float(rng.choice([0.0, 0.001, 0.05]))
+    pre = bool(rng.random() < 0.5)
+    if int(nlist * frac) < 2:
+        frac = 1.0
+    ctx = Context(0)
+    try:
+        s = Store(ctx, d)
+        s.build_csr(offsets, aids, vecs)
+        parent = Store(ctx, d)
+        parent.build_csr(np.array([0, nlist], np.int64), np.arange(nlist, dtype=np.int64), cent)
+        tag = dict(d=d, nlist=nlist, n=n, metric=metric, Q=Q, k=k, rt=rt, frac=frac, thr=thr, pre=pre)
+        gi, gd, gn = ctx.search_aps(parent, s, q, k, metric, rt, recompute_threshold=thr, use_precomputed=pre, initial_search_fraction=frac)
+        oi, od, on = O.search_aps(q, cent, vecs, aids, offsets, k, metric, rt, recompute_threshold=thr, use_precomputed=pre,
+                                  initial_search_fraction=frac, expanded=True, num_threads=8)
+        np.testing.assert_array_equal(gn, on, err_msg=str(tag))
+        np.testing.assert_array_equal(gi, oi, err_msg=str(tag))
+        np.testing.assert_array_equal(gd.view(np.uint32), od.view(np.uint32), err_msg=str(tag))
+    finally:
+        ctx.close()
