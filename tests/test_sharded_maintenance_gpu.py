@@ -266,3 +266,84 @@ def test_sharded_build_world2():
     ret = mgr.dict()
     mp.spawn(_build_worker, args=(2, port, ret), nprocs=2, join=True)
     assert ret.get(0) == "ok" and ret.get(1) == "ok"
+
+
+def _random_worker(rank, world, port, seed, ret):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from quake_amd.sharded_maintenance import ShardedQuakeIndex
+        torch.cuda.set_device(0)
+        rng = np.random.default_rng(4000 + seed)  # the same stream of decisions on both ranks
+        metric = str(rng.choice(["l2", "ip"]))
+        ivf = _corpus(metric, d=int(rng.choice([16, 64])), nlist=int(rng.choice([6, 16])), n=int(rng.choice([6000, 30000])), seed=4100 + seed)
+        d = ivf["d"]
+        ix = _plain(ivf, metric)
+        sh = ShardedQuakeIndex.from_global(dist, world, rank, ivf["centroids"], ivf["offsets"], ivf["ids"], ivf["vecs"], metric)
+        next_id = 50_000_000
+        for step in range(14):
+            live = ix._list_ids()
+            sizes = dict(zip(live, ix._partition_sizes(live)))
+            kind = int(rng.integers(0, 6))
+            if kind == 0:  # split one or two partitions that are large enough
+                big = [p for p in live if sizes[p] >= 16]
+                if not big:
+                    continue
+                pick = [int(p) for p in rng.permutation(big)[:int(rng.integers(1, 3))]]
+                op = ("split", pick)
+                _apply(sh.partitions, False, [op])
+                _apply(ix, True, [op])
+            elif kind == 1 and len(live) > 3:  # delete (with reassignment) one partition
+                op = ("delete", [int(rng.choice(live))])
+                _apply(sh.partitions, False, [op])
+                _apply(ix, True, [op])
+            elif kind == 2 and len(live) >= 2:  # one assignment pass over a random subset
+                sub = [int(p) for p in rng.permutation(live)[:int(rng.integers(2, min(len(live), 6) + 1))]]
+                if sum(sizes[p] for p in sub) == 0:
+                    continue
+                op = ("refine", sub, int(rng.integers(0, 2)))
+                _apply(sh.partitions, False, [op])
+                _apply(ix, True, [op])
+            elif kind == 3:
+                n = int(rng.integers(1, 400))
+                nx = rng.standard_normal((n, d)).astype(np.float32)
+                nid = np.arange(next_id, next_id + n, dtype=np.int64)
+                next_id += n
+                sh.add(nx, nid)
+                ix.add(torch.from_numpy(nx), torch.from_numpy(nid))
+            elif kind == 4 and ix.ntotal() > 50:
+                allids = ix.get_ids().numpy()
+                kill = rng.choice(allids, size=min(len(allids) // 5, 300), replace=False)
+                sh.remove(kill)
+                ix.remove(torch.from_numpy(kill))
+            assert sh.ntotal() == ix.ntotal() and sh.nlist() == ix.nlist(), (seed, step, kind)
+            _same_lists(sh, ix, rank, world)
+            nq = 64
+            q = torch.from_numpy(rng.standard_normal((nq, d)).astype(np.float32)).cuda()
+            nprobe = int(rng.choice([1, 3, sh.nlist()]))
+            k = int(rng.choice([1, 10, 40]))
+            gi, gd = sh.search(q, min(nprobe, sh.nlist()), k)
+            ri, rd = _search_plain(ix, q, min(nprobe, sh.nlist()), k)
+            torch.cuda.synchronize()
+            assert torch.equal(gi, ri), (seed, step, kind, nprobe, k)
+            assert torch.equal(gd.view(torch.int32), rd.view(torch.int32)), (seed, step, kind, nprobe, k)
+        ret[rank] = "ok"
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("QK_RANDOM_SHARDED", "3")))))  # (a one-off run of 30 passed)
+def test_world2_random_streams(seed):
+    """random maintenance / update streams on two ranks against one process applying the same operations"""
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_random_worker, args=(2, port, seed, ret), nprocs=2, join=True)
+    assert ret.get(0) == "ok" and ret.get(1) == "ok"
