@@ -72,6 +72,19 @@ def test_random_shape_search_bit_exact(seed):
         gi, gd = ctx.scan(s, c["q"], pids, c["k"], c["metric"])
         np.testing.assert_array_equal(gi, oi, err_msg=f"{tag} (coarse + scan) form={ctx.last_scan_kernel()}")
         np.testing.assert_array_equal(gd.view(np.uint32), od.view(np.uint32))
+        if seed % 3 == 0:  # the same batch handed over in device memory (no staging, results written in place)
+            import torch
+            ti, td = ctx.search(parent, s, torch.from_numpy(c["q"]).cuda(), c["nprobe"], c["k"], c["metric"])
+            ctx.synchronize()
+            np.testing.assert_array_equal(ti.cpu().numpy(), oi, err_msg=f"{tag} (device buffers)")
+            np.testing.assert_array_equal(td.cpu().numpy().view(np.uint32), od.view(np.uint32))
+        # no parent: every list is scanned (query_coordinator.cpp:624-626)
+        if c["Q"] * c["nlist"] <= 40000:
+            fi, fd = ctx.search(None, s, c["q"], 1, c["k"], c["metric"])
+            allp = np.broadcast_to(np.arange(c["nlist"], dtype=np.int64), (c["Q"], c["nlist"])).copy()
+            ei, ed = O.batched_serial_scan(c["q"], c["vecs"], c["ids"], c["offsets"], allp, c["k"], c["metric"])
+            np.testing.assert_array_equal(fi, ei, err_msg=f"{tag} (flat) form={ctx.last_scan_kernel()}")
+            np.testing.assert_array_equal(fd.view(np.uint32), ed.view(np.uint32))
     finally:
         ctx.close()
 
