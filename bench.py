@@ -182,32 +182,48 @@ def pick_nprobe(step, batches, gts, k, target, fixed, recall_fn):
     return nprobe, rec(nprobe), sweep
 
 
-def timed_region(ctx, step, nprobe, steps, warmup, settle, dist, dev):
+def timed_region(ctx, step, nprobe, steps, warmup, settle, dist, dev, ctxs=None):
     """settle + warmup untimed, then EXACTLY `steps` steps between barrier + synchronize; one HIP event pair per step around
-    the scan kernel (timing mode 3).  Returns (elapsed seconds max over ranks, scan-kernel event sums, phase sums)."""
-    ctx.set_timing(0)
+    the scan kernel (timing mode 3).  ctxs: the contexts the steps rotate over (step i runs on ctxs[i % len]; each has its own
+    stream and output buffers, so len(ctxs) batches are in flight at a time); default [ctx].
+    Returns (elapsed seconds max over ranks, scan-kernel event sums, phase sums)."""
+    ctxs = ctxs or [ctx]
+    nc = len(ctxs)
+
+    def sync_all():
+        for c in ctxs:
+            c.synchronize()
+        torch.cuda.synchronize()
+
+    for c in ctxs:
+        c.set_timing(0)
     for i in range(max(settle, 0)):
-        step(nprobe, i % N_BATCHES)
+        step(nprobe, i % N_BATCHES, i % nc)
     for i in range(warmup):
-        step(nprobe, i % N_BATCHES)
-    ctx.set_timing(3)
+        step(nprobe, i % N_BATCHES, i % nc)
+    for c in ctxs:
+        c.set_timing(3)
     if dist is not None:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync_all()
     t0 = time.perf_counter()
     for i in range(steps):
-        step(nprobe, i % N_BATCHES)
+        step(nprobe, i % N_BATCHES, i % nc)
     if dist is not None:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync_all()
     elapsed = time.perf_counter() - t0
-    ev = ctx.read_timing()
-    ctx.set_timing(2)  # phase breakdown: a short untimed pass with events around every phase
+    ev = None
+    for c in ctxs:  # the scan-kernel event pairs of all streams
+        e = c.read_timing()
+        ev = e if ev is None else {kk: ev[kk] + e[kk] for kk in ev}
+    ctx.set_timing(2)  # phase breakdown: a short untimed pass on ONE stream with events around every phase
     for i in range(min(steps, 20)):
-        step(nprobe, i % N_BATCHES)
-    torch.cuda.synchronize()
+        step(nprobe, i % N_BATCHES, 0)
+    sync_all()
     ev_ph = ctx.read_timing()
-    ctx.set_timing(0)
+    for c in ctxs:
+        c.set_timing(0)
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if str(dist.get_backend()).lower() != "gloo" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -274,11 +290,17 @@ def run_single_workload(ctx, dev, args, name, sigma, fixed_nprobe, steps, warmup
     torch.cuda.synchronize()
     log(f"[{name}] brute-force ground truth of {N_BATCHES} batches {time.time() - t0:.2f}s")
     del x
-    out_i = torch.empty((Q, k), dtype=torch.int64, device=dev)
-    out_d = torch.empty((Q, k), dtype=torch.float32, device=dev)
+    # (extra measurement) `inflight` batches at a time: step i runs on context i % inflight -- own HIP stream, own output buffers, the same
+    # stores -- so the small kernels of one batch (prep, nearest centroid, group + seed, merge) run under the partition
+    # scan of another.  (The extra contexts use the library's private non-blocking streams.)
+    from quake_amd.capi import Context
+    inflight = max(1, int(args.inflight))
+    ctxs = [ctx] + [Context(dev.index) for _ in range(inflight - 1)]
+    outs = [(torch.empty((Q, k), dtype=torch.int64, device=dev), torch.empty((Q, k), dtype=torch.float32, device=dev))
+            for _ in range(inflight)]
 
-    def step(nprobe, b):
-        return ctx.search(parent, store, batches[b], nprobe, k, metric, out=(out_i, out_d))
+    def step(nprobe, b, slot=0):
+        return ctxs[slot].search(parent, store, batches[b], nprobe, k, metric, out=outs[slot])
 
     nprobe, recall, sweep = pick_nprobe(step, batches, gts, k, args.recall_target, fixed_nprobe,
                                         lambda ri, b: recall_at_k(ri, gts[b], k))
@@ -286,7 +308,17 @@ def run_single_workload(ctx, dev, args, name, sigma, fixed_nprobe, steps, warmup
     ctx.set_timing(1)
     _, _, tinfo = ctx.search(parent, store, batches[0], nprobe, k, metric, timing=True)
     log(f"[{name}] phases (ms):", {kk: round(v, 4) if isinstance(v, float) else v for kk, v in tinfo.items()})
-    elapsed, ev, ev_ph = timed_region(ctx, step, nprobe, steps, warmup, settle, None, dev)
+    # the timed region of the contract: one batch at a time on one stream
+    elapsed, ev, ev_ph = timed_region(ctx, step, nprobe, steps, warmup, settle, None, dev, ctxs=[ctx])
+    piped = None
+    if inflight > 1:  # the same steps with `inflight` batches in flight, reported beside the headline figure (never `value`)
+        n2 = max(steps // 2, 10)
+        e2, ev2, _ = timed_region(ctx, step, nprobe, n2, min(warmup, 10), 0, None, dev, ctxs=ctxs)
+        piped = {"batches_in_flight": inflight, "value": round(Q * n2 / e2, 1), "unit": "queries/s",
+                 "ms_per_step": round(1e3 * e2 / n2, 4), "steps": n2,
+                 "scan_kernel_ms_avg": round(ev2["scan_ms"] / max(ev2["calls"], 1), 5),
+                 "note": f"step i runs on HIP stream i % {inflight} (own context and output buffers, same index): the small kernels "
+                         "of one batch run under the partition scan of another; every step is still one complete qk_search"}
     # algorithmic bytes: mean over the rotated batches (each launch reports the unique rows it scanned)
     scan_bytes = 0
     ctx.set_timing(1)
@@ -305,6 +337,7 @@ def run_single_workload(ctx, dev, args, name, sigma, fixed_nprobe, steps, warmup
             "recall_at_k": round(recall, 4), "recall_sweep": sweep, "settle_steps": max(settle, 0),
             "query_batches_rotated": N_BATCHES,
         },
+        "batches_in_flight": piped,
         "roofline": roofline_of(scan_bytes, ev, committed_traffic(traffic_file, n, d, k, nprobe) if traffic_file else None,
                                 kernel=ctx.last_scan_kernel()),
         "phases_ms": phases_of(ev_ph),
@@ -358,6 +391,13 @@ def run_single_workload(ctx, dev, args, name, sigma, fixed_nprobe, steps, warmup
             "ids_equal_serial_lane_sum_frac": round(float((ids_s == gi0).mean()), 5),
         }
         res["speedup_vs_cpu"] = round(res["value"] / res["cpu_baseline"]["value"], 1)
+        if inflight > 1:  # the other stream's answer for the same batch: the same bits
+            gi1, gd1 = step(nprobe, 0, 1)
+            ctxs[1].synchronize()
+            if not (np.array_equal(gi1.cpu().numpy(), gi0) and np.array_equal(gd1.cpu().numpy().view(np.uint32), gd0.view(np.uint32))):
+                raise SystemExit(f"[{name}] PARITY FAILURE: the second stream's answer differs from the first")
+    for c in ctxs[1:]:
+        c.close()
     store.close()
     parent.close()
     del idx, batches, gts
@@ -540,7 +580,7 @@ def run_sharded(ctx, dev, args, dist, rank, world):
     out_d = torch.empty((Q, k), dtype=torch.float32, device=dev)
     sharded = ShardedIndex(GpuEngine(ctx, parent, store, metric), dist, world, rank, result="owner")
 
-    def step(nprobe, b):
+    def step(nprobe, b, slot=0):  # (one batch in flight: the collectives order the steps)
         return sharded.search(batches[b], nprobe, k, out=(out_i, out_d))
 
     def rec(ri, b):
@@ -597,6 +637,8 @@ def main():
     ap.add_argument("--niter", type=int, default=5)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline legs (and the oracle parity check)")
     ap.add_argument("--no-extra", action="store_true", help="headline workload only")
+    ap.add_argument("--inflight", type=int, default=2,
+                    help="extra measurement beside the timed region: the same steps rotated over this many HIP streams (1 = skip)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
 
@@ -644,6 +686,8 @@ def main():
         "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": main_res["config"],
         "roofline": main_res["roofline"], "phases_ms": main_res["phases_ms"], "build": main_res["build"],
     }
+    if main_res.get("batches_in_flight"):
+        result["batches_in_flight"] = main_res["batches_in_flight"]
     if world == 1:
         result["cpu_baseline"] = main_res.get("cpu_baseline")
         if "speedup_vs_cpu" in main_res:
