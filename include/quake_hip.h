@@ -101,6 +101,9 @@ QK_API int qk_ctx_last_scan_kernel(qk_ctx *ctx, char *name, int name_len);
  * Replaces faiss::DynamicInvertedLists / IndexPartition as the thing the scan reads
  * (dynamic_inverted_list.h:25-33, index_partition.h:19-32, accessors dynamic_inverted_list.cpp:68-90).
  * Observable behaviour kept: append order, swap-with-last remove (index_partition.cpp:79-102).      */
+/* A store belongs to the context it was created with (mutations run on that context's stream), but it may be SEARCHED through
+ * any context of the same device -- several at once, each on its own stream -- as long as nobody mutates it meanwhile
+ * (bench.py's `batches_in_flight` measurement does that: two contexts, one index). */
 QK_API int qk_store_create(qk_ctx *ctx, int d, qk_store **out);                 /* DynamicInvertedLists(0, d*4) */
 QK_API int qk_store_destroy(qk_store *s);
 QK_API int qk_store_reset(qk_store *s);                                         /* reset() :300-304 */
