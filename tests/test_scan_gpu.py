@@ -333,3 +333,39 @@ def test_deferred_timing_modes(ctx):
             assert t["group_ms"] > 0.0 and t["coarse_ms"] > 0.0
         assert torch.equal(gi, ref_i) and torch.equal(gd, ref_d)
     assert ctx.read_timing()["calls"] == 0
+
+
+def test_two_contexts_search_one_store_concurrently():
+    """two contexts (two HIP streams) searching the same stores back to back without synchronising in between -- the
+    batches_in_flight measurement of bench.py -- give the answers of a single context"""
+    import torch
+    from quake_amd.capi import Context, Store
+    c1, c2 = Context(0), Context(0)
+    ivf = make_ivf(200000, 64, 128, seed=91)
+    s = Store(c1, 64)
+    s.build_csr(ivf["offsets"], ivf["ids"], ivf["vecs"])
+    parent = Store(c1, 64)
+    parent.build_csr(np.array([0, 128], np.int64), np.arange(128, dtype=np.int64), ivf["centroids"])
+    qs = [torch.from_numpy(make_queries(512, 64, seed=92 + b, like=ivf["x"])).cuda() for b in range(4)]
+    ref = []
+    for nprobe, k in ((1, 10), (8, 10)):
+        for q in qs:
+            ri, rd = c1.search(parent, s, q, nprobe, k, "l2")
+            c1.synchronize()
+            ref.append((ri.clone(), rd.clone()))
+    outs = [(torch.empty((512, 10), dtype=torch.int64, device="cuda"), torch.empty((512, 10), dtype=torch.float32, device="cuda"))
+            for _ in range(8)]
+    for rep in range(5):
+        j = 0
+        for nprobe, k in ((1, 10), (8, 10)):
+            for b, q in enumerate(qs):
+                (c1, c2)[j % 2].search(parent, s, q, nprobe, k, "l2", out=outs[j])
+                j += 1
+        c1.synchronize()
+        c2.synchronize()
+        for j in range(8):
+            assert torch.equal(outs[j][0], ref[j][0]) and torch.equal(outs[j][1], ref[j][1]), (rep, j)
+    s.close()
+    parent.close()
+    c2.close()
+    c1.close()
