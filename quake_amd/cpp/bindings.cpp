@@ -32,6 +32,7 @@ PYBIND11_MODULE(_bindings, m) {
         .def("nlist", &QuakeIndex::nlist)
         .def("d", &QuakeIndex::d)
         .def("set_track_hits", &QuakeIndex::set_track_hits, "Record the partitions each query probes, so that maintenance() can act.")
+        .def("set_latency_profile", &QuakeIndex::set_latency_profile, "Scan-latency grid of the maintenance cost model from a CSV (reference profile format).")
         .def("validate", &QuakeIndex::validate)
         .def_readonly("parent", &QuakeIndex::parent_)
         .def_readonly("partition_manager", &QuakeIndex::partition_manager_)

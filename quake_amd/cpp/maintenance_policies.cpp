@@ -228,6 +228,10 @@ ScanProfileFn device_profile_fn(int d, int n_trials) {
     };
 }
 
+shared_ptr<ListScanLatencyEstimator> default_latency_estimator(int d, const std::string &profile_filename) {
+    return std::make_shared<ListScanLatencyEstimator>(d, kDefaultRangeN, kDefaultRangeK, 5, false, profile_filename);
+}
+
 // ---- MaintenanceCostEstimator -----------------------------------------------------------------------------------------
 MaintenanceCostEstimator::MaintenanceCostEstimator(int d, float alpha, int k, shared_ptr<ListScanLatencyEstimator> lat, ScanProfileFn fn)
     : d_(d), alpha_(alpha), k_(k), latency_estimator_(lat) {

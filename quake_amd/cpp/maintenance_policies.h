@@ -64,6 +64,8 @@ public:
 };
 
 ScanProfileFn device_profile_fn(int d, int n_trials = 5);
+// the default grid (common.h:97-99) with its latency model read from / written to `profile_filename`
+shared_ptr<ListScanLatencyEstimator> default_latency_estimator(int d, const std::string &profile_filename);
 
 class MaintenanceCostEstimator {
 public:

@@ -145,6 +145,13 @@ void QuakeIndex::initialize_maintenance_policy(shared_ptr<MaintenancePolicyParam
     }
 }
 
+void QuakeIndex::set_latency_profile(const std::string &path) {
+    if (!maintenance_policy_ || !partition_manager_) throw std::runtime_error("[QuakeIndex::set_latency_profile()] No maintenance policy set.");
+    auto lat = default_latency_estimator(partition_manager_->d(), path);
+    maintenance_policy_->cost_estimator_ =
+        std::make_shared<MaintenanceCostEstimator>(partition_manager_->d(), maintenance_policy_->params_->alpha, 10, lat);
+}
+
 void QuakeIndex::set_track_hits(bool on) {
     if (!maintenance_policy_) throw std::runtime_error("[QuakeIndex::set_track_hits()] No maintenance policy set.");
     maintenance_policy_->track_hits_ = on;

@@ -42,6 +42,9 @@ public:
     // the reference never feeds its hit tracker from search(): with this switch on, search() records the
     // partitions every query probed, so maintenance() has a window to act on
     void set_track_hits(bool on);
+    // scan-latency grid of the maintenance cost model from a CSV in the reference's profile format
+    // (maintenance_cost_estimator.cpp:259-365): loaded if the file exists, else profiled on the device and saved there
+    void set_latency_profile(const std::string &path);
     bool validate();
     void save(const std::string &path);
     void load(const std::string &path, int n_workers = 0);

@@ -115,3 +115,70 @@ def test_two_mirrors_and_the_model_agree(qb, seed, tmp_path):
         agree(tag)
         if step % 4 == 3:
             search_both(tag + " (periodic)")
+
+
+def _write_profile(path, fn):
+    from quake_amd.maintenance import DEFAULT_LATENCY_ESTIMATOR_RANGE_K as KV, DEFAULT_LATENCY_ESTIMATOR_RANGE_N as NV
+    with open(path, "w") as f:
+        f.write("n_size,k_size\n%d,%d\n" % (len(NV), len(KV)))
+        f.write(",".join(str(v) for v in NV) + "\n" + ",".join(str(v) for v in KV) + "\n")
+        for n in NV:
+            f.write(",".join(repr(float(fn(n, k))) for k in KV) + "\n")
+
+
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("QK_RANDOM_MAINT", "4")))))  # (a one-off run of 40 passed)
+def test_two_mirrors_take_the_same_maintenance_decisions(qb, seed, tmp_path):
+    """the maintenance policy of the Python mirror and of the compiled mirror, given the SAME latency model (a CSV in the
+    reference's profile format) and the SAME searches, split / delete / refine identically: same counts, same partitions,
+    same rows, same search results afterwards"""
+    import quake_amd as qp
+    from quake_amd.maintenance import DEFAULT_LATENCY_ESTIMATOR_RANGE_K as KV, DEFAULT_LATENCY_ESTIMATOR_RANGE_N as NV
+    from quake_amd.maintenance import ListScanLatencyEstimator, MaintenanceCostEstimator
+    rng = np.random.default_rng(600 + seed)
+    d = int(rng.choice([16, 48]))
+    nlist = int(rng.choice([10, 24]))
+    metric = str(rng.choice(["l2", "ip"]))
+    g = torch.Generator().manual_seed(600 + seed)
+    cent = torch.randn(nlist, d, generator=g) * 4
+    w = torch.rand(nlist, generator=g) ** 3 + 0.01
+    n = 20000
+    x = cent[torch.multinomial(w, n, replacement=True, generator=g)] + torch.randn(n, d, generator=g)
+    ids = torch.arange(n)
+    prof = str(tmp_path / "latency.csv")
+    per_row = float(rng.choice([0.5, 1.0, 3.0]))
+    _write_profile(prof, lambda nn, kk: 100.0 + per_row * nn)
+    a, b = qp.QuakeIndex(), qb.QuakeIndex()
+    a.build(x.clone(), ids.clone(), _params(qp.IndexBuildParams, nlist=nlist, metric=metric, niter=3))
+    b.build(x.clone(), ids.clone(), _params(qb.IndexBuildParams, nlist=nlist, metric=metric, niter=3))
+    kw = dict(window_size=int(rng.choice([64, 200])), refinement_radius=int(rng.choice([0, 3])), refinement_iterations=1,
+              min_partition_size=32, delete_threshold_ns=float(rng.choice([0.1, 5.0])), split_threshold_ns=float(rng.choice([0.1, 5.0])),
+              enable_delete_rejection=bool(rng.random() < 0.5))
+    pa, pb = _params(qp.MaintenancePolicyParams, **kw), _params(qb.MaintenancePolicyParams, **kw)
+    lat = ListScanLatencyEstimator(d, NV, KV, 1, profile_filename=prof)
+    a.initialize_maintenance_policy(pa, cost_estimator=MaintenanceCostEstimator(d, pa.alpha, 10, latency_estimator=lat))
+    b.initialize_maintenance_policy(pb)
+    b.set_latency_profile(prof)
+    a.track_hits = True
+    b.set_track_hits(True)
+    sa, sb = _params(qp.SearchParams, k=10, nprobe=2, batched_scan=True), _params(qb.SearchParams, k=10, nprobe=2, batched_scan=True)
+    for rnd in range(3):
+        hot = x[torch.randint(0, n, (kw["window_size"] + 40,), generator=g)] + 0.05 * torch.randn(kw["window_size"] + 40, d, generator=g)
+        for i in range(0, hot.shape[0], 50):
+            ra, rb = a.search(hot[i:i + 50], sa), b.search(hot[i:i + 50], sb)
+            np.testing.assert_array_equal(ra.ids.numpy(), rb.ids.numpy())
+        ta, tb = a.maintenance(), b.maintenance()
+        tag = f"seed {seed} round {rnd} {kw}"
+        assert (ta.n_splits, ta.n_deletes) == (tb.n_splits, tb.n_deletes), tag
+        print(f"[maintenance] seed {seed} round {rnd}: splits {ta.n_splits} deletes {ta.n_deletes} nlist {a.nlist()}")
+        assert a.nlist() == b.nlist() and a.ntotal() == b.ntotal() == n, tag
+        pa_ids, pb_ids = np.sort(a.parent.get_ids().numpy()), np.sort(b.parent.get_ids().numpy())
+        np.testing.assert_array_equal(pa_ids, pb_ids, err_msg=tag)
+        ca = a.parent.get(torch.from_numpy(pa_ids)).numpy()
+        cb = b.parent.get(torch.from_numpy(pa_ids)).numpy()
+        np.testing.assert_array_equal(ca.view(np.uint32), cb.view(np.uint32), err_msg=tag)
+        q = torch.randn(64, d, generator=g)
+        for nprobe in (1, 3, a.nlist()):
+            ra = a.search(q, _params(qp.SearchParams, k=10, nprobe=nprobe, batched_scan=True))
+            rb = b.search(q, _params(qb.SearchParams, k=10, nprobe=nprobe, batched_scan=True))
+            np.testing.assert_array_equal(ra.ids.numpy(), rb.ids.numpy(), err_msg=tag)
+            np.testing.assert_array_equal(ra.distances.numpy().view(np.uint32), rb.distances.numpy().view(np.uint32), err_msg=tag)
