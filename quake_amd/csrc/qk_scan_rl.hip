@@ -193,10 +193,10 @@ __global__ __launch_bounds__(256) void k_scan_rl(ScanParams P) {
         if (P.wave_clock) dbg_t_stage += wall_clock64() - dbg_s0;
 
         // ---- fused top-k of one group's 64 rows x 4 queries: lane = row, acc[i] = query i of the group ----------------------
-        auto epilogue = [&](int g, const f32x4 acc, int ch, const float yn, const int64_t idr) {
+        // (xn4 / tau4: the group's four |x|^2 and bounds, requested from LDS before the group's chains start -- with one wave
+        //  per SIMD a read issued here would be waited for in full, twice per loop step)
+        auto epilogue = [&](int g, const f32x4 acc, int ch, const float yn, const int64_t idr, const float4 xn4, const uint4 tau4) {
             const bool rowvalid = 64 * ch + lane < size_p;
-            const float4 xn4 = *(const float4 *)(s_xn + 4 * g);
-            const uint4 tau4 = *(const uint4 *)(s_tau + 4 * g);
             const float xnv[4] = {xn4.x, xn4.y, xn4.z, xn4.w};
             const uint32_t tauv[4] = {tau4.x, tau4.y, tau4.z, tau4.w};
             uint32_t ordv[4];
@@ -284,6 +284,10 @@ __global__ __launch_bounds__(256) void k_scan_rl(ScanParams P) {
                     nb_[c_] = p1_[c_ * 64];                                                                           \
                 }                                                                                                     \
             }                                                                                                         \
+            const int g1_ = min(g0_ + 1, ng - 1);                                                                     \
+            const float4 xa_ = *(const float4 *)(s_xn + 4 * g0_), xb_ = *(const float4 *)(s_xn + 4 * g1_);            \
+            const uint4 ta_ = *(const uint4 *)(s_tau + 4 * g0_), tb_ = *(const uint4 *)(s_tau + 4 * g1_);             \
+            __builtin_amdgcn_sched_barrier(0); /* (keep the reads up here: the scheduler sinks them to their use otherwise) */ \
             if (!(P.rl_probe & 2)) {                                                                                  \
                 _Pragma("unroll") for (int c_ = 0; c_ < NB; c_++) { RL_MF16(A, c_) }                                  \
             } else {                                                                                                  \
@@ -291,8 +295,8 @@ __global__ __launch_bounds__(256) void k_scan_rl(ScanParams P) {
                 acc1_[1] += A[NB * 2].y + qb_[NB - 1];                                                                \
             }                                                                                                         \
             if (!(P.rl_probe & 1)) {                                                                                  \
-                epilogue(g0_, acc0_, CH, Y, I);                                                                       \
-                if (g0_ + 1 < ng) epilogue(g0_ + 1, acc1_, CH, Y, I);                                                 \
+                epilogue(g0_, acc0_, CH, Y, I, xa_, ta_);                                                             \
+                if (g0_ + 1 < ng) epilogue(g0_ + 1, acc1_, CH, Y, I, xb_, tb_);                                       \
             } else if (acc0_[0] + acc1_[1] + Y + (float)I == 12345.678f) {                                            \
                 s_cnt[0] = 1;                                                                                         \
             }                                                                                                         \
