@@ -1161,10 +1161,20 @@ __global__ __launch_bounds__(64) void k_merge(MergeParams M) {
         }
     };
     auto consume = [&](int rec, const int2 hdr, const uint32_t o0, const int64_t d0) { consume2(rec, hdr, o0, d0, 0u, 0, 0u, false); };
-    for (int r = 0; r < M.P; r++) {
+    // The slot lines of up to 64 pairs are fetched into LDS in one go (they are contiguous: [q * P, q * P + P) x 32 ints): one
+    // memory round trip per 64 pairs instead of one per pair in front of every record fetch.  (Requesting the records of pair
+    // r + 1 before merging those of pair r as well was measured SLOWER -- 22 -> 29 us at nprobe 16: the copies of eight
+    // records' registers cost more than the round trip they hide.)
+    int *s_slots = (int *)(smem + (((size_t)Cm * 12 + 15) & ~(size_t)15));
+    for (int r0 = 0; r0 < M.P; r0 += 64) {
+    const int pb = min(64, M.P - r0);
+    for (int i = lane; i < pb * QK_SLOTS; i += 64) s_slots[i] = M.pair_slots[(q * M.P + r0) * QK_SLOTS + i];
+    __syncthreads();
+    for (int rb = 0; rb < pb; rb++) {
+        const int r = r0 + rb;
         const int64_t pair = q * M.P + r;
         // slot line of the pair: lane 0 = record count, lanes 1..31 = the first records
-        const int sv = lane < QK_SLOTS ? M.pair_slots[pair * QK_SLOTS + lane] : 0;
+        const int sv = lane < QK_SLOTS ? s_slots[rb * QK_SLOTS + lane] : 0;
         const int nrecs = __builtin_amdgcn_readlane(sv, 0);
         const int ns = min(nrecs, QK_SLOTS - 1);
         if (M.clock) {
@@ -1209,6 +1219,8 @@ __global__ __launch_bounds__(64) void k_merge(MergeParams M) {
                 d0 = nd0;
             }
         }
+    }
+    __syncthreads();
     }
     if (M.clock) ck[4] = wall_clock64();
     cnt = compact_pool<MAXCH>(pool_ord, pool_id, cnt, k, lane);
@@ -1720,7 +1732,7 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
                             : qshare ? (size_t)nw * (q_bytes + (size_t)16 * C * 12) : q_bytes + (size_t)nw * 16 * C * 12;
     const int Cm = qk_round_up(k + 64, 64);
     const int maxch_m = Cm <= 128 ? 2 : Cm <= 256 ? 4 : Cm <= 512 ? 8 : 16;
-    const size_t lds_merge = (size_t)Cm * 12;
+    const size_t lds_merge = (((size_t)Cm * 12 + 15) & ~(size_t)15) + (size_t)64 * QK_SLOTS * 4;  // pool + 64 pair slot lines
 
     const int num_cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
     // persistent grid: as many single-wave workgroups as stay resident (LDS-limited; registers allow ~12 per CU); the tile
