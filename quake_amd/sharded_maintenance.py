@@ -471,8 +471,29 @@ class ShardedQuakeIndex:
         return cls(ix, dist, world, rank, result)
 
     # -- search / add / remove ---------------------------------------------------------------------------------------------------
-    def search(self, q, nprobe, k):
+    def search(self, q, nprobe, k=None):
+        """search(q, nprobe, k) -> (ids, distances) on the device; or, with the reference's signature, search(q, search_params)
+        -> an object with .ids / .distances on the host (what quake_amd.workload.replay_workload drives): the batch is padded
+        to a multiple of the number of ranks and the padding rows are dropped again."""
         import torch
+        if k is None and hasattr(nprobe, "k"):
+            sp = nprobe
+            kk = int(sp.k) if sp.k and sp.k > 0 else 1
+            xd = torch.as_tensor(q, dtype=torch.float32).cuda(self.index._device).contiguous()
+            n = int(xd.shape[0])
+            pad = (-n) % self.world
+            if pad:
+                xd = torch.cat([xd, xd[-1:].expand(pad, -1)]).contiguous()
+            was = self.searcher.result
+            self.searcher.result = "all"  # the harness wants the whole answer on every rank
+            try:
+                ids, dist = self.search(xd, min(max(int(sp.nprobe), 1), self.nlist()), kk)
+            finally:
+                self.searcher.result = was
+            from .index import SearchResult
+            res = SearchResult()
+            res.ids, res.distances = ids[:n].cpu(), dist[:n].cpu()
+            return res
         out = self.searcher.search(q, int(nprobe), int(k))
         if self.track_hits:
             p = self.searcher.last_pids
