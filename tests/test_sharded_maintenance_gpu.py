@@ -347,3 +347,61 @@ def test_world2_random_streams(seed):
     ret = mgr.dict()
     mp.spawn(_random_worker, args=(2, port, seed, ret), nprocs=2, join=True)
     assert ret.get(0) == "ok" and ret.get(1) == "ok"
+
+
+def _replay_worker(rank, world, port, wdir, ret):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import quake_amd as quake
+        from quake_amd.sharded_maintenance import ShardedQuakeIndex
+        from quake_amd.workload import replay_workload
+        torch.cuda.set_device(0)
+        base = torch.load(os.path.join(wdir, "base_vectors.pt"), weights_only=True).to(torch.float32)
+        first = torch.load(os.path.join(wdir, "initial_indices.pt"), weights_only=True).to(torch.int64)
+        bp = quake.IndexBuildParams()
+        bp.metric, bp.nlist, bp.niter = "l2", 8, 3
+        sp = quake.SearchParams()
+        sp.k, sp.nprobe, sp.batched_scan = 5, 3, True
+        plain = quake.QuakeIndex()
+        plain.build(base[first], first, bp)
+        pids = [int(p) for p in plain._store.list_ids()]
+        lists = [plain._store.get_list(p) for p in pids]
+        offs = np.concatenate([[0], np.cumsum([len(i) for _, i in lists])]).astype(np.int64)
+        sh = ShardedQuakeIndex.from_global(dist, world, rank, plain.parent.get(torch.tensor(pids)).numpy(), offs,
+                                           np.concatenate([i for _, i in lists]), np.concatenate([v for v, _ in lists]), "l2")
+        ra = replay_workload(wdir, os.path.join(wdir, f"plain_r{rank}"), "plain", nlist=8, search_params=sp, index=plain)
+        rb = replay_workload(wdir, os.path.join(wdir, f"sharded_r{rank}"), "sharded", nlist=8, search_params=sp, index=sh)
+        assert len(ra) == len(rb) > 0
+        for a, b in zip(ra, rb):  # same resident set, same answers (recall is computed from the ids found)
+            assert (a["operation_type"], a["n_total"], a["n_list"]) == (b["operation_type"], b["n_total"], b["n_list"]), (a, b)
+            assert a["recall"] == b["recall"], (a, b)
+            assert b["n_total"] == b["n_resident"]
+        ret[rank] = "ok"
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world2_workload_replay(tmp_path):
+    """the dynamic-workload harness over a sharded index: two ranks replay a runbook (inserts, deletes, query batches) and get
+    the recalls and resident counts of one process replaying it on a plain index"""
+    import torch.multiprocessing as mp
+    from quake_amd.workload import WorkloadSpec, generate_workload
+    g = torch.Generator().manual_seed(77)
+    cent = torch.randn(8, 16, generator=g) * 3
+    base = cent[torch.randint(0, 8, (20000,), generator=g)] + torch.randn(20000, 16, generator=g)
+    wdir = str(tmp_path / "w")
+    spec = WorkloadSpec(metric="l2", insert_ratio=0.3, delete_ratio=0.2, query_ratio=0.5, update_batch_size=500, query_batch_size=65,
+                        number_of_operations=20, initial_size=8000, cluster_size=2500, seed=5)
+    generate_workload(wdir, base, spec)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_replay_worker, args=(2, port, wdir, ret), nprocs=2, join=True)
+    assert ret.get(0) == "ok" and ret.get(1) == "ok"
