@@ -194,6 +194,41 @@ class ListScanLatencyEstimator:
         lo, up = _linear_extrapolate(f11, f21, t), _linear_extrapolate(f12, f22, t)
         return _linear_extrapolate(lo, up, u)
 
+    def estimate_many(self, n, k):
+        """estimate_scan_latency for an int array n (same k): the same IEEE operations in the same order, element by element,
+        so every entry has the bits of the scalar call (the policy's decisions must not depend on which one ran)."""
+        n = np.asarray(n, dtype=np.int64)
+        k = int(k)
+        out = np.zeros(n.shape, np.float64)
+        if k == 0 or n.size == 0:
+            return out
+        if k < self.k_values_[0] or (n[n != 0] < self.n_values_[0]).any():
+            raise IndexError("n or k is below the minimum supported values.")
+        nv = np.asarray(self.n_values_, np.int64)
+        m = np.asarray(self.scan_latency_model_, np.float64)
+        jl, ju, u, k_in = self._axis(self.k_values_, k)
+        inside = n <= nv[-1]
+        it = np.searchsorted(nv, n, side="right")
+        il = np.where(inside, np.where(it == len(nv), len(nv) - 2, it - 1), len(nv) - 2)
+        iu = np.where(inside, np.where(it == len(nv), len(nv) - 1, it), len(nv) - 1)
+        il = np.clip(il, 0, len(nv) - 2)
+        iu = np.clip(iu, 1, len(nv) - 1)
+        span = (nv[iu] - nv[il]).astype(np.float64)
+        t = np.where(inside, np.where(it == len(nv), 1.0, (n - nv[il]) / span), (n - nv[iu]) / span)
+        f11, f12, f21, f22 = m[il, jl], m[il, ju], m[iu, jl], m[iu, ju]
+        if k_in:
+            a = (1 - t) * (1 - u) * f11 + t * (1 - u) * f21 + (1 - t) * u * f12 + t * u * f22
+            lo, up = f21 + t * (f21 - f11), f22 + t * (f22 - f12)
+            b = (1 - u) * lo + u * up
+        else:
+            lo, up = f12 + u * (f12 - f11), f22 + u * (f22 - f21)
+            a = (1 - t) * lo + t * up
+            lo2, up2 = f21 + t * (f21 - f11), f22 + t * (f22 - f12)
+            b = up2 + u * (up2 - lo2)
+        out = np.where(inside, a, b)
+        out[n == 0] = 0.0
+        return out
+
     # the reference's CSV layout (maintenance_cost_estimator.cpp:259-365): header, "n_size,k_size", n values, k values, rows
     def save_latency_profile(self, filename):
         try:
@@ -307,6 +342,28 @@ class MaintenanceCostEstimator:
             cost_new = (total_partitions - 1) * merged_hit_rate * L(int(math.ceil(merged_size)), k)
         return delta_overhead + (cost_new - cost_old)
 
+    def compute_deltas_many(self, sizes, hit_rates, total_partitions, avg_partition_hit_rate, avg_partition_size):
+        """(delete deltas, split deltas) of every partition at once: compute_delete_delta / compute_split_delta element by
+        element, same operations in the same order (10000 partitions: 240 ms of scalar calls -> a few ms)."""
+        sizes = np.asarray(sizes, np.int64)
+        hr = np.asarray(hit_rates, np.float64)
+        Ls, Lm = self.latency_estimator_.estimate_scan_latency, self.latency_estimator_.estimate_many
+        k, tp = self.k_, int(total_partitions)
+        L_size = Lm(sizes, k)
+        split = (Ls(tp + 1, k) - Ls(tp, k)) + Lm(sizes // 2, k) * hr * (2.0 * self.alpha_) - L_size * hr
+        if tp <= 1:
+            return np.zeros(sizes.shape, np.float64), split
+        delta_overhead = Ls(tp - 1, k) - Ls(tp, k)
+        L_avg, L_avg1 = Ls(int(avg_partition_size), k), Ls(int(avg_partition_size + 1), k)
+        cost_old = (tp - 1) * avg_partition_hit_rate * L_avg + hr * L_size
+        merged_size = avg_partition_size + sizes.astype(np.float64) / (tp - 1)
+        merged_hit_rate = avg_partition_hit_rate + hr / float(tp - 1)
+        small = sizes < tp
+        cost_small = sizes * merged_hit_rate * L_avg1 + (tp - sizes - 1) * merged_hit_rate * L_avg
+        cost_big = (tp - 1) * merged_hit_rate * Lm(np.ceil(merged_size).astype(np.int64), k)
+        cost_new = np.where(small, cost_small, cost_big)
+        return delta_overhead + (cost_new - cost_old), split
+
     def compute_delete_delta_w_reassign(self, partition_size, hit_rate, total_partitions, reassign_counts, reassign_sizes,
                                         reassign_hit_rates):
         if total_partitions <= 1:
@@ -358,10 +415,13 @@ class MaintenancePolicy:
         sizes = dict(zip(all_pids, idx._partition_sizes(all_pids)))
         to_delete, to_split = [], []
         ce = self.cost_estimator_
-        for pid in all_pids:
-            hit_rate = float(np.float32(hits.get(pid, 0)) / np.float32(p.window_size))
+        size_v = np.array([sizes[pid] for pid in all_pids], np.int64)
+        hr_v = (np.array([hits.get(pid, 0) for pid in all_pids], np.float32) / np.float32(p.window_size)).astype(np.float64)
+        dd_v, sd_v = ce.compute_deltas_many(size_v, hr_v, total_partitions, scan_fraction, avg_size)
+        for ix_, pid in enumerate(all_pids):
+            hit_rate = float(hr_v[ix_])
             size = sizes[pid]
-            dd = ce.compute_delete_delta(size, hit_rate, total_partitions, scan_fraction, avg_size)
+            dd = float(dd_v[ix_])
             if dd < -p.delete_threshold_ns:
                 if p.enable_delete_rejection and size > p.min_partition_size:
                     # where would its vectors go?  second-nearest centroid of every vector (:79-101)
@@ -374,7 +434,7 @@ class MaintenancePolicy:
                 else:
                     to_delete.append(pid)
             elif size > p.min_partition_size:
-                if ce.compute_split_delta(size, hit_rate, total_partitions) < -p.split_threshold_ns:
+                if float(sd_v[ix_]) < -p.split_threshold_ns:
                     to_split.append(pid)
         if len(to_delete) >= total_partitions:
             # (safety, not in the reference: a model that wants every partition gone would leave the vectors nowhere to

@@ -129,3 +129,28 @@ def test_cost_estimator_invalid_parameters():  # InvalidParametersThrow
         MaintenanceCostEstimator(128, -0.5, 10, latency_estimator=object())
     with pytest.raises(ValueError):
         MaintenanceCostEstimator(128, 0.9, 0, latency_estimator=object())
+
+
+def test_vectorised_cost_deltas_have_the_bits_of_the_scalar_calls():
+    """the policy evaluates every partition at once (estimate_many / compute_deltas_many); each entry must be the scalar
+    function's result bit for bit -- inside the grid, beyond it in n and in k, at the grid nodes, n = 0"""
+    import math
+    from quake_amd.maintenance import (DEFAULT_LATENCY_ESTIMATOR_RANGE_K as KV, DEFAULT_LATENCY_ESTIMATOR_RANGE_N as NV,
+                                       ListScanLatencyEstimator, MaintenanceCostEstimator)
+    rng = np.random.default_rng(0)
+    for trial in range(40):
+        a, b, c = rng.uniform(10, 500), rng.uniform(0.1, 5), rng.uniform(0, 3)
+        lat = ListScanLatencyEstimator(16, NV, KV, 1, profile_fn=lambda n, k: a + b * n + c * k * math.sqrt(n) + rng.uniform(0, 20))
+        ce = MaintenanceCostEstimator(16, float(rng.uniform(0.5, 1.0)), int(rng.choice([1, 10, 300])), latency_estimator=lat)
+        n = np.concatenate([rng.integers(0, 200000, 300), np.array([0, 1, 2, 65535, 65536, 65537, 4096])])
+        for k in (1, 3, 10, 256, 300):
+            v = lat.estimate_many(n, k)
+            s = np.array([lat.estimate_scan_latency(int(x), k) for x in n])
+            assert (v.view(np.uint64) == s.view(np.uint64)).all()
+        tp, sf, avg = int(rng.integers(2, 20000)), float(np.float32(rng.uniform(0, 0.2))), int(rng.integers(1, 5000))
+        sizes = rng.integers(1, 30000, 300)
+        hr = (rng.integers(0, 200, 300).astype(np.float32) / np.float32(200)).astype(np.float64)
+        dd, sd = ce.compute_deltas_many(sizes, hr, tp, sf, avg)
+        d1 = np.array([ce.compute_delete_delta(int(z), float(h), tp, sf, avg) for z, h in zip(sizes, hr)])
+        s1 = np.array([ce.compute_split_delta(int(z), float(h), tp) for z, h in zip(sizes, hr)])
+        assert (dd.view(np.uint64) == d1.view(np.uint64)).all() and (sd.view(np.uint64) == s1.view(np.uint64)).all()
