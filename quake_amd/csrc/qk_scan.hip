@@ -499,6 +499,18 @@ __global__ __launch_bounds__(64) void k_seed_tau(SeedParams S) {
     seed_tau_body<M, 8>(S, blockIdx.x, threadIdx.x);
 }
 
+// The same for larger batches: the counting pass of the three-kernel grouping and the seeding kernel in one launch (the
+// first n_count_blocks workgroups count, the others carry 4 seeding waves each).
+__global__ __launch_bounds__(256) void k_group_count_seed(GroupParams G, SeedParams S, int n_count_blocks, int64_t n_seed_waves) {
+    if ((int)blockIdx.x < n_count_blocks) {
+        const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+        if (i < G.npairs) group_count_one(G, i);
+        return;
+    }
+    const int64_t w = ((int64_t)blockIdx.x - n_count_blocks) * 4 + (threadIdx.x >> 6);
+    if (w < n_seed_waves) seed_tau_body<1, 8>(S, w, threadIdx.x & 63);
+}
+
 // Grouping and bound seeding of a small batch in ONE launch: both depend only on the probed-partition lists, neither on the
 // other.  Workgroup 0 is k_group_small, the others carry 16 seeding waves each (k <= 64: a 64-row sample per wave).  In line
 // the two kernels took 12.4 + 10.1 us of the 0.31 ms bench step.
@@ -1871,7 +1883,7 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
     //  the 64*M-row sample costs 0.1 ms at d = 768; the wider instantiations stay available for probing)
     static const int seed_max_k = qk_env_int("QK_SEED_MAX_K", 64);
     const bool seeded = !no_seed && share_tau && k <= std::min(seed_max_k, 512) && npairs > 0 && npids > 0;
-    bool fused_group = false;
+    bool fused_group = false, fused_count = false;
     if (seeded) {
         // bound seeding: for the first (nearest) partitions of every query, the k-th smallest distance of a 64-row
         // sample goes into gtau[q]
@@ -1907,6 +1919,11 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
             const int64_t nsw = Q * sd.seed_ranks;
             hipLaunchKernelGGL(k_group_seed, dim3((unsigned)(1 + (nsw + 15) / 16)), dim3(1024), 0, st, G, sd, nsw);
             fused_group = true;
+        } else if (k <= 64 && seed_waves == 1 && npairs > QK_GROUP_SMALL && !no_fuse) {
+            const int64_t nsw = Q * sd.seed_ranks;
+            const int ncb = (int)((npairs + 255) / 256);
+            hipLaunchKernelGGL(k_group_count_seed, dim3((unsigned)(ncb + (nsw + 3) / 4)), dim3(256), 0, st, G, sd, ncb, nsw);
+            fused_count = true;
         } else if (k <= 64 && seed_waves == 4)
             hipLaunchKernelGGL((k_seed_tau_wg<4>), sg, dim3(256), 0, st, sd);
         else if (k <= 64 && seed_waves == 2)
@@ -1926,7 +1943,7 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
     } else if (npairs <= QK_GROUP_SMALL && !no_small) {
         hipLaunchKernelGGL(k_group_small, dim3(1), dim3(1024), 0, st, G);
     } else {
-        if (npairs > 0) hipLaunchKernelGGL(k_group_count, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, st, G);
+        if (npairs > 0 && !fused_count) hipLaunchKernelGGL(k_group_count, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, st, G);
         hipLaunchKernelGGL(k_group_scan, dim3(1), dim3(1024), 0, st, G);
         if (npairs > 0) hipLaunchKernelGGL(k_group_scatter, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, st, G);
     }
