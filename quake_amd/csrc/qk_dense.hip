@@ -168,6 +168,14 @@ __global__ __launch_bounds__(64) void k_select_rows(SelectParams S) {
     const uint32_t *row = S.D + q * S.ld;
     uint32_t tau = 0xFFFFFFFFu;
     int cnt = 0;
+    // Pool entries [n_ids, cnt) hold the ROW of a candidate, not yet its id: an id load inside the append path is a dependent
+    // memory round trip per passing key; the ids of all new entries are fetched together right before the pool is selected
+    // (the (key, id) order needs them there), one round trip per selection.
+    int n_ids = 0;
+    auto to_ids = [&](int n) {
+        for (int e = n_ids + lane; e < n; e += 64) pool_id[e] = S.ids[pool_id[e]];
+        n_ids = n;
+    };
     // pass 1: a bound without any top-k bookkeeping.  Every lane keeps the m = ceil(k/64) smallest keys it sees; the k-th
     // smallest of those 64*m values has at least k keys <= it, so it bounds the k-th best overall.  Without it the first keys
     // all pass (tau = inf) and the pool is compacted over and over (k = 81: 199 us per launch instead of ~15).
@@ -248,18 +256,21 @@ __global__ __launch_bounds__(64) void k_select_rows(SelectParams S) {
                     if (pass) {
                         const int sl = cnt + __popcll(m & ((1ull << lane) - 1ull));
                         pool_ord[sl] = kk[t];
-                        pool_id[sl] = S.ids[r];
+                        pool_id[sl] = r;  // the ROW for now: its id is fetched when the pool is next selected (see to_ids)
                     }
                     cnt += __popcll(m);
                     if (cnt > Cm - 64) {  // (unsorted k best + their bound; the final compaction sorts)
+                        to_ids(cnt);
                         uint32_t kth;
                         cnt = select_pool<MAXCH>(pool_ord, pool_id, cnt, k, lane, kth);
+                        n_ids = cnt;
                         if (cnt >= k) tau = min(tau, kth);
                     }
                 }
             }
         }
     }
+    to_ids(cnt);
     cnt = compact_pool<MAXCH>(pool_ord, pool_id, cnt, k, lane);
     for (int e = lane; e < k; e += 64) {
         int64_t oid = -1;
