@@ -1100,7 +1100,7 @@ struct MergeParams {
 };
 
 template <int MAXCH>
-__global__ __launch_bounds__(64) void k_merge(MergeParams M) {
+__device__ __forceinline__ void merge_chain_body(const MergeParams &M) {
     long long ck[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // start, slot line, fetch, bound, consume, final sort, end; [7] = records
     if (M.clock) ck[0] = wall_clock64();
     extern __shared__ __align__(16) unsigned char smem[];
@@ -1256,6 +1256,124 @@ __global__ __launch_bounds__(64) void k_merge(MergeParams M) {
     if (M.clock && lane == 0) {
         ck[6] = wall_clock64();
         for (int i = 0; i < 8; i++) M.clock[q * 8 + i] = ck[i];
+    }
+}
+
+template <int MAXCH>
+__global__ __launch_bounds__(64) void k_merge(MergeParams M) {
+    merge_chain_body<MAXCH>(M);
+}
+
+// FLAT form (k <= 32, P <= 64, no chained records): the walk above is a chain of dependent round trips -- per pair: its records,
+// then their merge (nprobe 16: 17 of them, 36 us).  Here the records of ALL pairs of the query are listed first (slot lines in
+// LDS), the bound comes from the k-th keys of the full records in one round trip, and the entries are read 64 / k records per
+// load instruction (lane = (record, entry)), the next batch in flight while the current one is pooled.  Same pooling, same
+// final compact_pool under (key, id): the same answer.
+template <int MAXCH>
+__global__ __launch_bounds__(64) void k_merge_flat(MergeParams M) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int lane = threadIdx.x;
+    const int64_t q = blockIdx.x;
+    const int k = M.k, Cm = M.Cm, P = M.P;
+    int64_t *pool_id = (int64_t *)smem;
+    uint32_t *pool_ord = (uint32_t *)(smem + (size_t)Cm * 8);
+    int *s_slots = (int *)(smem + (((size_t)Cm * 12 + 15) & ~(size_t)15));  // [P][32]
+    int *s_recs = s_slots + 64 * QK_SLOTS;                                  // [<= P * 31]
+    int *s_recn = s_recs + 64 * (QK_SLOTS - 1);
+    for (int i = lane; i < P * QK_SLOTS; i += 64) s_slots[i] = M.pair_slots[q * P * QK_SLOTS + i];
+    __syncthreads();
+    const int n_p_raw = lane < P ? s_slots[lane * QK_SLOTS] : 0;
+    if (__ballot(n_p_raw > QK_SLOTS - 1)) {  // chained records somewhere: the general walk
+        __syncthreads();
+        merge_chain_body<MAXCH>(M);
+        return;
+    }
+    int inc = n_p_raw;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(inc, o);
+        if (lane >= o) inc += v;
+    }
+    const int R = __shfl(inc, 63);
+    {
+        const int off = inc - n_p_raw;
+        for (int j = 0; j < n_p_raw; j++) s_recs[off + j] = s_slots[lane * QK_SLOTS + 1 + j];
+    }
+    __syncthreads();
+    // bound: the smallest k-th key among the full records; record sizes kept for the entry pass
+    uint32_t tau = 0xFFFFFFFFu;
+    for (int r = lane; r < R; r += 64) {
+        const int rec = s_recs[r];
+        int n = 0;
+        if (rec >= 0 && rec < M.max_recs) {
+            n = M.rec_hdr[rec].y;
+            if (n >= k) tau = min(tau, M.rec_ord[(int64_t)rec * k + k - 1]);
+        }
+        s_recn[r] = n;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) tau = min(tau, (uint32_t)__shfl_xor((int)tau, o));
+    __syncthreads();
+    const int rpb = 64 / k;  // records per load instruction
+    const int j = lane / k, e = lane - j * k;
+    const bool act = j < rpb;
+    const int nb = (R + rpb - 1) / rpb;
+    int cnt = 0;
+    auto load = [&](int b, uint32_t &o, int64_t &dd) -> bool {
+        const int r = b * rpb + j;
+        bool has = false;
+        o = 0xFFFFFFFFu;
+        dd = -1;
+        if (act && r < R) {
+            const int rec = s_recs[r];
+            if (e < s_recn[r]) {
+                has = true;
+                o = M.rec_ord[(int64_t)rec * k + e];
+                dd = M.rec_id[(int64_t)rec * k + e];
+            }
+        }
+        return has;
+    };
+    uint32_t o_cur = 0xFFFFFFFFu, o_nxt;
+    int64_t d_cur = -1, d_nxt;
+    bool h_cur = nb > 0 ? load(0, o_cur, d_cur) : false, h_nxt;
+    for (int b = 0; b < nb; b++) {
+        h_nxt = b + 1 < nb ? load(b + 1, o_nxt, d_nxt) : false;
+        const bool pass = h_cur && o_cur <= tau;
+        const uint64_t m = __ballot(pass);
+        if (m) {
+            if (pass) {
+                const int sl = cnt + __popcll(m & ((1ull << lane) - 1ull));
+                pool_ord[sl] = o_cur;
+                pool_id[sl] = d_cur;
+            }
+            cnt += __popcll(m);
+            if (cnt > Cm - 64) {
+                uint32_t kth;
+                cnt = select_pool<MAXCH>(pool_ord, pool_id, cnt, k, lane, kth);
+                if (cnt >= k) tau = min(tau, kth);
+            }
+        }
+        o_cur = o_nxt;
+        d_cur = d_nxt;
+        h_cur = h_nxt;
+    }
+    cnt = compact_pool<MAXCH>(pool_ord, pool_id, cnt, k, lane);
+    for (int e2 = lane; e2 < k; e2 += 64) {
+        int64_t oid = -1;
+        float od = M.metric == QK_METRIC_IP ? -INFINITY : INFINITY;
+        if (e2 < cnt) {
+            oid = pool_id[e2];
+            const uint32_t o = pool_ord[e2];
+            if (M.metric == QK_METRIC_L2) {
+                const float d2 = __uint_as_float(o);
+                od = M.sqrt_l2 ? sqrtf(d2) : d2;
+            } else {
+                od = ip_from_ord(o);
+            }
+        }
+        M.out_ids[q * k + e2] = oid;
+        if (M.out_dist) M.out_dist[q * k + e2] = od;
     }
 }
 
@@ -2240,8 +2358,14 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
         mp.clock = d_mclock;
     }
     static const int merge_wide_min_k = qk_env_int("QK_MERGE_WIDE_MIN_K", 33);
+    static const bool merge_flat = qk_env_int("QK_MERGE_FLAT", 1) != 0;
     if (k >= merge_wide_min_k) {
         hipLaunchKernelGGL(k_merge_wide, mgrid, dim3(256), 0, st, mp);
+    } else
+    if (mp.P <= 64 && k <= 32 && !mp.clock && merge_flat) {
+        const size_t lds_flat = lds_merge + (size_t)2 * 64 * (QK_SLOTS - 1) * 4;  // + record list, record sizes
+        if (maxch_m == 2) hipLaunchKernelGGL((k_merge_flat<2>), mgrid, dim3(64), lds_flat, st, mp);
+        else hipLaunchKernelGGL((k_merge_flat<4>), mgrid, dim3(64), lds_flat, st, mp);
     } else
     switch (maxch_m) {
         case 2: hipLaunchKernelGGL((k_merge<2>), mgrid, dim3(64), lds_merge, st, mp); break;
