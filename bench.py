@@ -42,6 +42,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+MFMA_F32_PEAK_TFLOPS = 157.3  # dense fp32 MFMA peak (MI355X_MICROARCH.md); the 16x16x4 f32 instruction reaches 142 in isolation
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 METRIC_NAME = "queries/sec at recall@10≥0.9 (SIFT1M, k=10); 1/2/4/8 GPU"
 N_BATCHES = 4  # query batches the timed region rotates over
@@ -231,14 +232,30 @@ def timed_region(ctx, step, nprobe, steps, warmup, settle, dist, dev, ctxs=None)
     return elapsed, ev, ev_ph
 
 
-def roofline_of(scan_bytes, ev, traffic=None, kernel="k_scan"):
+def roofline_of(scan_bytes, ev, traffic=None, kernel="k_scan", pair_rows=None, d=None):
+    """the launch against both roofs: unique bytes / time against the HBM peak, and -- when `pair_rows` (rows x probing queries,
+    summed over the probed lists) is given -- 2*d flops per (row, query) against the dense fp32 MFMA peak (bit parity pins the
+    path to fp32 matrix instructions).  `bound` names the roof that gives the LONGER minimum time for this batch; the top-level
+    achieved / peak / frac are that roof's, the other one is kept under its own key."""
     scan_ms = ev["scan_ms"] / max(ev["calls"], 1)
     achieved = scan_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
-    return {
+    r = {
         "kernel": kernel, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
         "algorithmic_bytes_per_launch": int(scan_bytes), "kernel_ms_avg": round(scan_ms, 5), "launches": ev["calls"],
     }
+    if pair_rows is not None and scan_ms > 0:
+        flops = 2.0 * d * pair_rows
+        tf = flops / (scan_ms * 1e-3) / 1e12
+        r["mfma"] = {"algorithmic_flops_per_launch": int(flops), "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TFLOPS,
+                     "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4),
+                     "queries_per_scanned_row": round(pair_rows * d * 4 / max(scan_bytes, 1), 2),
+                     "min_ms_hbm": round(scan_bytes / (HBM_PEAK_GBS * 1e9) * 1e3, 4),
+                     "min_ms_mfma": round(flops / (MFMA_F32_PEAK_TFLOPS * 1e12) * 1e3, 4)}
+        if r["mfma"]["min_ms_mfma"] > r["mfma"]["min_ms_hbm"]:
+            r["hbm"] = {"achieved": r["achieved"], "peak": r["peak"], "unit": r["unit"], "frac": r["frac"]}
+            r.update(bound="mfma", achieved=r["mfma"]["achieved"], peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s", frac=r["mfma"]["frac"])
+    return r
 
 
 def phases_of(ev_ph):
@@ -326,6 +343,10 @@ def run_single_workload(ctx, dev, args, name, sigma, fixed_nprobe, steps, warmup
         scan_bytes += int(ctx.search(parent, store, batches[b], nprobe, k, metric, timing=True)[2]["scan_bytes"])
     ctx.set_timing(0)
     scan_bytes //= N_BATCHES
+    # rows x probing queries over the probed lists (mean over the rotated batches): the flops side of the same launch
+    scan_kernel = ctx.last_scan_kernel()  # (before the coarse calls below: they are launches of their own)
+    cnt_t = torch.as_tensor(idx["counts"], device=dev)
+    pair_rows = int(sum(int(cnt_t[ctx.coarse(parent, batches[b], nprobe, metric)[0]].sum().item()) for b in range(N_BATCHES)) // N_BATCHES)
     res = {
         "value": round(Q * steps / elapsed, 1), "unit": "queries/s", "ms_per_step": round(1e3 * elapsed / steps, 4),
         "steps": steps, "warmup": warmup,
@@ -339,7 +360,7 @@ def run_single_workload(ctx, dev, args, name, sigma, fixed_nprobe, steps, warmup
         },
         "batches_in_flight": piped,
         "roofline": roofline_of(scan_bytes, ev, committed_traffic(traffic_file, n, d, k, nprobe) if traffic_file else None,
-                                kernel=ctx.last_scan_kernel()),
+                                kernel=scan_kernel, pair_rows=pair_rows, d=d),
         "phases_ms": phases_of(ev_ph),
         "build": {"kmeans_s": round(idx["kmeans_s"], 2), "niter": args.niter},
     }
