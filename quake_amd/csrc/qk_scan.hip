@@ -1667,7 +1667,7 @@ int qk_merge_topk_device(qk_ctx *ctx, const int64_t *in_ids, const float *in_key
 
 // ---- host orchestration -------------------------------------------------------------------------------------
 // row-per-lane form (qk_scan_rl.hip)
-size_t qk_scan_rl_lds_per_wave(int nblk, int C);
+size_t qk_scan_rl_lds_per_wave(int nblk, int C, int qb);
 int qk_launch_scan_rl(int nblk, dim3 grid, size_t lds, hipStream_t st, const ScanParams &sp);
 
 template <int DB, int MAXCH, int MODE, bool L2>
@@ -1827,7 +1827,8 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
     // 32 queries from one read of its rows -- the regime where several queries of the batch probe the same partition.
     bool use_rl = false;
     int64_t rl_per_list = 0;
-    RlCost rlc{12, 8, 1, 16, 4};
+    RlCost rlc{12, 8, 1, 16, 4, 32};
+    int rl_app = 32;
     {
         // Measured (10M x 128, 1024 queries, k = 10; k_scan ms old form -> this form): nprobe 1: 0.252 -> 0.246, 2: 0.324 -> 0.313,
         // 4: 0.404 -> 0.362, 8: 0.488 -> 0.439, 16: 0.694 -> 0.616, 32: 0.958 -> 1.02 (MFMA-bound: 5 us of chain per chunk);
@@ -1841,12 +1842,31 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
         static const int rl_e = qk_env_int("QK_SCAN_RL_E", 1);
         static const int rl_ovh = qk_env_int("QK_SCAN_RL_OVH", 16);
         static const int rl_m = qk_env_int("QK_SCAN_RL_M", 4);
-        rlc = RlCost{std::max(1, rl_h0), std::max(1, rl_h1), std::max(0, rl_e), std::max(0, rl_ovh), std::max(1, rl_m)};
         const int64_t present = std::max<int64_t>(1, std::min<int64_t>(s->nlist, std::max<int64_t>(npairs, 1)));
         const int64_t per_list = npairs / present;
-        const int C_rl = std::min(64, qk_round_up(k + 32, 4));
-        // (4 waves per CU, each with its own LDS copy of the pass's queries and 32 pools: d = 128 with k = 32 does not fit)
-        const bool rl_fits = 4 * ((qk_scan_rl_lds_per_wave(nblk, C_rl) + 15) & ~(size_t)15) <= (size_t)160 * 1024;
+        // Pass width: a partition probed by more queries than a pass holds is streamed once per pass (1024 waves x 1-2 MB
+        // partitions: nothing survives in the L2s); the width is bounded by the wave's quarter of the LDS (queries: qb x dpad
+        // floats, + pools).  32 queries with pools of k + 32 entries is the product setting.  Measured against 48 queries with
+        // pools of k + 16 entries and appends by quarter waves (the widest that fits at d = 128, k = 10; bytes-weighted re-reads
+        // on the bench mixture at 32 / 48 / 64 queries per pass: nprobe 8 1.17 / 1.09 / 1.05, nprobe 16 1.47 / 1.28 / 1.16):
+        // kernel ms nprobe 4 0.381 -> 0.377, 8 0.454 -> 0.446, 16 0.602 -> 0.606, 32 0.985 -> 0.985, merge +2 us each
+        // (scripts/gpu_r3h.sh) -- the re-reads are not what the launch waits for.  The wider pass stays behind the probe switch.
+        static const int rl_qb_env = qk_env_int("QK_SCAN_RL_QB", 0);  // probe: 32 ... 64 (0: 32)
+        int qb = 32, C_rl = std::min(64, qk_round_up(k + 32, 4));
+        auto fits = [&](int q, int c) { return 4 * ((qk_scan_rl_lds_per_wave(nblk, c, q) + 15) & ~(size_t)15) <= (size_t)160 * 1024; };
+        if (rl_qb_env > 32) {
+            const int c16 = qk_round_up(k + 16, 4);
+            for (int q = std::min(rl_qb_env & ~3, QK_RL_QB_MAX); q > 32; q -= 4)
+                if (fits(q, c16)) {
+                    qb = q;
+                    C_rl = c16;
+                    rl_app = 16;
+                    break;
+                }
+        }
+        rlc = RlCost{std::max(1, rl_h0), std::max(1, rl_h1), std::max(0, rl_e), std::max(0, rl_ovh), std::max(1, rl_m), qb};
+        // (4 waves per CU, each with its own LDS copy of the pass's queries and its pools: d = 128 with k = 32 does not fit)
+        const bool rl_fits = fits(qb, C_rl);
         const bool rl_ok = nblk <= 8 && k <= 32 && rl_fits && !a.per_pair && !emit && npairs > 0 && ctx->qprep_xp4 != nullptr &&
                            a.xq4 == (const float4 *)ctx->qprep;
         use_rl = rl_ok && (rl_env == 1 || (rl_env < 0 && per_list < rl_max && P > 1));
@@ -1858,7 +1878,7 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
         }
     }
     const int maxch = pick_maxch(C);
-    const size_t lds_scan = use_rl ? ((qk_scan_rl_lds_per_wave(nblk, C) + 15) & ~(size_t)15)
+    const size_t lds_scan = use_rl ? ((qk_scan_rl_lds_per_wave(nblk, C, rlc.qb) + 15) & ~(size_t)15)
                             : qshare ? (size_t)nw * (q_bytes + (size_t)16 * C * 12) : q_bytes + (size_t)nw * 16 * C * 12;
     const int Cm = qk_round_up(k + 64, 64);
     const int maxch_m = Cm <= 128 ? 2 : Cm <= 256 ? 4 : Cm <= 512 ? 8 : 16;
@@ -1906,8 +1926,8 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
     }
     const int64_t seg_starts = n_wgs + dyn_ranges;
     // (row-per-lane form: a segment emits one record per live query of its pass; every range boundary inside a pass adds at
-    //  most QK_RL_QB records)
-    const int64_t max_recs = use_rl ? std::min<int64_t>(0x7FFFFFF0LL, npairs + (int64_t)QK_RL_QB * (n_waves + QK_RL_DYN_MAX + 2))
+    //  most rlc.qb records)
+    const int64_t max_recs = use_rl ? std::min<int64_t>(0x7FFFFFF0LL, npairs + (int64_t)rlc.qb * (n_waves + QK_RL_DYN_MAX + 2))
                                     : std::min<int64_t>(0x7FFFFFF0LL, nw * std::min<int64_t>(16 * (items_bound + seg_starts), npairs + 16 * seg_starts));
 
     // ---- workspace ---------------------------------------------------------------------------------
@@ -2110,6 +2130,8 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
         sp.rl_h1 = rlc.h1;
         sp.rl_e = rlc.e;
         sp.rl_m = rlc.m;
+        sp.rl_qb = rlc.qb;
+        sp.rl_app = rl_app;
         static const int rl_probe = qk_env_int("QK_SCAN_RL_PROBE", 0);
         sp.rl_probe = rl_probe;
         sp.key_out = a.key_out;

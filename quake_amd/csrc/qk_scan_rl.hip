@@ -11,7 +11,7 @@
 // streaming every shared partition once per 16-query tile.  Here the 16 blocks of the 4x4x1 form are
 // 16 row groups of 4 rows against the SAME 4 queries: one instruction = 64 rows x 4 queries x 1 column at the same
 // 64 FLOP/clk/SIMD, so the matrix work follows the live queries in steps of 4 and a pass over a partition serves up to
-// QK_RL_QB = 32 queries from ONE read of its rows.  k = 1 per instruction: the accumulator chain is literally
+// RlCost::qb (32-64) queries from ONE read of its rows.  k = 1 per instruction: the accumulator chain is literally
 // acc = fma(row[k], query[k], acc) in column order -- the canonical arithmetic, bit-identical to k_scan.
 //
 // Operand layout (scripts/micro/mfma_4x4x1.hip prints it from the hardware and checks the chain against fmaf):
@@ -45,8 +45,10 @@ template <int NB, bool L2>
 __global__ __launch_bounds__(256) void k_scan_rl(ScanParams P) {
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int NKK = NB * 4;        // float4 (4 consecutive columns) per padded row
-    constexpr int QB = QK_RL_QB;       // query slots per pass
-    constexpr int NG = QB / 4;         // groups per pass
+    constexpr int NGMAX = QK_RL_QB_MAX / 4;
+    const int QB = P.rl_qb;            // query slots per pass (lane s owns slot s)
+    const int NG = QB >> 2;            // groups per pass
+    const int APP = P.rl_app;          // lanes per append round: a pool at most k long has room for APP more
     const int lane = threadIdx.x & 63, wvp = threadIdx.x >> 6;
     const int qi = lane & 3, b4 = lane >> 2;  // A: lane (block b4, query qi of the group) keeps q_qi[16c + b4] in register c
     const int tq = lane >> 4, r = lane & 15;  // B / D: lane = row of the chunk = (tile tq, row r)
@@ -89,7 +91,7 @@ __global__ __launch_bounds__(256) void k_scan_rl(ScanParams P) {
     const long long cy0 = P.wave_clock ? clock64() : 0;
     int dbg_comp = 0, dbg_app = 0, dbg_seg = 0;  // probe counters (QK_SCAN_WAVE_CLOCK)
     long long dbg_t_end = 0, dbg_t_stage = 0, dbg_gc = 0;
-    const RlCost rc{P.rl_h0, P.rl_h1, P.rl_e, P.seg_ovh, P.rl_m};
+    const RlCost rc{P.rl_h0, P.rl_h1, P.rl_e, P.seg_ovh, P.rl_m, QB};
     const int n_active = *P.n_active;
     long long xcd_ticks = 0;  // time spent on the static share (what the XCD balance learns from)
     for (;;) {
@@ -167,7 +169,7 @@ __global__ __launch_bounds__(256) void k_scan_rl(ScanParams P) {
         {
             const float *xp = (const float *)P.xp4;
 #pragma unroll
-            for (int g = 0; g < NG; g++) {
+            for (int g = 0; g < NGMAX; g++) {
                 if (g < ng) {
                     const int qsl = __shfl(myq, 4 * g + qi);
                     const float *qsrc = xp + (int64_t)max(qsl, 0) * (NKK * 4) + b4;
@@ -222,18 +224,17 @@ __global__ __launch_bounds__(256) void k_scan_rl(ScanParams P) {
                         uint32_t *my_ord = pool_ord + s * C;
                         int64_t *my_id = pool_id + s * C;
                         dbg_app += __popcll(m);
-                        // the pool has room for 32 more entries whenever it is at most k long: append by half waves
-#pragma unroll
-                        for (int h = 0; h < 2; h++) {
-                            const uint64_t mh = h ? (m & 0xFFFFFFFF00000000ull) : (m & 0xFFFFFFFFull);
+                        // the pool has room for APP more entries whenever it is at most k long: append by half / quarter waves
+                        for (int h = 0; h < 64; h += APP) {
+                            const uint64_t mh = m & ((APP == 32 ? 0xFFFFFFFFull : 0xFFFFull) << h);
                             if (!mh) continue;
-                            if (pass && (lane >> 5) == h) {
+                            if (pass && (lane & -APP) == h) {
                                 const int slot = cnt + __popcll(mh & ((1ull << lane) - 1ull));
                                 my_ord[slot] = ord;
                                 my_id[slot] = idr;
                             }
                             cnt += __popcll(mh);
-                            if (cnt > C - 32) {
+                            if (cnt > C - APP) {
                                 dbg_comp++;
                                 uint32_t kth;
                                 cnt = select_pool<1>(my_ord, my_id, cnt, k, lane, kth);
@@ -408,8 +409,8 @@ __global__ __launch_bounds__(256) void k_scan_rl(ScanParams P) {
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------------
-size_t qk_scan_rl_lds_per_wave(int nblk, int C) {
-    return (size_t)(QK_RL_QB / 4) * nblk * 64 * 4 + (size_t)QK_RL_QB * C * 12 + (size_t)QK_RL_QB * 4 * 5;
+size_t qk_scan_rl_lds_per_wave(int nblk, int C, int qb) {
+    return (size_t)(qb / 4) * nblk * 64 * 4 + (size_t)qb * C * 12 + (size_t)qb * 4 * 5;
 }
 
 template <int NB, bool L2>

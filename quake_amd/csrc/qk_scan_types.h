@@ -67,21 +67,23 @@ struct ScanParams {
     // row-per-lane scan (qk_scan_rl.hip)
     const float4 *xp4;  // [Q][dpad/4] row-major zero-padded queries
     int rl_h0, rl_h1, rl_e, rl_m;  // cost model of the work sequence (RlCost; ovh = seg_ovh)
+    int rl_qb, rl_app;       // queries per pass; lanes per append round (32: pools of k + 32 entries, 16: k + 16)
     int rl_probe;            // probe (QK_SCAN_RL_PROBE): bit 0 = no top-k epilogue, bit 1 = no MFMA chains (attribution only; uniform branches OUTSIDE the chain)
 };
 
 // ---- row-per-lane scan (qk_scan_rl.hip): cost model of the work sequence ----------------------------------------------------
-// A partition probed by cnt queries is scanned in passes of up to QK_RL_QB queries (QK_RL_QB / 4 groups of 4: one
+// A partition probed by cnt queries is scanned in passes of up to RlCost::qb queries (qb / 4 groups of 4: one
 // v_mfma_f32_4x4x1_16b_f32 serves 64 rows x 4 queries).  A pass walks the partition in chunks of 64 rows; a chunk of a pass
 // with g groups weighs max(h, m * ceil(g / 2) + e) units -- h stands for streaming the chunk (h0: from HBM, first pass; h1:
 // later passes find it in L2 / Infinity Cache), m for one step of the MFMA loop (two groups' chains interleaved: 256
 // instructions + two top-k epilogues; measured 1.44 us against ~4.3 us for a chunk when every wave streams, hence m = 4,
 // h0 = 12) -- and every pass starts with `ovh` units (query staging, record emission).  The grouping stage lays the
 // partitions end to end in these units; k_scan_rl cuts the head of the sequence statically and hands the tail out dynamically.
-constexpr int QK_RL_QB = 32;
+constexpr int QK_RL_QB_MAX = 64;  // widest pass: the slot of a query is owned by the lane of its number
 constexpr int QK_RL_DYN_MAX = 4096;  // most ranges the dynamic tail is cut into (bounds the records a launch can emit)
 struct RlCost {
     int h0, h1, e, ovh, m;
+    int qb;  // queries per pass (multiple of 4, <= QK_RL_QB_MAX): what fits in the wave's share of LDS (queries + pools)
 };
 __host__ __device__ inline int rl_w(int g, bool first, const RlCost &c) {
     const int h = first ? c.h0 : c.h1, v = c.m * ((g + 1) >> 1) + c.e;
@@ -89,11 +91,11 @@ __host__ __device__ inline int rl_w(int g, bool first, const RlCost &c) {
 }
 __host__ __device__ inline long long rl_part_len(int cnt, int size, const RlCost &c) {
     const long long nch = (size + 63) >> 6;
-    const int nqb = (cnt + QK_RL_QB - 1) / QK_RL_QB;
-    const int g_last = (cnt - QK_RL_QB * (nqb - 1) + 3) >> 2;
+    const int nqb = (cnt + c.qb - 1) / c.qb;
+    const int g_last = (cnt - c.qb * (nqb - 1) + 3) >> 2;
     if (nqb <= 1) return c.ovh + nch * rl_w(g_last, true, c);
     return (long long)nqb * c.ovh +
-           nch * ((long long)rl_w(QK_RL_QB / 4, true, c) + (long long)(nqb - 2) * rl_w(QK_RL_QB / 4, false, c) + rl_w(g_last, false, c));
+           nch * ((long long)rl_w(c.qb / 4, true, c) + (long long)(nqb - 2) * rl_w(c.qb / 4, false, c) + rl_w(g_last, false, c));
 }
 
 
