@@ -25,13 +25,19 @@ def owner_of_list(list_no, world, lists_per_rank=None):
     return int(list_no) % int(world)
 
 
+def owners_of_lists(list_nos, world, lists_per_rank=None):
+    """owner_of_list for an array of list numbers"""
+    a = np.asarray(list_nos, dtype=np.int64)
+    return a // int(lists_per_rank) if lists_per_rank else a % int(world)
+
+
 def shard_offsets(offsets, rank, world, lists_per_rank=None):
     """CSR of a GLOBAL index -> (local_offsets [nlist+1], row_selector) keeping every list number but emptying the lists
     this rank does not own (an empty list is skipped by the scan, like the reference skips empty partitions)."""
     offsets = np.asarray(offsets, dtype=np.int64)
     nlist = offsets.shape[0] - 1
     sizes = np.diff(offsets)
-    own = np.array([owner_of_list(p, world, lists_per_rank) == rank for p in range(nlist)], dtype=bool)
+    own = owners_of_lists(np.arange(nlist), world, lists_per_rank) == rank
     local_sizes = np.where(own, sizes, 0)
     local_offsets = np.zeros(nlist + 1, np.int64)
     local_offsets[1:] = np.cumsum(local_sizes)
@@ -267,7 +273,7 @@ class ShardedIndex:
         import torch
         assign = self.engine.assign(x)
         a = assign.cpu().numpy() if torch.is_tensor(assign) else np.asarray(assign)
-        own = np.array([owner_of_list(p, self.world, lists_per_rank) == self.rank for p in a], dtype=bool)
+        own = owners_of_lists(a, self.world, lists_per_rank) == self.rank
         if not own.any():
             return 0
         sel = np.nonzero(own)[0]

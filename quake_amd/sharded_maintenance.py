@@ -30,7 +30,7 @@ GpuPartitions implements it on libquake_hip.so (over an index.QuakeIndex); the g
 """
 import numpy as np
 
-from .sharded import owner_of_list
+from .sharded import owner_of_list, owners_of_lists
 
 
 _SEQ = 1 << 40  # row-order keys: (position of the source list) * _SEQ + row
@@ -287,7 +287,7 @@ class ShardedPartitions:
         new_pids = list(range(self._next_pid, self._next_pid + n))
         self._next_pid += n
         slot = np.concatenate([np.full(len(i), j, np.int64) for j, i in enumerate(clustering["vector_ids"])]) if n else np.zeros(0, np.int64)
-        dest = np.array([self.owner(new_pids[j]) for j in slot], np.int64)
+        dest = owners_of_lists(np.asarray(new_pids, np.int64)[slot], self.world)
         d = self.d()
         v = np.concatenate(clustering["vectors"]) if n else np.zeros((0, d), np.float32)
         i = np.concatenate(clustering["vector_ids"]) if n else np.zeros(0, np.int64)
@@ -361,7 +361,7 @@ class ShardedPartitions:
         if int(counts.sum()) != total:
             raise RuntimeError("refine_partitions: %d of %d vectors could not be assigned (NaN centroid from an emptied cluster)"
                                % (total - int(counts.sum()), total))
-        dest = np.array([self.owner(pids[j]) for j in a], np.int64)
+        dest = owners_of_lists(np.asarray(pids, np.int64)[a], self.world)
         # rows of a new list arrive in the order of the original concatenation: with one assignment pass that is the order a
         # single rank would append them in
         ra, rx, ri = self.comm.route_rows(dest, a, x, ids, key=seq)
@@ -462,7 +462,7 @@ class ShardedQuakeIndex:
         c, a = sharded_kmeans(ctx, dist, xd, int(nlist), metric, niter=int(niter), seed=int(seed), rank=rank, world=world)
         a = a.cpu().numpy()
         comm = Comm(dist, world, rank)
-        dest = np.array([owner_of_list(p, world) for p in a], np.int64)
+        dest = owners_of_lists(a, world)
         ra, rx, ri = comm.route_rows(dest, a, xd.cpu().numpy(), np.asarray(ids, dtype=np.int64))  # IP: the normalised copy
         order = np.argsort(ra, kind="stable")
         offsets = np.zeros(int(nlist) + 1, np.int64)
