@@ -222,11 +222,11 @@ int qk_store_sync_table(qk_store *s) {
 void qk_store_ensure_index(qk_store *s) {
     if (s->index_valid) return;
     s->id_to_list.clear();
-    s->id_to_list.reserve((size_t)s->ntotal * 2 + 16);
+    s->id_to_list.reserve((size_t)s->ntotal + 16);
     for (size_t pi = 0; pi < s->parts.size(); pi++) {
         const qk_part &p = s->parts[pi];
         if (!p.present) continue;
-        for (int64_t i = 0; i < p.size; i++) s->id_to_list.emplace(p.ids[i], (int32_t)pi);  // first list wins (get order)
+        for (int64_t i = 0; i < p.size; i++) s->id_to_list.set_if_absent(p.ids[i], (int32_t)pi);  // first list wins (get order)
     }
     s->index_valid = true;
 }
@@ -433,8 +433,7 @@ int qk_store_remove_list(qk_store *s, int64_t list_no) {
         for (int64_t id : p.ids) {
             // only the entries that still name THIS list: while refine_lists replaces its lists one after the other, an id of
             // this list's old contents may already live in (and be indexed under) a list replaced before it
-            auto it = s->id_to_list.find(id);
-            if (it != s->id_to_list.end() && it->second == (int32_t)list_no) s->id_to_list.erase(it);
+            s->id_to_list.erase_if(id, (int32_t)list_no);
         }
     s->ntotal -= p.size;
     s->dead_rows += p.cap;
@@ -469,7 +468,7 @@ int qk_store_add_entries(qk_store *s, int64_t list_no, int64_t n, const int64_t 
     QK_HIP(hipStreamSynchronize(c->stream));  // staging buffer / caller memory reusable on return
     note_ids(s, p.ids.data() + old, n);
     if (s->index_valid)
-        for (int64_t i = 0; i < n; i++) s->id_to_list[p.ids[old + i]] = (int32_t)list_no;
+        for (int64_t i = 0; i < n; i++) s->id_to_list.set(p.ids[old + i], (int32_t)list_no);
     p.size += n;
     s->ntotal += n;
     s->table_dirty = true;
@@ -560,7 +559,29 @@ int qk_store_remove_ids(qk_store *s, int64_t n, const int64_t *ids_host, int64_t
     if (!ids_host) QK_FAIL(QK_ERR_INVALID, "qk_store_remove_ids: null ids");
     qk_ctx *c = s->ctx;
     QK_HIP(hipSetDevice(c->device));
-    std::unordered_set<int64_t> kill(ids_host, ids_host + n);
+    // membership of the ids to remove: one bit per id of the range the store has ever held when that range is small (ids are
+    // row numbers of a corpus in practice: 50M ids = 6 MB, cache-resident) -- the sweep below asks once per row of every
+    // touched list, and a hash probe per row (5M rows for 500k ids spread over the index) was 80 % of the call; else a hash set.
+    // The bitmap lives in the store, all zero between calls (the bits set here are cleared before returning).
+    const int64_t id_lo = s->min_id_seen, id_hi = s->max_id_seen;
+    const bool use_bits = id_hi >= id_lo && (id_hi - id_lo) < ((int64_t)1 << 30);
+    QkIdMap kill;  // (as a set)
+    if (use_bits) {
+        const size_t words = (size_t)((id_hi - id_lo) >> 6) + 1;
+        if (s->kill_bits.size() < words) s->kill_bits.resize(words, 0);
+        for (int64_t i = 0; i < n; i++) {
+            const int64_t v = ids_host[i];
+            if (v >= id_lo && v <= id_hi) s->kill_bits[(size_t)((v - id_lo) >> 6)] |= 1ull << ((v - id_lo) & 63);
+        }
+    } else {
+        kill.reserve((size_t)n);
+        for (int64_t i = 0; i < n; i++) kill.set(ids_host[i], 0);
+    }
+    const uint64_t *bits = s->kill_bits.data();
+    auto is_kill = [&](int64_t v) -> bool {
+        if (use_bits) return v >= id_lo && v <= id_hi && ((bits[(size_t)((v - id_lo) >> 6)] >> ((v - id_lo) & 63)) & 1ull);
+        return kill.find(v) >= 0;
+    };
     std::vector<int64_t> mv_dst, mv_src;
     int64_t removed = 0;
     std::vector<int64_t> cur;
@@ -569,8 +590,8 @@ int qk_store_remove_ids(qk_store *s, int64_t n, const int64_t *ids_host, int64_t
     qk_store_ensure_index(s);
     std::vector<char> touched_list(s->parts.size(), 0);
     for (int64_t i = 0; i < n; i++) {
-        auto it = s->id_to_list.find(ids_host[i]);
-        if (it != s->id_to_list.end()) touched_list[(size_t)it->second] = 1;
+        const int32_t holder = s->id_to_list.find(ids_host[i]);
+        if (holder >= 0) touched_list[(size_t)holder] = 1;
     }
     for (size_t pi = 0; pi < s->parts.size(); pi++) {
         qk_part &p = s->parts[pi];
@@ -579,7 +600,7 @@ int qk_store_remove_ids(qk_store *s, int64_t n, const int64_t *ids_host, int64_t
         bool touched = false;
         int64_t sz = p.size;
         for (int64_t i = 0; i < sz;) {
-            if (kill.count(p.ids[i])) {
+            if (is_kill(p.ids[i])) {
                 if (!touched) {
                     cur.resize(p.size);
                     for (int64_t t = 0; t < p.size; t++) cur[t] = t;
@@ -614,6 +635,11 @@ int qk_store_remove_ids(qk_store *s, int64_t n, const int64_t *ids_host, int64_t
         QK_TRY(qk_launch_move_rows(c, s->vecs, s->norms, s->ids, s->nblk, dd, ds, (int64_t)mv_dst.size()));
         QK_HIP(hipStreamSynchronize(c->stream));
     }
+    if (use_bits)
+        for (int64_t i = 0; i < n; i++) {
+            const int64_t v = ids_host[i];
+            if (v >= id_lo && v <= id_hi) s->kill_bits[(size_t)((v - id_lo) >> 6)] = 0;
+        }
     s->ntotal -= removed;
     if (removed) s->table_dirty = true;
     if (n_removed) *n_removed = removed;
@@ -676,9 +702,9 @@ int qk_store_get_vector(qk_store *s, int64_t id, float *vec_out_host, int *found
     QK_HIP(hipSetDevice(c->device));
     *found = 0;
     qk_store_ensure_index(s);
-    auto it = s->id_to_list.find(id);
-    if (it == s->id_to_list.end()) return QK_OK;
-    qk_part &p = s->parts[(size_t)it->second];
+    const int32_t holder = s->id_to_list.find(id);
+    if (holder < 0) return QK_OK;
+    qk_part &p = s->parts[(size_t)holder];
     for (int64_t i = 0; i < p.size; i++)  // find_id inside the one list that holds it (index_partition.cpp:129-145)
         if (p.ids[i] == id) {
             size_t vb = (size_t)s->d * sizeof(float);
@@ -724,7 +750,7 @@ int qk_store_add_batch(qk_store *s, int64_t n, const int64_t *ids, const float *
         if (h_ids[i] > s->max_id_seen) s->max_id_seen = h_ids[i];
         if (h_ids[i] < s->min_id_seen) s->min_id_seen = h_ids[i];
         p.size++;
-        if (s->index_valid) s->id_to_list[h_ids[i]] = (int32_t)h_assign[i];
+        if (s->index_valid) s->id_to_list.set(h_ids[i], (int32_t)h_assign[i]);
     }
     s->ntotal += n;
     s->table_dirty = true;
