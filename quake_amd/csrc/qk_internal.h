@@ -313,6 +313,10 @@ int qk_merge_topk_device(qk_ctx *ctx, const int64_t *in_ids, const float *in_key
 int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *timing, int ev_base);
 // one-launch search of a small batch (qk_small.hip)
 bool qk_small_supported(qk_ctx *ctx, qk_store *parent, qk_store *s, int64_t Q, int nprobe, int k);
+// coarse step of a mid-sized batch in one launch (qk_small.hip: k_coarse_small)
+bool qk_coarse_small_supported(const qk_store *s, int64_t Q, int nrows, int k);
+int qk_launch_coarse_small(qk_ctx *ctx, qk_store *s, int64_t row_off, int nrows, const float *x, int64_t Q, int k, int metric,
+                           bool sqrt_l2, int64_t *out_ids, float *out_dist);
 int qk_search_small_device(qk_ctx *ctx, qk_store *parent, qk_store *s, const float *x, int64_t Q, int nprobe, int k, int metric,
                            int64_t *out_ids, float *out_dist, bool sqrt_l2);
 // dense form (every query x one list, Q large): distance matrix on MFMA + per-query select.  qk_dense.hip

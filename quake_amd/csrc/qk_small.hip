@@ -475,6 +475,113 @@ __global__ __launch_bounds__(QK_SMALL_THREADS) void k_search_small(SmallParams P
 // ---- host side -----------------------------------------------------------------------------------------------------------
 // Supported envelope (qk_search routes everything else through the batch pipeline): flat parent with one list of at most
 // 4096 centroids whose ids are >= 0, nprobe <= 64, k <= 32, Q <= 64 (QK_SMALL_MAXQ_DEFAULT).
+// ---- coarse step of a mid-sized batch (32 < Q <= 256 against <= 4096 centroids) in ONE launch ------------------------------------
+// The batch pipeline's coarse step is k_dense_ord + k_select_rows (key matrix written and read back, two launches sized for
+// thousands of queries); for a few dozen queries it is ~25 us of mostly launch latency.  Here workgroup q computes the keys of
+// ALL centroids for its query (the same canonical chains as k_search_small: the centroid arena is L2-resident) and selects the
+// nprobe nearest with block_topk -- same keys, same (key, id) order, same output as the two-kernel form.
+struct CoarseSmallParams {
+    const float4 *c_vecs;
+    const float *c_norms;
+    const int64_t *c_ids;  // arena ids
+    int64_t c_row0;
+    int c_n;
+    int nblk, d;
+    const float *x;  // [Q][d] row-major
+    int k;
+    int metric, sqrt_l2;
+    int64_t *out_ids;  // [Q][k]
+    float *out_dist;   // [Q][k] or nullptr
+};
+
+__global__ __launch_bounds__(QK_SMALL_THREADS) void k_coarse_small(CoarseSmallParams P) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    __shared__ uint32_t s_mord[QK_SMALL_NW * QK_SMALL_MAXP];
+    __shared__ int64_t s_mid[QK_SMALL_NW * QK_SMALL_MAXP];
+    __shared__ int s_got[QK_SMALL_NW];
+    const int tid = threadIdx.x;
+    const int64_t q = blockIdx.x;
+    const bool l2 = P.metric == QK_METRIC_L2;
+    const int dpad = P.nblk * 16;
+    float *sq = (float *)smem;                                                  // [dpad]
+    int64_t *s_cid = (int64_t *)(smem + (size_t)dpad * 4);                      // [c_n]
+    uint32_t *s_ck = (uint32_t *)(s_cid + P.c_n);                               // [c_n]
+    for (int c = tid; c < dpad; c += QK_SMALL_THREADS) sq[c] = c < P.d ? P.x[q * P.d + c] : 0.0f;
+    for (int r = tid; r < P.c_n; r += QK_SMALL_THREADS) s_cid[r] = P.c_ids[P.c_row0 + r];
+    __syncthreads();
+    float xn = 0.0f;
+    if (l2) {
+        const float4 *sq4 = (const float4 *)sq;
+#pragma unroll 8
+        for (int c = 0; c < dpad / 4; c++) {
+            const float4 v = sq4[c];
+            xn = __fmaf_rn(v.x, v.x, xn);
+            xn = __fmaf_rn(v.y, v.y, xn);
+            xn = __fmaf_rn(v.z, v.z, xn);
+            xn = __fmaf_rn(v.w, v.w, xn);
+        }
+    }
+    for (int r = tid; r < P.c_n; r += 2 * QK_SMALL_THREADS) {
+        const int r2 = r + QK_SMALL_THREADS;
+        uint32_t k1, k2 = 0;
+        if (r2 < P.c_n) {
+            small_row_key2(P.c_vecs, P.c_norms, P.nblk, P.c_row0 + r, P.c_row0 + r2, sq, xn, l2, k1, k2);
+            s_ck[r2] = k2;
+        } else {
+            k1 = small_row_key(P.c_vecs, P.c_norms, P.nblk, P.c_row0 + r, sq, xn, l2);
+        }
+        s_ck[r] = k1;
+    }
+    __syncthreads();
+    const int nn = block_topk(s_ck, s_cid, P.c_n, min(P.k, P.c_n), s_mord, s_mid, s_got);
+    for (int e = tid; e < P.k; e += QK_SMALL_THREADS) {
+        int64_t oid = -1;
+        float od = l2 ? INFINITY : -INFINITY;
+        if (e < nn) {
+            oid = s_cid[e];
+            const uint32_t o = s_ck[e];
+            if (l2) {
+                const float d2 = __uint_as_float(o);
+                od = P.sqrt_l2 ? sqrtf(d2) : d2;
+            } else {
+                od = ip_from_ord(o);
+            }
+        }
+        P.out_ids[q * P.k + e] = oid;
+        if (P.out_dist) P.out_dist[q * P.k + e] = od;
+    }
+}
+
+bool qk_coarse_small_supported(const qk_store *s, int64_t Q, int nrows, int k) {
+    static const int enabled = qk_env_int("QK_COARSE_SMALL", 1);
+    if (!enabled || Q <= 0 || Q > 256 || k < 2 || k > QK_SMALL_MAXP || nrows <= 0 || nrows > 256 * QK_SMALL_CPT) return false;
+    if (Q * (int64_t)nrows > 256 * 1024) return false;  // every workgroup reads the whole centroid arena from L2
+    if ((size_t)s->dpad * 4 + (size_t)nrows * 12 + 8192 > 64 * 1024) return false;
+    return true;
+}
+
+int qk_launch_coarse_small(qk_ctx *ctx, qk_store *s, int64_t row_off, int nrows, const float *x, int64_t Q, int k, int metric,
+                           bool sqrt_l2, int64_t *out_ids, float *out_dist) {
+    CoarseSmallParams P;
+    P.c_vecs = (const float4 *)s->vecs;
+    P.c_norms = s->norms;
+    P.c_ids = s->ids;
+    P.c_row0 = row_off;
+    P.c_n = nrows;
+    P.nblk = s->nblk;
+    P.d = s->d;
+    P.x = x;
+    P.k = k;
+    P.metric = metric;
+    P.sqrt_l2 = sqrt_l2 ? 1 : 0;
+    P.out_ids = out_ids;
+    P.out_dist = out_dist;
+    const size_t lds = (size_t)s->dpad * 4 + (size_t)nrows * 12 + 16;
+    hipLaunchKernelGGL(k_coarse_small, dim3((unsigned)Q), dim3(QK_SMALL_THREADS), lds, ctx->stream, P);
+    QK_HIP(hipGetLastError());
+    return QK_OK;
+}
+
 bool qk_small_supported(qk_ctx *ctx, qk_store *parent, qk_store *s, int64_t Q, int nprobe, int k) {
     static const int enabled = qk_env_int("QK_SMALL", 1);
     static const int max_q = qk_env_int("QK_SMALL_MAX_Q", QK_SMALL_MAXQ_DEFAULT);
