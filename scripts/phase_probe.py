@@ -23,7 +23,7 @@ def main():
     parent = Store(ctx, d); parent.build_csr(np.array([0, nlist], np.int64), torch.arange(nlist, device=dev), centroids.contiguous())
     q = B.gen_queries(8192, cent_true, seed=2, device=dev)
     ctx.set_timing(1)
-    for Q in (1, 4, 8, 16, 32, 64, 128, 256, 1024):
+    for Q in ([int(v) for v in sys.argv[1:]] or (1, 4, 8, 16, 32, 64, 128, 256, 1024)):
         rows = []
         for i in range(24):
             tm = ctx.search(parent, store, q[(i * Q) % 4096:(i * Q) % 4096 + Q], nprobe, k, "l2", timing=True)[2]
