@@ -220,6 +220,35 @@ def test_small_batches_one_launch_search(ctx, metric):
     assert (gi == -1).any()
 
 
+@pytest.mark.parametrize("metric", ["l2", "ip"])
+def test_mid_sized_batches_one_launch_coarse(ctx, metric):
+    """33..256 queries against <= 4096 centroids, 2 <= nprobe <= 64: the coarse step is ONE launch (k_coarse_small,
+    qk_small.hip) -- same partitions, same order, same distance bits as the oracle's coarse step (= the reference's parent
+    search, query_coordinator.cpp:628-644), duplicated centroids on the nprobe cut included; shapes outside the envelope
+    (nprobe 100, 300 queries) take the two-kernel form and must agree as well"""
+    rng = np.random.default_rng(17)
+    for nlist, d in [(5, 24), (64, 128), (1000, 128), (4096, 40), (300, 200)]:
+        ivf = make_ivf(max(4 * nlist, 2000), d, nlist, seed=40 + nlist, metric=metric)
+        cent = ivf["centroids"].copy()
+        if nlist >= 64:  # exact duplicates: ties between partitions, resolved by partition id
+            cent[nlist // 2:nlist // 2 + 20] = cent[:20]
+            ivf = dict(ivf, centroids=cent)
+        parent, s = build_stores(ctx, ivf)
+        for Q in (33, 64, 200, 256, 300):
+            q = make_queries(Q, d, seed=int(rng.integers(1 << 30)), like=ivf["x"], metric=metric)
+            if nlist >= 64:
+                q[: Q // 2] = cent[rng.integers(0, 20, Q // 2)] + (0.01 * rng.standard_normal((Q // 2, d))).astype(np.float32)
+            for nprobe in (2, 10, 64, 100):
+                cp, cd = ctx.coarse(parent, q, nprobe, metric)
+                op, od = O.coarse(q, cent, None, nprobe, metric)
+                np.testing.assert_array_equal(cp, op)
+                np.testing.assert_array_equal(cd.view(np.uint32), od.view(np.uint32))
+            gi, gd = ctx.search(parent, s, q, 10, 10, metric)
+            oi, od = O.search(q, cent, ivf["vecs"], ivf["ids"], ivf["offsets"], 10, 10, metric, batched_scan=True)
+            np.testing.assert_array_equal(gi, oi)
+            np.testing.assert_array_equal(gd.view(np.uint32), od.view(np.uint32))
+
+
 def test_wide_k_with_timing_on_a_fresh_context():
     """k > QK_MAX_K with a qk_timing requested as the FIRST call of a context (what QuakeIndex.search always does): the wide-k
     pipeline records its own phase events, so the timings are real and the call does not fail on never-recorded events."""
