@@ -63,16 +63,6 @@ struct SmallParams {
 
 // canonical key of arena row `row` against the query staged in LDS (sq, zero-padded to 16 columns): one k-ordered fmaf chain
 // over the tile-major layout (qk_internal.h): float4 (tile*nblk + c)*64 + g*16 + r holds columns 16c + {g, 4+g, 8+g, 12+g}
-template <bool NT>
-__device__ __forceinline__ float4 small_ld(const float4 *p) {
-    if (NT) {  // partition rows are read once: keep them out of the way of the L2-resident centroids
-        const f32x4 t = __builtin_nontemporal_load((const f32x4 *)p);
-        return make_float4(t[0], t[1], t[2], t[3]);
-    }
-    return *p;
-}
-
-template <bool NT = false>
 __device__ __forceinline__ uint32_t small_row_key(const float4 *vecs, const float *norms, int nblk, int64_t row, const float *sq,
                                                   float xn, bool l2) {
     const int64_t tile = row >> 4;
@@ -86,7 +76,7 @@ __device__ __forceinline__ uint32_t small_row_key(const float4 *vecs, const floa
         for (int c = 0; c < 8; c++) {
             const int cc = min(c0 + c, nblk - 1);
 #pragma unroll
-            for (int g = 0; g < 4; g++) v[c][g] = small_ld<NT>(base + cc * 64 + g * 16);
+            for (int g = 0; g < 4; g++) v[c][g] = base[cc * 64 + g * 16];
         }
 #pragma unroll
         for (int c = 0; c < 8; c++) {
@@ -111,7 +101,6 @@ __device__ __forceinline__ uint32_t small_row_key(const float4 *vecs, const floa
 }
 
 // two rows at once (d <= 128 per pass: both rows' 32 float4 are requested before either chain starts)
-template <bool NT = false>
 __device__ __forceinline__ void small_row_key2(const float4 *vecs, const float *norms, int nblk, int64_t rowa, int64_t rowb, const float *sq,
                                                float xn, bool l2, uint32_t &ka, uint32_t &kb) {
     const float4 *ba = vecs + (rowa >> 4) * nblk * 64 + (int)(rowa & 15);
@@ -125,8 +114,8 @@ __device__ __forceinline__ void small_row_key2(const float4 *vecs, const float *
             const int cc = min(c0 + c, nblk - 1);
 #pragma unroll
             for (int g = 0; g < 4; g++) {
-                va[c][g] = small_ld<NT>(ba + cc * 64 + g * 16);
-                vb[c][g] = small_ld<NT>(bb + cc * 64 + g * 16);
+                va[c][g] = ba[cc * 64 + g * 16];
+                vb[c][g] = bb[cc * 64 + g * 16];
             }
         }
 #pragma unroll
@@ -371,41 +360,28 @@ __global__ __launch_bounds__(QK_SMALL_THREADS) void k_search_small(SmallParams P
         if (tid == 0) s_fill = cnt;
         __syncthreads();
         const int iters = (int)((end - base + QK_SMALL_THREADS - 1) / QK_SMALL_THREADS);
-        // two rows per thread in flight (both rows' data requested before either chain starts), streamed past the caches
-        for (int it = 0; it < iters; it += 2) {
-            const long long g1 = base + tid + QK_SMALL_THREADS * (long long)it, g2 = g1 + QK_SMALL_THREADS;
-            const bool has1 = g1 < end, has2 = g2 < end;
-            uint32_t key1 = 0xFFFFFFFFu, key2 = 0xFFFFFFFFu;
-            int64_t id1 = -1, id2 = -1;
-            if (has1) {
+        for (int it = 0; it < iters; it++) {
+            const long long g = base + tid + QK_SMALL_THREADS * (long long)it;
+            bool pass = false;
+            uint32_t key = 0xFFFFFFFFu;
+            int64_t id = -1;
+            if (g < end) {
                 int pi = 0;
-                while (pi + 1 < np && s_pre[pi + 1] <= g1) pi++;
-                const int64_t row1 = s_off[pi] + (g1 - s_pre[pi]);
-                id1 = P.ids[row1];  // (requested before the row data: one round trip, not two)
-                if (has2) {
-                    while (pi + 1 < np && s_pre[pi + 1] <= g2) pi++;
-                    const int64_t row2 = s_off[pi] + (g2 - s_pre[pi]);
-                    id2 = P.ids[row2];
-                    small_row_key2<true>(P.vecs, P.norms, P.nblk, row1, row2, sq, xn, l2, key1, key2);
-                } else {
-                    key1 = small_row_key<true>(P.vecs, P.norms, P.nblk, row1, sq, xn, l2);
-                }
+                while (pi + 1 < np && s_pre[pi + 1] <= g) pi++;
+                const int64_t row = s_off[pi] + (g - s_pre[pi]);
+                id = P.ids[row];  // (requested before the row data: one round trip, not two)
+                key = small_row_key(P.vecs, P.norms, P.nblk, row, sq, xn, l2);
+                pass = key != 0xFFFFFFFFu && key <= tau;
             }
-#pragma unroll
-            for (int h = 0; h < 2; h++) {
-                const uint32_t key = h ? key2 : key1;
-                const int64_t id = h ? id2 : id1;
-                const bool pass = (h ? has2 : has1) && key != 0xFFFFFFFFu && key <= tau;
-                const uint64_t m = __ballot(pass);
-                if (m) {
-                    int at = 0;
-                    if (lane == 0) at = atomicAdd(&s_fill, __popcll(m));
-                    at = __builtin_amdgcn_readfirstlane(at);
-                    if (pass) {
-                        const int sl = at + __popcll(m & ((1ull << lane) - 1ull));
-                        pool_ord[sl] = key;
-                        pool_id[sl] = id;
-                    }
+            const uint64_t m = __ballot(pass);
+            if (m) {
+                int at = 0;
+                if (lane == 0) at = atomicAdd(&s_fill, __popcll(m));
+                at = __builtin_amdgcn_readfirstlane(at);
+                if (pass) {
+                    const int sl = at + __popcll(m & ((1ull << lane) - 1ull));
+                    pool_ord[sl] = key;
+                    pool_id[sl] = id;
                 }
             }
         }
