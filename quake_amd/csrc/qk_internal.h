@@ -1,5 +1,6 @@
 // qk_internal.h -- shared declarations of libquake_hip.so (not part of the C ABI).
 #pragma once
+#include "qk_idmap.h"
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string>
@@ -124,103 +125,6 @@ void *qk_ws_alloc(qk_ctx *ctx, size_t bytes);          // 256-B aligned slice; n
 int qk_pinned_reserve(qk_ctx *ctx, size_t bytes);
 int qk_stage_reserve(qk_ctx *ctx, size_t bytes);
 int qk_aps_reserve(qk_ctx *ctx, size_t bytes);
-
-// id -> list number: open addressing, linear probing, power-of-two capacity, load <= 0.5 (live + erased slots).  The store
-// inserts / erases hundreds of thousands of ids per add / remove call: a node-based std::unordered_map spent more time in
-// its allocator than the device spent on the rows.
-struct QkIdMap {
-    static constexpr int32_t EMPTY = -1, ERASED = -2;  // list numbers are >= 0
-    std::vector<int64_t> keys;
-    std::vector<int32_t> vals;
-    size_t live = 0, used = 0;  // used = live + erased
-    static inline uint64_t mix(uint64_t x) {
-        x ^= x >> 30;
-        x *= 0xbf58476d1ce4e5b9ull;
-        x ^= x >> 27;
-        x *= 0x94d049bb133111ebull;
-        x ^= x >> 31;
-        return x;
-    }
-    size_t size() const { return live; }
-    void clear() {
-        keys.clear();
-        vals.clear();
-        live = used = 0;
-    }
-    void rehash(size_t want_live) {
-        size_t cap = 64;
-        while (cap < want_live * 2 + 16) cap <<= 1;
-        std::vector<int64_t> ok;
-        std::vector<int32_t> ov;
-        ok.swap(keys);
-        ov.swap(vals);
-        keys.assign(cap, 0);
-        vals.assign(cap, EMPTY);
-        live = used = 0;
-        for (size_t i = 0; i < ov.size(); i++)
-            if (ov[i] >= 0) set(ok[i], ov[i]);
-    }
-    void reserve(size_t n) {
-        if (keys.size() < n * 2 + 16) rehash(n);
-    }
-    // slot of `key`, or of the first free slot of its probe sequence (erased slots are reused)
-    inline size_t probe(int64_t key, bool &found) const {
-        const size_t mask = keys.size() - 1;
-        size_t i = (size_t)mix((uint64_t)key) & mask, first_free = (size_t)-1;
-        for (;; i = (i + 1) & mask) {
-            const int32_t v = vals[i];
-            if (v == EMPTY) {
-                found = false;
-                return first_free != (size_t)-1 ? first_free : i;
-            }
-            if (v == ERASED) {
-                if (first_free == (size_t)-1) first_free = i;
-            } else if (keys[i] == key) {
-                found = true;
-                return i;
-            }
-        }
-    }
-    int32_t find(int64_t key) const {  // list number or -1
-        if (keys.empty()) return -1;
-        bool f;
-        const size_t i = probe(key, f);
-        return f ? vals[i] : -1;
-    }
-    void put(int64_t key, int32_t val, bool overwrite) {
-        if ((used + 1) * 2 > keys.size()) rehash(std::max<size_t>(live + 1, live * 2));
-        bool f;
-        const size_t i = probe(key, f);
-        if (f) {
-            if (overwrite) vals[i] = val;
-            return;
-        }
-        if (vals[i] == EMPTY) used++;
-        keys[i] = key;
-        vals[i] = val;
-        live++;
-    }
-    void set(int64_t key, int32_t val) { put(key, val, true); }
-    void set_if_absent(int64_t key, int32_t val) { put(key, val, false); }
-    void erase(int64_t key) {
-        if (keys.empty()) return;
-        bool f;
-        const size_t i = probe(key, f);
-        if (f) {
-            vals[i] = ERASED;
-            live--;
-        }
-    }
-    void erase_if(int64_t key, int32_t val) {  // only while it still maps to `val`
-        if (keys.empty()) return;
-        bool f;
-        const size_t i = probe(key, f);
-        if (f && vals[i] == val) {
-            vals[i] = ERASED;
-            live--;
-        }
-    }
-};
 
 // ---- store -----------------------------------------------------------------------------------
 struct qk_part {

@@ -144,10 +144,11 @@ def test_sharded_search_equals_unsharded(metric):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    mgr = mp.Manager()
-    ret = mgr.dict()
-    mp.spawn(_worker, args=(2, port, metric, ret), nprocs=2, join=True)
-    assert ret.get(0) == "ok" and ret.get(1) == "ok"
+    with mp.Manager() as mgr:  # (shut down with the test: two dozen live manager processes made later ones refuse connections)
+        ret = mgr.dict()
+        mp.spawn(_worker, args=(2, port, metric, ret), nprocs=2, join=True)
+        got = dict(ret)
+    assert got.get(0) == "ok" and got.get(1) == "ok"
 
 
 class OracleKmeans:
@@ -206,10 +207,11 @@ def test_sharded_kmeans_world2(metric, m, ordered):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    mgr = mp.Manager()
-    ret = mgr.dict()
-    mp.spawn(_kmeans_worker, args=(2, port, metric, m, ordered, ret), nprocs=2, join=True)
-    assert ret.get(0) == "ok" and ret.get(1) == "ok"
+    with mp.Manager() as mgr:  # (shut down with the test: two dozen live manager processes made later ones refuse connections)
+        ret = mgr.dict()
+        mp.spawn(_kmeans_worker, args=(2, port, metric, m, ordered, ret), nprocs=2, join=True)
+        got = dict(ret)
+    assert got.get(0) == "ok" and got.get(1) == "ok"
 
 
 def test_sharded_kmeans_world1_is_plain_kmeans():

@@ -117,10 +117,11 @@ def test_gpu_engine_world2_processes(metric):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    mgr = mp.Manager()
-    ret = mgr.dict()
-    mp.spawn(_world2_worker, args=(2, port, metric, ret), nprocs=2, join=True)
-    assert ret.get(0) == "ok" and ret.get(1) == "ok"
+    with mp.Manager() as mgr:  # (shut down with the test: two dozen live manager processes made later ones refuse connections)
+        ret = mgr.dict()
+        mp.spawn(_world2_worker, args=(2, port, metric, ret), nprocs=2, join=True)
+        got = dict(ret)
+    assert got.get(0) == "ok" and got.get(1) == "ok"
 
 
 def test_sharded_kmeans_world1_equals_qk_kmeans():

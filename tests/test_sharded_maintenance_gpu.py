@@ -211,10 +211,11 @@ def test_world2_processes(metric):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    mgr = mp.Manager()
-    ret = mgr.dict()
-    mp.spawn(_world2_worker, args=(2, port, metric, ret), nprocs=2, join=True)
-    assert ret.get(0) == "ok" and ret.get(1) == "ok"
+    with mp.Manager() as mgr:  # (shut down with the test: two dozen live manager processes made later ones refuse connections)
+        ret = mgr.dict()
+        mp.spawn(_world2_worker, args=(2, port, metric, ret), nprocs=2, join=True)
+        got = dict(ret)
+    assert got.get(0) == "ok" and got.get(1) == "ok"
 
 
 def _build_worker(rank, world, port, ret):
@@ -262,10 +263,11 @@ def test_sharded_build_world2():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    mgr = mp.Manager()
-    ret = mgr.dict()
-    mp.spawn(_build_worker, args=(2, port, ret), nprocs=2, join=True)
-    assert ret.get(0) == "ok" and ret.get(1) == "ok"
+    with mp.Manager() as mgr:  # (shut down with the test: two dozen live manager processes made later ones refuse connections)
+        ret = mgr.dict()
+        mp.spawn(_build_worker, args=(2, port, ret), nprocs=2, join=True)
+        got = dict(ret)
+    assert got.get(0) == "ok" and got.get(1) == "ok"
 
 
 def _random_worker(rank, world, port, seed, ret):
@@ -343,10 +345,11 @@ def test_world2_random_streams(seed):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    mgr = mp.Manager()
-    ret = mgr.dict()
-    mp.spawn(_random_worker, args=(2, port, seed, ret), nprocs=2, join=True)
-    assert ret.get(0) == "ok" and ret.get(1) == "ok"
+    with mp.Manager() as mgr:  # (shut down with the test: two dozen live manager processes made later ones refuse connections)
+        ret = mgr.dict()
+        mp.spawn(_random_worker, args=(2, port, seed, ret), nprocs=2, join=True)
+        got = dict(ret)
+    assert got.get(0) == "ok" and got.get(1) == "ok"
 
 
 def _replay_worker(rank, world, port, wdir, ret):
@@ -401,7 +404,8 @@ def test_world2_workload_replay(tmp_path):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    mgr = mp.Manager()
-    ret = mgr.dict()
-    mp.spawn(_replay_worker, args=(2, port, wdir, ret), nprocs=2, join=True)
-    assert ret.get(0) == "ok" and ret.get(1) == "ok"
+    with mp.Manager() as mgr:  # (shut down with the test: two dozen live manager processes made later ones refuse connections)
+        ret = mgr.dict()
+        mp.spawn(_replay_worker, args=(2, port, wdir, ret), nprocs=2, join=True)
+        got = dict(ret)
+    assert got.get(0) == "ok" and got.get(1) == "ok"
