@@ -1829,6 +1829,7 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
     int64_t rl_per_list = 0;
     RlCost rlc{12, 8, 1, 16, 4, 32};
     int rl_app = 32;
+    int rl_waves = 4;
     {
         // Measured (10M x 128, 1024 queries, k = 10; k_scan ms old form -> this form): nprobe 1: 0.252 -> 0.246, 2: 0.324 -> 0.313,
         // 4: 0.404 -> 0.362, 8: 0.488 -> 0.439, 16: 0.694 -> 0.616, 32: 0.958 -> 1.02 (MFMA-bound: 5 us of chain per chunk);
@@ -1853,7 +1854,9 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
         // (scripts/gpu_r3h.sh) -- the re-reads are not what the launch waits for.  The wider pass stays behind the probe switch.
         static const int rl_qb_env = qk_env_int("QK_SCAN_RL_QB", 0);  // probe: 32 ... 64 (0: 32)
         int qb = 32, C_rl = std::min(64, qk_round_up(k + 32, 4));
-        auto fits = [&](int q, int c) { return 4 * ((qk_scan_rl_lds_per_wave(nblk, c, q) + 15) & ~(size_t)15) <= (size_t)160 * 1024; };
+        static const int rl_waves_env = qk_env_int("QK_SCAN_RL_WAVES", 4);  // probe: waves per CU (3 leaves room for 64-query passes at d = 128)
+        rl_waves = std::min(4, std::max(1, rl_waves_env));
+        auto fits = [&](int q, int c) { return rl_waves * ((qk_scan_rl_lds_per_wave(nblk, c, q) + 15) & ~(size_t)15) <= (size_t)160 * 1024; };
         if (rl_qb_env > 32) {
             const int c16 = qk_round_up(k + 16, 4);
             for (int q = std::min(rl_qb_env & ~3, QK_RL_QB_MAX); q > 32; q -= 4)
@@ -1903,7 +1906,7 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
         static const int wpc = qk_env_int("QK_SCAN_WAVES_PER_CU", 0);  // probe override
         if (wpc > 0) waves_per_cu = std::max(nw, wpc / nw * nw);
     }
-    if (use_rl) waves_per_cu = 4;  // one wave per SIMD: 256+ registers of row data per wave
+    if (use_rl) waves_per_cu = rl_waves;  // one wave per SIMD: 256+ registers of row data per wave
     // wide rows (d >= 256: the LDS query tile leaves room for <= 4 waves per CU): 16 blocks = 16 KB per load step, so
     // that the few resident waves still keep enough bytes in flight to cover the HBM latency
     if (nblk % 16 == 0 && waves_per_cu <= 4 && !qshare && !use_rl && !qk_env_set("QK_SCAN_NO_DB16")) DB = 16;
@@ -2151,8 +2154,9 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
         // a static partition the slowest CU sets the kernel time)
         // (measured +2 % at 6 and 8 per CU; at 5 per CU the padded request only fits 4 -- pad the tested counts only)
         size_t lds_launch = lds_scan;
-        if (wgs_per_cu == 4 || wgs_per_cu == 6 || wgs_per_cu == 8 || (nw > 1 && wgs_per_cu <= 2))
+        if (wgs_per_cu == 4 || wgs_per_cu == 6 || wgs_per_cu == 8 || (nw > 1 && wgs_per_cu <= 2) || (use_rl && wgs_per_cu == 3))
             lds_launch = std::max<size_t>(lds_scan, (size_t)(160 * 1024) / wgs_per_cu - 512);
+        if (use_rl) lds_launch &= ~(size_t)15;  // (per-wave slices of one allocation: float4 reads need the alignment)
         // dynamic tail: measured wave end times spread over 65-100 % of the kernel with a purely static cut
         static const int dyn_pct = qk_env_int("QK_SCAN_DYN_PCT", QK_DYN_PCT_DEFAULT);
         static const int dyn_chunk = qk_env_int("QK_SCAN_DYN_CHUNK", QK_DYN_CHUNK_DEFAULT);
@@ -2174,12 +2178,13 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
         // single-wave workgroups are bundled four to a hardware workgroup: one wave per SIMD, guaranteed (see k_scan)
         static const bool no_pack = qk_env_set("QK_SCAN_NO_PACK");
         const bool pack4 = use_rl || (nw == 1 && !qshare && !no_pack && (wgs_per_cu == 4 || wgs_per_cu == 8) && lds_launch % 16 == 0);
-        sp.pack = pack4 ? 4 : 1;
+        const int pk = use_rl ? rl_waves : 4;
+        sp.pack = pack4 ? pk : 1;
         sp.pack_lds = (int)lds_launch;
-        const int wpw = pack4 ? 4 : nw;  // waves per hardware workgroup
+        const int wpw = pack4 ? pk : nw;  // waves per hardware workgroup
         if (pack4) {
-            grid = (grid + 3) / 4;
-            lds_launch *= 4;
+            grid = (grid + pk - 1) / pk;
+            lds_launch *= pk;
         }
         // ---- XCD balance (see qk_ctx::xcd_state) ---------------------------------------------------------------------------
         static const int xcd_adapt = qk_env_int("QK_SCAN_XCD_ADAPT", 1);

@@ -69,8 +69,9 @@ __global__ __launch_bounds__(256) void k_scan_rl(ScanParams P) {
     // one atomic counter by whoever finishes first (the cost model cannot know how much HBM bandwidth a wave will get while
     // others are in MFMA-bound passes)
     const long long T = *P.n_tiles;
-    const long long W = (long long)gridDim.x * 4;
-    const long long vblock = (long long)blockIdx.x * 4 + wvp;
+    const int PK = P.pack;  // waves per hardware workgroup (4: one per SIMD; 3 when a wider pass needs the LDS)
+    const long long W = (long long)gridDim.x * PK;
+    const long long vblock = (long long)blockIdx.x * PK + wvp;
     const bool dyn = P.dyn_counter != nullptr;
     const long long Ts = dyn ? T - (T * P.dyn_pct) / 100 : T;
     long long T0 = (Ts * vblock) / W, T1 = (Ts * (vblock + 1)) / W;
@@ -80,8 +81,8 @@ __global__ __launch_bounds__(256) void k_scan_rl(ScanParams P) {
 #pragma unroll
         for (int i = 0; i < 8; i++) pre[i + 1] = pre[i] + P.xcd_w[i];
         const long long u = blockIdx.x, gu = gridDim.x;
-        const long long total = ((gu >> 3) * pre[8] + pre[gu & 7]) * 4;
-        const long long a0 = ((u >> 3) * pre[8] + pre[u & 7]) * 4 + (long long)P.xcd_w[u & 7] * wvp;
+        const long long total = ((gu >> 3) * pre[8] + pre[gu & 7]) * PK;
+        const long long a0 = ((u >> 3) * pre[8] + pre[u & 7]) * PK + (long long)P.xcd_w[u & 7] * wvp;
         const long long a1 = a0 + P.xcd_w[u & 7];
         T0 = a0 <= 0 ? 0 : (long long)((double)Ts * (double)a0 / (double)total);
         T1 = a1 >= total ? Ts : (long long)((double)Ts * (double)a1 / (double)total);
@@ -416,7 +417,7 @@ size_t qk_scan_rl_lds_per_wave(int nblk, int C, int qb) {
 template <int NB, bool L2>
 static int launch_rl_m(dim3 grid, size_t lds, hipStream_t st, const ScanParams &sp) {
     QK_HIP(hipFuncSetAttribute((const void *)k_scan_rl<NB, L2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((k_scan_rl<NB, L2>), grid, dim3(256), lds, st, sp);
+    hipLaunchKernelGGL((k_scan_rl<NB, L2>), grid, dim3(64 * sp.pack), lds, st, sp);
     return QK_OK;
 }
 template <int NB>
@@ -424,7 +425,7 @@ static int launch_rl_t(dim3 grid, size_t lds, hipStream_t st, const ScanParams &
     return sp.metric == QK_METRIC_L2 ? launch_rl_m<NB, true>(grid, lds, st, sp) : launch_rl_m<NB, false>(grid, lds, st, sp);
 }
 
-// grid = hardware workgroups of 4 independent waves; lds = 4 x sp.pack_lds
+// grid = hardware workgroups of sp.pack independent waves; lds = sp.pack x sp.pack_lds
 int qk_launch_scan_rl(int nblk, dim3 grid, size_t lds, hipStream_t st, const ScanParams &sp) {
     switch (nblk) {
         case 1: return launch_rl_t<1>(grid, lds, st, sp);
