@@ -155,17 +155,33 @@ struct SelectParams {
     int sqrt_l2;
     int64_t *out_ids;
     float *out_dist;
+    // long rows: every key row is cut into `slices` slices of slice_len keys (a multiple of 1024), one wave each; the wave
+    // leaves the k best of its slice as (id, key) in out_ids / out_ord [Q][slices][k] and k_merge_slices finishes the query
+    int slices;
+    int slice_len;
+    uint32_t *out_ord;
 };
 
 template <int MAXCH>
-__global__ __launch_bounds__(64) void k_select_rows(SelectParams S) {
+__global__ __launch_bounds__(64) void k_select_rows(SelectParams S0) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = threadIdx.x;
-    const int64_t q = blockIdx.x;
+    SelectParams S = S0;
+    int64_t q = blockIdx.x;
+    const uint32_t *row;
+    if (S.slices > 1) {  // this wave's slice of query qq's row
+        const int64_t qq = q / S.slices;
+        const int sl = (int)(q - qq * S.slices);
+        const int r0 = sl * S.slice_len;
+        row = S.D + qq * S.ld + r0;
+        S.ids += r0;
+        S.nrows = max(0, min(S.slice_len, S.nrows - r0));
+    } else {
+        row = S.D + q * S.ld;
+    }
     const int k = S.k, Cm = S.Cm;
     int64_t *pool_id = (int64_t *)smem;
     uint32_t *pool_ord = (uint32_t *)(smem + (size_t)Cm * 8);
-    const uint32_t *row = S.D + q * S.ld;
     uint32_t tau = 0xFFFFFFFFu;
     int cnt = 0;
     // Pool entries [n_ids, cnt) hold the ROW of a candidate, not yet its id: an id load inside the append path is a dependent
@@ -272,6 +288,13 @@ __global__ __launch_bounds__(64) void k_select_rows(SelectParams S) {
     }
     to_ids(cnt);
     cnt = compact_pool<MAXCH>(pool_ord, pool_id, cnt, k, lane);
+    if (S.slices > 1) {
+        for (int e = lane; e < k; e += 64) {
+            S.out_ids[q * k + e] = e < cnt ? pool_id[e] : -1;
+            S.out_ord[q * k + e] = e < cnt ? pool_ord[e] : 0xFFFFFFFFu;
+        }
+        return;
+    }
     for (int e = lane; e < k; e += 64) {
         int64_t oid = -1;
         float od = S.metric == QK_METRIC_IP ? -INFINITY : INFINITY;
@@ -290,6 +313,50 @@ __global__ __launch_bounds__(64) void k_select_rows(SelectParams S) {
     }
 }
 
+
+// The slices of a query (k_select_rows with slices > 1): S x k candidates, each slice sorted under (key, id) -> the k best overall,
+// sorted, as ids + distances.  One wave per query; S * k <= 1024.
+template <int MAXCH>
+__global__ __launch_bounds__(64) void k_merge_slices(const int64_t *in_ids, const uint32_t *in_ord, int slices, int k, int metric, int sqrt_l2,
+                                                     int64_t *out_ids, float *out_dist) {
+    __shared__ int64_t pool_id[MAXCH * 64];
+    __shared__ uint32_t pool_ord[MAXCH * 64];
+    const int lane = threadIdx.x;
+    const int64_t q = blockIdx.x;
+    const int n_in = slices * k;  // <= MAXCH * 64
+    // live entries first (a slice shorter than k is padded with 0xFFFFFFFF keys): ballot-compacted copy
+    int cnt = 0;
+    for (int base = 0; base < n_in; base += 64) {
+        const int e = base + lane;
+        const uint32_t o = e < n_in ? in_ord[q * n_in + e] : 0xFFFFFFFFu;
+        const int64_t id = e < n_in ? in_ids[q * n_in + e] : -1;
+        const bool live = e < n_in && o != 0xFFFFFFFFu;  // (padding of a slice shorter than k: never a live key)
+        const uint64_t m = __ballot(live);
+        if (live) {
+            const int sl = cnt + __popcll(m & ((1ull << lane) - 1ull));
+            pool_ord[sl] = o;
+            pool_id[sl] = id;
+        }
+        cnt += __popcll(m);
+    }
+    cnt = compact_pool<MAXCH>(pool_ord, pool_id, cnt, k, lane);
+    for (int e = lane; e < k; e += 64) {
+        int64_t oid = -1;
+        float od = metric == QK_METRIC_IP ? -INFINITY : INFINITY;
+        if (e < cnt) {
+            oid = pool_id[e];
+            const uint32_t o = pool_ord[e];
+            if (metric == QK_METRIC_L2) {
+                const float d2 = __uint_as_float(o);
+                od = sqrt_l2 ? sqrtf(d2) : d2;
+            } else {
+                od = ip_from_ord(o);
+            }
+        }
+        out_ids[q * k + e] = oid;
+        if (out_dist) out_dist[q * k + e] = od;
+    }
+}
 
 // ---- large-k selection (448 < k <= QK_MAX_NPROBE): the coarse step with nprobe / APS candidate counts beyond the LDS pools ----
 // One workgroup of 256 threads per query over its key row (L2-resident):
@@ -806,9 +873,29 @@ int qk_dense_device(qk_ctx *ctx, qk_store *s, int64_t list_no, const qk_scan_arg
     // query batching keeps the key matrix under 1 GiB
     int64_t qb = std::max<int64_t>(NQ * 16, ((int64_t)1 << 30) / (ld * 4));
     qb = std::min<int64_t>(Q, (qb / (NQ * 16)) * (NQ * 16));
-    QK_TRY(qk_ws_reserve(ctx, (size_t)qb * ld * 4 + 4096));
+    // sliced selection of long rows (see below): scratch for the slices' candidates
+    static const int sel_slices = qk_env_int("QK_SELECT_SLICES", 1);  // probe: 0 = never
+    int slices = 1, slice_len = 0;
+    if (sel_slices && !large_k && k <= 64 && nrows >= 8192) {
+        slice_len = 4096;
+        slices = (nrows + slice_len - 1) / slice_len;
+        while (slices * k > 1024) {  // the merge wave holds all candidates of a query
+            slice_len *= 2;
+            slices = (nrows + slice_len - 1) / slice_len;
+        }
+        if (slices < 2) slices = 1;
+    }
+    const size_t sl_bytes = slices > 1 ? (size_t)qb * slices * k * 12 + 512 : 0;
+    QK_TRY(qk_ws_reserve(ctx, (size_t)qb * ld * 4 + sl_bytes + 4096));
     uint32_t *D = (uint32_t *)qk_ws_alloc(ctx, (size_t)qb * ld * 4);
     if (!D) QK_FAIL(QK_ERR_OOM, "dense scan: workspace exhausted");
+    int64_t *sl_ids = nullptr;
+    uint32_t *sl_ord = nullptr;
+    if (slices > 1) {
+        sl_ids = (int64_t *)qk_ws_alloc(ctx, (size_t)qb * slices * k * 8);
+        sl_ord = (uint32_t *)qk_ws_alloc(ctx, (size_t)qb * slices * k * 4);
+        if (!sl_ids || !sl_ord) QK_FAIL(QK_ERR_OOM, "dense scan: workspace exhausted");
+    }
     const int num_cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
     QK_TRY(pe.mark(0));
     QK_TRY(pe.mark(1));
@@ -876,11 +963,36 @@ int qk_dense_device(qk_ctx *ctx, qk_store *s, int64_t list_no, const qk_scan_arg
             continue;
         }
         const size_t lds_s = (size_t)Cm * 12;
+        // long rows (>= 8192 keys, k <= 64): one wave per 4096-key slice instead of one wave per row -- a single wave walking
+        // 65536 keys twice was 2/3 of the coarse call at 65536 centroids -- and a one-wave merge of the slices' candidates
+        sp.slices = 1;
+        sp.slice_len = 0;
+        sp.out_ord = nullptr;
+        unsigned nwaves = (unsigned)nq;
+        if (sl_ids) {
+            sp.slices = slices;
+            sp.slice_len = slice_len;
+            sp.out_ids = sl_ids;
+            sp.out_ord = sl_ord;
+            sp.out_dist = nullptr;
+            nwaves = (unsigned)(nq * slices);
+        }
         switch (mc) {
-            case 2: hipLaunchKernelGGL((k_select_rows<2>), dim3((unsigned)nq), dim3(64), lds_s, st, sp); break;
-            case 4: hipLaunchKernelGGL((k_select_rows<4>), dim3((unsigned)nq), dim3(64), lds_s, st, sp); break;
-            case 8: hipLaunchKernelGGL((k_select_rows<8>), dim3((unsigned)nq), dim3(64), lds_s, st, sp); break;
-            default: hipLaunchKernelGGL((k_select_rows<16>), dim3((unsigned)nq), dim3(64), lds_s, st, sp); break;
+            case 2: hipLaunchKernelGGL((k_select_rows<2>), dim3(nwaves), dim3(64), lds_s, st, sp); break;
+            case 4: hipLaunchKernelGGL((k_select_rows<4>), dim3(nwaves), dim3(64), lds_s, st, sp); break;
+            case 8: hipLaunchKernelGGL((k_select_rows<8>), dim3(nwaves), dim3(64), lds_s, st, sp); break;
+            default: hipLaunchKernelGGL((k_select_rows<16>), dim3(nwaves), dim3(64), lds_s, st, sp); break;
+        }
+        if (sl_ids) {
+            const int n_in = slices * k;
+#define MS_LAUNCH(M_)                                                                                                        \
+    hipLaunchKernelGGL((k_merge_slices<M_>), dim3((unsigned)nq), dim3(64), 0, st, sl_ids, sl_ord, slices, k, a.metric, a.sqrt_l2 ? 1 : 0, \
+                       a.out_ids + q0 * k, a.out_dist ? a.out_dist + q0 * k : nullptr)
+            if (n_in <= 128) MS_LAUNCH(2);
+            else if (n_in <= 256) MS_LAUNCH(4);
+            else if (n_in <= 512) MS_LAUNCH(8);
+            else MS_LAUNCH(16);
+#undef MS_LAUNCH
         }
     }
     QK_HIP(hipGetLastError());

@@ -12,11 +12,13 @@ dev = torch.device("cuda", 0)
 d, Q = 128, 1024
 g = torch.Generator(device=dev).manual_seed(0)
 q = torch.randn(Q, d, generator=g, device=dev)
-for nl in (4096, 8192, 16384, 32768, 65536):
+NLS = [int(v) for v in sys.argv[1].split(',')] if len(sys.argv) > 1 else (4096, 8192, 16384, 32768, 65536)
+NPS = [int(v) for v in sys.argv[2].split(',')] if len(sys.argv) > 2 else (1, 32, 100, 400)
+for nl in NLS:
     c = torch.randn(nl, d, generator=g, device=dev)
     parent = Store(ctx, d)
     parent.build_csr(np.array([0, nl], np.int64), torch.arange(nl, device=dev), c)
-    for nprobe in (1, 32, 100, 400):
+    for nprobe in NPS:
         for _ in range(3):
             ctx.coarse(parent, q, nprobe, "l2")
         torch.cuda.synchronize()

@@ -249,6 +249,38 @@ def test_mid_sized_batches_one_launch_coarse(ctx, metric):
             np.testing.assert_array_equal(gd.view(np.uint32), od.view(np.uint32))
 
 
+@pytest.mark.parametrize("metric", ["l2", "ip"])
+def test_long_rows_sliced_selection(ctx, metric):
+    """>= 8192 rows in the scanned list (coarse step over many centroids, flat index) with k <= 64: the selection runs one wave
+    per 4096-key slice + a merge of the slices' candidates (k_select_rows slices, k_merge_slices) -- same ids, order and
+    distance bits as the oracle; duplicated rows across slices included; k = 100 takes the one-wave-per-row form"""
+    rng = np.random.default_rng(23)
+    for nlist, d in [(8192, 16), (20000, 24), (70000, 8)]:
+        cent = rng.standard_normal((nlist, d)).astype(np.float32)
+        cent[nlist - 50:] = cent[:50]  # exact duplicates in the first and the last slice: ties cut by id
+        if metric == "ip":
+            cent /= np.linalg.norm(cent, axis=1, keepdims=True)
+        from quake_amd.capi import Store
+        parent = Store(ctx, d)
+        parent.build_csr(np.array([0, nlist], np.int64), np.arange(nlist, dtype=np.int64), cent)
+        for Q in (40, 300):
+            q = (cent[rng.integers(0, nlist, Q)] + 0.05 * rng.standard_normal((Q, d))).astype(np.float32)
+            q[: Q // 2] = cent[rng.integers(0, 50, Q // 2)]
+            for nprobe in (2, 10, 64, 100):
+                cp, cd = ctx.coarse(parent, q, nprobe, metric)
+                op, od = O.coarse(q, cent, None, nprobe, metric)
+                np.testing.assert_array_equal(cp, op)
+                np.testing.assert_array_equal(cd.view(np.uint32), od.view(np.uint32))
+    # flat index (one list of 30000 rows, ids not in row order): same path through qk_search
+    ivf = make_ivf(30000, 32, 1, seed=77, metric=metric)
+    parent, s = build_stores(ctx, ivf)
+    q = make_queries(64, 32, seed=78, like=ivf["x"], metric=metric)
+    gi, gd = ctx.search(None, s, q, 1, 10, metric)
+    oi, od = O.search(q, ivf["centroids"], ivf["vecs"], ivf["ids"], ivf["offsets"], 1, 10, metric, batched_scan=True)
+    np.testing.assert_array_equal(gi, oi)
+    np.testing.assert_array_equal(gd.view(np.uint32), od.view(np.uint32))
+
+
 def test_wide_k_with_timing_on_a_fresh_context():
     """k > QK_MAX_K with a qk_timing requested as the FIRST call of a context (what QuakeIndex.search always does): the wide-k
     pipeline records its own phase events, so the timings are real and the call does not fail on never-recorded events."""
