@@ -162,7 +162,9 @@ int qk_ws_reserve(qk_ctx *c, size_t bytes) {
     if (c->ws) QK_HIP(hipFree(c->ws));
     c->ws = nullptr;
     c->ws_cap = 0;
-    size_t want = bytes + bytes / 4 + (1u << 20);
+    // powers of two from 64 MB: a few regrowths in the life of a context instead of one per slightly larger request
+    size_t want = (size_t)64 << 20;
+    while (want < bytes + (1u << 20)) want <<= 1;
     hipError_t e = hipMalloc((void **)&c->ws, want);
     if (e != hipSuccess) {
         qk_set_error("workspace allocation of %zu bytes failed: %s", want, hipGetErrorString(e));

@@ -180,6 +180,10 @@ __global__ __launch_bounds__(64) void k_select_rows(SelectParams S0) {
         row = S.D + q * S.ld;
     }
     const int k = S.k, Cm = S.Cm;
+    // every wave starts its walk at a different 4 KB block of its keys (the walk order does not matter to a selection): rows and
+    // slices start at multiples of 16 KB, and thousands of waves stepping through them in phase hit the same few memory channels
+    const int niter = (S.nrows + 1023) >> 10;
+    const int rot = niter > 1 ? (int)(blockIdx.x % (unsigned)niter) : 0;
     int64_t *pool_id = (int64_t *)smem;
     uint32_t *pool_ord = (uint32_t *)(smem + (size_t)Cm * 8);
     uint32_t tau = 0xFFFFFFFFu;
@@ -200,7 +204,8 @@ __global__ __launch_bounds__(64) void k_select_rows(SelectParams S0) {
         uint32_t lm[8];
 #pragma unroll
         for (int t = 0; t < 8; t++) lm[t] = 0xFFFFFFFFu;
-        for (int base = 0; base < S.nrows; base += 1024) {
+        for (int it = 0; it < niter; it++) {
+            const int base = ((it + rot) % niter) * 1024;
             uint4 kv4[4];
 #pragma unroll
             for (int u = 0; u < 4; u++) {
@@ -247,7 +252,8 @@ __global__ __launch_bounds__(64) void k_select_rows(SelectParams S0) {
         tau = bound;
     }
     // 4 keys per lane per load (16 B), 4 loads in flight: 1024 rows per wave step
-    for (int base = 0; base < S.nrows; base += 1024) {
+    for (int it = 0; it < niter; it++) {
+        const int base = ((it + rot) % niter) * 1024;
         uint4 kv4[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
@@ -918,7 +924,9 @@ int qk_dense_device(qk_ctx *ctx, qk_store *s, int64_t list_no, const qk_scan_arg
         const int ntile = (nrows + 15) / 16;
         // enough workgroups to fill the chip, at least 4 tiles (one per wave) each
         // staging the query tile costs as much as ~8 row tiles per wave: aim at one workgroup per CU, >= 16 tiles each
-        int64_t want_chunks = std::max<int64_t>(1, ((int64_t)num_cus + qgroups - 1) / qgroups);
+        // (two workgroups per CU from 65536 rows on: the key epilogue of one wave runs under the MFMAs of the other -- 1024 queries,
+        //  nprobe 32: 430 -> 371 us; below that the choice made no difference worth having: 16384 rows 106 -> 103)
+        int64_t want_chunks = std::max<int64_t>(1, ((int64_t)(ntile >= 4096 ? 2 : 1) * num_cus + qgroups - 1) / qgroups);
         int tiles_per_wg = (int)std::max<int64_t>(16, (ntile + want_chunks - 1) / want_chunks);
         tiles_per_wg = qk_round_up(tiles_per_wg, 4);
         dp.tiles_per_wg = tiles_per_wg;
