@@ -2166,6 +2166,9 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
         if (use_rl) {  // row-per-lane form: dynamic tail in ranges of rl_dyn_chunk units (>= tail / QK_RL_DYN_MAX)
             // (share of the sequence handed out dynamically: 40 % when partitions are mostly probed by one query -- the cost
             //  model has little to say there and the tail evens out XCD / placement differences --, 25 % otherwise)
+            // (re-checked on the final kernels, scripts/gpu_r4e.sh: 25 / 40 / 50 % x ranges of 16 / 32 / 64 units -- nprobe 8 within 1 %
+            //  everywhere, nprobe 16 on the skewed mixture best at 25 % (0.610 against 0.630 ms at 40 %), the uniformly probed corpus best at
+            //  40 % / 16 units (0.778 against 0.793 ms): no setting wins both, the rule stays)
             static const int rl_dyn_env = qk_env_int("QK_SCAN_RL_DYN_PCT", -1);
             // (small launches -- under 1024 pairs, a wave's static share is a chunk or two -- finish sooner without a tail to
             //  claim: 64 queries x nprobe 10: scan 60 -> 55 us, 8 queries: 46 -> 25 us; from 2560 pairs on the tail pays)
