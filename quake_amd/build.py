@@ -22,6 +22,9 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 # The product build has none of them.
 if os.environ.get("QK_BUILD_PROBES", "0") not in ("", "0"):
     FLAGS.append("-DQK_PROBES")
+# QK_BUILD_DEV=1: development build -- the row-per-lane scan is instantiated for d = 128 only (never ship it)
+if os.environ.get("QK_BUILD_DEV", "0") not in ("", "0"):
+    FLAGS.append("-DQK_RL_DEV")
 
 
 def _stale(out, deps):

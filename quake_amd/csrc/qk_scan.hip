@@ -156,7 +156,26 @@ struct GroupParams {
     int rl;               // 1: the sequence is measured in the units of the row-per-lane scan (rl_part_len), else seq_weight
     RlCost rlc;
     int32_t *n_pairs_live; // [1] (query, partition) pairs that reach a present, non-empty partition (qk_timing::partitions_scanned)
+    // mixed sequence (rl only): lists with cnt >= hot.min weigh nothing in the per-wave sequence and are cut into items instead
+    HotCost hot;
+    int32_t *act_hoff;     // [npids+1] hot items in front of every active list; entry n_active is the total
+    int32_t *n_hot;        // [1]
+    long long *hot_units;  // [1]
 };
+
+// length of a list in the per-wave sequence, and the hot items / hot cost it contributes instead when it is hot
+__device__ __forceinline__ long long group_seq_len(const GroupParams &G, int c, int sz, int *items, long long *hunits) {
+    *items = 0;
+    *hunits = 0;
+    if (!G.rl) return 0;  // (seq_weight: the caller)
+    if (G.hot.min > 0 && c >= G.hot.min) {
+        const HotShape hs = hot_shape(c, sz, G.hot);
+        *items = hs.nqblk * hs.nrr;
+        *hunits = hot_units_of(c, sz, G.hot);
+        return 0;
+    }
+    return rl_part_len(c, sz, G.rlc);
+}
 
 __device__ __forceinline__ int pair_pid(const GroupParams &G, int64_t i) {
     int64_t p;
@@ -234,7 +253,7 @@ __device__ __forceinline__ long long seq_weight(int cnt_q, int size_p, int G, in
 // scope loads, which go past the L2; behind a kernel boundary (three-kernel form) plain loads do, and hit in L2 -- the scan
 // kernel is a chain of dependent loads and nothing else (4096 active lists: 16 round trips per thread)
 template <bool SAME_KERNEL>
-__device__ __forceinline__ void group_scan_body(const GroupParams &G, long long *s_w /*[48] LDS*/) {
+__device__ __forceinline__ void group_scan_body(const GroupParams &G, long long *s_w /*[64] LDS*/) {
     const int tid = threadIdx.x;
     // (agent-scope loads: in the single-kernel form the counters were just written with atomics by this workgroup)
     const int n_act = SAME_KERNEL ? __hip_atomic_load(G.n_act, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *G.n_act;
@@ -242,53 +261,68 @@ __device__ __forceinline__ void group_scan_body(const GroupParams &G, long long 
     const int b = tid * per, e = min(n_act, b + per);
     int sq = 0, sa = 0;
     long long stl = 0, sr = 0;
+    unsigned long long sh = 0;  // hot items (low 32 bits) | hot units (high 32 bits)
     for (int i = b; i < e; i++) {
         const int p = G.act_list[i];
         const int c = SAME_KERNEL ? __hip_atomic_load(&G.g_cnt[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : G.g_cnt[p];
         const int sz = G.pt_size[p];
         sq += c;
         sa += 1;
-        stl += G.rl ? rl_part_len(c, sz, G.rlc) : seq_weight(c, sz, G.qgroup, G.seg_ovh);
+        int hi_;
+        long long hu_;
+        const long long rl_len = group_seq_len(G, c, sz, &hi_, &hu_);
+        stl += G.rl ? rl_len : seq_weight(c, sz, G.qgroup, G.seg_ovh);
+        sh += (unsigned long long)(unsigned)hi_ | ((unsigned long long)(hu_ > 0x3FFFFFFFll ? 0x3FFFFFFFll : hu_) << 32);
         sr += sz;
     }
     // three scans behind ONE pair of barriers: (active count | grouped-query count) packed in 64 bits (both < 2^31, so
     // the halves never carry into each other), tiles, rows (total only)
     long long tq, ta, tt, tr;
     long long aq, aa, at;
+    unsigned long long ah, th;  // hot items | hot units: exclusive prefix of this thread, total
     {
         const int lane = tid & 63, wave = tid >> 6;
         unsigned long long i0 = ((unsigned long long)(unsigned)sa << 32) | (unsigned)sq;
         long long i1 = stl, i2 = sr;
+        unsigned long long i3 = sh;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
             const unsigned long long o0 = __shfl_up(i0, off);
             const long long o1 = __shfl_up(i1, off), o2 = __shfl_up(i2, off);
+            const unsigned long long o3 = __shfl_up(i3, off);
             if (lane >= off) {
                 i0 += o0;
                 i1 += o1;
                 i2 += o2;
+                i3 += o3;
             }
         }
         if (lane == 63) {
             s_w[wave] = (long long)i0;
             s_w[16 + wave] = i1;
             s_w[32 + wave] = i2;
+            s_w[48 + wave] = (long long)i3;
         }
         __syncthreads();
-        unsigned long long p0 = 0, t0 = 0;
+        unsigned long long p0 = 0, t0 = 0, p3 = 0, t3 = 0;
         long long p1 = 0, t1 = 0, t2 = 0;
 #pragma unroll
         for (int w = 0; w < 16; w++) {
             const unsigned long long v0 = (unsigned long long)s_w[w];
             const long long v1 = s_w[16 + w];
+            const unsigned long long v3 = (unsigned long long)s_w[48 + w];
             if (w < wave) {
                 p0 += v0;
                 p1 += v1;
+                p3 += v3;
             }
             t0 += v0;
             t1 += v1;
             t2 += s_w[32 + w];
+            t3 += v3;
         }
+        ah = p3 + i3 - sh;
+        th = t3;
         const unsigned long long e0 = p0 + i0 - (((unsigned long long)(unsigned)sa << 32) | (unsigned)sq);
         aq = (long long)(e0 & 0xFFFFFFFFull);
         aa = (long long)(e0 >> 32);
@@ -310,7 +344,13 @@ __device__ __forceinline__ void group_scan_body(const GroupParams &G, long long 
         *G.n_tiles = tt;
         *G.n_rows_unique = tr;
         *G.n_pairs_live = (int)tq;
+        if (G.act_hoff) {
+            G.act_hoff[ta] = (int)(th & 0xFFFFFFFFull);
+            *G.n_hot = (int)(th & 0xFFFFFFFFull);
+            *G.hot_units = (long long)(th >> 32);
+        }
     }
+    int ahi = (int)(ah & 0xFFFFFFFFull);
     for (int i = b; i < e; i++) {
         const int p = G.act_list[i];
         const int c = SAME_KERNEL ? __hip_atomic_load(&G.g_cnt[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : G.g_cnt[p];
@@ -323,14 +363,19 @@ __device__ __forceinline__ void group_scan_body(const GroupParams &G, long long 
         inf.cnt = c;
         inf.qoff = (int)aq;
         G.active[aa] = inf;
+        if (G.act_hoff) G.act_hoff[aa] = ahi;
         aq += c;
         aa += 1;
-        at += G.rl ? rl_part_len(c, G.pt_size[p], G.rlc) : seq_weight(c, G.pt_size[p], G.qgroup, G.seg_ovh);
+        int hi_;
+        long long hu_;
+        const long long rl_len = group_seq_len(G, c, G.pt_size[p], &hi_, &hu_);
+        at += G.rl ? rl_len : seq_weight(c, G.pt_size[p], G.qgroup, G.seg_ovh);
+        ahi += hi_;
     }
 }
 
 __global__ __launch_bounds__(1024) void k_group_scan(GroupParams G) {
-    __shared__ long long s_w[48];
+    __shared__ long long s_w[64];
     group_scan_body<false>(G, s_w);
 }
 
@@ -354,7 +399,7 @@ __global__ void k_group_scatter(GroupParams G) {
 // all there is (a 1-query search: 10 pairs), so it serves batches up to 1024 pairs.
 constexpr int QK_GROUP_SMALL = 1024;
 __device__ __forceinline__ void group_small_body(const GroupParams &G) {
-    __shared__ long long s_w[48];
+    __shared__ long long s_w[64];
     // partition and arrival rank of this thread's pairs stay in registers: the scatter below needs neither the list numbers
     // again nor a second round of atomics (three dependent memory round trips less in a kernel that is nothing but those)
     int pp[QK_GROUP_SMALL / 1024], pos[QK_GROUP_SMALL / 1024];
@@ -1668,6 +1713,7 @@ int qk_merge_topk_device(qk_ctx *ctx, const int64_t *in_ids, const float *in_key
 // ---- host orchestration -------------------------------------------------------------------------------------
 // row-per-lane form (qk_scan_rl.hip)
 size_t qk_scan_rl_lds_per_wave(int nblk, int C, int qb);
+size_t qk_scan_hot_lds(int nblk, int C, int hq);
 int qk_launch_scan_rl(int nblk, dim3 grid, size_t lds, hipStream_t st, const ScanParams &sp);
 
 template <int DB, int MAXCH, int MODE, bool L2>
@@ -1880,6 +1926,22 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
             C = C_rl;
         }
     }
+    // Mixed work sequence (qk_scan_rl.hip, HOT form): lists probed by >= hot.min queries of the batch become dense items on
+    // v_mfma_f32_16x16x4_f32 claimed by whole workgroups; the block width hq is what the workgroup's LDS (the four waves' slices
+    // of the per-wave form together) holds next to one pool of C entries per query.
+    HotCost hot{0, 0, 0, 0, 0};
+    if (use_rl && rl_waves == 4) {
+        static const int hot_min = qk_env_int("QK_SCAN_HOT_MIN", 33);   // 0: per-wave walk only
+        static const int hot_unit = qk_env_int("QK_SCAN_HOT_UNIT", 256);
+        static const int hot_w10 = qk_env_int("QK_SCAN_HOT_W10", 12);
+        static const int hot_ovh = qk_env_int("QK_SCAN_HOT_OVH", 64);
+        static const int hot_hq = qk_env_int("QK_SCAN_HOT_HQ", 128);
+        const size_t per_wave = std::max<size_t>((qk_scan_rl_lds_per_wave(nblk, C, rlc.qb) + 15) & ~(size_t)15, (size_t)(160 * 1024) / 4 - 512) & ~(size_t)15;
+        int hq = std::min(128, std::max(16, hot_hq)) & ~15;
+        while (hq >= 32 && qk_scan_hot_lds(nblk, C, hq) > 4 * per_wave) hq -= 16;
+        if (hot_min > 0 && hq >= 32 && npairs >= 1024)
+            hot = HotCost{std::max(hot_min, 17), hq, std::max(16, hot_unit), std::max(1, hot_w10), std::max(0, hot_ovh)};
+    }
     const int maxch = pick_maxch(C);
     const size_t lds_scan = use_rl ? ((qk_scan_rl_lds_per_wave(nblk, C, rlc.qb) + 15) & ~(size_t)15)
                             : qshare ? (size_t)nw * (q_bytes + (size_t)16 * C * 12) : q_bytes + (size_t)nw * 16 * C * 12;
@@ -1930,7 +1992,9 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
     const int64_t seg_starts = n_wgs + dyn_ranges;
     // (row-per-lane form: a segment emits one record per live query of its pass; every range boundary inside a pass adds at
     //  most rlc.qb records)
-    const int64_t max_recs = use_rl ? std::min<int64_t>(0x7FFFFFF0LL, npairs + (int64_t)rlc.qb * (n_waves + QK_RL_DYN_MAX + 2))
+    // (hot lists: a pair leaves one record per row range of its list, at most QK_HOT_NRR_MAX)
+    const int64_t hot_recs = hot.min > 0 ? npairs * std::min<int64_t>(QK_HOT_NRR_MAX, (((std::max<int64_t>(1, s->max_size) + 15) / 16) * (hot.hq / 16)) / hot.unit + 1) : 0;
+    const int64_t max_recs = use_rl ? std::min<int64_t>(0x7FFFFFF0LL, npairs + hot_recs + (int64_t)rlc.qb * (n_waves + QK_RL_DYN_MAX + 2))
                                     : std::min<int64_t>(0x7FFFFFF0LL, nw * std::min<int64_t>(16 * (items_bound + seg_starts), npairs + 16 * seg_starts));
 
     // ---- workspace ---------------------------------------------------------------------------------
@@ -1940,6 +2004,7 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
     add((size_t)npids * 4 * 2 + 256 + (size_t)Q * 4 + 64);
     add((size_t)(npids + 1) * sizeof(ActiveInfo) + 64);
     add((size_t)(npids + 1) * 4 + 64);
+    add((size_t)(npids + 2) * 4 + 64);
     add((size_t)np1 * 4 * 3);
     add((size_t)np1 * QK_SLOTS * 4);
     add((size_t)(std::min<int64_t>(npids, np1) + 1) * 4 + 64);
@@ -1962,6 +2027,8 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
     int32_t *scal = g_cursor + npids;
     ActiveInfo *active = (ActiveInfo *)qk_ws_alloc(ctx, (size_t)(npids + 1) * sizeof(ActiveInfo) + 64);
     int32_t *g_qoff = (int32_t *)qk_ws_alloc(ctx, (size_t)(npids + 1) * 4 + 64);
+    int32_t *act_hoff = (int32_t *)qk_ws_alloc(ctx, (size_t)(npids + 2) * 4 + 64);
+    // (+ [8] hot items, [10..11] hot units (i64), [12] next hot item: the mixed sequence of the row-per-lane form)
     // scal layout (int32 units): [0] n_active, [1] rec_counter, [2..3] n_rows_unique (i64), [4..5] n_tiles (i64), [6] n_act, [7] live pairs
     int32_t *n_active = scal, *rec_counter = scal + 1;
     int64_t *n_rows_unique = (int64_t *)(scal + 2);
@@ -1975,7 +2042,7 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
     int2 *rec_hdr = (int2 *)qk_ws_alloc(ctx, (size_t)max_recs * 8);
     uint32_t *rec_ord = (uint32_t *)qk_ws_alloc(ctx, (size_t)max_recs * k * 4);
     int64_t *rec_id = (int64_t *)qk_ws_alloc(ctx, (size_t)max_recs * k * 8);
-    if (!g_cnt || !active || !g_qoff || !grouped_q || !pair_slots || !act_list || !gtau || !rec_hdr || !rec_ord || !rec_id)
+    if (!g_cnt || !active || !g_qoff || !act_hoff || !grouped_q || !pair_slots || !act_list || !gtau || !rec_hdr || !rec_ord || !rec_id)
         QK_FAIL(QK_ERR_OOM, "qk_scan: workspace exhausted");
 
     QK_TRY(pe.mark(0));
@@ -2019,6 +2086,10 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
     G.n_pairs_live = scal + 7;
     G.pair_slots = pair_slots;
     G.gtau = gtau;
+    G.hot = hot;
+    G.act_hoff = hot.min > 0 ? act_hoff : nullptr;
+    G.n_hot = scal + 8;
+    G.hot_units = (long long *)(scal + 10);
     static const int no_seed = qk_env_int("QK_NO_SEED", 0);
     // (measured: for k > 64 a sample bound is far looser than the bound the pools reach by themselves -- no gain, and
     //  the 64*M-row sample costs 0.1 ms at d = 768; the wider instantiations stay available for probing)
@@ -2137,6 +2208,11 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
         sp.rl_app = rl_app;
         static const int rl_probe = qk_env_int("QK_SCAN_RL_PROBE", 0);
         sp.rl_probe = rl_probe;
+        sp.hot = hot;
+        sp.act_hoff = act_hoff;
+        sp.n_hot = scal + 8;
+        sp.hot_units = (const long long *)(scal + 10);
+        sp.hot_counter = scal + 12;  // zeroed with the counters
         sp.key_out = a.key_out;
         sp.pair_base = a.pair_base;
         sp.pair_slots = pair_slots;
@@ -2243,7 +2319,7 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
             QK_HIP(hipMemsetAsync(d_clock, 0, (size_t)grid * wpw * 64, st));
             sp.wave_clock = d_clock;
         }
-        ctx->last_scan_kernel = use_rl ? "k_scan_rl" : qshare ? "k_scan (query-sharing)" : "k_scan";
+        ctx->last_scan_kernel = use_rl ? (hot.min > 0 ? "k_scan_rl (mixed)" : "k_scan_rl") : qshare ? "k_scan (query-sharing)" : "k_scan";
         if (use_rl)
             QK_TRY(qk_launch_scan_rl(nblk, dim3((unsigned)grid), lds_launch, st, sp));
         else

@@ -39,9 +39,296 @@ __device__ __forceinline__ float4 rl_ld_nt(const float4 *p) {
 }
 __device__ __forceinline__ float f4c(const float4 &v, int t) { return t == 0 ? v.x : t == 1 ? v.y : t == 2 ? v.z : v.w; }
 
+
+// ---- hot lists: dense items on v_mfma_f32_16x16x4_f32, one workgroup per item (HOT form) --------------------------------------
+// With realistic nprobe a few lists are probed by 33 ... 600 queries of a 1024-query batch: on the bench mixture they hold 9 / 21 /
+// 32 % of the probed bytes and 57 / 78 / 89 % of the multiply-adds at nprobe 8 / 16 / 32.  The per-wave walk above serves them in
+// passes of 32 queries (one more read of the list per pass) on the 4x4x1 instruction, whose two-pass issue leaves no room to hide
+// the top-k epilogue.  Here such a list is a GEMM: an ITEM = (list, block of <= hq queries, row range).  The block's queries sit
+// in LDS ONCE for the workgroup, in B-operand order (hq / 16 query tiles, 1 KB per tile and 16 columns); the four waves take
+// different row-tile pairs of the range (A operands straight from the tile-major arena: 2 x NB float4 per lane, register
+// double-buffered) and multiply each pair with every query tile: two interleaved accumulator chains of 4 NB instructions -- the
+// same k-ordered chain as k_scan, so the same bits.  16x16x4 is an 8-pass instruction: the epilogue of the previous query tile
+// (8 keys per lane against the tile's bounds, one ballot) issues in the shadow of the next tile's chains.
+// Top-k: ONE pool per query of the block, shared by the four waves (an append takes the query's LDS spin lock; appends are rare
+// once the bound has settled, and a wave never holds two locks or waits at a barrier inside one).  At the end of the item every
+// non-empty pool leaves as a record of its (query, list) pair, exactly like a segment of the per-wave walk.
+struct HotLds {
+    float4 *sB;          // [hq/16][NB][64] query tiles, B-operand lane order
+    int64_t *pool_id;    // [hq][C]
+    uint32_t *pool_ord;  // [hq][C]
+    int *q, *pair;       // [hq] query / pair of every slot (-1: dead slot)
+    uint32_t *tau;       // [hq] running bound (key)
+    int *cnt, *lock;     // [hq] pool fill, spin lock
+    float *xn;           // [hq] |x|^2
+    int *item;           // [4] claimed item (broadcast)
+};
+__device__ __forceinline__ HotLds hot_lds(unsigned char *smem, int hq, int nb, int C) {
+    HotLds h;
+    h.sB = (float4 *)smem;
+    h.pool_id = (int64_t *)(smem + (size_t)hq * nb * 64);
+    h.pool_ord = (uint32_t *)((unsigned char *)h.pool_id + (size_t)hq * C * 8);
+    h.q = (int *)(h.pool_ord + (size_t)hq * C);
+    h.pair = h.q + hq;
+    h.tau = (uint32_t *)(h.pair + hq);
+    h.cnt = (int *)(h.tau + hq);
+    h.lock = h.cnt + hq;
+    h.xn = (float *)(h.lock + hq);
+    h.item = (int *)(h.xn + hq);
+    return h;
+}
+size_t qk_scan_hot_lds(int nblk, int C, int hq) { return (size_t)hq * ((size_t)nblk * 64 + (size_t)C * 12 + 24) + 64; }
+
+// one item; every thread of the workgroup calls it with the same arguments.  Barriers: after staging, before and after the
+// record emission.
+template <int NB, bool L2>
+__device__ __forceinline__ void rl_hot_item(const ScanParams &P, const HotLds &H, const ActiveInfo &inf, const int q0, const int nq,
+                                            const int t_lo, const int t_hi, int &dbg_app, int &dbg_comp) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int j = lane & 15, g = lane >> 4;
+    const int C = P.C, k = P.k;
+    const int QT = (nq + 15) >> 4;
+    const int size_p = inf.size;
+    const int64_t tile_p0 = inf.row_off >> 4;
+    const int npairs_t = (t_hi - t_lo + 1) >> 1;  // row-tile pairs of the range; wave w takes pairs w, w + 4, ...
+
+    float4 a0[2 * NB], a1[2 * NB];  // [tile of the pair][block]
+    float4 y0[2], y1[2];
+    longlong2 i0[4], i1[4];
+    int lp = wv;  // next pair to load
+#define HOT_LOAD(A, Y, I)                                                                                   \
+    if (lp < npairs_t) {                                                                                    \
+        const int pc_ = lp;                                                                                 \
+        _Pragma("unroll") for (int u_ = 0; u_ < 2; u_++) {                                                  \
+            const int64_t ta_ = tile_p0 + min(t_lo + 2 * pc_ + u_, t_hi - 1);                               \
+            const float4 *src_ = P.vecs + ta_ * (NB * 64) + lane;                                           \
+            _Pragma("unroll") for (int c_ = 0; c_ < NB; c_++) A[u_ * NB + c_] = rl_ld_nt(src_ + c_ * 64);   \
+            Y[u_] = ((const float4 *)(P.norms + (ta_ << 4)))[g];                                            \
+            I[2 * u_] = ((const longlong2 *)(P.ids + (ta_ << 4)))[2 * g];                                   \
+            I[2 * u_ + 1] = ((const longlong2 *)(P.ids + (ta_ << 4)))[2 * g + 1];                           \
+        }                                                                                                   \
+        lp += 4;                                                                                            \
+    }
+    HOT_LOAD(a0, y0, i0);
+
+    // ---- stage the block: query tiles in B-operand order + per-slot state, while the first pair is in flight ---------------
+    {
+        const int nslot = QT * 16;
+        for (int sl = threadIdx.x; sl < nslot; sl += 256) {
+            const bool live = sl < nq;
+            const int gi = inf.qoff + q0 + sl;
+            const int qq = live ? P.grouped_q[gi] : -1;
+            H.q[sl] = qq;
+            H.pair[sl] = live ? P.grouped_pair[gi] : -1;
+            uint32_t t0 = 0xFFFFFFFFu;
+            if (P.gtau && live) t0 = ~__hip_atomic_load(&P.gtau[qq], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            H.tau[sl] = t0;
+            H.cnt[sl] = 0;
+            H.lock[sl] = 0;
+            H.xn[sl] = (L2 && live) ? P.xn[qq] : 0.0f;
+        }
+        // float4 index i of the staged tiles = ((qt * NB + c) * 64 + g' * 16 + j'): xq4[(q * NB + c) * 4 + g']
+        const int total = QT * NB * 64;
+        for (int i = threadIdx.x; i < total; i += 256) {
+            const int jj = i & 15, gg = (i >> 4) & 3, c = (i >> 6) % NB, qt = (i >> 6) / NB;
+            const int sl = 16 * qt + jj;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (sl < nq) {
+                const int qq = P.grouped_q[inf.qoff + q0 + sl];
+                v = P.xq4[((int64_t)qq * NB + c) * 4 + gg];
+            }
+            H.sB[i] = v;
+        }
+    }
+    __syncthreads();
+
+    // ---- epilogue of one query tile: keys of this lane's 2 x 4 rows for query j of the tile ----------------------------------
+    auto keys = [&](const int qt, const f32x4 ac0, const f32x4 ac1, const int pi, const float4 *Y, uint32_t *ordv, const float xnj,
+                    const uint32_t tauj) -> bool {
+        const bool livej = 16 * qt + j < nq;
+        bool anyp = false;
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int tl = t_lo + 2 * pi + u;
+            const float yv[4] = {Y[u].x, Y[u].y, Y[u].z, Y[u].w};
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) {
+                const float v = u == 0 ? ac0[reg] : ac1[reg];
+                const uint32_t o = L2 ? ord_from_l2(l2_expanded(xnj, yv[reg], v)) : ord_from_ip(v);
+                const bool valid = livej & (tl < t_hi) & (16 * tl + 4 * g + reg < size_p);
+                ordv[4 * u + reg] = valid ? o : 0xFFFFFFFFu;
+                anyp |= valid & (o <= tauj);
+            }
+        }
+        return anyp;
+    };
+    // slow path: the lanes of column jq append under the query's lock
+    auto append = [&](const int qt, const uint32_t *ordv, const longlong2 *I, const uint64_t pm) {
+        uint32_t cols = (uint32_t)((pm | (pm >> 16) | (pm >> 32) | (pm >> 48)) & 0xFFFFull);
+        while (cols) {
+            const int jq = __ffs(cols) - 1;
+            cols &= cols - 1;
+            const int sl = 16 * qt + jq;
+            if (lane == 0) {
+                while (__hip_atomic_exchange(&H.lock[sl], 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != 0) __builtin_amdgcn_s_sleep(1);
+            }
+            __builtin_amdgcn_wave_barrier();
+            uint32_t tau = __hip_atomic_load(&H.tau[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            int cnt = __hip_atomic_load(&H.cnt[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            tau = __builtin_amdgcn_readfirstlane(tau);
+            cnt = __builtin_amdgcn_readfirstlane(cnt);
+            uint32_t *my_ord = H.pool_ord + (size_t)sl * C;
+            int64_t *my_id = H.pool_id + (size_t)sl * C;
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const bool pass = (j == jq) && ordv[e] != 0xFFFFFFFFu && ordv[e] <= tau;
+                const uint64_t m = __ballot(pass);
+                if (m) {
+                    if (pass) {
+                        const int slot = cnt + __popcll(m & ((1ull << lane) - 1ull));
+                        const longlong2 iv = I[e >> 1];
+                        my_ord[slot] = ordv[e];
+                        my_id[slot] = (e & 1) ? iv.y : iv.x;
+                    }
+                    cnt += __popcll(m);
+                    dbg_app += __popcll(m);
+                    if (cnt > C - 4) {
+                        dbg_comp++;
+                        uint32_t kth;
+                        cnt = select_pool<1>(my_ord, my_id, cnt, k, lane, kth);
+                        if (cnt >= k) {
+                            tau = min(tau, kth);
+                            if (P.gtau && P.tau_publish && lane == 0) atomicMax(&P.gtau[H.q[sl]], ~tau);
+                        }
+                    }
+                }
+            }
+            if (lane == 0) {
+                H.cnt[sl] = cnt;
+                H.tau[sl] = tau;
+                __hip_atomic_store(&H.lock[sl], 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    };
+
+#define HOT_CHAIN(A, QT_, AC0, AC1)                                                                          \
+    {                                                                                                        \
+        const float4 *bq_ = H.sB + (size_t)(QT_) * NB * 64 + lane;                                           \
+        AC0 = (f32x4){0.f, 0.f, 0.f, 0.f};                                                                   \
+        AC1 = (f32x4){0.f, 0.f, 0.f, 0.f};                                                                   \
+        _Pragma("unroll") for (int c_ = 0; c_ < NB; c_++) {                                                  \
+            const float4 b_ = bq_[c_ * 64];                                                                  \
+            AC0 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[c_].x, b_.x, AC0, 0, 0, 0);                         \
+            AC1 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[NB + c_].x, b_.x, AC1, 0, 0, 0);                    \
+            AC0 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[c_].y, b_.y, AC0, 0, 0, 0);                         \
+            AC1 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[NB + c_].y, b_.y, AC1, 0, 0, 0);                    \
+            AC0 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[c_].z, b_.z, AC0, 0, 0, 0);                         \
+            AC1 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[NB + c_].z, b_.z, AC1, 0, 0, 0);                    \
+            AC0 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[c_].w, b_.w, AC0, 0, 0, 0);                         \
+            AC1 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[NB + c_].w, b_.w, AC1, 0, 0, 0);                    \
+        }                                                                                                    \
+    }
+// all query tiles against the pair held in A: the keys of tile qt - 1 are computed after the chains of tile qt were issued
+#define HOT_PAIR(A, Y, I, PI)                                                                                \
+    {                                                                                                        \
+        f32x4 pa0_, pa1_, na0_, na1_;                                                                        \
+        HOT_CHAIN(A, 0, pa0_, pa1_);                                                                         \
+        for (int qt_ = 1; qt_ < QT; qt_++) {                                                                 \
+            const float xnj_ = H.xn[16 * (qt_ - 1) + j];                                                     \
+            const uint32_t tauj_ = H.tau[16 * (qt_ - 1) + j];                                                \
+            HOT_CHAIN(A, qt_, na0_, na1_);                                                                   \
+            uint32_t ordv_[8];                                                                               \
+            const bool anyp_ = keys(qt_ - 1, pa0_, pa1_, PI, Y, ordv_, xnj_, tauj_);                         \
+            const uint64_t pm_ = __ballot(anyp_);                                                            \
+            if (pm_) append(qt_ - 1, ordv_, I, pm_);                                                         \
+            pa0_ = na0_;                                                                                     \
+            pa1_ = na1_;                                                                                     \
+        }                                                                                                    \
+        {                                                                                                    \
+            const float xnj_ = H.xn[16 * (QT - 1) + j];                                                      \
+            const uint32_t tauj_ = H.tau[16 * (QT - 1) + j];                                                 \
+            uint32_t ordv_[8];                                                                               \
+            const bool anyp_ = keys(QT - 1, pa0_, pa1_, PI, Y, ordv_, xnj_, tauj_);                          \
+            const uint64_t pm_ = __ballot(anyp_);                                                            \
+            if (pm_) append(QT - 1, ordv_, I, pm_);                                                          \
+        }                                                                                                    \
+    }
+
+    {
+        int pi = wv;  // (the pair a0 holds, if it exists)
+        while (pi < npairs_t) {
+            HOT_LOAD(a1, y1, i1);
+            HOT_PAIR(a0, y0, i0, pi);
+            pi += 4;
+            if (pi >= npairs_t) break;
+            HOT_LOAD(a0, y0, i0);
+            HOT_PAIR(a1, y1, i1, pi);
+            pi += 4;
+        }
+    }
+#undef HOT_LOAD
+#undef HOT_CHAIN
+#undef HOT_PAIR
+
+    // ---- item end: every non-empty pool becomes a record of its pair (wave w takes slots [w * hq / 4, (w + 1) * hq / 4)) -----
+    __syncthreads();
+    {
+        const int spw = P.hot.hq >> 2;  // slots per wave (multiple of 4, <= 32)
+        const int sl = wv * spw + lane;
+        const bool own = lane < spw && sl < QT * 16;
+        int cntl = own ? H.cnt[sl] : 0;
+        uint64_t need = __ballot(cntl > 0);
+        while (need) {
+            const int sq = __ffsll((unsigned long long)need) - 1;
+            need &= need - 1;
+            const int n = __builtin_amdgcn_readlane(cntl, sq);
+            const int nn = compact_pool<1>(H.pool_ord + (size_t)(wv * spw + sq) * C, H.pool_id + (size_t)(wv * spw + sq) * C, n, k, lane);
+            if (lane == sq) cntl = nn;
+        }
+        const uint64_t have = __ballot(cntl > 0);
+        if (have) {
+            const int mypair = own ? H.pair[sl] : -1;
+            const int myq = own ? H.q[sl] : -1;
+            int slot = -1, base_rec = 0;
+            if (cntl > 0) slot = atomicAdd(&P.pair_slots[(int64_t)mypair * QK_SLOTS], 1);
+            if (lane == 0) base_rec = atomicAdd(P.rec_counter, __popcll(have));
+            const int rec0 = __builtin_amdgcn_readfirstlane(base_rec);
+            int myrec = -1;
+            if (cntl > 0) {
+                myrec = rec0 + __popcll(have & ((1ull << lane) - 1ull));
+                if (slot < QK_SLOTS - 1) P.pair_slots[(int64_t)mypair * QK_SLOTS + 1 + slot] = myrec < P.max_recs ? myrec : -1;
+                if (myrec >= P.max_recs) *P.overflow = 1;
+                if (myrec < P.max_recs) {
+                    int old = -1;
+                    if (slot >= QK_SLOTS - 1) old = atomicExch(&P.pair_head[mypair], myrec);
+                    P.rec_hdr[myrec] = make_int2(old, cntl);
+                    if (P.gtau && P.tau_publish && cntl >= k) atomicMax(&P.gtau[myq], ~H.pool_ord[(size_t)sl * C + k - 1]);
+                }
+            }
+            uint64_t todo = have;
+            while (todo) {
+                const int sq = __ffsll((unsigned long long)todo) - 1;
+                todo &= todo - 1;
+                const int n = __builtin_amdgcn_readlane(cntl, sq);
+                const int rec = __builtin_amdgcn_readlane(myrec, sq);
+                if (rec < P.max_recs)
+                    for (int e = lane; e < n; e += 64) {
+                        P.rec_ord[(int64_t)rec * k + e] = H.pool_ord[(size_t)(wv * spw + sq) * C + e];
+                        P.rec_id[(int64_t)rec * k + e] = H.pool_id[(size_t)(wv * spw + sq) * C + e];
+                    }
+            }
+        }
+    }
+    __syncthreads();
+}
+
 // NB = 16-column blocks per row (d <= 128).  One hardware workgroup = 4 independent waves (own range, own LDS, no barrier).
 // (the metric is a template parameter: as a runtime flag it left uniform branches around every result element of the epilogue)
-template <int NB, bool L2>
+// HOT: the mixed work sequence -- lists probed by >= P.hot.min queries are items of a second queue (rl_hot_item); workgroups
+// below n_hot_first start there and join the per-wave sequence's dynamic tail afterwards, the others walk their static share
+// and the tail first and take hot items when the sequence is exhausted: MFMA-bound and HBM-bound work overlap on the chip.
+template <int NB, bool L2, bool HOT>
 __global__ __launch_bounds__(256) void k_scan_rl(ScanParams P) {
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int NKK = NB * 4;        // float4 (4 consecutive columns) per padded row
@@ -70,24 +357,42 @@ __global__ __launch_bounds__(256) void k_scan_rl(ScanParams P) {
     // others are in MFMA-bound passes)
     const long long T = *P.n_tiles;
     const int PK = P.pack;  // waves per hardware workgroup (4: one per SIMD; 3 when a wider pass needs the LDS)
-    const long long W = (long long)gridDim.x * PK;
-    const long long vblock = (long long)blockIdx.x * PK + wvp;
     const bool dyn = P.dyn_counter != nullptr;
     const long long Ts = dyn ? T - (T * P.dyn_pct) / 100 : T;
-    long long T0 = (Ts * vblock) / W, T1 = (Ts * (vblock + 1)) / W;
-    if (P.xcd_on) {
-        long long pre[9];
-        pre[0] = 0;
-#pragma unroll
-        for (int i = 0; i < 8; i++) pre[i + 1] = pre[i] + P.xcd_w[i];
-        const long long u = blockIdx.x, gu = gridDim.x;
-        const long long total = ((gu >> 3) * pre[8] + pre[gu & 7]) * PK;
-        const long long a0 = ((u >> 3) * pre[8] + pre[u & 7]) * PK + (long long)P.xcd_w[u & 7] * wvp;
-        const long long a1 = a0 + P.xcd_w[u & 7];
-        T0 = a0 <= 0 ? 0 : (long long)((double)Ts * (double)a0 / (double)total);
-        T1 = a1 >= total ? Ts : (long long)((double)Ts * (double)a1 / (double)total);
+    // hot-first workgroups: their share of the grid = the hot items' share of the launch's cost (multiple of 8: whole rounds
+    // over the XCDs); they take no static share of the per-wave sequence
+    int n_hot = 0, n_hot_first = 0;
+    if (HOT) {
+        n_hot = *P.n_hot;
+        if (n_hot > 0 && dyn && gridDim.x >= 16) {
+            const double hu = (double)*P.hot_units;
+            n_hot_first = ((int)((double)gridDim.x * hu / (hu + (double)T + 1.0) + 4.0)) & ~7;
+            n_hot_first = max(0, min(n_hot_first, ((int)gridDim.x - 8) & ~7));
+        }
     }
-    if (!dyn && T1 <= T0) return;
+    const bool hot_first = HOT && (int)blockIdx.x < n_hot_first;
+    const long long gu = (long long)gridDim.x - n_hot_first;   // workgroups that cut the static share
+    const long long u = (long long)blockIdx.x - n_hot_first;   // (n_hot_first is a multiple of 8: u % 8 is still the XCD class)
+    const long long W = gu * PK;
+    const long long vblock = (long long)blockIdx.x * PK + wvp;
+    const long long vb_c = u * PK + wvp;
+    long long T0 = 0, T1 = 0;
+    if (!hot_first) {
+        T0 = (Ts * vb_c) / W;
+        T1 = (Ts * (vb_c + 1)) / W;
+        if (P.xcd_on) {
+            long long pre[9];
+            pre[0] = 0;
+#pragma unroll
+            for (int i = 0; i < 8; i++) pre[i + 1] = pre[i] + P.xcd_w[i];
+            const long long total = ((gu >> 3) * pre[8] + pre[gu & 7]) * PK;
+            const long long a0 = ((u >> 3) * pre[8] + pre[u & 7]) * PK + (long long)P.xcd_w[u & 7] * wvp;
+            const long long a1 = a0 + P.xcd_w[u & 7];
+            T0 = a0 <= 0 ? 0 : (long long)((double)Ts * (double)a0 / (double)total);
+            T1 = a1 >= total ? Ts : (long long)((double)Ts * (double)a1 / (double)total);
+        }
+    }
+    if (!HOT && !dyn && T1 <= T0) return;
     const long long wc0 = (P.xcd_stat || P.wave_clock) ? wall_clock64() : 0;
     const long long cy0 = P.wave_clock ? clock64() : 0;
     int dbg_comp = 0, dbg_app = 0, dbg_seg = 0;  // probe counters (QK_SCAN_WAVE_CLOCK)
@@ -95,6 +400,50 @@ __global__ __launch_bounds__(256) void k_scan_rl(ScanParams P) {
     const RlCost rc{P.rl_h0, P.rl_h1, P.rl_e, P.seg_ovh, P.rl_m, QB};
     const int n_active = *P.n_active;
     long long xcd_ticks = 0;  // time spent on the static share (what the XCD balance learns from)
+    for (int ph = 0; ph < (HOT ? 2 : 1); ph++) {
+    if (HOT && ((ph == 0) == hot_first)) {
+        // ---- hot items: the whole workgroup, one item at a time from the queue --------------------------------------------
+        if (n_hot <= 0) continue;
+        if (!hot_first) __syncthreads();  // every wave has left the per-wave sequence (and its slice of the LDS)
+        const HotLds H = hot_lds(smem, P.hot.hq, NB, C);
+        for (;;) {
+            if (threadIdx.x == 0) H.item[0] = atomicAdd(P.hot_counter, 1);
+            __syncthreads();
+            const int item = H.item[0];
+            if (item >= n_hot) {
+                __syncthreads();  // (the word sits in a wave's slice of the per-wave form)
+                break;
+            }
+            // 64-ary search: act_hoff[lo] <= item < act_hoff[lo + 1]
+            int lo = 0, hi = n_active;
+            while (hi - lo > 1) {
+                const int span = hi - lo;
+                const int step = (span + 63) >> 6;
+                const int probe = min(lo + (lane + 1) * step, hi);
+                const bool gt = (probe >= hi) || (P.act_hoff[probe] > item);
+                const uint64_t m = __ballot(gt);
+                const int first = __ffsll((unsigned long long)m) - 1;
+                const int nlo = min(lo + first * step, hi - 1);
+                const int nhi = min(lo + (first + 1) * step, hi);
+                lo = nlo;
+                hi = nhi;
+            }
+            const ActiveInfo inf = P.active[lo];
+            const HotShape hs = hot_shape(inf.cnt, inf.size, P.hot);
+            const int local = item - P.act_hoff[lo];
+            const int qb = local / hs.nrr, rr = local - qb * hs.nrr;
+            const int q0 = qb * hs.qpb, nq = min(hs.qpb, inf.cnt - q0);
+            const int ntl = (inf.size + 15) >> 4;
+            const int t_lo = (int)(((long long)ntl * rr) / hs.nrr), t_hi = (int)(((long long)ntl * (rr + 1)) / hs.nrr);
+            if (nq <= 0 || t_hi <= t_lo) {
+                __syncthreads();
+                continue;
+            }
+            dbg_seg++;
+            rl_hot_item<NB, L2>(P, H, inf, q0, nq, t_lo, t_hi, dbg_app, dbg_comp);
+        }
+        continue;
+    }
     for (;;) {
     if (T1 > T0) {
     // 64-ary search for the partition that holds unit T0: active[lo].toff <= T0 < active[lo+1].toff
@@ -118,6 +467,10 @@ __global__ __launch_bounds__(256) void k_scan_rl(ScanParams P) {
         // ---- segment = chunks [ch0, ch1) of pass b over partition active[ai] ---------------------------------------------
         const ActiveInfo inf = P.active[ai];
         const int size_p = inf.size, cnt_p = inf.cnt;
+        if (HOT && P.hot.min > 0 && cnt_p >= P.hot.min) {  // a hot list: no units in this sequence (rl_hot_item)
+            ai++;
+            continue;
+        }
         const int nch = (size_p + 63) >> 6, ntl = (size_p + 15) >> 4;
         const int nqb = (cnt_p + QB - 1) / QB;
         const int g_last = (cnt_p - QB * (nqb - 1) + 3) >> 2;
@@ -390,7 +743,8 @@ __global__ __launch_bounds__(256) void k_scan_rl(ScanParams P) {
         if (T0 >= T) break;
         T1 = min(T, T0 + chunk);
     }
-    if (P.xcd_stat && lane == 0) {
+    }  // phase
+    if (P.xcd_stat && lane == 0 && !hot_first) {
         atomicAdd(&P.xcd_stat[blockIdx.x & 7], (unsigned long long)(xcd_ticks ? xcd_ticks : wall_clock64() - wc0));
         atomicAdd(&P.xcd_stat[8 + (blockIdx.x & 7)], 1ull);
     }
@@ -414,11 +768,16 @@ size_t qk_scan_rl_lds_per_wave(int nblk, int C, int qb) {
     return (size_t)(qb / 4) * nblk * 64 * 4 + (size_t)qb * C * 12 + (size_t)qb * 4 * 5;
 }
 
+template <int NB, bool L2, bool HOT>
+static int launch_rl_h(dim3 grid, size_t lds, hipStream_t st, const ScanParams &sp) {
+    QK_HIP(hipFuncSetAttribute((const void *)k_scan_rl<NB, L2, HOT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_scan_rl<NB, L2, HOT>), grid, dim3(64 * sp.pack), lds, st, sp);
+    return QK_OK;
+}
 template <int NB, bool L2>
 static int launch_rl_m(dim3 grid, size_t lds, hipStream_t st, const ScanParams &sp) {
-    QK_HIP(hipFuncSetAttribute((const void *)k_scan_rl<NB, L2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((k_scan_rl<NB, L2>), grid, dim3(64 * sp.pack), lds, st, sp);
-    return QK_OK;
+    // (the mixed form needs whole workgroups of four waves and the LDS of all four slices)
+    return sp.hot.min > 0 ? launch_rl_h<NB, L2, true>(grid, lds, st, sp) : launch_rl_h<NB, L2, false>(grid, lds, st, sp);
 }
 template <int NB>
 static int launch_rl_t(dim3 grid, size_t lds, hipStream_t st, const ScanParams &sp) {
@@ -428,6 +787,7 @@ static int launch_rl_t(dim3 grid, size_t lds, hipStream_t st, const ScanParams &
 // grid = hardware workgroups of sp.pack independent waves; lds = sp.pack x sp.pack_lds
 int qk_launch_scan_rl(int nblk, dim3 grid, size_t lds, hipStream_t st, const ScanParams &sp) {
     switch (nblk) {
+#ifndef QK_RL_DEV  // (development builds instantiate d = 128 only: this file is five minutes of hipcc otherwise)
         case 1: return launch_rl_t<1>(grid, lds, st, sp);
         case 2: return launch_rl_t<2>(grid, lds, st, sp);
         case 3: return launch_rl_t<3>(grid, lds, st, sp);
@@ -435,6 +795,7 @@ int qk_launch_scan_rl(int nblk, dim3 grid, size_t lds, hipStream_t st, const Sca
         case 5: return launch_rl_t<5>(grid, lds, st, sp);
         case 6: return launch_rl_t<6>(grid, lds, st, sp);
         case 7: return launch_rl_t<7>(grid, lds, st, sp);
+#endif
         case 8: return launch_rl_t<8>(grid, lds, st, sp);
     }
     QK_FAIL(QK_ERR_UNSUPPORTED, "row-per-lane scan: d > 128 (nblk=%d)", nblk);

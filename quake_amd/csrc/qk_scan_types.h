@@ -16,6 +16,48 @@ struct __align__(16) ActiveInfo {
     int qoff;           // offset of its group in grouped_q / grouped_pair
 };
 
+// ---- hot lists (qk_scan_rl.hip, HOT form) -----------------------------------------------------------------------------------
+// A list probed by cnt >= min queries of the batch is MFMA-bound whatever form scans it: it leaves the
+// per-wave sequence and becomes nqblk x nrr items -- query block b of <= hq queries (hq / 16 query tiles of
+// v_mfma_f32_16x16x4_f32 staged in LDS in B-operand order, shared by the four waves of a workgroup) x row range r -- sized to
+// about `unit` (row tile x query tile) products each, so that the queue of items stays fine-grained next to a ~0.4 ms launch.
+constexpr int QK_HOT_NRR_MAX = 16;  // most row ranges a (list, query block) is cut into: bounds the records of a hot pair
+struct HotCost {
+    int min;    // lists with cnt >= min are hot (0: none)
+    int hq;     // queries per block: multiple of 16, <= 128, what the workgroup's LDS holds (queries + pools)
+    int unit;   // (row tile x query tile) products per item
+    int w10;    // cost of one such product in tenths of a per-wave sequence unit (all four waves busy)
+    int ovh;    // cost of starting an item (staging the block's queries, emitting its records), per-wave sequence units
+};
+struct HotShape {
+    int nqblk, qpb, nrr;  // query blocks, queries per block (multiple of 16), row ranges
+};
+__host__ __device__ inline HotShape hot_shape(int cnt, int size, const HotCost &h) {
+    HotShape s;
+    const int ntl = (size + 15) >> 4;
+    s.nqblk = (cnt + h.hq - 1) / h.hq;
+    s.qpb = (((cnt + s.nqblk - 1) / s.nqblk) + 15) & ~15;
+    const long long prod = (long long)ntl * (s.qpb >> 4);
+    long long nrr = (prod + h.unit / 2) / h.unit;
+    const long long cap = ntl / 2 > 1 ? ntl / 2 : 1;  // a range holds at least two row tiles
+    if (nrr > cap) nrr = cap;
+    if (nrr < 1) nrr = 1;
+    if (nrr > QK_HOT_NRR_MAX) nrr = QK_HOT_NRR_MAX;
+    s.nrr = (int)nrr;
+    return s;
+}
+__host__ __device__ inline long long hot_units_of(int cnt, int size, const HotCost &h) {
+    const HotShape s = hot_shape(cnt, size, h);
+    const long long ntl = (size + 15) >> 4;
+    long long u = 0;
+    for (int b = 0; b < s.nqblk; b++) {
+        const int nq = cnt - b * s.qpb < s.qpb ? cnt - b * s.qpb : s.qpb;
+        if (nq <= 0) break;
+        u += (long long)s.nrr * h.ovh + (ntl * ((nq + 15) >> 4) * h.w10 + 9) / 10;
+    }
+    return u;
+}
+
 struct ScanParams {
     const float4 *vecs;
     const float *norms;
@@ -69,6 +111,13 @@ struct ScanParams {
     int rl_h0, rl_h1, rl_e, rl_m;  // cost model of the work sequence (RlCost; ovh = seg_ovh)
     int rl_qb, rl_app;       // queries per pass; lanes per append round (32: pools of k + 32 entries, 16: k + 16)
     int rl_probe;            // probe (QK_SCAN_RL_PROBE): bit 0 = no top-k epilogue, bit 1 = no MFMA chains (attribution only; uniform branches OUTSIDE the chain)
+    // hot lists of the mixed work sequence (k_scan_rl<.., HOT = true>): lists probed by >= hot.min queries are not part of the
+    // per-wave sequence; they are cut into ITEMS (query block x row range) that whole workgroups claim from a second queue
+    HotCost hot;
+    const int32_t *act_hoff;      // [n_active + 1] hot items in front of every active list (sentinel: the total)
+    const int32_t *n_hot;         // [1] hot items of the launch
+    const long long *hot_units;   // [1] their cost in units of the per-wave sequence
+    int32_t *hot_counter;         // [1] next hot item to hand out (zeroed per call)
 };
 
 // ---- row-per-lane scan (qk_scan_rl.hip): cost model of the work sequence ----------------------------------------------------

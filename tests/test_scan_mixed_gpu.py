@@ -1,0 +1,145 @@
+"""The mixed work sequence of the row-per-lane scan (qk_scan_rl.hip, HOT form): lists probed by >= 33 queries of the batch
+are scanned as dense workgroup items on v_mfma_f32_16x16x4_f32, the others by the per-wave walk -- one launch, one record
+format, the same bits as the oracle's batched path (query_coordinator.cpp:675-799, list_scanning.h:313-366)."""
+import numpy as np
+import pytest
+
+import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from quake_amd.capi import Context
+    c = Context(0)
+    yield c
+    c.close()
+
+
+def make_sized_ivf(sizes, d, seed, metric="l2", integer=False):
+    """lists of the given sizes: Gaussian blobs around random centres (or SIFT-like integers: exact ties)"""
+    rng = np.random.default_rng(seed)
+    nlist = len(sizes)
+    if integer:
+        cent = rng.integers(0, 40, size=(nlist, d)).astype(np.float32)
+    else:
+        cent = rng.standard_normal((nlist, d)).astype(np.float32)
+    vecs, offsets = [], np.zeros(nlist + 1, np.int64)
+    for p, n in enumerate(sizes):
+        if integer:
+            v = cent[p] + rng.integers(-3, 4, size=(n, d)).astype(np.float32)
+        else:
+            v = (cent[p] + 0.5 * rng.standard_normal((n, d))).astype(np.float32)
+        vecs.append(v)
+        offsets[p + 1] = offsets[p] + n
+    x = np.ascontiguousarray(np.concatenate(vecs, 0), np.float32)
+    if metric == "ip":
+        x /= np.maximum(np.linalg.norm(x, axis=1, keepdims=True), 1e-6)
+    ids = rng.permutation(x.shape[0]).astype(np.int64) + 1000
+    return dict(vecs=x, ids=ids, offsets=offsets, centroids=cent, d=d, nlist=nlist)
+
+
+def build(ctx, ivf):
+    from quake_amd.capi import Store
+    s = Store(ctx, ivf["d"])
+    s.build_csr(ivf["offsets"], ivf["ids"], ivf["vecs"])
+    return s
+
+
+def skewed_pids(Q, P, nlist, hot, rng):
+    """[Q, P] list numbers without repeats inside a row: list h of `hot` = {list: cnt} is probed by exactly cnt queries"""
+    pids = np.full((Q, P), -1, np.int64)
+    fill = np.zeros(Q, np.int64)
+    for p, cnt in hot.items():
+        rows = rng.permutation(Q)[:cnt]
+        for r in rows:
+            if fill[r] < P:
+                pids[r, fill[r]] = p
+                fill[r] += 1
+    cold = np.array([p for p in range(nlist) if p not in hot])
+    for r in range(Q):
+        need = P - fill[r]
+        if need > 0:
+            pids[r, fill[r]:] = rng.choice(cold, size=need, replace=False)
+    return pids
+
+
+def check(ctx, s, ivf, q, pids, k, metric, want_form="k_scan_rl (mixed)"):
+    gi, gd = ctx.scan(s, q, pids, k, metric)
+    assert ctx.last_scan_kernel() == want_form
+    oi, od = O.batched_serial_scan(q, ivf["vecs"], ivf["ids"], ivf["offsets"], pids, k, metric)
+    np.testing.assert_array_equal(gi, oi)
+    np.testing.assert_array_equal(gd.view(np.uint32), od.view(np.uint32))
+
+
+@pytest.mark.parametrize("metric", ["l2", "ip"])
+@pytest.mark.parametrize("d,k", [(128, 10), (100, 32), (32, 1), (64, 17)])
+def test_hot_and_cold_lists_one_launch(ctx, metric, d, k):
+    rng = np.random.default_rng(11)
+    nlist = 1500
+    sizes = rng.integers(0, 120, size=nlist)
+    # hot lists of every shape: many row ranges, one tile, a ragged last tile, fewer rows than k, a single row
+    sizes[:8] = [6000, 1300, 17, 16, 5, 1, 2500, 331]
+    ivf = make_sized_ivf(sizes, d, seed=12, metric=metric)
+    s = build(ctx, ivf)
+    Q, P = 700, 6
+    q = ivf["vecs"][rng.integers(0, ivf["vecs"].shape[0], size=Q)] + 0.1 * rng.standard_normal((Q, d)).astype(np.float32)
+    q = np.ascontiguousarray(q, np.float32)
+    # 700 queries on list 0 (6 blocks), 130 on list 1 (80 + 50), 33 / 32 around the threshold, 129, 257, 48, 64
+    hot = {0: 700, 1: 130, 2: 33, 3: 32, 4: 129, 5: 257, 6: 48, 7: 64}
+    pids = skewed_pids(Q, P, nlist, hot, rng)
+    pids[::9, -1] = -1
+    check(ctx, s, ivf, q, pids, k, metric)
+    s.close()
+
+
+def test_hot_lists_with_exact_ties(ctx):
+    """SIFT-like integer data: exact distance ties across the waves of an item and across items -> the (key, id) order"""
+    rng = np.random.default_rng(21)
+    nlist = 1200
+    sizes = rng.integers(1, 80, size=nlist)
+    sizes[:3] = [3000, 900, 64]
+    ivf = make_sized_ivf(sizes, 128, seed=22, integer=True)
+    s = build(ctx, ivf)
+    Q, P = 512, 8
+    q = ivf["vecs"][rng.integers(0, 3964, size=Q)] + rng.integers(-2, 3, size=(Q, 128)).astype(np.float32)
+    q = np.ascontiguousarray(q, np.float32)
+    pids = skewed_pids(Q, P, nlist, {0: 512, 1: 200, 2: 40}, rng)
+    for k in (10, 24):  # (d = 128 with k = 32: the per-wave form's LDS does not fit, k_scan serves it)
+        check(ctx, s, ivf, q, pids, k, "l2")
+    s.close()
+
+
+def test_every_list_hot_and_none(ctx):
+    rng = np.random.default_rng(31)
+    nlist = 1100
+    sizes = rng.integers(1, 60, size=nlist)
+    sizes[:4] = [2000, 1000, 500, 250]
+    ivf = make_sized_ivf(sizes, 128, seed=32)
+    s = build(ctx, ivf)
+    Q = 600
+    q = np.ascontiguousarray(ivf["vecs"][rng.integers(0, 3750, size=Q)] + 0.1 * rng.standard_normal((Q, 128)).astype(np.float32))
+    # every pair lands on a hot list: the per-wave sequence is empty
+    pids = np.tile(np.array([0, 1, 2, 3], np.int64), (Q, 1))
+    check(ctx, s, ivf, q, pids, 10, "l2")
+    # nobody shares a list with more than 32 others: no hot item at all, the same kernel
+    pids = np.stack([rng.choice(np.arange(4, nlist), size=4, replace=False) for _ in range(Q)]).astype(np.int64)
+    check(ctx, s, ivf, q, pids, 10, "l2")
+    s.close()
+
+
+def test_repeated_calls_reuse_counters(ctx):
+    """the hot queue's counter lives in the per-call zeroed state: a second and third call must start from item 0"""
+    rng = np.random.default_rng(41)
+    nlist = 1100
+    sizes = rng.integers(1, 60, size=nlist)
+    sizes[:2] = [4000, 700]
+    ivf = make_sized_ivf(sizes, 64, seed=42)
+    s = build(ctx, ivf)
+    Q = 520
+    q = np.ascontiguousarray(ivf["vecs"][rng.integers(0, 4700, size=Q)] + 0.1 * rng.standard_normal((Q, 64)).astype(np.float32))
+    for it in range(3):
+        pids = skewed_pids(Q, 4, nlist, {0: 520 - 40 * it, 1: 100 + it}, rng)
+        check(ctx, s, ivf, q, pids, 10, "l2")
+    s.close()
