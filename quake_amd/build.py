@@ -34,16 +34,20 @@ def _stale(out, deps):
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
-def build_lib(force=False, verbose=False):
+def build_lib(force=False, verbose=False, variant=None, extra_flags=()):
+    """variant: a side build (objects under build/<variant>, library lib/libquake_hip_<variant>.so, selected at run time with
+    QUAKE_HIP_LIB) with extra_flags on top of the product flags -- the probe / development builds of scripts/."""
     os.makedirs(LIBDIR, exist_ok=True)
-    objdir = os.path.join(HERE, "build")
+    objdir = os.path.join(HERE, "build", variant) if variant else os.path.join(HERE, "build")
+    lib = os.path.join(LIBDIR, f"libquake_hip_{variant}.so") if variant else LIB
+    flags = FLAGS + list(extra_flags)
     os.makedirs(objdir, exist_ok=True)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers.append(os.path.join(os.path.dirname(HERE), "include", "quake_hip.h"))
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     # a change of flags (product <-> probe build) rebuilds everything
     flag_file = os.path.join(objdir, "flags.txt")
-    flag_text = " ".join(FLAGS)
+    flag_text = " ".join(flags)
     if not os.path.exists(flag_file) or open(flag_file).read() != flag_text:
         force = True
     objs = []
@@ -53,7 +57,7 @@ def build_lib(force=False, verbose=False):
         obj = os.path.join(objdir, s.replace(".hip", ".o"))
         objs.append(obj)
         if force or _stale(obj, [src] + headers):
-            jobs.append([HIPCC] + FLAGS + ["-c", src, "-o", obj])
+            jobs.append([HIPCC] + flags + ["-c", src, "-o", obj])
     if jobs:
         with cf.ThreadPoolExecutor(max_workers=min(len(jobs), 6)) as ex:
             for cmd, res in zip(jobs, ex.map(lambda c: subprocess.run(c, capture_output=True, text=True), jobs)):
@@ -61,16 +65,21 @@ def build_lib(force=False, verbose=False):
                     sys.stderr.write(" ".join(cmd) + "\n" + res.stdout + res.stderr)
                 if res.returncode != 0:
                     raise RuntimeError("hipcc failed for " + cmd[-3])
-    if jobs or force or _stale(LIB, objs):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    if jobs or force or _stale(lib, objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs
         res = subprocess.run(cmd, capture_output=True, text=True)
         if res.returncode != 0:
             sys.stderr.write(res.stdout + res.stderr)
             raise RuntimeError("link failed")
         with open(flag_file, "w") as f:
             f.write(flag_text)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":
-    print(build_lib(force="--force" in sys.argv, verbose=True))
+    if "--probe" in sys.argv:  # tuning build: QK_* environment switches compiled in, row-per-lane scan for d = 128 only
+        # (QK_VARIANT / QK_EXTRA_FLAGS: a second side build with other -D switches, for A/B runs in one box visit)
+        print(build_lib(force="--force" in sys.argv, verbose=True, variant=os.environ.get("QK_VARIANT", "probe"),
+                        extra_flags=["-DQK_PROBES", "-DQK_RL_DEV"] + os.environ.get("QK_EXTRA_FLAGS", "").split()))
+    else:
+        print(build_lib(force="--force" in sys.argv, verbose=True))

@@ -1929,18 +1929,42 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
     // Mixed work sequence (qk_scan_rl.hip, HOT form): lists probed by >= hot.min queries of the batch become dense items on
     // v_mfma_f32_16x16x4_f32 claimed by whole workgroups; the block width hq is what the workgroup's LDS (the four waves' slices
     // of the per-wave form together) holds next to one pool of C entries per query.
-    HotCost hot{0, 0, 0, 0, 0};
-    if (use_rl && rl_waves == 4) {
-        static const int hot_min = qk_env_int("QK_SCAN_HOT_MIN", 33);   // 0: per-wave walk only
-        static const int hot_unit = qk_env_int("QK_SCAN_HOT_UNIT", 256);
-        static const int hot_w10 = qk_env_int("QK_SCAN_HOT_W10", 12);
+    HotCost hot{0, 0, 0, 0, 0, 0, 0};
+    {
+        // Measured (10M x 128, 1024 queries, k = 10, scripts/nprobe_sweep.py; kernel ms per-wave walk alone -> mixed, lists with
+        // >= 13 probing queries hot): skewed mixture nprobe 8 / 16 / 32 / 64: 0.461 / 0.623 / 1.027 / 1.808 -> 0.474 / 0.512 / 0.632 /
+        // 0.878; uniformly probed corpus nprobe 8 / 16 / 32 / 64: 0.683 / 0.798 / 0.960 / 1.002 -> 0.686 / 0.827 / 0.841 / 1.048 (the
+        // query-sharing form of k_scan, which used to take over from 6 probing queries per list on: 1.019 / 1.177 at nprobe 32 / 64).
+        // At nprobe 2 / 4 (under two probing queries per list on average) the few hot lists are home lists -- every other row tile
+        // has a true candidate -- and the items only add their fixed costs: 0.344 / 0.382 -> 0.413 / 0.447; the hot form stays off.
+        static const int hot_min = qk_env_int("QK_SCAN_HOT_MIN", 13);   // 0: per-wave walk only
+        static const int hot_unit = qk_env_int("QK_SCAN_HOT_UNIT", 300);
+        static const int hot_w10 = qk_env_int("QK_SCAN_HOT_W10", 3);
+        static const int hot_ht10 = qk_env_int("QK_SCAN_HOT_HT10", 30);
         static const int hot_ovh = qk_env_int("QK_SCAN_HOT_OVH", 64);
         static const int hot_hq = qk_env_int("QK_SCAN_HOT_HQ", 128);
-        const size_t per_wave = std::max<size_t>((qk_scan_rl_lds_per_wave(nblk, C, rlc.qb) + 15) & ~(size_t)15, (size_t)(160 * 1024) / 4 - 512) & ~(size_t)15;
-        int hq = std::min(128, std::max(16, hot_hq)) & ~15;
-        while (hq >= 32 && qk_scan_hot_lds(nblk, C, hq) > 4 * per_wave) hq -= 16;
-        if (hot_min > 0 && hq >= 32 && npairs >= 1024)
-            hot = HotCost{std::max(hot_min, 17), hq, std::max(16, hot_unit), std::max(1, hot_w10), std::max(0, hot_ovh)};
+        static const int hot_per_list = qk_env_int("QK_SCAN_HOT_PER_LIST", 2);
+        static const int rl_env2 = qk_env_int("QK_SCAN_RL", -1);
+        const bool rl_possible = nblk <= 8 && k <= 32 && rl_waves == 4 && rlc.qb == 32 && !a.per_pair && !emit && npairs >= 1024 && P > 1 &&
+                                 ctx->qprep_xp4 != nullptr && a.xq4 == (const float4 *)ctx->qprep && rl_env2 != 0 &&
+                                 4 * ((qk_scan_rl_lds_per_wave(nblk, std::min(64, qk_round_up(k + 32, 4)), rlc.qb) + 15) & ~(size_t)15) <= (size_t)160 * 1024;
+        if (rl_possible && hot_min > 0 && rl_per_list >= hot_per_list) {
+            const int C_rl2 = std::min(64, qk_round_up(k + 32, 4));
+            const size_t per_wave = std::max<size_t>((qk_scan_rl_lds_per_wave(nblk, C_rl2, rlc.qb) + 15) & ~(size_t)15, (size_t)(160 * 1024) / 4 - 512) & ~(size_t)15;
+            // (pools of k + 22 entries: appends come four at a time at most, and a block's pools share the LDS with its query
+            //  tiles in fp32 and in bf16)
+            const int C_hot = std::min(64, qk_round_up(k + 22, 4));
+            int hq = std::min(128, std::max(16, hot_hq)) & ~15;
+            while (hq >= 32 && qk_scan_hot_lds(nblk, C_hot, hq) > 4 * per_wave) hq -= 16;
+            if (hq >= 32) {
+                hot = HotCost{std::max(hot_min, 1), hq, std::max(16, hot_unit), std::max(1, hot_w10), std::max(1, hot_ht10), std::max(0, hot_ovh), C_hot};
+                // the mixed form serves every sharing level: it replaces the query-sharing form of k_scan too
+                use_rl = true;
+                nw = 1;
+                qshare = 0;
+                C = C_rl2;
+            }
+        }
     }
     const int maxch = pick_maxch(C);
     const size_t lds_scan = use_rl ? ((qk_scan_rl_lds_per_wave(nblk, C, rlc.qb) + 15) & ~(size_t)15)
@@ -1993,7 +2017,7 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
     // (row-per-lane form: a segment emits one record per live query of its pass; every range boundary inside a pass adds at
     //  most rlc.qb records)
     // (hot lists: a pair leaves one record per row range of its list, at most QK_HOT_NRR_MAX)
-    const int64_t hot_recs = hot.min > 0 ? npairs * std::min<int64_t>(QK_HOT_NRR_MAX, (((std::max<int64_t>(1, s->max_size) + 15) / 16) * (hot.hq / 16)) / hot.unit + 1) : 0;
+    const int64_t hot_recs = hot.min > 0 ? npairs * std::min<int64_t>(QK_HOT_NRR_MAX, hot_block_cost((int)((std::max<int64_t>(1, s->max_size) + 15) / 16), hot.hq / 16, hot) / hot.unit + 1) : 0;
     const int64_t max_recs = use_rl ? std::min<int64_t>(0x7FFFFFF0LL, npairs + hot_recs + (int64_t)rlc.qb * (n_waves + QK_RL_DYN_MAX + 2))
                                     : std::min<int64_t>(0x7FFFFFF0LL, nw * std::min<int64_t>(16 * (items_bound + seg_starts), npairs + 16 * seg_starts));
 
@@ -2316,7 +2340,7 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
         sp.wave_clock = nullptr;
         if (probe_clock) {
             if (!d_clock) QK_HIP(hipMalloc((void **)&d_clock, (size_t)1 << 20));
-            QK_HIP(hipMemsetAsync(d_clock, 0, (size_t)grid * wpw * 64, st));
+            QK_HIP(hipMemsetAsync(d_clock, 0, (size_t)grid * wpw * 64 * 2, st));
             sp.wave_clock = d_clock;
         }
         ctx->last_scan_kernel = use_rl ? (hot.min > 0 ? "k_scan_rl (mixed)" : "k_scan_rl") : qshare ? "k_scan (query-sharing)" : "k_scan";
@@ -2408,6 +2432,19 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
                 sum += (double)(h[8 * i + 1] - t0);
             }
             std::sort(ws.begin(), ws.end(), [](const W &a, const W &b) { return a.end < b.end; });
+            if (use_rl && hot.min > 0) {  // mixed sequence: phases of the hot items (second half of the probe buffer)
+                std::vector<long long> hh((size_t)grid * wpw * 8);
+                QK_HIP(hipMemcpy(hh.data(), d_clock + (size_t)grid * wpw * 8, hh.size() * 8, hipMemcpyDeviceToHost));
+                double t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, nf = 0;
+                for (size_t i = 0; i < (size_t)grid * wpw; i++) {
+                    for (int c = 0; c < 8; c++) t[c] += (double)hh[8 * i + c];
+                }
+                fprintf(stderr, "[k_scan_rl prefilter] %.0f row-tile x query-tile products tested, %.0f recomputed exactly (%.3f)\n", t[6], t[7], t[7] / std::max(1.0, t[6]));
+                const double ni = std::max(1.0, t[5]);
+                fprintf(stderr, "[k_scan_rl hot] items per wave %.1f (hot-first waves %.0f); ticks per item and wave: staging %.0f, chains+keys+appends %.0f, "
+                        "wait for the workgroup %.0f, emission %.0f, whole item %.0f; hot share of the wave time %.2f\n",
+                        t[5] / (grid * wpw), nf, t[0] / ni, t[1] / ni, t[2] / ni, t[3] / ni, t[4] / ni, t[4] / std::max(1.0, sum));
+            }
             if (use_rl) {  // row-per-lane form: field 5 = shader cycles, field 6 = MFMA loop steps
                 double cyc = 0, tk = 0, steps = 0;
                 for (size_t i = 0; i < nwv; i++) {

@@ -53,8 +53,22 @@ __device__ __forceinline__ float f4c(const float4 &v, int t) { return t == 0 ? v
 // Top-k: ONE pool per query of the block, shared by the four waves (an append takes the query's LDS spin lock; appends are rare
 // once the bound has settled, and a wave never holds two locks or waits at a barrier inside one).  At the end of the item every
 // non-empty pool leaves as a record of its (query, list) pair, exactly like a segment of the per-wave walk.
+//
+// PREFILTER.  Every (row tile pair, query tile) product is first computed on v_mfma_f32_16x16x32_bf16 -- the same fragments
+// rounded to bf16, 16x the fp32 rate -- and only when some lane's APPROXIMATE key could beat its query's bound does the pair
+// run the exact fp32 chains.  The test is one-sided and rigorous: with x~ = bf16(x), y~ = bf16(y) (round to nearest: relative
+// error <= 2^-9 each) |x~.y~ - x.y| <= (2^-8 + 2^-18) sum|x_i y_i| <= (2^-8 + 2^-18) (|x|^2 + |y|^2) / 2, the fp32
+// accumulation of either path adds less than 2^-16 of that, so with c = 2^-8 * 17/16 + 2^-21
+//     L2:  d2_exact >= (|x|^2 + |y|^2)(1 - c) - 2 x~.y~        IP:  x.y <= x~.y~ + c (|x|^2 + |y|^2) / 2
+// and a candidate whose bound already loses against the running k-th key cannot enter the top-k.  Everything that IS appended
+// went through the exact chain, so ids and distance bits are those of the unfiltered scan; the k-order of the bf16
+// instruction is free, so its operands are the fp32 fragments converted in place (no second layout).
+constexpr float QK_PF_C = 0.0041509f;   // >= 2^-8 * 17/16 + 2^-21
+constexpr float QK_PF_K1 = 0.995849f;   // <= 1 - QK_PF_C
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 struct HotLds {
     float4 *sB;          // [hq/16][NB][64] query tiles, B-operand lane order
+    uint4 *sBh;          // [hq/16][(NB+1)/2][64] the same tiles in bf16: 8 values per lane and 32-column step
     int64_t *pool_id;    // [hq][C]
     uint32_t *pool_ord;  // [hq][C]
     int *q, *pair;       // [hq] query / pair of every slot (-1: dead slot)
@@ -66,7 +80,8 @@ struct HotLds {
 __device__ __forceinline__ HotLds hot_lds(unsigned char *smem, int hq, int nb, int C) {
     HotLds h;
     h.sB = (float4 *)smem;
-    h.pool_id = (int64_t *)(smem + (size_t)hq * nb * 64);
+    h.sBh = (uint4 *)(smem + (size_t)hq * nb * 64);
+    h.pool_id = (int64_t *)(smem + (size_t)hq * nb * 64 + (size_t)hq * ((nb + 1) / 2) * 64);
     h.pool_ord = (uint32_t *)((unsigned char *)h.pool_id + (size_t)hq * C * 8);
     h.q = (int *)(h.pool_ord + (size_t)hq * C);
     h.pair = h.q + hq;
@@ -77,16 +92,21 @@ __device__ __forceinline__ HotLds hot_lds(unsigned char *smem, int hq, int nb, i
     h.item = (int *)(h.xn + hq);
     return h;
 }
-size_t qk_scan_hot_lds(int nblk, int C, int hq) { return (size_t)hq * ((size_t)nblk * 64 + (size_t)C * 12 + 24) + 64; }
+size_t qk_scan_hot_lds(int nblk, int C, int hq) {
+    return (size_t)hq * ((size_t)nblk * 64 + (size_t)((nblk + 1) / 2) * 64 + (size_t)C * 12 + 24) + 64;
+}
 
 // one item; every thread of the workgroup calls it with the same arguments.  Barriers: after staging, before and after the
 // record emission.
 template <int NB, bool L2>
 __device__ __forceinline__ void rl_hot_item(const ScanParams &P, const HotLds &H, const ActiveInfo &inf, const int q0, const int nq,
-                                            const int t_lo, const int t_hi, int &dbg_app, int &dbg_comp) {
+                                            const int t_lo, const int t_hi, int &dbg_app, int &dbg_comp, long long *ht) {
+    long long dbg_prod = 0, dbg_exact = 0;  // probe: products tested, row tiles recomputed exactly
+    const long long ht0 = P.wave_clock ? wall_clock64() : 0;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int j = lane & 15, g = lane >> 4;
-    const int C = P.C, k = P.k;
+    const int C = P.hot.C, k = P.k;
+    constexpr int NM = (NB + 1) / 2;  // bf16 instructions per product (32 columns each)
     const int QT = (nq + 15) >> 4;
     const int size_p = inf.size;
     const int64_t tile_p0 = inf.row_off >> 4;
@@ -112,39 +132,66 @@ __device__ __forceinline__ void rl_hot_item(const ScanParams &P, const HotLds &H
     HOT_LOAD(a0, y0, i0);
 
     // ---- stage the block: query tiles in B-operand order + per-slot state, while the first pair is in flight ---------------
+    // Two memory round trips for the whole block: every thread first requests the query numbers it needs (one per query tile:
+    // thread (wave w, g, j) copies blocks c = w and w + 4 of slot 16 qt + j for every tile qt), then all its query pieces and
+    // the state of the slot it initialises (thread t < 16 QT: slot t) -- a loop of dependent loads was 13 us of a 60 us item
     {
-        const int nslot = QT * 16;
-        for (int sl = threadIdx.x; sl < nslot; sl += 256) {
-            const bool live = sl < nq;
-            const int gi = inf.qoff + q0 + sl;
-            const int qq = live ? P.grouped_q[gi] : -1;
-            H.q[sl] = qq;
-            H.pair[sl] = live ? P.grouped_pair[gi] : -1;
-            uint32_t t0 = 0xFFFFFFFFu;
-            if (P.gtau && live) t0 = ~__hip_atomic_load(&P.gtau[qq], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            H.tau[sl] = t0;
-            H.cnt[sl] = 0;
-            H.lock[sl] = 0;
-            H.xn[sl] = (L2 && live) ? P.xn[qq] : 0.0f;
+        const int qbase = inf.qoff + q0;
+        int qq[8];
+#pragma unroll
+        for (int qt = 0; qt < 8; qt++) {
+            const int sl = 16 * qt + j;
+            qq[qt] = (qt < QT && sl < nq) ? P.grouped_q[qbase + sl] : -1;
         }
-        // float4 index i of the staged tiles = ((qt * NB + c) * 64 + g' * 16 + j'): xq4[(q * NB + c) * 4 + g']
-        const int total = QT * NB * 64;
-        for (int i = threadIdx.x; i < total; i += 256) {
-            const int jj = i & 15, gg = (i >> 4) & 3, c = (i >> 6) % NB, qt = (i >> 6) / NB;
-            const int sl = 16 * qt + jj;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (sl < nq) {
-                const int qq = P.grouped_q[inf.qoff + q0 + sl];
-                v = P.xq4[((int64_t)qq * NB + c) * 4 + gg];
+        const int sl_own = threadIdx.x;
+        const bool own = sl_own < QT * 16;
+        const bool live_own = sl_own < nq;
+        const int q_own = live_own ? P.grouped_q[qbase + sl_own] : -1;
+        const int pair_own = live_own ? P.grouped_pair[qbase + sl_own] : -1;
+        float4 v[8][2];
+#pragma unroll
+        for (int qt = 0; qt < 8; qt++)
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const int c = wv + 4 * u;
+                v[qt][u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (c < NB && qq[qt] >= 0) v[qt][u] = P.xq4[((int64_t)qq[qt] * NB + c) * 4 + g];
             }
-            H.sB[i] = v;
+        uint32_t t_own = 0xFFFFFFFFu;
+        float xn_own = 0.0f;
+        if (live_own) {
+            if (P.gtau) t_own = ~__hip_atomic_load(&P.gtau[q_own], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (L2) xn_own = P.xn[q_own];
+        }
+#pragma unroll
+        for (int qt = 0; qt < 8; qt++)
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const int c = wv + 4 * u;
+                if (c < NB && qt < QT) H.sB[((size_t)qt * NB + c) * 64 + lane] = v[qt][u];
+                if (c < NB + (NB & 1) && qt < QT) {  // bf16 copy: block c is half (c & 1) of the lane's 16 bytes of step c / 2
+                    const float4 f = v[qt][u];   // (zero for the padding block of an odd NB)
+                    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+                    bf16x4 hv = {(__bf16)f.x, (__bf16)f.y, (__bf16)f.z, (__bf16)f.w};
+                    uint2 *dst = (uint2 *)(H.sBh + ((size_t)qt * NM + (c >> 1)) * 64 + lane) + (c & 1);
+                    *dst = __builtin_bit_cast(uint2, hv);
+                }
+            }
+        if (own) {
+            H.q[sl_own] = q_own;
+            H.pair[sl_own] = pair_own;
+            H.tau[sl_own] = t_own;
+            H.cnt[sl_own] = 0;
+            H.lock[sl_own] = 0;
+            H.xn[sl_own] = xn_own;
         }
     }
     __syncthreads();
+    const long long ht1 = P.wave_clock ? wall_clock64() : 0;
 
     // ---- epilogue of one query tile: keys of this lane's 2 x 4 rows for query j of the tile ----------------------------------
     auto keys = [&](const int qt, const f32x4 ac0, const f32x4 ac1, const int pi, const float4 *Y, uint32_t *ordv, const float xnj,
-                    const uint32_t tauj) -> bool {
+                    const uint32_t tauj, const int umask) -> bool {
         const bool livej = 16 * qt + j < nq;
         bool anyp = false;
 #pragma unroll
@@ -155,7 +202,7 @@ __device__ __forceinline__ void rl_hot_item(const ScanParams &P, const HotLds &H
             for (int reg = 0; reg < 4; reg++) {
                 const float v = u == 0 ? ac0[reg] : ac1[reg];
                 const uint32_t o = L2 ? ord_from_l2(l2_expanded(xnj, yv[reg], v)) : ord_from_ip(v);
-                const bool valid = livej & (tl < t_hi) & (16 * tl + 4 * g + reg < size_p);
+                const bool valid = livej & (tl < t_hi) & (16 * tl + 4 * g + reg < size_p) & ((umask >> u) & 1);
                 ordv[4 * u + reg] = valid ? o : 0xFFFFFFFFu;
                 anyp |= valid & (o <= tauj);
             }
@@ -212,13 +259,31 @@ __device__ __forceinline__ void rl_hot_item(const ScanParams &P, const HotLds &H
         }
     };
 
-#define HOT_CHAIN(A, QT_, AC0, AC1)                                                                          \
+#ifdef QK_PROBES  // (probe build only: rl_probe bit 8 drops the chains of the hot items -- the branch splits the block the keys hide in)
+#define HOT_PF_PROBE(x) ((P.rl_probe & 32) ? 3 : (P.rl_probe & 64) ? 0 : (x))  /* 32: every product exact; 64: none */
+#define HOT_CHAIN_PROBE(A, AC0, AC1, B) \
+    if (P.rl_probe & 8) {               \
+        AC0[0] += A[0].x + B[0].x;      \
+        AC1[1] += A[NB].y + B[NB - 1].y; \
+    } else
+#else
+#define HOT_CHAIN_PROBE(A, AC0, AC1, B)
+#define HOT_PF_PROBE(x) (x)
+#endif
+// the B operands of a query tile: NB float4 per lane, requested a whole tile AHEAD of their chains (with one buffer hipcc put a
+// ds_read_b128 and a full s_waitcnt lgkmcnt(0) in front of every 8 instructions of the chain)
+#define HOT_BLOAD(B, QT_)                                                                                    \
     {                                                                                                        \
         const float4 *bq_ = H.sB + (size_t)(QT_) * NB * 64 + lane;                                           \
+        _Pragma("unroll") for (int c_ = 0; c_ < NB; c_++) B[c_] = bq_[c_ * 64];                              \
+    }
+#define HOT_CHAIN(A, B, AC0, AC1)                                                                            \
+    {                                                                                                        \
         AC0 = (f32x4){0.f, 0.f, 0.f, 0.f};                                                                   \
         AC1 = (f32x4){0.f, 0.f, 0.f, 0.f};                                                                   \
+        HOT_CHAIN_PROBE(A, AC0, AC1, B)                                                                      \
         _Pragma("unroll") for (int c_ = 0; c_ < NB; c_++) {                                                  \
-            const float4 b_ = bq_[c_ * 64];                                                                  \
+            const float4 b_ = B[c_];                                                                         \
             AC0 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[c_].x, b_.x, AC0, 0, 0, 0);                         \
             AC1 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[NB + c_].x, b_.x, AC1, 0, 0, 0);                    \
             AC0 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[c_].y, b_.y, AC0, 0, 0, 0);                         \
@@ -229,29 +294,102 @@ __device__ __forceinline__ void rl_hot_item(const ScanParams &P, const HotLds &H
             AC1 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[NB + c_].w, b_.w, AC1, 0, 0, 0);                    \
         }                                                                                                    \
     }
-// all query tiles against the pair held in A: the keys of tile qt - 1 are computed after the chains of tile qt were issued
+// exact product of the pair in A with query tile QT_: fp32 operands from LDS, the canonical chains, keys, appends
+#define HOT_EXACT(A, Y, I, PI, QT_, UM_)                                                                     \
+    {                                                                                                        \
+        float4 bx_[NB];                                                                                      \
+        HOT_BLOAD(bx_, QT_);                                                                                 \
+        const float xne_ = H.xn[16 * (QT_) + j];                                                             \
+        const uint32_t taue_ = H.tau[16 * (QT_) + j];                                                        \
+        f32x4 ea0_ = {0.f, 0.f, 0.f, 0.f}, ea1_ = {0.f, 0.f, 0.f, 0.f};                                      \
+        if ((UM_) == 3) {                                                                                    \
+            HOT_CHAIN(A, bx_, ea0_, ea1_);                                                                   \
+        } else if ((UM_) == 1) {                                                                             \
+            HOT_CHAIN1(A, 0, bx_, ea0_);                                                                     \
+        } else {                                                                                             \
+            HOT_CHAIN1(A, NB, bx_, ea1_);                                                                    \
+        }                                                                                                    \
+        uint32_t ordv_[8];                                                                                   \
+        const bool anyp_ = keys(QT_, ea0_, ea1_, PI, Y, ordv_, xne_, taue_, UM_);                            \
+        const uint64_t pm_ = __ballot(anyp_);                                                                \
+        if (pm_) append(QT_, ordv_, I, pm_);                                                                 \
+    }
+// (one row tile only: a single dependent chain)
+#define HOT_CHAIN1(A, OFF_, B, AC)                                                                           \
+    {                                                                                                        \
+        _Pragma("unroll") for (int c_ = 0; c_ < NB; c_++) {                                                  \
+            const float4 b_ = B[c_];                                                                         \
+            AC = __builtin_amdgcn_mfma_f32_16x16x4f32(A[(OFF_) + c_].x, b_.x, AC, 0, 0, 0);                  \
+            AC = __builtin_amdgcn_mfma_f32_16x16x4f32(A[(OFF_) + c_].y, b_.y, AC, 0, 0, 0);                  \
+            AC = __builtin_amdgcn_mfma_f32_16x16x4f32(A[(OFF_) + c_].z, b_.z, AC, 0, 0, 0);                  \
+            AC = __builtin_amdgcn_mfma_f32_16x16x4f32(A[(OFF_) + c_].w, b_.w, AC, 0, 0, 0);                  \
+        }                                                                                                    \
+    }
+#define HOT_HLOAD(B, QT_)                                                                                    \
+    {                                                                                                        \
+        const uint4 *bq_ = H.sBh + (size_t)(QT_) * NM * 64 + lane;                                           \
+        _Pragma("unroll") for (int m_ = 0; m_ < NM; m_++) B[m_] = bq_[m_ * 64];                              \
+    }
+// one query tile: the bf16 product of the pair on the operands in BC (those of the next tile requested into BN first), the
+// one-sided test of its 8 approximate keys, and the exact product if any lane of the wave could still be a candidate
+#define HOT_TILE(A, Y, I, PI, BC, BN, QT_)                                                                   \
+    {                                                                                                        \
+        HOT_HLOAD(BN, min((QT_) + 1, QT - 1));                                                               \
+        const float xnj_ = H.xn[16 * (QT_) + j];                                                             \
+        const uint32_t tauj_ = H.tau[16 * (QT_) + j];                                                        \
+        f32x4 d0_ = {0.f, 0.f, 0.f, 0.f}, d1_ = {0.f, 0.f, 0.f, 0.f};                                        \
+        _Pragma("unroll") for (int m_ = 0; m_ < NM; m_++) {                                                  \
+            const bf16x8 bh_ = __builtin_bit_cast(bf16x8, BC[m_]);                                           \
+            d0_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah_[m_], bh_, d0_, 0, 0, 0);                       \
+            d1_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah_[NM + m_], bh_, d1_, 0, 0, 0);                  \
+        }                                                                                                    \
+        const bool livej_ = 16 * (QT_) + j < nq;                                                             \
+        const float xk_ = L2 ? xnj_ * QK_PF_K1 : xnj_ * (0.5f * QK_PF_C);                                    \
+        bool flag_ = false, flag1_ = false;                                                                  \
+        _Pragma("unroll") for (int e_ = 0; e_ < 8; e_++) {                                                   \
+            const float dd_ = e_ < 4 ? d0_[e_ & 3] : d1_[e_ & 3];                                            \
+            uint32_t o_;                                                                                     \
+            if (L2) {                                                                                        \
+                const float lo_ = __fmaf_rn(-2.0f, dd_, xk_ + yk_[e_]);                                      \
+                o_ = ord_from_l2(lo_ < 0.0f ? 0.0f : lo_);                                                   \
+            } else {                                                                                         \
+                o_ = ord_from_ip(dd_ + (xk_ + yk_[e_]));                                                     \
+            }                                                                                                \
+            if (e_ < 4) flag_ |= rv_[e_] & (o_ <= tauj_);                                                    \
+            else flag1_ |= rv_[e_] & (o_ <= tauj_);                                                          \
+        }                                                                                                    \
+        const int um_ = HOT_PF_PROBE((__ballot(flag_ & livej_) ? 1 : 0) | (__ballot(flag1_ & livej_) ? 2 : 0)); \
+        dbg_prod += 2;                                                                                       \
+        if (um_) {                                                                                           \
+            dbg_exact += (um_ & 1) + (um_ >> 1);                                                             \
+            HOT_EXACT(A, Y, I, PI, QT_, um_);                                                                \
+        }                                                                                                    \
+    }
 #define HOT_PAIR(A, Y, I, PI)                                                                                \
     {                                                                                                        \
-        f32x4 pa0_, pa1_, na0_, na1_;                                                                        \
-        HOT_CHAIN(A, 0, pa0_, pa1_);                                                                         \
-        for (int qt_ = 1; qt_ < QT; qt_++) {                                                                 \
-            const float xnj_ = H.xn[16 * (qt_ - 1) + j];                                                     \
-            const uint32_t tauj_ = H.tau[16 * (qt_ - 1) + j];                                                \
-            HOT_CHAIN(A, qt_, na0_, na1_);                                                                   \
-            uint32_t ordv_[8];                                                                               \
-            const bool anyp_ = keys(qt_ - 1, pa0_, pa1_, PI, Y, ordv_, xnj_, tauj_);                         \
-            const uint64_t pm_ = __ballot(anyp_);                                                            \
-            if (pm_) append(qt_ - 1, ordv_, I, pm_);                                                         \
-            pa0_ = na0_;                                                                                     \
-            pa1_ = na1_;                                                                                     \
+        /* bf16 copies of the pair's fragments (the fp32 lane layout, converted in place), the row part of the bound */ \
+        bf16x8 ah_[2 * NM];                                                                                  \
+        float yk_[8];                                                                                        \
+        bool rv_[8];                                                                                         \
+        _Pragma("unroll") for (int u_ = 0; u_ < 2; u_++) {                                                   \
+            _Pragma("unroll") for (int m_ = 0; m_ < NM; m_++) {                                              \
+                const float4 f0_ = A[u_ * NB + 2 * m_];                                                      \
+                const float4 f1_ = 2 * m_ + 1 < NB ? A[u_ * NB + (2 * m_ + 1 < NB ? 2 * m_ + 1 : 0)] : make_float4(0.f, 0.f, 0.f, 0.f); \
+                ah_[u_ * NM + m_] = (bf16x8){(__bf16)f0_.x, (__bf16)f0_.y, (__bf16)f0_.z, (__bf16)f0_.w,     \
+                                             (__bf16)f1_.x, (__bf16)f1_.y, (__bf16)f1_.z, (__bf16)f1_.w};    \
+            }                                                                                                \
+            const int tl_ = t_lo + 2 * (PI) + u_;                                                            \
+            const float yv_[4] = {Y[u_].x, Y[u_].y, Y[u_].z, Y[u_].w};                                       \
+            _Pragma("unroll") for (int reg_ = 0; reg_ < 4; reg_++) {                                         \
+                yk_[4 * u_ + reg_] = L2 ? yv_[reg_] * QK_PF_K1 : yv_[reg_] * (0.5f * QK_PF_C);               \
+                rv_[4 * u_ + reg_] = (tl_ < t_hi) & (16 * tl_ + 4 * g + reg_ < size_p);                      \
+            }                                                                                                \
         }                                                                                                    \
-        {                                                                                                    \
-            const float xnj_ = H.xn[16 * (QT - 1) + j];                                                      \
-            const uint32_t tauj_ = H.tau[16 * (QT - 1) + j];                                                 \
-            uint32_t ordv_[8];                                                                               \
-            const bool anyp_ = keys(QT - 1, pa0_, pa1_, PI, Y, ordv_, xnj_, tauj_);                          \
-            const uint64_t pm_ = __ballot(anyp_);                                                            \
-            if (pm_) append(QT - 1, ordv_, I, pm_);                                                          \
+        uint4 bc_[NM], bn_[NM];                                                                              \
+        HOT_HLOAD(bc_, 0);                                                                                   \
+        for (int qt_ = 0; qt_ < QT; qt_ += 2) {                                                              \
+            HOT_TILE(A, Y, I, PI, bc_, bn_, qt_);                                                            \
+            if (qt_ + 1 < QT) HOT_TILE(A, Y, I, PI, bn_, bc_, qt_ + 1);                                      \
         }                                                                                                    \
     }
 
@@ -269,10 +407,19 @@ __device__ __forceinline__ void rl_hot_item(const ScanParams &P, const HotLds &H
     }
 #undef HOT_LOAD
 #undef HOT_CHAIN
+#undef HOT_CHAIN_PROBE
+#undef HOT_PF_PROBE
+#undef HOT_EXACT
+#undef HOT_CHAIN1
+#undef HOT_HLOAD
+#undef HOT_BLOAD
+#undef HOT_TILE
 #undef HOT_PAIR
 
     // ---- item end: every non-empty pool becomes a record of its pair (wave w takes slots [w * hq / 4, (w + 1) * hq / 4)) -----
+    const long long ht2 = P.wave_clock ? wall_clock64() : 0;
     __syncthreads();
+    const long long ht3 = P.wave_clock ? wall_clock64() : 0;
     {
         const int spw = P.hot.hq >> 2;  // slots per wave (multiple of 4, <= 32)
         const int sl = wv * spw + lane;
@@ -321,6 +468,15 @@ __device__ __forceinline__ void rl_hot_item(const ScanParams &P, const HotLds &H
         }
     }
     __syncthreads();
+    if (P.wave_clock) {
+        const long long ht4 = wall_clock64();
+        ht[0] += ht1 - ht0;  // staging (+ first loads)
+        ht[1] += ht2 - ht1;  // chains + keys + appends
+        ht[2] += ht3 - ht2;  // waiting for the other waves of the item
+        ht[3] += ht4 - ht3;  // record emission + closing barrier
+        ht[6] += dbg_prod;
+        ht[7] += dbg_exact;
+    }
 }
 
 // NB = 16-column blocks per row (d <= 128).  One hardware workgroup = 4 independent waves (own range, own LDS, no barrier).
@@ -370,6 +526,7 @@ __global__ __launch_bounds__(256) void k_scan_rl(ScanParams P) {
             n_hot_first = max(0, min(n_hot_first, ((int)gridDim.x - 8) & ~7));
         }
     }
+    if (HOT && (P.rl_probe & 4)) n_hot_first = 0;  // probe: hot items are dropped, everybody cuts the per-wave sequence
     const bool hot_first = HOT && (int)blockIdx.x < n_hot_first;
     const long long gu = (long long)gridDim.x - n_hot_first;   // workgroups that cut the static share
     const long long u = (long long)blockIdx.x - n_hot_first;   // (n_hot_first is a multiple of 8: u % 8 is still the XCD class)
@@ -400,20 +557,27 @@ __global__ __launch_bounds__(256) void k_scan_rl(ScanParams P) {
     const RlCost rc{P.rl_h0, P.rl_h1, P.rl_e, P.seg_ovh, P.rl_m, QB};
     const int n_active = *P.n_active;
     long long xcd_ticks = 0;  // time spent on the static share (what the XCD balance learns from)
+    long long hot_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // probe: ticks in the phases of the hot items, whole items, items
     for (int ph = 0; ph < (HOT ? 2 : 1); ph++) {
     if (HOT && ((ph == 0) == hot_first)) {
         // ---- hot items: the whole workgroup, one item at a time from the queue --------------------------------------------
         if (n_hot <= 0) continue;
         if (!hot_first) __syncthreads();  // every wave has left the per-wave sequence (and its slice of the LDS)
-        const HotLds H = hot_lds(smem, P.hot.hq, NB, C);
+        const HotLds H = hot_lds(smem, P.hot.hq, NB, P.hot.C);
+        // (the queue is claimed one item AHEAD: the atomic for the next item goes out when this one starts and has long returned
+        //  when it ends -- a device-scope round trip of 1-2 us per item otherwise)
+        int next_item = 0;
+        if (threadIdx.x == 0) next_item = atomicAdd(P.hot_counter, 1);
         for (;;) {
-            if (threadIdx.x == 0) H.item[0] = atomicAdd(P.hot_counter, 1);
+            const long long hc0 = P.wave_clock ? wall_clock64() : 0;
+            if (threadIdx.x == 0) H.item[0] = next_item;
             __syncthreads();
             const int item = H.item[0];
             if (item >= n_hot) {
                 __syncthreads();  // (the word sits in a wave's slice of the per-wave form)
                 break;
             }
+            if (threadIdx.x == 0) next_item = atomicAdd(P.hot_counter, 1);
             // 64-ary search: act_hoff[lo] <= item < act_hoff[lo + 1]
             int lo = 0, hi = n_active;
             while (hi - lo > 1) {
@@ -433,14 +597,20 @@ __global__ __launch_bounds__(256) void k_scan_rl(ScanParams P) {
             const int local = item - P.act_hoff[lo];
             const int qb = local / hs.nrr, rr = local - qb * hs.nrr;
             const int q0 = qb * hs.qpb, nq = min(hs.qpb, inf.cnt - q0);
-            const int ntl = (inf.size + 15) >> 4;
-            const int t_lo = (int)(((long long)ntl * rr) / hs.nrr), t_hi = (int)(((long long)ntl * (rr + 1)) / hs.nrr);
+            int t_lo, t_hi;
+            hot_range(inf.size, rr, hs.nrr, &t_lo, &t_hi);
             if (nq <= 0 || t_hi <= t_lo) {
                 __syncthreads();
                 continue;
             }
             dbg_seg++;
-            rl_hot_item<NB, L2>(P, H, inf, q0, nq, t_lo, t_hi, dbg_app, dbg_comp);
+            hot_t[5]++;
+            if (P.rl_probe & 4) {  // probe: hot items claimed and dropped (what the per-wave sequence alone costs)
+                __syncthreads();
+                continue;
+            }
+            rl_hot_item<NB, L2>(P, H, inf, q0, nq, t_lo, t_hi, dbg_app, dbg_comp, hot_t);
+            if (P.wave_clock) hot_t[4] += wall_clock64() - hc0;
         }
         continue;
     }
@@ -469,6 +639,10 @@ __global__ __launch_bounds__(256) void k_scan_rl(ScanParams P) {
         const int size_p = inf.size, cnt_p = inf.cnt;
         if (HOT && P.hot.min > 0 && cnt_p >= P.hot.min) {  // a hot list: no units in this sequence (rl_hot_item)
             ai++;
+            continue;
+        }
+        if (HOT && (P.rl_probe & 16)) {  // probe: the per-wave walk does nothing (what the hot items alone cost)
+            cur = T1;
             continue;
         }
         const int nch = (size_p + 63) >> 6, ntl = (size_p + 15) >> 4;
@@ -760,6 +934,13 @@ __global__ __launch_bounds__(256) void k_scan_rl(ScanParams P) {
         const unsigned hw = __builtin_amdgcn_s_getreg((4) | (0 << 6) | ((32 - 1) << 11));
         const unsigned xcc = __builtin_amdgcn_s_getreg((20) | (0 << 6) | ((4 - 1) << 11));
         wcp[7] = ((long long)xcc << 32) | hw;
+        if (HOT) {  // second half of the probe buffer: the hot items of this wave
+            long long *hcp = P.wave_clock + 8 * ((long long)gridDim.x * PK + vblock);
+#pragma unroll
+            for (int i = 0; i < 6; i++) hcp[i] = hot_t[i];
+            hcp[6] = hot_t[6];
+            hcp[7] = hot_t[7];
+        }
     }
 }
 

@@ -25,35 +25,51 @@ constexpr int QK_HOT_NRR_MAX = 16;  // most row ranges a (list, query block) is 
 struct HotCost {
     int min;    // lists with cnt >= min are hot (0: none)
     int hq;     // queries per block: multiple of 16, <= 128, what the workgroup's LDS holds (queries + pools)
-    int unit;   // (row tile x query tile) products per item
-    int w10;    // cost of one such product in tenths of a per-wave sequence unit (all four waves busy)
-    int ovh;    // cost of starting an item (staging the block's queries, emitting its records), per-wave sequence units
+    int unit;   // cost of an item the cut aims at, in units of the per-wave sequence (summed over the four waves)
+    int w10;    // tenths of a unit per (row tile x query tile) product: the bf16 prefilter + its test
+    int ht10;   // tenths of a unit per row tile: streaming it (8 KB at d = 128) -- an item costs the larger of the two
+    int ovh;    // cost of starting an item (staging the block's queries, emitting its records)
+    int C;      // pool capacity per query of a block (k + slack; the block's pools sit next to fp32 AND bf16 query tiles)
 };
 struct HotShape {
     int nqblk, qpb, nrr;  // query blocks, queries per block (multiple of 16), row ranges
 };
+__host__ __device__ inline long long hot_block_cost(int ntl, int qt, const HotCost &h) {
+    const long long a = (long long)ntl * h.ht10, b = (long long)ntl * qt * h.w10;
+    return ((a > b ? a : b) + 9) / 10;
+}
 __host__ __device__ inline HotShape hot_shape(int cnt, int size, const HotCost &h) {
     HotShape s;
     const int ntl = (size + 15) >> 4;
     s.nqblk = (cnt + h.hq - 1) / h.hq;
     s.qpb = (((cnt + s.nqblk - 1) / s.nqblk) + 15) & ~15;
-    const long long prod = (long long)ntl * (s.qpb >> 4);
-    long long nrr = (prod + h.unit / 2) / h.unit;
-    const long long cap = ntl / 2 > 1 ? ntl / 2 : 1;  // a range holds at least two row tiles
+    const long long cost = hot_block_cost(ntl, s.qpb >> 4, h);
+    long long nrr = (cost + h.unit / 2) / h.unit;
+    const long long cap = (ntl + 7) >> 3;  // ranges are whole groups of 8 row tiles (hot_range)
     if (nrr > cap) nrr = cap;
     if (nrr < 1) nrr = 1;
     if (nrr > QK_HOT_NRR_MAX) nrr = QK_HOT_NRR_MAX;
     s.nrr = (int)nrr;
     return s;
 }
+// row tiles [lo, hi) of range r: the list is cut in groups of 8 row tiles -- 4 waves x one pair of tiles -- so that every wave of
+// the workgroup gets the same number of pairs (a ragged cut left one wave with a pair more than the others in most items:
+// 6 % of the item spent waiting at its closing barrier)
+__host__ __device__ inline void hot_range(int size, int r, int nrr, int *lo, int *hi) {
+    const int ntl = (size + 15) >> 4;
+    const long long ng = (ntl + 7) >> 3;
+    const long long a = (ng * r) / nrr * 8, b = (ng * (r + 1)) / nrr * 8;
+    *lo = (int)(a < ntl ? a : ntl);
+    *hi = (int)(b < ntl ? b : ntl);
+}
 __host__ __device__ inline long long hot_units_of(int cnt, int size, const HotCost &h) {
     const HotShape s = hot_shape(cnt, size, h);
-    const long long ntl = (size + 15) >> 4;
+    const int ntl = (size + 15) >> 4;
     long long u = 0;
     for (int b = 0; b < s.nqblk; b++) {
         const int nq = cnt - b * s.qpb < s.qpb ? cnt - b * s.qpb : s.qpb;
         if (nq <= 0) break;
-        u += (long long)s.nrr * h.ovh + (ntl * ((nq + 15) >> 4) * h.w10 + 9) / 10;
+        u += (long long)s.nrr * h.ovh + hot_block_cost(ntl, (nq + 15) >> 4, h);
     }
     return u;
 }
