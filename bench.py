@@ -667,21 +667,32 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+        raise SystemExit(f"bench.py --gpus {args.gpus}: the launcher started {world} rank(s) (WORLD_SIZE); launch one rank per GPU with "
+                         f"`python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 bench.py "
+                         f"--gpus {args.gpus} ...`")
     # QUAKE_BENCH_BACKEND=gloo lets two ranks share one GPU (functional check of the N>1 path on a 1-GPU box)
     backend = os.environ.get("QUAKE_BENCH_BACKEND", "nccl")
     dev_index = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     dist = None
-    if world > 1:
+    # QUAKE_BENCH_FORCE_SHARDED=1 (with QUAKE_FORCE_COLLECTIVES=1): the N > 1 path with ONE rank -- every collective of it runs
+    # on the real backend (tests/test_rccl_world1_gpu.py)
+    force_sharded = world == 1 and os.environ.get("QUAKE_BENCH_FORCE_SHARDED", "0") not in ("", "0")
+    if world > 1 or force_sharded:
         import torch.distributed as dist_
         dist = dist_
+        if force_sharded:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29517")
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, rank=rank, world_size=world)
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"bench.py --gpus {args.gpus}: the {backend} process group has {dist.get_world_size()} rank(s)")
+        if backend == "nccl" and world > 1 and torch.cuda.device_count() < world:
+            raise SystemExit(f"bench.py --gpus {args.gpus}: RCCL needs one GPU per rank, this node shows {torch.cuda.device_count()}")
 
     from quake_amd.capi import Context
     ctx = Context(dev_index)
@@ -692,7 +703,7 @@ def main():
     log("device", ctx.device_info())
     t_all = time.time()
 
-    if world == 1:
+    if world == 1 and not force_sharded:
         main_res = run_single_workload(ctx, dev, args, "headline", args.sigma, args.nprobe, args.steps, args.warmup, args.settle,
                                        args.cpu_seconds, traffic_file="r02_pmc_k_scan.json", manifold=args.manifold)
         cfg_no = 2 if (args.metric == "ip" and args.dim == 768) else 1
@@ -709,7 +720,7 @@ def main():
     }
     if main_res.get("batches_in_flight"):
         result["batches_in_flight"] = main_res["batches_in_flight"]
-    if world == 1:
+    if world == 1 and not force_sharded:
         result["cpu_baseline"] = main_res.get("cpu_baseline")
         if "speedup_vs_cpu" in main_res:
             result["speedup_vs_cpu"] = main_res["speedup_vs_cpu"]

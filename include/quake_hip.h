@@ -89,12 +89,15 @@ QK_API int qk_ctx_synchronize(qk_ctx *ctx);
  *   3 deferred, scan kernel only: one event pair per call around the partition-scan kernel (an event record costs the stream
  *     a few microseconds; the 8 of mode 2 add ~10 % to a 0.35 ms search). */
 QK_API int qk_ctx_set_timing(qk_ctx *ctx, int mode);
+/* The mode set last (0 at creation): a caller that switches the mode for one call restores what it found
+ * (QueryCoordinator::search fills SearchTimingInfo, query_coordinator.cpp:612-657, on a context others may be timing with). */
+QK_API int qk_ctx_get_timing(qk_ctx *ctx, int *mode);
 /* Synchronises, then returns the SUM of the phase durations over the calls recorded in deferred mode and their count. */
 QK_API int qk_ctx_read_timing(qk_ctx *ctx, qk_timing *sum, int64_t *calls);
 /* Device properties the harness prints: CU count, clock (kHz), total HBM bytes, gcnArchName. */
 QK_API int qk_ctx_device_info(qk_ctx *ctx, int *num_cus, int *clock_khz, int64_t *hbm_bytes, char *arch, int arch_len);
 /* Name of the partition-scan kernel the last qk_scan / qk_search on this context launched ("k_scan", "k_scan (query-sharing)",
- * "k_scan_rl", "k_search_small", "k_dense"; "" before the first call): what a harness labels its kernel timings with. */
+ * "k_scan_rl", "k_scan_rl (mixed)", "k_search_small", "k_dense"; "" before the first call): what a harness labels its kernel timings with. */
 QK_API int qk_ctx_last_scan_kernel(qk_ctx *ctx, char *name, int name_len);
 
 /* ---- partition store ---------------------------------------------------------------------------

@@ -43,6 +43,7 @@ SIGNATURES = {
     "qk_ctx_set_null_stream": (_int, [_vp]),
     "qk_ctx_synchronize": (_int, [_vp]),
     "qk_ctx_set_timing": (_int, [_vp, _int]),
+    "qk_ctx_get_timing": (_int, [_vp, C.POINTER(_int)]),
     "qk_ctx_set_squared_l2": (_int, [_vp, _int]),
     "qk_ctx_read_timing": (_int, [_vp, C.POINTER(QkTiming), C.POINTER(_i64)]),
     "qk_ctx_device_info": (_int, [_vp, C.POINTER(_int), C.POINTER(_int), C.POINTER(_i64), C.c_char_p, _int]),

@@ -111,6 +111,12 @@ class Context:
         the scan kernel only (what bench.py keeps on inside its timed region)."""
         check(self.lib.qk_ctx_set_timing(self.h, int(mode)))
 
+    def get_timing(self):
+        """the timing mode set last (qk_ctx_get_timing)"""
+        m = C.c_int(0)
+        check(self.lib.qk_ctx_get_timing(self.h, C.byref(m)))
+        return int(m.value)
+
     def read_timing(self):
         t, n = QkTiming(), C.c_int64()
         check(self.lib.qk_ctx_read_timing(self.h, C.byref(t), C.byref(n)))

@@ -70,6 +70,17 @@ shared_ptr<SearchResult> QueryCoordinator::search(Tensor x, shared_ptr<SearchPar
     std::memset(&tm, 0, sizeof(tm));
     const int mem = on_dev ? QK_MEM_DEVICE : QK_MEM_HOST;
     const bool track = maintenance_policy_ && maintenance_policy_->track_hits_ && parent_;
+    // per-call phase timing for SearchTimingInfo, in every branch; the context is shared (one per device), so the mode a caller
+    // had set -- the deferred modes of a harness, say -- is put back on every way out
+    struct TimingMode {
+        qk_ctx *c;
+        int was = 0;
+        explicit TimingMode(qk_ctx *ctx) : c(ctx) {
+            qk_ctx_get_timing(c, &was);
+            qk_ctx_set_timing(c, 1);
+        }
+        ~TimingMode() { qk_ctx_set_timing(c, was); }
+    } timing_mode(ctx);
     if (sp->recall_target > 0.0f && parent_ && !sp->batched_scan) {
         // adaptive partition scanning (:502,637-641): candidates = nlist * initial_search_fraction
         Tensor nscan = torch::empty({Q}, torch::TensorOptions().dtype(torch::kInt32).device(xq.device()));
@@ -87,12 +98,12 @@ shared_ptr<SearchResult> QueryCoordinator::search(Tensor x, shared_ptr<SearchPar
                          res->distances.data_ptr<float>(), mem, &tm));
         maintenance_policy_->record_query_batch(host_i64(pids));
         ti->partitions_scanned = (int)tm.partitions_scanned;
+        ti->job_enqueue_time_ns = (int64_t)(tm.group_ms * 1e6);
+        ti->job_wait_time_ns = (int64_t)(tm.scan_ms * 1e6);
+        ti->result_aggregate_time_ns = (int64_t)(tm.merge_ms * 1e6);
     } else {
-        qk_check(qk_ctx_set_timing(ctx, 1));
-        const int st = qk_search(ctx, parent_ ? parent_->store() : nullptr, store, xq.data_ptr<float>(), Q, nprobe, k, (int)metric_,
-                                 res->ids.data_ptr<int64_t>(), res->distances.data_ptr<float>(), mem, &tm);
-        qk_ctx_set_timing(ctx, 0);
-        qk_check(st);
+        qk_check(qk_search(ctx, parent_ ? parent_->store() : nullptr, store, xq.data_ptr<float>(), Q, nprobe, k, (int)metric_,
+                           res->ids.data_ptr<int64_t>(), res->distances.data_ptr<float>(), mem, &tm));
         ti->partitions_scanned = (int)tm.partitions_scanned;
         ti->job_enqueue_time_ns = (int64_t)(tm.group_ms * 1e6);
         ti->job_wait_time_ns = (int64_t)(tm.scan_ms * 1e6);

@@ -106,6 +106,12 @@ int qk_ctx_set_timing(qk_ctx *c, int enabled) {
     return QK_OK;
 }
 
+int qk_ctx_get_timing(qk_ctx *c, int *mode) {
+    if (!c || !mode) QK_FAIL(QK_ERR_INVALID, "qk_ctx_get_timing: null argument");
+    *mode = c->timing_mode;
+    return QK_OK;
+}
+
 static float elapsed_or_zero(hipEvent_t a, hipEvent_t b) {
     float ms = 0.f;
     if (!a || !b) return 0.f;

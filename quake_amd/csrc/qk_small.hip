@@ -616,14 +616,15 @@ int qk_search_small_device(qk_ctx *ctx, qk_store *parent, qk_store *s, const flo
     static const int split_min_wgs = qk_env_int("QK_SMALL_SPLIT_MIN", 96);
     int resident = 0;
     {
-        static std::map<size_t, int> occ_cache;  // by LDS size (the only launch parameter occupancy depends on)
-        auto it = occ_cache.find(lds);
-        if (it == occ_cache.end()) {
+        // workgroups per CU by LDS size (the only launch parameter occupancy depends on), cached in the CONTEXT: one store may
+        // be searched through several contexts at once (include/quake_hip.h), on devices with different CU counts
+        auto it = ctx->small_occ.find(lds);
+        if (it == ctx->small_occ.end()) {
             int per_cu = 0;
             QK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_search_small, QK_SMALL_THREADS, lds));
-            it = occ_cache.emplace(lds, per_cu * std::max(1, ctx->prop.multiProcessorCount)).first;
+            it = ctx->small_occ.emplace(lds, per_cu).first;
         }
-        resident = it->second;
+        resident = it->second * std::max(1, ctx->prop.multiProcessorCount);
     }
     bool split = split_env == 1 || (split_env < 0 && Q * (int64_t)W >= split_min_wgs);
     if (split) {

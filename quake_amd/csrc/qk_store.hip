@@ -565,6 +565,23 @@ int qk_store_remove_ids(qk_store *s, int64_t n, const int64_t *ids_host, int64_t
     // The bitmap lives in the store, all zero between calls (the bits set here are cleared before returning).
     const int64_t id_lo = s->min_id_seen, id_hi = s->max_id_seen;
     const bool use_bits = id_hi >= id_lo && (id_hi - id_lo) < ((int64_t)1 << 30);
+    // everything that can fail for lack of memory happens BEFORE the host mirror is touched: at most one row move per removed id
+    QK_TRY(qk_stage_reserve(c, 2 * (((size_t)n * sizeof(int64_t) + 255) & ~(size_t)255) + 256));
+    // the bits set below are cleared on EVERY way out of this function (a bit left behind would make the next call delete a
+    // row it was never asked to)
+    struct BitsGuard {
+        qk_store *s;
+        const int64_t *ids;
+        int64_t n, lo, hi;
+        bool on;
+        ~BitsGuard() {
+            if (!on) return;
+            for (int64_t i = 0; i < n; i++) {
+                const int64_t v = ids[i];
+                if (v >= lo && v <= hi) s->kill_bits[(size_t)((v - lo) >> 6)] = 0;
+            }
+        }
+    } bits_guard{s, ids_host, n, id_lo, id_hi, use_bits};
     QkIdMap kill;  // (as a set)
     if (use_bits) {
         const size_t words = (size_t)((id_hi - id_lo) >> 6) + 1;
@@ -626,23 +643,18 @@ int qk_store_remove_ids(qk_store *s, int64_t n, const int64_t *ids_host, int64_t
         p.size = sz;
         p.ids.resize(sz);
     }
+    // the host mirror is final here: counters first, so that they agree with it whatever the device step below returns
+    s->ntotal -= removed;
+    if (removed) s->table_dirty = true;
+    if (n_removed) *n_removed = removed;
     if (!mv_dst.empty()) {
         size_t b = mv_dst.size() * sizeof(int64_t);
-        QK_TRY(qk_stage_reserve(c, 2 * b + 256));
-        int64_t *dd = (int64_t *)c->stage, *ds = (int64_t *)(c->stage + ((b + 255) & ~(size_t)255));
+        int64_t *dd = (int64_t *)c->stage, *ds = (int64_t *)(c->stage + ((b + 255) & ~(size_t)255));  // (reserved above: moves <= n)
         QK_HIP(hipMemcpyAsync(dd, mv_dst.data(), b, hipMemcpyHostToDevice, c->stream));
         QK_HIP(hipMemcpyAsync(ds, mv_src.data(), b, hipMemcpyHostToDevice, c->stream));
         QK_TRY(qk_launch_move_rows(c, s->vecs, s->norms, s->ids, s->nblk, dd, ds, (int64_t)mv_dst.size()));
         QK_HIP(hipStreamSynchronize(c->stream));
     }
-    if (use_bits)
-        for (int64_t i = 0; i < n; i++) {
-            const int64_t v = ids_host[i];
-            if (v >= id_lo && v <= id_hi) s->kill_bits[(size_t)((v - id_lo) >> 6)] = 0;
-        }
-    s->ntotal -= removed;
-    if (removed) s->table_dirty = true;
-    if (n_removed) *n_removed = removed;
     return QK_OK;
 }
 

@@ -14,7 +14,17 @@ The arithmetic lives in an *engine*:
 so the orchestration can be exercised with world_size-2 gloo tests on CPU (tests/test_sharded_gloo.py), where the
 test injects an oracle-backed engine.
 """
+import os
+
 import numpy as np
+
+
+def collectives_active(dist, world):
+    """do the collectives run?  With several ranks, always.  With ONE rank only when QUAKE_FORCE_COLLECTIVES=1: the whole
+    exchange path -- device all-gather, async all-to-all, all-reduce, broadcasts, stream ordering against the library's kernels
+    -- then executes on the real backend (RCCL on one GPU) instead of being short-circuited, which is how the one-GPU test box
+    covers the branches an 8-GPU node takes (tests/test_rccl_world1_gpu.py)."""
+    return dist is not None and (int(world) > 1 or os.environ.get("QUAKE_FORCE_COLLECTIVES", "0") not in ("", "0"))
 
 
 def owner_of_list(list_no, world, lists_per_rank=None):
@@ -103,7 +113,7 @@ def _reduce_partials(dist, world, sums, counts, ordered=True):
     every rank -- a fixed fp32 summation order, so every rank (and a single-process restatement) gets the same bits; else one
     all-reduce (the order is the collective's: deterministic per topology, not specified)."""
     import torch
-    if dist is None or world == 1:
+    if not collectives_active(dist, world):
         return sums, counts
     ts = sums if torch.is_tensor(sums) else torch.from_numpy(sums)
     tc = counts if torch.is_tensor(counts) else torch.from_numpy(counts)
@@ -132,6 +142,9 @@ def sharded_kmeans(eng, dist, x, m, metric, niter=5, seed=1234, rank=0, world=1,
     trains on the first 256*m/world rows of it and contributes centroid slots [r*m/world, (r+1)*m/world).  With world = 1
     this is exactly qk_kmeans.
 
+    IP: the local rows are normalised IN PLACE (eng.normalize_rows) -- the caller stores the normalised copy, as
+    QuakeIndex::build does -- so hand over a copy if the raw rows are still needed.
+
     eng: the per-rank arithmetic -- quake_amd.capi.Context (libquake_hip.so), or any object with normalize_rows,
     rand_perm, kmeans_assign, kmeans_accumulate, kmeans_update (the gloo tests inject an oracle-backed one).
     Returns (centroids [m, d], assign [n_r])."""
@@ -156,7 +169,7 @@ def sharded_kmeans(eng, dist, x, m, metric, niter=5, seed=1234, rank=0, world=1,
     else:
         xt = np.ascontiguousarray(x[perm[:ntrain]]) if sub else x
         c_local = np.ascontiguousarray(x[perm[:m_r]])
-    if dist is not None and world > 1:
+    if collectives_active(dist, world):
         call = _all_gather_cat(dist, world, c_local if is_t else torch.from_numpy(c_local))
         c = call if is_t else call.numpy()
     else:
@@ -199,7 +212,7 @@ class ShardedIndex:
         self.last_pids = None
         # gloo (two ranks sharing one GPU in the functional tests) has no device all-to-all: stage through the host there
         self._stage_host = False
-        if dist is not None and self.world > 1:
+        if collectives_active(dist, self.world):
             try:
                 self._stage_host = str(dist.get_backend()).lower() == "gloo"
             except Exception:
@@ -240,7 +253,7 @@ class ShardedIndex:
     def search(self, q, nprobe, k, out=None):
         import torch
         Q = q.shape[0]
-        if self.world == 1 or self.dist is None:
+        if not collectives_active(self.dist, self.world):
             pids = self.last_pids = self.engine.coarse(q, nprobe)
             ids, keys = self.engine.scan(q, pids, k, out=out)
             return self.engine.merge(ids.reshape((1,) + tuple(ids.shape)), keys.reshape((1,) + tuple(keys.shape)))

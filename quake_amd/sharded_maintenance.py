@@ -30,7 +30,7 @@ GpuPartitions implements it on libquake_hip.so (over an index.QuakeIndex); the g
 """
 import numpy as np
 
-from .sharded import owner_of_list, owners_of_lists
+from .sharded import collectives_active, owner_of_list, owners_of_lists
 
 
 _SEQ = 1 << 40  # row-order keys: (position of the source list) * _SEQ + row
@@ -42,7 +42,7 @@ class Comm:
 
     def __init__(self, dist=None, world=1, rank=0, device=None):
         self.dist, self.world, self.rank = dist, int(world), int(rank)
-        self.active = dist is not None and self.world > 1
+        self.active = collectives_active(dist, self.world)
         self.device = device
         if self.active and device is None:
             import torch
@@ -62,6 +62,17 @@ class Comm:
         out = torch.empty((self.world * t.shape[0],), dtype=t.dtype, device=t.device)
         self.dist.all_gather_into_tensor(out, t)
         return out.cpu().numpy().reshape((self.world,) + a.shape)
+
+    def all_gather_var(self, a):
+        """1-D int64 arrays of different lengths -> their concatenation in rank order, on every rank"""
+        a = np.ascontiguousarray(a, dtype=np.int64)
+        if not self.active:
+            return a
+        n = self.all_gather(np.array([len(a)], np.int64)).reshape(-1)
+        pad = np.full(max(int(n.max()), 1), -1, np.int64)
+        pad[:len(a)] = a
+        g = self.all_gather(pad)
+        return np.concatenate([g[r, :int(n[r])] for r in range(self.world)])
 
     def all_sum(self, a):
         """integer sum over ranks (exact)"""
@@ -205,6 +216,7 @@ class ShardedPartitions:
         ids = local.list_ids()
         self._next_pid = (max(ids) + 1) if ids else 0
         self._gsizes = None
+        self._refresh_sizes()  # (construction is collective: every rank builds its ShardedPartitions at the same point)
         self.maintenance_policy_params_ = None
         self.maintenance_policy_ = None
         self._policy_cost_estimator = None
@@ -225,11 +237,17 @@ class ShardedPartitions:
     def nlist(self):
         return len(self.local.list_ids())
 
+    def _refresh_sizes(self):
+        """COLLECTIVE: global list sizes (one all-reduce).  Called at the end of every mutating collective (construction, add,
+        remove, split, delete, refine), so that the getters below -- ntotal(), _partition_sizes(), record_query_hits() -- never
+        start a collective themselves and may be called on one rank only (logging on rank 0 would otherwise hang the job)."""
+        pids = self.local.list_ids()
+        g = self.comm.all_sum(np.array([self.local.list_size(p) for p in pids], np.int64))
+        self._gsizes = dict(zip(pids, (int(v) for v in g)))
+
     def _sizes(self):
         if self._gsizes is None:
-            pids = self.local.list_ids()
-            g = self.comm.all_sum(np.array([self.local.list_size(p) for p in pids], np.int64))
-            self._gsizes = dict(zip(pids, (int(v) for v in g)))
+            raise RuntimeError("global list sizes are stale: a mutating collective did not finish with _refresh_sizes()")
         return self._gsizes
 
     def _partition_sizes(self, pids):
@@ -298,7 +316,7 @@ class ShardedPartitions:
                 m = rslot == j
                 self.local.add_entries(pid, ri[m], rv[m])
         self.local.add_centroids(clustering["centroids"], new_pids)
-        self._gsizes = None
+        self._refresh_sizes()
         return new_pids
 
     # -- delete (:522-554) -----------------------------------------------------------------------------------------------------
@@ -322,7 +340,7 @@ class ShardedPartitions:
             for t in np.unique(rt):
                 m = rt == t
                 self.local.add_entries(int(t), ri[m], rv[m])
-        self._gsizes = None
+        self._refresh_sizes()
 
     # -- local refinement (:446-487 -> kmeans_refine_partitions, clustering.cpp:99-182) -----------------------------------------
     def refine_partitions(self, partition_ids=None, iterations=0):
@@ -358,12 +376,16 @@ class ShardedPartitions:
             counts = self.comm.all_sum(pc)
             order = np.argsort(a, kind="stable")  # the per-vector append into the new partitions (:174)
             x, ids, a, seq = x[order], ids[order], a[order], seq[order]
+            # position of every row in the order ONE process would hold them in after this pass: by (list it was appended to,
+            # position before the pass) -- the stable sort above, made global: its rank among all ranks' previous positions
+            # (local rows stay in ascending position order, which the next pass's stable sort relies on)
+            if self.comm.active:
+                seq = a.astype(np.int64) * _SEQ + np.searchsorted(np.sort(self.comm.all_gather_var(seq)), seq)
         if int(counts.sum()) != total:
             raise RuntimeError("refine_partitions: %d of %d vectors could not be assigned (NaN centroid from an emptied cluster)"
                                % (total - int(counts.sum()), total))
         dest = owners_of_lists(np.asarray(pids, np.int64)[a], self.world)
-        # rows of a new list arrive in the order of the original concatenation: with one assignment pass that is the order a
-        # single rank would append them in
+        # rows of a new list arrive in ascending position: the order a single rank would append them in
         ra, rx, ri = self.comm.route_rows(dest, a, x, ids, key=seq)
         # replace the partitions (:481-483): every old list goes before the first new row comes in (a row that changes lists
         # must not be forgotten again when its old list is dropped)
@@ -375,12 +397,12 @@ class ShardedPartitions:
                 sel = ra == j
                 self.local.add_entries(p, ri[sel], rx[sel])
         self.local.set_centroids(pids, c)  # parent_->modify (:478): "the centroids used for the last assignment"
-        self._gsizes = None
+        self._refresh_sizes()
 
     # -- sharded add / remove bookkeeping -----------------------------------------------------------------------------------------
     def invalidate_sizes(self):
-        """after ShardedIndex.add / remove changed the lists"""
-        self._gsizes = None
+        """after ShardedIndex.add / remove changed the lists (collective, like the add / remove itself)"""
+        self._refresh_sizes()
 
     # -- the policy (quake_index.cpp:152-168; maintenance_policies.cpp) ---------------------------------------------------------
     def initialize_maintenance_policy(self, params, cost_estimator=None):
@@ -484,12 +506,16 @@ class ShardedQuakeIndex:
             pad = (-n) % self.world
             if pad:
                 xd = torch.cat([xd, xd[-1:].expand(pad, -1)]).contiguous()
-            was = self.searcher.result
+            was, was_track = self.searcher.result, self.track_hits
             self.searcher.result = "all"  # the harness wants the whole answer on every rank
+            self.track_hits = False       # (the padding rows are not queries: hits are recorded below, for the first n rows)
             try:
                 ids, dist = self.search(xd, min(max(int(sp.nprobe), 1), self.nlist()), kk)
             finally:
-                self.searcher.result = was
+                self.searcher.result, self.track_hits = was, was_track
+            if self.track_hits:
+                p = self.searcher.last_pids
+                self.partitions.record_query_hits((p.cpu().numpy() if torch.is_tensor(p) else np.asarray(p))[:n])
             from .index import SearchResult
             res = SearchResult()
             res.ids, res.distances = ids[:n].cpu(), dist[:n].cpu()
