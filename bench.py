@@ -31,9 +31,14 @@ timed region.  `cpu_baseline` times oracle/ (the CPU port of the reference path)
 of the same queries; the ids of the bench batch must equal the batched oracle's, bit for bit, or the run fails.
 """
 import argparse
+import csv
+import glob
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -232,7 +237,7 @@ def timed_region(ctx, step, nprobe, steps, warmup, settle, dist, dev, ctxs=None)
     return elapsed, ev, ev_ph
 
 
-def roofline_of(scan_bytes, ev, traffic=None, kernel="k_scan", pair_rows=None, d=None):
+def roofline_of(scan_bytes, ev, traffic=None, kernel="k_scan", pair_rows=None, d=None, traffic_source=None):
     """the launch against both roofs: unique bytes / time against the HBM peak, and -- when `pair_rows` (rows x probing queries,
     summed over the probed lists) is given -- 2*d flops per (row, query) against the dense fp32 MFMA peak (bit parity pins the
     path to fp32 matrix instructions).  `bound` names the roof that gives the LONGER minimum time for this batch; the top-level
@@ -241,7 +246,8 @@ def roofline_of(scan_bytes, ev, traffic=None, kernel="k_scan", pair_rows=None, d
     achieved = scan_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
     r = {
         "kernel": kernel, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source if traffic is not None else None,
+        "traffic_over_algorithmic": round(traffic / scan_bytes, 3) if traffic and scan_bytes else None,
         "algorithmic_bytes_per_launch": int(scan_bytes), "kernel_ms_avg": round(scan_ms, 5), "launches": ev["calls"],
     }
     if pair_rows is not None and scan_ms > 0:
@@ -265,6 +271,61 @@ def phases_of(ev_ph):
             "note": "separate untimed pass with events around every phase"}
 
 
+def measured_traffic(args, nprobe, manifold, timeout=420):
+    """HBM bytes per partition-scan launch, measured in THIS run: a rocprofv3 pass (--pmc FETCH_SIZE, kernel trace only: PMC
+    collection gets its own process, MI355X_MICROARCH.md "HBM / rocprofv3") over a short replay of the same workload
+    (`bench.py --traffic-probe`: same corpus, index, batches and nprobe; 8 searches).  FETCH_SIZE is reported in KB and, on
+    gfx950, tallies the 128-B requests of wide streaming reads at 64 B: x 1024 x 2.  None when rocprofv3 is not on the box,
+    the pass fails, or QUAKE_BENCH_NO_PMC is set."""
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None or os.environ.get("QUAKE_BENCH_NO_PMC"):
+        return None
+    tmp = tempfile.mkdtemp(prefix="quake_pmc_", dir="/tmp")
+    cmd = [exe, "--kernel-trace", "--pmc", "FETCH_SIZE", "--output-format", "csv", "-d", tmp, "--", sys.executable,
+           os.path.abspath(__file__), "--traffic-probe", "--nprobe", str(nprobe), "--nvec", str(args.nvec), "--dim", str(args.dim),
+           "--nlist", str(args.nlist), "--batch", str(args.batch), "--k", str(args.k), "--metric", args.metric,
+           "--sigma", str(args.sigma), "--niter", str(args.niter), "--manifold", str(manifold)]
+    try:
+        env = dict(os.environ, TMPDIR="/tmp", QUAKE_BENCH_NO_PMC="1")
+        r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout)
+        if r.returncode != 0:
+            log("rocprofv3 traffic pass failed:", r.stderr[-400:])
+            return None
+        tot, n = {}, {}
+        for f in glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True):
+            for row in csv.DictReader(open(f)):
+                if row.get("Counter_Name") == "FETCH_SIZE" and "k_scan" in row.get("Kernel_Name", ""):
+                    kn = row["Kernel_Name"].split("(")[0]
+                    tot[kn] = tot.get(kn, 0.0) + float(row["Counter_Value"])
+                    n[kn] = n.get(kn, 0) + 1
+        if not tot:
+            return None
+        kn = max(tot, key=tot.get)
+        return {"bytes_per_launch": int(tot[kn] / n[kn] * 1024 * 2), "kernel": kn.replace("void ", ""), "launches": n[kn]}
+    except Exception as e:  # (a profiler problem must never cost the bench line)
+        log("rocprofv3 traffic pass skipped:", repr(e)[:200])
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def run_traffic_probe(ctx, dev, args):
+    """`--traffic-probe`: the replay the rocprofv3 pass of measured_traffic() wraps -- build, then 8 searches at the given nprobe"""
+    n, d, nlist, k, Q, metric = args.nvec, args.dim, args.nlist, args.k, args.batch, args.metric
+    unit = metric == "ip"
+    if args.manifold:
+        x, basis = gen_manifold(n, d, seed=1, device=dev, latent=args.manifold)
+        batches = [gen_manifold(Q, d, seed=2 + b, device=dev, latent=args.manifold, basis=basis)[0] for b in range(N_BATCHES)]
+    else:
+        x, cent_true = gen_mixture(n, d, nlist, seed=1, device=dev, sigma=args.sigma, unit=unit)
+        batches = [gen_queries(Q, cent_true, seed=2 + b, device=dev, sigma=args.sigma, unit=unit) for b in range(N_BATCHES)]
+    idx = build_single(ctx, dev, x, nlist, metric, args.niter, keep_host=False)
+    del x
+    for i in range(8):
+        ctx.search(idx["parent"], idx["store"], batches[i % N_BATCHES], max(args.nprobe, 1), k, metric)
+    torch.cuda.synchronize()
+
+
 def committed_traffic(name, n, d, k, nprobe):
     """HBM bytes per k_scan launch from the committed rocprofv3 PMC pass of this command (profiles/<name>), if it matches
     the configuration that just ran; a PMC pass cannot run inside this process."""
@@ -281,7 +342,7 @@ def committed_traffic(name, n, d, k, nprobe):
 
 
 def run_single_workload(ctx, dev, args, name, sigma, fixed_nprobe, steps, warmup, settle, cpu_seconds, traffic_file=None,
-                        manifold=0):
+                        manifold=0, sweep_nprobes=()):
     """Build, sweep nprobe, time, verify against the oracle.  Returns the result dict of one single-GPU workload.
     manifold > 0: the low-intrinsic-dimension corpus (gen_manifold, latent dimension `manifold`) instead of the mixture."""
     n, d, nlist, k, Q, metric = args.nvec, args.dim, args.nlist, args.k, args.batch, args.metric
@@ -346,7 +407,53 @@ def run_single_workload(ctx, dev, args, name, sigma, fixed_nprobe, steps, warmup
     # rows x probing queries over the probed lists (mean over the rotated batches): the flops side of the same launch
     scan_kernel = ctx.last_scan_kernel()  # (before the coarse calls below: they are launches of their own)
     cnt_t = torch.as_tensor(idx["counts"], device=dev)
-    pair_rows = int(sum(int(cnt_t[ctx.coarse(parent, batches[b], nprobe, metric)[0]].sum().item()) for b in range(N_BATCHES)) // N_BATCHES)
+
+    def pair_rows_of(npb):
+        return int(sum(int(cnt_t[ctx.coarse(parent, batches[b], npb, metric)[0]].sum().item()) for b in range(N_BATCHES)) // N_BATCHES)
+
+    pair_rows = pair_rows_of(nprobe)
+    # HBM traffic of the scan launch: measured in this run (a rocprofv3 PMC pass over a replay of the workload) when the profiler is
+    # on the box, else the committed pass of the same configuration (profiles/), marked as such
+    traffic, traffic_source = None, None
+    if not args.no_pmc:
+        mt = measured_traffic(args, nprobe, manifold)
+        if mt is not None:
+            traffic, traffic_source = mt["bytes_per_launch"], f"rocprofv3 --pmc FETCH_SIZE in this run ({mt['kernel']}, {mt['launches']} launches; x1024 x2: KB, gfx950 wide-read tally)"
+    if traffic is None and traffic_file:
+        traffic = committed_traffic(traffic_file, n, d, k, nprobe)
+        traffic_source = f"committed: profiles/{traffic_file}" if traffic is not None else None
+    # the caller-visible rate through the reference's CPU-tensor API: host buffers in and out (QK_MEM_HOST: the queries cross
+    # PCIe, the answers come back, one synchronisation per call) -- reported beside `value`, never as it
+    host_api = None
+    if not args.no_host_api:
+        hq = [b.cpu().numpy() for b in batches]
+        for i in range(20):
+            ctx.search(parent, store, hq[i % N_BATCHES], nprobe, k, metric)
+        nh = max(20, min(steps, 100))
+        t1 = time.perf_counter()
+        for i in range(nh):
+            ctx.search(parent, store, hq[i % N_BATCHES], nprobe, k, metric)
+        dt = time.perf_counter() - t1
+        host_api = {"value": round(Q * nh / dt, 1), "unit": "queries/s", "ms_per_step": round(1e3 * dt / nh, 4), "steps": nh,
+                    "note": "numpy queries in, numpy ids / distances out (QK_MEM_HOST): H2D of the batch, the same qk_search, D2H of the "
+                            "answers and a synchronisation per call -- what a caller of the reference's CPU-tensor API sees"}
+    # the shared-list regime on the same index: fixed nprobe values, each with its own roofline (short timed regions)
+    sweep_res = []
+    for npb in sweep_nprobes:
+        if npb == nprobe:
+            continue
+        e_s, ev_s, _ = timed_region(ctx, step, npb, 30, 5, 20, None, dev, ctxs=[ctx])
+        ctx.set_timing(1)
+        sb = int(sum(int(ctx.search(parent, store, batches[b], npb, k, metric, timing=True)[2]["scan_bytes"]) for b in range(N_BATCHES)) // N_BATCHES)
+        ctx.set_timing(0)
+        kern = ctx.last_scan_kernel()
+        ri = step(npb, 0)[0]
+        torch.cuda.synchronize()
+        mt = None if args.no_pmc else measured_traffic(args, npb, manifold)
+        sweep_res.append({"nprobe": npb, "value": round(Q * 30 / e_s, 1), "unit": "queries/s", "ms_per_step": round(1e3 * e_s / 30, 4),
+                          "steps": 30, "recall_at_k": round(recall_at_k(ri, gts[0], k), 4),
+                          "roofline": roofline_of(sb, ev_s, mt["bytes_per_launch"] if mt else None, kernel=kern, pair_rows=pair_rows_of(npb), d=d,
+                                                  traffic_source=f"rocprofv3 --pmc FETCH_SIZE in this run ({mt['kernel']}, {mt['launches']} launches)" if mt else None)})
     res = {
         "value": round(Q * steps / elapsed, 1), "unit": "queries/s", "ms_per_step": round(1e3 * elapsed / steps, 4),
         "steps": steps, "warmup": warmup,
@@ -359,11 +466,13 @@ def run_single_workload(ctx, dev, args, name, sigma, fixed_nprobe, steps, warmup
             "query_batches_rotated": N_BATCHES,
         },
         "batches_in_flight": piped,
-        "roofline": roofline_of(scan_bytes, ev, committed_traffic(traffic_file, n, d, k, nprobe) if traffic_file else None,
-                                kernel=scan_kernel, pair_rows=pair_rows, d=d),
+        "roofline": roofline_of(scan_bytes, ev, traffic, kernel=scan_kernel, pair_rows=pair_rows, d=d, traffic_source=traffic_source),
+        "host_api": host_api,
         "phases_ms": phases_of(ev_ph),
         "build": {"kmeans_s": round(idx["kmeans_s"], 2), "niter": args.niter},
     }
+    if sweep_res:
+        res["nprobe_sweep"] = sweep_res
     # ---- parity + CPU baseline: the oracle port on the host cores (test infrastructure used as checker / timed port) ----
     if want_cpu:
         import oracle as O
@@ -409,7 +518,9 @@ def run_single_workload(ctx, dev, args, name, sigma, fixed_nprobe, steps, warmup
             "single_thread_qps": round(qps_1, 1), "threads_speedup": round(max(qps_b, qps_s) / max(qps_1, 1e-9), 1),
             "effective_cores_measured": eff_cores,
             "ids_equal_to_gpu_frac": same_ids, "distance_bits_equal_to_gpu_frac": same_dist,
-            "ids_equal_serial_lane_sum_frac": round(float((ids_s == gi0).mean()), 5),
+            # (NOT a parity figure: the timed serial leg sums like FAISS's AVX2 row loop -- 8 lane partial sums -- which is not the
+            #  canonical order, so a near-tie may land the other way round; the checker is the batched oracle above)
+            "timed_serial_leg_ids_agree_frac": round(float((ids_s == gi0).mean()), 5),
         }
         res["speedup_vs_cpu"] = round(res["value"] / res["cpu_baseline"]["value"], 1)
         if inflight > 1:  # the other stream's answer for the same batch: the same bits
@@ -661,6 +772,9 @@ def main():
     ap.add_argument("--inflight", type=int, default=2,
                     help="extra measurement beside the timed region: the same steps rotated over this many HIP streams (1 = skip)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-pmc", action="store_true", help="skip the in-run rocprofv3 FETCH_SIZE pass (roofline.traffic falls back to profiles/)")
+    ap.add_argument("--no-host-api", action="store_true", help="skip the host-buffer (QK_MEM_HOST) rate")
+    ap.add_argument("--traffic-probe", action="store_true", help="internal: the short replay measured_traffic() profiles")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -702,10 +816,14 @@ def main():
         ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     log("device", ctx.device_info())
     t_all = time.time()
+    if args.traffic_probe:
+        run_traffic_probe(ctx, dev, args)
+        return
 
     if world == 1 and not force_sharded:
         main_res = run_single_workload(ctx, dev, args, "headline", args.sigma, args.nprobe, args.steps, args.warmup, args.settle,
-                                       args.cpu_seconds, traffic_file="r02_pmc_k_scan.json", manifold=args.manifold)
+                                       args.cpu_seconds, traffic_file="r03_pmc_k_scan.json", manifold=args.manifold,
+                                       sweep_nprobes=() if (args.no_extra or args.manifold) else (8, 16, 32))
         cfg_no = 2 if (args.metric == "ip" and args.dim == 768) else 1
         main_res["config"]["workload"] += f" (BASELINE.json configs[{cfg_no}])"
         main_res["config"]["sharding"] = "single GPU"
@@ -720,6 +838,8 @@ def main():
     }
     if main_res.get("batches_in_flight"):
         result["batches_in_flight"] = main_res["batches_in_flight"]
+    if main_res.get("host_api"):
+        result["host_api"] = main_res["host_api"]
     if world == 1 and not force_sharded:
         result["cpu_baseline"] = main_res.get("cpu_baseline")
         if "speedup_vs_cpu" in main_res:
@@ -728,9 +848,13 @@ def main():
             extra = {}
             hard_steps = max(20, min(args.steps, 100))
             extra["hard"] = run_single_workload(ctx, dev, args, "hard", 0.0, 0, hard_steps, min(args.warmup, 10),
-                                                min(args.settle, 50), args.cpu_seconds * 0.5, traffic_file="r02_pmc_k_scan_hard.json",
+                                                min(args.settle, 50), args.cpu_seconds * 0.5, traffic_file="r03_pmc_k_scan_hard.json",
                                                 manifold=args.hard_latent)
             extra["configs0"] = run_configs0(ctx, dev, args)
+            if main_res.get("nprobe_sweep"):
+                # the headline index at fixed nprobe 8 / 16 / 32: the regime where a probed list is shared by many queries of the
+                # batch (the mixed work sequence of the row-per-lane scan), each line with its own roofline
+                extra["nprobe_sweep"] = main_res["nprobe_sweep"]
             result["workloads"] = extra
 
     log(f"total bench wall {time.time() - t_all:.1f}s")
