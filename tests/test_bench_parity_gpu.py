@@ -1,6 +1,8 @@
 """HIP path vs the CPU oracle, BIT-EXACT, at BASELINE.json's sizes -- the bench batches themselves, not scaled-down stand-ins:
 
-  configs[1]  10M x 128 L2, nlist 4096, 1024 queries, k 10   (the bench's own corpus / index / batch; nprobe 1 and 8)
+  configs[1]  10M x 128 L2, nlist 4096, 1024 queries, k 10   (the bench's own corpus / index / batch; nprobe 1, 8 and 32: k_scan,
+              and the mixed work sequence of the row-per-lane scan with its bf16 prefilter) and the bench's second corpus
+              (latent dimension 10, nprobe 16)
   configs[2]  10M x 768 IP, nlist 4096, 1024 queries, k 100  (nprobe 1 and 4)
   configs[0]  S-SIFT 1M x 128 integer-valued, nlist 1024, nprobe 10, k 10: batch = 1 and batch = 1000 against the SERIAL
               oracle (scan_list's direct-form distances) -- on integer data the direct and the expanded forms are both exact,
@@ -36,19 +38,27 @@ def _assert_same(gi, gd, oi, od, what):
     assert (gd.view(np.uint32) == od.view(np.uint32)).all(), f"{what}: distance bits differ"
 
 
-def _bench_case(ctx, n, d, nlist, k, metric, nprobes, sigma=0.3):
+def _bench_case(ctx, n, d, nlist, k, metric, nprobes, sigma=0.3, manifold=0, forms=None):
     import oracle as O
     dev = torch.device("cuda", 0)
-    x, cent_true = B.gen_mixture(n, d, nlist, seed=1, device=dev, sigma=sigma, unit=metric == "ip")
+    if manifold:
+        x, basis = B.gen_manifold(n, d, seed=1, device=dev, latent=manifold)
+    else:
+        x, cent_true = B.gen_mixture(n, d, nlist, seed=1, device=dev, sigma=sigma, unit=metric == "ip")
     idx = B.build_single(ctx, dev, x, nlist, metric, niter=5, keep_host=True)
     del x
-    q = B.gen_queries(1024, cent_true, seed=2, device=dev, sigma=sigma, unit=metric == "ip")  # the bench's batch 0
+    if manifold:
+        q = B.gen_manifold(1024, d, seed=2, device=dev, latent=manifold, basis=basis)[0]  # the bench's batch 0
+    else:
+        q = B.gen_queries(1024, cent_true, seed=2, device=dev, sigma=sigma, unit=metric == "ip")  # the bench's batch 0
     hv, hi, ho, hc = idx["host"]
     qh = q.cpu().numpy()
     for nprobe in nprobes:
         gi, gd = ctx.search(idx["parent"], idx["store"], q, nprobe, k, metric)
         torch.cuda.synchronize()
-        oi, od = O.search(qh, hc, hv, hi, ho, nprobe, k, metric, batched_scan=True)
+        if forms:
+            assert ctx.last_scan_kernel() == forms[nprobe], (nprobe, ctx.last_scan_kernel())
+        oi, od = O.search(qh, hc, hv, hi, ho, nprobe, k, metric, batched_scan=True, num_threads=O.max_threads())
         _assert_same(gi, gd, oi, od, f"{n}x{d} {metric} nprobe={nprobe} k={k}")
     idx["store"].close()
     idx["parent"].close()
@@ -56,12 +66,14 @@ def _bench_case(ctx, n, d, nlist, k, metric, nprobes, sigma=0.3):
 
 
 def test_configs1_bench_batch_bit_exact(ctx):
-    _bench_case(ctx, 10_000_000, 128, 4096, 10, "l2", (1, 8))
+    _bench_case(ctx, 10_000_000, 128, 4096, 10, "l2", (1, 4, 8, 32),
+                forms={1: "k_scan", 4: "k_scan_rl", 8: "k_scan_rl (mixed)", 32: "k_scan_rl (mixed)"})
 
 
-def test_configs1_hard_mixture_bit_exact(ctx):
-    """the bench's second workload (sigma 1.0: overlapping components, many queries per probed list)"""
-    _bench_case(ctx, 10_000_000, 128, 4096, 10, "l2", (16,), sigma=1.0)
+def test_configs1_hard_corpus_bit_exact(ctx):
+    """the bench's second workload (`workloads.hard`: x = zA + noise, latent dimension 10 -- no cluster structure, recall 0.9
+    needs nprobe 16, every list is probed by several queries of the batch)"""
+    _bench_case(ctx, 10_000_000, 128, 4096, 10, "l2", (16,), manifold=10, forms={16: "k_scan_rl (mixed)"})
 
 
 def test_configs2_bench_batch_bit_exact(ctx):
