@@ -871,6 +871,27 @@ int qk_dense_device(qk_ctx *ctx, qk_store *s, int64_t list_no, const qk_scan_arg
         }
         return QK_OK;
     }
+    static const bool no_pf = qk_env_set("QK_NO_DENSE_PF");
+    if (a.x && a.out_ids && !no_pf && qk_dense_pf_supported(ctx, s, Q, nrows, k)) {
+        // 2 <= k <= 64, d <= 128, thousands of rows: no key matrix -- approximate keys on bf16 MFMA settle which rows can matter,
+        // the exact keys of those candidates the answer (qk_dense_pf.hip)
+        QK_TRY(pe.mark(0));
+        QK_TRY(pe.mark(1));
+        QK_TRY(qk_dense_pf_device(ctx, s, pt.row_off, nrows, a));
+        QK_TRY(pe.mark(2));
+        QK_TRY(pe.mark(3));
+        if (timing) {
+            QK_TRY(qk_pinned_reserve(ctx, 64));
+            int32_t *hs = (int32_t *)ctx->pinned;
+            QK_HIP(hipStreamSynchronize(st));
+            hs[0] = 1;
+            hs[1] = 0;
+            hs[7] = (int32_t)std::min<int64_t>(Q, INT32_MAX);
+            int64_t rows = nrows;
+            memcpy(hs + 2, &rows, sizeof(rows));
+        }
+        return QK_OK;
+    }
     const int64_t ld = qk_round_up64(std::max(nrows, 1), 16);
     const int Cm = qk_round_up(k + 64, 64);
     const bool large_k = Cm > 1024;  // beyond the LDS pool machinery: bisection select + sort (k_select_rows_large)

@@ -226,6 +226,9 @@ int qk_search_small_device(qk_ctx *ctx, qk_store *parent, qk_store *s, const flo
                            int64_t *out_ids, float *out_dist, bool sqrt_l2);
 // dense form (every query x one list, Q large): distance matrix on MFMA + per-query select.  qk_dense.hip
 int qk_dense_device(qk_ctx *ctx, qk_store *s, int64_t list_no, const qk_scan_args &a, qk_timing *timing, int ev_base);
+// top-k of every query over one list without a key matrix: bf16 prefilter + exact finish (qk_dense_pf.hip; 2 <= k <= 64, d <= 128)
+bool qk_dense_pf_supported(const qk_ctx *ctx, const qk_store *s, int64_t Q, int nrows, int k);
+int qk_dense_pf_device(qk_ctx *ctx, qk_store *s, int64_t row_off, int nrows, const qk_scan_args &a);
 // k > QK_MAX_K over several lists: emit every key (qk_scan_device in emission mode), then exact selection per query.  qk_dense.hip
 int qk_widek_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *timing, int ev_base);
 constexpr int QK_MAX_WIDE_K = 8192;  // = the reference's TOP_K_BUFFER_CAPACITY (list_scanning.h:39)

@@ -1,0 +1,90 @@
+"""The coarse step without a key matrix (qk_dense_pf.hip: approximate keys on bf16 MFMA bound which rows can be among a query's
+k nearest, the exact k-ordered fmaf chain of those candidates is the answer) against the oracle's parent search
+(query_coordinator.cpp:628-644 -> batched_scan_list, list_scanning.h:313-366): ids and float32 distance bits."""
+import numpy as np
+import pytest
+
+import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from quake_amd.capi import Context
+    c = Context(0)
+    yield c
+    c.close()
+
+
+def _parent(ctx, cent, ids=None):
+    from quake_amd.capi import Store
+    n, d = cent.shape
+    p = Store(ctx, d)
+    p.build_csr(np.array([0, n], np.int64), np.arange(n, dtype=np.int64) if ids is None else ids, cent)
+    return p
+
+
+def _check(ctx, parent, cent, q, k, metric, ids=None):
+    gp, gd = ctx.coarse(parent, q, k, metric)
+    op, od = O.coarse(q, cent, ids, k, metric)
+    np.testing.assert_array_equal(gp, op)
+    np.testing.assert_array_equal(gd.view(np.uint32), od.view(np.uint32))
+
+
+@pytest.mark.parametrize("metric", ["l2", "ip"])
+@pytest.mark.parametrize("d", [128, 100, 32])
+def test_coarse_prefiltered_matches_oracle(ctx, metric, d):
+    rng = np.random.default_rng(7 + d)
+    for n in (1024, 4096, 5000, 20000):
+        cent = rng.standard_normal((n, d)).astype(np.float32)
+        if metric == "ip":
+            cent /= np.linalg.norm(cent, axis=1, keepdims=True)
+        parent = _parent(ctx, cent)
+        for nq in (64, 100, 1024):
+            q = (cent[rng.integers(0, n, nq)] + 0.3 * rng.standard_normal((nq, d))).astype(np.float32)
+            if metric == "ip":
+                q /= np.linalg.norm(q, axis=1, keepdims=True)
+            for k in (2, 10, 32, 64):
+                _check(ctx, parent, cent, q, k, metric)
+        parent.close()
+
+
+def test_coarse_prefiltered_65536_centroids(ctx):
+    rng = np.random.default_rng(3)
+    cent = rng.standard_normal((65536, 128)).astype(np.float32)
+    parent = _parent(ctx, cent)
+    q = (cent[rng.integers(0, 65536, 512)] + 0.5 * rng.standard_normal((512, 128))).astype(np.float32)
+    _check(ctx, parent, cent, q, 32, "l2")
+    parent.close()
+
+
+def test_ties_duplicates_and_candidate_overflow(ctx):
+    """exact duplicates straddling the k-th place (the (key, id) order decides), shuffled ids, and a list in which every row is
+    a candidate of every query -- the candidate lists overflow and the finish walks all rows"""
+    rng = np.random.default_rng(11)
+    base = rng.integers(0, 6, size=(300, 64)).astype(np.float32)     # SIFT-like integers: exact arithmetic, many ties
+    cent = base[rng.integers(0, 300, 6000)]
+    ids = rng.permutation(6000).astype(np.int64) + 17
+    parent = _parent(ctx, cent, ids)
+    q = (base[rng.integers(0, 300, 200)] + rng.integers(-1, 2, size=(200, 64))).astype(np.float32)
+    for k in (5, 40, 64):
+        _check(ctx, parent, cent, q, k, "l2", ids)
+    parent.close()
+    same = np.tile(rng.standard_normal((1, 128)).astype(np.float32), (4000, 1))  # 4000 copies of one vector
+    parent = _parent(ctx, same)
+    q = rng.standard_normal((70, 128)).astype(np.float32)
+    _check(ctx, parent, same, q, 10, "l2")
+    _check(ctx, parent, same, q, 10, "ip")
+    parent.close()
+
+
+def test_large_norm_spread(ctx):
+    """rows of very different norms (the bound scales with |x|^2 + |y|^2): tiny rows next to huge ones"""
+    rng = np.random.default_rng(13)
+    cent = rng.standard_normal((8192, 96)).astype(np.float32) * np.exp(rng.uniform(-6, 6, size=(8192, 1))).astype(np.float32)
+    parent = _parent(ctx, cent)
+    q = (cent[rng.integers(0, 8192, 256)] * (1 + 0.05 * rng.standard_normal((256, 96)))).astype(np.float32)
+    for metric in ("l2", "ip"):
+        _check(ctx, parent, cent, q, 16, metric)
+    parent.close()
