@@ -63,6 +63,9 @@ __device__ __forceinline__ float f4c(const float4 &v, int t) { return t == 0 ? v
 // and a candidate whose bound already loses against the running k-th key cannot enter the top-k.  Everything that IS appended
 // went through the exact chain, so ids and distance bits are those of the unfiltered scan; the k-order of the bf16
 // instruction is free, so its operands are the fp32 fragments converted in place (no second layout).
+// (fp16 operands -- a band of 2^-10 instead of 2^-8, with range guards for |x|^2 > 2^30 and an absolute term for its subnormals --
+//  were built and measured: parity green, fewer row tiles recomputed, and 2-9 % SLOWER at nprobe 8-64: the conversions cost two
+//  to three VALU instructions per value where v_cvt_pk_bf16_f32 converts a pair in one, and the test is VALU-bound.)
 constexpr float QK_PF_C = 0.0041509f;   // >= 2^-8 * 17/16 + 2^-21
 constexpr float QK_PF_K1 = 0.995849f;   // <= 1 - QK_PF_C
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));

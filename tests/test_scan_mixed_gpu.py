@@ -146,3 +146,29 @@ def test_repeated_calls_reuse_counters(ctx):
         pids = skewed_pids(Q, 4, nlist, {0: 520 - 40 * it, 1: 100 + it}, rng)
         check(ctx, s, ivf, q, pids, 10, "l2")
     s.close()
+
+
+@pytest.mark.parametrize("metric", ["l2", "ip"])
+def test_hot_lists_value_range(ctx, metric):
+    """the prefilter's bound over the whole float range: rows and queries with elements of 1e5-1e6 and of 1e-6 next to ordinary
+    ones, in hot lists (bf16 keeps fp32's exponent range: no guard needed; an fp16 variant needed two)"""
+    rng = np.random.default_rng(51)
+    nlist = 1100
+    sizes = rng.integers(1, 60, size=nlist)
+    sizes[:3] = [3000, 1200, 700]
+    ivf = make_sized_ivf(sizes, 96, seed=52)
+    x = ivf["vecs"]
+    x[100:400] *= 3.0e5       # elements ~ 1e5..1e6: beyond 65504
+    x[400:900] *= 1.0e-6      # fp16 subnormals / zeros
+    x[3000:3300] *= 2.0e3     # large but representable
+    if metric == "ip":
+        pass                   # (not normalised: the bound must hold for any norms)
+    s = build(ctx, ivf)
+    Q = 600
+    q = np.ascontiguousarray(x[rng.integers(0, 4900, size=Q)] * (1 + 0.05 * rng.standard_normal((Q, 96))).astype(np.float32))
+    q[:20] *= 1.0e5
+    q[20:40] *= 1.0e-5
+    pids = skewed_pids(Q, 4, nlist, {0: 600, 1: 300, 2: 64}, rng)
+    for k in (1, 10, 32):
+        check(ctx, s, ivf, q, pids, k, metric)
+    s.close()
