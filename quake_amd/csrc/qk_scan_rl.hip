@@ -348,18 +348,16 @@ __device__ __forceinline__ void rl_hot_item(const ScanParams &P, const HotLds &H
         }                                                                                                    \
         const bool livej_ = 16 * (QT_) + j < nq;                                                             \
         const float xk_ = L2 ? xnj_ * QK_PF_K1 : xnj_ * (0.5f * QK_PF_C);                                    \
+        /* the bound as a float (the test is VALU-bound: add + fma + compare per key instead of the key's bits): L2 keys are */ \
+        /* the bits of non-negative floats, IP keys descend with the dot product; "no bound yet" passes everything           */ \
+        const float tauf_ = L2 ? (tauj_ == 0xFFFFFFFFu ? __builtin_inff() : __uint_as_float(tauj_))          \
+                               : (tauj_ == 0xFFFFFFFFu ? -__builtin_inff() : ip_from_ord(tauj_));            \
         bool flag_ = false, flag1_ = false;                                                                  \
         _Pragma("unroll") for (int e_ = 0; e_ < 8; e_++) {                                                   \
             const float dd_ = e_ < 4 ? d0_[e_ & 3] : d1_[e_ & 3];                                            \
-            uint32_t o_;                                                                                     \
-            if (L2) {                                                                                        \
-                const float lo_ = __fmaf_rn(-2.0f, dd_, xk_ + yk_[e_]);                                      \
-                o_ = ord_from_l2(lo_ < 0.0f ? 0.0f : lo_);                                                   \
-            } else {                                                                                         \
-                o_ = ord_from_ip(dd_ + (xk_ + yk_[e_]));                                                     \
-            }                                                                                                \
-            if (e_ < 4) flag_ |= rv_[e_] & (o_ <= tauj_);                                                    \
-            else flag1_ |= rv_[e_] & (o_ <= tauj_);                                                          \
+            const bool p_ = L2 ? (__fmaf_rn(-2.0f, dd_, xk_ + yk_[e_]) <= tauf_) : (dd_ + (xk_ + yk_[e_]) >= tauf_); \
+            if (e_ < 4) flag_ |= rv_[e_] & p_;                                                               \
+            else flag1_ |= rv_[e_] & p_;                                                                     \
         }                                                                                                    \
         const int um_ = HOT_PF_PROBE((__ballot(flag_ & livej_) ? 1 : 0) | (__ballot(flag1_ & livej_) ? 2 : 0)); \
         dbg_prod += 2;                                                                                       \
