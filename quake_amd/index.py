@@ -653,33 +653,61 @@ class QuakeIndex:
                     meta[kk] = vv
         self.metric_ = int(meta.get("metric", 1))
         self.current_level = int(meta.get("level", 0))
+        # The file is STREAMED into the device arena (dynamic_inverted_list.cpp:421-520 reads partition by partition too): header
+        # and tables first, then windows of whole partitions of at most ~256 MB -- each window is one read into a reusable host
+        # buffer and one qk_store_add_batch (rows, ids and their list numbers; append order = file order).  The host never holds
+        # more than a window (a 10M x 768 index is a 30 GB file).
         with open(os.path.join(dir_path, "partitions"), "rb") as f:
-            blob = f.read()
-        magic, version, nlist, code_size, nparts = struct.unpack_from("<IIQQQ", blob, 0)
-        if magic != SERIALIZATION_MAGIC:
-            raise RuntimeError("Invalid file format (bad magic number).")
-        if version != SERIALIZATION_VERSION:
-            raise RuntimeError("Unsupported file version: %d" % version)
-        d = code_size // 4
-        offs = np.frombuffer(blob, "<u8", nparts + 1, 32)
-        pids = np.frombuffer(blob, "<u8", nparts, 32 + 8 * (nparts + 1))
-        start = 32 + 8 * (nparts + 1) + 8 * nparts
-        rec = code_size + 8
-        self._has_ctx = True
-        self._d = int(d)
-        self._store = capi.Store(self._ctx, int(d))
-        self._resident = _ResidentIds()
-        for i in range(nparts):
-            size = int(offs[i + 1] - offs[i])
-            if size % rec != 0:
+            head = f.read(32)
+            if len(head) < 32:
+                raise RuntimeError("Invalid file format (truncated header).")
+            magic, version, nlist, code_size, nparts = struct.unpack_from("<IIQQQ", head, 0)
+            if magic != SERIALIZATION_MAGIC:
+                raise RuntimeError("Invalid file format (bad magic number).")
+            if version != SERIALIZATION_VERSION:
+                raise RuntimeError("Unsupported file version: %d" % version)
+            d = code_size // 4
+            offs = np.frombuffer(f.read(8 * (nparts + 1)), "<u8", nparts + 1)
+            pids = np.frombuffer(f.read(8 * nparts), "<u8", nparts)
+            rec = code_size + 8
+            sizes = np.diff(offs.astype(np.int64))
+            if (sizes % rec != 0).any():
                 raise RuntimeError("Partition chunk size not divisible by (code_size+sizeof(idx_t))")
-            nv = size // rec
-            vecs = np.frombuffer(blob, "<f4", nv * d, start + int(offs[i])).reshape(nv, d)
-            ids = np.frombuffer(blob, "<i8", nv, start + int(offs[i]) + nv * code_size)
-            self._store.add_list(int(pids[i]))
-            if nv:
-                self._store.add_entries(int(pids[i]), ids.copy(), vecs.copy())
-            self._resident.update(ids.astype(np.int64))
+            nvs = sizes // rec
+            self._has_ctx = True
+            self._d = int(d)
+            self._store = capi.Store(self._ctx, int(d))
+            self._resident = _ResidentIds()
+            window = max(int(256 << 20), int(sizes.max()) if nparts else 0)
+            raw = np.empty(window, np.uint8)
+            i = 0
+            while i < nparts:
+                j, nbytes = i, 0
+                while j < nparts and (j == i or nbytes + int(sizes[j]) <= window):
+                    nbytes += int(sizes[j])
+                    j += 1
+                got = f.readinto(memoryview(raw)[:nbytes])
+                if got != nbytes:
+                    raise RuntimeError("Invalid file format (truncated partition data).")
+                nrows = int(nvs[i:j].sum())
+                wv = np.empty((nrows, d), np.float32)
+                wi = np.empty(nrows, np.int64)
+                wa = np.empty(nrows, np.int64)
+                r0, b0 = 0, 0
+                for t in range(i, j):
+                    nv = int(nvs[t])
+                    self._store.add_list(int(pids[t]))
+                    if nv:
+                        wv[r0:r0 + nv] = raw[b0:b0 + nv * code_size].view("<f4").reshape(nv, d)
+                        wi[r0:r0 + nv] = raw[b0 + nv * code_size:b0 + nv * rec].view("<i8")
+                        wa[r0:r0 + nv] = int(pids[t])
+                    r0 += nv
+                    b0 += int(sizes[t])
+                if nrows:
+                    self._store.add_batch(wi, wv, wa)
+                    self._resident.update(wi)
+                i = j
+            del raw
         self._next_pid = (int(pids.max()) + 1) if nparts else 0
         pdir = os.path.join(dir_path, "parent")
         if os.path.isdir(pdir):

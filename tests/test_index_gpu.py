@@ -2,6 +2,8 @@
 test/cpp/quake_index.cpp:47-251 (constructor/build/flat/search shapes/get/add/remove/ntotal/save-load),
 test/cpp/query_coordinator.cpp:309-371 (k > partition size -> -1 / inf padding), :459-497,
 test/cpp/search_recall_tests.cpp:160-254 (flat recall >= 0.99), and full-search parity with the oracle."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -329,3 +331,44 @@ def test_search_add_remove_maintenance_loop(quake):  # quake_index.cpp:482-529 S
         t = idx.maintenance()  # hits are not tracked by default: the window never fills (maintenance_policies.cpp:36-41)
         assert t.n_splits == 0 and t.n_deletes == 0
     assert idx.ntotal() == n + 30 * 5
+
+
+def test_load_streams_the_file(quake, tmp_path):
+    """load() reads the partitions file in windows of whole partitions (dynamic_inverted_list.cpp:421-520 reads partition by
+    partition): a 1.3 GB index loads with a fraction of its size in extra host memory, list contents and row order intact --
+    odd dimension (ids unaligned in the file), empty lists, lists of one row, several windows"""
+    import resource
+    d, nlist, n = 129, 300, 2_400_000
+    g = torch.Generator().manual_seed(23)
+    cent = torch.randn(nlist, d, generator=g)
+    assign = torch.randint(0, nlist - 3, (n,), generator=g)  # the last three lists stay empty
+    assign[:2] = torch.tensor([nlist - 4, nlist - 4])
+    x = cent[assign] + 0.2 * torch.randn(n, d, generator=g)
+    ids = torch.randperm(n, generator=g) + 5
+    order = torch.argsort(assign, stable=True)
+    counts = torch.bincount(assign, minlength=nlist).numpy().astype(np.int64)
+    offsets = np.zeros(nlist + 1, np.int64)
+    offsets[1:] = np.cumsum(counts)
+    from quake_amd.index import QuakeIndex
+    idx = QuakeIndex.from_partitions(cent.numpy(), offsets, ids[order].numpy(), x[order].numpy(), "l2")
+    path = str(tmp_path / "big")
+    idx.save(path)
+    assert os.path.getsize(path + "/partitions") > 1.2e9
+    del x, order
+    before = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss  # KB, monotone
+    loaded = quake.QuakeIndex()
+    loaded.load(path)
+    grown = (resource.getrusage(resource.RUSAGE_SELF).ru_maxrss - before) / 1e6
+    assert grown < 0.9, f"load() grew the peak host memory by {grown:.2f} GB for a 1.3 GB file"
+    assert loaded.ntotal() == n and loaded.nlist() == nlist
+    for p in (0, 7, nlist - 4, nlist - 1):
+        va, ia = idx._store.get_list(p)
+        vb, ib = loaded._store.get_list(p)
+        np.testing.assert_array_equal(ia, ib)
+        np.testing.assert_array_equal(va, vb)
+    q = cent[:64] + 0.1
+    sp = quake.SearchParams()
+    sp.k, sp.nprobe = 10, 8
+    a, b = idx.search(q, sp), loaded.search(q, sp)
+    np.testing.assert_array_equal(a.ids.numpy(), b.ids.numpy())
+    np.testing.assert_array_equal(a.distances.numpy(), b.distances.numpy())
