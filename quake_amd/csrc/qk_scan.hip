@@ -458,18 +458,24 @@ struct SeedParams {
 template <int M, int CB>
 __device__ __forceinline__ void seed_tau_body(const SeedParams &S, const int64_t w, const int lane) {
     const int64_t qq = w / S.seed_ranks;
-    const int rr = (int)(w % S.seed_ranks);
+    int rr = (int)(w % S.seed_ranks);
     if (rr >= S.P) return;
-    const int64_t pair = qq * S.P + rr;
-    int64_t p;
-    if (S.pids_packed) {
-        const unsigned long long v = S.pids_packed[pair];
-        p = v == ~0ull ? -1 : (int64_t)(v & 0xFFFFFFFFull);
-    } else {
-        p = S.pids ? S.pids[pair] : (pair % S.P);
+    int64_t p = -1;
+    int size_p = 0;
+    // one seeded rank: the nearest list that HOLDS k rows here (a rank of a sharded index owns one list in N: its nearest owned
+    // one is what it can learn a bound from; at most 8 places are tried)
+    for (int tries = 0; tries < (S.seed_ranks == 1 ? 8 : 1) && rr < S.P; tries++, rr++) {
+        const int64_t pair = qq * S.P + rr;
+        if (S.pids_packed) {
+            const unsigned long long v = S.pids_packed[pair];
+            p = v == ~0ull ? -1 : (int64_t)(v & 0xFFFFFFFFull);
+        } else {
+            p = S.pids ? S.pids[pair] : (pair % S.P);
+        }
+        size_p = (p >= 0 && p < S.npids) ? S.pt_size[p] : 0;
+        if (size_p >= S.k) break;
     }
     if (p < 0 || p >= S.npids) return;
-    const int size_p = S.pt_size[p];
     if (size_p < S.k) return;  // fewer than k rows: no bound from this partition
     const int n = min(size_p, 64 * M);
     const int64_t q = qq;
@@ -546,6 +552,7 @@ __global__ __launch_bounds__(64) void k_seed_tau(SeedParams S) {
 
 // The same for larger batches: the counting pass of the three-kernel grouping and the seeding kernel in one launch (the
 // first n_count_blocks workgroups count, the others carry 4 seeding waves each).
+template <int M>
 __global__ __launch_bounds__(256) void k_group_count_seed(GroupParams G, SeedParams S, int n_count_blocks, int64_t n_seed_waves) {
     if ((int)blockIdx.x < n_count_blocks) {
         const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -553,7 +560,7 @@ __global__ __launch_bounds__(256) void k_group_count_seed(GroupParams G, SeedPar
         return;
     }
     const int64_t w = ((int64_t)blockIdx.x - n_count_blocks) * 4 + (threadIdx.x >> 6);
-    if (w < n_seed_waves) seed_tau_body<1, 8>(S, w, threadIdx.x & 63);
+    if (w < n_seed_waves) seed_tau_body<M, 8>(S, w, threadIdx.x & 63);
 }
 
 // Grouping and bound seeding of a small batch in ONE launch: both depend only on the probed-partition lists, neither on the
@@ -2140,7 +2147,12 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
         sd.k = k;
         sd.metric = a.metric;
         sd.gtau = gtau;
-        sd.seed_ranks = std::min(2, G.P);
+        // which lists are sampled: the NEAREST one only (measured, nprobe 8-32 on both bench corpora: the second-nearest list's
+        // sample never tightened the bound -- same scan time, 4 us of seeding less), and 128 of its rows instead of 64 when the
+        // batch goes through the larger-batch launch (the scan of the mixed form is 2x slower without any seed and gains
+        // 8-16 us from the larger sample; 256 rows cost the seeding what they save the scan: it is bandwidth-bound)
+        static const int seed_ranks_env = qk_env_int("QK_SEED_RANKS", 1);
+        sd.seed_ranks = std::min(std::max(1, seed_ranks_env), G.P);
         // (a side stream + fork/join events was measured slower than running it in line: 45 vs 40 us group phase.
         //  Larger samples -- 128 / 256 rows, scalar or on MFMA with all tile loads in flight -- take 6-12 us off k_scan and
         //  add 10-40 us here: the kernel is a chain of five dependent memory round trips, not arithmetic.)
@@ -2158,7 +2170,13 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
         } else if (k <= 64 && seed_waves == 1 && npairs > QK_GROUP_SMALL && !no_fuse) {
             const int64_t nsw = Q * sd.seed_ranks;
             const int ncb = (int)((npairs + 255) / 256);
-            hipLaunchKernelGGL(k_group_count_seed, dim3((unsigned)(ncb + (nsw + 3) / 4)), dim3(256), 0, st, G, sd, ncb, nsw);
+            static const int seed_m2 = qk_env_int("QK_SEED_M2", 1);
+            // (128 rows pay at nprobe 2-4 -- scan 0.339 / 0.385 -> 0.318 / 0.370 ms, seeding +4 us; from nprobe 8 on the larger sample costs
+            //  the seeding what it saves the scan)
+            if (seed_m2 && G.P > 1 && G.P <= 4)
+                hipLaunchKernelGGL(k_group_count_seed<2>, dim3((unsigned)(ncb + (nsw + 3) / 4)), dim3(256), 0, st, G, sd, ncb, nsw);
+            else
+                hipLaunchKernelGGL(k_group_count_seed<1>, dim3((unsigned)(ncb + (nsw + 3) / 4)), dim3(256), 0, st, G, sd, ncb, nsw);
             fused_count = true;
         } else if (k <= 64 && seed_waves == 4)
             hipLaunchKernelGGL((k_seed_tau_wg<4>), sg, dim3(256), 0, st, sd);
