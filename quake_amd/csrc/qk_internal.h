@@ -152,6 +152,7 @@ struct qk_store {
     int64_t nlist = 0;
     int64_t ntotal = 0;
     int64_t max_size = 0;      // upper bound of the largest partition size (monotone; refreshed on table sync)
+    int64_t n_nonempty = 0;    // lists that hold rows (as of the last table sync): mean list length for the scan-form rule
     int64_t max_id_seen = -1;  // upper bound of every id ever stored (monotone): gates the 32-bit id packing of k_dense_argmin
     int64_t min_id_seen = 0;   // lower bound (negative ids disable the packing)
     // device partition table, indexed by list number

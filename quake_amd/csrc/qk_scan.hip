@@ -168,7 +168,7 @@ __device__ __forceinline__ long long group_seq_len(const GroupParams &G, int c, 
     *items = 0;
     *hunits = 0;
     if (!G.rl) return 0;  // (seq_weight: the caller)
-    if (G.hot.min > 0 && c >= G.hot.min) {
+    if (hot_list(c, sz, G.hot)) {
         const HotShape hs = hot_shape(c, sz, G.hot);
         *items = hs.nqblk * hs.nrr;
         *hunits = hot_units_of(c, sz, G.hot);
@@ -1936,7 +1936,7 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
     // Mixed work sequence (qk_scan_rl.hip, HOT form): lists probed by >= hot.min queries of the batch become dense items on
     // v_mfma_f32_16x16x4_f32 claimed by whole workgroups; the block width hq is what the workgroup's LDS (the four waves' slices
     // of the per-wave form together) holds next to one pool of C entries per query.
-    HotCost hot{0, 0, 0, 0, 0, 0, 0};
+    HotCost hot{0, 0, 0, 0, 0, 0, 0, 0};
     {
         // Measured (10M x 128, 1024 queries, k = 10, scripts/nprobe_sweep.py; kernel ms per-wave walk alone -> mixed, lists with
         // >= 13 probing queries hot): skewed mixture nprobe 8 / 16 / 32 / 64: 0.461 / 0.623 / 1.027 / 1.808 -> 0.474 / 0.512 / 0.632 /
@@ -1951,11 +1951,18 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
         static const int hot_ovh = qk_env_int("QK_SCAN_HOT_OVH", 64);
         static const int hot_hq = qk_env_int("QK_SCAN_HOT_HQ", 128);
         static const int hot_per_list = qk_env_int("QK_SCAN_HOT_PER_LIST", 2);
+        static const int hot_min_rows = qk_env_int("QK_SCAN_HOT_MIN_ROWS", 512);
+        // Short lists: on the configs[0] shape (1M x 128 in 1024 lists of ~1000 rows, nprobe 10) items are 61 row tiles long and
+        // their fixed costs show -- 256 / 1024 queries: scan 85 / 165 us with the round-2 forms (per-wave walk / query-sharing tile
+        // form), 143 / 236 us mixed -- so the mixed form serves indexes whose lists average >= 1400 rows, the round-2 rule the rest
+        static const int hot_mean_rows = qk_env_int("QK_SCAN_HOT_MEAN_ROWS", 1400);
+        const int64_t mean_rows = s->ntotal / std::max<int64_t>(1, s->n_nonempty);
+        const bool long_lists = mean_rows >= hot_mean_rows;
         static const int rl_env2 = qk_env_int("QK_SCAN_RL", -1);
         const bool rl_possible = nblk <= 8 && k <= 32 && rl_waves == 4 && rlc.qb == 32 && !a.per_pair && !emit && npairs >= 1024 && P > 1 &&
                                  ctx->qprep_xp4 != nullptr && a.xq4 == (const float4 *)ctx->qprep && rl_env2 != 0 &&
                                  4 * ((qk_scan_rl_lds_per_wave(nblk, std::min(64, qk_round_up(k + 32, 4)), rlc.qb) + 15) & ~(size_t)15) <= (size_t)160 * 1024;
-        if (rl_possible && hot_min > 0 && rl_per_list >= hot_per_list) {
+        if (rl_possible && hot_min > 0 && rl_per_list >= hot_per_list && long_lists) {
             const int C_rl2 = std::min(64, qk_round_up(k + 32, 4));
             const size_t per_wave = std::max<size_t>((qk_scan_rl_lds_per_wave(nblk, C_rl2, rlc.qb) + 15) & ~(size_t)15, (size_t)(160 * 1024) / 4 - 512) & ~(size_t)15;
             // (pools of k + 22 entries: appends come four at a time at most, and a block's pools share the LDS with its query
@@ -1964,7 +1971,7 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
             int hq = std::min(128, std::max(16, hot_hq)) & ~15;
             while (hq >= 32 && qk_scan_hot_lds(nblk, C_hot, hq) > 4 * per_wave) hq -= 16;
             if (hq >= 32) {
-                hot = HotCost{std::max(hot_min, 1), hq, std::max(16, hot_unit), std::max(1, hot_w10), std::max(1, hot_ht10), std::max(0, hot_ovh), C_hot};
+                hot = HotCost{std::max(hot_min, 1), hq, std::max(16, hot_unit), std::max(1, hot_w10), std::max(1, hot_ht10), std::max(0, hot_ovh), C_hot, std::max(16, hot_min_rows)};
                 // the mixed form serves every sharing level: it replaces the query-sharing form of k_scan too
                 use_rl = true;
                 nw = 1;

@@ -638,7 +638,7 @@ __global__ __launch_bounds__(256) void k_scan_rl(ScanParams P) {
         // ---- segment = chunks [ch0, ch1) of pass b over partition active[ai] ---------------------------------------------
         const ActiveInfo inf = P.active[ai];
         const int size_p = inf.size, cnt_p = inf.cnt;
-        if (HOT && P.hot.min > 0 && cnt_p >= P.hot.min) {  // a hot list: no units in this sequence (rl_hot_item)
+        if (HOT && hot_list(cnt_p, size_p, P.hot)) {  // a hot list: no units in this sequence (rl_hot_item)
             ai++;
             continue;
         }

@@ -30,7 +30,10 @@ struct HotCost {
     int ht10;   // tenths of a unit per row tile: streaming it (8 KB at d = 128) -- an item costs the larger of the two
     int ovh;    // cost of starting an item (staging the block's queries, emitting its records)
     int C;      // pool capacity per query of a block (k + slack; the block's pools sit next to fp32 AND bf16 query tiles)
+    int min_rows;  // ... and only lists of at least this many rows: an item has ~10 us of fixed cost (staging its query block,
+                   // claiming, emitting records), a shorter list is cheaper in passes of the per-wave walk
 };
+__host__ __device__ inline bool hot_list(int cnt, int size, const HotCost &h) { return h.min > 0 && cnt >= h.min && size >= h.min_rows; }
 struct HotShape {
     int nqblk, qpb, nrr;  // query blocks, queries per block (multiple of 16), row ranges
 };

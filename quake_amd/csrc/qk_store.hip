@@ -200,19 +200,22 @@ int qk_store_sync_table(qk_store *s) {
         QK_HIP(hipStreamSynchronize(c->stream));  // pinned buffer may still feed an earlier async copy
         int64_t *ho = (int64_t *)c->pinned;
         int32_t *hs = (int32_t *)(c->pinned + (size_t)n * sizeof(int64_t));
-        int64_t mx = 0;
+        int64_t mx = 0, nonempty = 0;
         for (int64_t p = 0; p < n; p++) {
             const qk_part &pt = s->parts[p];
             ho[p] = pt.row_off;
             hs[p] = pt.present ? (int32_t)pt.size : -1;
             if (pt.present) mx = std::max(mx, pt.size);
+            if (pt.present && pt.size > 0) nonempty++;
         }
         s->max_size = mx;
+        s->n_nonempty = nonempty;
         QK_HIP(hipMemcpyAsync(s->d_off, ho, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
         QK_HIP(hipMemcpyAsync(s->d_size, hs, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
         QK_HIP(hipStreamSynchronize(c->stream));
     } else {
         s->max_size = 0;
+        s->n_nonempty = 0;
     }
     s->table_dirty = false;
     return QK_OK;

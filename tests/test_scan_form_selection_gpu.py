@@ -30,36 +30,44 @@ def _stores(ctx, ivf):
     return parent, s
 
 
-# (d, k, queries, nprobe) -> form.  nlist = 1024 throughout: pairs per list = queries * nprobe / 1024.
+# (rows, lists, d, k, queries, nprobe) -> form.  Pairs per list = queries * nprobe / lists; the mixed form needs lists that
+# average >= 1400 rows.
 TABLE = [
     # one list per query: the 16 x 16 tile form (its static cut leaves the fewest records to merge)
-    (128, 10, 1024, 1, "k_scan"),
+    (60000, 1024, 128, 10, 1024, 1, "k_scan"),
+    (100000, 64, 128, 10, 1024, 1, "k_scan (query-sharing)"),  # (16 queries per list)
     # several lists per query, under two probing queries per list: the per-wave row-per-lane walk
-    (128, 10, 256, 4, "k_scan_rl"),
-    (64, 10, 512, 2, "k_scan_rl"),
-    # from two probing queries per list on: the mixed sequence (hot lists as dense items behind the bf16 prefilter)
-    (128, 10, 1024, 2, "k_scan_rl (mixed)"),
-    (128, 10, 1024, 8, "k_scan_rl (mixed)"),
-    (128, 10, 1024, 32, "k_scan_rl (mixed)"),
-    (100, 32, 1024, 8, "k_scan_rl (mixed)"),
-    (32, 1, 2048, 4, "k_scan_rl (mixed)"),
+    (60000, 1024, 128, 10, 256, 4, "k_scan_rl"),
+    (60000, 1024, 64, 10, 512, 2, "k_scan_rl"),
+    # LONG lists (1560 rows on average) from two probing queries per list on: the mixed sequence (hot lists as dense items behind
+    # the bf16 prefilter), whatever the sharing
+    (100000, 64, 128, 10, 1024, 2, "k_scan_rl (mixed)"),
+    (100000, 64, 128, 10, 1024, 8, "k_scan_rl (mixed)"),
+    (100000, 64, 128, 10, 1024, 32, "k_scan_rl (mixed)"),
+    (100000, 64, 100, 32, 1024, 8, "k_scan_rl (mixed)"),
+    (100000, 64, 32, 1, 2048, 4, "k_scan_rl (mixed)"),
+    # SHORT lists (58 rows on average): the round-2 rule -- per-wave walk under 6 probing queries per list, query-sharing tile
+    # form from there on
+    (60000, 1024, 128, 10, 1024, 2, "k_scan_rl"),
+    (60000, 1024, 128, 10, 1024, 8, "k_scan (query-sharing)"),
+    (60000, 1024, 128, 10, 1024, 32, "k_scan (query-sharing)"),
     # the row-per-lane form holds k <= 32 and d <= 128 (and d = 128 only up to k = 24: LDS): beyond, the tile form, with
     # query-sharing workgroups when lists are shared
-    (128, 32, 1024, 8, "k_scan (query-sharing)"),
-    (128, 100, 1024, 8, "k_scan (query-sharing)"),
-    (256, 10, 1024, 8, "k_scan (query-sharing)"),
-    (256, 10, 1024, 1, "k_scan"),
+    (100000, 64, 128, 32, 1024, 8, "k_scan (query-sharing)"),
+    (100000, 64, 128, 100, 1024, 8, "k_scan (query-sharing)"),
+    (100000, 64, 256, 10, 1024, 8, "k_scan (query-sharing)"),
+    (60000, 1024, 256, 10, 1024, 1, "k_scan"),
     # small batches against a small flat parent: the one-launch search
-    (128, 10, 1, 10, "k_search_small"),
-    (128, 10, 32, 10, "k_search_small"),
+    (60000, 1024, 128, 10, 1, 10, "k_search_small"),
+    (60000, 1024, 128, 10, 32, 10, "k_search_small"),
     # fewer than 1024 pairs: no hot items (a wave's share is a chunk or two)
-    (128, 10, 64, 10, "k_scan_rl"),
+    (100000, 64, 128, 10, 64, 2, "k_scan_rl"),
 ]
 
 
-@pytest.mark.parametrize("d,k,nq,nprobe,form", TABLE)
-def test_form_of_the_scan(ctx, d, k, nq, nprobe, form):
-    ivf = make_ivf(60000, d, 1024, seed=5 + d)
+@pytest.mark.parametrize("n,nlist,d,k,nq,nprobe,form", TABLE)
+def test_form_of_the_scan(ctx, n, nlist, d, k, nq, nprobe, form):
+    ivf = make_ivf(n, d, nlist, seed=5 + d)
     parent, s = _stores(ctx, ivf)
     q = make_queries(nq, d, seed=6, like=ivf["x"])
     gi, gd = ctx.search(parent, s, q, nprobe, k, "l2")

@@ -2,7 +2,8 @@
 are scanned as dense workgroup items -- a bf16 prefilter on v_mfma_f32_16x16x32_bf16 with a one-sided error bound, the exact
 chains on v_mfma_f32_16x16x4_f32 for every row tile that could still hold a candidate -- the others by the per-wave walk: one
 launch, one record format, the same bits as the oracle's batched path (query_coordinator.cpp:675-799,
-list_scanning.h:313-366).  The host turns the form on from two probing queries per list (batch average) on."""
+list_scanning.h:313-366).  The host turns the form on from two probing queries per list (batch average) on, on indexes whose
+lists average >= 1400 rows; a list is hot with >= 13 probing queries AND >= 512 rows."""
 import numpy as np
 import pytest
 
@@ -79,17 +80,19 @@ def check(ctx, s, ivf, q, pids, k, metric, want_form="k_scan_rl (mixed)"):
 @pytest.mark.parametrize("d,k", [(128, 10), (100, 32), (32, 1), (64, 17)])
 def test_hot_and_cold_lists_one_launch(ctx, metric, d, k):
     rng = np.random.default_rng(11)
-    nlist = 1500
-    sizes = rng.integers(0, 120, size=nlist)
-    # hot lists of every shape: many row ranges, one tile, a ragged last tile, fewer rows than k, a single row
-    sizes[:8] = [6000, 1300, 17, 16, 5, 1, 2500, 331]
+    nlist = 400
+    sizes = rng.integers(1400, 1900, size=nlist)
+    sizes[390:] = 0
+    # hot lists of every shape: many row ranges, a ragged last tile, exactly / just under the row threshold; lists shared by
+    # many queries but too short for an item (17 rows, 5 rows, 1 row, fewer than k): passes of the per-wave walk
+    sizes[:8] = [6000, 1300, 17, 512, 5, 1, 2500, 511]
     ivf = make_sized_ivf(sizes, d, seed=12, metric=metric)
     s = build(ctx, ivf)
     Q, P = 700, 6
     q = ivf["vecs"][rng.integers(0, ivf["vecs"].shape[0], size=Q)] + 0.1 * rng.standard_normal((Q, d)).astype(np.float32)
     q = np.ascontiguousarray(q, np.float32)
-    # 700 queries on list 0 (6 blocks), 130 on list 1 (80 + 50), 13 / 12 around the threshold, 129, 257, 48, 64
-    hot = {0: 700, 1: 130, 2: 13, 3: 12, 4: 129, 5: 257, 6: 48, 7: 64}
+    # 700 queries on list 0 (6 blocks), 130 on list 1 (80 + 50), 129, 257, 48, 64 on short lists; 13 / 12 around the threshold
+    hot = {0: 700, 1: 130, 2: 129, 3: 13, 4: 257, 5: 48, 6: 12, 7: 64}
     pids = skewed_pids(Q, P, nlist, hot, rng)
     pids[::9, -1] = -1
     check(ctx, s, ivf, q, pids, k, metric)
@@ -99,13 +102,13 @@ def test_hot_and_cold_lists_one_launch(ctx, metric, d, k):
 def test_hot_lists_with_exact_ties(ctx):
     """SIFT-like integer data: exact distance ties across the waves of an item and across items -> the (key, id) order"""
     rng = np.random.default_rng(21)
-    nlist = 1200
-    sizes = rng.integers(1, 80, size=nlist)
+    nlist = 300
+    sizes = rng.integers(1400, 1700, size=nlist)
     sizes[:3] = [3000, 900, 64]
     ivf = make_sized_ivf(sizes, 128, seed=22, integer=True)
     s = build(ctx, ivf)
     Q, P = 512, 8
-    q = ivf["vecs"][rng.integers(0, 3964, size=Q)] + rng.integers(-2, 3, size=(Q, 128)).astype(np.float32)
+    q = ivf["vecs"][rng.integers(0, 30000, size=Q)] + rng.integers(-2, 3, size=(Q, 128)).astype(np.float32)
     q = np.ascontiguousarray(q, np.float32)
     pids = skewed_pids(Q, P, nlist, {0: 512, 1: 200, 2: 40}, rng)
     for k in (10, 24):  # (d = 128 with k = 32: the per-wave form's LDS does not fit, k_scan serves it)
@@ -115,19 +118,19 @@ def test_hot_lists_with_exact_ties(ctx):
 
 def test_every_list_hot_and_none(ctx):
     rng = np.random.default_rng(31)
-    nlist = 1100
-    sizes = rng.integers(1, 60, size=nlist)
-    sizes[:4] = [2000, 1000, 500, 250]
+    nlist = 300
+    sizes = rng.integers(1400, 1600, size=nlist)
+    sizes[:4] = [2000, 1000, 600, 520]
     ivf = make_sized_ivf(sizes, 128, seed=32)
     s = build(ctx, ivf)
     Q = 600
-    q = np.ascontiguousarray(ivf["vecs"][rng.integers(0, 3750, size=Q)] + 0.1 * rng.standard_normal((Q, 128)).astype(np.float32))
+    q = np.ascontiguousarray(ivf["vecs"][rng.integers(0, 20000, size=Q)] + 0.1 * rng.standard_normal((Q, 128)).astype(np.float32))
     # every pair lands on a hot list: the per-wave sequence is empty
     pids = np.tile(np.array([0, 1, 2, 3], np.int64), (Q, 1))
     check(ctx, s, ivf, q, pids, 10, "l2")
     # nobody shares a list with more than a few others: no hot item at all, the same kernel
-    pids = np.stack([rng.choice(np.arange(4, nlist), size=4, replace=False) for _ in range(Q)]).astype(np.int64)
-    assert np.bincount(pids.ravel()).max() < 13
+    pids = (4 + ((np.arange(Q)[:, None] * 4 + np.arange(4)[None, :]) * 7919) % (nlist - 4)).astype(np.int64)  # round robin
+    assert np.bincount(pids.ravel()).max() < 13 and all(len(set(r)) == 4 for r in pids.tolist())
     check(ctx, s, ivf, q, pids, 10, "l2")
     s.close()
 
@@ -135,13 +138,13 @@ def test_every_list_hot_and_none(ctx):
 def test_repeated_calls_reuse_counters(ctx):
     """the hot queue's counter lives in the per-call zeroed state: a second and third call must start from item 0"""
     rng = np.random.default_rng(41)
-    nlist = 1000
-    sizes = rng.integers(1, 60, size=nlist)
+    nlist = 300
+    sizes = rng.integers(1400, 1600, size=nlist)
     sizes[:2] = [4000, 700]
     ivf = make_sized_ivf(sizes, 64, seed=42)
     s = build(ctx, ivf)
     Q = 520
-    q = np.ascontiguousarray(ivf["vecs"][rng.integers(0, 4700, size=Q)] + 0.1 * rng.standard_normal((Q, 64)).astype(np.float32))
+    q = np.ascontiguousarray(ivf["vecs"][rng.integers(0, 20000, size=Q)] + 0.1 * rng.standard_normal((Q, 64)).astype(np.float32))
     for it in range(3):
         pids = skewed_pids(Q, 4, nlist, {0: 520 - 40 * it, 1: 100 + it}, rng)
         check(ctx, s, ivf, q, pids, 10, "l2")
@@ -153,8 +156,8 @@ def test_hot_lists_value_range(ctx, metric):
     """the prefilter's bound over the whole float range: rows and queries with elements of 1e5-1e6 and of 1e-6 next to ordinary
     ones, in hot lists (bf16 keeps fp32's exponent range: no guard needed; an fp16 variant needed two)"""
     rng = np.random.default_rng(51)
-    nlist = 1100
-    sizes = rng.integers(1, 60, size=nlist)
+    nlist = 300
+    sizes = rng.integers(1400, 1600, size=nlist)
     sizes[:3] = [3000, 1200, 700]
     ivf = make_sized_ivf(sizes, 96, seed=52)
     x = ivf["vecs"]
