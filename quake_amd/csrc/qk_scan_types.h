@@ -139,6 +139,24 @@ struct ScanParams {
     int32_t *hot_counter;         // [1] next hot item to hand out (zeroed per call)
 };
 
+// ---- merge stage (qk_merge.hip) ------------------------------------------------------------------------------------------
+struct MergeParams {
+    int P;
+    const int32_t *pair_head;
+    const int32_t *pair_slots;
+    const int2 *rec_hdr;
+    const uint32_t *rec_ord;
+    const int64_t *rec_id;
+    int32_t max_recs;
+    int k;
+    int Cm;  // pool capacity, k <= Cm - 64
+    int metric;
+    int64_t *out_ids;   // [Q][k]
+    float *out_dist;    // [Q][k] or nullptr
+    int sqrt_l2;        // 1: output sqrt(d2) (search results); 0: squared (merge key of the sharded path)
+    long long *clock;   // probe (QK_MERGE_CLOCK): [Q][8] wall_clock64 ticks of the phases of every wave, or nullptr
+};
+
 // ---- row-per-lane scan (qk_scan_rl.hip): cost model of the work sequence ----------------------------------------------------
 // A partition probed by cnt queries is scanned in passes of up to RlCost::qb queries (qb / 4 groups of 4: one
 // v_mfma_f32_4x4x1_16b_f32 serves 64 rows x 4 queries).  A pass walks the partition in chunks of 64 rows; a chunk of a pass
