@@ -264,6 +264,10 @@ __device__ __forceinline__ void rl_hot_item(const ScanParams &P, const HotLds &H
 
 #ifdef QK_PROBES  // (probe build only: rl_probe bit 8 drops the chains of the hot items -- the branch splits the block the keys hide in)
 #define HOT_PF_PROBE(x) ((P.rl_probe & 32) ? 3 : (P.rl_probe & 64) ? 0 : (x))  /* 32: every product exact; 64: none */
+#define HOT_CHAIN1_PROBE(A, OFF_, B, AC) \
+    if (P.rl_probe & 8) {                \
+        AC[0] += A[OFF_].x + B[0].x;     \
+    } else
 #define HOT_CHAIN_PROBE(A, AC0, AC1, B) \
     if (P.rl_probe & 8) {               \
         AC0[0] += A[0].x + B[0].x;      \
@@ -271,6 +275,7 @@ __device__ __forceinline__ void rl_hot_item(const ScanParams &P, const HotLds &H
     } else
 #else
 #define HOT_CHAIN_PROBE(A, AC0, AC1, B)
+#define HOT_CHAIN1_PROBE(A, OFF_, B, AC)
 #define HOT_PF_PROBE(x) (x)
 #endif
 // the B operands of a query tile: NB float4 per lane, requested a whole tile AHEAD of their chains (with one buffer hipcc put a
@@ -315,11 +320,12 @@ __device__ __forceinline__ void rl_hot_item(const ScanParams &P, const HotLds &H
         uint32_t ordv_[8];                                                                                   \
         const bool anyp_ = keys(QT_, ea0_, ea1_, PI, Y, ordv_, xne_, taue_, UM_);                            \
         const uint64_t pm_ = __ballot(anyp_);                                                                \
-        if (pm_) append(QT_, ordv_, I, pm_);                                                                 \
+        if (pm_ && !(P.rl_probe & 128)) append(QT_, ordv_, I, pm_);  /* (probe 128: exact chains, nothing appended) */ \
     }
 // (one row tile only: a single dependent chain)
 #define HOT_CHAIN1(A, OFF_, B, AC)                                                                           \
     {                                                                                                        \
+        HOT_CHAIN1_PROBE(A, OFF_, B, AC)                                                                     \
         _Pragma("unroll") for (int c_ = 0; c_ < NB; c_++) {                                                  \
             const float4 b_ = B[c_];                                                                         \
             AC = __builtin_amdgcn_mfma_f32_16x16x4f32(A[(OFF_) + c_].x, b_.x, AC, 0, 0, 0);                  \
@@ -409,6 +415,7 @@ __device__ __forceinline__ void rl_hot_item(const ScanParams &P, const HotLds &H
 #undef HOT_LOAD
 #undef HOT_CHAIN
 #undef HOT_CHAIN_PROBE
+#undef HOT_CHAIN1_PROBE
 #undef HOT_PF_PROBE
 #undef HOT_EXACT
 #undef HOT_CHAIN1
