@@ -27,6 +27,9 @@
 // and k-slice g, the float4 {columns 16c+g, +4, +8, +12} -- 4 x 256 contiguous bytes per instruction -- and element t of it
 // is the B operand of column 16c + 4t + g.  Queries are staged per pass in LDS as [group][c][lane] floats (conflict-free
 // ds_read_b32, d/16 per group and chunk).
+//
+// Round 3: the same kernel carries the MIXED work sequence (template parameter HOT): lists shared by many queries of the batch
+// leave the per-wave sequence and become dense workgroup items behind a bf16 prefilter -- see "hot lists" below.
 #include "qk_internal.h"
 #include "qk_device.h"
 #include "qk_scan_types.h"
