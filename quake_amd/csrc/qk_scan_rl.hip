@@ -167,7 +167,7 @@ __device__ __forceinline__ void rl_hot_item(const ScanParams &P, const HotLds &H
         float xn_own = 0.0f;
         if (live_own) {
             if (P.gtau) t_own = ~__hip_atomic_load(&P.gtau[q_own], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (L2) xn_own = P.xn[q_own];
+            xn_own = P.xn[q_own];  // (IP too: the prefilter's error bound scales with |x|^2 + |y|^2 under either metric)
         }
 #pragma unroll
         for (int qt = 0; qt < 8; qt++)

@@ -175,3 +175,26 @@ def test_hot_lists_value_range(ctx, metric):
     for k in (1, 10, 32):
         check(ctx, s, ivf, q, pids, k, metric)
     s.close()
+
+
+@pytest.mark.parametrize("metric", ["ip", "l2"])
+def test_prefilter_bound_with_unequal_norms(ctx, metric):
+    """rows that differ from each other by less than a bf16 rounding step, queries of 100x their norm: the approximate order
+    inside a hot list is scrambled, so every row the bound cannot exclude must be recomputed -- and the bound has to use BOTH
+    norms under either metric (an IP bound built from the row norms alone lost candidates here)"""
+    rng = np.random.default_rng(61)
+    nlist = 300
+    sizes = rng.integers(1400, 1600, size=nlist)
+    sizes[:2] = [2500, 1800]
+    ivf = make_sized_ivf(sizes, 64, seed=62)
+    x = ivf["vecs"]
+    base = rng.standard_normal((2, 64)).astype(np.float32)
+    x[:2500] = base[0] + 1.0e-3 * rng.standard_normal((2500, 64)).astype(np.float32)
+    x[2500:4300] = base[1] + 1.0e-3 * rng.standard_normal((1800, 64)).astype(np.float32)
+    s = build(ctx, ivf)
+    Q = 512
+    q = (100.0 * (base[rng.integers(0, 2, size=Q)] + 0.05 * rng.standard_normal((Q, 64)))).astype(np.float32)
+    pids = skewed_pids(Q, 4, nlist, {0: 512, 1: 400}, rng)
+    for k in (10, 32):
+        check(ctx, s, ivf, np.ascontiguousarray(q), pids, k, metric)
+    s.close()
