@@ -26,7 +26,7 @@
 
 typedef __bf16 pf_bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 pf_bf16x4 __attribute__((ext_vector_type(4)));
-constexpr float PF_C = 0.0041509f;   // >= 2^-8 * 17/16 + 2^-21 (see qk_scan_rl.hip)
+constexpr float PF_C = 0.0078741f;   // >= 2^-7 * 129/128 + 2^-21 (see qk_scan_rl.hip: bf16 keeps 8 significant bits)
 constexpr int PF_CAP = 1536;         // candidate rows per query (a multiple of 64)
 constexpr int PF_NQ_MAX = 16;        // query tiles per workgroup: 256 queries share one pass over the rows
 constexpr int PF_WBUF = 128;         // candidates a wave parks in LDS before it hands them over

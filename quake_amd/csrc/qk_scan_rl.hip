@@ -59,18 +59,19 @@ __device__ __forceinline__ float f4c(const float4 &v, int t) { return t == 0 ? v
 //
 // PREFILTER.  Every (row tile pair, query tile) product is first computed on v_mfma_f32_16x16x32_bf16 -- the same fragments
 // rounded to bf16, 16x the fp32 rate -- and only when some lane's APPROXIMATE key could beat its query's bound does the pair
-// run the exact fp32 chains.  The test is one-sided and rigorous: with x~ = bf16(x), y~ = bf16(y) (round to nearest: relative
-// error <= 2^-9 each) |x~.y~ - x.y| <= (2^-8 + 2^-18) sum|x_i y_i| <= (2^-8 + 2^-18) (|x|^2 + |y|^2) / 2, the fp32
-// accumulation of either path adds less than 2^-16 of that, so with c = 2^-8 * 17/16 + 2^-21
+// run the exact fp32 chains.  The test is one-sided and rigorous: with x~ = bf16(x), y~ = bf16(y) (round to nearest even -- checked
+// on the hardware, scripts/micro/cvt_bf16.hip: 2^24 values, all equal to the reference -- 8 significant bits: relative error
+// <= 2^-8 each) |x~.y~ - x.y| <= (2^-7 + 2^-16) sum|x_i y_i| <= (2^-7 + 2^-16) (|x|^2 + |y|^2) / 2, the fp32
+// accumulation of either path adds less than 2^-16 of that, so with c = 2^-7 * 129/128 + 2^-21
 //     L2:  d2_exact >= (|x|^2 + |y|^2)(1 - c) - 2 x~.y~        IP:  x.y <= x~.y~ + c (|x|^2 + |y|^2) / 2
 // and a candidate whose bound already loses against the running k-th key cannot enter the top-k.  Everything that IS appended
 // went through the exact chain, so ids and distance bits are those of the unfiltered scan; the k-order of the bf16
 // instruction is free, so its operands are the fp32 fragments converted in place (no second layout).
 // (fp16 operands -- a band of 2^-10 instead of 2^-8, with range guards for |x|^2 > 2^30 and an absolute term for its subnormals --
-//  were built and measured: parity green, fewer row tiles recomputed, and 2-9 % SLOWER at nprobe 8-64: the conversions cost two
+//  were built and measured (against a bf16 band that was still taken as 2^-8): parity green, fewer row tiles recomputed, and 2-9 % SLOWER at nprobe 8-64: the conversions cost two
 //  to three VALU instructions per value where v_cvt_pk_bf16_f32 converts a pair in one, and the test is VALU-bound.)
-constexpr float QK_PF_C = 0.0041509f;   // >= 2^-8 * 17/16 + 2^-21
-constexpr float QK_PF_K1 = 0.995849f;   // <= 1 - QK_PF_C
+constexpr float QK_PF_C = 0.0078741f;   // >= 2^-7 * 129/128 + 2^-21
+constexpr float QK_PF_K1 = 0.992125f;   // <= 1 - QK_PF_C
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 struct HotLds {
     float4 *sB;          // [hq/16][NB][64] query tiles, B-operand lane order
