@@ -143,6 +143,17 @@ def build_single(ctx, dev, x, nlist, metric, niter, keep_host):
     centroids, assign, _ = ctx.kmeans(x, nlist, metric, niter=niter, seed=1234)
     torch.cuda.synchronize()
     t_kmeans = time.time() - t0
+    kt = ctx.kmeans_last_timing()  # last Lloyd iteration, HIP events inside the library
+    km_kernels = None
+    if kt["rows"] > 0 and kt["assign_ms"] > 0 and kt["update_ms"] > 0:
+        a_tf = 2.0 * kt["rows"] * kt["m"] * d / (kt["assign_ms"] * 1e-3) / 1e12
+        u_gbs = kt["rows"] * d * 4 / (kt["update_ms"] * 1e-3) / 1e9
+        km_kernels = {"rows": kt["rows"], "centroids": kt["m"],
+                      "assign": {"ms": round(kt["assign_ms"], 3), "achieved": round(a_tf, 1), "peak": MFMA_F32_PEAK_TFLOPS,
+                                 "unit": "TFLOP/s", "frac": round(a_tf / MFMA_F32_PEAK_TFLOPS, 3), "bound": "mfma"},
+                      "update": {"ms": round(kt["update_ms"], 3), "achieved": round(u_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": round(u_gbs / HBM_PEAK_GBS, 3), "bound": "hbm",
+                                 "note": "rows x d x 4 bytes (each training row read once) / (bucketing by assignment + k_accumulate)"}}
     order = torch.argsort(assign, stable=True)
     counts = torch.bincount(assign, minlength=nlist).cpu().numpy().astype(np.int64)
     ids_sorted = order.contiguous()
@@ -160,7 +171,7 @@ def build_single(ctx, dev, x, nlist, metric, niter, keep_host):
         host = (x_sorted.cpu().numpy(), ids_sorted.cpu().numpy(), offsets.copy(), centroids.cpu().numpy())
     log(f"index: {n}x{d} nlist={nlist} k-means {t_kmeans:.2f}s, list sizes min/mean/max = "
         f"{counts.min()}/{counts.mean():.0f}/{counts.max()}, arena {store.device_bytes() / 1e9:.2f} GB")
-    return dict(parent=parent, store=store, host=host, kmeans_s=t_kmeans, counts=counts)
+    return dict(parent=parent, store=store, host=host, kmeans_s=t_kmeans, counts=counts, kmeans_kernels=km_kernels)
 
 
 def pick_nprobe(step, batches, gts, k, target, fixed, recall_fn):
@@ -469,7 +480,7 @@ def run_single_workload(ctx, dev, args, name, sigma, fixed_nprobe, steps, warmup
         "roofline": roofline_of(scan_bytes, ev, traffic, kernel=scan_kernel, pair_rows=pair_rows, d=d, traffic_source=traffic_source),
         "host_api": host_api,
         "phases_ms": phases_of(ev_ph),
-        "build": {"kmeans_s": round(idx["kmeans_s"], 2), "niter": args.niter},
+        "build": {"kmeans_s": round(idx["kmeans_s"], 2), "niter": args.niter, "last_iteration": idx.get("kmeans_kernels")},
     }
     if sweep_res:
         res["nprobe_sweep"] = sweep_res

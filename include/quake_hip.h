@@ -211,6 +211,11 @@ QK_API int qk_kmeans(qk_ctx *ctx, float *x, int64_t n, int d, int64_t m, int met
 QK_API int qk_normalize_rows(qk_ctx *ctx, float *x, int64_t n, int d, int mem);
 QK_API int qk_kmeans_update(qk_ctx *ctx, const float *sums, int64_t *counts, int64_t m, int d, float *centroids, int mem);
 QK_API int qk_rand_perm(int64_t n, int64_t m, uint64_t seed, int64_t *perm_out_host);
+/* Kernel-side durations (HIP events on the context's stream) of the LAST Lloyd iteration of the last qk_kmeans on this context: the
+ * assign step (k_assign + its centroid re-tiling) and the update step (bucketing + k_accumulate) over `rows` training rows and `m`
+ * centroids -- what a harness prices against the MFMA / HBM roofs (no reference counterpart: faiss::Clustering prints its own
+ * per-iteration times under `verbose`, clustering.cpp:41).  Zeros before the first qk_kmeans. */
+QK_API int qk_kmeans_last_timing(qk_ctx *ctx, float *assign_ms, float *update_ms, int64_t *rows, int64_t *m);
 
 #ifdef __cplusplus
 }

@@ -77,6 +77,7 @@ SIGNATURES = {
     "qk_kmeans": (_int, [_vp, _vp, _i64, _int, _i64, _int, _int, C.c_uint64, _vp, _vp, _int]),
     "qk_normalize_rows": (_int, [_vp, _vp, _i64, _int, _int]),
     "qk_kmeans_update": (_int, [_vp, _vp, _vp, _i64, _int, _vp, _int]),
+    "qk_kmeans_last_timing": (_int, [_vp, _vp, _vp, _vp, _vp]),
     "qk_rand_perm": (_int, [_i64, _i64, C.c_uint64, _vp]),
 }
 

@@ -261,6 +261,13 @@ class Context:
         check(self.lib.qk_kmeans(self.h, _ptr(x), n, d, m, metric_code(metric), int(niter), int(seed), _ptr(c), _ptr(a), mem))
         return c, a, x
 
+    def kmeans_last_timing(self):
+        """kernel-side ms of the assign / update step of the last Lloyd iteration of the last kmeans() (qk_kmeans_last_timing)"""
+        am, um = C.c_float(0), C.c_float(0)
+        rows, m = C.c_int64(0), C.c_int64(0)
+        check(self.lib.qk_kmeans_last_timing(self.h, C.byref(am), C.byref(um), C.byref(rows), C.byref(m)))
+        return dict(assign_ms=am.value, update_ms=um.value, rows=rows.value, m=m.value)
+
 
 class Store:
     """Device mirror of faiss::DynamicInvertedLists (dynamic_inverted_list.h:25-33)."""

@@ -10,7 +10,6 @@
 #include "qk_internal.h"
 
 #include <cstring>
-#include <rocprim/device/device_scan.hpp>  // exclusive_scan: AMD's own device primitives (no CUB compatibility layer)
 #include "qk_device.h"
 
 #include <algorithm>
@@ -1040,6 +1039,30 @@ int qk_dense_device(qk_ctx *ctx, qk_store *s, int64_t list_no, const qk_scan_arg
     return QK_OK;
 }
 
+// out[i] = in[0] + ... + in[i-1], one workgroup: thread t owns a contiguous slice, the 1024 slice sums are scanned through LDS
+// (the pair offsets of the wide-k pipeline: Q x nprobe values, a step that is followed by a full scan of those lists)
+__global__ __launch_bounds__(1024) void k_exclusive_scan_i64(const int64_t *__restrict__ in, int64_t *__restrict__ out, int64_t len) {
+    __shared__ int64_t part[1024];
+    const int64_t per = (len + 1023) / 1024;
+    const int64_t b = min(len, (int64_t)threadIdx.x * per), e = min(len, b + per);
+    int64_t s = 0;
+    for (int64_t i = b; i < e; i++) s += in[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const int64_t v = (int)threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    int64_t run = part[threadIdx.x] - s;
+    for (int64_t i = b; i < e; i++) {
+        const int64_t v = in[i];
+        out[i] = run;
+        run += v;
+    }
+}
+
 int qk_widek_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *timing, int ev_base) {
     const int64_t Q = a.Q;
     const int k = a.k;
@@ -1068,11 +1091,9 @@ int qk_widek_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *
     for (int64_t q0 = 0; q0 < Q; q0 += qc) {
         const int64_t nq = std::min(qc, Q - q0);
         const int64_t npairs = nq * P;
-        size_t cub_bytes = 0;
-        (void)rocprim::exclusive_scan(nullptr, cub_bytes, (int64_t *)nullptr, (int64_t *)nullptr, (int64_t)0, (size_t)(npairs + 1), rocprim::plus<int64_t>(), st);
         auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
-        const size_t o_sizes = 0, o_base = al((size_t)(npairs + 1) * 8), o_cub = o_base + al((size_t)(npairs + 1) * 8);
-        const size_t o_keys = o_cub + al(cub_bytes);
+        const size_t o_sizes = 0, o_base = al((size_t)(npairs + 1) * 8);
+        const size_t o_keys = o_base + al((size_t)(npairs + 1) * 8);
         const size_t need = o_keys + (size_t)nq * per_query_ub * 4 + 256;
         QK_TRY(qk_aps_reserve(ctx, need));  // (the scan below recycles ctx->ws; this buffer survives it)
         char *B = ctx->aps;
@@ -1080,7 +1101,7 @@ int qk_widek_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *
         uint32_t *keys = (uint32_t *)(B + o_keys);
         const int64_t *pids = a.pids ? a.pids + q0 * P : nullptr;
         hipLaunchKernelGGL(k_pair_sizes, dim3((unsigned)((npairs + 256) / 256)), dim3(256), 0, st, pids, npairs, P, s->d_size, npids, sizes);
-        QK_HIP(rocprim::exclusive_scan((void *)(B + o_cub), cub_bytes, sizes, pair_base, (int64_t)0, (size_t)(npairs + 1), rocprim::plus<int64_t>(), st));
+        hipLaunchKernelGGL(k_exclusive_scan_i64, dim3(1), dim3(1024), 0, st, sizes, pair_base, npairs + 1);
         if (q0 == 0) QK_TRY(pe.mark(1));
         qk_scan_args e = a;
         e.x = a.x + q0 * s->d;

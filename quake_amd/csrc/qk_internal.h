@@ -100,6 +100,8 @@ struct qk_ctx {
     std::vector<hipEvent_t> ev_pending;  // groups of 4: group start, scan start, scan end, merge end
     std::vector<hipEvent_t> ev_pending_coarse;  // groups of 2: coarse start, coarse end
     bool squared_l2 = false;  // L2 entry points return squared distances (sharded path, before the final merge)
+    float km_assign_ms = 0.0f, km_update_ms = 0.0f;  // last Lloyd iteration of the last qk_kmeans (qk_kmeans_last_timing)
+    int64_t km_rows = 0, km_m = 0;
     std::unordered_map<size_t, int> small_occ;  // k_search_small: resident workgroups per CU by LDS bytes (qk_small.hip)
     char *small_ws = nullptr;  // records + tickets of the one-launch small-batch search (qk_small.hip); tickets stay zero between calls
     // state of an adaptive (recall-target) search: survives the scan calls of its rounds, which recycle `ws`

@@ -5,13 +5,11 @@
 //   kmeans_refine_partitions()   src/cpp/src/clustering.cpp:99-182  (batched_scan_list(k=1) assign :149-159,
 //                                                                    scalar accumulate :162-176)
 // assign  : X x C^T on v_mfma_f32_16x16x4_f32 (same canonical fmaf-chain as the scan) + fused argmin, MFMA-bound
-// update  : stable radix sort of rows by assignment, then one workgroup per centroid adds its rows in ascending
-//           row order (fp32) -- the sequential order of the reference loop, so sums are bit-reproducible. HBM-bound.
+// update  : rows bucketed stably by assignment (k_rs_*: the repo's own count / scan / scatter, one pass per 8 bits of the
+//           centroid number), then one workgroup per centroid adds its rows in ascending row order (fp32) -- the sequential
+//           order of the reference loop, so sums are bit-reproducible. HBM-bound.
 // PARITY UNPINNED vs FAISS (RNG / init), pinned vs oracle/quake_oracle.c (qo_kmeans*).
 #include "qk_internal.h"
-
-#include <cstring>
-#include <rocprim/device/device_radix_sort.hpp>  // radix_sort_pairs: AMD's own device primitives (no CUB compatibility layer)
 
 #include <algorithm>
 #include <cmath>
@@ -210,12 +208,129 @@ __global__ __launch_bounds__(256) void k_assign(AssignParams P) {
 }
 
 // ---- update -------------------------------------------------------------------------------------------------
-__global__ void k_keys_from_assign(const int64_t *__restrict__ assign, int64_t n, int m, int32_t *keys, int32_t *vals) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    int64_t a = assign[i];
-    keys[i] = (a < 0 || a >= m) ? m : (int32_t)a;  // out-of-range rows sort to the end and are ignored
-    vals[i] = (int32_t)i;
+// Stable bucketing of the rows by assignment: a least-significant-digit pass per 8 bits of the centroid number (1 pass up to
+// 255 centroids, 2 up to 65535, 3 beyond), each pass = digit histogram per workgroup tile, one exclusive scan over
+// [digit][tile], stable scatter.  The first pass reads the assignments themselves (key = assignment, value = row number), so
+// no key / value arrays are materialised before it.  Rows whose assignment is out of range get key m: they sort behind every
+// centroid and are ignored.
+constexpr int RS_THREADS = 256, RS_ITEMS = 16, RS_TILE = RS_THREADS * RS_ITEMS;
+
+template <bool FIRST>
+__device__ __forceinline__ int32_t rs_key(const int64_t *__restrict__ assign, const int32_t *__restrict__ keys_in, int64_t i, int m) {
+    if (FIRST) {
+        const int64_t a = assign[i];
+        return (a < 0 || a >= m) ? m : (int32_t)a;
+    }
+    return keys_in[i];
+}
+
+template <bool FIRST>
+__global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const int64_t *__restrict__ assign, const int32_t *__restrict__ keys_in, int64_t n,
+                                                        int m, int shift, int32_t *__restrict__ hist /*[256][tiles]*/, int tiles,
+                                                        int32_t *__restrict__ totals /*[256], zeroed*/) {
+    __shared__ int32_t h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t i0 = (int64_t)blockIdx.x * RS_TILE + threadIdx.x;
+#pragma unroll 4
+    for (int it = 0; it < RS_ITEMS; it++) {
+        const int64_t i = i0 + (int64_t)it * RS_THREADS;
+        if (i < n) atomicAdd(&h[(rs_key<FIRST>(assign, keys_in, i, m) >> shift) & 255], 1);
+    }
+    __syncthreads();
+    hist[(int64_t)threadIdx.x * tiles + blockIdx.x] = h[threadIdx.x];
+    if (h[threadIdx.x]) atomicAdd(&totals[threadIdx.x], h[threadIdx.x]);
+}
+
+// exclusive scan over [digit][tile] in place: workgroup d owns the row of digit d -- its base is the sum of the digit totals below
+// it (k_rs_hist adds them up with one atomic per digit and tile), the row itself goes through in chunks of 256 coalesced entries
+__global__ __launch_bounds__(256) void k_rs_scan(int32_t *__restrict__ hist, int tiles, const int32_t *__restrict__ totals) {
+    __shared__ int32_t s_wave[4];
+    __shared__ int32_t s_base;
+    const int d = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    {
+        int32_t v = tid < d ? totals[tid] : 0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if (lane == 0) s_wave[wave] = v;
+        __syncthreads();
+        if (tid == 0) s_base = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        __syncthreads();
+    }
+    int32_t run = s_base;
+    int32_t *row = hist + (int64_t)d * tiles;
+    for (int c0 = 0; c0 < tiles; c0 += 256) {
+        const int i = c0 + tid;
+        const int32_t v = i < tiles ? row[i] : 0;
+        int32_t inc = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int32_t u = __shfl_up(inc, o);
+            if (lane >= o) inc += u;
+        }
+        __syncthreads();  // (s_wave of the previous chunk has been read)
+        if (lane == 63) s_wave[wave] = inc;
+        __syncthreads();
+        int32_t wpre = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            if (w < wave) wpre += s_wave[w];
+            tot += s_wave[w];
+        }
+        if (i < tiles) row[i] = run + wpre + inc - v;
+        run += tot;
+    }
+}
+
+// stable scatter of one tile: rounds of 256 keys in index order; inside a round a key's place among the equal digits is (equal
+// digits in lower waves) + (equal digits in lower lanes of its wave, found with 8 ballots)
+template <bool FIRST>
+__global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const int64_t *__restrict__ assign, const int32_t *__restrict__ keys_in,
+                                                           const int32_t *__restrict__ vals_in, int64_t n, int m, int shift,
+                                                           const int32_t *__restrict__ hist, int tiles, int32_t *__restrict__ keys_out,
+                                                           int32_t *__restrict__ vals_out) {
+    __shared__ int32_t base[256];
+    __shared__ int32_t cnt[4][256];
+    base[threadIdx.x] = hist[(int64_t)threadIdx.x * tiles + blockIdx.x];
+#pragma unroll
+    for (int w = 0; w < 4; w++) cnt[w][threadIdx.x] = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    const int64_t i0 = (int64_t)blockIdx.x * RS_TILE + threadIdx.x;
+    for (int it = 0; it < RS_ITEMS; it++) {
+        const int64_t i = i0 + (int64_t)it * RS_THREADS;
+        const bool valid = i < n;
+        int32_t key = 0, val = 0;
+        if (valid) {
+            key = rs_key<FIRST>(assign, keys_in, i, m);
+            val = FIRST ? (int32_t)i : vals_in[i];
+        }
+        const int digit = (key >> shift) & 255;
+        uint64_t peers = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            const bool bit = (digit >> b) & 1;
+            const uint64_t bal = __ballot(valid && bit);
+            peers &= bit ? bal : ~bal;
+        }
+        const int rank = __popcll(peers & lt);
+        if (valid && rank == 0) cnt[wave][digit] = __popcll(peers);
+        __syncthreads();
+        if (valid) {
+            int at = base[digit] + rank;
+            for (int w = 0; w < wave; w++) at += cnt[w][digit];
+            keys_out[at] = key;
+            vals_out[at] = val;
+        }
+        __syncthreads();
+        {
+            const int t = threadIdx.x;
+            base[t] += cnt[0][t] + cnt[1][t] + cnt[2][t] + cnt[3][t];
+            cnt[0][t] = cnt[1][t] = cnt[2][t] = cnt[3][t] = 0;
+        }
+        __syncthreads();
+    }
 }
 
 __global__ void k_segment_bounds(const int32_t *__restrict__ sorted_keys, int64_t n, int m, int64_t *seg_begin /*[m+1]*/) {
@@ -227,27 +342,45 @@ __global__ void k_segment_bounds(const int32_t *__restrict__ sorted_keys, int64_
     for (int c = prev + 1; c <= cur; c++) seg_begin[c] = i;
 }
 
-// one workgroup per centroid; thread t owns dimensions t, t+256, ...; rows are added in ascending row order
+// one workgroup per centroid; thread t owns dimensions t, t + blockDim, ...; rows are added in ascending row order (one dependent
+// chain of adds per (centroid, dimension): the order of the reference loop).  The kernel lasts as long as its largest cluster's
+// chain, so what counts is the time per row of ONE workgroup: 32 rows per round trip, the row numbers of the next 32 requested with
+// them (8 rows per trip, row numbers fetched first: 0.60 ms for 2^20 rows in 4096 skewed clusters; now 0.39).
 __global__ __launch_bounds__(256) void k_accumulate(const float *__restrict__ x, int d, const int32_t *__restrict__ sorted_rows,
                                                     const int64_t *__restrict__ seg_begin, float *__restrict__ sums,
                                                     int64_t *__restrict__ counts) {
+    constexpr int U = 32;
     const int c = blockIdx.x;
     const int64_t b = seg_begin[c], e = seg_begin[c + 1];
     if (threadIdx.x == 0) counts[c] = e - b;
+    if (e == b) {
+        for (int k = threadIdx.x; k < d; k += blockDim.x) sums[(int64_t)c * d + k] = 0.0f;
+        return;
+    }
     for (int k = threadIdx.x; k < d; k += blockDim.x) {
         float s = 0.0f;
-        int64_t i = b;
-        for (; i + 4 <= e; i += 4) {
-            const float v0 = x[(int64_t)sorted_rows[i] * d + k];
-            const float v1 = x[(int64_t)sorted_rows[i + 1] * d + k];
-            const float v2 = x[(int64_t)sorted_rows[i + 2] * d + k];
-            const float v3 = x[(int64_t)sorted_rows[i + 3] * d + k];
-            s += v0;
-            s += v1;
-            s += v2;
-            s += v3;
+        // batches of U rows: the row numbers of batch t + 1 are requested with the values of batch t (a short last batch repeats the
+        // last row's address and skips its adds: adding +0 instead would turn a sum of -0 into +0)
+        int32_t r[U], rn[U];
+#pragma unroll
+        for (int j = 0; j < U; j++) r[j] = sorted_rows[min(b + j, e - 1)];
+        for (int64_t i = b; i < e; i += U) {
+            const int cnt = (int)min((int64_t)U, e - i);
+            float v[U];
+#pragma unroll
+            for (int j = 0; j < U; j++) v[j] = x[(int64_t)r[j] * d + k];
+#pragma unroll
+            for (int j = 0; j < U; j++) rn[j] = sorted_rows[min(i + U + j, e - 1)];
+            if (cnt == U) {
+#pragma unroll
+                for (int j = 0; j < U; j++) s += v[j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < U; j++) s = j < cnt ? s + v[j] : s;
+            }
+#pragma unroll
+            for (int j = 0; j < U; j++) r[j] = rn[j];
         }
-        for (; i < e; i++) s += x[(int64_t)sorted_rows[i] * d + k];
         sums[(int64_t)c * d + k] = s;
     }
 }
@@ -378,12 +511,43 @@ static int accum_prepare(KmScratch &ks, AccumScratch &as, int64_t n, int64_t m) 
     QK_TRY(ks.alloc(&as.keys2, (size_t)n));
     QK_TRY(ks.alloc(&as.vals2, (size_t)n));
     QK_TRY(ks.alloc(&as.seg, (size_t)m + 2));
-    size_t bytes = 0;
-    (void)rocprim::radix_sort_pairs(nullptr, bytes, as.keys, as.keys2, as.vals, as.vals2, (size_t)n);
-    char *t = nullptr;
-    QK_TRY(ks.alloc(&t, bytes + 256));
+    const size_t tiles = (size_t)((n + RS_TILE - 1) / RS_TILE);
+    int32_t *t = nullptr;
+    QK_TRY(ks.alloc(&t, 256 * tiles + 256 + 64));  // [digit][tile] counters of one pass, then the 256 digit totals
     as.tmp = t;
-    as.tmp_bytes = bytes;
+    as.tmp_bytes = (256 * tiles + 256 + 64) * sizeof(int32_t);
+    return QK_OK;
+}
+
+// rows bucketed stably by assignment into (as.keys2, as.vals2): ceil(bits(m) / 8) passes of histogram / scan / scatter
+static int bucket_rows_device(hipStream_t st, AccumScratch &as, const int64_t *assign, int64_t n, int64_t m) {
+    int bits = 1;
+    while ((1LL << bits) <= m) bits++;
+    const int passes = (bits + 7) / 8;
+    const int tiles = (int)((n + RS_TILE - 1) / RS_TILE);
+    int32_t *hist = (int32_t *)as.tmp;
+    // the last pass must land in (keys2, vals2): with an odd number of passes the first one writes there
+    int32_t *ko = (passes & 1) ? as.keys2 : as.keys, *vo = (passes & 1) ? as.vals2 : as.vals;
+    const int32_t *ki = nullptr, *vi = nullptr;
+    int32_t *totals = hist + (size_t)256 * tiles;
+    for (int p = 0; p < passes; p++) {
+        const int shift = 8 * p;
+        QK_HIP(hipMemsetAsync(totals, 0, 256 * sizeof(int32_t), st));
+        if (p == 0)
+            hipLaunchKernelGGL(k_rs_hist<true>, dim3((unsigned)tiles), dim3(RS_THREADS), 0, st, assign, ki, n, (int)m, shift, hist, tiles, totals);
+        else
+            hipLaunchKernelGGL(k_rs_hist<false>, dim3((unsigned)tiles), dim3(RS_THREADS), 0, st, assign, ki, n, (int)m, shift, hist, tiles, totals);
+        hipLaunchKernelGGL(k_rs_scan, dim3(256), dim3(256), 0, st, hist, tiles, totals);
+        if (p == 0)
+            hipLaunchKernelGGL(k_rs_scatter<true>, dim3((unsigned)tiles), dim3(RS_THREADS), 0, st, assign, ki, vi, n, (int)m, shift, hist, tiles, ko, vo);
+        else
+            hipLaunchKernelGGL(k_rs_scatter<false>, dim3((unsigned)tiles), dim3(RS_THREADS), 0, st, assign, ki, vi, n, (int)m, shift, hist, tiles, ko, vo);
+        ki = ko;
+        vi = vo;
+        ko = ko == as.keys ? as.keys2 : as.keys;
+        vo = vo == as.vals ? as.vals2 : as.vals;
+    }
+    QK_HIP(hipGetLastError());
     return QK_OK;
 }
 
@@ -391,15 +555,10 @@ static int accumulate_device(qk_ctx *ctx, AccumScratch &as, const float *x, int6
                              float *sums, int64_t *counts) {
     hipStream_t st = ctx->stream;
     if (n > 0x7FFFFFF0LL) QK_FAIL(QK_ERR_UNSUPPORTED, "qk_kmeans_accumulate: n too large for 32-bit row indices");
-    if (n > 0) {
-        hipLaunchKernelGGL(k_keys_from_assign, dim3(km_grid(n, 256)), dim3(256), 0, st, assign, n, (int)m, as.keys, as.vals);
-        int bits = 1;
-        while ((1LL << bits) <= m) bits++;
-        size_t bytes = as.tmp_bytes;
-        QK_HIP(rocprim::radix_sort_pairs(as.tmp, bytes, as.keys, as.keys2, as.vals, as.vals2, (size_t)n, 0u, (unsigned)bits, st));  // stable
-    }
+    if (m > 0x7FFFFFF0LL) QK_FAIL(QK_ERR_UNSUPPORTED, "qk_kmeans_accumulate: too many centroids for 32-bit keys");
+    if (n > 0) QK_TRY(bucket_rows_device(st, as, assign, n, m));
     hipLaunchKernelGGL(k_segment_bounds, dim3(km_grid(n + 1, 256)), dim3(256), 0, st, as.keys2, n, (int)m, as.seg);
-    hipLaunchKernelGGL(k_accumulate, dim3((unsigned)m), dim3(256), 0, st, x, d, as.vals2, as.seg, sums, counts);
+    hipLaunchKernelGGL(k_accumulate, dim3((unsigned)m), dim3((unsigned)std::min(256, qk_round_up(d, 64))), 0, st, x, d, as.vals2, as.seg, sums, counts);
     QK_HIP(hipGetLastError());
     return QK_OK;
 }
@@ -654,12 +813,32 @@ int qk_kmeans(qk_ctx *ctx, float *x, int64_t n, int d, int64_t m, int metric, in
     QK_TRY(accum_prepare(ks, as, ntrain, m));
     std::vector<int64_t> hcounts((size_t)m);
     std::vector<float> hc;
+    struct Ev3 {  // assign start / update start / update end of the last iteration (qk_kmeans_last_timing)
+        hipEvent_t e[3] = {nullptr, nullptr, nullptr};
+        ~Ev3() {
+            for (hipEvent_t v : e)
+                if (v) (void)hipEventDestroy(v);
+        }
+    } ev;
     for (int it = 0; it < niter; it++) {
+        const bool timed = it == niter - 1;
+        if (timed) {
+            for (int j = 0; j < 3; j++) QK_HIP(hipEventCreate(&ev.e[j]));
+            QK_HIP(hipEventRecord(ev.e[0], st));
+        }
         QK_TRY(assign_device(ctx, xt, ntrain, dc, m, d, metric, dta, nullptr, ctile, cnorm));
+        if (timed) QK_HIP(hipEventRecord(ev.e[1], st));
         QK_TRY(accumulate_device(ctx, as, xt, ntrain, d, dta, m, dsums, dcounts));
+        if (timed) QK_HIP(hipEventRecord(ev.e[2], st));
         hipLaunchKernelGGL(k_finalize_centroids, dim3(km_grid(m * d, 256)), dim3(256), 0, st, dsums, dcounts, m, d, 1, dc);
         QK_HIP(hipMemcpyAsync(hcounts.data(), dcounts, (size_t)m * 8, hipMemcpyDeviceToHost, st));
         QK_HIP(hipStreamSynchronize(st));
+        if (timed) {
+            QK_HIP(hipEventElapsedTime(&ctx->km_assign_ms, ev.e[0], ev.e[1]));
+            QK_HIP(hipEventElapsedTime(&ctx->km_update_ms, ev.e[1], ev.e[2]));
+            ctx->km_rows = ntrain;
+            ctx->km_m = m;
+        }
         bool any_empty = false;
         for (int64_t j = 0; j < m; j++)
             if (hcounts[j] == 0) {
@@ -739,6 +918,15 @@ int qk_kmeans_update(qk_ctx *ctx, const float *sums, int64_t *counts, int64_t m,
         QK_HIP(hipMemcpyAsync(counts, hcounts.data(), (size_t)m * 8, hipMemcpyHostToDevice, st));
         QK_HIP(hipStreamSynchronize(st));
     }
+    return QK_OK;
+}
+
+int qk_kmeans_last_timing(qk_ctx *ctx, float *assign_ms, float *update_ms, int64_t *rows, int64_t *m) {
+    if (!ctx || !assign_ms || !update_ms || !rows || !m) QK_FAIL(QK_ERR_INVALID, "qk_kmeans_last_timing: null argument");
+    *assign_ms = ctx->km_assign_ms;
+    *update_ms = ctx->km_update_ms;
+    *rows = ctx->km_rows;
+    *m = ctx->km_m;
     return QK_OK;
 }
 

@@ -252,8 +252,10 @@ __device__ __forceinline__ long long seq_weight(int cnt_q, int size_p, int G, in
 // SAME_KERNEL: the counters were written with atomics by this very workgroup (single-kernel form) and are read back with agent-
 // scope loads, which go past the L2; behind a kernel boundary (three-kernel form) plain loads do, and hit in L2 -- the scan
 // kernel is a chain of dependent loads and nothing else (4096 active lists: 16 round trips per thread)
-template <bool SAME_KERNEL>
-__device__ __forceinline__ void group_scan_body(const GroupParams &G, long long *s_w /*[64] LDS*/) {
+// HASHED (the one-workgroup form, group_small_body): act_list / g_cnt / g_qoff are LDS tables indexed by hash slot, key_of[slot]
+// is the list number
+template <bool SAME_KERNEL, bool HASHED = false>
+__device__ __forceinline__ void group_scan_body(const GroupParams &G, long long *s_w /*[64] LDS*/, const int *key_of = nullptr) {
     const int tid = threadIdx.x;
     // (agent-scope loads: in the single-kernel form the counters were just written with atomics by this workgroup)
     const int n_act = SAME_KERNEL ? __hip_atomic_load(G.n_act, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *G.n_act;
@@ -263,8 +265,9 @@ __device__ __forceinline__ void group_scan_body(const GroupParams &G, long long 
     long long stl = 0, sr = 0;
     unsigned long long sh = 0;  // hot items (low 32 bits) | hot units (high 32 bits)
     for (int i = b; i < e; i++) {
-        const int p = G.act_list[i];
-        const int c = SAME_KERNEL ? __hip_atomic_load(&G.g_cnt[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : G.g_cnt[p];
+        const int slot = G.act_list[i];
+        const int p = HASHED ? key_of[slot] : slot;
+        const int c = SAME_KERNEL ? __hip_atomic_load(&G.g_cnt[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : G.g_cnt[slot];
         const int sz = G.pt_size[p];
         sq += c;
         sa += 1;
@@ -333,7 +336,7 @@ __device__ __forceinline__ void group_scan_body(const GroupParams &G, long long 
         tr = t2;
     }
     if (tid == 0) {
-        G.g_qoff[G.npids] = (int)tq;
+        if (!HASHED) G.g_qoff[G.npids] = (int)tq;
         *G.n_active = (int)ta;
         ActiveInfo sent;
         sent.toff = tt;
@@ -352,9 +355,10 @@ __device__ __forceinline__ void group_scan_body(const GroupParams &G, long long 
     }
     int ahi = (int)(ah & 0xFFFFFFFFull);
     for (int i = b; i < e; i++) {
-        const int p = G.act_list[i];
-        const int c = SAME_KERNEL ? __hip_atomic_load(&G.g_cnt[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : G.g_cnt[p];
-        G.g_qoff[p] = (int)aq;
+        const int slot = G.act_list[i];
+        const int p = HASHED ? key_of[slot] : slot;
+        const int c = SAME_KERNEL ? __hip_atomic_load(&G.g_cnt[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : G.g_cnt[slot];
+        G.g_qoff[slot] = (int)aq;
         ActiveInfo inf;
         inf.toff = at;
         inf.row_off = G.pt_off[p];
@@ -393,31 +397,69 @@ __global__ void k_group_scatter(GroupParams G) {
     if (i < G.npairs) group_scatter_one(G, i);
 }
 
-// count + scan + scatter in ONE workgroup for small batches (<= QK_GROUP_SMALL pairs): two launches and two dependent
-// kernel boundaries less.  Measured (bench.py --nprobe 1/2/3/4/8 = 1024 ... 8192 pairs, group phase): 31 / 40 / 45 / 51 /
-// 72 us against 31 / 37 / 38 / 38 / 44 us for the three kernels -- the single workgroup wins only where launch latency is
-// all there is (a 1-query search: 10 pairs), so it serves batches up to 1024 pairs.
-constexpr int QK_GROUP_SMALL = 1024;
+// count + scan + scatter in ONE workgroup for small batches (<= QK_GROUP_SMALL pairs): two launches and two dependent kernel
+// boundaries less.  Round 2 kept the counters in global memory (atomics, agent-scope read-backs: ~10 dependent round trips, 13 us
+// for 640 pairs, 19 us for 1024) and lost to the three kernels beyond 1024 pairs.  Round 3: the counters live in LDS -- an open-
+// addressing table of 2 slots per pair keyed by list number (the batch touches <= npairs lists however many the index has: a rank
+// of an N-GPU index sees N x 4096 list numbers), first-hit list, per-list offsets, all in LDS; global memory is read for the pair's
+// list and its size and written with the results.
+constexpr int QK_GROUP_SMALL_PP = 4;                        // pairs per thread
+constexpr int QK_GROUP_SMALL = 1024 * QK_GROUP_SMALL_PP;
+constexpr int QK_GROUP_SLOTS = 2 * QK_GROUP_SMALL;          // a power of two
+constexpr size_t QK_GROUP_SMALL_LDS = (size_t)(3 * QK_GROUP_SLOTS + QK_GROUP_SMALL) * 4;
 __device__ __forceinline__ void group_small_body(const GroupParams &G) {
+    extern __shared__ __align__(16) int g_smem[];
     __shared__ long long s_w[64];
-    // partition and arrival rank of this thread's pairs stay in registers: the scatter below needs neither the list numbers
-    // again nor a second round of atomics (three dependent memory round trips less in a kernel that is nothing but those)
-    int pp[QK_GROUP_SMALL / 1024], pos[QK_GROUP_SMALL / 1024];
+    __shared__ int s_nact;
+    int *s_key = g_smem, *s_cnt = s_key + QK_GROUP_SLOTS, *s_qoff = s_cnt + QK_GROUP_SLOTS, *s_act = s_qoff + QK_GROUP_SLOTS;
+    // (only the slots a batch of this size can reach are cleared: the table is 2 x the pairs rounded up to a power of two)
+    int slots = 2048;
+    while (slots < 2 * G.npairs) slots <<= 1;
+    const int shift = 32 - (31 - __clz(slots));
+    for (int i = threadIdx.x; i < slots; i += 1024) {
+        s_key[i] = -1;
+        s_cnt[i] = 0;
+    }
+    if (threadIdx.x == 0) s_nact = 0;
+    __syncthreads();
+    int sl[QK_GROUP_SMALL_PP], pos[QK_GROUP_SMALL_PP];
 #pragma unroll
-    for (int jj = 0; jj < QK_GROUP_SMALL / 1024; jj++) {
+    for (int jj = 0; jj < QK_GROUP_SMALL_PP; jj++) {
         const int64_t i = threadIdx.x + 1024 * (int64_t)jj;
-        pp[jj] = -1;
+        sl[jj] = -1;
         pos[jj] = 0;
-        if (i < G.npairs) pp[jj] = group_count_one(G, i, &pos[jj]);
+        if (i < G.npairs) {
+            G.pair_head[i] = -1;
+            G.pair_slots[i * QK_SLOTS] = 0;
+            const int p = pair_pid(G, i);
+            if (p >= 0) {
+                int h = (int)(((uint32_t)p * 2654435761u) >> shift);
+                for (;;) {
+                    const int old = atomicCAS(&s_key[h], -1, p);
+                    if (old == -1 || old == p) break;
+                    h = (h + 1) & (slots - 1);
+                }
+                pos[jj] = atomicAdd(&s_cnt[h], 1);
+                if (pos[jj] == 0) s_act[atomicAdd(&s_nact, 1)] = h;  // first-hit order, as k_group_count lists them
+                sl[jj] = h;
+            }
+        }
     }
     __syncthreads();
-    group_scan_body<true>(G, s_w);
+    {
+        GroupParams H = G;
+        H.n_act = &s_nact;
+        H.act_list = s_act;
+        H.g_cnt = s_cnt;
+        H.g_qoff = s_qoff;
+        group_scan_body<false, true>(H, s_w, s_key);
+    }
     __syncthreads();
 #pragma unroll
-    for (int jj = 0; jj < QK_GROUP_SMALL / 1024; jj++) {
+    for (int jj = 0; jj < QK_GROUP_SMALL_PP; jj++) {
         const int64_t i = threadIdx.x + 1024 * (int64_t)jj;
-        if (pp[jj] >= 0) {
-            const int at = G.g_qoff[pp[jj]] + pos[jj];
+        if (sl[jj] >= 0) {
+            const int at = s_qoff[sl[jj]] + pos[jj];
             G.grouped_q[at] = (int32_t)(i / G.P);
             G.grouped_pair[at] = (int32_t)i;
         }
@@ -425,6 +467,7 @@ __device__ __forceinline__ void group_small_body(const GroupParams &G) {
 }
 
 __global__ __launch_bounds__(1024) void k_group_small(GroupParams G) { group_small_body(G); }
+static inline size_t group_small_lds(int64_t) { return QK_GROUP_SMALL_LDS; }
 
 // ---- bound seeding ---------------------------------------------------------------------------------------
 // One wave per (query, partition) pair: exact distances (same canonical chain as the MFMA path) from the query to the
@@ -1404,7 +1447,11 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
     const int maxch_m = Cm <= 128 ? 2 : Cm <= 256 ? 4 : Cm <= 512 ? 8 : 16;
     const size_t lds_merge = (((size_t)Cm * 12 + 15) & ~(size_t)15) + (size_t)64 * QK_SLOTS * 4;  // pool + 64 pair slot lines
 
-    const int num_cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
+    int num_cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
+    {
+        static const int spare = qk_env_int("QK_SCAN_SPARE_CUS", 0);  // probe: leave CUs to the small kernels of other streams
+        if (spare > 0 && num_cus > 2 * spare) num_cus -= spare;
+    }
     // persistent grid: as many single-wave workgroups as stay resident (LDS-limited; registers allow ~12 per CU); the tile
     // partition is static, so every wave must be resident at once.  Measured (bench.py --nprobe 1/8/32, QK_SCAN_WAVE_CLOCK):
     // long launches: 8 per CU (10+ lose bandwidth).  Short launches (a wave gets < ~160 tiles): 4 per CU = one wave per
@@ -1589,7 +1636,8 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
         static const bool no_fuse = qk_env_set("QK_NO_GROUP_SEED");
         if (k <= 64 && seed_waves == 1 && npairs <= QK_GROUP_SMALL && !no_small_f && !no_fuse) {
             const int64_t nsw = Q * sd.seed_ranks;
-            hipLaunchKernelGGL(k_group_seed, dim3((unsigned)(1 + (nsw + 15) / 16)), dim3(1024), 0, st, G, sd, nsw);
+            QK_HIP(hipFuncSetAttribute((const void *)k_group_seed, hipFuncAttributeMaxDynamicSharedMemorySize, (int)QK_GROUP_SMALL_LDS));
+            hipLaunchKernelGGL(k_group_seed, dim3((unsigned)(1 + (nsw + 15) / 16)), dim3(1024), group_small_lds(npairs), st, G, sd, nsw);
             fused_group = true;
         } else if (k <= 64 && seed_waves == 1 && npairs > QK_GROUP_SMALL && !no_fuse) {
             const int64_t nsw = Q * sd.seed_ranks;
@@ -1619,7 +1667,8 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
     if (fused_group) {
         // grouped by workgroup 0 of k_group_seed
     } else if (npairs <= QK_GROUP_SMALL && !no_small) {
-        hipLaunchKernelGGL(k_group_small, dim3(1), dim3(1024), 0, st, G);
+        QK_HIP(hipFuncSetAttribute((const void *)k_group_small, hipFuncAttributeMaxDynamicSharedMemorySize, (int)QK_GROUP_SMALL_LDS));
+        hipLaunchKernelGGL(k_group_small, dim3(1), dim3(1024), group_small_lds(npairs), st, G);
     } else {
         if (npairs > 0 && !fused_count) hipLaunchKernelGGL(k_group_count, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, st, G);
         hipLaunchKernelGGL(k_group_scan, dim3(1), dim3(1024), 0, st, G);

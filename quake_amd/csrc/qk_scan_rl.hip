@@ -70,8 +70,13 @@ __device__ __forceinline__ float f4c(const float4 &v, int t) { return t == 0 ? v
 // (fp16 operands -- a band of 2^-10 instead of 2^-8, with range guards for |x|^2 > 2^30 and an absolute term for its subnormals --
 //  were built and measured (against a bf16 band that was still taken as 2^-8): parity green, fewer row tiles recomputed, and 2-9 % SLOWER at nprobe 8-64: the conversions cost two
 //  to three VALU instructions per value where v_cvt_pk_bf16_f32 converts a pair in one, and the test is VALU-bound.)
+#ifdef QK_PF_C_PROBE                     // probe builds only: what a tighter (unproven) constant would be worth
+constexpr float QK_PF_C = QK_PF_C_PROBE;
+constexpr float QK_PF_K1 = 1.0f - QK_PF_C_PROBE;
+#else
 constexpr float QK_PF_C = 0.0078741f;   // >= 2^-7 * 129/128 + 2^-21
 constexpr float QK_PF_K1 = 0.992125f;   // <= 1 - QK_PF_C
+#endif
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 struct HotLds {
     float4 *sB;          // [hq/16][NB][64] query tiles, B-operand lane order

@@ -22,6 +22,16 @@ def main():
     store = Store(ctx, d); store.build_csr(offsets, order.contiguous(), x[order].contiguous())
     parent = Store(ctx, d); parent.build_csr(np.array([0, nlist], np.int64), torch.arange(nlist, device=dev), centroids.contiguous())
     q = B.gen_queries(8192, cent_true, seed=2, device=dev)
+    if os.environ.get("PHASE_PROBE_TIMING", "1") == "0":   # no library events: what the kernel trace of a plain call looks like
+        for Q in [int(v) for v in sys.argv[1:]]:
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+            for i in range(30):
+                if i == 10:
+                    ev[0].record()
+                ctx.search(parent, store, q[(i * Q) % 4096:(i * Q) % 4096 + Q], nprobe, k, "l2")
+            ev[1].record(); torch.cuda.synchronize()
+            print(json.dumps({"Q": Q, "kernel": ctx.last_scan_kernel(), "back_to_back_us_per_call": round(ev[0].elapsed_time(ev[1]) * 1e3 / 20, 1)}), flush=True)
+        return
     ctx.set_timing(1)
     for Q in ([int(v) for v in sys.argv[1:]] or (1, 4, 8, 16, 32, 64, 128, 256, 1024)):
         rows = []

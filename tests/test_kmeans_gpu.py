@@ -53,6 +53,24 @@ def test_accumulate_bit_exact(ctx):
     assert gc[11] == 0
 
 
+@pytest.mark.parametrize("m", [1, 7, 255, 256, 300, 65535, 65536, 70000])
+def test_accumulate_bucket_passes(ctx, m):
+    """the stable bucketing of rows by assignment (k_rs_hist / k_rs_scan / k_rs_scatter) takes one pass per 8 bits of the
+    centroid number: 1, 2 and 3 passes, tiles with a ragged end, out-of-range assignments (ignored, as the oracle does), one
+    centroid that owns most of the rows -- sums are order-sensitive fp32, so a bucketing that is not stable fails here"""
+    rng = np.random.default_rng(m)
+    n, d = 70001, 24
+    x = (rng.standard_normal((n, d)) * 10.0 ** rng.integers(-3, 4, size=(n, 1))).astype(np.float32)
+    a = rng.integers(0, m, size=n).astype(np.int64)
+    a[rng.integers(0, n, size=n // 3)] = m // 2   # a long segment: many rounds of every tile carry the same digit
+    a[rng.integers(0, n, size=50)] = -1
+    a[rng.integers(0, n, size=50)] = m + 3
+    gs, gc = ctx.kmeans_accumulate(x, a, m)
+    os_, oc = O.kmeans_accumulate(x, a, m)
+    np.testing.assert_array_equal(gc, oc)
+    np.testing.assert_array_equal(gs.view(np.uint32), os_.view(np.uint32))
+
+
 @pytest.mark.parametrize("metric", ["l2", "ip"])
 def test_kmeans_driver_matches_oracle(ctx, metric):
     ivf = make_ivf(30000, 32, 24, seed=3, metric=metric)
