@@ -1,5 +1,6 @@
 """Builds quake_amd/_bindings.so: the C++ host mirror (quake_amd/cpp/) + pybind11 module, linked against the in-tree
-libquake_hip.so.  `python -m quake_amd.build_ext`.  Uses torch.utils.cpp_extension (host C++ only: no device code here)."""
+libquake_hip.so.  `python -m quake_amd.build_ext`.  Uses torch.utils.cpp_extension (host C++ only: no device code here; the HIP runtime
+headers come in for c10::hip::getCurrentHIPStream alone)."""
 import glob
 import os
 import shutil
@@ -25,7 +26,8 @@ def build_bindings(force=False, verbose=False):
     cpp_extension.load(
         name="_bindings", sources=srcs, build_directory=bdir, verbose=verbose, is_python_module=False,
         extra_cflags=["-O2", "-std=c++17"],
-        extra_ldflags=[f"-L{libdir}", "-lquake_hip", "-Wl,-rpath,$ORIGIN/lib", f"-Wl,-rpath,{libdir}"],
+        extra_include_paths=["/opt/rocm/include"],  # (c10/hip/HIPStream.h: torch's current stream)
+        extra_ldflags=[f"-L{libdir}", "-lquake_hip", "-lc10_hip", "-Wl,-rpath,$ORIGIN/lib", f"-Wl,-rpath,{libdir}"],
         with_cuda=False)
     built = glob.glob(os.path.join(bdir, "_bindings*.so"))
     if not built:

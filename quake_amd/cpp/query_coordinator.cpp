@@ -1,6 +1,8 @@
 // query_coordinator.cpp -- see query_coordinator.h.  No arithmetic here: tensors are marshalled to the C ABI.
 #include "query_coordinator.h"
 
+#include <c10/hip/HIPStream.h>
+
 #include <chrono>
 #include <cstring>
 #include <stdexcept>
@@ -14,6 +16,23 @@ namespace quake_amd {
 namespace {
 using clk = std::chrono::high_resolution_clock;
 inline int64_t ns_since(clk::time_point t0) { return std::chrono::duration_cast<std::chrono::nanoseconds>(clk::now() - t0).count(); }
+
+// Device tensors in: the library works on torch's CURRENT stream for the length of the call (the newly bound stream waits for
+// the previous one through an event, qk_ctx_set_stream), so it is ordered behind whatever produced the inputs and the outputs are
+// ordered in front of whatever torch enqueues next -- no device-wide synchronisation.  The context is shared (one per device):
+// its private stream comes back on every way out.
+struct BoundToTorchStream {
+    qk_ctx *c = nullptr;
+    BoundToTorchStream(qk_ctx *ctx, const Tensor &t) {
+        if (!t.is_cuda()) return;
+        c = ctx;
+        hipStream_t st = c10::hip::getCurrentHIPStream(t.device().index()).stream();
+        qk_check(st ? qk_ctx_set_stream(c, (void *)st) : qk_ctx_set_null_stream(c));
+    }
+    ~BoundToTorchStream() {
+        if (c) (void)qk_ctx_set_stream(c, nullptr);
+    }
+};
 }  // namespace
 
 QueryCoordinator::QueryCoordinator(shared_ptr<QuakeIndex> parent, shared_ptr<PartitionManager> partition_manager,
@@ -53,9 +72,7 @@ shared_ptr<SearchResult> QueryCoordinator::search(Tensor x, shared_ptr<SearchPar
     if (!store) throw std::runtime_error("[QueryCoordinator::search] partitions are not initialized.");
     const bool on_dev = x.is_cuda();
     Tensor xq = on_dev ? x.to(torch::kFloat32).contiguous() : host_f32(x);
-    // the library runs on its own stream: device inputs must be complete before it starts (the calls below hand back a
-    // drained stream, so the outputs are ready for torch's stream)
-    if (on_dev) torch::cuda::synchronize(xq.device().index());
+    BoundToTorchStream bound(ctx, xq);
     const int64_t Q = xq.size(0);
     const int k = sp->k > 0 ? sp->k : 1;  // :490
     const int nprobe = std::max(sp->nprobe, 1);
@@ -125,10 +142,13 @@ shared_ptr<SearchResult> QueryCoordinator::scan_partitions(Tensor x, Tensor part
     auto t0 = clk::now();
     qk_store *store = partition_manager_->store();
     if (!store) throw std::runtime_error("[QueryCoordinator::scan_partitions] partitions are not initialized.");
-    Tensor xq = host_f32(x);
+    // device queries stay on the device (the list numbers follow them there), host queries go through the staging buffers
+    const bool on_dev = x.is_cuda();
+    Tensor xq = on_dev ? x.to(torch::kFloat32).contiguous() : host_f32(x);
+    BoundToTorchStream bound(partition_manager_->ctx(), xq);
     const int64_t Q = xq.size(0);
     const int k = sp->k > 0 ? sp->k : 1;
-    Tensor pids = host_i64(partition_ids);
+    Tensor pids = on_dev ? partition_ids.to(xq.device(), torch::kInt64).contiguous() : host_i64(partition_ids);
     if (pids.dim() == 1) pids = pids.unsqueeze(0).expand({Q, pids.size(0)}).contiguous();  // the same set for every query (:506-508)
     const int P = (int)pids.size(1);
     auto res = std::make_shared<SearchResult>();
@@ -136,14 +156,14 @@ shared_ptr<SearchResult> QueryCoordinator::scan_partitions(Tensor x, Tensor part
     ti->search_params = sp;
     ti->n_queries = Q;
     ti->n_clusters = partition_manager_->nlist();
-    res->ids = torch::empty({Q, k}, torch::kInt64);
-    res->distances = torch::empty({Q, k}, torch::kFloat32);
+    res->ids = torch::empty({Q, k}, torch::TensorOptions().dtype(torch::kInt64).device(xq.device()));
+    res->distances = torch::empty({Q, k}, torch::TensorOptions().dtype(torch::kFloat32).device(xq.device()));
     qk_timing tm;
     std::memset(&tm, 0, sizeof(tm));
-    Tensor none = torch::full({Q, 1}, -1, torch::kInt64);  // zero partitions: padded output (:459-497)
+    Tensor none = torch::full({Q, 1}, -1, torch::TensorOptions().dtype(torch::kInt64).device(xq.device()));  // zero partitions: padded output (:459-497)
     const Tensor &pp = P > 0 ? pids : none;
     qk_check(qk_scan(partition_manager_->ctx(), store, xq.data_ptr<float>(), Q, pp.data_ptr<int64_t>(), (int)pp.size(1), k, (int)metric_,
-                     res->ids.data_ptr<int64_t>(), res->distances.data_ptr<float>(), QK_MEM_HOST, &tm));
+                     res->ids.data_ptr<int64_t>(), res->distances.data_ptr<float>(), on_dev ? QK_MEM_DEVICE : QK_MEM_HOST, &tm));
     ti->partitions_scanned = (int)tm.partitions_scanned;
     ti->total_time_ns = ns_since(t0);
     return res;

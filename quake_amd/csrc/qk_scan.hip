@@ -1410,7 +1410,11 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
         static const int hot_ht10 = qk_env_int("QK_SCAN_HOT_HT10", 30);
         static const int hot_ovh = qk_env_int("QK_SCAN_HOT_OVH", 64);
         static const int hot_hq = qk_env_int("QK_SCAN_HOT_HQ", 128);
-        static const int hot_per_list = qk_env_int("QK_SCAN_HOT_PER_LIST", 2);
+        // (from THREE probing queries per list on average: at two -- nprobe 8-11 on the bench index -- the per-wave walk alone is
+        //  as fast or faster on both corpora: skewed mixture nprobe 8 / 10 / 12 / 14 walk 0.447 / 0.481 / 0.515 / 0.565 ms, mixed
+        //  0.475 / 0.480 / 0.490 / 0.498; uniformly probed corpus 0.683 / 0.714 / 0.738 / 0.763 against 0.692 / 0.747 / 0.785 / 0.809 --
+        //  there the mixed form only pays from nprobe ~24 on, a skew the host cannot see; the rule follows the skewed case)
+        static const int hot_per_list = qk_env_int("QK_SCAN_HOT_PER_LIST", 3);
         static const int hot_min_rows = qk_env_int("QK_SCAN_HOT_MIN_ROWS", 512);
         // Short lists: on the configs[0] shape (1M x 128 in 1024 lists of ~1000 rows, nprobe 10) items are 61 row tiles long and
         // their fixed costs show -- 256 / 1024 queries: scan 85 / 165 us with the round-2 forms (per-wave walk / query-sharing tile

@@ -18,11 +18,12 @@ bash scripts/gpu_profile.sh final3/hard --no-extra --no-pmc --steps 50 --manifol
 digest hard "k_scan_rl" "python bench.py --no-extra --no-pmc --steps 50 --manifold 10"
 python bench.py > gpurun_out/final3/bench.json 2> gpurun_out/final3/bench.log
 python bench.py --dim 768 --metric ip --k 100 --no-extra > gpurun_out/final3/c2_768.json 2> gpurun_out/final3/c2_768.log
-python scripts/nprobe_sweep.py --nprobes 1,2,4,8,16,32,64 --steps 50 --tag r03 --parity > gpurun_out/final3/sweep_mixture.jsonl 2>/dev/null
-python scripts/nprobe_sweep.py --corpus hard --nprobes 4,8,16,32,64 --steps 50 --tag r03 --parity > gpurun_out/final3/sweep_hard.jsonl 2>/dev/null
+python scripts/nprobe_sweep.py --nprobes 1,2,4,8,12,16,32,64 --steps 50 --tag r03 --parity > gpurun_out/final3/sweep_mixture.jsonl 2>/dev/null
+python scripts/nprobe_sweep.py --corpus hard --nprobes 4,8,12,16,32,64 --steps 50 --tag r03 --parity > gpurun_out/final3/sweep_hard.jsonl 2>/dev/null
 python scripts/coarse_probe.py 4096,8192,16384,32768,65536 1,2,8,32,64 > gpurun_out/final3/coarse_probe.jsonl 2>/dev/null
 python scripts/phase_probe.py > gpurun_out/final3/phase_probe.jsonl 2>/dev/null
 python scripts/latency_probe.py > gpurun_out/final3/latency.json 2>/dev/null
 python scripts/rank_step_probe.py 8 > gpurun_out/final3/rank8.json 2>/dev/null
+bash scripts/gpu_km_trace.sh > gpurun_out/final3/kmeans_trace.txt 2>&1
 tail -c 1500 gpurun_out/final3/bench.json; echo; grep -h "traffic_over_algorithmic\|kernel_avg_us_rocprof\|\"kernel\"" gpurun_out/final3/digest/*_pmc.json
 du -sh gpurun_out/final3

@@ -167,6 +167,53 @@ def test_bindings_internal_seams(qb):
     assert sorted(gi[0, :4].tolist()) == [0, 1, 2, 3] and (gi[:, 4:] == -1).all()
 
 
+def test_bindings_device_tensors_follow_torch_streams(qb):
+    """CUDA tensors in, CUDA tensors out, on whatever stream torch is on: the mirror binds the library to torch's current stream for
+    the call (no device-wide synchronisation), so queries produced by a kernel enqueued just before the call -- on the default
+    stream or on a side stream -- are seen, and the answers equal those for the same queries as CPU tensors (search: the reference's
+    entry point query_coordinator.cpp:612-657; scan_partitions :659-673 keeps device queries and list numbers on the device)."""
+    g = torch.Generator().manual_seed(51)
+    x = torch.randn(20000, 32, generator=g)
+    ids = torch.arange(20000) + 7
+    idx = qb.QuakeIndex()
+    bp = qb.IndexBuildParams()
+    bp.nlist = 40
+    idx.build(x, ids, bp)
+    qc = idx.query_coordinator
+    sp = qb.SearchParams()
+    sp.k, sp.nprobe = 10, 6
+    base = torch.randn(300, 32, generator=g)
+    side = torch.cuda.Stream()
+    for it in range(4):
+        qh = base * (1.0 + 0.25 * it) + 0.01 * it
+        want = idx.search(qh, sp)
+        assert not want.ids.is_cuda
+        bd = base.cuda()
+        torch.cuda.synchronize()
+        if it % 2 == 0:
+            qd = bd * (1.0 + 0.25 * it) + 0.01 * it          # produced on the current stream right before the call
+            got = idx.search(qd, sp)
+        else:
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                qd = bd * (1.0 + 0.25 * it) + 0.01 * it      # ... or on a side stream, which the call then runs on
+                got = idx.search(qd, sp)
+                gi, gdist = got.ids.cpu(), got.distances.cpu()
+            side.synchronize()
+        assert got.ids.is_cuda and got.distances.is_cuda
+        np.testing.assert_array_equal(got.ids.cpu().numpy(), want.ids.numpy())
+        np.testing.assert_array_equal(got.distances.cpu().numpy().view(np.uint32), want.distances.numpy().view(np.uint32))
+        probe = torch.tensor([[1, 7, 30, -1]] * 300)
+        rh = qc.scan_partitions(qh, probe, sp)
+        rd = qc.scan_partitions(qd, probe.cuda(), sp)
+        assert rd.ids.is_cuda and not rh.ids.is_cuda
+        np.testing.assert_array_equal(rd.ids.cpu().numpy(), rh.ids.numpy())
+        np.testing.assert_array_equal(rd.distances.cpu().numpy().view(np.uint32), rh.distances.numpy().view(np.uint32))
+        r1 = qc.scan_partitions(qd, torch.tensor([3, 9]), sp)  # host list numbers with device queries: moved over
+        r2 = qc.scan_partitions(qh, torch.tensor([3, 9]), sp)
+        np.testing.assert_array_equal(r1.ids.cpu().numpy(), r2.ids.numpy())
+
+
 def test_bindings_compiled_maintenance(qb):
     """maintenance() in the compiled mirror runs the policy (hit window -> split hot / delete cold partitions -> refine): after it,
     every vector is still resident exactly once and exhaustive search stays exact."""

@@ -39,7 +39,10 @@ TABLE = [
     # several lists per query, under two probing queries per list: the per-wave row-per-lane walk
     (60000, 1024, 128, 10, 256, 4, "k_scan_rl"),
     (60000, 1024, 64, 10, 512, 2, "k_scan_rl"),
-    # LONG lists (1560 rows on average) from two probing queries per list on: the mixed sequence (hot lists as dense items behind
+    # LONG lists (1400+ rows on average): the per-wave walk up to two probing queries per list, from three on the mixed sequence
+    (720000, 512, 64, 10, 512, 2, "k_scan_rl"),
+    (720000, 512, 64, 10, 512, 3, "k_scan_rl (mixed)"),
+    # LONG lists (1560 rows on average) and many probing queries per list: the mixed sequence (hot lists as dense items behind
     # the bf16 prefilter), whatever the sharing
     (100000, 64, 128, 10, 1024, 2, "k_scan_rl (mixed)"),
     (100000, 64, 128, 10, 1024, 8, "k_scan_rl (mixed)"),

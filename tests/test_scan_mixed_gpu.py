@@ -2,7 +2,7 @@
 are scanned as dense workgroup items -- a bf16 prefilter on v_mfma_f32_16x16x32_bf16 with a one-sided error bound, the exact
 chains on v_mfma_f32_16x16x4_f32 for every row tile that could still hold a candidate -- the others by the per-wave walk: one
 launch, one record format, the same bits as the oracle's batched path (query_coordinator.cpp:675-799,
-list_scanning.h:313-366).  The host turns the form on from two probing queries per list (batch average) on, on indexes whose
+list_scanning.h:313-366).  The host turns the form on from three probing queries per list (batch average) on, on indexes whose
 lists average >= 1400 rows; a list is hot with >= 13 probing queries AND >= 512 rows."""
 import numpy as np
 import pytest
