@@ -92,16 +92,24 @@ __global__ __launch_bounds__(256) void k_pf_gemm(PfParams P) {
     for (int t = tid; t < NQ * 16; t += 256) {
         const int64_t row = q_base + t;
         xn_s[t] = row < P.Q ? P.xn[row] : 0.0f;
-        if (MODE == 1) tau_s[t] = row < P.Q ? P.tau[row] : 0u;
+        if (MODE == 1) {
+            // the bound in the float domain: "no bound" (all ones) = +inf / -inf, so that the test below is one compare per product
+            const uint32_t tj = row < P.Q ? P.tau[row] : 0u;
+            const float tf = L2 ? (tj == 0xFFFFFFFFu ? __builtin_inff() : __uint_as_float(tj))
+                                : (tj == 0xFFFFFFFFu ? -__builtin_inff() : ip_from_ord(tj));
+            tau_s[t] = __float_as_uint(tf);
+        }
     }
     __syncthreads();
 
     const int ntile_all = (P.nrows + 15) >> 4;
     const int wg_t0 = blockIdx.y * P.tiles_per_wg;
     const int wg_t1 = min(ntile_all, wg_t0 + P.tiles_per_wg);
-    uint32_t mn[PF_NQ_MAX];
+    // MINIMA: per query the smallest UPPER bound of a key over the lane's rows, kept as a float (L2: the bound itself, minimum;
+    // IP: the lower bound of the dot product, maximum) and turned into a key once, at the end
+    float mn[PF_NQ_MAX];
 #pragma unroll
-    for (int i = 0; i < PF_NQ_MAX; i++) mn[i] = 0xFFFFFFFFu;
+    for (int i = 0; i < PF_NQ_MAX; i++) mn[i] = L2 ? __builtin_inff() : -__builtin_inff();
 
     // wave w takes row tiles wg_t0 + w, + 4, ...; the next tile's fragments are requested before this one's products
     float4 a_cur[NB], a_nxt[NB];
@@ -133,6 +141,8 @@ __global__ __launch_bounds__(256) void k_pf_gemm(PfParams P) {
             rv[r] = row0 + r < P.nrows;
             // L2 key bounds: (|x|^2 + |y|^2)(1 +- c) - 2 x~.y~ ; IP: the dot product -+ c (|x|^2 + |y|^2) / 2 (key order is descending dot)
             yk[r] = L2 ? yv[r] * (MODE == 0 ? 1.0f + PF_C : 1.0f - PF_C) : yv[r] * (0.5f * PF_C);
+            // MINIMA: a row beyond the list never wins (its bound is +inf / its dot product -inf)
+            if (MODE == 0 && !rv[r]) yk[r] = __builtin_inff();
         }
 #pragma unroll
         for (int nq = 0; nq < PF_NQ_MAX; nq++) {
@@ -144,38 +154,32 @@ __global__ __launch_bounds__(256) void k_pf_gemm(PfParams P) {
             const float xnj = xn_s[nq * 16 + j];
             const float xk = L2 ? xnj * (MODE == 0 ? 1.0f + PF_C : 1.0f - PF_C) : xnj * (0.5f * PF_C);
             if (MODE == 0) {
-                uint32_t m4 = 0xFFFFFFFFu;
+                // (two VALU per product: fma + min; clamping at 0 and the key conversion wait for the end)
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    uint32_t o;
-                    if (L2) {
-                        const float ub = __fmaf_rn(-2.0f, acc[r], xk + yk[r]);
-                        o = ord_from_l2(ub < 0.0f ? 0.0f : ub);
-                    } else {
-                        o = ord_from_ip(acc[r] - (xk + yk[r]));
-                    }
-                    m4 = min(m4, rv[r] ? o : 0xFFFFFFFFu);
+                    if (L2) mn[nq] = fminf(mn[nq], __fmaf_rn(-2.0f, acc[r], xk + yk[r]));
+                    else mn[nq] = fmaxf(mn[nq], acc[r] - (xk + yk[r]));
                 }
-                mn[nq] = min(mn[nq], m4);
             } else {
-                const uint32_t tauj = tau_s[nq * 16 + j];
-                const int64_t q = q_base + nq * 16 + j;
+                // one compare per product in the float domain (negated, so that a NaN stays a candidate), one uniform branch per
+                // query tile: candidates are rare (tens per query out of thousands of rows)
+                const float tauf = __uint_as_float(tau_s[nq * 16 + j]);
+                bool p[4];
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    uint32_t o;
-                    if (L2) {
-                        const float lb = __fmaf_rn(-2.0f, acc[r], xk + yk[r]);
-                        o = ord_from_l2(lb < 0.0f ? 0.0f : lb);
-                    } else {
-                        o = ord_from_ip(acc[r] + (xk + yk[r]));
-                    }
-                    if (rv[r] && q < P.Q && o <= tauj) {
-                        const int pos = atomicAdd(&cbuf_n[wave], 1);
-                        if (pos < PF_WBUF) {
-                            cbuf[pos] = make_int2((int)(q - q_base), row0 + r);
-                        } else {  // (buffer full: straight to the list)
-                            const int slot = atomicAdd(&P.ccnt[q], 1);
-                            if (slot < PF_CAP) P.cand[q * PF_CAP + slot] = row0 + r;
+                for (int r = 0; r < 4; r++)
+                    p[r] = L2 ? !(__fmaf_rn(-2.0f, acc[r], xk + yk[r]) > tauf) : !(acc[r] + (xk + yk[r]) < tauf);
+                const int64_t q = q_base + nq * 16 + j;
+                if (__ballot((p[0] | p[1] | p[2] | p[3]) && q < P.Q)) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        if (rv[r] && q < P.Q && p[r]) {
+                            const int pos = atomicAdd(&cbuf_n[wave], 1);
+                            if (pos < PF_WBUF) {
+                                cbuf[pos] = make_int2((int)(q - q_base), row0 + r);
+                            } else {  // (buffer full: straight to the list)
+                                const int slot = atomicAdd(&P.ccnt[q], 1);
+                                if (slot < PF_CAP) P.cand[q * PF_CAP + slot] = row0 + r;
+                            }
                         }
                     }
                 }
@@ -199,7 +203,10 @@ __global__ __launch_bounds__(256) void k_pf_gemm(PfParams P) {
 #pragma unroll
         for (int nq = 0; nq < PF_NQ_MAX; nq++) {
             if ((nq & 3) == 0 && nq >= NQ) break;
-            uint32_t v = mn[nq];
+            // the float bound as a key: L2 clamped at +0 (a negative bound of a squared distance), "no row seen" = all ones
+            const float f = mn[nq];
+            uint32_t v = L2 ? (f == __builtin_inff() ? 0xFFFFFFFFu : ord_from_l2(f > 0.0f ? f : 0.0f))
+                            : (f == -__builtin_inff() ? 0xFFFFFFFFu : ord_from_ip(f));
             v = min(v, (uint32_t)__shfl_xor((int)v, 16));
             v = min(v, (uint32_t)__shfl_xor((int)v, 32));
             const int64_t q = q_base + nq * 16 + j;
@@ -243,6 +250,7 @@ struct PfFinish {
     int d;
     const int32_t *cand;
     const int32_t *ccnt;
+    const uint32_t *tau;  // [Q] the bound of the filter pass: at least k rows have an exact key at or under it
     int k, Cm;
     int sqrt_l2;
     int64_t *out_ids;
@@ -266,7 +274,10 @@ __global__ __launch_bounds__(64) void k_pf_finish(PfFinish F) {
     __syncthreads();
     const bool all_rows = found > PF_CAP;  // the list overflowed: every row is a candidate (exact, slow, rare)
     const int n = all_rows ? F.nrows : found;
-    uint32_t tau = 0xFFFFFFFFu;
+    // the pool starts behind the filter's bound -- k rows are known to have exact keys at or under it -- so the slack of the
+    // lower-bound test (rows listed because their BOUND was small enough) never reaches the pool: one selection at the end
+    // instead of one per 64 candidates
+    uint32_t tau = F.tau[q];
     int cnt = 0;
     for (int base = 0; base < n; base += 64) {
         const int e = base + lane;
@@ -444,6 +455,7 @@ int qk_dense_pf_device(qk_ctx *ctx, qk_store *s, int64_t row_off, int nrows, con
     f.d = s->d;
     f.cand = cand;
     f.ccnt = ccnt;
+    f.tau = p.tau;
     f.k = k;
     f.Cm = Cm;
     f.sqrt_l2 = a.sqrt_l2 ? 1 : 0;
