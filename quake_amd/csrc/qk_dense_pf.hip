@@ -251,13 +251,17 @@ struct PfFinish {
     const int32_t *cand;
     const int32_t *ccnt;
     const uint32_t *tau;  // [Q] the bound of the filter pass: at least k rows have an exact key at or under it
+    const float *rm;      // [nrows][d] row-major copy of the list (RM form), or nullptr
     int k, Cm;
     int sqrt_l2;
     int64_t *out_ids;
     float *out_dist;
 };
 
-template <int NB, bool L2, int MAXCH>
+// RM: the candidate rows are read from the store's row-major copy (512 contiguous bytes at d = 128, four cache lines) instead of
+// the tile-major arena (32 pieces of 16 bytes in 32 lines: ~100 candidates x 1024 queries pulled ~400 MB through the L2 for 52 MB of
+// operands); the chain runs over the columns in the same natural order, so the key is the same bits
+template <int NB, bool L2, int MAXCH, bool RM>
 __global__ __launch_bounds__(64) void k_pf_finish(PfFinish F) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = threadIdx.x;
@@ -291,13 +295,31 @@ __global__ __launch_bounds__(64) void k_pf_finish(PfFinish F) {
         float acc = 0.0f;
         // the lane's row, one 16-column block at a time: float4 g of block c holds columns 16c + {g, 4+g, 8+g, 12+g}; the chain
         // runs over the columns in natural order (the canonical arithmetic)
+        if (RM) {
+            const float4 *rp = (const float4 *)(F.rm + (int64_t)row * F.d);  // (d is a multiple of 4 in this form)
+            const int nv = F.d >> 2;
 #pragma unroll
-        for (int c = 0; c < NB; c++) {
-            const float4 *blk = F.vecs + (tile * NB + c) * 64 + r;
-            const float4 v0 = blk[0], v1 = blk[16], v2 = blk[32], v3 = blk[48];
-            const float e16[16] = {v0.x, v1.x, v2.x, v3.x, v0.y, v1.y, v2.y, v3.y, v0.z, v1.z, v2.z, v3.z, v0.w, v1.w, v2.w, v3.w};
+            for (int c = 0; c < NB; c++) {
+                float4 v[4];
 #pragma unroll
-            for (int t = 0; t < 16; t++) acc = __fmaf_rn(e16[t], xs[16 * c + t], acc);
+                for (int i = 0; i < 4; i++) v[i] = 4 * c + i < nv ? rp[4 * c + i] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    acc = __fmaf_rn(v[i].x, xs[16 * c + 4 * i], acc);
+                    acc = __fmaf_rn(v[i].y, xs[16 * c + 4 * i + 1], acc);
+                    acc = __fmaf_rn(v[i].z, xs[16 * c + 4 * i + 2], acc);
+                    acc = __fmaf_rn(v[i].w, xs[16 * c + 4 * i + 3], acc);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < NB; c++) {
+                const float4 *blk = F.vecs + (tile * NB + c) * 64 + r;
+                const float4 v0 = blk[0], v1 = blk[16], v2 = blk[32], v3 = blk[48];
+                const float e16[16] = {v0.x, v1.x, v2.x, v3.x, v0.y, v1.y, v2.y, v3.y, v0.z, v1.z, v2.z, v3.z, v0.w, v1.w, v2.w, v3.w};
+#pragma unroll
+                for (int t = 0; t < 16; t++) acc = __fmaf_rn(e16[t], xs[16 * c + t], acc);
+            }
         }
         const float yn = F.norms[arow];
         uint32_t o = L2 ? ord_from_l2(l2_expanded(xnq, yn, acc)) : ord_from_ip(acc);
@@ -351,8 +373,13 @@ static int pf_launch(qk_ctx *ctx, const PfParams &p0, const PfFinish &f0, dim3 g
 #undef PF_TAU
     hipLaunchKernelGGL((k_pf_gemm<NB, L2, 1>), grid, dim3(256), lds, st, p);
     const size_t lds_f = (size_t)Cm * 12 + (size_t)NB * 16 * 4;
-    if (Cm <= 128) hipLaunchKernelGGL((k_pf_finish<NB, L2, 2>), dim3((unsigned)p.Q), dim3(64), lds_f, st, f0);
-    else hipLaunchKernelGGL((k_pf_finish<NB, L2, 4>), dim3((unsigned)p.Q), dim3(64), lds_f, st, f0);
+    if (f0.rm) {
+        if (Cm <= 128) hipLaunchKernelGGL((k_pf_finish<NB, L2, 2, true>), dim3((unsigned)p.Q), dim3(64), lds_f, st, f0);
+        else hipLaunchKernelGGL((k_pf_finish<NB, L2, 4, true>), dim3((unsigned)p.Q), dim3(64), lds_f, st, f0);
+    } else {
+        if (Cm <= 128) hipLaunchKernelGGL((k_pf_finish<NB, L2, 2, false>), dim3((unsigned)p.Q), dim3(64), lds_f, st, f0);
+        else hipLaunchKernelGGL((k_pf_finish<NB, L2, 4, false>), dim3((unsigned)p.Q), dim3(64), lds_f, st, f0);
+    }
     QK_HIP(hipGetLastError());
     return QK_OK;
 }
@@ -456,6 +483,8 @@ int qk_dense_pf_device(qk_ctx *ctx, qk_store *s, int64_t row_off, int nrows, con
     f.cand = cand;
     f.ccnt = ccnt;
     f.tau = p.tau;
+    f.rm = nullptr;
+    if (s->d % 4 == 0) QK_TRY(qk_store_rowmajor(s, row_off, nrows, &f.rm));
     f.k = k;
     f.Cm = Cm;
     f.sqrt_l2 = a.sqrt_l2 ? 1 : 0;

@@ -162,6 +162,13 @@ struct qk_store {
     int32_t *d_size = nullptr;
     int64_t table_cap = 0;
     bool table_dirty = true;
+    // row-major copy of ONE list's vectors ([rows][d] floats), built on demand for the exact finish of the coarse step without key
+    // matrix (qk_dense_pf.hip: a candidate row of the tile-major arena is 32 pieces of 16 bytes in 32 cache lines); dropped whenever
+    // the table changes
+    float *rowmajor = nullptr;
+    int64_t rowmajor_cap = 0;      // floats
+    int64_t rowmajor_row_off = -1, rowmajor_rows = 0;
+    bool rowmajor_valid = false;
     // id -> list number (lazy; makes get_vector / remove_ids proportional to the touched lists)
     QkIdMap id_to_list;
     std::vector<uint64_t> kill_bits;  // scratch of remove_ids: one bit per id of [min_id_seen, max_id_seen], zero between calls
@@ -170,6 +177,7 @@ struct qk_store {
 void qk_store_ensure_index(qk_store *s);
 
 int qk_store_sync_table(qk_store *s);                  // upload (row_off, size) if dirty
+int qk_store_rowmajor(qk_store *s, int64_t row_off, int nrows, const float **out);  // the copy above for rows [row_off, +nrows)
 int qk_store_reserve_rows(qk_store *s, int64_t rows);  // grow the arena so that used_rows + rows fits
 
 // ---- kernels exposed across translation units --------------------------------------------------

@@ -184,6 +184,7 @@ int qk_store_reserve_rows(qk_store *s, int64_t rows) {
 
 int qk_store_sync_table(qk_store *s) {
     if (!s->table_dirty) return QK_OK;
+    s->rowmajor_valid = false;
     qk_ctx *c = s->ctx;
     int64_t n = (int64_t)s->parts.size();
     if (n > s->table_cap) {
@@ -388,6 +389,37 @@ int qk_store_create(qk_ctx *ctx, int d, qk_store **out) {
     return QK_OK;
 }
 
+// Row-major copy of rows [row_off, row_off + nrows) (one list: the centroids of a parent / flat index), made on the STORE's
+// context stream and complete on return (a host synchronisation, once per change of the store): any context may read it afterwards.
+extern "C++" int qk_store_rowmajor(qk_store *s, int64_t row_off, int nrows, const float **out) {
+    *out = nullptr;
+    if (nrows <= 0 || s->table_dirty) return QK_OK;
+    if (s->rowmajor_valid && s->rowmajor_row_off == row_off && s->rowmajor_rows == nrows) {
+        *out = s->rowmajor;
+        return QK_OK;
+    }
+    qk_ctx *c = s->ctx;
+    const int64_t need = (int64_t)nrows * s->d;
+    if (need > s->rowmajor_cap) {
+        QK_HIP(hipStreamSynchronize(c->stream));
+        if (s->rowmajor) QK_HIP(hipFree(s->rowmajor));
+        s->rowmajor = nullptr;
+        s->rowmajor_cap = 0;
+        if (hipMalloc((void **)&s->rowmajor, (size_t)(need + need / 4) * sizeof(float)) != hipSuccess) {
+            (void)hipGetLastError();
+            return QK_OK;  // no room for the copy: the caller gathers from the arena
+        }
+        s->rowmajor_cap = need + need / 4;
+    }
+    QK_TRY(qk_launch_extract(c, s->vecs, s->nblk, s->d, row_off, nullptr, nrows, s->rowmajor));
+    QK_HIP(hipStreamSynchronize(c->stream));
+    s->rowmajor_valid = true;
+    s->rowmajor_row_off = row_off;
+    s->rowmajor_rows = nrows;
+    *out = s->rowmajor;
+    return QK_OK;
+}
+
 int qk_store_destroy(qk_store *s) {
     if (!s) return QK_OK;
     hipSetDevice(s->ctx->device);
@@ -397,6 +429,7 @@ int qk_store_destroy(qk_store *s) {
     if (s->ids) hipFree(s->ids);
     if (s->d_off) hipFree(s->d_off);
     if (s->d_size) hipFree(s->d_size);
+    if (s->rowmajor) hipFree(s->rowmajor);
     delete s;
     return QK_OK;
 }

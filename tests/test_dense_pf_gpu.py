@@ -88,3 +88,34 @@ def test_large_norm_spread(ctx):
     for metric in ("l2", "ip"):
         _check(ctx, parent, cent, q, 16, metric)
     parent.close()
+
+
+@pytest.mark.parametrize("d", [128, 100, 30])
+def test_row_major_copy_follows_the_store(ctx, d):
+    """the exact finish reads the candidates from a row-major copy of the list (d a multiple of 4; d = 30 keeps gathering from the
+    tile-major arena), made on first use and dropped whenever the store's table changes: centroids added and removed between calls
+    -- what split / delete of the maintenance policy do to the parent (partition_manager.cpp:236-258, 265-318) -- must show up"""
+    rng = np.random.default_rng(11 + d)
+    n = 3000
+    cent = rng.standard_normal((n, d)).astype(np.float32)
+    ids = np.arange(n, dtype=np.int64)
+    parent = _parent(ctx, cent, ids)
+    q = (cent[rng.integers(0, n, 200)] + 0.2 * rng.standard_normal((200, d))).astype(np.float32)
+    _check(ctx, parent, cent, q, 8, "l2", ids)
+    _check(ctx, parent, cent, q, 8, "l2", ids)                 # (second call: the copy exists)
+    new = (q[:150] + 1e-3).astype(np.float32)                  # 150 new centroids right next to the queries
+    new_ids = np.arange(150, dtype=np.int64) + 100000
+    parent.add_entries(0, new_ids, new)
+    cent2, ids2 = np.concatenate([cent, new]), np.concatenate([ids, new_ids])
+    gp, _ = ctx.coarse(parent, q, 8, "l2")
+    assert (gp[:150, 0] == new_ids).all()
+    _check(ctx, parent, cent2, q, 8, "l2", ids2)
+    parent.remove_ids(new_ids[:75])
+    # (remove = swap with the last row, index_partition.cpp:79-102: compare as sets of (id, distance) per query through the oracle on
+    #  the surviving rows in THEIR new order is not needed -- ids and distances are order-free under the total order)
+    keep = ~np.isin(ids2, new_ids[:75])
+    op, od = O.coarse(q, cent2[keep], ids2[keep], 8, "l2")
+    gp, gd = ctx.coarse(parent, q, 8, "l2")
+    np.testing.assert_array_equal(gp, op)
+    np.testing.assert_array_equal(gd.view(np.uint32), od.view(np.uint32))
+    parent.close()
