@@ -393,7 +393,7 @@ struct PfPlan {
     int64_t qgroups;
 };
 static bool pf_plan(const qk_ctx *ctx, const qk_store *s, int64_t Q, int nrows, int k, PfPlan *pl) {
-    if (!(s->nblk <= 8 && k >= 2 && k <= 64 && nrows >= 1024 && Q >= 64)) return false;
+    if (!(s->nblk <= 8 && k >= 1 && k <= 64 && nrows >= 1024 && Q >= 64)) return false;  // (k = 1: the caller asks from 32768 rows on)
     const int num_cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
     const int ntile = (nrows + 15) / 16;
     // query tiles per workgroup: up to 256 queries share a pass over the rows (each workgroup streams its rows from L2 / the

@@ -56,7 +56,43 @@ def test_coarse_prefiltered_65536_centroids(ctx):
     parent = _parent(ctx, cent)
     q = (cent[rng.integers(0, 65536, 512)] + 0.5 * rng.standard_normal((512, 128))).astype(np.float32)
     _check(ctx, parent, cent, q, 32, "l2")
+    _check(ctx, parent, cent, q, 1, "l2")   # the nearest centroid alone takes this form from 32768 rows on
     parent.close()
+
+
+@pytest.mark.parametrize("metric", ["l2", "ip"])
+def test_nearest_centroid_of_many_and_the_search_behind_it(ctx, metric):
+    """k = 1 over >= 32768 rows: the prefiltered form instead of the fused fp32 argmin -- alone (d = 100: padded columns), with exact
+    duplicates of the nearest row (ties go to the smaller id), and as the coarse step of a search with nprobe = 1, whose grouping
+    then reads plain list numbers instead of the argmin's packed (key, id) words"""
+    from quake_amd.capi import Store
+    from helpers import make_ivf, make_queries
+    rng = np.random.default_rng(5)
+    n, d = 40000, 100
+    cent = rng.standard_normal((n, d)).astype(np.float32)
+    cent[20000:20050] = cent[100:150]       # duplicates: the same key under two ids
+    if metric == "ip":
+        cent /= np.linalg.norm(cent, axis=1, keepdims=True)
+    parent = _parent(ctx, cent)
+    q = np.concatenate([cent[100:150] * np.float32(1.0), (cent[rng.integers(0, n, 250)] + 0.2 * rng.standard_normal((250, d))).astype(np.float32)])
+    if metric == "ip":
+        q /= np.linalg.norm(q, axis=1, keepdims=True)
+    q = np.ascontiguousarray(q, np.float32)
+    _check(ctx, parent, cent, q, 1, metric)
+    gp, _ = ctx.coarse(parent, q, 1, metric)
+    assert (gp[:50, 0] == np.arange(100, 150)).all()
+    parent.close()
+    ivf = make_ivf(70000, 32, 33000, seed=9, metric=metric)
+    s = Store(ctx, 32)
+    s.build_csr(ivf["offsets"], ivf["ids"], ivf["vecs"])
+    par = _parent(ctx, ivf["centroids"])
+    qq = make_queries(300, 32, seed=10, like=ivf["x"], metric=metric)
+    gi, gd = ctx.search(par, s, qq, 1, 5, metric)
+    oi, od = O.search(qq, ivf["centroids"], ivf["vecs"], ivf["ids"], ivf["offsets"], 1, 5, metric, batched_scan=True)
+    np.testing.assert_array_equal(gi, oi)
+    np.testing.assert_array_equal(gd.view(np.uint32), od.view(np.uint32))
+    s.close()
+    par.close()
 
 
 def test_ties_duplicates_and_candidate_overflow(ctx):
