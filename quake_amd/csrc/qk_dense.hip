@@ -790,7 +790,7 @@ int qk_dense_device(qk_ctx *ctx, qk_store *s, int64_t list_no, const qk_scan_arg
     if (lds > 160 * 1024) QK_FAIL(QK_ERR_UNSUPPORTED, "dense scan: d=%d too large for the LDS query tile", s->d);
     // (from 32768 rows on the prefiltered form below is the faster nearest-centroid search too -- 1024 queries: 32768 rows 84 -> 71 us,
     //  65536 rows 154 -> 96 us; at 16384 rows 50 against 54 us the fused fp32 argmin stays)
-    const bool pf_k1 = k == 1 && nrows >= 32768 && a.x && a.out_ids && !qk_env_set("QK_NO_DENSE_PF") && qk_dense_pf_supported(ctx, s, Q, nrows, 1);
+    const bool pf_k1 = k == 1 && nrows >= 32768 && Q <= 16384 && a.x && a.out_ids && !qk_env_set("QK_NO_DENSE_PF") && qk_dense_pf_supported(ctx, s, Q, nrows, 1);
     if (k == 1 && !pf_k1 && nrows > 0 && s->max_id_seen < ((int64_t)1 << 32) && s->min_id_seen >= 0 && !qk_env_set("QK_NO_ARGMIN")) {
         // nprobe = 1 / nearest centroid: fused argmin, no key matrix
         const size_t lds_a = lds + (size_t)4 * NQ * 16 * 8;

@@ -393,7 +393,9 @@ struct PfPlan {
     int64_t qgroups;
 };
 static bool pf_plan(const qk_ctx *ctx, const qk_store *s, int64_t Q, int nrows, int k, PfPlan *pl) {
-    if (!(s->nblk <= 8 && k >= 1 && k <= 64 && nrows >= 1024 && Q >= 64)) return false;  // (k = 1: the caller asks from 32768 rows on)
+    // (k = 1: the caller asks from 32768 rows on.  The workspace is ~14 KB per query -- group minima + a 1536-slot candidate list --:
+    //  batches beyond 65536 queries stay on the sliced key-matrix path / the fused argmin, whose state is a few bytes per query)
+    if (!(s->nblk <= 8 && k >= 1 && k <= 64 && nrows >= 1024 && Q >= 64 && Q <= 65536)) return false;
     const int num_cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
     const int ntile = (nrows + 15) / 16;
     // query tiles per workgroup: up to 256 queries share a pass over the rows (each workgroup streams its rows from L2 / the

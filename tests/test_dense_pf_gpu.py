@@ -155,3 +155,20 @@ def test_row_major_copy_follows_the_store(ctx, d):
     np.testing.assert_array_equal(gp, op)
     np.testing.assert_array_equal(gd.view(np.uint32), od.view(np.uint32))
     parent.close()
+
+
+def test_huge_batches_leave_the_prefiltered_form(ctx):
+    """the prefiltered form keeps ~14 KB of state per query: beyond 65536 queries (k = 1 over many rows: beyond 16384 -- the
+    assignment batches of PartitionManager::add) the sliced key-matrix path / the fused argmin serve the call, same answers"""
+    rng = np.random.default_rng(21)
+    cent = rng.standard_normal((2048, 16)).astype(np.float32)
+    parent = _parent(ctx, cent)
+    q = (cent[rng.integers(0, 2048, 70000)] + 0.3 * rng.standard_normal((70000, 16))).astype(np.float32)
+    _check(ctx, parent, cent, q, 4, "l2")
+    parent.close()
+    cent = rng.standard_normal((33000, 16)).astype(np.float32)
+    parent = _parent(ctx, cent)
+    q = (cent[rng.integers(0, 33000, 20000)] + 0.3 * rng.standard_normal((20000, 16))).astype(np.float32)
+    _check(ctx, parent, cent, q, 1, "l2")
+    _check(ctx, parent, cent, q[:5000], 1, "l2")
+    parent.close()
