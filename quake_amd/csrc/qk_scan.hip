@@ -196,11 +196,16 @@ __device__ __forceinline__ int group_count_one(const GroupParams &G, int64_t i, 
     int p = pair_pid(G, i);
     // the first query to reach a partition lists it: the scan below walks the probed partitions only, not all of them
     // (a rank of an N-GPU index sees N x 4096 list numbers, 1/N of the batch's queries land on its own)
+    int old = 0;
     if (p >= 0) {
-        const int old = atomicAdd(&G.g_cnt[p], 1);
+        old = atomicAdd(&G.g_cnt[p], 1);
         if (old == 0) G.act_list[atomicAdd(G.n_act, 1)] = p;
         if (pos) *pos = old;
     }
+    // the pair's list and arrival rank wait in the (still unused) record slots of its slot line for the scatter pass, which then
+    // needs neither the list numbers again nor a second round of atomics (three dependent round trips less)
+    G.pair_slots[i * QK_SLOTS + 1] = p;
+    G.pair_slots[i * QK_SLOTS + 2] = old;
     return p;
 }
 
@@ -384,9 +389,10 @@ __global__ __launch_bounds__(1024) void k_group_scan(GroupParams G) {
 }
 
 __device__ __forceinline__ void group_scatter_one(const GroupParams &G, int64_t i) {
-    int p = pair_pid(G, i);
+    // {list, arrival rank} left by group_count_one
+    const int p = G.pair_slots[i * QK_SLOTS + 1];
     if (p >= 0) {
-        int pos = atomicAdd(&G.g_cursor[p], 1);
+        const int pos = G.pair_slots[i * QK_SLOTS + 2];
         G.grouped_q[G.g_qoff[p] + pos] = (int32_t)(i / G.P);
         G.grouped_pair[G.g_qoff[p] + pos] = (int32_t)i;
     }
