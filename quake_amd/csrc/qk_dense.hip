@@ -331,16 +331,23 @@ __global__ __launch_bounds__(64) void k_merge_slices(const int64_t *in_ids, cons
     const int n_in = slices * k;  // <= MAXCH * 64
     // live entries first (a slice shorter than k is padded with 0xFFFFFFFF keys): ballot-compacted copy
     int cnt = 0;
-    for (int base = 0; base < n_in; base += 64) {
-        const int e = base + lane;
-        const uint32_t o = e < n_in ? in_ord[q * n_in + e] : 0xFFFFFFFFu;
-        const int64_t id = e < n_in ? in_ids[q * n_in + e] : -1;
-        const bool live = e < n_in && o != 0xFFFFFFFFu;  // (padding of a slice shorter than k: never a live key)
+    // (all loads of the wave in flight before the first ballot: a load per round of the loop below was a memory round trip each)
+    uint32_t ov[MAXCH];
+    int64_t iv[MAXCH];
+#pragma unroll
+    for (int c = 0; c < MAXCH; c++) {
+        const int e = c * 64 + lane;
+        ov[c] = e < n_in ? in_ord[q * n_in + e] : 0xFFFFFFFFu;
+        iv[c] = e < n_in ? in_ids[q * n_in + e] : -1;
+    }
+#pragma unroll
+    for (int c = 0; c < MAXCH; c++) {
+        const bool live = ov[c] != 0xFFFFFFFFu;  // (padding of a slice shorter than k: never a live key)
         const uint64_t m = __ballot(live);
         if (live) {
             const int sl = cnt + __popcll(m & ((1ull << lane) - 1ull));
-            pool_ord[sl] = o;
-            pool_id[sl] = id;
+            pool_ord[sl] = ov[c];
+            pool_id[sl] = iv[c];
         }
         cnt += __popcll(m);
     }
@@ -772,6 +779,23 @@ static int launch_dense_t(hipStream_t st, dim3 grid, size_t lds, const DensePara
     return dp.metric == QK_METRIC_L2 ? launch_dense_m<DB, NQ, true>(st, grid, lds, dp) : launch_dense_m<DB, NQ, false>(st, grid, lds, dp);
 }
 
+// k_merge_slices over the [Q][slices][k] candidates of a sliced selection (k_select_rows with slices > 1, k_dense_fused)
+int qk_launch_merge_slices(qk_ctx *ctx, const int64_t *sl_ids, const uint32_t *sl_ord, int64_t nq, int slices, int k, int metric,
+                           bool sqrt_l2, int64_t *out_ids, float *out_dist) {
+    hipStream_t st = ctx->stream;
+    const int n_in = slices * k;
+    if (n_in > 1024) QK_FAIL(QK_ERR_UNSUPPORTED, "slice merge: %d candidates per query", n_in);
+#define MS_LAUNCH(M_) \
+    hipLaunchKernelGGL((k_merge_slices<M_>), dim3((unsigned)nq), dim3(64), 0, st, sl_ids, sl_ord, slices, k, metric, sqrt_l2 ? 1 : 0, out_ids, out_dist)
+    if (n_in <= 128) MS_LAUNCH(2);
+    else if (n_in <= 256) MS_LAUNCH(4);
+    else if (n_in <= 512) MS_LAUNCH(8);
+    else MS_LAUNCH(16);
+#undef MS_LAUNCH
+    QK_HIP(hipGetLastError());
+    return QK_OK;
+}
+
 int qk_dense_device(qk_ctx *ctx, qk_store *s, int64_t list_no, const qk_scan_args &a, qk_timing *timing, int ev_base) {
     ctx->last_scan_kernel = "k_dense";
     const int64_t Q = a.Q;
@@ -873,12 +897,34 @@ int qk_dense_device(qk_ctx *ctx, qk_store *s, int64_t list_no, const qk_scan_arg
         }
         return QK_OK;
     }
+    static const bool no_fused = qk_env_set("QK_NO_DENSE_FUSED");
+    if (a.xq4 && a.out_ids && !no_fused && qk_dense_fused_supported(ctx, s, Q, nrows, k)) {
+        // 2 <= k <= 64, d <= 128, a few thousand rows: keys and their selection in one launch, no key matrix (qk_dense_fused.hip)
+        QK_TRY(pe.mark(0));
+        QK_TRY(pe.mark(1));
+        ctx->last_scan_kernel = "k_dense_fused";
+        QK_TRY(qk_dense_fused_device(ctx, s, pt.row_off, nrows, a));
+        QK_TRY(pe.mark(2));
+        QK_TRY(pe.mark(3));
+        if (timing) {
+            QK_TRY(qk_pinned_reserve(ctx, 64));
+            int32_t *hs = (int32_t *)ctx->pinned;
+            QK_HIP(hipStreamSynchronize(st));
+            hs[0] = 1;
+            hs[1] = 0;
+            hs[7] = (int32_t)std::min<int64_t>(Q, INT32_MAX);
+            int64_t rows = nrows;
+            memcpy(hs + 2, &rows, sizeof(rows));
+        }
+        return QK_OK;
+    }
     static const bool no_pf = qk_env_set("QK_NO_DENSE_PF");
     if (a.x && a.out_ids && !no_pf && qk_dense_pf_supported(ctx, s, Q, nrows, k)) {
         // 2 <= k <= 64, d <= 128, thousands of rows: no key matrix -- approximate keys on bf16 MFMA settle which rows can matter,
         // the exact keys of those candidates the answer (qk_dense_pf.hip)
         QK_TRY(pe.mark(0));
         QK_TRY(pe.mark(1));
+        ctx->last_scan_kernel = "k_dense_pf";
         QK_TRY(qk_dense_pf_device(ctx, s, pt.row_off, nrows, a));
         QK_TRY(pe.mark(2));
         QK_TRY(pe.mark(3));
@@ -1014,17 +1060,9 @@ int qk_dense_device(qk_ctx *ctx, qk_store *s, int64_t list_no, const qk_scan_arg
             case 8: hipLaunchKernelGGL((k_select_rows<8>), dim3(nwaves), dim3(64), lds_s, st, sp); break;
             default: hipLaunchKernelGGL((k_select_rows<16>), dim3(nwaves), dim3(64), lds_s, st, sp); break;
         }
-        if (sl_ids) {
-            const int n_in = slices * k;
-#define MS_LAUNCH(M_)                                                                                                        \
-    hipLaunchKernelGGL((k_merge_slices<M_>), dim3((unsigned)nq), dim3(64), 0, st, sl_ids, sl_ord, slices, k, a.metric, a.sqrt_l2 ? 1 : 0, \
-                       a.out_ids + q0 * k, a.out_dist ? a.out_dist + q0 * k : nullptr)
-            if (n_in <= 128) MS_LAUNCH(2);
-            else if (n_in <= 256) MS_LAUNCH(4);
-            else if (n_in <= 512) MS_LAUNCH(8);
-            else MS_LAUNCH(16);
-#undef MS_LAUNCH
-        }
+        if (sl_ids)
+            QK_TRY(qk_launch_merge_slices(ctx, sl_ids, sl_ord, nq, slices, k, a.metric, a.sqrt_l2, a.out_ids + q0 * k,
+                                          a.out_dist ? a.out_dist + q0 * k : nullptr));
     }
     QK_HIP(hipGetLastError());
     QK_TRY(pe.mark(3));

@@ -240,6 +240,11 @@ int qk_dense_device(qk_ctx *ctx, qk_store *s, int64_t list_no, const qk_scan_arg
 // top-k of every query over one list without a key matrix: bf16 prefilter + exact finish (qk_dense_pf.hip; 2 <= k <= 64, d <= 128)
 bool qk_dense_pf_supported(const qk_ctx *ctx, const qk_store *s, int64_t Q, int nrows, int k);
 int qk_dense_pf_device(qk_ctx *ctx, qk_store *s, int64_t row_off, int nrows, const qk_scan_args &a);
+// top-k of every query over one list of a few thousand rows, keys and selection in one launch (qk_dense_fused.hip; 2 <= k <= 64, d <= 128)
+bool qk_dense_fused_supported(const qk_ctx *ctx, const qk_store *s, int64_t Q, int nrows, int k);
+int qk_dense_fused_device(qk_ctx *ctx, qk_store *s, int64_t row_off, int nrows, const qk_scan_args &a);
+int qk_launch_merge_slices(qk_ctx *ctx, const int64_t *sl_ids, const uint32_t *sl_ord, int64_t nq, int slices, int k, int metric,
+                           bool sqrt_l2, int64_t *out_ids, float *out_dist);
 // k > QK_MAX_K over several lists: emit every key (qk_scan_device in emission mode), then exact selection per query.  qk_dense.hip
 int qk_widek_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *timing, int ev_base);
 constexpr int QK_MAX_WIDE_K = 8192;  // = the reference's TOP_K_BUFFER_CAPACITY (list_scanning.h:39)
