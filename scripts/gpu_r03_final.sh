@@ -20,7 +20,7 @@ python bench.py > gpurun_out/final3/bench.json 2> gpurun_out/final3/bench.log
 python bench.py --dim 768 --metric ip --k 100 --no-extra > gpurun_out/final3/c2_768.json 2> gpurun_out/final3/c2_768.log
 python scripts/nprobe_sweep.py --nprobes 1,2,4,8,12,16,32,64 --steps 50 --tag r03 --parity > gpurun_out/final3/sweep_mixture.jsonl 2>/dev/null
 python scripts/nprobe_sweep.py --corpus hard --nprobes 4,8,12,16,32,64 --steps 50 --tag r03 --parity > gpurun_out/final3/sweep_hard.jsonl 2>/dev/null
-python scripts/coarse_probe.py 4096,8192,16384,32768,65536 1,2,8,32,64 > gpurun_out/final3/coarse_probe.jsonl 2>/dev/null
+python scripts/coarse_probe.py 1024,2048,4096,8192,16384,32768,65536 1,2,8,32,64 > gpurun_out/final3/coarse_probe.jsonl 2>/dev/null
 python scripts/phase_probe.py > gpurun_out/final3/phase_probe.jsonl 2>/dev/null
 python scripts/latency_probe.py > gpurun_out/final3/latency.json 2>/dev/null
 python scripts/rank_step_probe.py 8 > gpurun_out/final3/rank8.json 2>/dev/null
