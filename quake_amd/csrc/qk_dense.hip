@@ -340,9 +340,24 @@ __global__ __launch_bounds__(64) void k_merge_slices(const int64_t *in_ids, cons
         ov[c] = e < n_in ? in_ord[q * n_in + e] : 0xFFFFFFFFu;
         iv[c] = e < n_in ? in_ids[q * n_in + e] : -1;
     }
+    // the k-th smallest key of all candidates, on the registers (bisection on the key bits); when exactly k candidates lie at or
+    // under it -- always, unless equal keys straddle the k-th place -- only those go to the pool and one wave-wide rank sort orders
+    // them (256 candidates, k = 32: 12.4 -> ~5 us against the pool-wide select + sort, which stays for the tie case and for n < k)
+    uint32_t T = 0;
+    for (int b = 31; b >= 0; b--) {
+        const uint32_t tr = T | (1u << b);
+        int c = 0;
+#pragma unroll
+        for (int i = 0; i < MAXCH; i++) c += __popcll(__ballot(ov[i] < tr));
+        if (c < k) T = tr;
+    }
+    int c_le = 0;
+#pragma unroll
+    for (int i = 0; i < MAXCH; i++) c_le += __popcll(__ballot(ov[i] <= T && ov[i] != 0xFFFFFFFFu));
+    const bool exact_cut = c_le <= k && k <= 64;  // (fewer than k live candidates: T = 0xFFFFFFFF, all of them pass)
 #pragma unroll
     for (int c = 0; c < MAXCH; c++) {
-        const bool live = ov[c] != 0xFFFFFFFFu;  // (padding of a slice shorter than k: never a live key)
+        const bool live = ov[c] != 0xFFFFFFFFu && (!exact_cut || ov[c] <= T);  // (padding of a slice shorter than k: never a live key)
         const uint64_t m = __ballot(live);
         if (live) {
             const int sl = cnt + __popcll(m & ((1ull << lane) - 1ull));
@@ -351,6 +366,8 @@ __global__ __launch_bounds__(64) void k_merge_slices(const int64_t *in_ids, cons
         }
         cnt += __popcll(m);
     }
+    if (exact_cut) cnt = compact_pool<1>(pool_ord, pool_id, cnt, k, lane);
+    else
     cnt = compact_pool<MAXCH>(pool_ord, pool_id, cnt, k, lane);
     for (int e = lane; e < k; e += 64) {
         int64_t oid = -1;

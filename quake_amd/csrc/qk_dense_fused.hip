@@ -1,6 +1,6 @@
 // qk_dense_fused.hip -- top-k of every query over ONE list of a few thousand rows: exact keys and their selection in one launch.
 //
-// The coarse step of QueryCoordinator::search over a parent of 1024-2048 centroids (src/cpp/src/query_coordinator.cpp:628-644 ->
+// The coarse step of QueryCoordinator::search over a parent of 1024-4096 centroids (src/cpp/src/query_coordinator.cpp:628-644 ->
 // batched_scan_list(x, centroids, ..., k = nprobe), src/cpp/include/list_scanning.h:313-366).  The other dense forms are sized
 // for long lists: k_dense_ord + k_select_rows write and re-read a [Q][n] key matrix, the prefiltered form (qk_dense_pf.hip) is four
 // dependent launches of 5-18 us each whatever the size.  At a few thousand rows the whole product is ~8 us of fp32 MFMA work, so:
@@ -10,8 +10,8 @@
 //                       rows at or under it are the slice's candidates, written as [Q][slices][k] (id, key) -- unsorted; only a
 //                       tie on the k-th key (duplicate rows) goes through compact_pool's (key, id) order
 //   k_merge_slices      (qk_dense.hip) one wave per query over slices * k <= 1024 candidates -> ids + distances
-// No key ever leaves the CU; the centroid rows are read from the L2 once per query tile and slice.  Serves 1024-2048 rows, see
-// fused_plan; beyond that the prefiltered form is faster (the merge wave's slices * k candidates grow with the rows).
+// No key ever leaves the CU; the centroid rows are read from the L2 once per query tile and slice.  Serves 1024-2048 rows (to 4096
+// for k > 32), see fused_plan; beyond that the prefiltered form is faster (the merge wave's slices * k candidates grow with the rows).
 #include "qk_internal.h"
 
 #include "qk_device.h"
@@ -55,18 +55,12 @@ __global__ __launch_bounds__(256) void k_dense_fused(FusedParams P) {
     const int slice = blockIdx.x;
     const int64_t q_base = (int64_t)blockIdx.y * (NQ * 16);
 
-    for (int t = wave; t < NQ * nblk; t += 4) {
-        const int nq = t / nblk, cb = t - nq * nblk;
-        const int64_t row = q_base + nq * 16 + j;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (row < P.Q) v = P.xq4[(row * nblk + cb) * 4 + g];
-        qs[(size_t)nq * nblk * 64 + cb * 64 + lane] = v;
-    }
-    if (tid < NQ * 16) {
-        const int64_t row = q_base + tid;
-        xn_s[tid] = (row < P.Q && l2) ? P.xn[row] : 0.0f;
-    }
-    __syncthreads();
+
+    // the ids of the slice's rows, lane + 64 i as in the selection: requested now, used after the products (a gather of the
+    // selected rows' ids at the end was one more dependent memory round trip per wave)
+    int64_t idv[R];
+#pragma unroll
+    for (int i = 0; i < R; i++) idv[i] = P.ids[min(slice * SR + lane + 64 * i, P.nrows - 1)];
 
     const int ntile_all = (P.nrows + 15) >> 4;
     const int wg_t0 = slice * (SR / 16);
@@ -78,19 +72,15 @@ __global__ __launch_bounds__(256) void k_dense_fused(FusedParams P) {
         for (int nq = 0; nq < NQ; nq++)
             *(uint4 *)(keys + (size_t)(nq * 16 + j) * LDK + c0) = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
     }
-    if (t1 > t0) {
-        float xnj[NQ];
-#pragma unroll
-        for (int nq = 0; nq < NQ; nq++) xnj[nq] = xn_s[nq * 16 + j];
-        const int ncd = nblk / DB;
-        const int64_t tile_abs0 = (P.row_off >> 4) + t0;
-        const float4 *src = P.vecs + tile_abs0 * nblk * 64 + lane;
-        const float4 *nsrc = (const float4 *)(P.norms + (tile_abs0 << 4)) + g;
-        const int nsteps = (t1 - t0) * ncd;
-        float4 a0[DB], a1[DB];
-        float4 yn_cur = make_float4(0.f, 0.f, 0.f, 0.f), yn_next = yn_cur;
-        f32x4 acc[NQ];
-        int dch = 0, tile = t0, ldch = 0, ltile = 0;
+    const int ncd = nblk / DB;
+    const int64_t tile_abs0 = (P.row_off >> 4) + t0;
+    const float4 *src = P.vecs + tile_abs0 * nblk * 64 + lane;
+    const float4 *nsrc = (const float4 *)(P.norms + (tile_abs0 << 4)) + g;
+    const int nsteps = (t1 - t0) * ncd;
+    float4 a0[DB], a1[DB];
+    float4 yn_cur = make_float4(0.f, 0.f, 0.f, 0.f), yn_next = yn_cur;
+    f32x4 acc[NQ];
+    int dch = 0, tile = t0, ldch = 0, ltile = 0;
 
 #define FU_LOAD(A, S)                                                 \
     {                                                                 \
@@ -141,7 +131,25 @@ __global__ __launch_bounds__(256) void k_dense_fused(FusedParams P) {
         }                                                                                                    \
     }
 
-        FU_LOAD(a0, 0);
+    // the workgroup's queries -> LDS; the first row tile (and the ids above) are requested before the barrier, so the two memory
+    // round trips of the prologue overlap
+    for (int t = wave; t < NQ * nblk; t += 4) {
+        const int nq = t / nblk, cb = t - nq * nblk;
+        const int64_t row = q_base + nq * 16 + j;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < P.Q) v = P.xq4[(row * nblk + cb) * 4 + g];
+        qs[(size_t)nq * nblk * 64 + cb * 64 + lane] = v;
+    }
+    if (tid < NQ * 16) {
+        const int64_t row = q_base + tid;
+        xn_s[tid] = (row < P.Q && l2) ? P.xn[row] : 0.0f;
+    }
+    if (t1 > t0) FU_LOAD(a0, 0);
+    __syncthreads();
+    if (t1 > t0) {
+        float xnj[NQ];
+#pragma unroll
+        for (int nq = 0; nq < NQ; nq++) xnj[nq] = xn_s[nq * 16 + j];
         yn_cur = yn_next;
         int s = 0;
         while (s < nsteps) {
@@ -184,6 +192,7 @@ __global__ __launch_bounds__(256) void k_dense_fused(FusedParams P) {
             if (c < k) T[u] = tr;
         }
     }
+    uint32_t tie_mask = 0;
 #pragma unroll
     for (int u = 0; u < QW; u++) {
         const int64_t q = q_base + wave + 4 * u;
@@ -202,7 +211,7 @@ __global__ __launch_bounds__(256) void k_dense_fused(FusedParams P) {
                 const uint64_t m = __ballot(pass);
                 if (pass) {
                     const int sl = n + __popcll(m & ((1ull << lane) - 1ull));
-                    P.out_ids[ob + sl] = P.ids[row_base + lane + 64 * i];
+                    P.out_ids[ob + sl] = idv[i];
                     P.out_ord[ob + sl] = o[u][i];
                 }
                 n += __popcll(m);
@@ -213,31 +222,36 @@ __global__ __launch_bounds__(256) void k_dense_fused(FusedParams P) {
             }
             continue;
         }
-        // several rows share the k-th key (duplicates): which of them stay is a matter of their ids -- through the pool, compact_pool
-        // keeps the k best under (key, id)
+        tie_mask |= 1u << u;
+    }
+    // several rows share the k-th key (duplicates): which of them stay is a matter of their ids -- through the pool, compact_pool
+    // keeps the k best under (key, id).  Rare: ONE rolled copy of this path for the wave's queries (unrolled per query and chunk it
+    // was 40 of the kernel's 54 KB of code), the keys re-read from LDS
+    for (int u = 0; tie_mask >> u; u++) {
+        if (!((tie_mask >> u) & 1u)) continue;
+        const int64_t q = q_base + wave + 4 * u;
+        const int64_t ob = (q * P.slices + slice) * k;
+        uint32_t Tu = T[0];
+#pragma unroll
+        for (int v = 1; v < QW; v++) Tu = u == v ? T[v] : Tu;
+        const uint32_t *kr = keys + (size_t)(wave + 4 * u) * LDK;
         int n = 0, n_ids = 0;
-        const uint32_t *kr = keys + (size_t)(wave + 4 * u) * LDK;  // (the rare path re-reads its keys: no unrolled copy of the pool code)
-        const uint32_t Tu = T[u];
         for (int i = 0; i < R; i++) {
             const uint32_t ov = kr[lane + 64 * i];
             const bool pass = ov <= Tu && ov != 0xFFFFFFFFu;
             const uint64_t m = __ballot(pass);
-            if (m) {
-                if (pass) {
-                    const int sl = n + __popcll(m & ((1ull << lane) - 1ull));
-                    pool_ord[sl] = ov;
-                    pool_id[sl] = row_base + lane + 64 * i;  // the ROW for now
-                }
-                n += __popcll(m);
-                if (n > FU_POOL - 64) {
-                    for (int e = n_ids + lane; e < n; e += 64) pool_id[e] = P.ids[pool_id[e]];
-                    n = compact_pool<2>(pool_ord, pool_id, n, k, lane);
-                    n_ids = n;
-                }
+            if (pass) {
+                const int sl = n + __popcll(m & ((1ull << lane) - 1ull));
+                pool_ord[sl] = ov;
+                pool_id[sl] = row_base + lane + 64 * i;  // the ROW for now
+            }
+            n += __popcll(m);
+            if (n > FU_POOL - 64 || i == R - 1) {
+                for (int e = n_ids + lane; e < n; e += 64) pool_id[e] = P.ids[pool_id[e]];
+                n = compact_pool<2>(pool_ord, pool_id, n, k, lane);
+                n_ids = n;
             }
         }
-        for (int e = n_ids + lane; e < n; e += 64) pool_id[e] = P.ids[pool_id[e]];
-        n = compact_pool<2>(pool_ord, pool_id, n, k, lane);
         for (int e = lane; e < k; e += 64) {
             P.out_ids[ob + e] = e < n ? pool_id[e] : -1;
             P.out_ord[ob + e] = e < n ? pool_ord[e] : 0xFFFFFFFFu;
@@ -253,10 +267,11 @@ struct FusedPlan {
 
 static bool fused_plan(const qk_ctx *ctx, const qk_store *s, int64_t Q, int nrows, int k, FusedPlan *pl) {
     // where this form is the fastest of the dense ones (1024 queries, scripts/coarse_probe.py, same box, prefiltered form -> this
-    // one, us per call at k = 2 / 8 / 32 / 64): 1024 rows 27 / 29 / 37 / 57 -> 23 / 24 / 29 / 46, 2048 rows 28 / 31 / 44 / 77 ->
-    // 28 / 29 / 37 / 54; at 4096 rows 30 / 33 / 45 / 70 against 38 / 40 / 50 / 89 the prefiltered form stays (8192: 36 / 39 / 54
-    // against 58 / 62 / 82): the merge wave's slices * k candidates grow with the rows
-    if (k < 2 || k > 64 || nrows < 1024 || nrows > 2048 || Q < 64 || Q > 65536) return false;
+    // one, us per call at k = 2 / 8 / 32 / 64): 1024 rows 27 / 29 / 37 / 57 -> 22 / 22 / 24 / 37, 2048 rows 28 / 31 / 44 / 77 ->
+    // 27 / 27 / 35 / 52; 3072 rows 30 / 33 / 45 / 101 against 32 / 33 / 38 / 49, 4096 rows 31 / 34 / 47 / 69 against 36 / 37 / 47 /
+    // 62: up to 2048 rows, to 3072 at k = 32 and to 4096 beyond -- the prefiltered form loses where its candidate lists grow (large
+    // k), this one where the merge wave's slices * k candidates do (more rows)
+    if (k < 2 || k > 64 || nrows < 1024 || nrows > (k > 32 ? 4096 : k == 32 ? 3072 : 2048) || Q < 64 || Q > 65536) return false;
     const int nblk = s->nblk;
     if (nblk > 8) return false;  // d <= 128: the query tile and the keys share the LDS
     // 16 queries per workgroup (four per wave in the selection, side by side); slices of 256 rows, 512 from k = 33 on (2048 rows,

@@ -49,9 +49,10 @@ def test_fused_coarse_matches_oracle(ctx, metric, d):
             if metric == "ip":
                 q /= np.linalg.norm(q, axis=1, keepdims=True)
             for k in (2, 10, 32, 33, 64):
-                # the form serves up to 2048 rows (fused_plan); the prefiltered form the rest (the key-matrix form where that
-                # one has too few row groups for its bound: small batches with a large k)
-                _check(ctx, parent, cent, q, k, metric, form="k_dense_fused" if n <= 2048 else ("k_dense_pf", "k_dense"))
+                # the form serves up to 2048 rows, 3072 at k = 32, 4096 beyond (fused_plan); the prefiltered form the rest (the
+                # key-matrix form where that one has too few row groups for its bound: small batches with a large k)
+                fused = n <= (4096 if k > 32 else 3072 if k == 32 else 2048)
+                _check(ctx, parent, cent, q, k, metric, form="k_dense_fused" if fused else ("k_dense_pf", "k_dense"))
         parent.close()
 
 
@@ -110,13 +111,13 @@ def test_fused_after_centroids_change(ctx):
 
 
 def test_shapes_outside_the_fused_form(ctx):
-    """above 2048 rows, k = 1, k > 64: other dense forms answer, same results"""
+    """above 2048 rows (4096 for k > 32), k = 1, k > 64: other dense forms answer, same results"""
     rng = np.random.default_rng(114)
     cent = rng.standard_normal((5000, 32)).astype(np.float32)
     parent = _parent(ctx, cent)
     q = (cent[rng.integers(0, 5000, 500)] + 0.3 * rng.standard_normal((500, 32))).astype(np.float32)
     _check(ctx, parent, cent, q, 8, "l2", form="k_dense_pf")
-    _check(ctx, parent, cent, q, 64, "l2", form=("k_dense_pf", "k_dense"))
+    _check(ctx, parent, cent, q, 32, "l2", form=("k_dense_pf", "k_dense"))
     parent.close()
     cent = rng.standard_normal((2048, 32)).astype(np.float32)
     parent = _parent(ctx, cent)
@@ -161,7 +162,7 @@ def test_random_dense_shapes_around_the_form_boundary(ctx, seed):
         tag = f"seed={seed} n={cent.shape[0]} d={cent.shape[1]} Q={q.shape[0]} k={k} {metric} form={form}"
         np.testing.assert_array_equal(gp, op, err_msg=tag)
         np.testing.assert_array_equal(gd.view(np.uint32), od.view(np.uint32), err_msg=tag)
-        if 64 <= q.shape[0] and cent.shape[0] <= 2048 and cent.shape[1] <= 128 and q.shape[0] > 256:
+        if cent.shape[0] <= 2048 and q.shape[0] > 256:
             assert form == "k_dense_fused", tag
     finally:
         parent.close()
