@@ -267,18 +267,19 @@ struct FusedPlan {
 
 static bool fused_plan(const qk_ctx *ctx, const qk_store *s, int64_t Q, int nrows, int k, FusedPlan *pl) {
     // where this form is the fastest of the dense ones (1024 queries, scripts/coarse_probe.py, same box, prefiltered form -> this
-    // one, us per call at k = 2 / 8 / 32 / 64): 1024 rows 27 / 29 / 37 / 57 -> 22 / 22 / 24 / 37, 2048 rows 28 / 31 / 44 / 77 ->
-    // 27 / 27 / 35 / 52; 3072 rows 30 / 33 / 45 / 101 against 32 / 33 / 38 / 49, 4096 rows 31 / 34 / 47 / 69 against 36 / 37 / 47 /
+    // one, us per call at k = 2 / 8 / 32 / 64): 1024 rows 27 / 29 / 37 / 57 -> 22 / 22 / 24 / 28, 2048 rows 28 / 31 / 44 / 77 ->
+    // 27 / 27 / 35 / 35; 3072 rows 30 / 33 / 45 / 101 against 32 / 33 / 38 / 49, 4096 rows 31 / 34 / 47 / 69 against 36 / 37 / 47 /
     // 62: up to 2048 rows, to 3072 at k = 32 and to 4096 beyond -- the prefiltered form loses where its candidate lists grow (large
     // k), this one where the merge wave's slices * k candidates do (more rows)
     if (k < 2 || k > 64 || nrows < 1024 || nrows > (k > 32 ? 4096 : k == 32 ? 3072 : 2048) || Q < 64 || Q > 65536) return false;
     const int nblk = s->nblk;
     if (nblk > 8) return false;  // d <= 128: the query tile and the keys share the LDS
-    // 16 queries per workgroup (four per wave in the selection, side by side); slices of 256 rows, 512 from k = 33 on (2048 rows,
-    // k = 64: 54 us with 512-row slices against 58).  Measured against it at 4096 rows, k = 2 / 32: 32 queries per workgroup (half
-    // the row traffic from the L2, twice the selection work per wave) 43 / 59 us against 38 / 53; 1024-row slices (a quarter of
-    // the candidates, one workgroup per CU) 55 / 61
-    const int NQ = 1, SR = k <= 32 ? 256 : 512;
+    // 16 queries per workgroup (four per wave in the selection, side by side); slices of 256 rows -- 512 only beyond 3072 rows at
+    // k > 32, where the merge wave would hold 1024 candidates (k = 64, 256- against 512-row slices: 1024 rows 28 against 37 us, 2048:
+    // 35 / 38, 3072: 45 / 47, 4096: 59 / 56).  Measured against it at 4096 rows, k = 2 / 32: 32 queries per workgroup (half the row
+    // traffic from the L2, twice the selection work per wave) 43 / 59 us against 38 / 53; 1024-row slices (a quarter of the
+    // candidates, one workgroup per CU) 55 / 61
+    const int NQ = 1, SR = (k <= 32 || nrows <= 3072) ? 256 : 512;
     const int slices = (nrows + SR - 1) / SR;
     if (slices * k > 1024) return false;
     pl->NQ = NQ;
