@@ -2,6 +2,7 @@
 """bench.py -- QuakeIndex::search() hot path on MI355X: queries/sec at recall@10 >= 0.9.
 
     python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus N --steps K --warmup W          # N = 2, 4, 8: starts its own N ranks (launch_ranks), or, equivalently,
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -755,6 +756,31 @@ def run_sharded(ctx, dev, args, dist, rank, world):
     }
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: re-run this command line as N ranks of one node (static rendezvous on
+    127.0.0.1 and a free port -- the container hostname may not resolve).  Returns the exit code of the job.  Fails before
+    anything is started when the node shows fewer than N GPUs (RCCL needs one per rank; QUAKE_BENCH_BACKEND=gloo lets ranks
+    share a GPU for a functional run)."""
+    import socket
+    backend = os.environ.get("QUAKE_BENCH_BACKEND", "nccl")
+    have = torch.cuda.device_count()
+    if backend == "nccl" and have < n:
+        print(f"bench.py --gpus {n}: this node shows {have} GPU(s); RCCL needs one per rank "
+              f"(QUAKE_BENCH_BACKEND=gloo runs the ranks on shared GPUs, functionally)", file=sys.stderr, flush=True)
+        return 2
+    if have < 1:
+        print(f"bench.py --gpus {n}: no GPU visible", file=sys.stderr, flush=True)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "8"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log("launching", n, "ranks:", " ".join(cmd))
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -788,6 +814,10 @@ def main():
     ap.add_argument("--traffic-probe", action="store_true", help="internal: the short replay measured_traffic() profiles")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves (the coordinator starts its own workers,
+        # query_coordinator.cpp:50-95) -- one process per GPU through torch.distributed.run, rank 0 prints the JSON line
+        raise SystemExit(launch_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

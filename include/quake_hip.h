@@ -174,6 +174,15 @@ QK_API int qk_search_aps(qk_ctx *ctx, qk_store *parent, qk_store *s, const float
  * returns after qk_ctx_set_squared_l2(ctx, 1); the output distances are sqrt'd.  Device pointers only. */
 QK_API int qk_merge_topk(qk_ctx *ctx, const int64_t *in_ids, const float *in_key, int G, int64_t Q, int k, int metric,
                          int64_t *out_ids, float *out_dist);
+/* The same exchange as ONE collective (the ids + keys of an entry travel together, 12 bytes): qk_pack_topk turns a rank's local
+ * result ids/key [G*per][k] into G blocks of qk_topk_block_bytes(per, k) bytes -- block j = queries [j*per, (j+1)*per): per*k
+ * int64 ids then per*k float keys, padded to 16 bytes -- which is the send buffer of one all_to_all_single with equal splits;
+ * qk_merge_topk_packed merges the receive buffer (block r = rank r's results for this rank's `per` queries) into [per][k]
+ * under the same (key,id) order.  Device pointers only; 16-byte aligned buffers. */
+QK_API size_t qk_topk_block_bytes(int64_t per, int k);
+QK_API int qk_pack_topk(qk_ctx *ctx, const int64_t *ids, const float *key, int G, int64_t per, int k, void *packed);
+QK_API int qk_merge_topk_packed(qk_ctx *ctx, const void *packed, int G, int64_t per, int k, int metric, int64_t *out_ids,
+                                float *out_dist);
 /* When enabled, qk_scan/qk_search return squared L2 distances (the merge key) instead of sqrt distances. */
 QK_API int qk_ctx_set_squared_l2(qk_ctx *ctx, int enabled);
 

@@ -71,6 +71,9 @@ SIGNATURES = {
     "qk_search_aps": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _int, C.c_float, C.c_float, _int, C.c_float, _vp, _vp, _vp, _int,
                       C.POINTER(QkTiming)]),
     "qk_merge_topk": (_int, [_vp, _vp, _vp, _int, _i64, _int, _int, _vp, _vp]),
+    "qk_topk_block_bytes": (C.c_size_t, [_i64, _int]),
+    "qk_pack_topk": (_int, [_vp, _vp, _vp, _int, _i64, _int, _vp]),
+    "qk_merge_topk_packed": (_int, [_vp, _vp, _int, _i64, _int, _int, _vp, _vp]),
     "qk_kmeans_assign": (_int, [_vp, _vp, _i64, _vp, _i64, _int, _int, _vp, _vp, _int]),
     "qk_kmeans_accumulate": (_int, [_vp, _vp, _i64, _int, _vp, _i64, _vp, _vp, _int]),
     "qk_store_refine_lists": (_int, [_vp, _vp, _i64, _vp, _int, _int, _int]),

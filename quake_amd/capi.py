@@ -215,6 +215,31 @@ class Context:
         check(self.lib.qk_merge_topk(self.h, _ptr(ids), _ptr(keys), G, Q, k, metric_code(metric), _ptr(out_i), _ptr(out_d)))
         return out_i, out_d
 
+    def topk_block_bytes(self, per, k):
+        return int(self.lib.qk_topk_block_bytes(int(per), int(k)))
+
+    def pack_topk(self, ids, keys, G, out=None):
+        """ids/keys: CUDA tensors [G*per][k] -> uint8 [G][block] send buffer of the one-collective exchange (block j = the
+        entries of queries [j*per, (j+1)*per): ids then keys)."""
+        import torch
+        ids, keys = _i64(ids), _f32(keys)
+        Q, k = ids.shape
+        per = Q // int(G)
+        blk = self.topk_block_bytes(per, k)
+        if out is None or tuple(out.shape) != (int(G), blk) or out.device != ids.device:
+            out = torch.empty((int(G), blk), dtype=torch.uint8, device=ids.device)
+        check(self.lib.qk_pack_topk(self.h, _ptr(ids), _ptr(keys), int(G), per, k, _ptr(out)))
+        return out
+
+    def merge_topk_packed(self, packed, per, k, metric):
+        """packed: uint8 [G][block] receive buffer (block r = rank r's entries for this rank's `per` queries)."""
+        import torch
+        G = packed.shape[0]
+        out_i = torch.empty((per, k), dtype=torch.int64, device=packed.device)
+        out_d = torch.empty((per, k), dtype=torch.float32, device=packed.device)
+        check(self.lib.qk_merge_topk_packed(self.h, _ptr(packed), G, int(per), int(k), metric_code(metric), _ptr(out_i), _ptr(out_d)))
+        return out_i, out_d
+
     # ---- k-means ----------------------------------------------------------------------------------------
     def kmeans_assign(self, x, c, metric):
         x, c = _f32(x), _f32(c)

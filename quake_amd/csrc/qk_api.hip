@@ -257,4 +257,21 @@ int qk_merge_topk(qk_ctx *ctx, const int64_t *in_ids, const float *in_key, int G
     return qk_merge_topk_device(ctx, in_ids, in_key, G, Q, k, metric, out_ids, out_dist, true);
 }
 
+size_t qk_topk_block_bytes(int64_t per, int k) { return (per < 0 || k <= 0) ? 0 : qk_topk_block_bytes_(per, k); }
+
+int qk_pack_topk(qk_ctx *ctx, const int64_t *ids, const float *key, int G, int64_t per, int k, void *packed) {
+    if (!ctx || (per > 0 && (!ids || !key || !packed))) QK_FAIL(QK_ERR_INVALID, "qk_pack_topk: null argument");
+    if (G <= 0 || k <= 0 || per < 0) QK_FAIL(QK_ERR_INVALID, "qk_pack_topk: bad sizes");
+    QK_HIP(hipSetDevice(ctx->device));
+    return qk_pack_topk_device(ctx, ids, key, G, per, k, packed);
+}
+
+int qk_merge_topk_packed(qk_ctx *ctx, const void *packed, int G, int64_t per, int k, int metric, int64_t *out_ids, float *out_dist) {
+    if (!ctx || (per > 0 && (!packed || !out_ids))) QK_FAIL(QK_ERR_INVALID, "qk_merge_topk_packed: null argument");
+    if (G <= 0 || k <= 0 || per < 0) QK_FAIL(QK_ERR_INVALID, "qk_merge_topk_packed: bad sizes");
+    QK_TRY(check_metric(metric));
+    QK_HIP(hipSetDevice(ctx->device));
+    return qk_merge_topk_packed_device(ctx, packed, G, per, k, metric, out_ids, out_dist, true);
+}
+
 }  // extern "C"

@@ -226,6 +226,10 @@ size_t qk_scan_zero_bytes(int64_t npids, int64_t Q);
 int qk_check_overflow(qk_ctx *ctx);
 int qk_merge_topk_device(qk_ctx *ctx, const int64_t *in_ids, const float *in_key, int G, int64_t Q, int k, int metric,
                          int64_t *out_ids, float *out_dist, bool sqrt_l2);
+size_t qk_topk_block_bytes_(int64_t per, int k);
+int qk_pack_topk_device(qk_ctx *ctx, const int64_t *ids, const float *key, int G, int64_t per, int k, void *packed);
+int qk_merge_topk_packed_device(qk_ctx *ctx, const void *packed, int G, int64_t per, int k, int metric, int64_t *out_ids,
+                                float *out_dist, bool sqrt_l2);
 int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *timing, int ev_base);
 // one-launch search of a small batch (qk_small.hip)
 bool qk_small_supported(qk_ctx *ctx, qk_store *parent, qk_store *s, int64_t Q, int nprobe, int k);

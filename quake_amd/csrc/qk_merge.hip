@@ -504,10 +504,12 @@ __global__ __launch_bounds__(256) void k_merge_wide(MergeParams M) {
 // ---- cross-rank merge: [G][Q][k] per-rank results -> [Q][k] ---------------------------------------
 // in_key are SQUARED L2 distances / inner products (what qk_search returns with qk_ctx_set_squared_l2), so the
 // merge runs on the same (key, id) order as the single-GPU path; sqrt is applied to the output.
+// rank r's results start at in_ids + r * id_stride / in_key + r * key_stride (BYTE strides: the plain form passes Q*k*8 / Q*k*4,
+// the packed form of the one-all-to-all exchange the block size for both, qk_topk_block_bytes)
 template <int MAXCH>
-__global__ __launch_bounds__(64) void k_merge_ranks(const int64_t *__restrict__ in_ids, const float *__restrict__ in_key, int G,
-                                                    int64_t Q, int k, int Cm, int metric, int sqrt_l2, int64_t *out_ids,
-                                                    float *out_dist) {
+__global__ __launch_bounds__(64) void k_merge_ranks(const int64_t *__restrict__ in_ids0, const float *__restrict__ in_key0, int G,
+                                                    size_t id_stride, size_t key_stride, int64_t Q, int k, int Cm, int metric,
+                                                    int sqrt_l2, int64_t *out_ids, float *out_dist) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = threadIdx.x;
     const int64_t q = blockIdx.x;
@@ -516,7 +518,9 @@ __global__ __launch_bounds__(64) void k_merge_ranks(const int64_t *__restrict__ 
     uint32_t tau = 0xFFFFFFFFu;
     int cnt = 0;
     for (int r = 0; r < G; r++) {
-        const int64_t base0 = ((int64_t)r * Q + q) * k;
+        const int64_t base0 = q * k;
+        const int64_t *__restrict__ in_ids = (const int64_t *)((const unsigned char *)in_ids0 + (size_t)r * id_stride);
+        const float *__restrict__ in_key = (const float *)((const unsigned char *)in_key0 + (size_t)r * key_stride);
         for (int base = 0; base < k; base += 64) {
             const int e = base + lane;
             int64_t id = -1;
@@ -562,22 +566,62 @@ __global__ __launch_bounds__(64) void k_merge_ranks(const int64_t *__restrict__ 
     }
 }
 
-int qk_merge_topk_device(qk_ctx *ctx, const int64_t *in_ids, const float *in_key, int G, int64_t Q, int k, int metric,
-                         int64_t *out_ids, float *out_dist, bool sqrt_l2) {
+static int launch_merge_ranks(qk_ctx *ctx, const int64_t *in_ids, const float *in_key, int G, size_t id_stride, size_t key_stride,
+                              int64_t Q, int k, int metric, int64_t *out_ids, float *out_dist, bool sqrt_l2) {
     if (Q <= 0) return QK_OK;
     const int Cm = qk_round_up(k + 64, 64);
     if (Cm > 1024) QK_FAIL(QK_ERR_UNSUPPORTED, "qk_merge_topk: k=%d too large", k);
     const size_t lds = (size_t)Cm * 12;
     const int mc = Cm <= 128 ? 2 : Cm <= 256 ? 4 : Cm <= 512 ? 8 : 16;
     hipStream_t st = ctx->stream;
+    const int sq = sqrt_l2 ? 1 : 0;
     switch (mc) {
-        case 2: hipLaunchKernelGGL((k_merge_ranks<2>), dim3((unsigned)Q), dim3(64), lds, st, in_ids, in_key, G, Q, k, Cm, metric, sqrt_l2 ? 1 : 0, out_ids, out_dist); break;
-        case 4: hipLaunchKernelGGL((k_merge_ranks<4>), dim3((unsigned)Q), dim3(64), lds, st, in_ids, in_key, G, Q, k, Cm, metric, sqrt_l2 ? 1 : 0, out_ids, out_dist); break;
-        case 8: hipLaunchKernelGGL((k_merge_ranks<8>), dim3((unsigned)Q), dim3(64), lds, st, in_ids, in_key, G, Q, k, Cm, metric, sqrt_l2 ? 1 : 0, out_ids, out_dist); break;
-        default: hipLaunchKernelGGL((k_merge_ranks<16>), dim3((unsigned)Q), dim3(64), lds, st, in_ids, in_key, G, Q, k, Cm, metric, sqrt_l2 ? 1 : 0, out_ids, out_dist); break;
+        case 2: hipLaunchKernelGGL((k_merge_ranks<2>), dim3((unsigned)Q), dim3(64), lds, st, in_ids, in_key, G, id_stride, key_stride, Q, k, Cm, metric, sq, out_ids, out_dist); break;
+        case 4: hipLaunchKernelGGL((k_merge_ranks<4>), dim3((unsigned)Q), dim3(64), lds, st, in_ids, in_key, G, id_stride, key_stride, Q, k, Cm, metric, sq, out_ids, out_dist); break;
+        case 8: hipLaunchKernelGGL((k_merge_ranks<8>), dim3((unsigned)Q), dim3(64), lds, st, in_ids, in_key, G, id_stride, key_stride, Q, k, Cm, metric, sq, out_ids, out_dist); break;
+        default: hipLaunchKernelGGL((k_merge_ranks<16>), dim3((unsigned)Q), dim3(64), lds, st, in_ids, in_key, G, id_stride, key_stride, Q, k, Cm, metric, sq, out_ids, out_dist); break;
     }
     QK_HIP(hipGetLastError());
     return QK_OK;
+}
+
+int qk_merge_topk_device(qk_ctx *ctx, const int64_t *in_ids, const float *in_key, int G, int64_t Q, int k, int metric,
+                         int64_t *out_ids, float *out_dist, bool sqrt_l2) {
+    return launch_merge_ranks(ctx, in_ids, in_key, G, (size_t)Q * k * 8, (size_t)Q * k * 4, Q, k, metric, out_ids, out_dist, sqrt_l2);
+}
+
+// ---- the one-all-to-all exchange of the sharded search (quake_amd/sharded.py) ------------------------------------------------
+// A rank's [Q][k] ids + keys become G blocks, block j = the results of queries [j*per, (j+1)*per) as ONE 12-byte-per-entry unit:
+// per*k int64 ids followed by per*k float keys, padded to 16 bytes -- the send buffer of a single all_to_all_single; the
+// receive buffer ([G] blocks, block r = rank r's results for THIS rank's queries) is merged in place by k_merge_ranks.
+size_t qk_topk_block_bytes_(int64_t per, int k) { return (((size_t)per * k * 12) + 15) & ~(size_t)15; }
+
+__global__ __launch_bounds__(256) void k_pack_topk(const int64_t *__restrict__ ids, const float *__restrict__ key, int64_t per, int k,
+                                                   size_t blk, int64_t total, unsigned char *__restrict__ packed) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;  // entry number in [Q][k]
+    if (i >= total) return;
+    const int64_t pk = per * k;
+    const int64_t j = i / pk, e = i - j * pk;
+    unsigned char *b = packed + (size_t)j * blk;
+    ((int64_t *)b)[e] = ids[i];
+    ((float *)(b + (size_t)pk * 8))[e] = key[i];
+}
+
+int qk_pack_topk_device(qk_ctx *ctx, const int64_t *ids, const float *key, int G, int64_t per, int k, void *packed) {
+    const int64_t total = (int64_t)G * per * k;
+    if (total <= 0) return QK_OK;
+    hipLaunchKernelGGL(k_pack_topk, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, ids, key, per, k,
+                       qk_topk_block_bytes_(per, k), total, (unsigned char *)packed);
+    QK_HIP(hipGetLastError());
+    return QK_OK;
+}
+
+int qk_merge_topk_packed_device(qk_ctx *ctx, const void *packed, int G, int64_t per, int k, int metric, int64_t *out_ids,
+                                float *out_dist, bool sqrt_l2) {
+    const size_t blk = qk_topk_block_bytes_(per, k);
+    const unsigned char *b = (const unsigned char *)packed;
+    return launch_merge_ranks(ctx, (const int64_t *)b, (const float *)(b + (size_t)per * k * 8), G, blk, blk, per, k, metric, out_ids,
+                              out_dist, sqrt_l2);
 }
 
 

@@ -80,6 +80,15 @@ class GpuEngine:
     def merge(self, ids, keys):
         return self.ctx.merge_topk(ids, keys, self.metric)
 
+    def pack(self, ids, keys, world, out=None):
+        """the send buffer of the one-collective exchange: uint8 [world][block], block j = ids then keys of queries
+        [j*per, (j+1)*per) (qk_pack_topk)"""
+        return self.ctx.pack_topk(ids, keys, world, out=out)
+
+    def merge_packed(self, packed, per, k):
+        """merge of the receive buffer (block r = rank r's entries for this rank's queries; qk_merge_topk_packed)"""
+        return self.ctx.merge_topk_packed(packed, per, k, self.metric)
+
     def assign(self, x):
         """nearest list (global number) of every vector: the k = 1 parent search of PartitionManager::add"""
         return self.ctx.coarse(self.parent, x, 1, self.metric)[0].reshape(-1)
@@ -190,8 +199,35 @@ class _Done:
         return True
 
 
+def topk_block_bytes(per, k):
+    """bytes of one block of the packed exchange: per*k int64 ids, then per*k float32 keys, padded to 16 (qk_topk_block_bytes)"""
+    return (int(per) * int(k) * 12 + 15) & ~15
+
+
+def pack_topk_host(ids, keys, world):
+    """the layout of qk_pack_topk with torch ops (engines without a native pack: the gloo tests' oracle engine)"""
+    import torch
+    ids = ids if torch.is_tensor(ids) else torch.from_numpy(np.ascontiguousarray(ids))
+    keys = keys if torch.is_tensor(keys) else torch.from_numpy(np.ascontiguousarray(keys))
+    Q, k = ids.shape
+    per = Q // world
+    buf = torch.zeros((world, topk_block_bytes(per, k)), dtype=torch.uint8, device=ids.device)
+    buf[:, :per * k * 8] = ids.contiguous().view(world, per * k).view(torch.uint8)
+    buf[:, per * k * 8:per * k * 12] = keys.contiguous().view(world, per * k).view(torch.uint8)
+    return buf
+
+
+def unpack_topk_host(buf, per, k):
+    """receive buffer [G][block] -> (ids [G, per, k], keys [G, per, k])"""
+    import torch
+    G = buf.shape[0]
+    ids = buf[:, :per * k * 8].contiguous().view(torch.int64).view(G, per, k)
+    keys = buf[:, per * k * 8:per * k * 12].contiguous().view(torch.float32).view(G, per, k)
+    return ids, keys
+
+
 class ShardedIndex:
-    """search() = sharded coarse + all-gather(pids) + local scan + all-gather(top-k) + merge.
+    """search() = sharded coarse + all-gather(pids) + local scan + ONE exchange of the per-rank top-k + merge.
     `dist` is torch.distributed (nccl = RCCL on ROCm, or gloo).  The coarse step is split by QUERIES (rank r takes
     the r-th slice of the batch against the replicated centroids) so its cost per rank does not grow with the number of
     ranks; the [Q, nprobe] partition lists are then all-gathered -- the one real exchange the path has besides the
@@ -208,7 +244,7 @@ class ShardedIndex:
             raise ValueError("result must be 'all' or 'owner'")
         self.result = result
         self._g_ids = self._g_keys = self._g_pids = None
-        self._x_ids = self._x_keys = None
+        self._x_send = self._x_recv = None
         self.last_pids = None
         # gloo (two ranks sharing one GPU in the functional tests) has no device all-to-all: stage through the host there
         self._stage_host = False
@@ -267,12 +303,16 @@ class ShardedIndex:
         self.last_pids = pids  # [Q, nprobe] of the whole batch, on every rank: what hit tracking records
         ids, keys = self.engine.scan(q, pids, k, out=out)
         if self.result == "owner":
-            ids = ids if torch.is_tensor(ids) else torch.from_numpy(np.ascontiguousarray(ids))
-            keys = keys if torch.is_tensor(keys) else torch.from_numpy(np.ascontiguousarray(keys))
-            x_ids, w1 = self._exchange("_x_ids", ids.view(self.world, per, -1))
-            x_keys, w2 = self._exchange("_x_keys", keys.view(self.world, per, -1))
-            w1.wait()
-            w2.wait()
+            # ONE all-to-all: an entry's id and key travel together (12-byte records, block j = this rank's results for the
+            # queries rank j owns); the receive buffer is merged where it lands
+            native = hasattr(self.engine, "pack")
+            send = self.engine.pack(ids, keys, self.world, out=self._x_send) if native else pack_topk_host(ids, keys, self.world)
+            self._x_send = send if native else None
+            recv, w = self._exchange("_x_recv", send)
+            w.wait()
+            if native:
+                return self.engine.merge_packed(recv, per, k)
+            x_ids, x_keys = unpack_topk_host(recv, per, k)
             return self.engine.merge(x_ids, x_keys)
         g_ids = self._gather("_g_ids", ids, torch.int64)
         g_keys = self._gather("_g_keys", keys, torch.float32)

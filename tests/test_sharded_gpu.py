@@ -138,3 +138,43 @@ def test_sharded_kmeans_world1_equals_qk_kmeans():
         torch.cuda.synchronize()
         assert torch.equal(c.view(torch.int32), rc.view(torch.int32)) and torch.equal(a, ra), metric
     ctx.close()
+
+
+@pytest.mark.parametrize("G,per,k,metric", [(1, 7, 3, "l2"), (3, 5, 7, "l2"), (8, 64, 10, "l2"), (4, 33, 100, "ip"), (2, 1, 1, "ip")])
+def test_packed_exchange_layout_and_merge(G, per, k, metric):
+    """qk_pack_topk / qk_merge_topk_packed (the one-all-to-all exchange): the packed layout is the documented one (block j = ids
+    then keys of queries [j*per, (j+1)*per), also with an odd number of entries: 16-byte padded blocks), the host restatement
+    sharded.pack_topk_host writes the same bytes, and merging G packed blocks equals qk_merge_topk on [G][per][k] bit for bit
+    (ties between ranks, -1 padded entries)."""
+    from quake_amd.capi import Context
+    from quake_amd.sharded import pack_topk_host, topk_block_bytes, unpack_topk_host
+    ctx = Context(0)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    rng = np.random.default_rng(100 * G + per + k)
+    # what one rank sends: its [G*per][k] local results
+    ids = rng.integers(0, 1 << 40, size=(G * per, k)).astype(np.int64)
+    keys = rng.integers(0, 50, size=(G * per, k)).astype(np.float32) * 0.25  # many ties
+    ids[rng.random(ids.shape) < 0.1] = -1
+    di, dk = torch.from_numpy(ids).cuda(), torch.from_numpy(keys).cuda()
+    packed = ctx.pack_topk(di, dk, G)
+    assert tuple(packed.shape) == (G, topk_block_bytes(per, k)) == (G, ctx.topk_block_bytes(per, k))
+    host = pack_topk_host(torch.from_numpy(ids), torch.from_numpy(keys), G)
+    n = per * k * 12
+    assert torch.equal(packed.cpu()[:, :n], host[:, :n])
+    ui, uk = unpack_topk_host(packed.cpu(), per, k)
+    np.testing.assert_array_equal(ui.numpy().reshape(G * per, k), ids)
+    np.testing.assert_array_equal(uk.numpy().reshape(G * per, k), keys)
+    # what one rank receives: G blocks (one per source rank) for ITS per queries
+    rid = rng.integers(0, 1 << 40, size=(G, per, k)).astype(np.int64)
+    rk = np.sort(rng.integers(0, 30, size=(G, per, k)).astype(np.float32) * 0.5, axis=2)
+    if metric == "ip":
+        rk = -rk
+    rid[:, :, k - 1:] = np.where(rng.random((G, per, 1)) < 0.3, -1, rid[:, :, k - 1:])
+    recv = torch.empty((G, topk_block_bytes(per, k)), dtype=torch.uint8)
+    for g in range(G):
+        recv[g] = pack_topk_host(torch.from_numpy(rid[g]), torch.from_numpy(rk[g]), 1)[0]
+    pi, pd = ctx.merge_topk_packed(recv.cuda(), per, k, metric)
+    mi, md = ctx.merge_topk(torch.from_numpy(rid).cuda(), torch.from_numpy(rk).cuda(), metric)
+    torch.cuda.synchronize()
+    assert torch.equal(pi, mi) and torch.equal(pd.view(torch.int32), md.view(torch.int32))
+    ctx.close()
