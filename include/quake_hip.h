@@ -82,6 +82,10 @@ QK_API int qk_ctx_set_stream(qk_ctx *ctx, void *hip_stream);
 /* Run on the device's NULL (legacy default) stream -- torch's default stream has the handle 0, which qk_ctx_set_stream reads
  * as "restore the private stream". */
 QK_API int qk_ctx_set_null_stream(qk_ctx *ctx);
+/* The stream the context is bound to now, so that a caller that rebinds it for one call can put the binding back:
+ * kind 0 = the private stream (restore with qk_ctx_set_stream(ctx, NULL)), 1 = the NULL stream (qk_ctx_set_null_stream),
+ * 2 = a caller-owned stream (*hip_stream; qk_ctx_set_stream(ctx, *hip_stream)). */
+QK_API int qk_ctx_get_stream(qk_ctx *ctx, void **hip_stream, int *kind);
 QK_API int qk_ctx_synchronize(qk_ctx *ctx);
 /* hipEvent timing of the phases, recorded on the context's stream around the kernels:
  *   0 off; 1 per call (the qk_timing* passed to qk_scan/qk_search is filled, which synchronises the stream);

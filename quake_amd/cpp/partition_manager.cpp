@@ -381,14 +381,19 @@ void PartitionManager::load(const std::string &path) {
     reset_store(d);
     const uint64_t rec = code_size + 8;
     int64_t max_pid = -1;
+    if (!ifs) throw std::runtime_error("Invalid file format (truncated offset / partition id table).");
+    const uint64_t start_of_chunks = 32 + 8 * (nparts + 1) + 8 * nparts;
     for (uint64_t i = 0; i < nparts; i++) {
+        if (offsets[i + 1] < offsets[i]) throw std::runtime_error("Invalid file format (partition offsets are not ascending).");
         const uint64_t chunk = offsets[i + 1] - offsets[i];
         if (chunk % rec != 0) throw std::runtime_error("Partition chunk size not divisible by (code_size+sizeof(idx_t))");
         const int64_t nv = (int64_t)(chunk / rec);
+        ifs.seekg((std::streamoff)(start_of_chunks + offsets[i]), std::ios::beg);  // dynamic_inverted_list.cpp:494
         std::vector<float> v((size_t)nv * d);
         std::vector<int64_t> id((size_t)nv);
         ifs.read((char *)v.data(), (std::streamsize)(v.size() * 4));
         ifs.read((char *)id.data(), (std::streamsize)(id.size() * 8));
+        if (!ifs) throw std::runtime_error("Invalid file format (truncated partition data).");
         qk_check(qk_store_add_list(store_, (int64_t)pids[i]));
         if (nv) qk_check(qk_store_add_entries(store_, (int64_t)pids[i], nv, id.data(), v.data(), QK_MEM_HOST));
         resident_ids_.insert(id.begin(), id.end());

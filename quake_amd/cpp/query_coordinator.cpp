@@ -20,17 +20,23 @@ inline int64_t ns_since(clk::time_point t0) { return std::chrono::duration_cast<
 // Device tensors in: the library works on torch's CURRENT stream for the length of the call (the newly bound stream waits for
 // the previous one through an event, qk_ctx_set_stream), so it is ordered behind whatever produced the inputs and the outputs are
 // ordered in front of whatever torch enqueues next -- no device-wide synchronisation.  The context is shared (one per device):
-// its private stream comes back on every way out.
+// the binding it had on entry -- its private stream, the NULL stream, or a stream a caller bound it to -- comes back on every
+// way out.
 struct BoundToTorchStream {
     qk_ctx *c = nullptr;
+    void *prev = nullptr;
+    int prev_kind = 0;
     BoundToTorchStream(qk_ctx *ctx, const Tensor &t) {
         if (!t.is_cuda()) return;
+        qk_check(qk_ctx_get_stream(ctx, &prev, &prev_kind));
         c = ctx;
         hipStream_t st = c10::hip::getCurrentHIPStream(t.device().index()).stream();
         qk_check(st ? qk_ctx_set_stream(c, (void *)st) : qk_ctx_set_null_stream(c));
     }
     ~BoundToTorchStream() {
-        if (c) (void)qk_ctx_set_stream(c, nullptr);
+        if (!c) return;
+        if (prev_kind == 1) (void)qk_ctx_set_null_stream(c);
+        else (void)qk_ctx_set_stream(c, prev_kind == 2 ? prev : nullptr);
     }
 };
 }  // namespace
@@ -87,17 +93,21 @@ shared_ptr<SearchResult> QueryCoordinator::search(Tensor x, shared_ptr<SearchPar
     std::memset(&tm, 0, sizeof(tm));
     const int mem = on_dev ? QK_MEM_DEVICE : QK_MEM_HOST;
     const bool track = maintenance_policy_ && maintenance_policy_->track_hits_ && parent_;
-    // per-call phase timing for SearchTimingInfo, in every branch; the context is shared (one per device), so the mode a caller
-    // had set -- the deferred modes of a harness, say -- is put back on every way out
+    // per-call phase timing for SearchTimingInfo (mode 1: the library synchronises the stream to read its events) -- for HOST
+    // tensors only, whose answers are copied back behind a synchronisation anyway.  Device tensors keep the call asynchronous:
+    // the phase fields then carry whatever mode the caller had set on the (shared, one per device) context, zeros by default.
+    // The caller's mode is put back on every way out.
     struct TimingMode {
-        qk_ctx *c;
+        qk_ctx *c = nullptr;
         int was = 0;
-        explicit TimingMode(qk_ctx *ctx) : c(ctx) {
-            qk_ctx_get_timing(c, &was);
-            qk_ctx_set_timing(c, 1);
+        TimingMode(qk_ctx *ctx, bool want) {
+            if (!want || qk_ctx_get_timing(ctx, &was) != QK_OK || was == 1) return;
+            if (qk_ctx_set_timing(ctx, 1) == QK_OK) c = ctx;
         }
-        ~TimingMode() { qk_ctx_set_timing(c, was); }
-    } timing_mode(ctx);
+        ~TimingMode() {
+            if (c) (void)qk_ctx_set_timing(c, was);
+        }
+    } timing_mode(ctx, !on_dev);
     if (sp->recall_target > 0.0f && parent_ && !sp->batched_scan) {
         // adaptive partition scanning (:502,637-641): candidates = nlist * initial_search_fraction
         Tensor nscan = torch::empty({Q}, torch::TensorOptions().dtype(torch::kInt32).device(xq.device()));

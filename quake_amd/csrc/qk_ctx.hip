@@ -93,6 +93,13 @@ int qk_ctx_set_null_stream(qk_ctx *c) {
     return switch_stream(c, nullptr);  // hipStream_t 0: ordered with every blocking stream of the device
 }
 
+int qk_ctx_get_stream(qk_ctx *c, void **hip_stream, int *kind) {
+    if (!c || !hip_stream || !kind) QK_FAIL(QK_ERR_INVALID, "qk_ctx_get_stream: null argument");
+    *hip_stream = (void *)c->stream;
+    *kind = c->stream == c->own_stream ? 0 : (c->stream == nullptr ? 1 : 2);
+    return QK_OK;
+}
+
 int qk_ctx_synchronize(qk_ctx *c) {
     if (!c) QK_FAIL(QK_ERR_INVALID, "qk_ctx_synchronize: ctx is null");
     QK_HIP(hipStreamSynchronize(c->stream));

@@ -177,6 +177,7 @@ struct qk_store {
 void qk_store_ensure_index(qk_store *s);
 
 int qk_store_sync_table(qk_store *s);                  // upload (row_off, size) if dirty
+constexpr int64_t QK_ROWMAJOR_MAX_BYTES = (int64_t)128 << 20;  // 262144 rows x 128: every parent the coarse forms are built for
 int qk_store_rowmajor(qk_store *s, int64_t row_off, int nrows, const float **out);  // the copy above for rows [row_off, +nrows)
 int qk_store_reserve_rows(qk_store *s, int64_t rows);  // grow the arena so that used_rows + rows fits
 

@@ -370,7 +370,8 @@ __device__ __forceinline__ void rl_hot_item(const ScanParams &P, const HotLds &H
         bool flag_ = false, flag1_ = false;                                                                  \
         _Pragma("unroll") for (int e_ = 0; e_ < 8; e_++) {                                                   \
             const float dd_ = e_ < 4 ? d0_[e_ & 3] : d1_[e_ & 3];                                            \
-            const bool p_ = L2 ? (__fmaf_rn(-2.0f, dd_, xk_ + yk_[e_]) <= tauf_) : (dd_ + (xk_ + yk_[e_]) >= tauf_); \
+            /* negated compares: a NaN bound (NaN / Inf data, overflow) stays a candidate, as in the per-wave walk and k_pf_gemm */ \
+            const bool p_ = L2 ? !(__fmaf_rn(-2.0f, dd_, xk_ + yk_[e_]) > tauf_) : !(dd_ + (xk_ + yk_[e_]) < tauf_); \
             if (e_ < 4) flag_ |= rv_[e_] & p_;                                                               \
             else flag1_ |= rv_[e_] & p_;                                                                     \
         }                                                                                                    \

@@ -391,9 +391,14 @@ int qk_store_create(qk_ctx *ctx, int d, qk_store **out) {
 
 // Row-major copy of rows [row_off, row_off + nrows) (one list: the centroids of a parent / flat index), made on the STORE's
 // context stream and complete on return (a host synchronisation, once per change of the store): any context may read it afterwards.
+// Meant for a PARENT's centroids (2 MB at 4096 rows, 33 MB at 65536): a list beyond QK_ROWMAJOR_MAX_BYTES gets no copy (*out stays
+// null and the caller gathers from the tile-major arena) -- a flat index of millions of rows must not silently double its
+// footprint.  One (row_off, nrows) entry is cached; it is replaced, under the store, by the next different request: callers on
+// several host threads must serialise searches that go through the prefiltered dense path of the SAME store.
 extern "C++" int qk_store_rowmajor(qk_store *s, int64_t row_off, int nrows, const float **out) {
     *out = nullptr;
     if (nrows <= 0 || s->table_dirty) return QK_OK;
+    if ((int64_t)nrows * s->d * (int64_t)sizeof(float) > QK_ROWMAJOR_MAX_BYTES) return QK_OK;
     if (s->rowmajor_valid && s->rowmajor_row_off == row_off && s->rowmajor_rows == nrows) {
         *out = s->rowmajor;
         return QK_OK;
@@ -683,14 +688,19 @@ int qk_store_remove_ids(qk_store *s, int64_t n, const int64_t *ids_host, int64_t
     s->ntotal -= removed;
     if (removed) s->table_dirty = true;
     if (n_removed) *n_removed = removed;
-    if (!mv_dst.empty()) {
-        size_t b = mv_dst.size() * sizeof(int64_t);
-        int64_t *dd = (int64_t *)c->stage, *ds = (int64_t *)(c->stage + ((b + 255) & ~(size_t)255));  // (reserved above: moves <= n)
-        QK_HIP(hipMemcpyAsync(dd, mv_dst.data(), b, hipMemcpyHostToDevice, c->stream));
-        QK_HIP(hipMemcpyAsync(ds, mv_src.data(), b, hipMemcpyHostToDevice, c->stream));
-        QK_TRY(qk_launch_move_rows(c, s->vecs, s->norms, s->ids, s->nblk, dd, ds, (int64_t)mv_dst.size()));
-        QK_HIP(hipStreamSynchronize(c->stream));
+    // one row move per removed row -- which is at most one per id asked for, UNLESS a list holds an id several times (the store
+    // does not enforce unique ids: add_batch / add_entries append whatever they are given).  The staging buffer was reserved for
+    // n moves before the mirror was touched; a longer move list goes through it in chunks of n (the moves of a sweep are
+    // independent: every source row lies beyond its list's new size, every destination row inside it).
+    const size_t cap = (size_t)n, slot = ((size_t)n * sizeof(int64_t) + 255) & ~(size_t)255;
+    for (size_t off = 0; off < mv_dst.size(); off += cap) {
+        const size_t m = std::min(cap, mv_dst.size() - off), b = m * sizeof(int64_t);
+        int64_t *dd = (int64_t *)c->stage, *ds = (int64_t *)(c->stage + slot);
+        QK_HIP(hipMemcpyAsync(dd, mv_dst.data() + off, b, hipMemcpyHostToDevice, c->stream));
+        QK_HIP(hipMemcpyAsync(ds, mv_src.data() + off, b, hipMemcpyHostToDevice, c->stream));
+        QK_TRY(qk_launch_move_rows(c, s->vecs, s->norms, s->ids, s->nblk, dd, ds, (int64_t)m));
     }
+    if (!mv_dst.empty()) QK_HIP(hipStreamSynchronize(c->stream));
     return QK_OK;
 }
 

@@ -37,7 +37,36 @@ SERIALIZATION_VERSION = 3        # common.h:67
 INT32_MAX = 2 ** 31 - 1
 
 
-class MaintenancePolicyParams:  # common.h:104-118, wrap.cpp:189-226
+def _js(v):
+    """one value of the JSON-style summaries wrap.cpp's __repr__s print (C++ stream formatting: true / false, %g floats)"""
+    if isinstance(v, bool):
+        return "true" if v else "false"
+    if isinstance(v, str):
+        return '"%s"' % v
+    if isinstance(v, float):
+        return "%g" % v
+    return str(v)
+
+
+class _Summary:
+    """__repr__ = the reference's one-line summary: _repr_fields names (summary key, attribute) pairs, _repr_trailing the
+    ", }" two of the reference's summaries end in (wrap.cpp:122-128, 211-226)"""
+    _repr_fields = ()
+    _repr_trailing = False
+
+    def _repr_pairs(self):
+        return [(k, getattr(self, a)) for k, a in self._repr_fields]
+
+    def __repr__(self):
+        return "{" + ", ".join('"%s": %s' % (k, _js(v)) for k, v in self._repr_pairs()) + (", }" if self._repr_trailing else "}")
+
+
+class MaintenancePolicyParams(_Summary):  # common.h:104-118, wrap.cpp:189-226
+    _repr_fields = tuple((k, k) for k in ("maintenance_policy", "window_size", "refinement_radius", "refinement_iterations",
+                                          "min_partition_size", "alpha", "enable_split_rejection", "enable_delete_rejection",
+                                          "delete_threshold_ns", "split_threshold_ns"))
+    _repr_trailing = True
+
     def __init__(self):
         self.maintenance_policy = "query_cost"
         self.window_size = 1000
@@ -51,7 +80,9 @@ class MaintenancePolicyParams:  # common.h:104-118, wrap.cpp:189-226
         self.split_threshold_ns = 10.0
 
 
-class IndexBuildParams:  # common.h:123-143, wrap.cpp:131-150
+class IndexBuildParams(_Summary):  # common.h:123-143, wrap.cpp:131-150
+    _repr_fields = tuple((k, k) for k in ("nlist", "niter", "metric", "num_workers"))
+
     def __init__(self):
         self.dimension = 0
         self.nlist = DEFAULT_NLIST
@@ -61,12 +92,11 @@ class IndexBuildParams:  # common.h:123-143, wrap.cpp:131-150
         self.use_gpu = True  # the reference's switch for GPU k-means (common.h:135); always on here
         self.seed = 1234     # faiss ClusteringParameters::seed default
 
-    def __repr__(self):
-        return '{"nlist": %d, "niter": %d, "metric": "%s", "num_workers": %d}' % (self.nlist, self.niter, self.metric,
-                                                                                     self.num_workers)
 
+class SearchParams(_Summary):  # common.h:171-184, wrap.cpp:153-186
+    _repr_fields = tuple((k, k) for k in ("k", "nprobe", "recall_target", "batched_scan", "use_precomputed",
+                                          "initial_search_fraction", "recompute_threshold", "aps_flush_period_us"))
 
-class SearchParams:  # common.h:171-184, wrap.cpp:153-186
     def __init__(self):
         self.nprobe = DEFAULT_NPROBE
         self.k = DEFAULT_K
@@ -80,7 +110,14 @@ class SearchParams:  # common.h:171-184, wrap.cpp:153-186
         self.aps_flush_period_us = DEFAULT_APS_FLUSH_PERIOD_US
 
 
-class SearchTimingInfo:  # common.h:214-228; device phases come from HIP events (qk_timing)
+class SearchTimingInfo(_Summary):  # common.h:214-228, wrap.cpp:279-320; device phases come from HIP events (qk_timing)
+    def _repr_pairs(self):
+        p = [(k, getattr(self, k)) for k in ("total_time_ns", "buffer_init_time_ns", "job_enqueue_time_ns",
+                                             "boundary_distance_time_ns", "job_wait_time_ns", "result_aggregate_time_ns")]
+        if self.parent_info is not None:
+            p.append(("parent_scan_time_ns", self.parent_info.total_time_ns))
+        return p + [(k, getattr(self, k)) for k in ("n_queries", "n_clusters", "partitions_scanned")]
+
     def __init__(self):
         self.n_queries = 0
         self.n_clusters = 0
@@ -95,7 +132,14 @@ class SearchTimingInfo:  # common.h:214-228; device phases come from HIP events 
         self.total_time_ns = 0
 
 
-class BuildTimingInfo:  # common.h:189-198
+class BuildTimingInfo(_Summary):  # common.h:189-198, wrap.cpp:323-350
+    _repr_fields = (("total_time_us", "total_time_us"), ("assign_time_us", "assign_time_us"), ("train_time_us", "train_time_us"),
+                    ("d", "d"), ("code_size", "code_size"), ("n_codebooks", "num_codebooks"), ("n_vectors", "n_vectors"))
+
+    @property
+    def n_codebooks(self):  # the bound name of num_codebooks (wrap.cpp:334)
+        return self.num_codebooks
+
     def __init__(self):
         self.n_vectors = 0
         self.n_clusters = 0
@@ -107,7 +151,10 @@ class BuildTimingInfo:  # common.h:189-198
         self.total_time_us = 0
 
 
-class ModifyTimingInfo:  # common.h:203-209; wrap.cpp:264 aliases modify_count to n_vectors
+class ModifyTimingInfo(_Summary):  # common.h:203-209; wrap.cpp:264 aliases modify_count to n_vectors
+    _repr_fields = (("modify_count", "n_vectors"), ("input_validation_time_us", "input_validation_time_us"),
+                    ("modify_time_us", "modify_time_us"), ("find_partition_time_us", "find_partition_time_us"))
+
     def __init__(self):
         self.n_vectors = 0
         self.input_validation_time_us = 0
@@ -120,7 +167,10 @@ class ModifyTimingInfo:  # common.h:203-209; wrap.cpp:264 aliases modify_count t
         return self.n_vectors
 
 
-class MaintenanceTimingInfo:  # common.h:233-241
+class MaintenanceTimingInfo(_Summary):  # common.h:233-241, wrap.cpp:244-256
+    _repr_fields = tuple((k, k) for k in ("total_time_us", "split_time_us", "delete_time_us", "split_refine_time_us",
+                                          "delete_refine_time_us", "n_splits", "n_deletes"))
+
     def __init__(self):
         self.n_splits = 0
         self.n_deletes = 0
@@ -670,9 +720,22 @@ class QuakeIndex:
             offs = np.frombuffer(f.read(8 * (nparts + 1)), "<u8", nparts + 1)
             pids = np.frombuffer(f.read(8 * nparts), "<u8", nparts)
             rec = code_size + 8
+            if len(offs) != nparts + 1 or len(pids) != nparts:
+                raise RuntimeError("Invalid file format (truncated offset / partition id table).")
             sizes = np.diff(offs.astype(np.int64))
+            # the reference seeks to start_of_chunks + offsets[i] per partition (dynamic_inverted_list.cpp:481-494); this loader reads
+            # the chunks in one forward pass, which is the same thing exactly when the offsets ascend (chunk i ends where chunk
+            # i + 1 starts: one cumulative table) -- anything else is refused rather than misparsed
+            if nparts and ((sizes < 0).any() or int(offs[0]) > (1 << 62)):
+                raise RuntimeError("Invalid file format (partition offsets are not ascending).")
             if (sizes % rec != 0).any():
                 raise RuntimeError("Partition chunk size not divisible by (code_size+sizeof(idx_t))")
+            start_of_chunks = 32 + 8 * (nparts + 1) + 8 * nparts
+            if nparts:
+                end = os.fstat(f.fileno()).st_size
+                if start_of_chunks + int(offs[-1]) > end:
+                    raise RuntimeError("Invalid file format (truncated partition data).")
+                f.seek(start_of_chunks + int(offs[0]))
             nvs = sizes // rec
             self._has_ctx = True
             self._d = int(d)

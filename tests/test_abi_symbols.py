@@ -101,3 +101,26 @@ def test_quake_package_alias():
     assert (sp.k, sp.nprobe, sp.batched_scan, bp.nlist, bp.niter, bp.metric) == (1, 1, False, 0, 5, "l2")
     for name in ("PartitionManager", "QueryCoordinator", "batched_scan_list", "MaintenancePolicyParams", "SearchResult"):
         assert hasattr(_bindings, name), name
+
+
+def test_summaries_of_both_mirrors_agree():
+    """the JSON-style __repr__ of every bound value class (wrap.cpp:122-350): the compiled mirror and the Python mirror print the
+    same line, and what must be JSON is JSON (two of the reference's summaries end in ", }" -- reproduced, not parsed)."""
+    import json
+    import quake._bindings as qb
+    import quake_amd as qa
+    for name in ("IndexBuildParams", "SearchParams", "SearchTimingInfo", "MaintenancePolicyParams"):
+        a, b = repr(getattr(qb, name)()), repr(getattr(qa, name)())
+        assert a == b, (name, a, b)
+        if not a.endswith(", }"):
+            json.loads(a)
+    assert repr(qb.MaintenancePolicyParams()).endswith('"split_threshold_ns": 10, }')
+    t = qb.SearchTimingInfo()
+    t.parent_info = qb.SearchTimingInfo()
+    assert '"parent_scan_time_ns": 0' in repr(t)
+    bi = qa.BuildTimingInfo()
+    assert bi.code_size == -1 and bi.n_codebooks == -1 and json.loads(repr(bi))["n_codebooks"] == -1
+    assert json.loads(repr(qa.ModifyTimingInfo()))["modify_count"] == 0 and "n_splits" in json.loads(repr(qa.MaintenanceTimingInfo()))
+    for cls in ("BuildTimingInfo", "ModifyTimingInfo", "MaintenanceTimingInfo"):
+        assert hasattr(getattr(qb, cls), "__repr__")
+    assert hasattr(qb.BuildTimingInfo, "code_size") and hasattr(qb.BuildTimingInfo, "n_codebooks")

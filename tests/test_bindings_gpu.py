@@ -33,6 +33,10 @@ def test_bindings_build_search_add_remove_save_load(qb, tmp_path):
     bp.nlist = 12
     info = idx.build(x, ids, bp)
     assert info.n_vectors == 3000 and info.d == 32 and idx.nlist() == 12 and idx.ntotal() == 3000 and idx.parent.ntotal() == 12
+    # the PQ fields of the bound build result (wrap.cpp:332-335) and its one-line summary (wrap.cpp:338-350): a caller printing it
+    assert info.code_size == -1 and info.n_codebooks == -1
+    import json
+    assert json.loads(repr(info))["n_vectors"] == 3000 and '"n_codebooks": -1' in repr(info)
     # search parity with the oracle on the built partitions
     import ctypes as C
     pv, pi = [], []
@@ -46,6 +50,7 @@ def test_bindings_build_search_add_remove_save_load(qb, tmp_path):
     np.testing.assert_array_equal(r.ids.numpy(), gt.indices.numpy())  # nprobe = nlist: exact
     np.testing.assert_allclose(r.distances.numpy(), gt.values.numpy(), atol=1e-4)
     assert r.timing_info.n_queries == 20 and r.timing_info.parent_info is not None
+    assert json.loads(repr(r.timing_info))["n_queries"] == 20 and "parent_scan_time_ns" in repr(r.timing_info)
     e = idx.search(torch.empty(0, 32), sp)
     assert e.ids.numel() == 0
     # add / remove / errors

@@ -257,3 +257,37 @@ def test_random_mutation_streams(ctx, seed):
         check_equal(s, m, d)
         if step % 5 == 4 and m.parts and s.ntotal() > 0:
             _search_equals_oracle(ctx, s, m, d, rng, metric, int(rng.choice([1, 10, 40])))
+
+
+def test_remove_of_an_id_held_many_times(ctx):
+    """The store does not enforce unique ids: a list that holds ONE id many times loses all of those rows when that id is
+    removed -- more row moves than ids asked for.  The staging buffer of the move list is sized for n ids; a longer move list must
+    go through it in chunks, not past its end (round-3 advisor finding: silent arena corruption from ~32 such moves on)."""
+    from quake_amd.capi import Store
+    d = 24
+    rng = np.random.default_rng(5)
+    ivf = make_ivf(3000, d, 3, seed=77)
+    s = Store(ctx, d)
+    s.build_csr(ivf["offsets"], ivf["ids"], ivf["vecs"])
+    m = HostModel(ivf)
+    dup_id = 7_000_000
+    # interleave 400 copies of one id with 400 fresh rows in list 1, so that the sweep swaps rows hundreds of times
+    n = 800
+    v = rng.standard_normal((n, d)).astype(np.float32)
+    ids = np.where(np.arange(n) % 2 == 0, dup_id, 8_000_000 + np.arange(n)).astype(np.int64)
+    s.add_entries(1, ids, v)
+    m.add(1, ids, v)
+    before = s.ntotal()
+    removed = s.remove_ids(np.array([dup_id], np.int64))
+    m.remove([dup_id])
+    assert removed == 400 and s.ntotal() == before - 400
+    check_equal(s, m, d)
+    # the neighbours of the staging buffer's user: the other lists are untouched and the store still searches correctly
+    keys, (vecs, aids, offs) = m.csr(d)
+    q = make_queries(16, d, seed=3, like=ivf["x"])
+    pids = np.tile(np.array(keys, np.int64), (16, 1))
+    gi, gd = ctx.scan(s, q, pids, 10, "l2")
+    oi, od = O.batched_serial_scan(q, vecs, aids, offs, np.tile(np.arange(len(keys), dtype=np.int64), (16, 1)), 10, "l2")
+    np.testing.assert_array_equal(gi, oi)
+    np.testing.assert_array_equal(gd.view(np.uint32), od.view(np.uint32))
+    s.close()
