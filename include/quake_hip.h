@@ -196,10 +196,19 @@ QK_API int qk_ctx_set_squared_l2(qk_ctx *ctx, int enabled);
  * x [n][d], c [m][d]; assign [n] (row index into c, ties -> lower index); val [n] squared L2 / dot (may be NULL). */
 QK_API int qk_kmeans_assign(qk_ctx *ctx, const float *x, int64_t n, const float *c, int64_t m, int d, int metric,
                             int64_t *assign, float *val, int mem);
-/* Update: per-centroid fp32 sums (rows added in ascending row order) and counts
- * (clustering.cpp:162-176 accumulate loop / faiss::Clustering mean update). sums [m][d], counts [m]. */
+/* Update: per-centroid fp32 sums and counts; sums [m][d], counts [m]; rows with an assignment outside [0, m) are ignored.
+ *   qk_kmeans_accumulate          rows added one after the other in ascending row order -- the order of the reference's own
+ *                                 accumulate loop in kmeans_refine_partitions (clustering.cpp:162-176: centroid_sums[c][j] += vec[j]),
+ *                                 what qk_store_refine_lists uses
+ *   qk_kmeans_accumulate_blocked  the mean update of kmeans() (clustering.cpp:51-55 hands it to faiss::Clustering, whose summation
+ *                                 order is its back end's): this library's canonical BLOCKED order -- a centroid's rows in ascending
+ *                                 row order, sequential fp32 sums over consecutive blocks of 32 rows, the block partials summed
+ *                                 sequentially per group of 32 blocks, the group partials summed sequentially (all from +0) -- so
+ *                                 that a large cluster is many independent chains; what qk_kmeans uses */
 QK_API int qk_kmeans_accumulate(qk_ctx *ctx, const float *x, int64_t n, int d, const int64_t *assign, int64_t m,
                                 float *sums, int64_t *counts, int mem);
+QK_API int qk_kmeans_accumulate_blocked(qk_ctx *ctx, const float *x, int64_t n, int d, const int64_t *assign, int64_t m,
+                                        float *sums, int64_t *counts, int mem);
 /* kmeans_refine_partitions() (clustering.cpp:99-182) together with the partition replacement of
  * PartitionManager::refine_partitions (partition_manager.cpp:446-487), applied to the device store: the vectors of the m
  * lists `list_nos` (host array) are re-assigned to the nearest of the m centroids [m][d] (in `mem`; row c = centroid of

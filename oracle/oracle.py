@@ -74,6 +74,7 @@ def lib():
         L.qo_rand_perm.argtypes = [C.c_int64, C.c_int64, C.c_uint64, _i64p]
         L.qo_kmeans_assign.argtypes = [_f32p, C.c_int64, _f32p, C.c_int64, C.c_int, C.c_int, C.c_int, _i64p, _f32p]
         L.qo_kmeans_accumulate.argtypes = [_f32p, C.c_int64, C.c_int, _i64p, C.c_int64, _f32p, _i64p]
+        L.qo_kmeans_accumulate_blocked.argtypes = [_f32p, C.c_int64, C.c_int, _i64p, C.c_int64, _f32p, _i64p]
         L.qo_kmeans_finalize.argtypes = [_f32p, _i64p, C.c_int64, C.c_int, C.c_int, _f32p]
         L.qo_normalize_rows.argtypes = [_f32p, C.c_int64, C.c_int]
         L.qo_kmeans_update.restype = C.c_int
@@ -295,12 +296,15 @@ def kmeans_assign(x, c, metric, num_threads=0):
     return a, v
 
 
-def kmeans_accumulate(x, assign, m):
+def kmeans_accumulate(x, assign, m, blocked=False):
+    """per-centroid sums / counts.  blocked=False: rows added one after the other (the reference's refine loop,
+    clustering.cpp:162-176); True: the blocked canonical order of the k-means driver's mean update (32-row blocks, 32-block
+    groups, groups in order)."""
     x, assign = _f32(x), _i64(assign)
     n, d = x.shape
     sums = np.empty((m, d), np.float32)
     counts = np.empty(m, np.int64)
-    lib().qo_kmeans_accumulate(_pf(x), n, d, _pi(assign), m, _pf(sums), _pi(counts))
+    (lib().qo_kmeans_accumulate_blocked if blocked else lib().qo_kmeans_accumulate)(_pf(x), n, d, _pi(assign), m, _pf(sums), _pi(counts))
     return sums, counts
 
 

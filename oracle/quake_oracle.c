@@ -779,8 +779,9 @@ QO_API void qo_kmeans_assign(const float *x, int64_t n, const float *c, int64_t 
 }
 
 /* update: per-cluster sums (fp32, rows added in ascending row index order) and counts.
- * This is the accumulate loop of kmeans_refine_partitions (clustering.cpp:168-171) and the mean
- * update of faiss::Clustering. */
+ * This is the accumulate loop of kmeans_refine_partitions (clustering.cpp:162-176: `centroid_sums[c][j] += vec[j]`,
+ * row after row) -- the reference's OWN order, followed literally.  (The mean update of kmeans() has no such order
+ * to follow: qo_kmeans_accumulate_blocked below.) */
 QO_API void qo_kmeans_accumulate(const float *x, int64_t n, int d, const int64_t *assign, int64_t m, float *sums,
                                  int64_t *counts) {
     memset(sums, 0, sizeof(float) * (size_t)m * (size_t)d);
@@ -793,6 +794,56 @@ QO_API void qo_kmeans_accumulate(const float *x, int64_t n, int d, const int64_t
         for (int k = 0; k < d; k++) s[k] += v[k];
         counts[a]++;
     }
+}
+
+/* The mean update of kmeans() (clustering.cpp:51-55 hands the iteration to faiss::Clustering, whose summation order is its
+ * back end's -- unlike the refine loop above there is no reference order to follow): the repository's canonical BLOCKED order,
+ * chosen so that a large cluster is many short independent chains on the GPU (k_accumulate_blocked).  With the
+ * rows of a centroid in ascending row order:
+ *   level 1  block  = 32 consecutive rows of the bucket: s = 0; s += x[row] row after row
+ *   level 2  group  = 32 consecutive blocks (1024 rows): run = 0; run += s block after block
+ *   level 3  centroid: tot = 0; tot += run group after group
+ * Rows with an assignment outside [0, m) are ignored. */
+#define QO_KM_L1 32
+#define QO_KM_L2 32
+QO_API void qo_kmeans_accumulate_blocked(const float *x, int64_t n, int d, const int64_t *assign, int64_t m, float *sums,
+                                         int64_t *counts) {
+    memset(sums, 0, sizeof(float) * (size_t)m * (size_t)d);
+    memset(counts, 0, sizeof(int64_t) * (size_t)m);
+    for (int64_t i = 0; i < n; i++)
+        if (assign[i] >= 0 && assign[i] < m) counts[assign[i]]++;
+    int64_t *begin = (int64_t *)malloc(sizeof(int64_t) * (size_t)(m + 1));
+    begin[0] = 0;
+    for (int64_t c = 0; c < m; c++) begin[c + 1] = begin[c] + counts[c];
+    int64_t *rows = (int64_t *)malloc(sizeof(int64_t) * (size_t)(begin[m] > 0 ? begin[m] : 1));
+    int64_t *cur = (int64_t *)malloc(sizeof(int64_t) * (size_t)m);
+    memcpy(cur, begin, sizeof(int64_t) * (size_t)m);
+    for (int64_t i = 0; i < n; i++) /* ascending row order inside every bucket */
+        if (assign[i] >= 0 && assign[i] < m) rows[cur[assign[i]]++] = i;
+    float *s = (float *)malloc(sizeof(float) * (size_t)d * 2);
+    float *run = s + d;
+    for (int64_t c = 0; c < m; c++) {
+        float *tot = sums + c * d;
+        const int64_t b = begin[c], e = begin[c + 1];
+        for (int64_t g0 = b; g0 < e; g0 += (int64_t)QO_KM_L1 * QO_KM_L2) {
+            const int64_t g1 = g0 + (int64_t)QO_KM_L1 * QO_KM_L2 < e ? g0 + (int64_t)QO_KM_L1 * QO_KM_L2 : e;
+            for (int k = 0; k < d; k++) run[k] = 0.0f;
+            for (int64_t b0 = g0; b0 < g1; b0 += QO_KM_L1) {
+                const int64_t b1 = b0 + QO_KM_L1 < g1 ? b0 + QO_KM_L1 : g1;
+                for (int k = 0; k < d; k++) s[k] = 0.0f;
+                for (int64_t r = b0; r < b1; r++) {
+                    const float *v = x + rows[r] * d;
+                    for (int k = 0; k < d; k++) s[k] += v[k];
+                }
+                for (int k = 0; k < d; k++) run[k] += s[k];
+            }
+            for (int k = 0; k < d; k++) tot[k] += run[k];
+        }
+    }
+    free(s);
+    free(cur);
+    free(rows);
+    free(begin);
 }
 
 /* centroids = sums / counts (clustering.cpp:122-124: float division by the count; count 0 -> NaN there;
@@ -874,7 +925,7 @@ QO_API void qo_kmeans(float *x, int64_t n, int d, int64_t m, int metric, int nit
     int64_t *ta = (int64_t *)malloc(sizeof(int64_t) * (size_t)ntrain);
     for (int it = 0; it < niter; it++) {
         qo_kmeans_assign(xt, ntrain, centroids, m, d, metric, num_threads, ta, NULL);
-        qo_kmeans_accumulate(xt, ntrain, d, ta, m, sums, counts);
+        qo_kmeans_accumulate_blocked(xt, ntrain, d, ta, m, sums, counts);
         qo_kmeans_finalize(sums, counts, m, d, 1, centroids);
         split_empty(centroids, counts, m, d);
     }

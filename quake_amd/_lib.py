@@ -77,6 +77,7 @@ SIGNATURES = {
     "qk_merge_topk_packed": (_int, [_vp, _vp, _int, _i64, _int, _int, _vp, _vp]),
     "qk_kmeans_assign": (_int, [_vp, _vp, _i64, _vp, _i64, _int, _int, _vp, _vp, _int]),
     "qk_kmeans_accumulate": (_int, [_vp, _vp, _i64, _int, _vp, _i64, _vp, _vp, _int]),
+    "qk_kmeans_accumulate_blocked": (_int, [_vp, _vp, _i64, _int, _vp, _i64, _vp, _vp, _int]),
     "qk_store_refine_lists": (_int, [_vp, _vp, _i64, _vp, _int, _int, _int]),
     "qk_kmeans": (_int, [_vp, _vp, _i64, _int, _i64, _int, _int, C.c_uint64, _vp, _vp, _int]),
     "qk_normalize_rows": (_int, [_vp, _vp, _i64, _int, _int]),

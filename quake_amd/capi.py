@@ -250,13 +250,16 @@ class Context:
         check(self.lib.qk_kmeans_assign(self.h, _ptr(x), n, _ptr(c), c.shape[0], d, metric_code(metric), _ptr(a), _ptr(v), mem))
         return a, v
 
-    def kmeans_accumulate(self, x, assign, m):
+    def kmeans_accumulate(self, x, assign, m, blocked=False):
+        """per-centroid sums and counts.  blocked=False: rows added one after the other (the reference's refine loop,
+        clustering.cpp:162-176); True: the blocked canonical order of the Lloyd driver (qk_kmeans_accumulate_blocked)."""
         x, assign = _f32(x), _i64(assign)
         n, d = x.shape
         mem = _mem_of(x, assign)
         sums = _empty_like_mem((m, d), np.float32, x)
         counts = _empty_like_mem((m,), np.int64, x)
-        check(self.lib.qk_kmeans_accumulate(self.h, _ptr(x), n, d, _ptr(assign), m, _ptr(sums), _ptr(counts), mem))
+        fn = self.lib.qk_kmeans_accumulate_blocked if blocked else self.lib.qk_kmeans_accumulate
+        check(fn(self.h, _ptr(x), n, d, _ptr(assign), m, _ptr(sums), _ptr(counts), mem))
         return sums, counts
 
     def normalize_rows(self, x):

@@ -208,12 +208,17 @@ __global__ __launch_bounds__(256) void k_assign(AssignParams P) {
 }
 
 // ---- update -------------------------------------------------------------------------------------------------
-// Stable bucketing of the rows by assignment: a least-significant-digit pass per 8 bits of the centroid number (1 pass up to
-// 255 centroids, 2 up to 65535, 3 beyond), each pass = digit histogram per workgroup tile, one exclusive scan over
-// [digit][tile], stable scatter.  The first pass reads the assignments themselves (key = assignment, value = row number), so
-// no key / value arrays are materialised before it.  Rows whose assignment is out of range get key m: they sort behind every
-// centroid and are ignored.
-constexpr int RS_THREADS = 256, RS_ITEMS = 16, RS_TILE = RS_THREADS * RS_ITEMS;
+// Stable bucketing of the rows by assignment: least-significant-digit passes of RS_BITS bits of the centroid number (12 bits per pass:
+// ONE pass up to 4094 centroids, two up to 2^24; 8 bits when the numbers fit), each pass = digit histogram per chunk of rows, one
+// exclusive scan over [chunk][digit], stable scatter.  The unit of work is a WAVE: it owns RS_WAVE_ROWS(n) consecutive rows, counts
+// and places them with wave-private LDS counters -- a key's place among the equal digits of its 64-row round comes from RS_BITS
+// ballots -- so the passes hold no workgroup barrier in their loops (the first version of round 3 ranked 256 keys per round across
+// the four waves of a workgroup: three barriers per round, 35-48 us per pass for 2^20 keys).  The four waves of a workgroup share
+// one row of the table: the scatter re-counts the chunk (the keys come back from L2) to find each wave's offset inside it, which
+// keeps the table at 2^RS_BITS * n / (4 * wave rows) entries.  The first pass reads the assignments themselves (key = assignment,
+// value = row number), so no key / value arrays are materialised before it.  Rows whose assignment is out of range get key m: they
+// sort behind every centroid and are ignored.
+constexpr int RS_THREADS = 256, RS_WAVES = 4;
 
 template <bool FIRST>
 __device__ __forceinline__ int32_t rs_key(const int64_t *__restrict__ assign, const int32_t *__restrict__ keys_in, int64_t i, int m) {
@@ -224,112 +229,141 @@ __device__ __forceinline__ int32_t rs_key(const int64_t *__restrict__ assign, co
     return keys_in[i];
 }
 
-template <bool FIRST>
-__global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const int64_t *__restrict__ assign, const int32_t *__restrict__ keys_in, int64_t n,
-                                                        int m, int shift, int32_t *__restrict__ hist /*[256][tiles]*/, int tiles,
-                                                        int32_t *__restrict__ totals /*[256], zeroed*/) {
-    __shared__ int32_t h[256];
-    h[threadIdx.x] = 0;
-    __syncthreads();
-    const int64_t i0 = (int64_t)blockIdx.x * RS_TILE + threadIdx.x;
-#pragma unroll 4
-    for (int it = 0; it < RS_ITEMS; it++) {
-        const int64_t i = i0 + (int64_t)it * RS_THREADS;
-        if (i < n) atomicAdd(&h[(rs_key<FIRST>(assign, keys_in, i, m) >> shift) & 255], 1);
-    }
-    __syncthreads();
-    hist[(int64_t)threadIdx.x * tiles + blockIdx.x] = h[threadIdx.x];
-    if (h[threadIdx.x]) atomicAdd(&totals[threadIdx.x], h[threadIdx.x]);
+struct RsPass {
+    const int64_t *assign;    // FIRST pass: the assignments
+    const int32_t *keys_in;   // later passes: keys / values of the previous pass
+    const int32_t *vals_in;
+    int64_t n;
+    int m, shift;
+    int wave_rows;            // rows per wave (multiple of 64); a workgroup's chunk = 4 * wave_rows consecutive rows
+    int nchunks;              // workgroups
+    int32_t *table;           // [nchunks][1 << BITS]: counts, then (after k_rs_scan) the first output position of (chunk, digit)
+    int32_t *totals;          // [1 << BITS], zeroed before k_rs_hist
+    int32_t *keys_out;        // may be null on the last pass
+    int32_t *vals_out;
+    int64_t *dbase_out;       // k_rs_scan: first output position of every digit ([1 << BITS], may be null) -- with a single pass
+                              // these ARE the segment bounds of the centroids
+};
+
+// digit counts of this wave's rows into its private LDS row hw[1 << BITS] (zeroed here)
+template <int BITS, bool FIRST>
+__device__ __forceinline__ void rs_count_wave(const RsPass &P, int32_t *hw, int64_t r0, int64_t r1, int lane) {
+    constexpr int NB = 1 << BITS;
+    for (int i = lane; i < NB; i += 64) hw[i] = 0;
+    __builtin_amdgcn_wave_barrier();
+    for (int64_t i = r0 + lane; i < r1; i += 64) atomicAdd(&hw[(rs_key<FIRST>(P.assign, P.keys_in, i, P.m) >> P.shift) & (NB - 1)], 1);
+    __builtin_amdgcn_wave_barrier();
 }
 
-// exclusive scan over [digit][tile] in place: workgroup d owns the row of digit d -- its base is the sum of the digit totals below
-// it (k_rs_hist adds them up with one atomic per digit and tile), the row itself goes through in chunks of 256 coalesced entries
-__global__ __launch_bounds__(256) void k_rs_scan(int32_t *__restrict__ hist, int tiles, const int32_t *__restrict__ totals) {
-    __shared__ int32_t s_wave[4];
-    __shared__ int32_t s_base;
-    const int d = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    {
-        int32_t v = tid < d ? totals[tid] : 0;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-        if (lane == 0) s_wave[wave] = v;
-        __syncthreads();
-        if (tid == 0) s_base = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
-        __syncthreads();
-    }
-    int32_t run = s_base;
-    int32_t *row = hist + (int64_t)d * tiles;
-    for (int c0 = 0; c0 < tiles; c0 += 256) {
-        const int i = c0 + tid;
-        const int32_t v = i < tiles ? row[i] : 0;
-        int32_t inc = v;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int32_t u = __shfl_up(inc, o);
-            if (lane >= o) inc += u;
-        }
-        __syncthreads();  // (s_wave of the previous chunk has been read)
-        if (lane == 63) s_wave[wave] = inc;
-        __syncthreads();
-        int32_t wpre = 0, tot = 0;
-#pragma unroll
-        for (int w = 0; w < 4; w++) {
-            if (w < wave) wpre += s_wave[w];
-            tot += s_wave[w];
-        }
-        if (i < tiles) row[i] = run + wpre + inc - v;
-        run += tot;
-    }
-}
-
-// stable scatter of one tile: rounds of 256 keys in index order; inside a round a key's place among the equal digits is (equal
-// digits in lower waves) + (equal digits in lower lanes of its wave, found with 8 ballots)
-template <bool FIRST>
-__global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const int64_t *__restrict__ assign, const int32_t *__restrict__ keys_in,
-                                                           const int32_t *__restrict__ vals_in, int64_t n, int m, int shift,
-                                                           const int32_t *__restrict__ hist, int tiles, int32_t *__restrict__ keys_out,
-                                                           int32_t *__restrict__ vals_out) {
-    __shared__ int32_t base[256];
-    __shared__ int32_t cnt[4][256];
-    base[threadIdx.x] = hist[(int64_t)threadIdx.x * tiles + blockIdx.x];
-#pragma unroll
-    for (int w = 0; w < 4; w++) cnt[w][threadIdx.x] = 0;
-    __syncthreads();
+template <int BITS, bool FIRST>
+__global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const RsPass P) {
+    constexpr int NB = 1 << BITS;
+    extern __shared__ int32_t rs_lds[];  // [4][NB]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t r0 = ((int64_t)blockIdx.x * RS_WAVES + wave) * P.wave_rows, r1 = min(P.n, r0 + P.wave_rows);
+    rs_count_wave<BITS, FIRST>(P, rs_lds + wave * NB, r0, r1, lane);
+    __syncthreads();
+    for (int i = threadIdx.x; i < NB; i += RS_THREADS) {
+        const int32_t v = rs_lds[i] + rs_lds[NB + i] + rs_lds[2 * NB + i] + rs_lds[3 * NB + i];
+        P.table[(int64_t)blockIdx.x * NB + i] = v;
+        if (v) atomicAdd(&P.totals[i], v);
+    }
+}
+
+// exclusive scan over [chunk][digit] in place, digit-major order (all chunks of digit 0, then digit 1, ...): workgroup g owns the
+// 64 digits 64g .. 64g+63 -- their bases are the sums of the digit totals below them (k_rs_hist added those up with one atomic per
+// non-empty (chunk, digit)) -- and walks the chunks in four contiguous quarters (thread = (quarter, digit): 64 consecutive digits
+// of one chunk are one coalesced 256-byte read)
+template <int BITS>
+__global__ __launch_bounds__(256) void k_rs_scan(const RsPass P) {
+    constexpr int NB = 1 << BITS;
+    __shared__ int32_t s_part[4];
+    __shared__ int32_t s_q[4][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int dg0 = blockIdx.x * 64;
+    int32_t below = 0;  // totals of the digits under dg0
+    for (int i = tid; i < dg0; i += 256) below += P.totals[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) below += __shfl_xor(below, o);
+    if (lane == 0) s_part[wave] = below;
+    __syncthreads();
+    const int32_t base0 = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+    // exclusive prefix of this workgroup's 64 digit totals (every wave computes it: lane = digit)
+    const int32_t tot = P.totals[dg0 + lane];
+    int32_t inc = tot;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int32_t u = __shfl_up(inc, o);
+        if (lane >= o) inc += u;
+    }
+    const int32_t dbase = base0 + inc - tot;
+    if (wave == 0 && P.dbase_out) P.dbase_out[dg0 + lane] = dbase;
+    // quarter `wave` of the chunks
+    const int per = (P.nchunks + 3) / 4, c0 = min(P.nchunks, wave * per), c1 = min(P.nchunks, c0 + per);
+    int32_t *col = P.table + dg0 + lane;
+    int32_t qs = 0;
+#pragma unroll 8
+    for (int c = c0; c < c1; c++) qs += col[(int64_t)c * NB];
+    s_q[wave][lane] = qs;
+    __syncthreads();
+    int32_t run = dbase;
+    for (int w = 0; w < wave; w++) run += s_q[w][lane];
+#pragma unroll 8
+    for (int c = c0; c < c1; c++) {
+        const int32_t v = col[(int64_t)c * NB];
+        col[(int64_t)c * NB] = run;
+        run += v;
+    }
+}
+
+// stable scatter: the workgroup re-counts its chunk per wave (the waves' offsets inside the chunk's table row), then every wave
+// places its rows in rounds of 64 in index order
+template <int BITS, bool FIRST>
+__global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const RsPass P) {
+    constexpr int NB = 1 << BITS;
+    extern __shared__ int32_t rs_lds[];  // [4][NB]: counts, then running output positions per wave
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t r0 = ((int64_t)blockIdx.x * RS_WAVES + wave) * P.wave_rows, r1 = min(P.n, r0 + P.wave_rows);
+    rs_count_wave<BITS, FIRST>(P, rs_lds + wave * NB, r0, r1, lane);
+    __syncthreads();
+    for (int i = threadIdx.x; i < NB; i += RS_THREADS) {
+        int32_t at = P.table[(int64_t)blockIdx.x * NB + i];
+#pragma unroll
+        for (int w = 0; w < RS_WAVES; w++) {
+            const int32_t c = rs_lds[w * NB + i];
+            rs_lds[w * NB + i] = at;
+            at += c;
+        }
+    }
+    __syncthreads();
+    int32_t *pos = rs_lds + wave * NB;
     const uint64_t lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
-    const int64_t i0 = (int64_t)blockIdx.x * RS_TILE + threadIdx.x;
-    for (int it = 0; it < RS_ITEMS; it++) {
-        const int64_t i = i0 + (int64_t)it * RS_THREADS;
-        const bool valid = i < n;
+    for (int64_t i0 = r0; i0 < r1; i0 += 64) {
+        const int64_t i = i0 + lane;
+        const bool valid = i < r1;
         int32_t key = 0, val = 0;
         if (valid) {
-            key = rs_key<FIRST>(assign, keys_in, i, m);
-            val = FIRST ? (int32_t)i : vals_in[i];
+            key = rs_key<FIRST>(P.assign, P.keys_in, i, P.m);
+            val = FIRST ? (int32_t)i : P.vals_in[i];
         }
-        const int digit = (key >> shift) & 255;
+        const int digit = (key >> P.shift) & (NB - 1);
         uint64_t peers = __ballot(valid);
 #pragma unroll
-        for (int b = 0; b < 8; b++) {
+        for (int b = 0; b < BITS; b++) {
             const bool bit = (digit >> b) & 1;
             const uint64_t bal = __ballot(valid && bit);
             peers &= bit ? bal : ~bal;
         }
         const int rank = __popcll(peers & lt);
-        if (valid && rank == 0) cnt[wave][digit] = __popcll(peers);
-        __syncthreads();
+        int at = 0;
+        if (valid) at = pos[digit] + rank;
+        __builtin_amdgcn_wave_barrier();
+        if (valid && rank == 0) pos[digit] += __popcll(peers);  // (one lane per distinct digit of the round)
+        __builtin_amdgcn_wave_barrier();
         if (valid) {
-            int at = base[digit] + rank;
-            for (int w = 0; w < wave; w++) at += cnt[w][digit];
-            keys_out[at] = key;
-            vals_out[at] = val;
+            if (P.keys_out) P.keys_out[at] = key;
+            P.vals_out[at] = val;
         }
-        __syncthreads();
-        {
-            const int t = threadIdx.x;
-            base[t] += cnt[0][t] + cnt[1][t] + cnt[2][t] + cnt[3][t];
-            cnt[0][t] = cnt[1][t] = cnt[2][t] = cnt[3][t] = 0;
-        }
-        __syncthreads();
     }
 }
 
@@ -342,10 +376,12 @@ __global__ void k_segment_bounds(const int32_t *__restrict__ sorted_keys, int64_
     for (int c = prev + 1; c <= cur; c++) seg_begin[c] = i;
 }
 
-// one workgroup per centroid; thread t owns dimensions t, t + blockDim, ...; rows are added in ascending row order (one dependent
-// chain of adds per (centroid, dimension): the order of the reference loop).  The kernel lasts as long as its largest cluster's
-// chain, so what counts is the time per row of ONE workgroup: 32 rows per round trip, the row numbers of the next 32 requested with
-// them (8 rows per trip, row numbers fetched first: 0.60 ms for 2^20 rows in 4096 skewed clusters; now 0.39).
+// REFERENCE ORDER (kmeans_refine_partitions' own accumulate loop, clustering.cpp:162-176: `centroid_sums[c][j] += vec[j]` row after
+// row): one workgroup per centroid; thread t owns dimensions t, t + blockDim, ...; rows are added in ascending row order -- one
+// dependent chain of adds per (centroid, dimension).  The kernel lasts as long as its largest cluster's chain, so what counts is the
+// time per row of ONE workgroup: 32 rows per round trip, the row numbers of the next 32 requested with them.  Used where the
+// reference fixes the order (qk_kmeans_accumulate, qk_store_refine_lists); the Lloyd driver, whose order FAISS leaves open, takes
+// k_accumulate_blocked below.
 __global__ __launch_bounds__(256) void k_accumulate(const float *__restrict__ x, int d, const int32_t *__restrict__ sorted_rows,
                                                     const int64_t *__restrict__ seg_begin, float *__restrict__ sums,
                                                     int64_t *__restrict__ counts) {
@@ -382,6 +418,118 @@ __global__ __launch_bounds__(256) void k_accumulate(const float *__restrict__ x,
             for (int j = 0; j < U; j++) r[j] = rn[j];
         }
         sums[(int64_t)c * d + k] = s;
+    }
+}
+
+// BLOCKED ORDER -- the canonical summation order of the Lloyd driver's mean update (faiss::Clustering leaves it to its back end:
+// clustering.cpp:51-55 hands the whole iteration to FAISS; qo_kmeans_accumulate_blocked is the same order on the host).  With the
+// rows of a centroid in ascending row order r_0 < r_1 < ...:
+//   level 1  a BLOCK is KM_L1 = 32 consecutive rows of the bucket; its partial is the sequential fp32 sum  ((0 + x[r_0]) + x[r_1]) + ...
+//   level 2  a GROUP is KM_L2 = 32 consecutive blocks (1024 rows); its partial is the sequential sum of its block partials, from 0
+//   level 3  the centroid's sum is the sequential sum of its group partials, from 0
+// so the longest dependent chain is 32 + 32 + n_c / 1024 adds instead of n_c, and the blocks of one centroid are independent work.
+// Grid (m, KM_GLANES): workgroup (c, j) takes the groups j, j + KM_GLANES, ... of centroid c (most centroids have one); inside a
+// group `NCH = 256 / TPC` blocks run side by side (TPC threads per block chain, one float4 -- or one float when d % 4 != 0 -- of the
+// row per thread), and after each such round the chain-0 threads fold the round's partials in block order.  A centroid with several
+// groups leaves the group partials in `gpart` and its last workgroup to arrive (ticket) folds them in group order.
+constexpr int KM_L1 = 32, KM_L2 = 32, KM_GROUP = KM_L1 * KM_L2, KM_GLANES = 8;
+
+template <typename V>
+__device__ __forceinline__ V km_zero();
+template <>
+__device__ __forceinline__ float km_zero<float>() { return 0.0f; }
+template <>
+__device__ __forceinline__ float4 km_zero<float4>() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ float km_add(float a, float b) { return a + b; }
+__device__ __forceinline__ float4 km_add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float km_ld_agent(const float *p) {
+    return __uint_as_float(__hip_atomic_load((const uint32_t *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ float4 km_ld_agent(const float4 *p) {
+    const float *f = (const float *)p;
+    return make_float4(km_ld_agent(f), km_ld_agent(f + 1), km_ld_agent(f + 2), km_ld_agent(f + 3));
+}
+// gpart slot of group g of the centroid whose bucket starts at row b: distinct for all (centroid, group) pairs
+__device__ __host__ __forceinline__ int64_t km_gslot(int64_t b, int64_t c, int64_t g) { return b / KM_GROUP + c + g; }
+
+template <typename V>  // V = float4 (d % 4 == 0) or float; `units` = d / 4 or d elements of V per row
+__global__ __launch_bounds__(256) void k_accumulate_blocked(const V *__restrict__ x, int units, const int32_t *__restrict__ sorted_rows,
+                                                            const int64_t *__restrict__ seg_begin, V *__restrict__ sums,
+                                                            int64_t *__restrict__ counts, V *__restrict__ gpart,
+                                                            unsigned int *__restrict__ tickets) {
+    __shared__ V s_part[256];
+    __shared__ int s_last;
+    const int c = blockIdx.x, gl = blockIdx.y, tid = threadIdx.x;
+    const int64_t b = seg_begin[c], e = seg_begin[c + 1], nc = e - b;
+    const int64_t G = (nc + KM_GROUP - 1) / KM_GROUP;  // groups of this centroid
+    if (gl == 0 && tid == 0) counts[c] = nc;
+    if (nc == 0) {
+        if (gl == 0)
+            for (int u = tid; u < units; u += 256) sums[(int64_t)c * units + u] = km_zero<V>();
+        return;
+    }
+    if (gl >= G) return;
+    const int TPC = min(units, 256), NCH = 256 / TPC;  // threads per chain, chains side by side
+    const int cs = tid / TPC, j = tid - cs * TPC;
+    const bool chain = cs < NCH;
+    for (int u0 = 0; u0 < units; u0 += TPC) {  // (one trip unless a row is wider than 256 units)
+        const int u = u0 + j;
+        const bool live = chain && u < units;
+        for (int64_t g = gl; g < G; g += KM_GLANES) {
+            const int64_t gb = b + g * KM_GROUP, ge = min(e, gb + KM_GROUP);
+            const int nb = (int)((ge - gb + KM_L1 - 1) / KM_L1);
+            V run = km_zero<V>();
+            for (int b0 = 0; b0 < nb; b0 += NCH) {
+                const int blk = b0 + cs;
+                if (live && blk < nb) {
+                    const int64_t rb = gb + (int64_t)blk * KM_L1;
+                    const int cnt = (int)min((int64_t)KM_L1, ge - rb);
+                    int32_t r[KM_L1];
+#pragma unroll
+                    for (int t = 0; t < KM_L1; t++) r[t] = sorted_rows[min(rb + t, ge - 1)];
+                    V v[KM_L1];
+#pragma unroll
+                    for (int t = 0; t < KM_L1; t++) v[t] = x[(int64_t)r[t] * units + u];
+                    V s = km_zero<V>();
+                    if (cnt == KM_L1) {
+#pragma unroll
+                        for (int t = 0; t < KM_L1; t++) s = km_add(s, v[t]);
+                    } else {
+#pragma unroll
+                        for (int t = 0; t < KM_L1; t++) s = t < cnt ? km_add(s, v[t]) : s;
+                    }
+                    s_part[tid] = s;
+                }
+                __syncthreads();
+                if (cs == 0 && u < units) {
+                    const int lim = min(NCH, nb - b0);
+                    for (int t = 0; t < lim; t++) run = km_add(run, s_part[t * TPC + j]);
+                }
+                __syncthreads();
+            }
+            if (cs == 0 && u < units) {
+                if (G == 1) sums[(int64_t)c * units + u] = run;
+                else gpart[km_gslot(b, c, g) * units + u] = run;
+            }
+        }
+    }
+    if (G == 1) return;
+    // several groups: the last workgroup of the centroid to arrive adds the group partials in group order
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned int lanes = (unsigned int)min((int64_t)KM_GLANES, G);
+        const unsigned int t = atomicAdd(&tickets[c], 1u);
+        s_last = t == lanes - 1 ? 1 : 0;
+        if (s_last) tickets[c] = 0;  // (zero between launches)
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    for (int u = tid; u < units; u += 256) {
+        V tot = km_zero<V>();
+        for (int64_t g = 0; g < G; g++) tot = km_add(tot, km_ld_agent(&gpart[km_gslot(b, c, g) * units + u]));
+        sums[(int64_t)c * units + u] = tot;
     }
 }
 
@@ -499,66 +647,118 @@ static int assign_device(qk_ctx *ctx, const float *x, int64_t n, const float *c,
 }
 
 struct AccumScratch {
-    int32_t *keys = nullptr, *vals = nullptr, *keys2 = nullptr, *vals2 = nullptr;
-    int64_t *seg = nullptr;
-    void *tmp = nullptr;
-    size_t tmp_bytes = 0;
+    int32_t *keys = nullptr, *vals = nullptr, *keys2 = nullptr, *vals2 = nullptr;  // (keys2, vals2) hold the bucketed rows
+    int64_t *seg = nullptr;        // [max(m + 2, 4097)] segment bounds of the centroids in vals2
+    int32_t *table = nullptr;      // [nchunks][1 << bits] + [1 << bits] digit totals
+    float *gpart = nullptr;        // group partials of the blocked order: [n / KM_GROUP + m + 2][d]
+    unsigned int *tickets = nullptr;  // [m], zero between launches
+    int wave_rows = 0, nchunks = 0, bits = 0, passes = 0;
 };
 
-static int accum_prepare(KmScratch &ks, AccumScratch &as, int64_t n, int64_t m) {
-    QK_TRY(ks.alloc(&as.keys, (size_t)n));
-    QK_TRY(ks.alloc(&as.vals, (size_t)n));
-    QK_TRY(ks.alloc(&as.keys2, (size_t)n));
+static void rs_plan(int64_t n, int64_t m, AccumScratch &as) {
+    int kb = 1;
+    while ((1LL << kb) <= m) kb++;  // the keys are 0 .. m (m = out of range)
+    as.bits = kb <= 8 ? 8 : 12;
+    as.passes = (kb + as.bits - 1) / as.bits;
+    // a wave's share: 1024 rows, more once the table would pass ~64 MB
+    int64_t wr = 1024;
+    while (((n + 4 * wr - 1) / (4 * wr)) * ((int64_t)4 << as.bits) > ((int64_t)64 << 20)) wr *= 2;
+    as.wave_rows = (int)wr;
+    as.nchunks = (int)std::max<int64_t>(1, (n + 4 * wr - 1) / (4 * wr));
+}
+
+static int accum_prepare(KmScratch &ks, AccumScratch &as, int64_t n, int64_t m, int d) {
+    rs_plan(n, m, as);
     QK_TRY(ks.alloc(&as.vals2, (size_t)n));
-    QK_TRY(ks.alloc(&as.seg, (size_t)m + 2));
-    const size_t tiles = (size_t)((n + RS_TILE - 1) / RS_TILE);
-    int32_t *t = nullptr;
-    QK_TRY(ks.alloc(&t, 256 * tiles + 256 + 64));  // [digit][tile] counters of one pass, then the 256 digit totals
-    as.tmp = t;
-    as.tmp_bytes = (256 * tiles + 256 + 64) * sizeof(int32_t);
+    if (as.passes > 1) {
+        QK_TRY(ks.alloc(&as.keys, (size_t)n));
+        QK_TRY(ks.alloc(&as.vals, (size_t)n));
+        QK_TRY(ks.alloc(&as.keys2, (size_t)n));
+    }
+    QK_TRY(ks.alloc(&as.seg, (size_t)std::max<int64_t>(m + 2, ((int64_t)1 << as.bits) + 1)));
+    QK_TRY(ks.alloc(&as.table, ((size_t)as.nchunks + 1) << as.bits));
+    QK_TRY(ks.alloc(&as.gpart, (size_t)(n / KM_GROUP + m + 2) * d));
+    QK_TRY(ks.alloc(&as.tickets, (size_t)m));
+    QK_HIP(hipMemset(as.tickets, 0, (size_t)m * sizeof(unsigned int)));
     return QK_OK;
 }
 
-// rows bucketed stably by assignment into (as.keys2, as.vals2): ceil(bits(m) / 8) passes of histogram / scan / scatter
+template <int BITS>
+static int rs_pass_launch(hipStream_t st, const RsPass &P, bool first) {
+    constexpr size_t lds = (size_t)RS_WAVES * sizeof(int32_t) << BITS;
+    static bool attr_set = false;
+    if (!attr_set) {
+        QK_HIP(hipFuncSetAttribute((const void *)k_rs_hist<BITS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        QK_HIP(hipFuncSetAttribute((const void *)k_rs_hist<BITS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        QK_HIP(hipFuncSetAttribute((const void *)k_rs_scatter<BITS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        QK_HIP(hipFuncSetAttribute((const void *)k_rs_scatter<BITS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    QK_HIP(hipMemsetAsync(P.totals, 0, sizeof(int32_t) << BITS, st));
+    const dim3 grid((unsigned)P.nchunks), block(RS_THREADS);
+    if (first) hipLaunchKernelGGL((k_rs_hist<BITS, true>), grid, block, lds, st, P);
+    else hipLaunchKernelGGL((k_rs_hist<BITS, false>), grid, block, lds, st, P);
+    hipLaunchKernelGGL((k_rs_scan<BITS>), dim3((1u << BITS) / 64), dim3(256), 0, st, P);
+    if (first) hipLaunchKernelGGL((k_rs_scatter<BITS, true>), grid, block, lds, st, P);
+    else hipLaunchKernelGGL((k_rs_scatter<BITS, false>), grid, block, lds, st, P);
+    QK_HIP(hipGetLastError());
+    return QK_OK;
+}
+
+// rows bucketed stably by assignment into as.vals2 (row numbers; as.keys2 holds their keys when there are several passes) and the
+// segment bounds of the centroids into as.seg
 static int bucket_rows_device(hipStream_t st, AccumScratch &as, const int64_t *assign, int64_t n, int64_t m) {
-    int bits = 1;
-    while ((1LL << bits) <= m) bits++;
-    const int passes = (bits + 7) / 8;
-    const int tiles = (int)((n + RS_TILE - 1) / RS_TILE);
-    int32_t *hist = (int32_t *)as.tmp;
+    RsPass P;
+    P.assign = assign;
+    P.n = n;
+    P.m = (int)m;
+    P.wave_rows = as.wave_rows;
+    P.nchunks = as.nchunks;
+    P.table = as.table;
+    P.totals = as.table + ((size_t)as.nchunks << as.bits);
     // the last pass must land in (keys2, vals2): with an odd number of passes the first one writes there
-    int32_t *ko = (passes & 1) ? as.keys2 : as.keys, *vo = (passes & 1) ? as.vals2 : as.vals;
+    int32_t *ko = (as.passes & 1) ? as.keys2 : as.keys, *vo = (as.passes & 1) ? as.vals2 : as.vals;
     const int32_t *ki = nullptr, *vi = nullptr;
-    int32_t *totals = hist + (size_t)256 * tiles;
-    for (int p = 0; p < passes; p++) {
-        const int shift = 8 * p;
-        QK_HIP(hipMemsetAsync(totals, 0, 256 * sizeof(int32_t), st));
-        if (p == 0)
-            hipLaunchKernelGGL(k_rs_hist<true>, dim3((unsigned)tiles), dim3(RS_THREADS), 0, st, assign, ki, n, (int)m, shift, hist, tiles, totals);
-        else
-            hipLaunchKernelGGL(k_rs_hist<false>, dim3((unsigned)tiles), dim3(RS_THREADS), 0, st, assign, ki, n, (int)m, shift, hist, tiles, totals);
-        hipLaunchKernelGGL(k_rs_scan, dim3(256), dim3(256), 0, st, hist, tiles, totals);
-        if (p == 0)
-            hipLaunchKernelGGL(k_rs_scatter<true>, dim3((unsigned)tiles), dim3(RS_THREADS), 0, st, assign, ki, vi, n, (int)m, shift, hist, tiles, ko, vo);
-        else
-            hipLaunchKernelGGL(k_rs_scatter<false>, dim3((unsigned)tiles), dim3(RS_THREADS), 0, st, assign, ki, vi, n, (int)m, shift, hist, tiles, ko, vo);
+    for (int p = 0; p < as.passes; p++) {
+        P.keys_in = ki;
+        P.vals_in = vi;
+        P.shift = as.bits * p;
+        P.keys_out = as.passes > 1 ? ko : nullptr;
+        P.vals_out = vo;
+        P.dbase_out = as.passes == 1 ? as.seg : nullptr;  // one pass: the digit bases are the segment bounds
+        if (as.bits == 8) QK_TRY(rs_pass_launch<8>(st, P, p == 0));
+        else QK_TRY(rs_pass_launch<12>(st, P, p == 0));
         ki = ko;
         vi = vo;
         ko = ko == as.keys ? as.keys2 : as.keys;
         vo = vo == as.vals ? as.vals2 : as.vals;
     }
+    if (as.passes > 1) hipLaunchKernelGGL(k_segment_bounds, dim3(km_grid(n + 1, 256)), dim3(256), 0, st, as.keys2, n, (int)m, as.seg);
     QK_HIP(hipGetLastError());
     return QK_OK;
 }
 
+// blocked = false: the reference's row-after-row order (k_accumulate); true: the blocked canonical order of the Lloyd driver
 static int accumulate_device(qk_ctx *ctx, AccumScratch &as, const float *x, int64_t n, int d, const int64_t *assign, int64_t m,
-                             float *sums, int64_t *counts) {
+                             float *sums, int64_t *counts, bool blocked) {
     hipStream_t st = ctx->stream;
     if (n > 0x7FFFFFF0LL) QK_FAIL(QK_ERR_UNSUPPORTED, "qk_kmeans_accumulate: n too large for 32-bit row indices");
     if (m > 0x7FFFFFF0LL) QK_FAIL(QK_ERR_UNSUPPORTED, "qk_kmeans_accumulate: too many centroids for 32-bit keys");
-    if (n > 0) QK_TRY(bucket_rows_device(st, as, assign, n, m));
-    hipLaunchKernelGGL(k_segment_bounds, dim3(km_grid(n + 1, 256)), dim3(256), 0, st, as.keys2, n, (int)m, as.seg);
-    hipLaunchKernelGGL(k_accumulate, dim3((unsigned)m), dim3((unsigned)std::min(256, qk_round_up(d, 64))), 0, st, x, d, as.vals2, as.seg, sums, counts);
+    if (n <= 0) {
+        QK_HIP(hipMemsetAsync(sums, 0, (size_t)m * d * sizeof(float), st));
+        QK_HIP(hipMemsetAsync(counts, 0, (size_t)m * sizeof(int64_t), st));
+        return QK_OK;
+    }
+    QK_TRY(bucket_rows_device(st, as, assign, n, m));
+    if (!blocked) {
+        hipLaunchKernelGGL(k_accumulate, dim3((unsigned)m), dim3((unsigned)std::min(256, qk_round_up(d, 64))), 0, st, x, d, as.vals2, as.seg, sums, counts);
+    } else if (d % 4 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)sums & 15) == 0) {
+        hipLaunchKernelGGL((k_accumulate_blocked<float4>), dim3((unsigned)m, KM_GLANES), dim3(256), 0, st, (const float4 *)x, d / 4, as.vals2, as.seg,
+                           (float4 *)sums, counts, (float4 *)as.gpart, as.tickets);
+    } else {
+        hipLaunchKernelGGL((k_accumulate_blocked<float>), dim3((unsigned)m, KM_GLANES), dim3(256), 0, st, x, d, as.vals2, as.seg, sums, counts,
+                           as.gpart, as.tickets);
+    }
     QK_HIP(hipGetLastError());
     return QK_OK;
 }
@@ -650,14 +850,14 @@ int qk_kmeans_assign(qk_ctx *ctx, const float *x, int64_t n, const float *c, int
     return QK_OK;
 }
 
-int qk_kmeans_accumulate(qk_ctx *ctx, const float *x, int64_t n, int d, const int64_t *assign, int64_t m, float *sums,
-                         int64_t *counts, int mem) {
+static int kmeans_accumulate_api(qk_ctx *ctx, const float *x, int64_t n, int d, const int64_t *assign, int64_t m, float *sums,
+                                 int64_t *counts, int mem, bool blocked) {
     if (!ctx || !x || !assign || !sums || !counts) QK_FAIL(QK_ERR_INVALID, "qk_kmeans_accumulate: null argument");
     if (n < 0 || m <= 0 || d <= 0) QK_FAIL(QK_ERR_INVALID, "qk_kmeans_accumulate: bad sizes");
     QK_HIP(hipSetDevice(ctx->device));
     KmScratch ks;
     AccumScratch as;
-    QK_TRY(accum_prepare(ks, as, std::max<int64_t>(n, 1), m));
+    QK_TRY(accum_prepare(ks, as, std::max<int64_t>(n, 1), m, d));
     const float *dx = x;
     const int64_t *da = assign;
     float *ds = sums;
@@ -676,13 +876,23 @@ int qk_kmeans_accumulate(qk_ctx *ctx, const float *x, int64_t n, int d, const in
         ds = bs;
         dc = bc;
     }
-    QK_TRY(accumulate_device(ctx, as, dx, n, d, da, m, ds, dc));
+    QK_TRY(accumulate_device(ctx, as, dx, n, d, da, m, ds, dc, blocked));
     if (mem == QK_MEM_HOST) {
         QK_HIP(hipMemcpyAsync(sums, bs, (size_t)m * d * 4, hipMemcpyDeviceToHost, ctx->stream));
         QK_HIP(hipMemcpyAsync(counts, bc, (size_t)m * 8, hipMemcpyDeviceToHost, ctx->stream));
     }
     QK_HIP(hipStreamSynchronize(ctx->stream));
     return QK_OK;
+}
+
+int qk_kmeans_accumulate(qk_ctx *ctx, const float *x, int64_t n, int d, const int64_t *assign, int64_t m, float *sums,
+                         int64_t *counts, int mem) {
+    return kmeans_accumulate_api(ctx, x, n, d, assign, m, sums, counts, mem, false);
+}
+
+int qk_kmeans_accumulate_blocked(qk_ctx *ctx, const float *x, int64_t n, int d, const int64_t *assign, int64_t m, float *sums,
+                                 int64_t *counts, int mem) {
+    return kmeans_accumulate_api(ctx, x, n, d, assign, m, sums, counts, mem, true);
 }
 
 // kmeans_refine_partitions (clustering.cpp:99-182) + the partition replacement of PartitionManager::refine_partitions
@@ -733,13 +943,13 @@ int qk_store_refine_lists(qk_store *s, const int64_t *list_nos, int64_t m, float
         pos += pt.size;
     }
     AccumScratch as;
-    QK_TRY(accum_prepare(ks, as, std::max<int64_t>(total, 1), m));
+    QK_TRY(accum_prepare(ks, as, std::max<int64_t>(total, 1), m, d));
     std::vector<int64_t> hcounts((size_t)m, 0);
     for (int iter = 0; iter < iterations; iter++) {
         if (iter > 0)  // centroids = sums / counts; a count of 0 gives NaN exactly like the reference (:122-124)
             hipLaunchKernelGGL(k_finalize_centroids, dim3(km_grid(m * d, 256)), dim3(256), 0, st, dsums, dcounts, m, d, 0, dc);
         QK_TRY(assign_device(ctx, xa, total, dc, m, d, metric, dassign, nullptr, ctile, cnorm));
-        QK_TRY(accumulate_device(ctx, as, xa, total, d, dassign, m, dsums, dcounts));
+        QK_TRY(accumulate_device(ctx, as, xa, total, d, dassign, m, dsums, dcounts, false));  // the reference's own order (:162-176)
         // stable bucket by assignment == the per-vector append into the new partitions (:174); accumulate_device left
         // the stably sorted row list in as.vals2
         if (total > 0) {
@@ -810,7 +1020,7 @@ int qk_kmeans(qk_ctx *ctx, float *x, int64_t n, int d, int64_t m, int metric, in
     // centroids = first m rows of the permutation (of the subsample if any)
     hipLaunchKernelGGL(k_gather_rows, dim3(km_grid(m * d, 256)), dim3(256), 0, st, dx, d, dperm, m, dc);
     AccumScratch as;
-    QK_TRY(accum_prepare(ks, as, ntrain, m));
+    QK_TRY(accum_prepare(ks, as, ntrain, m, d));
     std::vector<int64_t> hcounts((size_t)m);
     std::vector<float> hc;
     struct Ev3 {  // assign start / update start / update end of the last iteration (qk_kmeans_last_timing)
@@ -828,7 +1038,7 @@ int qk_kmeans(qk_ctx *ctx, float *x, int64_t n, int d, int64_t m, int metric, in
         }
         QK_TRY(assign_device(ctx, xt, ntrain, dc, m, d, metric, dta, nullptr, ctile, cnorm));
         if (timed) QK_HIP(hipEventRecord(ev.e[1], st));
-        QK_TRY(accumulate_device(ctx, as, xt, ntrain, d, dta, m, dsums, dcounts));
+        QK_TRY(accumulate_device(ctx, as, xt, ntrain, d, dta, m, dsums, dcounts, true));  // FAISS leaves the order open: blocked
         if (timed) QK_HIP(hipEventRecord(ev.e[2], st));
         hipLaunchKernelGGL(k_finalize_centroids, dim3(km_grid(m * d, 256)), dim3(256), 0, st, dsums, dcounts, m, d, 1, dc);
         QK_HIP(hipMemcpyAsync(hcounts.data(), dcounts, (size_t)m * 8, hipMemcpyDeviceToHost, st));

@@ -185,7 +185,7 @@ def sharded_kmeans(eng, dist, x, m, metric, niter=5, seed=1234, rank=0, world=1,
         c = c_local.clone() if is_t else c_local.copy()
     for _ in range(niter):
         a, _v = eng.kmeans_assign(xt, c, metric)
-        sums, counts = eng.kmeans_accumulate(xt, a, m)
+        sums, counts = eng.kmeans_accumulate(xt, a, m, blocked=True)  # the Lloyd driver's blocked order (qk_kmeans's)
         sums, counts = _reduce_partials(dist, world, sums, counts, ordered)
         c, _ = eng.kmeans_update(sums, counts, c)
     if metric == "ip":

@@ -88,7 +88,7 @@ def sharded_kmeans_reference(O, shards, m, metric, niter=5, seed=1234):
         s = cnt = None
         for r in range(world):
             a, _ = O.kmeans_assign(xt[r], c, metric)
-            ps, pc = O.kmeans_accumulate(xt[r], a, m)
+            ps, pc = O.kmeans_accumulate(xt[r], a, m, blocked=True)
             s = ps if s is None else s + ps
             cnt = pc if cnt is None else cnt + pc
         c, _ = O.kmeans_update(s, cnt, c)

@@ -53,22 +53,56 @@ def test_accumulate_bit_exact(ctx):
     assert gc[11] == 0
 
 
-@pytest.mark.parametrize("m", [1, 7, 255, 256, 300, 65535, 65536, 70000])
-def test_accumulate_bucket_passes(ctx, m):
-    """the stable bucketing of rows by assignment (k_rs_hist / k_rs_scan / k_rs_scatter) takes one pass per 8 bits of the
-    centroid number: 1, 2 and 3 passes, tiles with a ragged end, out-of-range assignments (ignored, as the oracle does), one
-    centroid that owns most of the rows -- sums are order-sensitive fp32, so a bucketing that is not stable fails here"""
+@pytest.mark.parametrize("blocked", [False, True])
+@pytest.mark.parametrize("m", [1, 7, 255, 256, 300, 4095, 4096, 65535, 65536, 70000])
+def test_accumulate_bucket_passes(ctx, m, blocked):
+    """the stable bucketing of rows by assignment (k_rs_hist / k_rs_scan / k_rs_scatter): one pass of 8 bits up to 255 centroids,
+    one of 12 bits up to 4095 (the segment bounds then come from the scan itself), two beyond; chunks with a ragged end, out-of-range
+    assignments (ignored, as the oracle does), one centroid that owns a third of the rows -- sums are order-sensitive fp32, so a
+    bucketing that is not stable fails here, under the reference's row-after-row order and under the blocked one"""
     rng = np.random.default_rng(m)
     n, d = 70001, 24
     x = (rng.standard_normal((n, d)) * 10.0 ** rng.integers(-3, 4, size=(n, 1))).astype(np.float32)
     a = rng.integers(0, m, size=n).astype(np.int64)
-    a[rng.integers(0, n, size=n // 3)] = m // 2   # a long segment: many rounds of every tile carry the same digit
+    a[rng.integers(0, n, size=n // 3)] = m // 2   # a long segment: many rounds of every chunk carry the same digit
     a[rng.integers(0, n, size=50)] = -1
     a[rng.integers(0, n, size=50)] = m + 3
-    gs, gc = ctx.kmeans_accumulate(x, a, m)
-    os_, oc = O.kmeans_accumulate(x, a, m)
+    gs, gc = ctx.kmeans_accumulate(x, a, m, blocked=blocked)
+    os_, oc = O.kmeans_accumulate(x, a, m, blocked=blocked)
     np.testing.assert_array_equal(gc, oc)
     np.testing.assert_array_equal(gs.view(np.uint32), os_.view(np.uint32))
+
+
+@pytest.mark.parametrize("n,m,d,big", [(20000, 29, 48, 0), (60000, 5, 128, 30000), (9000, 3, 100, 5000), (40000, 17, 6, 20000),
+                                       (12000, 4, 768, 9000), (3000, 2, 1100, 2500), (1024 * 9 + 5, 1, 32, 0), (1023, 1, 8, 0)])
+def test_accumulate_blocked_order(ctx, n, m, d, big):
+    """qk_kmeans_accumulate_blocked == the oracle's blocked order bit for bit: clusters below one block, of exactly a group, of
+    more groups than the launch has group lanes (the last workgroup to arrive folds the group partials), rows wider than one
+    float4 per thread (d = 1100) and not a multiple of four (d = 6, 100 ... no: 100 is), empty clusters; and the order really is
+    another one than the row-after-row sum (it must differ from it somewhere on data with spread magnitudes)."""
+    rng = np.random.default_rng(n + d)
+    x = (rng.standard_normal((n, d)) * 10.0 ** rng.integers(-2, 3, size=(n, 1))).astype(np.float32)
+    a = rng.integers(0, m, size=n).astype(np.int64)
+    if big:
+        a[rng.permutation(n)[:big]] = m - 1
+    if m > 3:
+        a[a == 1] = 2  # an empty cluster
+    gs, gc = ctx.kmeans_accumulate(x, a, m, blocked=True)
+    os_, oc = O.kmeans_accumulate(x, a, m, blocked=True)
+    np.testing.assert_array_equal(gc, oc)
+    np.testing.assert_array_equal(gs.view(np.uint32), os_.view(np.uint32))
+    ser, _ = O.kmeans_accumulate(x, a, m)
+    np.testing.assert_allclose(gs, ser, rtol=1e-3, atol=1e-2)
+    if n >= 9000:
+        assert (gs.view(np.uint32) != ser.view(np.uint32)).any()
+    # device buffers in and out, twice on one context (the tickets of the multi-group fold must be back at zero)
+    import torch
+    xd, ad = torch.from_numpy(x).cuda(), torch.from_numpy(a).cuda()
+    for _ in range(2):
+        ds, dc = ctx.kmeans_accumulate(xd, ad, m, blocked=True)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(ds.cpu().numpy().view(np.uint32), os_.view(np.uint32))
+        np.testing.assert_array_equal(dc.cpu().numpy(), oc)
 
 
 @pytest.mark.parametrize("metric", ["l2", "ip"])

@@ -73,7 +73,7 @@ for metric in ("l2", "ip"):
                 assert torch.equal(gi, ri), (metric, result, nprobe, k)
                 assert torch.equal(gd.view(torch.int32), rd.view(torch.int32)), (metric, result, nprobe, k)
         assert sh._g_pids is not None and sh._g_pids.is_cuda
-        assert (sh._x_ids if result == "owner" else sh._g_ids).is_cuda
+        assert (sh._x_recv if result == "owner" else sh._g_ids).is_cuda  # (owner: ONE packed all-to-all, uint8 [G][block])
     # a side stream: the library follows torch's current stream, the collectives order themselves against it
     st = torch.cuda.Stream()
     with torch.cuda.stream(st):

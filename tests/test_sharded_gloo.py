@@ -167,9 +167,9 @@ class OracleKmeans:
         import oracle as O
         return O.kmeans_assign(x, c, metric)
 
-    def kmeans_accumulate(self, x, a, m):
+    def kmeans_accumulate(self, x, a, m, blocked=False):
         import oracle as O
-        return O.kmeans_accumulate(x, a, m)
+        return O.kmeans_accumulate(x, a, m, blocked=blocked)
 
     def kmeans_update(self, sums, counts, c):
         import oracle as O
