@@ -216,15 +216,15 @@ __global__ __launch_bounds__(256) void k_assign(AssignParams P) {
 // the four waves of a workgroup: three barriers per round, 35-48 us per pass for 2^20 keys).  The four waves of a workgroup share
 // one row of the table: the scatter re-counts the chunk (the keys come back from L2) to find each wave's offset inside it, which
 // keeps the table at 2^RS_BITS * n / (4 * wave rows) entries.  The first pass reads the assignments themselves (key = assignment,
-// value = row number), so no key / value arrays are materialised before it.  Rows whose assignment is out of range get key m: they
-// sort behind every centroid and are ignored.
+// value = row number), so no key / value arrays are materialised before it.  Rows whose assignment is out of range are dropped by the
+// first pass (no key of their own: 4096 centroids stay ONE 12-bit pass); the number of rows kept travels on the device (n_dev).
 constexpr int RS_THREADS = 256, RS_WAVES = 4;
 
 template <bool FIRST>
 __device__ __forceinline__ int32_t rs_key(const int64_t *__restrict__ assign, const int32_t *__restrict__ keys_in, int64_t i, int m) {
     if (FIRST) {
         const int64_t a = assign[i];
-        return (a < 0 || a >= m) ? m : (int32_t)a;
+        return (a < 0 || a >= m) ? -1 : (int32_t)a;  // out of range: the row is dropped by the first pass
     }
     return keys_in[i];
 }
@@ -233,7 +233,8 @@ struct RsPass {
     const int64_t *assign;    // FIRST pass: the assignments
     const int32_t *keys_in;   // later passes: keys / values of the previous pass
     const int32_t *vals_in;
-    int64_t n;
+    int64_t n;                // rows of the first pass (host value); later passes read the rows kept from n_dev
+    int32_t *n_dev;           // [1] rows kept = sum of the digit totals, written by every k_rs_scan
     int m, shift;
     int wave_rows;            // rows per wave (multiple of 64); a workgroup's chunk = 4 * wave_rows consecutive rows
     int nchunks;              // workgroups
@@ -241,7 +242,7 @@ struct RsPass {
     int32_t *totals;          // [1 << BITS], zeroed before k_rs_hist
     int32_t *keys_out;        // may be null on the last pass
     int32_t *vals_out;
-    int64_t *dbase_out;       // k_rs_scan: first output position of every digit ([1 << BITS], may be null) -- with a single pass
+    int64_t *dbase_out;       // k_rs_scan: first output position of every digit ([(1 << BITS) + 1], may be null) -- with a single pass
                               // these ARE the segment bounds of the centroids
 };
 
@@ -251,7 +252,10 @@ __device__ __forceinline__ void rs_count_wave(const RsPass &P, int32_t *hw, int6
     constexpr int NB = 1 << BITS;
     for (int i = lane; i < NB; i += 64) hw[i] = 0;
     __builtin_amdgcn_wave_barrier();
-    for (int64_t i = r0 + lane; i < r1; i += 64) atomicAdd(&hw[(rs_key<FIRST>(P.assign, P.keys_in, i, P.m) >> P.shift) & (NB - 1)], 1);
+    for (int64_t i = r0 + lane; i < r1; i += 64) {
+        const int32_t key = rs_key<FIRST>(P.assign, P.keys_in, i, P.m);
+        if (key >= 0) atomicAdd(&hw[(key >> P.shift) & (NB - 1)], 1);
+    }
     __builtin_amdgcn_wave_barrier();
 }
 
@@ -260,7 +264,8 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const RsPass P) {
     constexpr int NB = 1 << BITS;
     extern __shared__ int32_t rs_lds[];  // [4][NB]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t r0 = ((int64_t)blockIdx.x * RS_WAVES + wave) * P.wave_rows, r1 = min(P.n, r0 + P.wave_rows);
+    const int64_t n = FIRST ? P.n : (int64_t)*P.n_dev;
+    const int64_t r0 = ((int64_t)blockIdx.x * RS_WAVES + wave) * P.wave_rows, r1 = min(n, r0 + P.wave_rows);
     rs_count_wave<BITS, FIRST>(P, rs_lds + wave * NB, r0, r1, lane);
     __syncthreads();
     for (int i = threadIdx.x; i < NB; i += RS_THREADS) {
@@ -298,6 +303,10 @@ __global__ __launch_bounds__(256) void k_rs_scan(const RsPass P) {
     }
     const int32_t dbase = base0 + inc - tot;
     if (wave == 0 && P.dbase_out) P.dbase_out[dg0 + lane] = dbase;
+    if (wave == 0 && lane == 63 && blockIdx.x == gridDim.x - 1) {  // rows kept (all digits) = the end of the last segment
+        *P.n_dev = base0 + inc;
+        if (P.dbase_out) P.dbase_out[NB] = base0 + inc;
+    }
     // quarter `wave` of the chunks
     const int per = (P.nchunks + 3) / 4, c0 = min(P.nchunks, wave * per), c1 = min(P.nchunks, c0 + per);
     int32_t *col = P.table + dg0 + lane;
@@ -323,7 +332,8 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const RsPass P) {
     constexpr int NB = 1 << BITS;
     extern __shared__ int32_t rs_lds[];  // [4][NB]: counts, then running output positions per wave
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t r0 = ((int64_t)blockIdx.x * RS_WAVES + wave) * P.wave_rows, r1 = min(P.n, r0 + P.wave_rows);
+    const int64_t n = FIRST ? P.n : (int64_t)*P.n_dev;
+    const int64_t r0 = ((int64_t)blockIdx.x * RS_WAVES + wave) * P.wave_rows, r1 = min(n, r0 + P.wave_rows);
     rs_count_wave<BITS, FIRST>(P, rs_lds + wave * NB, r0, r1, lane);
     __syncthreads();
     for (int i = threadIdx.x; i < NB; i += RS_THREADS) {
@@ -340,11 +350,12 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const RsPass P) {
     const uint64_t lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
     for (int64_t i0 = r0; i0 < r1; i0 += 64) {
         const int64_t i = i0 + lane;
-        const bool valid = i < r1;
+        bool valid = i < r1;
         int32_t key = 0, val = 0;
         if (valid) {
             key = rs_key<FIRST>(P.assign, P.keys_in, i, P.m);
             val = FIRST ? (int32_t)i : P.vals_in[i];
+            valid = key >= 0;
         }
         const int digit = (key >> P.shift) & (NB - 1);
         uint64_t peers = __ballot(valid);
@@ -367,8 +378,10 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const RsPass P) {
     }
 }
 
-__global__ void k_segment_bounds(const int32_t *__restrict__ sorted_keys, int64_t n, int m, int64_t *seg_begin /*[m+1]*/) {
+__global__ void k_segment_bounds(const int32_t *__restrict__ sorted_keys, const int32_t *__restrict__ n_dev, int m,
+                                 int64_t *seg_begin /*[m+1]*/) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t n = *n_dev;
     if (i > n) return;
     // seg_begin[c] = first position with key >= c
     int prev = i == 0 ? -1 : sorted_keys[i - 1];
@@ -657,7 +670,7 @@ struct AccumScratch {
 
 static void rs_plan(int64_t n, int64_t m, AccumScratch &as) {
     int kb = 1;
-    while ((1LL << kb) <= m) kb++;  // the keys are 0 .. m (m = out of range)
+    while ((1LL << kb) < m) kb++;  // the keys are 0 .. m - 1 (rows out of range are dropped by the first pass)
     as.bits = kb <= 8 ? 8 : 12;
     as.passes = (kb + as.bits - 1) / as.bits;
     // a wave's share: 1024 rows, more once the table would pass ~64 MB
@@ -676,7 +689,7 @@ static int accum_prepare(KmScratch &ks, AccumScratch &as, int64_t n, int64_t m, 
         QK_TRY(ks.alloc(&as.keys2, (size_t)n));
     }
     QK_TRY(ks.alloc(&as.seg, (size_t)std::max<int64_t>(m + 2, ((int64_t)1 << as.bits) + 1)));
-    QK_TRY(ks.alloc(&as.table, ((size_t)as.nchunks + 1) << as.bits));
+    QK_TRY(ks.alloc(&as.table, (((size_t)as.nchunks + 1) << as.bits) + 16));  // + digit totals + n_dev
     QK_TRY(ks.alloc(&as.gpart, (size_t)(n / KM_GROUP + m + 2) * d));
     QK_TRY(ks.alloc(&as.tickets, (size_t)m));
     QK_HIP(hipMemset(as.tickets, 0, (size_t)m * sizeof(unsigned int)));
@@ -716,6 +729,7 @@ static int bucket_rows_device(hipStream_t st, AccumScratch &as, const int64_t *a
     P.nchunks = as.nchunks;
     P.table = as.table;
     P.totals = as.table + ((size_t)as.nchunks << as.bits);
+    P.n_dev = P.totals + ((size_t)1 << as.bits);
     // the last pass must land in (keys2, vals2): with an odd number of passes the first one writes there
     int32_t *ko = (as.passes & 1) ? as.keys2 : as.keys, *vo = (as.passes & 1) ? as.vals2 : as.vals;
     const int32_t *ki = nullptr, *vi = nullptr;
@@ -733,7 +747,7 @@ static int bucket_rows_device(hipStream_t st, AccumScratch &as, const int64_t *a
         ko = ko == as.keys ? as.keys2 : as.keys;
         vo = vo == as.vals ? as.vals2 : as.vals;
     }
-    if (as.passes > 1) hipLaunchKernelGGL(k_segment_bounds, dim3(km_grid(n + 1, 256)), dim3(256), 0, st, as.keys2, n, (int)m, as.seg);
+    if (as.passes > 1) hipLaunchKernelGGL(k_segment_bounds, dim3(km_grid(n + 1, 256)), dim3(256), 0, st, as.keys2, P.n_dev, (int)m, as.seg);
     QK_HIP(hipGetLastError());
     return QK_OK;
 }
@@ -949,6 +963,9 @@ int qk_store_refine_lists(qk_store *s, const int64_t *list_nos, int64_t m, float
         if (iter > 0)  // centroids = sums / counts; a count of 0 gives NaN exactly like the reference (:122-124)
             hipLaunchKernelGGL(k_finalize_centroids, dim3(km_grid(m * d, 256)), dim3(256), 0, st, dsums, dcounts, m, d, 0, dc);
         QK_TRY(assign_device(ctx, xa, total, dc, m, d, metric, dassign, nullptr, ctile, cnorm));
+        // (a row without an assignment -- NaN centroid -- is dropped by the bucketing: the tail of the row list it leaves must not
+        //  hold garbage for the gathers below; the call fails after the loop in that case)
+        if (total > 0) QK_HIP(hipMemsetAsync(as.vals2, 0, (size_t)total * sizeof(int32_t), st));
         QK_TRY(accumulate_device(ctx, as, xa, total, d, dassign, m, dsums, dcounts, false));  // the reference's own order (:162-176)
         // stable bucket by assignment == the per-vector append into the new partitions (:174); accumulate_device left
         // the stably sorted row list in as.vals2
