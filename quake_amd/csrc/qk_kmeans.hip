@@ -262,14 +262,18 @@ __device__ __forceinline__ void rs_count_wave(const RsPass &P, int32_t *hw, int6
 template <int BITS, bool FIRST>
 __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const RsPass P) {
     constexpr int NB = 1 << BITS;
-    extern __shared__ int32_t rs_lds[];  // [4][NB]
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    extern __shared__ int32_t rs_lds[];  // [NB]: the counts of the whole chunk (the scatter finds the waves' shares itself)
+    for (int i = threadIdx.x; i < NB; i += RS_THREADS) rs_lds[i] = 0;
+    __syncthreads();
     const int64_t n = FIRST ? P.n : (int64_t)*P.n_dev;
-    const int64_t r0 = ((int64_t)blockIdx.x * RS_WAVES + wave) * P.wave_rows, r1 = min(n, r0 + P.wave_rows);
-    rs_count_wave<BITS, FIRST>(P, rs_lds + wave * NB, r0, r1, lane);
+    const int64_t r0 = (int64_t)blockIdx.x * RS_WAVES * P.wave_rows, r1 = min(n, r0 + (int64_t)RS_WAVES * P.wave_rows);
+    for (int64_t i = r0 + threadIdx.x; i < r1; i += RS_THREADS) {
+        const int32_t key = rs_key<FIRST>(P.assign, P.keys_in, i, P.m);
+        if (key >= 0) atomicAdd(&rs_lds[(key >> P.shift) & (NB - 1)], 1);
+    }
     __syncthreads();
     for (int i = threadIdx.x; i < NB; i += RS_THREADS) {
-        const int32_t v = rs_lds[i] + rs_lds[NB + i] + rs_lds[2 * NB + i] + rs_lds[3 * NB + i];
+        const int32_t v = rs_lds[i];
         P.table[(int64_t)blockIdx.x * NB + i] = v;
         if (v) atomicAdd(&P.totals[i], v);
     }
@@ -346,6 +350,9 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const RsPass P) {
         }
     }
     __syncthreads();
+    // the digit totals go back to zero for the next pass / call (their only reader, k_rs_scan, ran before this launch)
+    if (blockIdx.x == 0)
+        for (int i = threadIdx.x; i < NB; i += RS_THREADS) P.totals[i] = 0;
     int32_t *pos = rs_lds + wave * NB;
     const uint64_t lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
     for (int64_t i0 = r0; i0 < r1; i0 += 64) {
@@ -680,7 +687,7 @@ static void rs_plan(int64_t n, int64_t m, AccumScratch &as) {
     as.nchunks = (int)std::max<int64_t>(1, (n + 4 * wr - 1) / (4 * wr));
 }
 
-static int accum_prepare(KmScratch &ks, AccumScratch &as, int64_t n, int64_t m, int d) {
+static int accum_prepare(hipStream_t st, KmScratch &ks, AccumScratch &as, int64_t n, int64_t m, int d) {
     rs_plan(n, m, as);
     QK_TRY(ks.alloc(&as.vals2, (size_t)n));
     if (as.passes > 1) {
@@ -692,13 +699,15 @@ static int accum_prepare(KmScratch &ks, AccumScratch &as, int64_t n, int64_t m, 
     QK_TRY(ks.alloc(&as.table, (((size_t)as.nchunks + 1) << as.bits) + 16));  // + digit totals + n_dev
     QK_TRY(ks.alloc(&as.gpart, (size_t)(n / KM_GROUP + m + 2) * d));
     QK_TRY(ks.alloc(&as.tickets, (size_t)m));
-    QK_HIP(hipMemset(as.tickets, 0, (size_t)m * sizeof(unsigned int)));
+    // (on the stream the kernels run on: it may be a non-blocking one, which a null-stream memset would not order with)
+    QK_HIP(hipMemsetAsync(as.tickets, 0, (size_t)m * sizeof(unsigned int), st));
+    QK_HIP(hipMemsetAsync(as.table + ((size_t)as.nchunks << as.bits), 0, (sizeof(int32_t) << as.bits) + 16 * sizeof(int32_t), st));  // digit totals: zero between passes
     return QK_OK;
 }
 
 template <int BITS>
 static int rs_pass_launch(hipStream_t st, const RsPass &P, bool first) {
-    constexpr size_t lds = (size_t)RS_WAVES * sizeof(int32_t) << BITS;
+    constexpr size_t lds = (size_t)RS_WAVES * sizeof(int32_t) << BITS, lds_hist = sizeof(int32_t) << BITS;
     static bool attr_set = false;
     if (!attr_set) {
         QK_HIP(hipFuncSetAttribute((const void *)k_rs_hist<BITS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -707,10 +716,9 @@ static int rs_pass_launch(hipStream_t st, const RsPass &P, bool first) {
         QK_HIP(hipFuncSetAttribute((const void *)k_rs_scatter<BITS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    QK_HIP(hipMemsetAsync(P.totals, 0, sizeof(int32_t) << BITS, st));
     const dim3 grid((unsigned)P.nchunks), block(RS_THREADS);
-    if (first) hipLaunchKernelGGL((k_rs_hist<BITS, true>), grid, block, lds, st, P);
-    else hipLaunchKernelGGL((k_rs_hist<BITS, false>), grid, block, lds, st, P);
+    if (first) hipLaunchKernelGGL((k_rs_hist<BITS, true>), grid, block, lds_hist, st, P);
+    else hipLaunchKernelGGL((k_rs_hist<BITS, false>), grid, block, lds_hist, st, P);
     hipLaunchKernelGGL((k_rs_scan<BITS>), dim3((1u << BITS) / 64), dim3(256), 0, st, P);
     if (first) hipLaunchKernelGGL((k_rs_scatter<BITS, true>), grid, block, lds, st, P);
     else hipLaunchKernelGGL((k_rs_scatter<BITS, false>), grid, block, lds, st, P);
@@ -871,7 +879,7 @@ static int kmeans_accumulate_api(qk_ctx *ctx, const float *x, int64_t n, int d, 
     QK_HIP(hipSetDevice(ctx->device));
     KmScratch ks;
     AccumScratch as;
-    QK_TRY(accum_prepare(ks, as, std::max<int64_t>(n, 1), m, d));
+    QK_TRY(accum_prepare(ctx->stream, ks, as, std::max<int64_t>(n, 1), m, d));
     const float *dx = x;
     const int64_t *da = assign;
     float *ds = sums;
@@ -957,7 +965,7 @@ int qk_store_refine_lists(qk_store *s, const int64_t *list_nos, int64_t m, float
         pos += pt.size;
     }
     AccumScratch as;
-    QK_TRY(accum_prepare(ks, as, std::max<int64_t>(total, 1), m, d));
+    QK_TRY(accum_prepare(st, ks, as, std::max<int64_t>(total, 1), m, d));
     std::vector<int64_t> hcounts((size_t)m, 0);
     for (int iter = 0; iter < iterations; iter++) {
         if (iter > 0)  // centroids = sums / counts; a count of 0 gives NaN exactly like the reference (:122-124)
@@ -1037,7 +1045,7 @@ int qk_kmeans(qk_ctx *ctx, float *x, int64_t n, int d, int64_t m, int metric, in
     // centroids = first m rows of the permutation (of the subsample if any)
     hipLaunchKernelGGL(k_gather_rows, dim3(km_grid(m * d, 256)), dim3(256), 0, st, dx, d, dperm, m, dc);
     AccumScratch as;
-    QK_TRY(accum_prepare(ks, as, ntrain, m, d));
+    QK_TRY(accum_prepare(st, ks, as, ntrain, m, d));
     std::vector<int64_t> hcounts((size_t)m);
     std::vector<float> hc;
     struct Ev3 {  // assign start / update start / update end of the last iteration (qk_kmeans_last_timing)
