@@ -495,7 +495,7 @@ __global__ __launch_bounds__(256) void k_accumulate_blocked(const V *__restrict_
     for (int u0 = 0; u0 < units; u0 += TPC) {  // (one trip unless a row is wider than 256 units)
         const int u = u0 + j;
         const bool live = chain && u < units;
-        for (int64_t g = gl; g < G; g += KM_GLANES) {
+        for (int64_t g = gl; g < G; g += gridDim.y) {
             const int64_t gb = b + g * KM_GROUP, ge = min(e, gb + KM_GROUP);
             const int nb = (int)((ge - gb + KM_L1 - 1) / KM_L1);
             V run = km_zero<V>();
@@ -538,7 +538,7 @@ __global__ __launch_bounds__(256) void k_accumulate_blocked(const V *__restrict_
     __threadfence();
     __syncthreads();
     if (tid == 0) {
-        const unsigned int lanes = (unsigned int)min((int64_t)KM_GLANES, G);
+        const unsigned int lanes = (unsigned int)min((int64_t)gridDim.y, G);
         const unsigned int t = atomicAdd(&tickets[c], 1u);
         s_last = t == lanes - 1 ? 1 : 0;
         if (s_last) tickets[c] = 0;  // (zero between launches)
@@ -774,12 +774,17 @@ static int accumulate_device(qk_ctx *ctx, AccumScratch &as, const float *x, int6
     QK_TRY(bucket_rows_device(st, as, assign, n, m));
     if (!blocked) {
         hipLaunchKernelGGL(k_accumulate, dim3((unsigned)m), dim3((unsigned)std::min(256, qk_round_up(d, 64))), 0, st, x, d, as.vals2, as.seg, sums, counts);
-    } else if (d % 4 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)sums & 15) == 0) {
-        hipLaunchKernelGGL((k_accumulate_blocked<float4>), dim3((unsigned)m, KM_GLANES), dim3(256), 0, st, (const float4 *)x, d / 4, as.vals2, as.seg,
-                           (float4 *)sums, counts, (float4 *)as.gpart, as.tickets);
     } else {
-        hipLaunchKernelGGL((k_accumulate_blocked<float>), dim3((unsigned)m, KM_GLANES), dim3(256), 0, st, x, d, as.vals2, as.seg, sums, counts,
-                           as.gpart, as.tickets);
+        // group lanes: workgroups per centroid (most exit at once: a centroid with <= 1024 rows has one group).  Eight when the mean
+        // cluster is a few hundred rows (a skewed mixture then holds clusters of many groups), fewer for many small clusters
+        // (65536 x 8 mostly empty workgroups cost more than the rare long cluster they would split)
+        const unsigned lanes = (unsigned)std::min<int64_t>(KM_GLANES, std::max<int64_t>(2, (n + 16 * m - 1) / (16 * m)));
+        if (d % 4 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)sums & 15) == 0)
+            hipLaunchKernelGGL((k_accumulate_blocked<float4>), dim3((unsigned)m, lanes), dim3(256), 0, st, (const float4 *)x, d / 4, as.vals2, as.seg,
+                               (float4 *)sums, counts, (float4 *)as.gpart, as.tickets);
+        else
+            hipLaunchKernelGGL((k_accumulate_blocked<float>), dim3((unsigned)m, lanes), dim3(256), 0, st, x, d, as.vals2, as.seg, sums, counts,
+                               as.gpart, as.tickets);
     }
     QK_HIP(hipGetLastError());
     return QK_OK;

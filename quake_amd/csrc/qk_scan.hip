@@ -1410,7 +1410,14 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
         // query-sharing form of k_scan, which used to take over from 6 probing queries per list on: 1.019 / 1.177 at nprobe 32 / 64).
         // At nprobe 2 / 4 (under two probing queries per list on average) the few hot lists are home lists -- every other row tile
         // has a true candidate -- and the items only add their fixed costs: 0.344 / 0.382 -> 0.413 / 0.447; the hot form stays off.
-        static const int hot_min = qk_env_int("QK_SCAN_HOT_MIN", 13);   // 0: per-wave walk only
+        // Round 4: the launch must END in the per-wave walk's fine-grained dynamic tail, not in items (47 us apiece: the wave end
+        // times of round 3 spread from 414 to 545 us around a mean of 445 at nprobe 16, the slowest workgroups all inside an item).
+        // The hot-first workgroups' share of the grid is therefore taken at 3x the items' modelled cost (ScanParams::hot_first_pct),
+        // half of the walk is handed out dynamically, and with that balance the thresholds moved: hot from 18 probing queries
+        // (13), mixed form from TWO probing queries per list on average (three).  Kernel ms before -> after, skewed mixture nprobe
+        // 8 / 10 / 12 / 16 / 32 / 64: 0.459 / 0.484 / 0.503 / 0.516 / 0.602 / 0.806 -> 0.399 / 0.411 / 0.423 / 0.446 / 0.555 / 0.773;
+        // uniformly probed corpus 16 / 32 / 64: 0.832 / 0.851 / 1.003 -> 0.818 / 0.865 / 1.012 (scripts/gpu_knobs.sh).
+        static const int hot_min = qk_env_int("QK_SCAN_HOT_MIN", 18);   // 0: per-wave walk only
         static const int hot_unit = qk_env_int("QK_SCAN_HOT_UNIT", 300);
         static const int hot_w10 = qk_env_int("QK_SCAN_HOT_W10", 3);
         static const int hot_ht10 = qk_env_int("QK_SCAN_HOT_HT10", 30);
@@ -1420,7 +1427,12 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
         //  as fast or faster on both corpora: skewed mixture nprobe 8 / 10 / 12 / 14 walk 0.447 / 0.481 / 0.515 / 0.565 ms, mixed
         //  0.475 / 0.480 / 0.490 / 0.498; uniformly probed corpus 0.683 / 0.714 / 0.738 / 0.763 against 0.692 / 0.747 / 0.785 / 0.809 --
         //  there the mixed form only pays from nprobe ~24 on, a skew the host cannot see; the rule follows the skewed case)
-        static const int hot_per_list = qk_env_int("QK_SCAN_HOT_PER_LIST", 3);
+        // (the form used to start at THREE probing queries per list on average -- an index-wide mean that says nothing about a few
+        //  very hot lists.  With the balance above it is at least as fast as the plain walk from one on -- mixture nprobe 2 / 4 / 6:
+        //  0.339 / 0.387 / 0.418 -> 0.333 / 0.369 / 0.386 ms, uniformly probed corpus 2 / 4 / 6 / 8: 0.357 / 0.522 / 0.630 / 0.685 ->
+        //  0.352 / 0.527 / 0.637 / 0.700 (no hot list there: the walk with half its sequence dynamic) -- so whether a list is hot is
+        //  decided per list on the device, by the grouping stage that counts its probing queries, for every batch with nprobe > 1)
+        static const int hot_per_list = qk_env_int("QK_SCAN_HOT_PER_LIST", 1);
         static const int hot_min_rows = qk_env_int("QK_SCAN_HOT_MIN_ROWS", 512);
         // Short lists: on the configs[0] shape (1M x 128 in 1024 lists of ~1000 rows, nprobe 10) items are 61 row tiles long and
         // their fixed costs show -- 256 / 1024 queries: scan 85 / 165 us with the round-2 forms (per-wave walk / query-sharing tile
@@ -1738,6 +1750,8 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
         sp.n_hot = scal + 8;
         sp.hot_units = (const long long *)(scal + 10);
         sp.hot_counter = scal + 12;  // zeroed with the counters
+        static const int hot_first_pct = qk_env_int("QK_SCAN_HOT_FIRST_PCT", 300);
+        sp.hot_first_pct = std::max(1, hot_first_pct);
         sp.key_out = a.key_out;
         sp.pair_base = a.pair_base;
         sp.pair_slots = pair_slots;
@@ -1773,7 +1787,8 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
             static const int rl_dyn_env = qk_env_int("QK_SCAN_RL_DYN_PCT", -1);
             // (small launches -- under 1024 pairs, a wave's static share is a chunk or two -- finish sooner without a tail to
             //  claim: 64 queries x nprobe 10: scan 60 -> 55 us, 8 queries: 46 -> 25 us; from 2560 pairs on the tail pays)
-            const int rl_dyn_pct = rl_dyn_env >= 0 ? rl_dyn_env : (npairs < 1024 ? 0 : rl_per_list <= 1 ? 40 : 25);
+            // (mixed form: half of the walk -- the hot-first workgroups join it when the items are gone, see hot_first_pct)
+            const int rl_dyn_pct = rl_dyn_env >= 0 ? rl_dyn_env : (npairs < 1024 ? 0 : hot.min > 0 ? 50 : rl_per_list <= 1 ? 40 : 25);
             static const int rl_dyn_chunk = qk_env_int("QK_SCAN_RL_DYN_CHUNK", 64);
             sp.dyn_counter = rl_dyn_pct > 0 ? (unsigned long long *)(scal + 16) : nullptr;
             sp.dyn_chunk = std::max(1, rl_dyn_chunk);

@@ -128,9 +128,13 @@ __device__ __forceinline__ void rl_hot_item(const ScanParams &P, const HotLds &H
     float4 y0[2], y1[2];
     longlong2 i0[4], i1[4];
     int lp = wv;  // next pair to load
+    // EVERY load of the pair loop is unconditional (a wave that has run out of pairs requests its last one again): a load inside
+    // a runtime branch makes hipcc wait for vmcnt(0) -- or nearly: the ISA of round 3 held `s_waitcnt vmcnt(2)` right behind the 22
+    // loads of the NEXT pair -- before the fragments of the CURRENT pair are touched, so every pair paid a whole HBM round trip
+    // with nothing under it (one wave per SIMD); with counted waits the next pair stays in flight under this pair's products
 #define HOT_LOAD(A, Y, I)                                                                                   \
-    if (lp < npairs_t) {                                                                                    \
-        const int pc_ = lp;                                                                                 \
+    {                                                                                                       \
+        const int pc_ = min(lp, max(npairs_t - 1 - ((npairs_t - 1 - wv) & 3), 0));                          \
         _Pragma("unroll") for (int u_ = 0; u_ < 2; u_++) {                                                  \
             const int64_t ta_ = tile_p0 + min(t_lo + 2 * pc_ + u_, t_hi - 1);                               \
             const float4 *src_ = P.vecs + ta_ * (NB * 64) + lane;                                           \
@@ -255,10 +259,10 @@ __device__ __forceinline__ void rl_hot_item(const ScanParams &P, const HotLds &H
                         dbg_comp++;
                         uint32_t kth;
                         cnt = select_pool<1>(my_ord, my_id, cnt, k, lane, kth);
-                        if (cnt >= k) {
-                            tau = min(tau, kth);
-                            if (P.gtau && P.tau_publish && lane == 0) atomicMax(&P.gtau[H.q[sl]], ~tau);
-                        }
+                        // (the tightened bound is published at the item's end, with its record: a global atomic HERE puts a memory
+                        //  operation inside the pair loop's body, and hipcc then drains the prefetched pair -- s_waitcnt vmcnt(0) --
+                        //  before every query-tile loop)
+                        if (cnt >= k) tau = min(tau, kth);
                     }
                 }
             }
@@ -539,7 +543,7 @@ __global__ __launch_bounds__(256) void k_scan_rl(ScanParams P) {
     if (HOT) {
         n_hot = *P.n_hot;
         if (n_hot > 0 && dyn && gridDim.x >= 16) {
-            const double hu = (double)*P.hot_units;
+            const double hu = (double)*P.hot_units * (double)P.hot_first_pct * 0.01;
             n_hot_first = ((int)((double)gridDim.x * hu / (hu + (double)T + 1.0) + 4.0)) & ~7;
             n_hot_first = max(0, min(n_hot_first, ((int)gridDim.x - 8) & ~7));
         }

@@ -137,6 +137,9 @@ struct ScanParams {
     const int32_t *n_hot;         // [1] hot items of the launch
     const long long *hot_units;   // [1] their cost in units of the per-wave sequence
     int32_t *hot_counter;         // [1] next hot item to hand out (zeroed per call)
+    int hot_first_pct;            // the hot-first workgroups' share of the grid = hot / (hot + walk) cost with the items' cost taken at
+                                  // this percentage: > 100 puts more workgroups on items at the start, so that the ITEMS (47 us
+                                  // apiece) run out first and the launch ends in the fine-grained dynamic tail of the per-wave walk
 };
 
 // ---- merge stage (qk_merge.hip) ------------------------------------------------------------------------------------------

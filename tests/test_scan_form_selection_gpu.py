@@ -31,7 +31,7 @@ def _stores(ctx, ivf):
 
 
 # (rows, lists, d, k, queries, nprobe) -> form.  Pairs per list = queries * nprobe / lists; the mixed form needs lists that
-# average >= 1400 rows.
+# average >= 1400 rows (round 4: and nothing else -- it used to start at three probing queries per list).
 TABLE = [
     # one list per query: the 16 x 16 tile form (its static cut leaves the fewest records to merge)
     (60000, 1024, 128, 10, 1024, 1, "k_scan"),
@@ -39,9 +39,12 @@ TABLE = [
     # several lists per query, under two probing queries per list: the per-wave row-per-lane walk
     (60000, 1024, 128, 10, 256, 4, "k_scan_rl"),
     (60000, 1024, 64, 10, 512, 2, "k_scan_rl"),
-    # LONG lists (1400+ rows on average): the per-wave walk up to two probing queries per list, from three on the mixed sequence
-    (720000, 512, 64, 10, 512, 2, "k_scan_rl"),
+    # LONG lists (1400+ rows on average), nprobe > 1, 1024+ pairs: the mixed sequence whatever the sharing -- which lists are hot
+    # (>= 18 probing queries) is decided per list on the device; without one the launch is the per-wave walk
+    (720000, 512, 64, 10, 1024, 1, "k_scan"),
+    (720000, 512, 64, 10, 512, 2, "k_scan_rl (mixed)"),
     (720000, 512, 64, 10, 512, 3, "k_scan_rl (mixed)"),
+    (1500000, 1024, 64, 10, 512, 2, "k_scan_rl (mixed)"),  # (one probing query per list on average)
     # LONG lists (1560 rows on average) and many probing queries per list: the mixed sequence (hot lists as dense items behind
     # the bf16 prefilter), whatever the sharing
     (100000, 64, 128, 10, 1024, 2, "k_scan_rl (mixed)"),
