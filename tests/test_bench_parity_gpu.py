@@ -67,7 +67,7 @@ def _bench_case(ctx, n, d, nlist, k, metric, nprobes, sigma=0.3, manifold=0, for
 
 def test_configs1_bench_batch_bit_exact(ctx):
     _bench_case(ctx, 10_000_000, 128, 4096, 10, "l2", (1, 4, 8, 12, 32),
-                forms={1: "k_scan", 4: "k_scan_rl", 8: "k_scan_rl", 12: "k_scan_rl (mixed)", 32: "k_scan_rl (mixed)"})
+                forms={1: "k_scan", 4: "k_scan_rl (mixed)", 8: "k_scan_rl (mixed)", 12: "k_scan_rl (mixed)", 32: "k_scan_rl (mixed)"})
 
 
 def test_configs1_hard_corpus_bit_exact(ctx):

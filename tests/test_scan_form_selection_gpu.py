@@ -41,7 +41,6 @@ TABLE = [
     (60000, 1024, 64, 10, 512, 2, "k_scan_rl"),
     # LONG lists (1400+ rows on average), nprobe > 1, 1024+ pairs: the mixed sequence whatever the sharing -- which lists are hot
     # (>= 18 probing queries) is decided per list on the device; without one the launch is the per-wave walk
-    (720000, 512, 64, 10, 1024, 1, "k_scan"),
     (720000, 512, 64, 10, 512, 2, "k_scan_rl (mixed)"),
     (720000, 512, 64, 10, 512, 3, "k_scan_rl (mixed)"),
     (1500000, 1024, 64, 10, 512, 2, "k_scan_rl (mixed)"),  # (one probing query per list on average)
