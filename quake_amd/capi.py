@@ -374,6 +374,19 @@ class Store:
         check(self.lib.qk_store_get_list(self.h, int(list_no), _ptr(vecs), _ptr(ids), QK_MEM_HOST))
         return vecs, ids
 
+    def get_list_device(self, list_no):
+        """(vectors [n, d] as a CUDA tensor on the store's device -- extracted from the tile-major arena on the context's stream,
+        no host hop -- , ids [n] as a host array: the store's own id mirror)"""
+        import torch
+        n = self.list_size(list_no)
+        dev = torch.device("cuda", self.ctx.device)
+        vecs = torch.empty((n, self.d), dtype=torch.float32, device=dev)
+        ids = np.empty(n, np.int64)
+        if n:
+            check(self.lib.qk_store_get_list(self.h, int(list_no), _ptr(vecs), None, QK_MEM_DEVICE))
+            check(self.lib.qk_store_get_list(self.h, int(list_no), None, _ptr(ids), QK_MEM_HOST))
+        return vecs, ids
+
     def get_vector(self, vid):
         out = np.empty(self.d, np.float32)
         found = C.c_int()

@@ -36,9 +36,37 @@ from .sharded import collectives_active, owner_of_list, owners_of_lists
 _SEQ = 1 << 40  # row-order keys: (position of the source list) * _SEQ + row
 
 
+# Row blocks (the [n, d] vectors: 512 bytes a row at d = 128) stay in whatever memory the `local` keeps them in -- CUDA tensors
+# for GpuPartitions: extracted from the arena, routed between ranks and appended again without ever crossing PCIe -- while the
+# control data (ids, assignments, order keys: 8 bytes a row) is host numpy, where the bookkeeping that reads it lives.  The
+# three things the orchestration does with a row block, for both kinds:
+def _is_t(a):
+    import torch
+    return torch.is_tensor(a)
+
+
+def _cat_rows(blocks):
+    """concatenation of [n_i, d] blocks of one kind (at least one block)"""
+    if _is_t(blocks[0]):
+        import torch
+        return torch.cat(list(blocks), 0) if len(blocks) > 1 else blocks[0]
+    return np.concatenate(blocks) if len(blocks) > 1 else np.ascontiguousarray(blocks[0])
+
+
+def _take_rows(v, sel):
+    """v[sel] for a host selector (boolean mask or index array) over a row block of either kind"""
+    sel = np.asarray(sel)
+    if not _is_t(v):
+        return np.ascontiguousarray(v[sel])
+    import torch
+    idx = np.nonzero(sel)[0] if sel.dtype == np.bool_ else sel.astype(np.int64)
+    return v[torch.from_numpy(np.ascontiguousarray(idx)).to(v.device)]
+
+
 class Comm:
-    """The collective shapes maintenance needs, host numpy in and out, over torch.distributed (RCCL or gloo).  Tensors are
-    staged on `device` for the collective (RCCL wants device memory; gloo takes host)."""
+    """The collective shapes maintenance needs over torch.distributed (RCCL or gloo).  Control data is host numpy in and out
+    (staged on `device` for the collective: RCCL wants device memory, gloo takes host); row blocks handed to route_rows as
+    device tensors are exchanged and returned in device memory."""
 
     def __init__(self, dist=None, world=1, rank=0, device=None):
         self.dist, self.world, self.rank = dist, int(world), int(rank)
@@ -102,23 +130,35 @@ class Comm:
         ranks), in ascending key order, i.e. the order ONE rank holding every row would have seen them in."""
         dest = np.asarray(dest, dtype=np.int64)
         if not self.active:
-            return tuple(np.ascontiguousarray(a) for a in arrays)
+            return tuple(a if _is_t(a) else np.ascontiguousarray(a) for a in arrays)
         if key is not None:
             got = self.route_rows(dest, np.asarray(key, dtype=np.int64), *arrays)
             o = np.argsort(got[0], kind="stable")
-            return tuple(a[o] for a in got[1:])
+            return tuple(_take_rows(a, o) for a in got[1:])
         import torch
         order = np.argsort(dest, kind="stable")
         send = np.bincount(dest, minlength=self.world).astype(np.int64)
         recv = self.all_gather(send)[:, self.rank]
+        nrecv = int(recv.sum())
+        splits = dict(output_split_sizes=[int(v) for v in recv], input_split_sizes=[int(v) for v in send])
         out = []
         for a in arrays:
+            if _is_t(a):
+                # a row block in device memory: permuted, exchanged and handed back THERE (RCCL moves it GPU to GPU; under gloo --
+                # ranks sharing one GPU in the functional tests -- the collective itself is staged through the host)
+                src = _take_rows(a, order).contiguous()
+                stage = src.is_cuda and str(self.dist.get_backend()).lower() == "gloo"
+                sbuf = src.cpu() if stage else src
+                dst = torch.empty((nrecv,) + tuple(src.shape[1:]), dtype=src.dtype, device=sbuf.device)
+                self.dist.all_to_all_single(dst, sbuf, **splits)
+                out.append(dst.to(src.device) if stage else dst)
+                continue
             a = np.ascontiguousarray(a)
             w = int(np.prod(a.shape[1:])) if a.ndim > 1 else 1
             src = self._t(a[order].reshape(-1, w) if a.shape[0] else a.reshape(0, w))
-            dst = torch.empty((int(recv.sum()), w), dtype=src.dtype, device=src.device)
-            self.dist.all_to_all_single(dst, src, output_split_sizes=[int(v) for v in recv], input_split_sizes=[int(v) for v in send])
-            out.append(dst.cpu().numpy().reshape((int(recv.sum()),) + a.shape[1:]))
+            dst = torch.empty((nrecv, w), dtype=src.dtype, device=src.device)
+            self.dist.all_to_all_single(dst, src, **splits)
+            out.append(dst.cpu().numpy().reshape((nrecv,) + a.shape[1:]))
         return tuple(out)
 
 
@@ -139,21 +179,30 @@ class GpuPartitions:
         return int(self.ix._store.list_size(int(p)))
 
     def get_list(self, p):
-        return self.ix._store.get_list(int(p))
+        """(vectors: a CUDA tensor extracted from the arena on the device, ids: host array)"""
+        return self.ix._store.get_list_device(int(p))
+
+    def empty_rows(self):
+        import torch
+        return torch.empty((0, self.d), dtype=torch.float32, device=torch.device("cuda", self.ix._device))
 
     def add_list(self, p):
         self.ix._store.add_list(int(p))
         self.ix._next_pid = max(self.ix._next_pid, int(p) + 1)
 
     def remove_list(self, p):
-        _, ids = self.ix._store.get_list(int(p))
+        _, ids = self.ix._store.get_list_device(int(p)) if self.ix._store.list_size(int(p)) else (None, np.zeros(0, np.int64))
         self.ix._resident.discard_all(np.asarray(ids, dtype=np.int64))
         self.ix._store.remove_list(int(p))
 
     def add_entries(self, p, ids, vecs):
+        import torch
         if len(ids):
-            self.ix._store.add_entries(int(p), np.ascontiguousarray(ids, dtype=np.int64), np.ascontiguousarray(vecs, dtype=np.float32))
-            self.ix._resident.update(np.asarray(ids, dtype=np.int64))
+            ids = np.ascontiguousarray(ids, dtype=np.int64)
+            vd = vecs if torch.is_tensor(vecs) else torch.from_numpy(np.ascontiguousarray(vecs, dtype=np.float32))
+            vd = vd.to(device=torch.device("cuda", self.ix._device), dtype=torch.float32).contiguous()
+            self.ix._store.add_entries(int(p), torch.from_numpy(ids).to(vd.device), vd)
+            self.ix._resident.update(ids)
 
     def ntotal(self):
         return self.ix.ntotal()
@@ -180,6 +229,8 @@ class GpuPartitions:
     # arithmetic
     def _dev(self, x):
         import torch
+        if torch.is_tensor(x):
+            return x.to(device=torch.device("cuda", self.ix._device), dtype=torch.float32).contiguous()
         return torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).cuda(self.ix._device)
 
     def nearest(self, x, k):
@@ -188,8 +239,9 @@ class GpuPartitions:
         return self.ix._ctx.coarse(self.ix.parent._store, self._dev(x), int(k), self.ix.metric_)[0].cpu().numpy()
 
     def two_means(self, x):
+        """-> (centroids [2, d] host, assign [n] host, the rows as stored -- normalised for IP -- where x lives)"""
         cent, assign, xs = self.ix._ctx.kmeans(self._dev(x), 2, self.ix.metric_, niter=5, seed=1234)
-        return cent.cpu().numpy(), assign.cpu().numpy(), xs.cpu().numpy()
+        return cent.cpu().numpy(), assign.cpu().numpy(), xs
 
     def kmeans_assign(self, x, c):
         if len(x) == 0:
@@ -223,6 +275,11 @@ class ShardedPartitions:
 
     def owner(self, p):
         return owner_of_list(p, self.world)
+
+    def _empty_rows(self):
+        """a row block of no rows, of the kind the `local` keeps its rows in (device tensor / host array)"""
+        f = getattr(self.local, "empty_rows", None)
+        return f() if f is not None else np.zeros((0, self.d()), np.float32)
 
     def owns(self, p):
         return self.owner(p) == self.rank
@@ -290,10 +347,10 @@ class ShardedPartitions:
                 c, a, vs = self.local.two_means(v)
                 cent[2 * j:2 * j + 2] = c
                 for h in range(2):
-                    vecs.append(np.ascontiguousarray(vs[a == h]))
+                    vecs.append(_take_rows(vs, a == h))
                     ids.append(np.ascontiguousarray(i[a == h]))
             else:
-                vecs += [np.zeros((0, d), np.float32)] * 2
+                vecs += [self._empty_rows()] * 2
                 ids += [np.zeros(0, np.int64)] * 2
         g = self.comm.all_gather(cent)  # rows of a split come from the rank that owns the partition
         for j, p in enumerate(pids):
@@ -306,23 +363,21 @@ class ShardedPartitions:
         self._next_pid += n
         slot = np.concatenate([np.full(len(i), j, np.int64) for j, i in enumerate(clustering["vector_ids"])]) if n else np.zeros(0, np.int64)
         dest = owners_of_lists(np.asarray(new_pids, np.int64)[slot], self.world)
-        d = self.d()
-        v = np.concatenate(clustering["vectors"]) if n else np.zeros((0, d), np.float32)
+        v = _cat_rows(clustering["vectors"]) if n else self._empty_rows()
         i = np.concatenate(clustering["vector_ids"]) if n else np.zeros(0, np.int64)
-        rslot, rv, ri = self.comm.route_rows(dest, slot, v.reshape(-1, d), i)
+        rslot, rv, ri = self.comm.route_rows(dest, slot, v, i)
         for j, pid in enumerate(new_pids):
             self.local.add_list(pid)
             if self.owns(pid):
                 m = rslot == j
-                self.local.add_entries(pid, ri[m], rv[m])
+                self.local.add_entries(pid, ri[m], _take_rows(rv, m))
         self.local.add_centroids(clustering["centroids"], new_pids)
         self._refresh_sizes()
         return new_pids
 
     # -- delete (:522-554) -----------------------------------------------------------------------------------------------------
     def _delete_partitions(self, pids, reassign=True):
-        d = self.d()
-        held_v, held_i, held_k = [np.zeros((0, d), np.float32)], [np.zeros(0, np.int64)], [np.zeros(0, np.int64)]
+        held_v, held_i, held_k = [self._empty_rows()], [np.zeros(0, np.int64)], [np.zeros(0, np.int64)]
         for j, p in enumerate(pids):
             if self.owns(p) and reassign:
                 v, i = self.local.get_list(p)
@@ -333,13 +388,13 @@ class ShardedPartitions:
         for p in pids:
             self.local.remove_list(p)
         if reassign:
-            v, i = np.concatenate(held_v), np.concatenate(held_i)
+            v, i = _cat_rows(held_v), np.concatenate(held_i)
             target = self.local.nearest(v, 1).reshape(-1)  # nearest REMAINING centroid (PartitionManager::add, :219-230)
-            dest = np.array([self.owner(t) for t in target], np.int64)
+            dest = owners_of_lists(target, self.world)
             rt, rv, ri = self.comm.route_rows(dest, target, v, i, key=np.concatenate(held_k))
             for t in np.unique(rt):
                 m = rt == t
-                self.local.add_entries(int(t), ri[m], rv[m])
+                self.local.add_entries(int(t), ri[m], _take_rows(rv, m))
         self._refresh_sizes()
 
     # -- local refinement (:446-487 -> kmeans_refine_partitions, clustering.cpp:99-182) -----------------------------------------
@@ -352,14 +407,14 @@ class ShardedPartitions:
             raise RuntimeError("refine_partitions: duplicate partition")
         m, d = len(pids), self.d()
         c = np.ascontiguousarray(self.local.centroids(pids), dtype=np.float32)
-        xs, ids, seq = [np.zeros((0, d), np.float32)], [np.zeros(0, np.int64)], [np.zeros(0, np.int64)]
+        xs, ids, seq = [self._empty_rows()], [np.zeros(0, np.int64)], [np.zeros(0, np.int64)]
         for j, p in enumerate(pids):
             if self.owns(p):
                 v, i = self.local.get_list(p)
                 xs.append(v)
                 ids.append(i)
                 seq.append(_SEQ * j + np.arange(len(i), dtype=np.int64))  # position in the concatenation of the lists (:104-108)
-        x, ids, seq = np.concatenate(xs), np.concatenate(ids), np.concatenate(seq)
+        x, ids, seq = _cat_rows(xs), np.concatenate(ids), np.concatenate(seq)
         total = int(self.comm.all_sum(np.array([len(ids)], np.int64))[0])
         sums = counts = a = None
         for it in range(max(int(iterations), 1)):  # clustering.cpp:110
@@ -375,7 +430,7 @@ class ShardedPartitions:
                 sums += g[r]
             counts = self.comm.all_sum(pc)
             order = np.argsort(a, kind="stable")  # the per-vector append into the new partitions (:174)
-            x, ids, a, seq = x[order], ids[order], a[order], seq[order]
+            x, ids, a, seq = _take_rows(x, order), ids[order], a[order], seq[order]
             # position of every row in the order ONE process would hold them in after this pass: by (list it was appended to,
             # position before the pass) -- the stable sort above, made global: its rank among all ranks' previous positions
             # (local rows stay in ascending position order, which the next pass's stable sort relies on)
@@ -395,7 +450,7 @@ class ShardedPartitions:
         for j, p in enumerate(pids):
             if self.owns(p):
                 sel = ra == j
-                self.local.add_entries(p, ri[sel], rx[sel])
+                self.local.add_entries(p, ri[sel], _take_rows(rx, sel))
         self.local.set_centroids(pids, c)  # parent_->modify (:478): "the centroids used for the last assignment"
         self._refresh_sizes()
 
@@ -460,6 +515,7 @@ class ShardedQuakeIndex:
         self.engine = GpuEngine(index._ctx, index.parent._store, index._store, self.local.metric)
         self.searcher = ShardedIndex(self.engine, dist, world, rank, result=result)
         self.track_hits = False
+        self._pending_hits = []  # [Q, nprobe] lists of tracked searches not yet handed to the policy (device tensors)
 
     # -- construction ---------------------------------------------------------------------------------------------------------
     @classmethod
@@ -485,11 +541,12 @@ class ShardedQuakeIndex:
         a = a.cpu().numpy()
         comm = Comm(dist, world, rank)
         dest = owners_of_lists(a, world)
-        ra, rx, ri = comm.route_rows(dest, a, xd.cpu().numpy(), np.asarray(ids, dtype=np.int64))  # IP: the normalised copy
+        # the rows travel GPU to GPU (IP: the normalised copy); assignments and ids -- 16 bytes a row -- through the host
+        ra, rx, ri = comm.route_rows(dest, a, xd, np.asarray(ids, dtype=np.int64))
         order = np.argsort(ra, kind="stable")
         offsets = np.zeros(int(nlist) + 1, np.int64)
         offsets[1:] = np.cumsum(np.bincount(ra, minlength=int(nlist)))
-        ix = QuakeIndex.from_partitions(c, offsets, ri[order], rx[order], metric, device)
+        ix = QuakeIndex.from_partitions(c, offsets, ri[order], _take_rows(rx, order), metric, device)
         return cls(ix, dist, world, rank, result)
 
     # -- search / add / remove ---------------------------------------------------------------------------------------------------
@@ -515,16 +572,39 @@ class ShardedQuakeIndex:
                 self.searcher.result, self.track_hits = was, was_track
             if self.track_hits:
                 p = self.searcher.last_pids
-                self.partitions.record_query_hits((p.cpu().numpy() if torch.is_tensor(p) else np.asarray(p))[:n])
+                self._pending_hits.append(p[:n].clone() if torch.is_tensor(p) else np.array(p[:n]))
+                if len(self._pending_hits) >= 64:
+                    self._flush_hits()
             from .index import SearchResult
             res = SearchResult()
             res.ids, res.distances = ids[:n].cpu(), dist[:n].cpu()
             return res
         out = self.searcher.search(q, int(nprobe), int(k))
         if self.track_hits:
+            # the batch's [Q, nprobe] lists stay where the all-gather left them (a copy: the buffer is reused by the next search);
+            # they cross to the host in ONE transfer when the policy needs them (maintenance(), or 64 batches pending) -- a
+            # search with hit tracking on does not synchronise the device
             p = self.searcher.last_pids
-            self.partitions.record_query_hits(p.cpu().numpy() if torch.is_tensor(p) else np.asarray(p))
+            self._pending_hits.append(p.clone() if torch.is_tensor(p) else np.array(p))
+            if len(self._pending_hits) >= 64:
+                self._flush_hits()
         return out
+
+    def _flush_hits(self):
+        import torch
+        pend, self._pending_hits = self._pending_hits, []
+        if not pend:
+            return
+        if all(torch.is_tensor(p) for p in pend) and len({tuple(p.shape[1:]) for p in pend}) == 1:
+            sizes = [int(p.shape[0]) for p in pend]
+            host = torch.cat(pend, 0).cpu().numpy()  # one transfer
+            at = 0
+            for n in sizes:
+                self.partitions.record_query_hits(host[at:at + n])
+                at += n
+            return
+        for p in pend:
+            self.partitions.record_query_hits(p.cpu().numpy() if torch.is_tensor(p) else np.asarray(p))
 
     def add(self, x, ids):
         """x [n, d], ids [n] on every rank; each rank stores the rows whose nearest list it owns"""
@@ -552,6 +632,7 @@ class ShardedQuakeIndex:
         self.partitions.initialize_maintenance_policy(params, cost_estimator)
 
     def maintenance(self):
+        self._flush_hits()
         return self.partitions.maintenance()
 
     def refine_partitions(self, partition_ids=None, iterations=0):

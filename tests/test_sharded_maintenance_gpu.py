@@ -81,7 +81,9 @@ def _same_lists(sh, ix, rank, world, ordered=True):
     b = ix.parent.get(torch.tensor(pids, dtype=torch.int64)).numpy()
     assert (a.view(np.uint32) == b.view(np.uint32)).all()
     for p in pids:
-        v, i = sh.local.get_list(p)
+        v, i = sh.local.get_list(p)  # (the product `local` keeps row blocks on the device: CUDA tensor + host ids)
+        assert torch.is_tensor(v) and v.is_cuda
+        v = v.cpu().numpy()
         rv, ri = ix._store.get_list(p)
         if p % world != rank:
             assert len(i) == 0, p
