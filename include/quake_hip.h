@@ -86,6 +86,13 @@ QK_API int qk_ctx_set_null_stream(qk_ctx *ctx);
  * kind 0 = the private stream (restore with qk_ctx_set_stream(ctx, NULL)), 1 = the NULL stream (qk_ctx_set_null_stream),
  * 2 = a caller-owned stream (*hip_stream; qk_ctx_set_stream(ctx, *hip_stream)). */
 QK_API int qk_ctx_get_stream(qk_ctx *ctx, void **hip_stream, int *kind);
+/* Form feedback (default on): the partition scan has several forms with identical results (16 x 16 tiles, per-wave row-per-lane
+ * walk, mixed sequence with dense hot items); which is fastest depends on how the batch's queries concentrate on lists, which
+ * the host cannot see.  With feedback on, a context times whole scan calls per (store, batch shape) with HIP events it reads
+ * back later without synchronising, tries every admissible form twice, then uses the fastest and re-checks the others every
+ * few hundred calls.  Off: the static rule alone (what the first call of a shape always uses).  No reference counterpart:
+ * the reference picks serial / batched / worker scans by SearchParams (query_coordinator.cpp:612-673). */
+QK_API int qk_ctx_set_form_feedback(qk_ctx *ctx, int enabled);
 QK_API int qk_ctx_synchronize(qk_ctx *ctx);
 /* hipEvent timing of the phases, recorded on the context's stream around the kernels:
  *   0 off; 1 per call (the qk_timing* passed to qk_scan/qk_search is filled, which synchronises the stream);

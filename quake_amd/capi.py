@@ -96,6 +96,10 @@ class Context:
     def synchronize(self):
         check(self.lib.qk_ctx_synchronize(self.h))
 
+    def set_form_feedback(self, enabled):
+        """measured choice between the scan forms per batch shape (default on); off = the static rule alone"""
+        check(self.lib.qk_ctx_set_form_feedback(self.h, int(bool(enabled))))
+
     def set_stream(self, hip_stream):
         """hip_stream: a hipStream_t handle (e.g. torch.cuda.current_stream().cuda_stream); 0 = the device's NULL stream
         (torch's default stream); None = back to the context's private stream."""

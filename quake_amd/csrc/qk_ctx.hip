@@ -59,6 +59,10 @@ int qk_ctx_destroy(qk_ctx *c) {
     if (c->overflow_host) hipHostFree(c->overflow_host);
     if (c->xcd_host) hipHostFree(c->xcd_host);
     if (c->xcd_ev) hipEventDestroy(c->xcd_ev);
+    for (auto &f : c->form_stats) {
+        if (f.e0) hipEventDestroy(f.e0);
+        if (f.e1) hipEventDestroy(f.e1);
+    }
     if (c->stream_ev) hipEventDestroy(c->stream_ev);
     for (auto &e : c->ev)
         if (e) hipEventDestroy(e);
@@ -97,6 +101,12 @@ int qk_ctx_get_stream(qk_ctx *c, void **hip_stream, int *kind) {
     if (!c || !hip_stream || !kind) QK_FAIL(QK_ERR_INVALID, "qk_ctx_get_stream: null argument");
     *hip_stream = (void *)c->stream;
     *kind = c->stream == c->own_stream ? 0 : (c->stream == nullptr ? 1 : 2);
+    return QK_OK;
+}
+
+int qk_ctx_set_form_feedback(qk_ctx *c, int enabled) {
+    if (!c) QK_FAIL(QK_ERR_INVALID, "qk_ctx_set_form_feedback: ctx is null");
+    c->form_feedback = enabled != 0;
     return QK_OK;
 }
 

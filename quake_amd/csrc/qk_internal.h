@@ -88,6 +88,21 @@ struct qk_ctx {
     unsigned long long *qprep_best64 = nullptr;  // [Q] set to ~0 by the prep kernel; valid while qprep_best64_n == Q
     int64_t qprep_best64_n = 0;
     const char *last_scan_kernel = "";  // form of the last scan launch (qk_ctx_last_scan_kernel)
+    // Which form of the partition scan serves a batch shape best is measured, not only modelled (qk_scan.hip, "form feedback"):
+    // per (store, Q / 64, nprobe, k, metric) the context keeps the mean device time of a whole scan call -- grouping, scan
+    // kernel, merge: HIP events around it, read back without synchronising -- under each of the forms the shape admits.
+    struct form_stat {
+        uint64_t key = 0;
+        float ms[3] = {0.f, 0.f, 0.f};  // 0: 16 x 16 tile form (k_scan, plain or query-sharing), 1: per-wave walk (k_scan_rl), 2: mixed
+        int n[3] = {0, 0, 0};           // measurements taken
+        int64_t calls = 0, last_use = 0;
+        int pending = -1;               // form whose event pair is in flight
+        int rr = 0;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+    };
+    std::vector<form_stat> form_stats;
+    int64_t form_clock = 0;
+    bool form_feedback = true;          // qk_ctx_set_form_feedback
     int *overflow_host = nullptr;    // pinned, device-visible: a scan kernel sets it when its record buffer overflows
     int *overflow_dev = nullptr;
     char *qprep_zero = nullptr;      // region cleared by the prep kernel for the scan of the same batch

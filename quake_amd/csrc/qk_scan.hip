@@ -1251,6 +1251,80 @@ static int launch_scan(int db, int maxch, dim3 grid, dim3 block, size_t lds, hip
 
 static int pick_maxch(int cap) { return cap <= 64 ? 1 : cap <= 128 ? 2 : cap <= 256 ? 4 : 8; }
 
+// form feedback (see qk_scan_device): the form to use for this call of the shape `key`; *measure is set when the call is to be
+// timed (the caller records measure->e0 / e1 around its launches)
+static int qk_pick_form(qk_ctx *ctx, uint64_t key, int form_static, const bool admissible[3], qk_ctx::form_stat **measure) {
+    *measure = nullptr;
+    qk_ctx::form_stat *st = nullptr;
+    for (auto &f : ctx->form_stats)
+        if (f.key == key) st = &f;
+    if (!st) {
+        if (ctx->form_stats.size() >= 32) {  // recycle the entry that has not been used for longest (its events stay)
+            st = &ctx->form_stats[0];
+            for (auto &f : ctx->form_stats)
+                if (f.last_use < st->last_use) st = &f;
+            hipEvent_t e0 = st->e0, e1 = st->e1;
+            if (st->pending >= 0 && hipEventSynchronize(e1) != hipSuccess) (void)hipGetLastError();
+            *st = qk_ctx::form_stat();
+            st->e0 = e0;
+            st->e1 = e1;
+        } else {
+            ctx->form_stats.emplace_back();
+            st = &ctx->form_stats.back();
+        }
+        st->key = key;
+    }
+    st->calls++;
+    st->last_use = ++ctx->form_clock;
+    if (!st->e0 && (hipEventCreate(&st->e0) != hipSuccess || hipEventCreate(&st->e1) != hipSuccess)) {
+        (void)hipGetLastError();
+        return form_static;
+    }
+    if (st->pending >= 0) {  // harvest the measurement in flight, if the device is past it
+        const hipError_t q = hipEventQuery(st->e1);
+        if (q == hipSuccess) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, st->e0, st->e1) == hipSuccess && ms > 0.f) {
+                const int f = st->pending;
+                // (the first call of a form pays one-off costs -- function attributes, cold instruction cache: keep the smaller
+                //  of the first two, then a running mean)
+                st->ms[f] = st->n[f] == 0 ? ms : st->n[f] == 1 ? std::min(st->ms[f], ms) : 0.75f * st->ms[f] + 0.25f * ms;
+                st->n[f]++;
+            } else {
+                (void)hipGetLastError();
+            }
+            st->pending = -1;
+        } else {
+            (void)hipGetLastError();  // hipErrorNotReady
+        }
+    }
+    int best = -1;
+    for (int f = 0; f < 3; f++)
+        if (admissible[f] && st->n[f] >= 2 && (best < 0 || st->ms[f] < st->ms[best])) best = f;
+    if (st->pending >= 0) return best >= 0 ? best : form_static;  // one measurement at a time
+    int next = -1;
+    if (st->n[form_static] < 2) {
+        next = form_static;
+    } else {
+        for (int f = 0; f < 3 && next < 0; f++)
+            if (admissible[f] && st->n[f] < 2) next = f;
+    }
+    if (next < 0 && best >= 0 && st->calls % 512 == 0) {  // re-check a form that lost (the data under the index changes)
+        for (int t = 0; t < 3 && next < 0; t++) {
+            const int f = (st->rr + t) % 3;
+            if (admissible[f] && f != best) next = f;
+        }
+        st->rr = (next + 1) % 3;
+    }
+    if (next < 0 && best >= 0 && st->calls % 64 == 0) next = best;  // keep the winner's figure current
+    if (next >= 0) {
+        st->pending = next;
+        *measure = st;
+        return next;
+    }
+    return best >= 0 ? best : form_static;
+}
+
 int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *timing, int ev_base) {
     const int64_t Q = a.Q;
     const bool emit = a.key_out != nullptr;  // key emission for qk_widek_device: no top-k, k plays no role here
@@ -1344,7 +1418,9 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
     // Row-per-lane form (qk_scan_rl.hip, v_mfma_f32_4x4x1_16b_f32: 64 rows x 4 queries per instruction): narrow rows, k <= 32,
     // whole prepared batch.  The matrix work follows the live queries in steps of 4 and a pass over a partition serves up to
     // 32 queries from one read of its rows -- the regime where several queries of the batch probe the same partition.
-    bool use_rl = false;
+    const int nw_tile = nw, qshare_tile = qshare, C_tile = C;  // the 16 x 16 tile form's geometry (form 0)
+    bool use_rl = false, rl_avail = false;
+    int C_walk = C;
     int64_t rl_per_list = 0;
     RlCost rlc{12, 8, 1, 16, 4, 32};
     int rl_app = 32;
@@ -1392,17 +1468,16 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
         const bool rl_ok = nblk <= 8 && k <= 32 && rl_fits && !a.per_pair && !emit && npairs > 0 && ctx->qprep_xp4 != nullptr &&
                            a.xq4 == (const float4 *)ctx->qprep;
         use_rl = rl_ok && (rl_env == 1 || (rl_env < 0 && per_list < rl_max && P > 1));
+        rl_avail = rl_ok && rl_env != 0 && P > 1;
+        C_walk = C_rl;
         rl_per_list = per_list;
-        if (use_rl) {
-            nw = 1;
-            qshare = 0;
-            C = C_rl;
-        }
     }
     // Mixed work sequence (qk_scan_rl.hip, HOT form): lists probed by >= hot.min queries of the batch become dense items on
     // v_mfma_f32_16x16x4_f32 claimed by whole workgroups; the block width hq is what the workgroup's LDS (the four waves' slices
     // of the per-wave form together) holds next to one pool of C entries per query.
-    HotCost hot{0, 0, 0, 0, 0, 0, 0, 0};
+    HotCost hot{0, 0, 0, 0, 0, 0, 0, 0}, hot_cand{0, 0, 0, 0, 0, 0, 0, 0};
+    bool mixed_avail = false, mixed_static = false;
+    int C_mixed = C;
     {
         // Measured (10M x 128, 1024 queries, k = 10, scripts/nprobe_sweep.py; kernel ms per-wave walk alone -> mixed, lists with
         // >= 13 probing queries hot): skewed mixture nprobe 8 / 16 / 32 / 64: 0.461 / 0.623 / 1.027 / 1.808 -> 0.474 / 0.512 / 0.632 /
@@ -1444,7 +1519,7 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
         const bool rl_possible = nblk <= 8 && k <= 32 && rl_waves == 4 && rlc.qb == 32 && !a.per_pair && !emit && npairs >= 1024 && P > 1 &&
                                  ctx->qprep_xp4 != nullptr && a.xq4 == (const float4 *)ctx->qprep && rl_env2 != 0 &&
                                  4 * ((qk_scan_rl_lds_per_wave(nblk, std::min(64, qk_round_up(k + 32, 4)), rlc.qb) + 15) & ~(size_t)15) <= (size_t)160 * 1024;
-        if (rl_possible && hot_min > 0 && rl_per_list >= hot_per_list && long_lists) {
+        if (rl_possible && hot_min > 0 && long_lists) {
             const int C_rl2 = std::min(64, qk_round_up(k + 32, 4));
             const size_t per_wave = std::max<size_t>((qk_scan_rl_lds_per_wave(nblk, C_rl2, rlc.qb) + 15) & ~(size_t)15, (size_t)(160 * 1024) / 4 - 512) & ~(size_t)15;
             // (pools of k + 22 entries: appends come four at a time at most, and a block's pools share the LDS with its query
@@ -1453,14 +1528,54 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
             int hq = std::min(128, std::max(16, hot_hq)) & ~15;
             while (hq >= 32 && qk_scan_hot_lds(nblk, C_hot, hq) > 4 * per_wave) hq -= 16;
             if (hq >= 32) {
-                hot = HotCost{std::max(hot_min, 1), hq, std::max(16, hot_unit), std::max(1, hot_w10), std::max(1, hot_ht10), std::max(0, hot_ovh), C_hot, std::max(16, hot_min_rows)};
-                // the mixed form serves every sharing level: it replaces the query-sharing form of k_scan too
-                use_rl = true;
-                nw = 1;
-                qshare = 0;
-                C = C_rl2;
+                hot_cand = HotCost{std::max(hot_min, 1), hq, std::max(16, hot_unit), std::max(1, hot_w10), std::max(1, hot_ht10), std::max(0, hot_ovh), C_hot, std::max(16, hot_min_rows)};
+                // the mixed form serves every sharing level: by the static rule it replaces the query-sharing form of k_scan too
+                mixed_avail = true;
+                mixed_static = rl_per_list >= hot_per_list;
+                C_mixed = C_rl2;
             }
         }
+    }
+    // ---- form feedback --------------------------------------------------------------------------------------------------
+    // The static rule above knows index-wide means; how the queries of THIS batch concentrate on lists it cannot see, and that
+    // decides: 1024 queries around a few neighbouring clusters of a 1M x 128 index in 400 lists (the "skewed" batches of the
+    // dynamic workload, BASELINE.json configs[4]): scan 235 us on the query-sharing tile form, 760 us mixed (every list hot, most
+    // row tiles true candidates: the prefilter skips nothing and the items' pools are appended to under locks); the same batch
+    // shape spread over the whole 10M x 128 bench index: 403 us mixed, 478 us on the walk (scripts/skew_probe.py).  So the forms
+    // a shape admits are MEASURED: whole calls (grouping + scan + merge) between two HIP events, read back at a later call
+    // without synchronising; every admissible form twice, then the fastest, the others re-checked every 512 calls.  All forms
+    // give the same bits (the parity suites run each of them), so which one answers is invisible to the caller.
+    const int form_static = mixed_static ? 2 : use_rl ? 1 : 0;
+    int form = form_static;
+    qk_ctx::form_stat *fmeasure = nullptr;
+    {
+        const bool admissible[3] = {true, rl_avail, mixed_avail};
+        if (ctx->form_feedback && !a.per_pair && !emit && npairs >= 1024 && P > 1 && (rl_avail || mixed_avail)) {
+            const uint64_t key = (s->uid * 0x9E3779B97F4A7C15ull) ^ ((uint64_t)(Q >> 6) << 40) ^ ((uint64_t)P << 24) ^ ((uint64_t)k << 8) ^ (uint64_t)a.metric;
+            form = qk_pick_form(ctx, key, form_static, admissible, &fmeasure);
+        }
+    }
+    if (fmeasure && hipEventRecord(fmeasure->e0, ctx->stream) != hipSuccess) {
+        (void)hipGetLastError();
+        fmeasure->pending = -1;
+        fmeasure = nullptr;
+    }
+    if (form == 2) {
+        hot = hot_cand;
+        use_rl = true;
+        nw = 1;
+        qshare = 0;
+        C = C_mixed;
+    } else if (form == 1) {
+        use_rl = true;
+        nw = 1;
+        qshare = 0;
+        C = C_walk;
+    } else {
+        use_rl = false;
+        nw = nw_tile;
+        qshare = qshare_tile;
+        C = C_tile;
     }
     const int maxch = pick_maxch(C);
     const size_t lds_scan = use_rl ? ((qk_scan_rl_lds_per_wave(nblk, C, rlc.qb) + 15) & ~(size_t)15)
@@ -2010,6 +2125,10 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
     mp.sqrt_l2 = a.sqrt_l2 ? 1 : 0;
     const dim3 mgrid((unsigned)(a.per_pair ? Q * P : Q));
     QK_TRY(qk_launch_merge(ctx, mp, mgrid));
+    if (fmeasure && hipEventRecord(fmeasure->e1, ctx->stream) != hipSuccess) {
+        (void)hipGetLastError();
+        fmeasure->pending = -1;
+    }
     QK_TRY(pe.mark(3));
     if (timing) {
         // device scalars come back through pinned memory; the caller synchronises before reading them

@@ -27,6 +27,7 @@ def ctx():
     from quake_amd.capi import Context
     c = Context(0)
     c.set_stream(torch.cuda.current_stream().cuda_stream)
+    c.set_form_feedback(False)  # the forms asserted below are the static rule's
     yield c
     c.close()
 

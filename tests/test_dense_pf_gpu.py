@@ -172,3 +172,32 @@ def test_huge_batches_leave_the_prefiltered_form(ctx):
     _check(ctx, parent, cent, q, 1, "l2")
     _check(ctx, parent, cent, q[:5000], 1, "l2")
     parent.close()
+
+
+@pytest.mark.parametrize("metric", ["l2", "ip"])
+@pytest.mark.parametrize("n", [8192, 4096])   # the prefiltered form and (at k = 40) the one-launch form below it
+def test_bound_adversarial_at_the_kth_key(ctx, metric, n):
+    """centroids whose keys lie within one bf16 rounding step of a query's k-th best -- clusters of near-copies
+    scale * (base + 2^-12 noise) at scales 2^-20 .. 2^+20, with exact duplicates straddling the cut -- so that the approximate
+    products say nothing about their order and only the one-sided bounds (group minima, candidate filter) keep every true
+    member a candidate.  The coarse step must return the oracle's ids and distance bits for k inside, at and beyond the size
+    of a cluster of near-copies."""
+    rng = np.random.default_rng(n + (metric == "ip"))
+    d = 96
+    scales = [2.0 ** -20, 2.0 ** -10, 1.0, 2.0 ** 10, 2.0 ** 20]
+    per = n // len(scales)
+    bases = rng.standard_normal((len(scales), d)).astype(np.float32)
+    rows = []
+    for j, sc in enumerate(scales):
+        m = per if j < len(scales) - 1 else n - per * (len(scales) - 1)
+        c = (sc * (bases[j] + 2.0 ** -12 * rng.standard_normal((m, d)))).astype(np.float32)
+        c[:30] = c[30:60]  # exact duplicates
+        rows.append(c)
+    cent = np.ascontiguousarray(np.concatenate(rows), np.float32)
+    ids = rng.permutation(n).astype(np.int64) + 5
+    parent = _parent(ctx, cent, ids)
+    which = rng.integers(0, len(scales), size=320)
+    q = np.stack([scales[w] * (bases[w] + 2.0 ** -9 * rng.standard_normal(d)) for w in which]).astype(np.float32)
+    for k in (2, 8, 40, 64):
+        _check(ctx, parent, cent, q, k, metric, ids)
+    parent.close()

@@ -1,0 +1,55 @@
+"""Form feedback (qk_ctx_set_form_feedback, qk_scan.hip): repeated searches of one batch shape are answered by whichever form of
+the partition scan -- 16 x 16 tiles, per-wave walk, mixed sequence -- MEASURED fastest on that shape; the answer is the same
+bits under every form, so the choice must be invisible: ids and distances of every call equal the oracle's
+(query_coordinator.cpp:612-799), whatever the context is trying at the moment."""
+import numpy as np
+import pytest
+
+import oracle as O
+from helpers import make_ivf, make_queries
+
+pytestmark = pytest.mark.gpu
+
+
+def _stores(ctx, ivf):
+    from quake_amd.capi import Store
+    s = Store(ctx, ivf["d"])
+    s.build_csr(ivf["offsets"], ivf["ids"], ivf["vecs"])
+    parent = Store(ctx, ivf["d"])
+    parent.build_csr(np.array([0, ivf["nlist"]], np.int64), np.arange(ivf["nlist"], dtype=np.int64), ivf["centroids"])
+    return parent, s
+
+
+@pytest.mark.parametrize("concentrated", [True, False])
+def test_every_call_is_the_oracles_answer_whatever_form_runs(concentrated):
+    import torch
+    from quake_amd.capi import Context
+    ctx = Context(0)
+    ivf = make_ivf(200000, 64, 64, seed=21)  # 3125 rows per list: long lists, all three forms admissible at nprobe 4
+    parent, s = _stores(ctx, ivf)
+    rng = np.random.default_rng(22)
+    if concentrated:  # every query next to one of three rows: the whole batch lands on a handful of lists
+        q = (ivf["x"][rng.integers(0, 3, 1024)] + 0.05 * rng.standard_normal((1024, 64))).astype(np.float32)
+    else:
+        q = make_queries(1024, 64, seed=23, like=ivf["x"])
+    oi, od = O.search(q, ivf["centroids"], ivf["vecs"], ivf["ids"], ivf["offsets"], 4, 10, "l2", batched_scan=True)
+    forms = []
+    qd = torch.from_numpy(q).cuda()
+    for rep in range(40):
+        gi, gd = ctx.search(parent, s, qd, 4, 10, "l2")
+        torch.cuda.synchronize()  # (so that the measurement in flight is ready for the next call to read)
+        forms.append(ctx.last_scan_kernel())
+        np.testing.assert_array_equal(gi.cpu().numpy(), oi, err_msg=f"rep {rep} form {forms[-1]}")
+        np.testing.assert_array_equal(gd.cpu().numpy().view(np.uint32), od.view(np.uint32), err_msg=f"rep {rep} form {forms[-1]}")
+    assert forms[0] == "k_scan_rl (mixed)"                      # the static rule answers the first call of a shape
+    tried = set(forms)
+    assert {"k_scan_rl (mixed)", "k_scan_rl"} <= tried and any(f.startswith("k_scan") and "rl" not in f for f in tried), tried
+    assert len(set(forms[-12:])) == 1, forms                    # ... and the context settles on one form
+    # feedback off: the static rule, always
+    ctx.set_form_feedback(False)
+    for _ in range(3):
+        ctx.search(parent, s, qd, 4, 10, "l2")
+        assert ctx.last_scan_kernel() == "k_scan_rl (mixed)"
+    s.close()
+    parent.close()
+    ctx.close()

@@ -16,6 +16,7 @@ pytestmark = pytest.mark.gpu
 def ctx():
     from quake_amd.capi import Context
     c = Context(0)
+    c.set_form_feedback(False)  # this module pins WHICH form answers: the static rule alone (feedback: test_scan_feedback_gpu.py)
     yield c
     c.close()
 

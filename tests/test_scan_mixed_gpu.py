@@ -16,6 +16,7 @@ pytestmark = pytest.mark.gpu
 def ctx():
     from quake_amd.capi import Context
     c = Context(0)
+    c.set_form_feedback(False)  # this module pins WHICH form answers: the static rule alone (feedback: test_scan_feedback_gpu.py)
     yield c
     c.close()
 
@@ -196,5 +197,43 @@ def test_prefilter_bound_with_unequal_norms(ctx, metric):
     q = (100.0 * (base[rng.integers(0, 2, size=Q)] + 0.05 * rng.standard_normal((Q, 64)))).astype(np.float32)
     pids = skewed_pids(Q, 4, nlist, {0: 512, 1: 400}, rng)
     for k in (10, 32):
+        check(ctx, s, ivf, np.ascontiguousarray(q), pids, k, metric)
+    s.close()
+
+
+@pytest.mark.parametrize("metric", ["l2", "ip"])
+def test_prefilter_adversarial_at_the_kth_key(ctx, metric):
+    """The one place a silent recall loss could hide behind green random tests (round-3 review): rows whose keys sit within ONE
+    bf16 rounding step of the query's k-th best -- the approximate products of hundreds of rows are equal or out of order, so
+    the prefilter's one-sided bound alone decides which row tiles get their exact chain -- in lists whose norms span 2^-20 ..
+    2^+20 (the slack of the bound scales with |x|^2 + |y|^2).  Every hot list holds ~2000 rows of the form
+    scale * (base + eps * noise) with eps = 2^-12 (a sixteenth of a bf16 step) around one base vector, probed by queries
+    scale * (base + small offset): the exact order among the rows is decided 4-5 decimal digits below what bf16 resolves.
+    Ids and distance bits must equal the oracle's, as everywhere."""
+    rng = np.random.default_rng(97)
+    d, nlist = 64, 300
+    scales = [2.0 ** -20, 2.0 ** -10, 1.0, 2.0 ** 10, 2.0 ** 20]
+    sizes = rng.integers(1400, 1600, size=nlist)
+    sizes[:len(scales)] = 2000
+    ivf = make_sized_ivf(sizes, d, seed=98)
+    x = ivf["vecs"]
+    bases = rng.standard_normal((len(scales), d)).astype(np.float32)
+    for j, sc in enumerate(scales):
+        lo, hi = int(ivf["offsets"][j]), int(ivf["offsets"][j + 1])
+        x[lo:hi] = (sc * (bases[j] + 2.0 ** -12 * rng.standard_normal((hi - lo, d)))).astype(np.float32)
+        x[lo:lo + 40] = x[lo + 40:lo + 80]          # exact duplicates on top: ties on the k-th key, (key, id) decides
+    if metric == "ip":
+        pass  # (raw inner products: rows of the same direction and nearly equal length -- the hardest case for the IP bound)
+    s = build(ctx, ivf)
+    Q = 640
+    which = rng.integers(0, len(scales), size=Q)
+    q = np.stack([scales[w] * (bases[w] + 2.0 ** -9 * rng.standard_normal(d)) for w in which]).astype(np.float32)
+    # every query probes "its" scale's list (hot: ~128 probing queries each) + three cold lists
+    pids = np.full((Q, 4), -1, np.int64)
+    cold = np.arange(len(scales), nlist)
+    for r in range(Q):
+        pids[r, 0] = which[r]
+        pids[r, 1:] = rng.choice(cold, size=3, replace=False)
+    for k in (1, 10, 32):
         check(ctx, s, ivf, np.ascontiguousarray(q), pids, k, metric)
     s.close()
