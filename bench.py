@@ -215,6 +215,14 @@ def timed_region(ctx, step, nprobe, steps, warmup, settle, dist, dev, ctxs=None)
 
     for c in ctxs:
         c.set_timing(0)
+    # form feedback (qk_ctx_set_form_feedback): a context measures the admissible forms of the scan on the first calls of a
+    # shape -- each twice, one measurement in flight at a time, read back at a later call.  Give it synchronised calls to finish
+    # that before anything is timed (a few of them run a form that loses: they belong to the untimed part)
+    for c_i in range(nc):
+        for i in range(16):
+            step(nprobe, i % N_BATCHES, c_i)
+            ctxs[c_i].synchronize()
+            torch.cuda.synchronize()
     for i in range(max(settle, 0)):
         step(nprobe, i % N_BATCHES, i % nc)
     for i in range(warmup):

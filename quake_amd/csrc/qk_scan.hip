@@ -1286,6 +1286,11 @@ static int qk_pick_form(qk_ctx *ctx, uint64_t key, int form_static, const bool a
             float ms = 0.f;
             if (hipEventElapsedTime(&ms, st->e0, st->e1) == hipSuccess && ms > 0.f) {
                 const int f = st->pending;
+                if (st->n[f] >= 2 && (ms > 1.5f * st->ms[f] || ms < 0.6f * st->ms[f])) {
+                    // the same shape takes a very different time: the batches changed (how the queries concentrate on lists is
+                    // not part of the key) -- every form is measured again, starting from this figure
+                    for (int g = 0; g < 3; g++) st->n[g] = 0;
+                }
                 // (the first call of a form pays one-off costs -- function attributes, cold instruction cache: keep the smaller
                 //  of the first two, then a running mean)
                 st->ms[f] = st->n[f] == 0 ? ms : st->n[f] == 1 ? std::min(st->ms[f], ms) : 0.75f * st->ms[f] + 0.25f * ms;
@@ -1316,7 +1321,7 @@ static int qk_pick_form(qk_ctx *ctx, uint64_t key, int form_static, const bool a
         }
         st->rr = (next + 1) % 3;
     }
-    if (next < 0 && best >= 0 && st->calls % 64 == 0) next = best;  // keep the winner's figure current
+    if (next < 0 && best >= 0 && st->calls % 16 == 0) next = best;  // keep the winner's figure current (and notice a change of regime)
     if (next >= 0) {
         st->pending = next;
         *measure = st;
