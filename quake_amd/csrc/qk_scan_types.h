@@ -187,4 +187,24 @@ __host__ __device__ inline long long rl_part_len(int cnt, int size, const RlCost
            nch * ((long long)rl_w(c.qb / 4, true, c) + (long long)(nqb - 2) * rl_w(c.qb / 4, false, c) + rl_w(g_last, false, c));
 }
 
+// row-per-lane kernel (qk_scan_rl.hip): LDS of one wave's slice / of a hot item's block, and the launch
+size_t qk_scan_rl_lds_per_wave(int nblk, int C, int qb);
+size_t qk_scan_hot_lds(int nblk, int C, int hq);
+int qk_launch_scan_rl(int nblk, dim3 grid, size_t lds, hipStream_t st, const ScanParams &sp);
 
+// ---- the host's plan for one scan call (qk_scan_plan.hip) ---------------------------------------------------------------------
+inline bool have_scan_qs(int db, int maxch) { return (db == 8 || db == 4 || db == 2) && (maxch == 1 || maxch == 2 || maxch == 4); }
+inline int pick_maxch(int cap) { return cap <= 64 ? 1 : cap <= 128 ? 2 : cap <= 256 ? 4 : 8; }
+struct ScanPlan {
+    int DB = 1;              // 16-column blocks per load step of k_scan
+    int C = 0;               // pool capacity per query
+    int nw = 1, qshare = 0;  // waves per workgroup of the tile form; query-sharing workgroups
+    bool use_rl = false;     // row-per-lane kernel (forms 1 and 2)
+    int form = 0;            // 0 tile form, 1 per-wave walk, 2 mixed sequence
+    int64_t rl_per_list = 0; // batch average of probing queries per list (what the static rule looks at)
+    RlCost rlc{12, 8, 1, 16, 4, 32};
+    int rl_app = 32, rl_waves = 4;
+    HotCost hot{0, 0, 0, 0, 0, 0, 0, 0};
+    qk_ctx::form_stat *measure = nullptr;  // form feedback: this call is timed (e0 is already on the stream; the caller records e1)
+};
+int qk_scan_plan(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, bool emit, int k, int P, int64_t npairs, ScanPlan *pl);

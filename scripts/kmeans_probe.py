@@ -1,5 +1,5 @@
 """k-means kernels on the bench shape and on a 65536-centroid case: ms of the assign and the update step of the last Lloyd iteration
-(qk_kmeans_last_timing); scripts/gpu_km_trace.sh wraps it in a rocprofv3 kernel trace."""
+(qk_kmeans_last_timing); wrap it in `rocprofv3 --kernel-trace --stats` for the per-kernel split."""
 import json, sys, os, torch, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench as B
