@@ -124,3 +124,11 @@ def test_summaries_of_both_mirrors_agree():
     for cls in ("BuildTimingInfo", "ModifyTimingInfo", "MaintenanceTimingInfo"):
         assert hasattr(getattr(qb, cls), "__repr__")
     assert hasattr(qb.BuildTimingInfo, "code_size") and hasattr(qb.BuildTimingInfo, "n_codebooks")
+
+
+def test_integration_doc_names_every_entry_point():
+    """INTEGRATION.md is the reference-side binding story: every symbol of the C ABI has a row saying which reference interface
+    it replaces (or that it has none)"""
+    txt = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    missing = [s for s in declared_symbols() if s not in txt]
+    assert not missing, missing
