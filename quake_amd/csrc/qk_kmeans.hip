@@ -775,10 +775,10 @@ static int accumulate_device(qk_ctx *ctx, AccumScratch &as, const float *x, int6
     if (!blocked) {
         hipLaunchKernelGGL(k_accumulate, dim3((unsigned)m), dim3((unsigned)std::min(256, qk_round_up(d, 64))), 0, st, x, d, as.vals2, as.seg, sums, counts);
     } else {
-        // group lanes: workgroups per centroid (most exit at once: a centroid with <= 1024 rows has one group).  Eight when the mean
-        // cluster is a few hundred rows (a skewed mixture then holds clusters of many groups), fewer for many small clusters
-        // (65536 x 8 mostly empty workgroups cost more than the rare long cluster they would split)
-        const unsigned lanes = (unsigned)std::min<int64_t>(KM_GLANES, std::max<int64_t>(2, (n + 16 * m - 1) / (16 * m)));
+        // group lanes: workgroups per centroid (most exit at once: a centroid with <= 1024 rows has one group): two at a mean
+        // cluster of 256 rows (a skewed training sample then holds clusters of a few groups), eight from ~1000 rows per cluster on;
+        // empty workgroups are not free (4096 x 8 of them: ~10 us of a 100 us launch)
+        const unsigned lanes = (unsigned)std::min<int64_t>(KM_GLANES, std::max<int64_t>(2, (n + 128 * m - 1) / (128 * m)));
         if (d % 4 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)sums & 15) == 0)
             hipLaunchKernelGGL((k_accumulate_blocked<float4>), dim3((unsigned)m, lanes), dim3(256), 0, st, (const float4 *)x, d / 4, as.vals2, as.seg,
                                (float4 *)sums, counts, (float4 *)as.gpart, as.tickets);
