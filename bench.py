@@ -299,10 +299,23 @@ def phases_of(ev_ph):
             "note": "separate untimed pass with events around every phase"}
 
 
-def measured_traffic(args, nprobe, manifold, timeout=420):
+def _form_matches(form, kernel_name):
+    """does a kernel symbol of the profile belong to the scan form qk_ctx_last_scan_kernel named?"""
+    kn = kernel_name.replace(" ", "")
+    if form is None:
+        return "k_scan" in kn
+    if "(mixed)" in form:
+        return "k_scan_rl<" in kn and kn.split("(")[0].endswith(",true>")
+    if form.startswith("k_scan_rl"):
+        return "k_scan_rl<" in kn and kn.split("(")[0].endswith(",false>")
+    return "k_scan<" in kn
+
+
+def measured_traffic(args, nprobe, manifold, timeout=420, form=None):
     """HBM bytes per partition-scan launch, measured in THIS run: a rocprofv3 pass (--pmc FETCH_SIZE, kernel trace only: PMC
     collection gets its own process, MI355X_MICROARCH.md "HBM / rocprofv3") over a short replay of the same workload
-    (`bench.py --traffic-probe`: same corpus, index, batches and nprobe; 8 searches).  FETCH_SIZE is reported in KB and, on
+    (`bench.py --traffic-probe`: same corpus, index, batches and nprobe; 32 synchronised searches, so that the form feedback
+    settles as it did in the timed run); the launches counted are those of `form`, the form the timed region ran.  FETCH_SIZE is reported in KB and, on
     gfx950, tallies the 128-B requests of wide streaming reads at 64 B: x 1024 x 2.  None when rocprofv3 is not on the box,
     the pass fails, or QUAKE_BENCH_NO_PMC is set."""
     exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
@@ -322,7 +335,8 @@ def measured_traffic(args, nprobe, manifold, timeout=420):
         tot, n = {}, {}
         for f in glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True):
             for row in csv.DictReader(open(f)):
-                if row.get("Counter_Name") == "FETCH_SIZE" and "k_scan" in row.get("Kernel_Name", ""):
+                # (the launches of the form that was TIMED: with form feedback on, the replay also runs the forms it compares)
+                if row.get("Counter_Name") == "FETCH_SIZE" and _form_matches(form, row.get("Kernel_Name", "")):
                     kn = row["Kernel_Name"].split("(")[0]
                     tot[kn] = tot.get(kn, 0.0) + float(row["Counter_Value"])
                     n[kn] = n.get(kn, 0) + 1
@@ -349,9 +363,9 @@ def run_traffic_probe(ctx, dev, args):
         batches = [gen_queries(Q, cent_true, seed=2 + b, device=dev, sigma=args.sigma, unit=unit) for b in range(N_BATCHES)]
     idx = build_single(ctx, dev, x, nlist, metric, args.niter, keep_host=False)
     del x
-    for i in range(8):
+    for i in range(32):  # (synchronised: the form feedback reads one measurement per call)
         ctx.search(idx["parent"], idx["store"], batches[i % N_BATCHES], max(args.nprobe, 1), k, metric)
-    torch.cuda.synchronize()
+        torch.cuda.synchronize()
 
 
 def committed_traffic(name, n, d, k, nprobe):
@@ -444,7 +458,7 @@ def run_single_workload(ctx, dev, args, name, sigma, fixed_nprobe, steps, warmup
     # on the box, else the committed pass of the same configuration (profiles/), marked as such
     traffic, traffic_source = None, None
     if not args.no_pmc:
-        mt = measured_traffic(args, nprobe, manifold)
+        mt = measured_traffic(args, nprobe, manifold, form=scan_kernel)
         if mt is not None:
             traffic, traffic_source = mt["bytes_per_launch"], f"rocprofv3 --pmc FETCH_SIZE in this run ({mt['kernel']}, {mt['launches']} launches; x1024 x2: KB, gfx950 wide-read tally)"
     if traffic is None and traffic_file:
@@ -477,7 +491,7 @@ def run_single_workload(ctx, dev, args, name, sigma, fixed_nprobe, steps, warmup
         kern = ctx.last_scan_kernel()
         ri = step(npb, 0)[0]
         torch.cuda.synchronize()
-        mt = None if args.no_pmc else measured_traffic(args, npb, manifold)
+        mt = None if args.no_pmc else measured_traffic(args, npb, manifold, form=kern)
         sweep_res.append({"nprobe": npb, "value": round(Q * 30 / e_s, 1), "unit": "queries/s", "ms_per_step": round(1e3 * e_s / 30, 4),
                           "steps": 30, "recall_at_k": round(recall_at_k(ri, gts[0], k), 4),
                           "roofline": roofline_of(sb, ev_s, mt["bytes_per_launch"] if mt else None, kernel=kern, pair_rows=pair_rows_of(npb), d=d,
