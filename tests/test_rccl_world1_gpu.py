@@ -189,12 +189,14 @@ def test_bench_refuses_a_rank_count_mismatch():
     assert r.returncode != 0 and "--gpus 2" in (r.stderr + r.stdout)
 
 
-def test_bench_starts_its_own_ranks():
-    """plain `python bench.py --gpus 2` (no launcher, WORLD_SIZE unset): bench.py starts the two ranks itself; over gloo they share
-    the one GPU of the test box.  One JSON line from rank 0, n_gpus = 2, recall as good as the single-GPU path's."""
+@pytest.mark.parametrize("nranks", [2, 4])
+def test_bench_starts_its_own_ranks(nranks):
+    """plain `python bench.py --gpus N` (no launcher, WORLD_SIZE unset): bench.py starts the N ranks itself; over gloo they share
+    the one GPU of the test box.  One JSON line from rank 0, n_gpus = N, recall as good as the single-GPU path's (N = 4: the
+    list p % N ownership, the N-block packed exchange and the rank-ordered reductions beyond two ranks)."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     env.update(QUAKE_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--settle", "5",
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(nranks), "--steps", "5", "--warmup", "2", "--settle", "5",
                         "--nvec-sharded", "300000", "--nlist-sharded", "128", "--batch-sharded", "128", "--no-cpu", "--no-extra"],
                        env=env, cwd=ROOT, capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
@@ -202,8 +204,8 @@ def test_bench_starts_its_own_ranks():
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
     line = json.loads(lines[0])
-    assert line["n_gpus"] == 2 and line["config"]["recall_at_k"] >= 0.9 and line["config"]["batch"] == 256
-    assert "lists sharded by number over 2 ranks" in line["config"]["workload"]
+    assert line["n_gpus"] == nranks and line["config"]["recall_at_k"] >= 0.9 and line["config"]["batch"] == 128 * nranks
+    assert f"lists sharded by number over {nranks} ranks" in line["config"]["workload"]
 
 
 def test_bench_refuses_more_ranks_than_gpus_on_rccl():
