@@ -863,8 +863,10 @@ int qk_dense_device(qk_ctx *ctx, qk_store *s, int64_t list_no, const qk_scan_arg
         const int64_t qgroups = (Q + NQ * 16 - 1) / (NQ * 16);
         const int ntile = (nrows + 15) / 16;
         // two workgroups per CU, at least 8 row tiles each (the query tile staging costs about as much as 8 tiles)
-        const int64_t want_chunks = std::max<int64_t>(1, ((int64_t)2 * num_cus_a + qgroups - 1) / qgroups);
-        int tiles_per_wg = (int)std::max<int64_t>(8, (ntile + want_chunks - 1) / want_chunks);
+        static const int am_wgs = std::max(1, qk_env_int("QK_ARGMIN_WG_PER_CU", 2));
+        static const int am_min_tiles = std::max(4, qk_env_int("QK_ARGMIN_MIN_TILES", 8));
+        const int64_t want_chunks = std::max<int64_t>(1, ((int64_t)am_wgs * num_cus_a + qgroups - 1) / qgroups);
+        int tiles_per_wg = (int)std::max<int64_t>(am_min_tiles, (ntile + want_chunks - 1) / want_chunks);
         tiles_per_wg = qk_round_up(tiles_per_wg, 4);
         ap.tiles_per_wg = tiles_per_wg;
         const int rchunks = std::max(1, (ntile + tiles_per_wg - 1) / tiles_per_wg);
