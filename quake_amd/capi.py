@@ -102,7 +102,10 @@ class Context:
 
     def set_stream(self, hip_stream):
         """hip_stream: a hipStream_t handle (e.g. torch.cuda.current_stream().cuda_stream); 0 = the device's NULL stream
-        (torch's default stream); None = back to the context's private stream."""
+        (torch's default stream); None = back to the context's private stream.
+        Calls on DEVICE buffers (torch CUDA tensors in, torch CUDA tensors out) are ordered on the context's stream only: the private
+        stream is non-blocking, so a caller that mixes them with torch operations binds the context to torch's current stream first
+        (GpuEngine and the bindings do) -- otherwise torch may read an output before the library's kernel wrote it."""
         if hip_stream is None:
             check(self.lib.qk_ctx_set_stream(self.h, None))
         elif int(hip_stream) == 0:

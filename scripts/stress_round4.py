@@ -15,6 +15,7 @@ from quake_amd.capi import Context, Store
 ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 ctx = Context(0)
+ctx.set_stream(torch.cuda.current_stream().cuda_stream)   # device tensors go through torch ops (cat, equal) below
 bad = []
 t0 = time.time()
 for c in range(ncases):
