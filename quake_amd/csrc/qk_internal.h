@@ -260,6 +260,10 @@ int qk_dense_device(qk_ctx *ctx, qk_store *s, int64_t list_no, const qk_scan_arg
 // top-k of every query over one list without a key matrix: bf16 prefilter + exact finish (qk_dense_pf.hip; 2 <= k <= 64, d <= 128)
 bool qk_dense_pf_supported(const qk_ctx *ctx, const qk_store *s, int64_t Q, int nrows, int k);
 int qk_dense_pf_device(qk_ctx *ctx, qk_store *s, int64_t row_off, int nrows, const qk_scan_args &a);
+// nearest centroid of many rows behind a bf16 prefilter (qk_assign_pf.hip); cnorm = the canonical norms of c's rows
+bool qk_assign_pf_supported(int64_t n, int64_t m, int d, int metric);
+int qk_assign_pf_device(qk_ctx *ctx, const float *x, int64_t n, const float *c, int64_t m, int d, int metric, const float *cnorm,
+                        int64_t *assign, float *val);
 // top-k of every query over one list of a few thousand rows, keys and selection in one launch (qk_dense_fused.hip; 2 <= k <= 64, d <= 128)
 bool qk_dense_fused_supported(const qk_ctx *ctx, const qk_store *s, int64_t Q, int nrows, int k);
 int qk_dense_fused_device(qk_ctx *ctx, qk_store *s, int64_t row_off, int nrows, const qk_scan_args &a);

@@ -638,6 +638,8 @@ static int assign_device(qk_ctx *ctx, const float *x, int64_t n, const float *c,
     QK_HIP(hipMemsetAsync(ctile, 0, (size_t)mt * 16 * dpad * sizeof(float), ctx->stream));
     QK_HIP(hipMemsetAsync(cnorm, 0, (size_t)mt * 16 * sizeof(float), ctx->stream));
     QK_TRY(qk_launch_ingest(ctx, c, nullptr, m, d, nblk, ctile, cnorm, nullptr, 0));
+    // many rows: the bf16-prefiltered form (same bits, ~6x the rate: qk_assign_pf.hip)
+    if (qk_assign_pf_supported(n, m, d, metric)) return qk_assign_pf_device(ctx, x, n, c, m, d, metric, cnorm, assign, val);
     AssignParams ap;
     ap.x = x;
     ap.n = n;
