@@ -248,13 +248,16 @@ class Context:
         return out_i, out_d
 
     # ---- k-means ----------------------------------------------------------------------------------------
-    def kmeans_assign(self, x, c, metric):
+    def kmeans_assign(self, x, c, metric, values=True):
+        """nearest centroid of every row (and, with values, its distance / dot product); values=False passes val = NULL, the
+        form the Lloyd driver uses (rows with a single candidate skip the exact key: qk_assign_pf.hip)."""
         x, c = _f32(x), _f32(c)
         n, d = x.shape
         mem = _mem_of(x, c)
         a = _empty_like_mem((n,), np.int64, x)
-        v = _empty_like_mem((n,), np.float32, x)
-        check(self.lib.qk_kmeans_assign(self.h, _ptr(x), n, _ptr(c), c.shape[0], d, metric_code(metric), _ptr(a), _ptr(v), mem))
+        v = _empty_like_mem((n,), np.float32, x) if values else None
+        check(self.lib.qk_kmeans_assign(self.h, _ptr(x), n, _ptr(c), c.shape[0], d, metric_code(metric), _ptr(a),
+                                        _ptr(v) if values else None, mem))
         return a, v
 
     def kmeans_accumulate(self, x, assign, m, blocked=False):

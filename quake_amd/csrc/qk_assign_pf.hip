@@ -373,13 +373,43 @@ __global__ __launch_bounds__(64 * APF_WAVES) void k_assign_pf(AssignPfParams P) 
     }
 #undef APF_TILE_OPERANDS
 #undef APF_PRODUCTS
+    // The end of the list.  A row with ONE candidate needs no exact key when only the assignment is asked for (the candidates
+    // provably include the nearest centroid): the Lloyd iterations and the final assignment of a build pass val = nullptr, and on
+    // clustered data three rows in four are such rows.  The chunk buffers are free now (everybody is past the last barrier): per wave
+    // a candidate count and the last candidate of every row.
+    int *ncand = (int *)smem + wave * (2 * WR), *onlyc = ncand + WR;
+    for (int rr = lane; rr < WR; rr += 64) ncand[rr] = 0;
+    for (int e = lane; e < cnt; e += 64) {
+        const uint32_t pk = cbuf[e];
+        const int xl = (int)(pk >> 24), ci = (int)(pk & 0xFFFFFFu);
+        if (ci < P.m) {  // (a padding row of the last centroid tile is a candidate only under a non-finite bound)
+            atomicAdd(&ncand[xl], 1);
+            onlyc[xl] = ci;
+        }
+    }
+    if (!P.val) {
+        // keep the pairs of rows with several candidates (or with keys from an earlier flush), in place, batch by batch
+        int kept = 0;
+        for (int base = 0; base < cnt; base += 64) {
+            const int e = base + lane;
+            const uint32_t pk = e < cnt ? cbuf[e] : 0u;
+            const int xl = (int)(pk >> 24);
+            const bool need = e < cnt && (ncand[xl] > 1 || best_w[xl] != ~0ull);
+            const uint64_t mk = __ballot(need);
+            if (need) cbuf[kept + __popcll(mk & lt)] = pk;
+            kept += __popcll(mk);
+        }
+        cnt = kept;
+    }
     apf_exact<L2, true>(P.x, P.c, P.cnorm, P.n, P.m, d, wrow0, cbuf, cnt, best_w, xn_w);
     for (int rr = lane; rr < WR; rr += 64) {
         const int64_t row = wrow0 + rr;
         if (row >= P.n) continue;
         const unsigned long long v = best_w[rr];
         const uint32_t o = (uint32_t)(v >> 32);
-        P.assign[row] = v == ~0ull ? -1 : (int64_t)(v & 0xFFFFFFFFull);
+        int64_t a = v == ~0ull ? -1 : (int64_t)(v & 0xFFFFFFFFull);
+        if (v == ~0ull && !P.val && ncand[rr] == 1) a = onlyc[rr];
+        P.assign[row] = a;
         if (P.val) P.val[row] = L2 ? __uint_as_float(o) : ip_from_ord(o);
     }
 }

@@ -12,13 +12,14 @@ if len(sys.argv) > 1:
 for n, m, d in shapes:
     x, _ = B.gen_mixture(n, d, m, seed=1, device=dev)
     c = x[torch.randperm(n, device=dev)[:m]].contiguous()
-    for metric in ("l2",):
-        ctx.kmeans_assign(x, c, metric)
+    for metric, values in (("l2", True), ("l2", False)):
+        ctx.kmeans_assign(x, c, metric, values=values)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(5):
-            a, v = ctx.kmeans_assign(x, c, metric)
+            a, v = ctx.kmeans_assign(x, c, metric, values=values)
         e1.record(); torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / 5
-        print(json.dumps({"n": n, "m": m, "d": d, "metric": metric, "ms": round(ms, 4), "tflops": round(2.0 * n * m * d / ms / 1e9, 1)}), flush=True)
+        print(json.dumps({"n": n, "m": m, "d": d, "metric": metric, "values": values, "ms": round(ms, 4),
+                          "tflops": round(2.0 * n * m * d / ms / 1e9, 1)}), flush=True)
     del x, c

@@ -30,6 +30,8 @@ def _halves(ctx, x, c, metric):
 
 def _check(ctx, x, c, metric, oracle=True):
     ga, gv = ctx.kmeans_assign(x, c, metric)
+    na, _ = ctx.kmeans_assign(x, c, metric, values=False)   # (val = NULL: rows with one candidate take it without an exact key)
+    np.testing.assert_array_equal(na, ga)
     if x.shape[0] < 131072:
         ha, hv = _halves(ctx, x, c, metric)
         np.testing.assert_array_equal(ga, ha)
