@@ -260,6 +260,10 @@ class Context:
                                         _ptr(v) if values else None, mem))
         return a, v
 
+    def kmeans_assign_only(self, x, c, metric):
+        """the assignments alone (val = NULL): what a Lloyd iteration needs"""
+        return self.kmeans_assign(x, c, metric, values=False)[0]
+
     def kmeans_accumulate(self, x, assign, m, blocked=False):
         """per-centroid sums and counts.  blocked=False: rows added one after the other (the reference's refine loop,
         clustering.cpp:162-176); True: the blocked canonical order of the Lloyd driver (qk_kmeans_accumulate_blocked)."""

@@ -183,14 +183,16 @@ def sharded_kmeans(eng, dist, x, m, metric, niter=5, seed=1234, rank=0, world=1,
         c = call if is_t else call.numpy()
     else:
         c = c_local.clone() if is_t else c_local.copy()
+    # (assignments only: an engine that can skip the distances -- capi.Context, val = NULL -- says so with kmeans_assign_only)
+    assign_of = getattr(eng, "kmeans_assign_only", None) or (lambda xs, cs, mt: eng.kmeans_assign(xs, cs, mt)[0])
     for _ in range(niter):
-        a, _v = eng.kmeans_assign(xt, c, metric)
+        a = assign_of(xt, c, metric)
         sums, counts = eng.kmeans_accumulate(xt, a, m, blocked=True)  # the Lloyd driver's blocked order (qk_kmeans's)
         sums, counts = _reduce_partials(dist, world, sums, counts, ordered)
         c, _ = eng.kmeans_update(sums, counts, c)
     if metric == "ip":
         c = eng.normalize_rows(c)
-    assign, _v = eng.kmeans_assign(x, c, metric)
+    assign = assign_of(x, c, metric)
     return c, assign
 
 

@@ -246,7 +246,7 @@ class GpuPartitions:
     def kmeans_assign(self, x, c):
         if len(x) == 0:
             return np.zeros(0, np.int64)
-        return self.ix._ctx.kmeans_assign(self._dev(x), self._dev(c), self.metric)[0].cpu().numpy()
+        return self.ix._ctx.kmeans_assign(self._dev(x), self._dev(c), self.metric, values=False)[0].cpu().numpy()
 
     def kmeans_accumulate(self, x, assign, m):
         import torch
