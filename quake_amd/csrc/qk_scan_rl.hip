@@ -74,8 +74,12 @@ __device__ __forceinline__ float f4c(const float4 &v, int t) { return t == 0 ? v
 constexpr float QK_PF_C = QK_PF_C_PROBE;
 constexpr float QK_PF_K1 = 1.0f - QK_PF_C_PROBE;
 #else
-constexpr float QK_PF_C = 0.0078741f;   // >= 2^-7 * 129/128 + 2^-21
-constexpr float QK_PF_K1 = 0.992125f;   // <= 1 - QK_PF_C
+// (round 4: + 2^-15 + 2^-20.  The accumulator of the bf16 product now STARTS at the row's part of the bound -- -|y|^2 (1 - c) / 2 --
+//  so that the test is one compare of the instruction's result with a per-query threshold: its roundings are then relative to
+//  |y|^2 / 2 + sum|x_i y_i| <= |x|^2 + |y|^2, 2^-16 of that on a quantity that enters the key's scale twice; the threshold's own
+//  rounding is 2^-24 of |x|^2 + tau.)
+constexpr float QK_PF_C = 0.0079071f;   // >= 2^-7 * 129/128 + 2^-21 + 2^-15 + 2^-20
+constexpr float QK_PF_K1 = 0.992092f;   // <= 1 - QK_PF_C
 #endif
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 struct HotLds {
@@ -87,6 +91,7 @@ struct HotLds {
     uint32_t *tau;       // [hq] running bound (key)
     int *cnt, *lock;     // [hq] pool fill, spin lock
     float *xn;           // [hq] |x|^2
+    float *theta;        // [hq] the prefilter's threshold of the slot (hot_theta): follows tau
     int *item;           // [4] claimed item (broadcast)
 };
 __device__ __forceinline__ HotLds hot_lds(unsigned char *smem, int hq, int nb, int C) {
@@ -101,11 +106,27 @@ __device__ __forceinline__ HotLds hot_lds(unsigned char *smem, int hq, int nb, i
     h.cnt = (int *)(h.tau + hq);
     h.lock = h.cnt + hq;
     h.xn = (float *)(h.lock + hq);
-    h.item = (int *)(h.xn + hq);
+    h.theta = h.xn + hq;
+    h.item = (int *)(h.theta + hq);
     return h;
 }
 size_t qk_scan_hot_lds(int nblk, int C, int hq) {
-    return (size_t)hq * ((size_t)nblk * 64 + (size_t)((nblk + 1) / 2) * 64 + (size_t)C * 12 + 24) + 64;
+    return (size_t)hq * ((size_t)nblk * 64 + (size_t)((nblk + 1) / 2) * 64 + (size_t)C * 12 + 28) + 64;
+}
+
+// The prefilter's test of an approximate product against a query's bound, as ONE compare.  With a~ the bf16 product:
+//   L2  a row cannot enter the top-k if (|x|^2 + |y|^2)(1 - c) - 2 a~ > tau  <=>  a~ - |y|^2 (1 - c) / 2 < (|x|^2 (1 - c) - tau) / 2
+//   IP  ... if a~ + c (|x|^2 + |y|^2) / 2 < tau                               <=>  a~ + c |y|^2 / 2       < tau - c |x|^2 / 2
+// The left side comes out of the MFMA itself (its accumulator starts at the row's term), the right side is hot_theta: per query
+// slot, recomputed only when the slot's bound moves.  "No bound yet" (all ones) gives -inf: everything passes.
+template <bool L2>
+__device__ __forceinline__ float hot_theta(uint32_t tau, float xn) {
+    if (L2) {
+        const float tf = tau == 0xFFFFFFFFu ? __builtin_inff() : __uint_as_float(tau);
+        return 0.5f * (xn * QK_PF_K1 - tf);
+    }
+    const float tf = tau == 0xFFFFFFFFu ? -__builtin_inff() : ip_from_ord(tau);
+    return tf - xn * (0.5f * QK_PF_C);
 }
 
 // one item; every thread of the workgroup calls it with the same arguments.  Barriers: after staging, before and after the
@@ -200,6 +221,7 @@ __device__ __forceinline__ void rl_hot_item(const ScanParams &P, const HotLds &H
             H.cnt[sl_own] = 0;
             H.lock[sl_own] = 0;
             H.xn[sl_own] = xn_own;
+            H.theta[sl_own] = live_own ? hot_theta<L2>(t_own, xn_own) : __builtin_inff();  // (a dead slot passes nothing)
         }
     }
     __syncthreads();
@@ -269,6 +291,7 @@ __device__ __forceinline__ void rl_hot_item(const ScanParams &P, const HotLds &H
             if (lane == 0) {
                 H.cnt[sl] = cnt;
                 H.tau[sl] = tau;
+                H.theta[sl] = hot_theta<L2>(tau, H.xn[sl]);
                 __hip_atomic_store(&H.lock[sl], 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
             __builtin_amdgcn_wave_barrier();
@@ -357,29 +380,18 @@ __device__ __forceinline__ void rl_hot_item(const ScanParams &P, const HotLds &H
 #define HOT_TILE(A, Y, I, PI, BC, BN, QT_)                                                                   \
     {                                                                                                        \
         HOT_HLOAD(BN, min((QT_) + 1, QT - 1));                                                               \
-        const float xnj_ = H.xn[16 * (QT_) + j];                                                             \
-        const uint32_t tauj_ = H.tau[16 * (QT_) + j];                                                        \
-        f32x4 d0_ = {0.f, 0.f, 0.f, 0.f}, d1_ = {0.f, 0.f, 0.f, 0.f};                                        \
+        const float thj_ = H.theta[16 * (QT_) + j];                                                          \
+        f32x4 d0_ = {ykh_[0], ykh_[1], ykh_[2], ykh_[3]}, d1_ = {ykh_[4], ykh_[5], ykh_[6], ykh_[7]};        \
         _Pragma("unroll") for (int m_ = 0; m_ < NM; m_++) {                                                  \
             const bf16x8 bh_ = __builtin_bit_cast(bf16x8, BC[m_]);                                           \
             d0_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah_[m_], bh_, d0_, 0, 0, 0);                       \
             d1_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah_[NM + m_], bh_, d1_, 0, 0, 0);                  \
         }                                                                                                    \
-        const bool livej_ = 16 * (QT_) + j < nq;                                                             \
-        const float xk_ = L2 ? xnj_ * QK_PF_K1 : xnj_ * (0.5f * QK_PF_C);                                    \
-        /* the bound as a float (the test is VALU-bound: add + fma + compare per key instead of the key's bits): L2 keys are */ \
-        /* the bits of non-negative floats, IP keys descend with the dot product; "no bound yet" passes everything           */ \
-        const float tauf_ = L2 ? (tauj_ == 0xFFFFFFFFu ? __builtin_inff() : __uint_as_float(tauj_))          \
-                               : (tauj_ == 0xFFFFFFFFu ? -__builtin_inff() : ip_from_ord(tauj_));            \
-        bool flag_ = false, flag1_ = false;                                                                  \
-        _Pragma("unroll") for (int e_ = 0; e_ < 8; e_++) {                                                   \
-            const float dd_ = e_ < 4 ? d0_[e_ & 3] : d1_[e_ & 3];                                            \
-            /* negated compares: a NaN bound (NaN / Inf data, overflow) stays a candidate, as in the per-wave walk and k_pf_gemm */ \
-            const bool p_ = L2 ? !(__fmaf_rn(-2.0f, dd_, xk_ + yk_[e_]) > tauf_) : !(dd_ + (xk_ + yk_[e_]) < tauf_); \
-            if (e_ < 4) flag_ |= rv_[e_] & p_;                                                               \
-            else flag1_ |= rv_[e_] & p_;                                                                     \
-        }                                                                                                    \
-        const int um_ = HOT_PF_PROBE((__ballot(flag_ & livej_) ? 1 : 0) | (__ballot(flag1_ & livej_) ? 2 : 0)); \
+        /* one compare per row tile (hot_theta); negated: a NaN on either side stays a candidate, as in the per-wave walk and */ \
+        /* k_pf_gemm; a row beyond the list started at -inf and passes only a query without a bound (the exact path masks it) */ \
+        const bool flag_ = !(fmaxf(fmaxf(d0_[0], d0_[1]), fmaxf(d0_[2], d0_[3])) < thj_);                    \
+        const bool flag1_ = !(fmaxf(fmaxf(d1_[0], d1_[1]), fmaxf(d1_[2], d1_[3])) < thj_);                   \
+        const int um_ = HOT_PF_PROBE((__ballot(flag_) ? 1 : 0) | (__ballot(flag1_) ? 2 : 0));                \
         dbg_prod += 2;                                                                                       \
         if (um_) {                                                                                           \
             dbg_exact += (um_ & 1) + (um_ >> 1);                                                             \
@@ -390,8 +402,7 @@ __device__ __forceinline__ void rl_hot_item(const ScanParams &P, const HotLds &H
     {                                                                                                        \
         /* bf16 copies of the pair's fragments (the fp32 lane layout, converted in place), the row part of the bound */ \
         bf16x8 ah_[2 * NM];                                                                                  \
-        float yk_[8];                                                                                        \
-        bool rv_[8];                                                                                         \
+        float ykh_[8];  /* where the accumulator of a row starts (hot_theta) */                              \
         _Pragma("unroll") for (int u_ = 0; u_ < 2; u_++) {                                                   \
             _Pragma("unroll") for (int m_ = 0; m_ < NM; m_++) {                                              \
                 const float4 f0_ = A[u_ * NB + 2 * m_];                                                      \
@@ -402,8 +413,8 @@ __device__ __forceinline__ void rl_hot_item(const ScanParams &P, const HotLds &H
             const int tl_ = t_lo + 2 * (PI) + u_;                                                            \
             const float yv_[4] = {Y[u_].x, Y[u_].y, Y[u_].z, Y[u_].w};                                       \
             _Pragma("unroll") for (int reg_ = 0; reg_ < 4; reg_++) {                                         \
-                yk_[4 * u_ + reg_] = L2 ? yv_[reg_] * QK_PF_K1 : yv_[reg_] * (0.5f * QK_PF_C);               \
-                rv_[4 * u_ + reg_] = (tl_ < t_hi) & (16 * tl_ + 4 * g + reg_ < size_p);                      \
+                const bool rv_ = (tl_ < t_hi) & (16 * tl_ + 4 * g + reg_ < size_p);                          \
+                ykh_[4 * u_ + reg_] = !rv_ ? -__builtin_inff() : L2 ? -0.5f * (yv_[reg_] * QK_PF_K1) : yv_[reg_] * (0.5f * QK_PF_C); \
             }                                                                                                \
         }                                                                                                    \
         uint4 bc_[NM], bn_[NM];                                                                              \
