@@ -62,6 +62,11 @@ struct QkIdMap {
             }
         }
     }
+    // the cache line a later find / set / erase of `key` starts at: the store walks hundreds of thousands of random ids per call, one
+    // DRAM round trip each when the table is larger than the caches -- requested a few iterations ahead they overlap
+    inline void prefetch(int64_t key) const {
+        if (!slots.empty()) __builtin_prefetch(&slots[(size_t)mix((uint64_t)key) & (slots.size() - 1)]);
+    }
     int32_t find(int64_t key) const {  // list number or -1
         if (slots.empty()) return -1;
         bool f;
@@ -91,6 +96,16 @@ struct QkIdMap {
             slots[i].val = ERASED;
             live--;
         }
+    }
+    int32_t take(int64_t key) {  // find + erase in one probe: the value the key had, or -1
+        if (slots.empty()) return -1;
+        bool f;
+        const size_t i = probe(key, f);
+        if (!f) return -1;
+        const int32_t v = slots[i].val;
+        slots[i].val = ERASED;
+        live--;
+        return v;
     }
     void erase_if(int64_t key, int32_t val) {  // only while it still maps to `val`
         if (slots.empty()) return;

@@ -633,7 +633,10 @@ int qk_store_remove_ids(qk_store *s, int64_t n, const int64_t *ids_host, int64_t
         }
     } else {
         kill.reserve((size_t)n);
-        for (int64_t i = 0; i < n; i++) kill.set(ids_host[i], 0);
+        for (int64_t i = 0; i < n; i++) {
+            if (i + 16 < n) kill.prefetch(ids_host[i + 16]);
+            kill.set(ids_host[i], 0);
+        }
     }
     const uint64_t *bits = s->kill_bits.data();
     auto is_kill = [&](int64_t v) -> bool {
@@ -647,8 +650,12 @@ int qk_store_remove_ids(qk_store *s, int64_t n, const int64_t *ids_host, int64_t
     // every partition, dynamic_inverted_list.cpp:137-149 -- same result, O(touched lists) instead of O(N))
     qk_store_ensure_index(s);
     std::vector<char> touched_list(s->parts.size(), 0);
+    // (the index entry of an id goes HERE, in the one pass over the request whose table accesses can be requested ahead: the list
+    //  that holds the id is swept below and every row with a requested id leaves it, so the entry would be erased there anyway --
+    //  by a random access per removed row in the middle of a sequential sweep)
     for (int64_t i = 0; i < n; i++) {
-        const int32_t holder = s->id_to_list.find(ids_host[i]);
+        if (i + 16 < n) s->id_to_list.prefetch(ids_host[i + 16]);
+        const int32_t holder = s->id_to_list.take(ids_host[i]);
         if (holder >= 0) touched_list[(size_t)holder] = 1;
     }
     for (size_t pi = 0; pi < s->parts.size(); pi++) {
@@ -664,7 +671,6 @@ int qk_store_remove_ids(qk_store *s, int64_t n, const int64_t *ids_host, int64_t
                     for (int64_t t = 0; t < p.size; t++) cur[t] = t;
                     touched = true;
                 }
-                s->id_to_list.erase(p.ids[i]);
                 if (i != sz - 1) {
                     p.ids[i] = p.ids[sz - 1];
                     cur[i] = cur[sz - 1];
@@ -801,7 +807,10 @@ int qk_store_add_batch(qk_store *s, int64_t n, const int64_t *ids, const float *
     for (size_t p = 0; p < extra.size(); p++)
         if (extra[p]) QK_TRY(ensure_part_capacity(s, s->parts[p], extra[p]));
     std::vector<int64_t> rows((size_t)n);
+    if (s->index_valid) s->id_to_list.reserve(s->id_to_list.size() + (size_t)n);  // (no rehash inside the loop)
+    constexpr int64_t AHEAD = 16;
     for (int64_t i = 0; i < n; i++) {
+        if (s->index_valid && i + AHEAD < n) s->id_to_list.prefetch(h_ids[i + AHEAD]);
         qk_part &p = s->parts[(size_t)h_assign[i]];
         rows[i] = p.row_off + p.size;
         p.ids.push_back(h_ids[i]);

@@ -1,5 +1,5 @@
 // QkIdMap (quake_amd/csrc/qk_idmap.h) against std::unordered_map on a random stream of set / set_if_absent / erase / erase_if /
-// find / clear / reserve.  Built and run by tests/test_idmap_host.py (g++, no GPU).
+// take / prefetch / find / clear / reserve.  Built and run by tests/test_idmap_host.py (g++, no GPU).
 #include "qk_idmap.h"
 
 #include <cstdio>
@@ -13,7 +13,7 @@ int main() {
     for (int it = 0; it < 3000000; it++) {
         const int64_t key = (int64_t)(rng() % 200000) - 1000;  // negative ids too
         const int32_t val = (int32_t)(rng() % 5000);
-        switch (rng() % 6) {
+        switch (rng() % 7) {
             case 0:
                 m.set(key, val);
                 r[key] = val;
@@ -30,6 +30,17 @@ int main() {
                 m.erase_if(key, val);
                 auto f = r.find(key);
                 if (f != r.end() && f->second == val) r.erase(f);
+                break;
+            }
+            case 4: {  // take = find + erase (prefetch first, as the store does)
+                m.prefetch(key);
+                auto f = r.find(key);
+                const int32_t want = f == r.end() ? -1 : f->second;
+                if (m.take(key) != want) {
+                    printf("TAKE MISMATCH at step %d\n", it);
+                    return 1;
+                }
+                if (f != r.end()) r.erase(f);
                 break;
             }
             default: {
