@@ -34,6 +34,9 @@ constexpr int APF_CAP = 512;   // candidates a wave parks before it works them o
 // <= |x|^2 + |y|^2 (2^-16 of that, on a in the key's scale twice), and the roundings of the bound itself (<= 2^-22 of it)
 constexpr float APF_C = 0.0079061f;
 
+// (timing / counting switches of side builds -- scripts/build_variant.sh <name> qk_assign_pf.hip -DAPF_...: APF_PROBE_STATS counts
+//  tests, slow paths and candidates; APF_V_NOPASS2 / APF_V_NOFLUSH drop pass 2 / the exact keys (wrong answers, timing only);
+//  APF_V_W16 runs 16 waves x 4 row tiles per workgroup.  The product build has none of them.)
 #ifdef APF_PROBE_STATS
 __device__ unsigned long long apf_stats[4];  // steps (groups of 4 row tiles x centroid tile), slow groups, candidates, flushes
 #define APF_STAT(i_, v_) do { if ((threadIdx.x & 63) == 0) atomicAdd(&apf_stats[i_], (unsigned long long)(v_)); } while (0)
@@ -52,8 +55,13 @@ struct AssignPfParams {
     const float *cnorm;   // [>= m] canonical |y|^2
     const float *ynmax;   // [1] max |y|^2 (bits: NaN > inf > finite)
     int m, nch;
-    int64_t *assign;
+    int64_t *assign;      // [n] centroid ROW of every x row (k-means), or nullptr with packed_out
     float *val;           // [n] exact key of the assignment as a distance / dot product, or nullptr
+    // the nearest-list form (qk_dense_device, k = 1: PartitionManager::add's parent search over many rows): ties go to the smaller ID,
+    // and the answer leaves as k_dense_argmin's packed word (key << 32 | id; key 0 where none was asked for and none was needed)
+    const int64_t *ids;           // [m] ids of the centroid rows (each in [0, 2^32)), or nullptr: the row number orders and is returned
+    unsigned long long *packed_out;  // [n] or nullptr
+    int want_keys;        // exact keys for every row (val / the packed word's key are read)
 };
 
 // centroid tile t in bf16, step s of lane (i, g) = columns 32 s + 8 g .. + 7 of centroid 16 t + i (the k-order of the bf16
@@ -91,7 +99,7 @@ __global__ __launch_bounds__(64) void k_apf_prep(const float *__restrict__ c, co
 template <bool L2, bool FAST>
 __device__ __forceinline__ void apf_exact(const float *__restrict__ x, const float *__restrict__ c, const float *__restrict__ cnorm, int64_t n,
                                           int m, int d, int64_t wrow0, const uint32_t *cbuf, int cnt, unsigned long long *best,
-                                          const float *xn_w) {
+                                          const float *xn_w, const int64_t *__restrict__ ids) {
 #ifdef APF_V_NOFLUSH
     return;
 #endif
@@ -153,14 +161,15 @@ __device__ __forceinline__ void apf_exact(const float *__restrict__ x, const flo
         }
         for (int p = 0; p < npad; p++) acc = __fmaf_rn(0.0f, 0.0f, acc);  // (the MFMA path runs over the zero columns of the last block)
         const uint32_t o = L2 ? ord_from_l2(l2_expanded(xn_w[xl], cnorm[min(ci, m - 1)], acc)) : ord_from_ip(acc);
-        if (has) atomicMin(&best[xl], ((unsigned long long)o << 32) | (unsigned long long)(uint32_t)ci);
+        const uint32_t low = ids ? (uint32_t)ids[min(ci, m - 1)] : (uint32_t)ci;  // what breaks a tie of keys (and what is returned)
+        if (has) atomicMin(&best[xl], ((unsigned long long)o << 32) | (unsigned long long)low);
     }
 }
 template <bool L2>
 __device__ __noinline__ void apf_flush(const float *__restrict__ x, const float *__restrict__ c, const float *__restrict__ cnorm, int64_t n,
                                        int m, int d, int64_t wrow0, const uint32_t *cbuf, int cnt, unsigned long long *best,
-                                       const float *xn_w) {
-    apf_exact<L2, false>(x, c, cnorm, n, m, d, wrow0, cbuf, cnt, best, xn_w);
+                                       const float *xn_w, const int64_t *__restrict__ ids) {
+    apf_exact<L2, false>(x, c, cnorm, n, m, d, wrow0, cbuf, cnt, best, xn_w, ids);
 }
 
 // chunk `chunk` of the centroid stream (APF_CH tiles, then their 256 norms) into LDS: one wave-instruction = 64 consecutive uint4
@@ -275,11 +284,7 @@ __global__ __launch_bounds__(64 * APF_WAVES) void k_assign_pf(AssignPfParams P) 
     }                                                                                                \
     apf_bf16x8 A[NM];                                                                                \
     _Pragma("unroll") for (int s = 0; s < NM; s++) A[s] = __builtin_bit_cast(apf_bf16x8, a_[s]);
-#ifdef APF_V_NOMFMA
-#define APF_MFMA(a_, b_, c_) ((c_) + (f32x4){(float)(a_)[0], (float)(b_)[0], 0.f, 0.f})
-#else
 #define APF_MFMA(a_, b_, c_) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_, b_, c_, 0, 0, 0)
-#endif
 #define APF_PRODUCTS(X0)                                                                             \
     f32x4 acc[4];                                                                                    \
     _Pragma("unroll") for (int u = 0; u < 4; u++) acc[u] = y4;                                       \
@@ -290,9 +295,7 @@ __global__ __launch_bounds__(64 * APF_WAVES) void k_assign_pf(AssignPfParams P) 
     // ---- pass 1: the minimum of h per row ----
     for (int it = 0; it < nch; it++) {
         const int cur = it & 1;
-#ifndef APF_V_NOSTAGE
         apf_stage<NM, APF_WAVES>(P.cbf, it + 1 < nch ? it + 1 : 0, buf + (size_t)(cur ^ 1) * CHB_U4);  // (the last one: chunk 0 of pass 2)
-#endif
         const uint32_t cb_addr = lds0 + (uint32_t)cur * (CHB_U4 * 16) + lane * 16;
         const uint32_t yb_addr = lds0 + (uint32_t)cur * (CHB_U4 * 16) + CH_U4 * 16 + g * 16;
         for (int t = 0; t < APF_CH; t++) {
@@ -330,15 +333,13 @@ __global__ __launch_bounds__(64 * APF_WAVES) void k_assign_pf(AssignPfParams P) 
     }
     // ---- pass 2: the same products against the bound ----
 #ifdef APF_V_NOPASS2
-    if (P.val && hw[0] + hw[XT - 1] == 12345.0f) P.val[0] = hw[1];
+    if (P.assign && hw[0] + hw[XT - 1] == 12345.0f) P.assign[0] = (int64_t)hw[1];
     for (int it = 0; it < 0; it++) {
 #else
     for (int it = 0; it < nch; it++) {
 #endif
         const int cur = (nch + it) & 1;
-#ifndef APF_V_NOSTAGE
         if (it + 1 < nch) apf_stage<NM, APF_WAVES>(P.cbf, it + 1, buf + (size_t)(cur ^ 1) * CHB_U4);
-#endif
         const uint32_t cb_addr = lds0 + (uint32_t)cur * (CHB_U4 * 16) + lane * 16;
         const uint32_t yb_addr = lds0 + (uint32_t)cur * (CHB_U4 * 16) + CH_U4 * 16 + g * 16;
         for (int t = 0; t < APF_CH; t++) {
@@ -358,7 +359,7 @@ __global__ __launch_bounds__(64 * APF_WAVES) void k_assign_pf(AssignPfParams P) 
                             const bool p = !(acc[u][r] < hw[xt]);
                             const uint64_t mk = __ballot(p);
                             if (cnt > APF_CAP - 64) {
-                                apf_flush<L2>(P.x, P.c, P.cnorm, P.n, P.m, d, wrow0, cbuf, cnt, best_w, xn_w);
+                                apf_flush<L2>(P.x, P.c, P.cnorm, P.n, P.m, d, wrow0, cbuf, cnt, best_w, xn_w, P.ids);
                                 cnt = 0;
                             }
                             if (p) cbuf[cnt + __popcll(mk & lt)] = ((uint32_t)(xt * 16 + j) << 24) | (uint32_t)(cidx0 + r);
@@ -387,7 +388,7 @@ __global__ __launch_bounds__(64 * APF_WAVES) void k_assign_pf(AssignPfParams P) 
             onlyc[xl] = ci;
         }
     }
-    if (!P.val) {
+    if (!P.want_keys) {
         // keep the pairs of rows with several candidates (or with keys from an earlier flush), in place, batch by batch
         int kept = 0;
         for (int base = 0; base < cnt; base += 64) {
@@ -401,15 +402,16 @@ __global__ __launch_bounds__(64 * APF_WAVES) void k_assign_pf(AssignPfParams P) 
         }
         cnt = kept;
     }
-    apf_exact<L2, true>(P.x, P.c, P.cnorm, P.n, P.m, d, wrow0, cbuf, cnt, best_w, xn_w);
+    apf_exact<L2, true>(P.x, P.c, P.cnorm, P.n, P.m, d, wrow0, cbuf, cnt, best_w, xn_w, P.ids);
     for (int rr = lane; rr < WR; rr += 64) {
         const int64_t row = wrow0 + rr;
         if (row >= P.n) continue;
         const unsigned long long v = best_w[rr];
         const uint32_t o = (uint32_t)(v >> 32);
-        int64_t a = v == ~0ull ? -1 : (int64_t)(v & 0xFFFFFFFFull);
-        if (v == ~0ull && !P.val && ncand[rr] == 1) a = onlyc[rr];
-        P.assign[row] = a;
+        const bool only = v == ~0ull && !P.want_keys && ncand[rr] == 1;
+        const uint32_t low1 = only ? (P.ids ? (uint32_t)P.ids[onlyc[rr]] : (uint32_t)onlyc[rr]) : 0u;
+        if (P.packed_out) P.packed_out[row] = only ? (unsigned long long)low1 : v;
+        if (P.assign) P.assign[row] = only ? (int64_t)low1 : v == ~0ull ? -1 : (int64_t)(v & 0xFFFFFFFFull);
         if (P.val) P.val[row] = L2 ? __uint_as_float(o) : ip_from_ord(o);
     }
 }
@@ -438,24 +440,24 @@ static int apf_launch(hipStream_t st, const AssignPfParams &p, int metric) {
     return QK_OK;
 }
 
-// nearest centroid of every row of x; c: [m][d] row-major, cnorm: canonical norms of its rows (device pointers throughout)
-int qk_assign_pf_device(qk_ctx *ctx, const float *x, int64_t n, const float *c, int64_t m, int d, int metric, const float *cnorm,
-                        int64_t *assign, float *val) {
+size_t qk_assign_pf_scratch_bytes(int64_t m, int d) {
+    const int NM = (d + 31) / 32;
+    const int64_t nch = ((m + 15) / 16 + APF_CH - 1) / APF_CH;
+    return (((size_t)nch * ((size_t)APF_CH * NM * 1024 + 1024) + 255) & ~(size_t)255) + 256;
+}
+
+// the launches; scratch: qk_assign_pf_scratch_bytes(m, d) bytes of device memory, 256-byte aligned
+int qk_assign_pf_launch(qk_ctx *ctx, const float *x, int64_t n, const float *c, int64_t m, int d, int metric, const float *cnorm,
+                        const int64_t *ids, int64_t *assign, float *val, unsigned long long *packed_out, bool want_keys, void *scratch) {
     if (!qk_assign_pf_supported(n, m, d, metric)) QK_FAIL(QK_ERR_UNSUPPORTED, "assign (prefiltered): unsupported shape");
     hipStream_t st = ctx->stream;
     const int NM = (d + 31) / 32;
     const int64_t mt = (m + 15) / 16;
     const int nch = (int)((mt + APF_CH - 1) / APF_CH);
     const int64_t mtp = (int64_t)nch * APF_CH;
-    size_t need = 0;
-    auto add = [&](size_t b) { need += (b + 255) & ~(size_t)255; };
     const size_t cbf_bytes = (size_t)nch * ((size_t)APF_CH * NM * 1024 + 1024);
-    add(cbf_bytes);
-    add(256);
-    QK_TRY(qk_ws_reserve(ctx, need + 4096));
-    uint4 *cbf = (uint4 *)qk_ws_alloc(ctx, cbf_bytes);
-    unsigned int *ynmax = (unsigned int *)qk_ws_alloc(ctx, 256);
-    if (!cbf || !ynmax) QK_FAIL(QK_ERR_OOM, "assign (prefiltered): workspace exhausted");
+    uint4 *cbf = (uint4 *)scratch;
+    unsigned int *ynmax = (unsigned int *)((unsigned char *)scratch + ((cbf_bytes + 255) & ~(size_t)255));
     QK_HIP(hipMemsetAsync(ynmax, 0, 4, st));
     hipLaunchKernelGGL(k_apf_prep, dim3((unsigned)mtp), dim3(64), 0, st, c, cnorm, (int)m, d, NM, metric == QK_METRIC_L2 ? 1 : 0, cbf, ynmax);
     AssignPfParams p;
@@ -470,6 +472,9 @@ int qk_assign_pf_device(qk_ctx *ctx, const float *x, int64_t n, const float *c, 
     p.nch = nch;
     p.assign = assign;
     p.val = val;
+    p.ids = ids;
+    p.packed_out = packed_out;
+    p.want_keys = (want_keys || val) ? 1 : 0;
     const int num_cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
     const bool big = n >= (int64_t)num_cus * 1024;  // 1024-row workgroups once they fill the chip
 #ifdef APF_V_W16
@@ -504,4 +509,15 @@ int qk_assign_pf_device(qk_ctx *ctx, const float *x, int64_t n, const float *c, 
     }
 #undef APF_CASE
     return QK_ERR_UNSUPPORTED;
+}
+
+
+// nearest centroid of every row of x (k-means); c: [m][d] row-major, cnorm: canonical norms of its rows (device pointers throughout)
+int qk_assign_pf_device(qk_ctx *ctx, const float *x, int64_t n, const float *c, int64_t m, int d, int metric, const float *cnorm,
+                        int64_t *assign, float *val) {
+    const size_t need = qk_assign_pf_scratch_bytes(m, d);
+    QK_TRY(qk_ws_reserve(ctx, need + 4096));
+    void *scratch = qk_ws_alloc(ctx, need);
+    if (!scratch) QK_FAIL(QK_ERR_OOM, "assign (prefiltered): workspace exhausted");
+    return qk_assign_pf_launch(ctx, x, n, c, m, d, metric, cnorm, nullptr, assign, val, nullptr, val != nullptr, scratch);
 }

@@ -264,6 +264,11 @@ int qk_dense_pf_device(qk_ctx *ctx, qk_store *s, int64_t row_off, int nrows, con
 bool qk_assign_pf_supported(int64_t n, int64_t m, int d, int metric);
 int qk_assign_pf_device(qk_ctx *ctx, const float *x, int64_t n, const float *c, int64_t m, int d, int metric, const float *cnorm,
                         int64_t *assign, float *val);
+// the same launches on caller-provided scratch (qk_assign_pf_scratch_bytes), optionally with ids that order ties and are returned,
+// and k_dense_argmin's packed word (key << 32 | id) as the output: the nearest-list search of many rows (qk_dense_device, k = 1)
+size_t qk_assign_pf_scratch_bytes(int64_t m, int d);
+int qk_assign_pf_launch(qk_ctx *ctx, const float *x, int64_t n, const float *c, int64_t m, int d, int metric, const float *cnorm,
+                        const int64_t *ids, int64_t *assign, float *val, unsigned long long *packed_out, bool want_keys, void *scratch);
 // top-k of every query over one list of a few thousand rows, keys and selection in one launch (qk_dense_fused.hip; 2 <= k <= 64, d <= 128)
 bool qk_dense_fused_supported(const qk_ctx *ctx, const qk_store *s, int64_t Q, int nrows, int k);
 int qk_dense_fused_device(qk_ctx *ctx, qk_store *s, int64_t row_off, int nrows, const qk_scan_args &a);

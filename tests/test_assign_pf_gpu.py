@@ -146,3 +146,51 @@ def test_kmeans_driver_uses_it_and_stays_equal_to_the_oracle(ctx):
     oc, oa, _ = O.kmeans(x.copy(), 100, "l2", niter=3, seed=11)
     np.testing.assert_array_equal(a, oa)
     np.testing.assert_array_equal(c.view(np.uint32), oc.view(np.uint32))
+
+
+# ---- the nearest-list search of many rows (qk_dense_device, k = 1: PartitionManager::add's parent search) through the same kernels ----
+def _parent(ctx, cent, ids):
+    from quake_amd.capi import Store
+    p = Store(ctx, cent.shape[1])
+    p.build_csr(np.array([0, cent.shape[0]], np.int64), ids, cent)
+    return p
+
+
+@pytest.mark.parametrize("metric", ["l2", "ip"])
+def test_nearest_list_of_many_rows(ctx, metric):
+    """coarse(nprobe = 1) over 70000 rows: ids that are NOT the row numbers (a parent after splits and deletes), duplicate centroids
+    (equal keys: the smaller ID wins, not the smaller row), against the fp32 argmin (the same rows in halves) and the oracle."""
+    rng = np.random.default_rng(21)
+    x, c = _mixture(rng, 70000, 600, 64)
+    c[100:150] = c[400:450]                               # duplicates
+    ids = rng.permutation(5000)[:600].astype(np.int64)    # arbitrary ids: of a duplicate pair either row may hold the smaller one
+    p = _parent(ctx, c, ids)
+    gp, gd = ctx.coarse(p, x, 1, metric)
+    assert ctx.last_scan_kernel() == "k_assign_pf"
+    h = 35000
+    p0, d0 = ctx.coarse(p, x[:h], 1, metric)
+    assert ctx.last_scan_kernel() != "k_assign_pf"
+    p1, d1 = ctx.coarse(p, x[h:], 1, metric)
+    np.testing.assert_array_equal(gp, np.concatenate([p0, p1]))
+    np.testing.assert_array_equal(gd.view(np.uint32), np.concatenate([d0, d1]).view(np.uint32))
+    op, od = O.coarse(x, c, ids, 1, metric, num_threads=0)
+    np.testing.assert_array_equal(gp, op)
+    np.testing.assert_array_equal(gd.view(np.uint32), od.view(np.uint32))
+    p.close()
+
+
+def test_nearest_list_through_search(ctx):
+    """search(nprobe = 1) of a 66000-query batch: the coarse step goes through the prefiltered kernels, the answer stays the oracle's"""
+    from helpers import make_ivf, make_queries
+    from quake_amd.capi import Store
+    ivf = make_ivf(200000, 32, 128, seed=31)
+    s = Store(ctx, 32)
+    s.build_csr(ivf["offsets"], ivf["ids"], ivf["vecs"])
+    p = _parent(ctx, ivf["centroids"], np.arange(128, dtype=np.int64))
+    q = make_queries(66000, 32, seed=32, like=ivf["x"])
+    gi, gd = ctx.search(p, s, q, 1, 10, "l2")
+    oi, od = O.search(q, ivf["centroids"], ivf["vecs"], ivf["ids"], ivf["offsets"], 1, 10, "l2", batched_scan=True)
+    np.testing.assert_array_equal(gi, oi)
+    np.testing.assert_array_equal(gd.view(np.uint32), od.view(np.uint32))
+    s.close()
+    p.close()
