@@ -1,13 +1,14 @@
 """Seeded stress of the prefiltered k-means assign (qk_assign_pf.hip: n >= 65536) against the fp32 MFMA kernel it stands in for
 (k_assign answers calls under 65536 rows: the same rows in slices), on shapes and data nobody picked by hand: random n / m / d,
 mixtures, structureless data, scales, duplicate centroids, rows that are centroids, heavy-tailed norms; both metrics; with and
-without distances.  python scripts/stress_assign_pf.py [n_cases] [seed0]"""
+without distances; every fourth case also as the nearest-list search of a parent store (coarse, nprobe 1) with permuted ids.
+python scripts/stress_assign_pf.py [n_cases] [seed0]"""
 import json, os, sys, time
 import numpy as np
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from quake_amd.capi import Context
+from quake_amd.capi import Context, Store
 
 ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
@@ -48,6 +49,19 @@ for c in range(ncases):
     ra, rv = torch.cat(ra), torch.cat(rv)
     torch.cuda.synchronize()
     ok = torch.equal(ga, ra) and torch.equal(na, ra) and torch.equal(gv.view(torch.int32), rv.view(torch.int32))
+    if c % 4 == 0:  # the nearest-list search through the same kernels: a parent store whose ids are not the row numbers
+        ids = torch.from_numpy(rng.permutation(4 * m)[:m].astype(np.int64))
+        par = Store(ctx, d)
+        par.build_csr(np.array([0, m], np.int64), ids.numpy(), cen.cpu().numpy())
+        gp, gd = ctx.coarse(par, x, 1, metric)
+        big = ctx.last_scan_kernel() == "k_assign_pf"
+        sp, sd = [], []
+        for lo in range(0, n, 60000):
+            pp, dd = ctx.coarse(par, x[lo:lo + 60000].contiguous(), 1, metric)
+            sp.append(pp); sd.append(dd)
+        torch.cuda.synchronize()
+        ok = ok and big and torch.equal(gp, torch.cat(sp)) and torch.equal(gd.view(torch.int32), torch.cat(sd).view(torch.int32))
+        par.close()
     if not ok:
         bad.append((seed0 + c, n, m, d, kind, metric, int((ga != ra).sum()), int((na != ra).sum())))
     print(json.dumps({"case": c, "n": n, "m": m, "d": d, "kind": kind, "metric": metric, "ok": bool(ok)}), flush=True)
