@@ -469,6 +469,12 @@ __device__ __forceinline__ float4 km_ld_agent(const float4 *p) {
     const float *f = (const float *)p;
     return make_float4(km_ld_agent(f), km_ld_agent(f + 1), km_ld_agent(f + 2), km_ld_agent(f + 3));
 }
+// a training row is read ONCE per update: non-temporal (the partition scan's loads gained 12 % that way)
+__device__ __forceinline__ float km_ld_once(const float *p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ float4 km_ld_once(const float4 *p) {
+    const f32x4 t = __builtin_nontemporal_load((const f32x4 *)p);
+    return make_float4(t[0], t[1], t[2], t[3]);
+}
 // gpart slot of group g of the centroid whose bucket starts at row b: distinct for all (centroid, group) pairs
 __device__ __host__ __forceinline__ int64_t km_gslot(int64_t b, int64_t c, int64_t g) { return b / KM_GROUP + c + g; }
 
@@ -509,7 +515,11 @@ __global__ __launch_bounds__(256) void k_accumulate_blocked(const V *__restrict_
                     for (int t = 0; t < KM_L1; t++) r[t] = sorted_rows[min(rb + t, ge - 1)];
                     V v[KM_L1];
 #pragma unroll
+#ifdef KM_PLAIN_LOADS
                     for (int t = 0; t < KM_L1; t++) v[t] = x[(int64_t)r[t] * units + u];
+#else
+                    for (int t = 0; t < KM_L1; t++) v[t] = km_ld_once(x + (int64_t)r[t] * units + u);
+#endif
                     V s = km_zero<V>();
                     if (cnt == KM_L1) {
 #pragma unroll
