@@ -1,7 +1,7 @@
 // qk_assign_pf.hip -- nearest centroid of MANY rows (k-means assign, the final assignment of an index build) behind a bf16 prefilter.
 //
 // Replaces the assign step of kmeans() / kmeans_refine_partitions() (src/cpp/src/clustering.cpp:51-66 -> faiss::Clustering::train /
-// IndexFlat::search(k = 1), :149-159 batched_scan_list(k = 1)) for n >= 2^16 rows, d <= 128 with d % 8 == 0.
+// IndexFlat::search(k = 1), :149-159 batched_scan_list(k = 1)) for n >= 40960 rows, d <= 128 with d % 8 == 0.
 //
 // k_assign (qk_kmeans.hip) computes every (row, centroid) key on v_mfma_f32_16x16x4_f32: 0.78 of the fp32 MFMA peak, 9.0 ms for
 // 2^20 rows x 4096 centroids -- and only ONE key per row matters.  Which one can be settled at bf16 precision with the one-sided
@@ -420,8 +420,11 @@ __global__ __launch_bounds__(64 * APF_WAVES) void k_assign_pf(AssignPfParams P) 
 bool qk_assign_pf_supported(int64_t n, int64_t m, int d, int metric) {
     if (qk_env_set("QK_NO_ASSIGN_PF")) return false;
     if (metric != QK_METRIC_L2 && metric != QK_METRIC_IP) return false;
-    // (a workgroup is 512 or 1024 rows: under 2^16 rows the chip is not filled; under 64 centroids there is nothing to filter)
-    return d % 8 == 0 && d >= 8 && d <= 128 && m >= 64 && m <= (1 << 24) && n >= 65536;
+    // (a workgroup is 512 or 1024 rows: with few rows the chip is not filled; under 64 centroids there is nothing to filter)
+#ifndef APF_MIN_ROWS
+#define APF_MIN_ROWS 40960  /* measured: 32768 rows tie with the fp32 kernel, 49152 win by 7-25 % (scripts/assign_crossover.py) */
+#endif
+    return d % 8 == 0 && d >= 8 && d <= 128 && m >= 64 && m <= (1 << 24) && n >= APF_MIN_ROWS;
 }
 
 template <int NM, int XT, int WAVES>

@@ -1,4 +1,4 @@
-"""Where the prefiltered assign stops paying: 262144 rows through qk_assign_pf.hip against the fp32 kernel (60000 rows, scaled), over the
+"""Where the prefiltered assign stops paying: 262144 rows through qk_assign_pf.hip against the fp32 kernel (30000 rows, scaled), over the
 number of centroids (64 ... 1024) and d = 128 / 64 / 32.  Round 4: the prefiltered form wins from 64 centroids on (0.15 against 0.42 ms).
 python scripts/assign_crossover.py"""
 import json, sys, os, torch
@@ -19,5 +19,5 @@ for d in (128, 64, 32):
     for m in (64, 128, 192, 256, 384, 512, 1024):
         c = xb[torch.randperm(1 << 20, device=dev)[:m]].contiguous()
         big = t(xb[:1 << 18].contiguous(), c)             # 262144 rows: prefiltered
-        small = t(xb[:60000].contiguous(), c) * (262144 / 60000.0)   # fp32 kernel, scaled to the same rows
+        small = t(xb[:30000].contiguous(), c) * (262144 / 30000.0)   # fp32 kernel, scaled to the same rows
         print(json.dumps({"d": d, "m": m, "pf_ms_262144": round(big, 4), "fp32_ms_scaled": round(small, 4)}), flush=True)

@@ -1,5 +1,5 @@
-"""Seeded stress of the prefiltered k-means assign (qk_assign_pf.hip: n >= 65536) against the fp32 MFMA kernel it stands in for
-(k_assign answers calls under 65536 rows: the same rows in slices), on shapes and data nobody picked by hand: random n / m / d,
+"""Seeded stress of the prefiltered k-means assign (qk_assign_pf.hip: n >= 40960) against the fp32 MFMA kernel it stands in for
+(k_assign answers calls under 40960 rows: the same rows in slices), on shapes and data nobody picked by hand: random n / m / d,
 mixtures, structureless data, scales, duplicate centroids, rows that are centroids, heavy-tailed norms; both metrics; with and
 without distances; every fourth case also as the nearest-list search of a parent store (coarse, nprobe 1) with permuted ids.
 python scripts/stress_assign_pf.py [n_cases] [seed0]"""
@@ -43,8 +43,8 @@ for c in range(ncases):
     ga, gv = ctx.kmeans_assign(x, cen, metric)
     na, _ = ctx.kmeans_assign(x, cen, metric, values=False)
     ra, rv = [], []
-    for lo in range(0, n, 60000):
-        a, v = ctx.kmeans_assign(x[lo:lo + 60000].contiguous(), cen, metric)
+    for lo in range(0, n, 30000):
+        a, v = ctx.kmeans_assign(x[lo:lo + 30000].contiguous(), cen, metric)
         ra.append(a); rv.append(v)
     ra, rv = torch.cat(ra), torch.cat(rv)
     torch.cuda.synchronize()
@@ -56,8 +56,8 @@ for c in range(ncases):
         gp, gd = ctx.coarse(par, x, 1, metric)
         big = ctx.last_scan_kernel() == "k_assign_pf"
         sp, sd = [], []
-        for lo in range(0, n, 60000):
-            pp, dd = ctx.coarse(par, x[lo:lo + 60000].contiguous(), 1, metric)
+        for lo in range(0, n, 30000):
+            pp, dd = ctx.coarse(par, x[lo:lo + 30000].contiguous(), 1, metric)
             sp.append(pp); sd.append(dd)
         torch.cuda.synchronize()
         ok = ok and big and torch.equal(gp, torch.cat(sp)) and torch.equal(gd.view(torch.int32), torch.cat(sd).view(torch.int32))

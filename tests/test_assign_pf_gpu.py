@@ -1,6 +1,6 @@
-"""k-means assign behind the bf16 prefilter (qk_assign_pf.hip: n >= 65536 rows, d % 8 == 0, d <= 128, m >= 64) against the oracle
+"""k-means assign behind the bf16 prefilter (qk_assign_pf.hip: n >= 40960 rows, d % 8 == 0, d <= 128, m >= 64) against the oracle
 (qo_kmeans_assign: clustering.cpp:51-66, :149-159 -- IndexFlat::search(k = 1) / batched_scan_list(k = 1)) AND against the fp32 MFMA
-kernel it stands in for (k_assign answers calls of fewer than 65536 rows: the same rows in two halves).  Assignments and distance
+kernel it stands in for (k_assign answers calls of fewer than 40960 rows: the same rows in two halves).  Assignments and distance
 bits must be equal: every key that decides goes through the exact chain, the prefilter only decides which keys are computed.
 The shapes aim at what a filter can get wrong: ties (duplicate centroids, duplicate rows, distance 0 where the expanded form clamps),
 rows at the same distance from many centroids, scales far from 1, ragged n / m / d, non-finite values."""
@@ -22,7 +22,7 @@ def ctx():
 
 def _halves(ctx, x, c, metric):
     h = x.shape[0] // 2
-    assert h < 65536 and x.shape[0] - h < 65536
+    assert h < 40960 and x.shape[0] - h < 40960
     a0, v0 = ctx.kmeans_assign(x[:h], c, metric)
     a1, v1 = ctx.kmeans_assign(x[h:], c, metric)
     return np.concatenate([a0, a1]), np.concatenate([v0, v1])
@@ -32,7 +32,7 @@ def _check(ctx, x, c, metric, oracle=True):
     ga, gv = ctx.kmeans_assign(x, c, metric)
     na, _ = ctx.kmeans_assign(x, c, metric, values=False)   # (val = NULL: rows with one candidate take it without an exact key)
     np.testing.assert_array_equal(na, ga)
-    if x.shape[0] < 131072:
+    if x.shape[0] < 81920:
         ha, hv = _halves(ctx, x, c, metric)
         np.testing.assert_array_equal(ga, ha)
         np.testing.assert_array_equal(gv.view(np.uint32), hv.view(np.uint32))
@@ -51,6 +51,7 @@ def _mixture(rng, n, m, d, sigma=0.3):
 
 @pytest.mark.parametrize("n,m,d,metric", [
     (65536, 64, 128, "l2"),
+    (40960, 300, 128, "l2"),
     (70001, 1000, 128, "l2"),
     (70001, 1000, 128, "ip"),
     (66000, 4096, 128, "l2"),
