@@ -838,7 +838,7 @@ int qk_dense_device(qk_ctx *ctx, qk_store *s, int64_t list_no, const qk_scan_arg
         // many rows (PartitionManager::add's parent search, a nearest-list search of a huge batch): the k-means assign's bf16
         // prefilter (qk_assign_pf.hip) with the list's ids as the tie order -- the same packed words, ~4x the rate
         const float *rm = nullptr;
-        bool apf = a.x && qk_assign_pf_supported(Q, nrows, s->d, a.metric) && !qk_env_set("QK_NO_DENSE_APF");
+        bool apf = a.x && ((uintptr_t)a.x & 15) == 0 && qk_assign_pf_supported(Q, nrows, s->d, a.metric) && !qk_env_set("QK_NO_DENSE_APF");
         if (apf) QK_TRY(qk_store_rowmajor(s, pt.row_off, nrows, &rm));
         if (!rm) apf = false;  // (a list beyond the row-major cap, a table not yet synchronised)
         const size_t apf_bytes = apf ? qk_assign_pf_scratch_bytes(nrows, s->d) : 0;

@@ -649,7 +649,9 @@ static int assign_device(qk_ctx *ctx, const float *x, int64_t n, const float *c,
     QK_HIP(hipMemsetAsync(cnorm, 0, (size_t)mt * 16 * sizeof(float), ctx->stream));
     QK_TRY(qk_launch_ingest(ctx, c, nullptr, m, d, nblk, ctile, cnorm, nullptr, 0));
     // many rows: the bf16-prefiltered form (same bits, ~6x the rate: qk_assign_pf.hip)
-    if (qk_assign_pf_supported(n, m, d, metric)) return qk_assign_pf_device(ctx, x, n, c, m, d, metric, cnorm, assign, val);
+    // (its float4 loads want 16-byte aligned rows: d % 8 == 0 is part of `supported`, the base pointers are checked here)
+    if (qk_assign_pf_supported(n, m, d, metric) && ((uintptr_t)x & 15) == 0 && ((uintptr_t)c & 15) == 0)
+        return qk_assign_pf_device(ctx, x, n, c, m, d, metric, cnorm, assign, val);
     AssignParams ap;
     ap.x = x;
     ap.n = n;

@@ -195,3 +195,22 @@ def test_nearest_list_through_search(ctx):
     np.testing.assert_array_equal(gd.view(np.uint32), od.view(np.uint32))
     s.close()
     p.close()
+
+
+def test_rows_that_are_not_16_byte_aligned_take_the_fp32_kernel(ctx):
+    """the prefiltered kernels read rows as float4: a base pointer off by one float must not reach them (and the answer stays right)"""
+    import torch
+    rng = np.random.default_rng(41)
+    x, c = _mixture(rng, 50000, 200, 64)
+    buf = torch.empty(50000 * 64 + 1, dtype=torch.float32, device="cuda")
+    xt = buf[1:].view(50000, 64)
+    xt.copy_(torch.from_numpy(x))
+    ct = torch.from_numpy(c).cuda()
+    assert xt.data_ptr() % 16 == 4
+    torch.cuda.synchronize()
+    a, v = ctx.kmeans_assign(xt, ct, "l2")
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    oa, ov = O.kmeans_assign(x, c, "l2")
+    np.testing.assert_array_equal(a.cpu().numpy(), oa)
+    np.testing.assert_array_equal(v.cpu().numpy().view(np.uint32), ov.view(np.uint32))
