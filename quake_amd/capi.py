@@ -147,15 +147,16 @@ class Context:
         return dict(num_cus=cus.value, clock_khz=clk.value, hbm_bytes=hbm.value, arch=arch.value.decode())
 
     # ---- search ---------------------------------------------------------------------------------------
-    def coarse(self, parent, x, nprobe, metric):
+    def coarse(self, parent, x, nprobe, metric, values=True):
+        """the nprobe nearest lists of every row (and, with values, their distances; values=False passes out_dist = NULL)"""
         x = _f32(x)
         Q = x.shape[0]
         kk = int(min(nprobe, parent.ntotal()))
         mem = _mem_of(x)
         out_p = _empty_like_mem((Q, kk), np.int64, x)
-        out_d = _empty_like_mem((Q, kk), np.float32, x)
-        check(self.lib.qk_coarse(self.h, parent.h, _ptr(x), Q, int(nprobe), metric_code(metric), _ptr(out_p), _ptr(out_d),
-                                 mem))
+        out_d = _empty_like_mem((Q, kk), np.float32, x) if values else None
+        check(self.lib.qk_coarse(self.h, parent.h, _ptr(x), Q, int(nprobe), metric_code(metric), _ptr(out_p),
+                                 _ptr(out_d) if values else None, mem))
         return out_p, out_d
 
     def scan(self, store, x, pids, k, metric, timing=False):

@@ -83,7 +83,7 @@ int run_search(qk_ctx *ctx, qk_store *parent, qk_store *s, const float *x, int64
         b += bp;
         sv.out_ids = (int64_t *)b;
         b += bi;
-        sv.out_dist = (float *)b;
+        sv.out_dist = out_dist ? (float *)b : nullptr;  // (no distances asked for: none computed -- the kernels take NULL)
     } else {
         sv.x = x;
         sv.out_ids = out_ids;

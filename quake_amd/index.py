@@ -432,7 +432,7 @@ class QuakeIndex:
             if self.track_hits and self.parent is not None:
                 # hit tracking for maintenance(): the probed partitions are needed on the host, so coarse and scan are
                 # two calls here (same kernels, one extra copy of [Q, nprobe] ids)
-                pids, _ = self._ctx.coarse(self.parent._store, xd, nprobe, self.metric_)
+                pids, _ = self._ctx.coarse(self.parent._store, xd, nprobe, self.metric_, values=False)
                 ids, dist, tm = self._ctx.scan(self._store, xd, pids, int(k), self.metric_, timing=True)
                 self.record_query_hits(pids.cpu().numpy())
             else:
@@ -502,7 +502,7 @@ class QuakeIndex:
             assign = torch.zeros(n, dtype=torch.int64, device=xd.device)
         else:
             # parent_->search(x, {k = 1, nprobe = parent nlist}) (:219-230) == coarse step with nprobe 1
-            pids, _ = self._ctx.coarse(self.parent._store, xd, 1, self.metric_)
+            pids, _ = self._ctx.coarse(self.parent._store, xd, 1, self.metric_, values=False)
             assign = pids.reshape(-1)
         info.find_partition_time_us = _us(t0)
         t0 = time.perf_counter()
@@ -591,7 +591,7 @@ class QuakeIndex:
         """where would the vectors of partition `pid` go if it were deleted: the other partitions among every vector's two
         nearest centroids and how many vectors name each (maintenance_policies.cpp:79-101).  -> (pids, counts) lists."""
         vecs, _ = self._store.get_list(int(pid))
-        near, _ = self._ctx.coarse(self.parent._store, torch.from_numpy(vecs).cuda(self._device), 2, self.metric_)
+        near, _ = self._ctx.coarse(self.parent._store, torch.from_numpy(vecs).cuda(self._device), 2, self.metric_, values=False)
         flat = near.reshape(-1)
         flat = flat[(flat != int(pid)) & (flat >= 0)]
         uniq, counts = torch.unique(flat, return_counts=True)
@@ -601,7 +601,7 @@ class QuakeIndex:
         """the partitions whose centroids are among the `radius` nearest of each given partition's centroid, sorted
         (maintenance_policies.cpp:187-202)."""
         cent = self.parent.get(torch.tensor([int(p) for p in pids], dtype=torch.int64))
-        near, _ = self._ctx.coarse(self.parent._store, cent.cuda(self._device), int(radius), self.metric_)
+        near, _ = self._ctx.coarse(self.parent._store, cent.cuda(self._device), int(radius), self.metric_, values=False)
         out = torch.unique(near.reshape(-1))
         return [int(v) for v in out[out != -1].tolist()]
 
@@ -655,7 +655,7 @@ class QuakeIndex:
                     continue
                 # PartitionManager::add(vectors, ids, {}, check_uniques = false): nearest remaining centroid
                 xd = torch.from_numpy(v).cuda(self._device)
-                near, _ = self._ctx.coarse(self.parent._store, xd, 1, self.metric_)
+                near, _ = self._ctx.coarse(self.parent._store, xd, 1, self.metric_, values=False)
                 self._store.add_batch(torch.from_numpy(i).cuda(self._device), xd, near.reshape(-1).contiguous())
 
     # -- sizes ---------------------------------------------------------------------------------------------------------------

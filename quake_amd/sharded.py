@@ -63,7 +63,7 @@ class GpuEngine:
 
     def coarse(self, q, nprobe):
         """[n, nprobe] global partition numbers for a slice of the batch (replicated centroids)."""
-        return self.ctx.coarse(self.parent, q, nprobe, self.metric)[0]
+        return self.ctx.coarse(self.parent, q, nprobe, self.metric, values=False)[0]
 
     def scan(self, q, pids, k, out=None):
         """local top-k over the probed lists this rank owns: (ids [Q,k], merge keys [Q,k]).  Ranks exchange the merge key
@@ -91,7 +91,7 @@ class GpuEngine:
 
     def assign(self, x):
         """nearest list (global number) of every vector: the k = 1 parent search of PartitionManager::add"""
-        return self.ctx.coarse(self.parent, x, 1, self.metric)[0].reshape(-1)
+        return self.ctx.coarse(self.parent, x, 1, self.metric, values=False)[0].reshape(-1)
 
     def add_local(self, ids, x, assign):
         self.store.add_batch(ids, x, assign)
