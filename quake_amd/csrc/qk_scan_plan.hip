@@ -208,7 +208,9 @@ int qk_scan_plan(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, bool emit, int
         rlc = RlCost{std::max(1, rl_h0), std::max(1, rl_h1), std::max(0, rl_e), std::max(0, rl_ovh), std::max(1, rl_m), qb};
         // (4 waves per CU, each with its own LDS copy of the pass's queries and its pools: d = 128 with k = 32 does not fit)
         const bool rl_fits = fits(qb, C_rl);
-        const bool rl_ok = nblk <= 8 && k <= 32 && rl_fits && !a.per_pair && !emit && npairs > 0 && ctx->qprep_xp4 != nullptr &&
+        // (per_pair -- the rounds of the recall-target search -- takes these forms too: every pool IS a (query, list) pair's, the bound
+        //  is the caller's and is never published; round 4: its rounds ran 670 us each in the plain tile form)
+        const bool rl_ok = nblk <= 8 && k <= 32 && rl_fits && !emit && npairs > 0 && ctx->qprep_xp4 != nullptr &&
                            a.xq4 == (const float4 *)ctx->qprep;
         use_rl = rl_ok && (rl_env == 1 || (rl_env < 0 && per_list < rl_max && P > 1));
         rl_avail = rl_ok && rl_env != 0 && P > 1;
@@ -259,7 +261,7 @@ int qk_scan_plan(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, bool emit, int
         const int64_t mean_rows = s->ntotal / std::max<int64_t>(1, s->n_nonempty);
         const bool long_lists = mean_rows >= hot_mean_rows;
         static const int rl_env2 = qk_env_int("QK_SCAN_RL", -1);
-        const bool rl_possible = nblk <= 8 && k <= 32 && rl_waves == 4 && rlc.qb == 32 && !a.per_pair && !emit && npairs >= 1024 && P > 1 &&
+        const bool rl_possible = nblk <= 8 && k <= 32 && rl_waves == 4 && rlc.qb == 32 && !emit && npairs >= 1024 && P > 1 &&
                                  ctx->qprep_xp4 != nullptr && a.xq4 == (const float4 *)ctx->qprep && rl_env2 != 0 &&
                                  4 * ((qk_scan_rl_lds_per_wave(nblk, std::min(64, qk_round_up(k + 32, 4)), rlc.qb) + 15) & ~(size_t)15) <= (size_t)160 * 1024;
         if (rl_possible && hot_min > 0 && long_lists) {
@@ -293,8 +295,9 @@ int qk_scan_plan(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, bool emit, int
     qk_ctx::form_stat *fmeasure = nullptr;
     {
         const bool admissible[3] = {true, rl_avail, mixed_avail};
-        if (ctx->form_feedback && !a.per_pair && !emit && npairs >= 1024 && P > 1 && (rl_avail || mixed_avail)) {
-            const uint64_t key = (s->uid * 0x9E3779B97F4A7C15ull) ^ ((uint64_t)(Q >> 6) << 40) ^ ((uint64_t)P << 24) ^ ((uint64_t)k << 8) ^ (uint64_t)a.metric;
+        if (ctx->form_feedback && !emit && npairs >= 1024 && P > 1 && (rl_avail || mixed_avail)) {
+            const uint64_t key = (s->uid * 0x9E3779B97F4A7C15ull) ^ ((uint64_t)(Q >> 6) << 40) ^ ((uint64_t)P << 24) ^ ((uint64_t)k << 8) ^ (uint64_t)a.metric ^
+                                 (a.per_pair ? 1ull << 63 : 0ull);
             form = qk_pick_form(ctx, key, form_static, admissible, &fmeasure);
         }
     }
