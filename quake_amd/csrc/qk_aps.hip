@@ -29,6 +29,7 @@ constexpr int APS_NX = 1001;      // geometry.h:7  NUM_X_VALUES
 constexpr double APS_STOP = 1.0e-8;   // geometry.h:9
 constexpr double APS_TINY = 1.0e-30;  // geometry.h:10
 constexpr int APS_CH = 32;        // partitions per query and round (upper bound)
+constexpr int APS_FIRST = 2;      // partitions of the first round
 
 // ---- regularised incomplete beta I_x(a, b): Lentz's continued fraction, the published algorithm geometry.h uses.
 // One definition serves the host (table of the precomputed path) and the device (IP metric / use_precomputed = false).
@@ -353,7 +354,7 @@ __global__ __launch_bounds__(64) void k_aps_update(UpdateParams U) {
     }
 }
 
-__global__ void k_aps_init(int64_t Q, int M, int metric, int32_t *run_cnt, int32_t *have_probs, int32_t *next_p, int32_t *want,
+__global__ void k_aps_init(int64_t Q, int M, int first, int metric, int32_t *run_cnt, int32_t *have_probs, int32_t *next_p, int32_t *want,
                            int32_t *nscan, float *radius, uint32_t *run_tau) {
     const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= Q) return;
@@ -361,7 +362,7 @@ __global__ void k_aps_init(int64_t Q, int M, int metric, int32_t *run_cnt, int32
     run_tau[q] = 0u;
     have_probs[q] = 0;
     next_p[q] = 0;
-    want[q] = min(2, M);  // the estimate is empty before the second partition: nobody stops earlier
+    want[q] = min(first, M);  // (at least 2: the estimate is empty before the second partition, nobody stops earlier)
     nscan[q] = 0;
     radius[q] = metric == QK_METRIC_L2 ? 1000000.0f : -1000000.0f;  // query_coordinator.cpp:523-527
 }
@@ -390,7 +391,9 @@ extern "C" int qk_search_aps(qk_ctx *ctx, qk_store *parent, qk_store *s, const f
     if (M < 2) QK_FAIL(QK_ERR_INVALID, "Boundary distances must have at least 2 partitions to create an estimate.");  // geometry.h:350
     if (M > QK_MAX_NPROBE) QK_FAIL(QK_ERR_UNSUPPORTED, "qk_search_aps: %d candidate partitions exceed QK_MAX_NPROBE=%d", M, QK_MAX_NPROBE);
     hipStream_t st = ctx->stream;
-    const int CH = std::min(APS_CH, M);
+    static const int aps_ch = std::max(2, qk_env_int("QK_APS_CH", APS_CH));
+    static const int aps_first = std::max(2, qk_env_int("QK_APS_FIRST", APS_FIRST));
+    const int CH = std::min(aps_ch, M);
 
     // ---- partition id -> arena row of its centroid (host mirror of the parent's ids) -------------------------------
     int64_t max_id = -1;
@@ -489,7 +492,7 @@ extern "C" int qk_search_aps(qk_ctx *ctx, qk_store *parent, qk_store *s, const f
         bp.euclid = metric == QK_METRIC_L2 ? 1 : 0;
         bp.bd = bd;
         hipLaunchKernelGGL(k_aps_boundary, dim3((unsigned)((QM + 255) / 256)), dim3(256), 0, st, bp);
-        hipLaunchKernelGGL(k_aps_init, dim3((unsigned)((Q + 255) / 256)), dim3(256), 0, st, Q, M, metric, run_cnt, have_probs, next_p,
+        hipLaunchKernelGGL(k_aps_init, dim3((unsigned)((Q + 255) / 256)), dim3(256), 0, st, Q, M, std::min(aps_first, CH), metric, run_cnt, have_probs, next_p,
                            want, nscan, radius, run_tau);
         QK_HIP(hipGetLastError());
     }
