@@ -197,6 +197,63 @@ QK_API int qk_merge_topk_packed(qk_ctx *ctx, const void *packed, int G, int64_t 
 /* When enabled, qk_scan/qk_search return squared L2 distances (the merge key) instead of sqrt distances. */
 QK_API int qk_ctx_set_squared_l2(qk_ctx *ctx, int enabled);
 
+/* ---- device group: IndexBuildParams::num_workers as GPUs ---------------------------------------------------------------
+ * The reference spreads a search over cores with num_workers (common.h:73,127): QueryCoordinator::initialize_workers
+ * (query_coordinator.cpp:50-74) starts one thread per core, PartitionManager::distribute_partitions pins partition i to core
+ * i % num_workers (partition_manager.cpp:557-603), worker_scan (query_coordinator.cpp:243-469) hands every core the jobs of its
+ * partitions and batch_adds the per-core buffers into the global one (:167-173,231-235).  Here a worker is a device: a group is
+ * ONE process driving G members -- one context + one shard store each; members may share a physical device (num_workers larger
+ * than the node, and one-GPU test boxes) -- and list p lives in member p % G.  A search: the batch reaches the lead (member 0),
+ * the others pull it over xGMI; the coarse step is split by queries and every member writes its slice of the [Q][nprobe] list
+ * numbers straight into every other member's copy (peer stores); every member scans the whole batch over ITS lists and writes
+ * its packed [Q][k] (ids, merge keys) block -- qk_pack_topk's layout -- into the lead's receive buffer; the lead merges the G
+ * blocks under the (key, id) order.  Events order the devices; there is no host thread per device and no host synchronisation
+ * inside a call on device buffers.  Results (ids and distance bits) equal the one-store search on the same lists.
+ * Requires peer access between all distinct devices of the group (QK_ERR_UNSUPPORTED otherwise). */
+typedef struct qk_group qk_group;
+QK_API int qk_group_create(const int *devices, int G, int d, qk_group **out);   /* initialize_workers :50-74 */
+QK_API int qk_group_destroy(qk_group *g);                                       /* shutdown_workers :77-95 */
+QK_API int qk_group_size(qk_group *g);
+/* member i's context and shard store (borrowed; the store holds the lists p with p % G == i under their global numbers) */
+QK_API int qk_group_member(qk_group *g, int i, qk_ctx **ctx, qk_store **store);
+QK_API int qk_group_owner(qk_group *g, int64_t list_no);                        /* get_partition_core_id: list_no % G */
+/* The lead's stream: outputs in device memory are complete in its order (qk_ctx_set_stream / _set_null_stream / _get_stream of
+ * the lead's context); inputs in device memory are read behind whatever that stream holds at the time of the call. */
+QK_API int qk_group_set_stream(qk_group *g, void *hip_stream);
+QK_API int qk_group_set_null_stream(qk_group *g);
+QK_API int qk_group_get_stream(qk_group *g, void **hip_stream, int *kind);
+QK_API int qk_group_synchronize(qk_group *g);                                   /* every member's stream */
+QK_API int qk_group_set_form_feedback(qk_group *g, int enabled);                /* qk_ctx_set_form_feedback on every member */
+/* The store surface over the members (same arguments, same errors as the qk_store_* call each one routes to). */
+QK_API int qk_group_reset(qk_group *g);
+QK_API int qk_group_add_list(qk_group *g, int64_t list_no);
+QK_API int qk_group_remove_list(qk_group *g, int64_t list_no);
+QK_API int qk_group_add_entries(qk_group *g, int64_t list_no, int64_t n, const int64_t *ids, const float *vecs, int mem);
+QK_API int qk_group_add_batch(qk_group *g, int64_t n, const int64_t *ids, const float *vecs, const int64_t *assign, int mem);
+QK_API int qk_group_build_csr(qk_group *g, int64_t nlist, const int64_t *offsets_host, const int64_t *ids, const float *vecs,
+                              int mem);                                         /* init_partitions + distribute_partitions */
+QK_API int qk_group_remove_ids(qk_group *g, int64_t n, const int64_t *ids_host, int64_t *n_removed);
+QK_API int qk_group_list_size(qk_group *g, int64_t list_no, int64_t *out);
+QK_API int64_t qk_group_ntotal(qk_group *g);
+QK_API int64_t qk_group_nlist(qk_group *g);
+QK_API int qk_group_d(qk_group *g);
+QK_API int qk_group_list_ids(qk_group *g, int64_t *out_host, int64_t *n);
+QK_API int qk_group_get_list(qk_group *g, int64_t list_no, float *vecs_out, int64_t *ids_out, int mem); /* complete on return */
+QK_API int qk_group_get_vector(qk_group *g, int64_t id, float *vec_out_host, int *found);
+QK_API int64_t qk_group_device_bytes(qk_group *g);
+/* qk_store_refine_lists over lists of several members: they meet in a temporary store on the member holding the first one,
+ * are refined there (same order, same arithmetic) and go back to their owners, device to device. */
+QK_API int qk_group_refine_lists(qk_group *g, const int64_t *list_nos, int64_t m, float *centroids, int metric,
+                                 int refinement_iterations, int mem);
+/* worker_scan (query_coordinator.cpp:243-469) through scan_partitions (:659-673): qk_scan over the members. */
+QK_API int qk_group_scan(qk_group *g, const float *x, int64_t Q, const int64_t *pids, int P, int k, int metric, int64_t *out_ids,
+                         float *out_dist, int mem, qk_timing *timing);
+/* QueryCoordinator::search (:612-657) with workers: qk_search over the members.  `parent` is the parent's ordinary store (any
+ * device); the group keeps a replica of it per member and refreshes the replicas when the parent has changed.  timing:
+ * coarse_ms / scan_ms / merge_ms / total_ms between events on the lead, the counters summed over the members. */
+QK_API int qk_group_search(qk_group *g, qk_store *parent, const float *x, int64_t Q, int nprobe, int k, int metric,
+                           int64_t *out_ids, float *out_dist, int mem, qk_timing *timing);
+
 /* ---- k-means ----------------------------------------------------------------------------------- */
 /* Nearest-centroid assignment: IndexFlat::search(n, x, 1) (clustering.cpp:63-66) and the
  * batched_scan_list(k=1) of kmeans_refine_partitions (clustering.cpp:149-159).

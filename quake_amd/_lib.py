@@ -85,6 +85,34 @@ SIGNATURES = {
     "qk_kmeans_update": (_int, [_vp, _vp, _vp, _i64, _int, _vp, _int]),
     "qk_kmeans_last_timing": (_int, [_vp, _vp, _vp, _vp, _vp]),
     "qk_rand_perm": (_int, [_i64, _i64, C.c_uint64, _vp]),
+    "qk_group_create": (_int, [C.POINTER(_int), _int, _int, C.POINTER(_vp)]),
+    "qk_group_destroy": (_int, [_vp]),
+    "qk_group_size": (_int, [_vp]),
+    "qk_group_member": (_int, [_vp, _int, C.POINTER(_vp), C.POINTER(_vp)]),
+    "qk_group_owner": (_int, [_vp, _i64]),
+    "qk_group_set_stream": (_int, [_vp, _vp]),
+    "qk_group_set_null_stream": (_int, [_vp]),
+    "qk_group_get_stream": (_int, [_vp, C.POINTER(_vp), C.POINTER(_int)]),
+    "qk_group_synchronize": (_int, [_vp]),
+    "qk_group_set_form_feedback": (_int, [_vp, _int]),
+    "qk_group_reset": (_int, [_vp]),
+    "qk_group_add_list": (_int, [_vp, _i64]),
+    "qk_group_remove_list": (_int, [_vp, _i64]),
+    "qk_group_add_entries": (_int, [_vp, _i64, _i64, _vp, _vp, _int]),
+    "qk_group_add_batch": (_int, [_vp, _i64, _vp, _vp, _vp, _int]),
+    "qk_group_build_csr": (_int, [_vp, _i64, _vp, _vp, _vp, _int]),
+    "qk_group_remove_ids": (_int, [_vp, _i64, _vp, C.POINTER(_i64)]),
+    "qk_group_list_size": (_int, [_vp, _i64, C.POINTER(_i64)]),
+    "qk_group_ntotal": (_i64, [_vp]),
+    "qk_group_nlist": (_i64, [_vp]),
+    "qk_group_d": (_int, [_vp]),
+    "qk_group_list_ids": (_int, [_vp, _vp, C.POINTER(_i64)]),
+    "qk_group_get_list": (_int, [_vp, _i64, _vp, _vp, _int]),
+    "qk_group_get_vector": (_int, [_vp, _i64, _vp, C.POINTER(_int)]),
+    "qk_group_device_bytes": (_i64, [_vp]),
+    "qk_group_refine_lists": (_int, [_vp, _vp, _i64, _vp, _int, _int, _int]),
+    "qk_group_scan": (_int, [_vp, _vp, _i64, _vp, _int, _int, _int, _vp, _vp, _int, C.POINTER(QkTiming)]),
+    "qk_group_search": (_int, [_vp, _vp, _vp, _i64, _int, _int, _int, _vp, _vp, _int, C.POINTER(QkTiming)]),
 }
 
 _lib = None

@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libquake_hip.so")
-SOURCES = ["qk_ctx.hip", "qk_store.hip", "qk_scan.hip", "qk_scan_plan.hip", "qk_merge.hip", "qk_scan_rl.hip", "qk_small.hip", "qk_dense.hip", "qk_dense_pf.hip", "qk_dense_fused.hip", "qk_kmeans.hip", "qk_assign_pf.hip", "qk_aps.hip", "qk_api.hip"]
+SOURCES = ["qk_ctx.hip", "qk_store.hip", "qk_scan.hip", "qk_scan_plan.hip", "qk_merge.hip", "qk_scan_rl.hip", "qk_small.hip", "qk_dense.hip", "qk_dense_pf.hip", "qk_dense_fused.hip", "qk_kmeans.hip", "qk_assign_pf.hip", "qk_aps.hip", "qk_api.hip", "qk_group.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fvisibility=hidden",
          "-Wall", "-Wno-unused-function", "-Wno-unused-variable", "-Wno-unused-value"]

@@ -419,3 +419,179 @@ class Store:
 
     def device_bytes(self):
         return self.lib.qk_store_device_bytes(self.h)
+
+
+class Group:
+    """Device group (qk_group_*): IndexBuildParams.num_workers as GPUs.  One process drives G members -- a context and a shard
+    store each, list p in member p % G -- behind the Store surface (same method names; every call is routed to the member that
+    holds the list) plus search() / scan() over the members.  `devices`: one HIP ordinal per member (repeats allowed)."""
+
+    def __init__(self, devices, d):
+        self.lib = _lib.load()
+        devs = [int(v) for v in devices]
+        arr = (C.c_int * len(devs))(*devs)
+        self.h = C.c_void_p()
+        check(self.lib.qk_group_create(arr, len(devs), int(d), C.byref(self.h)))
+        self.devices = devs
+        self.device = devs[0]
+        self.d = int(d)
+
+    def close(self):
+        if getattr(self, "h", None) and self.h:
+            self.lib.qk_group_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def size(self):
+        return int(self.lib.qk_group_size(self.h))
+
+    def owner(self, list_no):
+        return int(self.lib.qk_group_owner(self.h, int(list_no)))
+
+    def member_handles(self, i):
+        """(qk_ctx*, qk_store*) of member i (borrowed)"""
+        c, s = C.c_void_p(), C.c_void_p()
+        check(self.lib.qk_group_member(self.h, int(i), C.byref(c), C.byref(s)))
+        return c, s
+
+    def member_list_ids(self, i):
+        """list numbers member i holds"""
+        _, s = self.member_handles(i)
+        n = C.c_int64()
+        check(self.lib.qk_store_list_ids(s, None, C.byref(n)))
+        out = np.empty(n.value, np.int64)
+        if n.value:
+            check(self.lib.qk_store_list_ids(s, _ptr(out), C.byref(n)))
+        return out
+
+    def set_stream(self, hip_stream):
+        """the lead's stream (see Context.set_stream)"""
+        if hip_stream is None:
+            check(self.lib.qk_group_set_stream(self.h, None))
+        elif int(hip_stream) == 0:
+            check(self.lib.qk_group_set_null_stream(self.h))
+        else:
+            check(self.lib.qk_group_set_stream(self.h, C.c_void_p(int(hip_stream))))
+
+    def synchronize(self):
+        check(self.lib.qk_group_synchronize(self.h))
+
+    def set_form_feedback(self, enabled):
+        check(self.lib.qk_group_set_form_feedback(self.h, int(bool(enabled))))
+
+    # ---- the Store surface ------------------------------------------------------------------------------------------------
+    def reset(self):
+        check(self.lib.qk_group_reset(self.h))
+
+    def add_list(self, list_no):
+        check(self.lib.qk_group_add_list(self.h, int(list_no)))
+
+    def remove_list(self, list_no):
+        check(self.lib.qk_group_remove_list(self.h, int(list_no)))
+
+    def add_entries(self, list_no, ids, vecs):
+        ids, vecs = _i64(ids), _f32(vecs)
+        check(self.lib.qk_group_add_entries(self.h, int(list_no), ids.shape[0], _ptr(ids), _ptr(vecs), _mem_of(ids, vecs)))
+
+    def add_batch(self, ids, vecs, assign):
+        ids, vecs, assign = _i64(ids), _f32(vecs), _i64(assign)
+        check(self.lib.qk_group_add_batch(self.h, ids.shape[0], _ptr(ids), _ptr(vecs), _ptr(assign), _mem_of(ids, vecs, assign)))
+
+    def build_csr(self, offsets, ids, vecs):
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        ids, vecs = _i64(ids), _f32(vecs)
+        check(self.lib.qk_group_build_csr(self.h, offsets.shape[0] - 1, _ptr(offsets), _ptr(ids), _ptr(vecs), _mem_of(ids, vecs)))
+
+    def remove_ids(self, ids):
+        ids = np.ascontiguousarray(ids, dtype=np.int64)
+        n = C.c_int64()
+        check(self.lib.qk_group_remove_ids(self.h, ids.shape[0], _ptr(ids), C.byref(n)))
+        return n.value
+
+    def list_size(self, list_no):
+        out = C.c_int64()
+        check(self.lib.qk_group_list_size(self.h, int(list_no), C.byref(out)))
+        return out.value
+
+    def ntotal(self):
+        return self.lib.qk_group_ntotal(self.h)
+
+    def nlist(self):
+        return self.lib.qk_group_nlist(self.h)
+
+    def list_ids(self):
+        n = C.c_int64()
+        check(self.lib.qk_group_list_ids(self.h, None, C.byref(n)))
+        out = np.empty(n.value, np.int64)
+        if n.value:
+            check(self.lib.qk_group_list_ids(self.h, _ptr(out), C.byref(n)))
+        return out
+
+    def get_list(self, list_no):
+        n = self.list_size(list_no)
+        vecs = np.empty((n, self.d), np.float32)
+        ids = np.empty(n, np.int64)
+        check(self.lib.qk_group_get_list(self.h, int(list_no), _ptr(vecs), _ptr(ids), QK_MEM_HOST))
+        return vecs, ids
+
+    def get_list_device(self, list_no):
+        """(vectors [n, d] as a CUDA tensor on the LEAD's device, written there by the owner; ids [n] as a host array)"""
+        import torch
+        n = self.list_size(list_no)
+        vecs = torch.empty((n, self.d), dtype=torch.float32, device=torch.device("cuda", self.device))
+        ids = np.empty(n, np.int64)
+        if n:
+            check(self.lib.qk_group_get_list(self.h, int(list_no), _ptr(vecs), None, QK_MEM_DEVICE))
+            check(self.lib.qk_group_get_list(self.h, int(list_no), None, _ptr(ids), QK_MEM_HOST))
+        return vecs, ids
+
+    def get_vector(self, vid):
+        out = np.empty(self.d, np.float32)
+        found = C.c_int()
+        check(self.lib.qk_group_get_vector(self.h, int(vid), _ptr(out), C.byref(found)))
+        return out if found.value else None
+
+    def refine_lists(self, list_nos, centroids, metric, refinement_iterations=0):
+        list_nos = np.ascontiguousarray(list_nos, dtype=np.int64)
+        c = _f32(centroids)
+        c = c.clone() if _is_torch(c) else c.copy()
+        check(self.lib.qk_group_refine_lists(self.h, _ptr(list_nos), list_nos.shape[0], _ptr(c), metric_code(metric),
+                                             int(refinement_iterations), _mem_of(c)))
+        return c
+
+    def device_bytes(self):
+        return self.lib.qk_group_device_bytes(self.h)
+
+    # ---- search over the members ------------------------------------------------------------------------------------------
+    def search(self, parent, x, nprobe, k, metric, timing=False, out=None):
+        """QueryCoordinator::search with workers.  parent: the parent's Store (replicated per member by the library)."""
+        x = _f32(x)
+        Q = x.shape[0]
+        if out is None:
+            out_i = _empty_like_mem((Q, k), np.int64, x)
+            out_d = _empty_like_mem((Q, k), np.float32, x)
+        else:
+            out_i, out_d = out
+        t = QkTiming()
+        check(self.lib.qk_group_search(self.h, parent.h, _ptr(x), Q, int(nprobe), int(k), metric_code(metric), _ptr(out_i),
+                                       _ptr(out_d), _mem_of(x), C.byref(t) if timing else None))
+        return (out_i, out_d, timing_dict(t)) if timing else (out_i, out_d)
+
+    def scan(self, x, pids, k, metric, timing=False):
+        """scan_partitions with workers (worker_scan): pids [Q, P] (or [P]: the same set for every query), -1 = skip"""
+        x, pids = _f32(x), _i64(pids)
+        Q = x.shape[0]
+        if pids.ndim == 1:
+            pids = (pids[None, :].expand(Q, -1).contiguous() if _is_torch(pids)
+                    else np.ascontiguousarray(np.broadcast_to(pids[None, :], (Q, pids.shape[0]))))
+        out_i = _empty_like_mem((Q, k), np.int64, x)
+        out_d = _empty_like_mem((Q, k), np.float32, x)
+        t = QkTiming()
+        check(self.lib.qk_group_scan(self.h, _ptr(x), Q, _ptr(pids) if pids.shape[1] > 0 else None, int(pids.shape[1]), int(k),
+                                     metric_code(metric), _ptr(out_i), _ptr(out_d), _mem_of(x, pids), C.byref(t) if timing else None))
+        return (out_i, out_d, timing_dict(t)) if timing else (out_i, out_d)

@@ -16,8 +16,10 @@ struct Staged {  // device-side views of the caller's buffers for one call
 
 inline size_t al256(size_t b) { return (b + 255) & ~(size_t)255; }
 
+}  // namespace
+
 // read back phase timings (events) and device scalars after the stream has drained
-int finish_timing(qk_ctx *ctx, qk_store *s, qk_timing *t, bool have_coarse, int scan_ev_base) {
+int qk_finish_timing(qk_ctx *ctx, qk_store *s, qk_timing *t, bool have_coarse, int scan_ev_base) {
     if (!t) return QK_OK;
     QK_HIP(hipStreamSynchronize(ctx->stream));
     const int32_t *hs = (const int32_t *)ctx->pinned;
@@ -44,14 +46,19 @@ int finish_timing(qk_ctx *ctx, qk_store *s, qk_timing *t, bool have_coarse, int 
     return QK_OK;
 }
 
+namespace {
 int check_metric(int metric) {
     if (metric != QK_METRIC_L2 && metric != QK_METRIC_IP) QK_FAIL(QK_ERR_INVALID, "Metric type not supported");
     return QK_OK;
 }
+}  // namespace
 
-// scan with every pointer in `mem`; parent == nullptr && pids == nullptr -> all lists
-int run_search(qk_ctx *ctx, qk_store *parent, qk_store *s, const float *x, int64_t Q, const int64_t *pids, int P, int nprobe,
-               int k, int metric, int64_t *out_ids, float *out_dist, int mem, qk_timing *timing, bool coarse_only) {
+// scan with every pointer in `mem`; parent == nullptr && pids == nullptr -> all lists.
+// defer_finish (device memory only; the device group of qk_group.hip): nothing here waits for the stream -- the scalars behind
+// `timing` are requested but read later, by qk_finish_timing, once every member of the group has been enqueued.
+int qk_run_search(qk_ctx *ctx, qk_store *parent, qk_store *s, const float *x, int64_t Q, const int64_t *pids, int P, int nprobe,
+                  int k, int metric, int64_t *out_ids, float *out_dist, int mem, qk_timing *timing, bool coarse_only,
+                  bool defer_finish) {
     QK_TRY(qk_check_overflow(ctx));  // a record-buffer overflow of an earlier launch is reported by the next call
     QK_HIP(hipSetDevice(ctx->device));
     if (timing) memset(timing, 0, sizeof(*timing));
@@ -120,8 +127,11 @@ int run_search(qk_ctx *ctx, qk_store *parent, qk_store *s, const float *x, int64
             QK_HIP(hipStreamSynchronize(ctx->stream));
         }
         if (timing) {  // one kernel: everything is "scan"; the pair / byte counters are not collected on this path
-            QK_HIP(hipStreamSynchronize(ctx->stream));
             timing->partitions_scanned = Q * (int64_t)kk;
+            timing->n_items = -1;  // (tells a deferred finish that this call left no scalars behind)
+            if (defer_finish) return QK_OK;
+            timing->n_items = 0;
+            QK_HIP(hipStreamSynchronize(ctx->stream));
             if (tm) {
                 float ms = 0.f;
                 QK_HIP(hipEventElapsedTime(&ms, ctx->ev[4], ctx->ev[7]));
@@ -185,12 +195,11 @@ int run_search(qk_ctx *ctx, qk_store *parent, qk_store *s, const float *x, int64
         if (out_dist) QK_HIP(hipMemcpyAsync(out_dist, sv.out_dist, (size_t)Q * kout * 4, hipMemcpyDeviceToHost, ctx->stream));
         QK_HIP(hipStreamSynchronize(ctx->stream));
     }
-    if (timing) QK_TRY(finish_timing(ctx, coarse_only ? parent : s, timing, use_parent && !coarse_only, coarse_only ? 0 : 4));
+    if (defer_finish) return QK_OK;
+    if (timing) QK_TRY(qk_finish_timing(ctx, coarse_only ? parent : s, timing, use_parent && !coarse_only, coarse_only ? 0 : 4));
     if (timing || mem == QK_MEM_HOST) QK_TRY(qk_check_overflow(ctx));  // these paths have synchronised: report now
     return QK_OK;
 }
-
-}  // namespace
 
 extern "C" {
 
@@ -199,7 +208,7 @@ int qk_coarse(qk_ctx *ctx, qk_store *parent, const float *x, int64_t Q, int npro
     if (!ctx || !parent || (Q > 0 && (!x || !out_pids))) QK_FAIL(QK_ERR_INVALID, "qk_coarse: null argument");
     if (nprobe <= 0) QK_FAIL(QK_ERR_INVALID, "qk_coarse: nprobe must be positive");
     QK_TRY(check_metric(metric));
-    return run_search(ctx, parent, parent, x, Q, nullptr, 0, nprobe, 0, metric, out_pids, out_dist, mem, nullptr, true);
+    return qk_run_search(ctx, parent, parent, x, Q, nullptr, 0, nprobe, 0, metric, out_pids, out_dist, mem, nullptr, true, false);
 }
 
 int qk_scan(qk_ctx *ctx, qk_store *s, const float *x, int64_t Q, const int64_t *pids, int P, int k, int metric, int64_t *out_ids,
@@ -225,12 +234,12 @@ int qk_scan(qk_ctx *ctx, qk_store *s, const float *x, int64_t Q, const int64_t *
         if (mem == QK_MEM_HOST) {
             // build a [Q][1] list of -1
             std::vector<int64_t> neg((size_t)std::max<int64_t>(Q, 1), -1);
-            return run_search(ctx, nullptr, s, x, Q, neg.data(), 1, 0, k, metric, out_ids, out_dist, mem, timing, false);
+            return qk_run_search(ctx, nullptr, s, x, Q, neg.data(), 1, 0, k, metric, out_ids, out_dist, mem, timing, false, false);
         }
         (void)dummy;
         QK_FAIL(QK_ERR_INVALID, "qk_scan: P == 0 needs host memory (pass a [Q][1] list of -1 instead)");
     }
-    return run_search(ctx, nullptr, s, x, Q, pp, PP, 0, k, metric, out_ids, out_dist, mem, timing, false);
+    return qk_run_search(ctx, nullptr, s, x, Q, pp, PP, 0, k, metric, out_ids, out_dist, mem, timing, false, false);
 }
 
 int qk_search(qk_ctx *ctx, qk_store *parent, qk_store *s, const float *x, int64_t Q, int nprobe, int k, int metric,
@@ -239,7 +248,7 @@ int qk_search(qk_ctx *ctx, qk_store *parent, qk_store *s, const float *x, int64_
     if (k <= 0) QK_FAIL(QK_ERR_INVALID, "qk_search: k must be positive");
     if (parent && nprobe <= 0) QK_FAIL(QK_ERR_INVALID, "qk_search: nprobe must be positive");
     QK_TRY(check_metric(metric));
-    return run_search(ctx, parent, s, x, Q, nullptr, 0, nprobe, k, metric, out_ids, out_dist, mem, timing, false);
+    return qk_run_search(ctx, parent, s, x, Q, nullptr, 0, nprobe, k, metric, out_ids, out_dist, mem, timing, false, false);
 }
 
 int qk_ctx_set_squared_l2(qk_ctx *ctx, int enabled) {

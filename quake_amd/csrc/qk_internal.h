@@ -177,6 +177,7 @@ struct qk_store {
     int32_t *d_size = nullptr;
     int64_t table_cap = 0;
     bool table_dirty = true;
+    uint64_t version = 0;  // bumped by every table sync that found the store changed: replicas (qk_group.hip) compare it
     // row-major copy of ONE list's vectors ([rows][d] floats), built on demand for the exact finish of the coarse step without key
     // matrix (qk_dense_pf.hip: a candidate row of the tile-major arena is 32 pieces of 16 bytes in 32 cache lines); dropped whenever
     // the table changes
@@ -192,6 +193,18 @@ struct qk_store {
 void qk_store_ensure_index(qk_store *s);
 
 int qk_store_sync_table(qk_store *s);                  // upload (row_off, size) if dirty
+// qk_store_build_csr in three steps, with an ownership filter (qk_group.hip: member `rem` of `mod` members takes the lists
+// p % mod == rem; the others are not created and their rows are skipped): begin lays the lists out and uploads the tables,
+// chunk ingests source rows [i0, i0 + n) of the CSR numbering from DEVICE-readable memory (no synchronisation), end waits and
+// publishes the partition table.
+struct qk_csr_build {
+    int64_t nlist = 0, total = 0;
+    int64_t *d_offsets = nullptr, *d_part_row = nullptr;
+};
+int qk_store_csr_begin(qk_store *s, int64_t nlist, const int64_t *offsets_host, const int64_t *ids_host, int mod, int rem,
+                       qk_csr_build *b);
+int qk_store_csr_chunk(qk_store *s, const qk_csr_build *b, const float *vecs_dev, const int64_t *ids_dev, int64_t n, int64_t i0);
+int qk_store_csr_end(qk_store *s, qk_csr_build *b, int rc);
 constexpr int64_t QK_ROWMAJOR_MAX_BYTES = (int64_t)128 << 20;  // 262144 rows x 128: every parent the coarse forms are built for
 int qk_store_rowmajor(qk_store *s, int64_t row_off, int nrows, const float **out);  // the copy above for rows [row_off, +nrows)
 int qk_store_reserve_rows(qk_store *s, int64_t rows);  // grow the arena so that used_rows + rows fits
@@ -247,6 +260,11 @@ int qk_pack_topk_device(qk_ctx *ctx, const int64_t *ids, const float *key, int G
 int qk_merge_topk_packed_device(qk_ctx *ctx, const void *packed, int G, int64_t per, int k, int metric, int64_t *out_ids,
                                 float *out_dist, bool sqrt_l2);
 int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *timing, int ev_base);
+// the body of qk_coarse / qk_scan / qk_search (qk_api.hip) and the read-back of its scalars; see there
+int qk_run_search(qk_ctx *ctx, qk_store *parent, qk_store *s, const float *x, int64_t Q, const int64_t *pids, int P, int nprobe,
+                  int k, int metric, int64_t *out_ids, float *out_dist, int mem, qk_timing *timing, bool coarse_only,
+                  bool defer_finish);
+int qk_finish_timing(qk_ctx *ctx, qk_store *s, qk_timing *t, bool have_coarse, int scan_ev_base);
 // one-launch search of a small batch (qk_small.hip)
 bool qk_small_supported(qk_ctx *ctx, qk_store *parent, qk_store *s, int64_t Q, int nprobe, int k);
 // coarse step of a mid-sized batch in one launch (qk_small.hip: k_coarse_small)

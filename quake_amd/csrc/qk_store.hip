@@ -43,7 +43,8 @@ __device__ __forceinline__ int64_t ingest_dst_row(const IngestMap &m, int64_t i)
     if (!m.offsets) return m.row0 + i;
     int64_t gi = m.src_base + i;
     int64_t p = csr_find(m.offsets, m.nlist, gi);
-    return m.part_row[p] + (gi - m.offsets[p]);
+    const int64_t base = m.part_row[p];  // < 0: a list this store does not hold (qk_store_csr_begin with mod > 1)
+    return base < 0 ? -1 : base + (gi - m.offsets[p]);
 }
 
 __global__ void k_ingest_vecs(const float *__restrict__ src, int64_t n, int d, int nblk, float4 *__restrict__ vecs, IngestMap m) {
@@ -54,6 +55,7 @@ __global__ void k_ingest_vecs(const float *__restrict__ src, int64_t n, int d, i
     int rem = (int)(idx - i * per_row);
     int c = rem >> 2, g = rem & 3;
     int64_t row = ingest_dst_row(m, i);
+    if (row < 0) return;
     int64_t tile = row >> 4;
     int r = (int)(row & 15);
     const float *s = src + i * d;
@@ -71,10 +73,11 @@ __global__ void k_ingest_norms_ids(const float *__restrict__ src, const int64_t 
                                    float *__restrict__ norms, int64_t *__restrict__ ids, IngestMap m) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    int64_t row = ingest_dst_row(m, i);
+    if (row < 0) return;
     const float *s = src + i * d;
     float acc = 0.0f;
     for (int k = 0; k < d; k++) acc = __fmaf_rn(s[k], s[k], acc);
-    int64_t row = ingest_dst_row(m, i);
     norms[row] = acc;
     if (ids && src_ids) ids[row] = src_ids[i];
 }
@@ -184,6 +187,7 @@ int qk_store_reserve_rows(qk_store *s, int64_t rows) {
 
 int qk_store_sync_table(qk_store *s) {
     if (!s->table_dirty) return QK_OK;
+    s->version++;
     s->rowmajor_valid = false;
     qk_ctx *c = s->ctx;
     int64_t n = (int64_t)s->parts.size();
@@ -520,27 +524,8 @@ int qk_store_build_csr(qk_store *s, int64_t nlist, const int64_t *offsets, const
     if (!s || !offsets || nlist < 0) QK_FAIL(QK_ERR_INVALID, "qk_store_build_csr: bad arguments");
     qk_ctx *c = s->ctx;
     QK_HIP(hipSetDevice(c->device));
-    QK_TRY(qk_store_reset(s));
-    int64_t total = offsets[nlist];
+    const int64_t total = offsets[nlist];
     if (total > 0 && (!ids || !vecs)) QK_FAIL(QK_ERR_INVALID, "qk_store_build_csr: null data");
-    s->parts.resize(nlist);
-    int64_t rows = 0;
-    std::vector<int64_t> part_row(nlist);
-    for (int64_t p = 0; p < nlist; p++) {
-        int64_t sz = offsets[p + 1] - offsets[p];
-        if (sz < 0) QK_FAIL(QK_ERR_INVALID, "qk_store_build_csr: offsets not monotone at %lld", (long long)p);
-        qk_part &pt = s->parts[p];
-        pt.present = true;
-        pt.size = sz;
-        pt.cap = qk_round_up64(sz, 16);
-        pt.row_off = rows;
-        part_row[p] = rows;
-        rows += pt.cap;
-    }
-    s->nlist = nlist;
-    s->ntotal = total;
-    QK_TRY(qk_store_reserve_rows(s, rows));
-    s->used_rows = rows;
     // host mirror of ids
     std::vector<int64_t> host_ids;
     const int64_t *hid = ids;
@@ -552,17 +537,11 @@ int qk_store_build_csr(qk_store *s, int64_t nlist, const int64_t *offsets, const
         QK_HIP(hipMemcpy(host_ids.data(), ids, (size_t)total * sizeof(int64_t), hipMemcpyDeviceToHost));
         hid = host_ids.data();
     }
-    for (int64_t p = 0; p < nlist; p++) s->parts[p].ids.assign(hid + offsets[p], hid + offsets[p + 1]);
-    note_ids(s, hid, total);
+    qk_csr_build b;
+    QK_TRY(qk_store_csr_begin(s, nlist, offsets, hid, 1, 0, &b));
+    int rc = QK_OK;
     if (total > 0) {
-        // CSR tables on the device
-        int64_t *d_offsets = nullptr, *d_part_row = nullptr;
-        QK_HIP(hipMalloc((void **)&d_offsets, (size_t)(nlist + 1) * sizeof(int64_t)));
-        QK_HIP(hipMalloc((void **)&d_part_row, (size_t)nlist * sizeof(int64_t)));
-        QK_HIP(hipMemcpy(d_offsets, offsets, (size_t)(nlist + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
-        QK_HIP(hipMemcpy(d_part_row, part_row.data(), (size_t)nlist * sizeof(int64_t), hipMemcpyHostToDevice));
         const int64_t CH = mem == QK_MEM_HOST ? std::max<int64_t>(1, (int64_t)(128u << 20) / ((int64_t)s->d * 4 + 8)) : total;
-        int rc = QK_OK;
         if (mem == QK_MEM_HOST) rc = qk_stage_reserve(c, (size_t)CH * ((size_t)s->d * 4 + 8) + 512);
         for (int64_t i0 = 0; rc == QK_OK && i0 < total; i0 += CH) {
             int64_t n = std::min(CH, total - i0);
@@ -580,18 +559,81 @@ int qk_store_build_csr(qk_store *s, int64_t nlist, const int64_t *offsets, const
                 dv = (const float *)c->stage;
                 di = (const int64_t *)si;
             }
-            IngestMap m{0, d_offsets, d_part_row, nlist, i0, nullptr};
-            rc = launch_ingest(c, dv, di, n, s->d, s->nblk, s->vecs, s->norms, s->ids, m);
+            rc = qk_store_csr_chunk(s, &b, dv, di, n, i0);
             if (rc == QK_OK && mem == QK_MEM_HOST && hipStreamSynchronize(c->stream) != hipSuccess) rc = QK_ERR_HIP;
         }
-        hipStreamSynchronize(c->stream);
-        hipFree(d_offsets);
-        hipFree(d_part_row);
-        QK_TRY(rc);
     }
+    return qk_store_csr_end(s, &b, rc);
+}
+
+}  // extern "C"
+
+int qk_store_csr_begin(qk_store *s, int64_t nlist, const int64_t *offsets, const int64_t *hid, int mod, int rem, qk_csr_build *b) {
+    qk_ctx *c = s->ctx;
+    QK_HIP(hipSetDevice(c->device));
+    QK_TRY(qk_store_reset(s));
+    b->nlist = nlist;
+    b->total = offsets[nlist];
+    s->parts.resize(nlist);
+    int64_t rows = 0, owned_total = 0, owned_lists = 0;
+    std::vector<int64_t> part_row(nlist);
+    for (int64_t p = 0; p < nlist; p++) {
+        int64_t sz = offsets[p + 1] - offsets[p];
+        if (sz < 0) QK_FAIL(QK_ERR_INVALID, "qk_store_build_csr: offsets not monotone at %lld", (long long)p);
+        qk_part &pt = s->parts[p];
+        if (mod > 1 && (int)(p % mod) != rem) {  // another member's list
+            pt = qk_part();
+            part_row[p] = -1;
+            continue;
+        }
+        pt.present = true;
+        pt.size = sz;
+        pt.cap = qk_round_up64(sz, 16);
+        pt.row_off = rows;
+        part_row[p] = rows;
+        rows += pt.cap;
+        owned_total += sz;
+        owned_lists++;
+    }
+    s->nlist = owned_lists;
+    s->ntotal = owned_total;
+    QK_TRY(qk_store_reserve_rows(s, rows));
+    s->used_rows = rows;
+    for (int64_t p = 0; p < nlist; p++)
+        if (s->parts[p].present) {
+            s->parts[p].ids.assign(hid + offsets[p], hid + offsets[p + 1]);
+            note_ids(s, hid + offsets[p], offsets[p + 1] - offsets[p]);
+        }
+    if (b->total > 0) {
+        // CSR tables on the device
+        QK_HIP(hipMalloc((void **)&b->d_offsets, (size_t)(nlist + 1) * sizeof(int64_t)));
+        QK_HIP(hipMalloc((void **)&b->d_part_row, (size_t)nlist * sizeof(int64_t)));
+        QK_HIP(hipMemcpy(b->d_offsets, offsets, (size_t)(nlist + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
+        QK_HIP(hipMemcpy(b->d_part_row, part_row.data(), (size_t)nlist * sizeof(int64_t), hipMemcpyHostToDevice));
+    }
+    return QK_OK;
+}
+
+int qk_store_csr_chunk(qk_store *s, const qk_csr_build *b, const float *dv, const int64_t *di, int64_t n, int64_t i0) {
+    qk_ctx *c = s->ctx;
+    QK_HIP(hipSetDevice(c->device));
+    IngestMap m{0, b->d_offsets, b->d_part_row, b->nlist, i0, nullptr};
+    return launch_ingest(c, dv, di, n, s->d, s->nblk, s->vecs, s->norms, s->ids, m);
+}
+
+int qk_store_csr_end(qk_store *s, qk_csr_build *b, int rc) {
+    qk_ctx *c = s->ctx;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    if (b->d_offsets) hipFree(b->d_offsets);
+    if (b->d_part_row) hipFree(b->d_part_row);
+    b->d_offsets = b->d_part_row = nullptr;
+    QK_TRY(rc);
     s->table_dirty = true;
     return qk_store_sync_table(s);
 }
+
+extern "C" {
 
 int qk_store_remove_ids(qk_store *s, int64_t n, const int64_t *ids_host, int64_t *n_removed) {
     if (!s) QK_FAIL(QK_ERR_INVALID, "qk_store_remove_ids: null store");
