@@ -80,14 +80,23 @@ PYBIND11_MODULE(_bindings, m) {
         .def("get_partition_ids", &PartitionManager::get_partition_ids)
         .def("get_partition_sizes", [](PartitionManager &pm, torch::Tensor pids) { return pm.get_partition_sizes(pids); })
         .def("get_ids", &PartitionManager::get_ids)
-        .def("validate", &PartitionManager::validate);
+        .def("validate", &PartitionManager::validate)
+        // workers = GPUs: the partition -> worker map (partition_manager.h:170-187)
+        .def("distribute_partitions", &PartitionManager::distribute_partitions)
+        .def("get_partition_core_id", &PartitionManager::get_partition_core_id)
+        .def("set_partition_core_id", &PartitionManager::set_partition_core_id)
+        .def("num_workers", &PartitionManager::num_workers, "Members of the device group the partitions are distributed over (0: one store).");
 
     py::class_<QueryCoordinator, std::shared_ptr<QueryCoordinator>>(m, "QueryCoordinator")
         .def("search", &QueryCoordinator::search)
         .def("scan_partitions", &QueryCoordinator::scan_partitions)
         .def("serial_scan", &QueryCoordinator::serial_scan)
         .def("batched_serial_scan", &QueryCoordinator::batched_serial_scan)
-        .def("worker_scan", &QueryCoordinator::worker_scan);
+        .def("worker_scan", &QueryCoordinator::worker_scan)
+        .def("initialize_workers", &QueryCoordinator::initialize_workers)  // query_coordinator.h:150-160
+        .def("shutdown_workers", &QueryCoordinator::shutdown_workers)
+        .def_readonly("workers_initialized", &QueryCoordinator::workers_initialized_)
+        .def_readonly("num_workers", &QueryCoordinator::num_workers_);
 
     // list_scanning.h seam: one query (or a block of queries) against one raw list
     m.def("batched_scan_list", [](torch::Tensor queries, torch::Tensor list_vecs, torch::Tensor list_ids, int k, std::string metric) {

@@ -21,7 +21,7 @@ inline int us_since(clk::time_point t0) { return (int)std::chrono::duration_cast
 
 size_t DynamicInvertedLists::list_size(size_t list_no) const {
     int64_t sz = 0;
-    qk_check(qk_store_list_size(s_, (int64_t)list_no, &sz));
+    qk_check(s_->list_size((int64_t)list_no, &sz));
     return (size_t)sz;
 }
 
@@ -29,24 +29,49 @@ PartitionManager::PartitionManager() = default;
 
 PartitionManager::~PartitionManager() {
     partition_store_ = nullptr;
-    if (store_) qk_store_destroy(store_);
-    store_ = nullptr;
+    release_lists();
+}
+
+void PartitionManager::release_lists() {
+    if (lists_.store) qk_store_destroy(lists_.store);
+    if (lists_.group) qk_group_destroy(lists_.group);
+    lists_ = DeviceLists();
+}
+
+// num_workers members, member j on GPU j % #GPUs (more workers than GPUs: several members per device, like several worker
+// threads per core in the reference)
+void PartitionManager::make_group(int num_workers, int d) {
+    const int ndev = std::max<int>(1, (int)torch::cuda::device_count());
+    std::vector<int> devices((size_t)num_workers);
+    for (int j = 0; j < num_workers; j++) devices[(size_t)j] = j % ndev;
+    qk_check(qk_group_create(devices.data(), num_workers, d, &lists_.group));
+    ctx_ = qk_device_context(0);  // parent searches, k-means of a split: the shared context of device 0, as without workers
+}
+
+qk_ctx *PartitionManager::search_ctx() const {
+    qk_ctx *c = ctx_;
+    if (lists_.group) qk_check(qk_group_member(lists_.group, 0, &c, nullptr));
+    return c;
 }
 
 void PartitionManager::reset_store(int d) {
-    ctx_ = qk_device_context(0);
     partition_store_ = nullptr;
-    if (store_) qk_store_destroy(store_);
-    store_ = nullptr;
-    qk_check(qk_store_create(ctx_, d, &store_));
-    partition_store_ = std::make_shared<DynamicInvertedLists>(store_, (size_t)d * 4);
+    release_lists();
+    // workers only where there are partitions to distribute: a flat index (no parent: ONE partition) stays one store
+    if (planned_workers_ > 0 && parent_) {
+        make_group(planned_workers_, d);
+    } else {
+        ctx_ = qk_device_context(0);
+        qk_check(qk_store_create(ctx_, d, &lists_.store));
+    }
+    partition_store_ = std::make_shared<DynamicInvertedLists>(&lists_, (size_t)d * 4);
     d_ = d;
     resident_ids_.clear();
     core_of_.clear();
 }
 
 void PartitionManager::require_store(const char *who) const {
-    if (!store_) throw std::runtime_error(std::string("[PartitionManager] ") + who + ": partitions are not initialized.");
+    if (!lists_) throw std::runtime_error(std::string("[PartitionManager] ") + who + ": partitions are not initialized.");
 }
 
 void PartitionManager::init_partitions(shared_ptr<QuakeIndex> parent, shared_ptr<Clustering> c, bool check_uniques) {
@@ -63,7 +88,7 @@ void PartitionManager::init_partitions(shared_ptr<QuakeIndex> parent, shared_ptr
     int64_t max_pid = -1;
     for (int64_t i = 0; i < nlist; i++) {
         const int64_t pid = pids[i].item<int64_t>();
-        qk_check(qk_store_add_list(store_, pid));
+        qk_check(lists_.add_list(pid));
         Tensor v = host_f32(c->vectors[(size_t)i]), id = host_i64(c->vector_ids[(size_t)i]).reshape({-1});
         if (v.size(0) != id.size(0)) throw std::runtime_error("[PartitionManager] init_partitions: vectors and ids disagree.");
         const int64_t *ip = id.data_ptr<int64_t>();
@@ -72,7 +97,7 @@ void PartitionManager::init_partitions(shared_ptr<QuakeIndex> parent, shared_ptr
                 if (!resident_ids_.insert(ip[j]).second)
                     throw std::runtime_error("[PartitionManager] init_partitions: vector ID already exists in the index.");
         if (!check_uniques) resident_ids_.insert(ip, ip + id.size(0));
-        if (id.size(0)) qk_check(qk_store_add_entries(store_, pid, id.size(0), ip, v.data_ptr<float>(), QK_MEM_HOST));
+        if (id.size(0)) qk_check(lists_.add_entries(pid, id.size(0), ip, v.data_ptr<float>(), QK_MEM_HOST));
         max_pid = std::max(max_pid, pid);
     }
     curr_partition_id_ = max_pid + 1;
@@ -83,7 +108,7 @@ void PartitionManager::init_from_csr(shared_ptr<QuakeIndex> parent, const Tensor
     Tensor off = host_i64(offsets), id = host_i64(ids), v = host_f32(vectors);
     const int64_t nlist = off.size(0) - 1;
     reset_store((int)v.size(1));
-    qk_check(qk_store_build_csr(store_, nlist, off.data_ptr<int64_t>(), id.data_ptr<int64_t>(), v.data_ptr<float>(), QK_MEM_HOST));
+    qk_check(lists_.build_csr(nlist, off.data_ptr<int64_t>(), id.data_ptr<int64_t>(), v.data_ptr<float>(), QK_MEM_HOST));
     const int64_t *ip = id.data_ptr<int64_t>();
     resident_ids_.insert(ip, ip + id.size(0));
     curr_partition_id_ = nlist;
@@ -127,7 +152,7 @@ shared_ptr<ModifyTimingInfo> PartitionManager::add(const Tensor &vectors, const 
     info->find_partition_time_us = us_since(t0);
     t0 = clk::now();
     // per-list append order = input order (:245-258); the ids become resident only once the device step succeeded
-    qk_check(qk_store_add_batch(store_, n, ip, xh.data_ptr<float>(), assign.data_ptr<int64_t>(), QK_MEM_HOST));
+    qk_check(lists_.add_batch(n, ip, xh.data_ptr<float>(), assign.data_ptr<int64_t>(), QK_MEM_HOST));
     resident_ids_.insert(ip, ip + n);
     info->modify_time_us = us_since(t0);
     return info;
@@ -145,7 +170,7 @@ shared_ptr<ModifyTimingInfo> PartitionManager::remove(const Tensor &ids) {  // p
         if (!resident_ids_.count(ip[i])) throw std::runtime_error("[PartitionManager] remove: vector ID does not exist in the index.");
     info->input_validation_time_us = us_since(t0);
     t0 = clk::now();
-    qk_check(qk_store_remove_ids(store_, idh.size(0), ip, nullptr));
+    qk_check(lists_.remove_ids(idh.size(0), ip, nullptr));
     for (int64_t i = 0; i < idh.size(0); i++) resident_ids_.erase(ip[i]);
     info->modify_time_us = us_since(t0);
     return info;
@@ -157,7 +182,7 @@ Tensor PartitionManager::get(const Tensor &ids) {
     Tensor out = torch::empty({idh.size(0), d_}, torch::kFloat32);
     for (int64_t i = 0; i < idh.size(0); i++) {
         int found = 0;
-        qk_check(qk_store_get_vector(store_, idh.data_ptr<int64_t>()[i], out.data_ptr<float>() + i * d_, &found));
+        qk_check(lists_.get_vector(idh.data_ptr<int64_t>()[i], out.data_ptr<float>() + i * d_, &found));
         if (!found) throw std::runtime_error("ID not found in any partition");
     }
     return out;
@@ -166,16 +191,16 @@ Tensor PartitionManager::get(const Tensor &ids) {
 Tensor PartitionManager::get_partition_ids() {
     require_store("get_partition_ids");
     int64_t nl = 0;
-    qk_check(qk_store_list_ids(store_, nullptr, &nl));
+    qk_check(lists_.list_ids(nullptr, &nl));
     Tensor out = torch::empty({nl}, torch::kInt64);
-    if (nl) qk_check(qk_store_list_ids(store_, out.data_ptr<int64_t>(), &nl));
+    if (nl) qk_check(lists_.list_ids(out.data_ptr<int64_t>(), &nl));
     return out;
 }
 
 int64_t PartitionManager::get_partition_size(int64_t partition_id) {
     require_store("get_partition_size");
     int64_t sz = 0;
-    qk_check(qk_store_list_size(store_, partition_id, &sz));
+    qk_check(lists_.list_size(partition_id, &sz));
     return sz;
 }
 
@@ -196,11 +221,11 @@ Tensor PartitionManager::get_partition_sizes(Tensor partition_ids) {
 Tensor PartitionManager::get_ids() {
     require_store("get_ids");
     Tensor lists = get_partition_ids();
-    Tensor out = torch::empty({qk_store_ntotal(store_)}, torch::kInt64);
+    Tensor out = torch::empty({lists_.ntotal()}, torch::kInt64);
     int64_t pos = 0;
     for (int64_t i = 0; i < lists.size(0); i++) {
         const int64_t p = lists[i].item<int64_t>(), sz = get_partition_size(p);
-        if (sz) qk_check(qk_store_get_list(store_, p, nullptr, out.data_ptr<int64_t>() + pos, QK_MEM_HOST));
+        if (sz) qk_check(lists_.get_list(p, nullptr, out.data_ptr<int64_t>() + pos, QK_MEM_HOST));
         pos += sz;
     }
     return out;
@@ -215,7 +240,7 @@ shared_ptr<Clustering> PartitionManager::select_partitions(const Tensor &partiti
     for (int64_t i = 0; i < p.size(0); i++) {
         const int64_t pid = p[i].item<int64_t>(), sz = get_partition_size(pid);
         Tensor v = torch::empty({sz, d_}, torch::kFloat32), id = torch::empty({sz}, torch::kInt64);
-        if (sz) qk_check(qk_store_get_list(store_, pid, v.data_ptr<float>(), id.data_ptr<int64_t>(), QK_MEM_HOST));
+        if (sz) qk_check(lists_.get_list(pid, v.data_ptr<float>(), id.data_ptr<int64_t>(), QK_MEM_HOST));
         c->vectors.push_back(v);
         c->vector_ids.push_back(id);
     }
@@ -264,9 +289,9 @@ void PartitionManager::add_partitions(shared_ptr<Clustering> c) {  // :489-520
     parent_->add(c->centroids, new_ids);
     for (int64_t i = 0; i < n; i++) {
         const int64_t pid = new_ids[i].item<int64_t>();
-        qk_check(qk_store_add_list(store_, pid));
+        qk_check(lists_.add_list(pid));
         Tensor v = host_f32(c->vectors[(size_t)i]), id = host_i64(c->vector_ids[(size_t)i]).reshape({-1});
-        if (id.size(0)) qk_check(qk_store_add_entries(store_, pid, id.size(0), id.data_ptr<int64_t>(), v.data_ptr<float>(), QK_MEM_HOST));
+        if (id.size(0)) qk_check(lists_.add_entries(pid, id.size(0), id.data_ptr<int64_t>(), v.data_ptr<float>(), QK_MEM_HOST));
         const int64_t *ip = id.data_ptr<int64_t>();
         resident_ids_.insert(ip, ip + id.size(0));
     }
@@ -279,7 +304,7 @@ void PartitionManager::delete_partitions(const Tensor &partition_ids, bool reass
     Tensor p = host_i64(partition_ids).reshape({-1});
     parent_->remove(p);
     for (int64_t i = 0; i < p.size(0); i++) {
-        qk_check(qk_store_remove_list(store_, p[i].item<int64_t>()));
+        qk_check(lists_.remove_list(p[i].item<int64_t>()));
         Tensor id = sel->vector_ids[(size_t)i];
         for (int64_t j = 0; j < id.size(0); j++) resident_ids_.erase(id[j].item<int64_t>());
     }
@@ -296,30 +321,65 @@ void PartitionManager::refine_partitions(Tensor partition_ids, int refinement_it
     if (partition_ids.size(0) == 0) return;
     Tensor pids = host_i64(partition_ids).reshape({-1});
     Tensor cent = parent_->get(pids);
-    qk_check(qk_store_refine_lists(store_, pids.data_ptr<int64_t>(), pids.size(0), cent.data_ptr<float>(), metric_, refinement_iterations,
+    qk_check(lists_.refine_lists(pids.data_ptr<int64_t>(), pids.size(0), cent.data_ptr<float>(), metric_, refinement_iterations,
                                    QK_MEM_HOST));
     parent_->modify(pids, cent);  // :478
 }
 
-void PartitionManager::distribute_partitions(int num_workers) {  // :557-603: partition i -> worker i % num_workers
-    if (num_workers <= 0) return;
-    Tensor p = get_partition_ids();
-    for (int64_t i = 0; i < p.size(0); i++) core_of_[p[i].item<int64_t>()] = (int)(i % num_workers);
+// :557-603: partition i -> worker i % num_workers.  Here: the partitions move into a device group of num_workers members
+// (partition p -> member p % num_workers), device to device, and every later call goes to the member that holds the partition.
+void PartitionManager::distribute_partitions(int num_workers) {
+    if (num_workers <= 0 || !lists_) return;
+    planned_workers_ = num_workers;
+    if (!parent_) return;  // a flat index is ONE partition: nothing to distribute, its one store keeps serving it
+    if (lists_.group) {
+        if (qk_group_size(lists_.group) == num_workers) return;
+        throw std::runtime_error("[PartitionManager] distribute_partitions: partitions are already distributed over " +
+                                 std::to_string(qk_group_size(lists_.group)) + " workers.");
+    }
+    qk_store *old = lists_.store;
+    lists_.store = nullptr;
+    try {
+        make_group(num_workers, d_);
+        int64_t nl = 0;
+        qk_check(qk_store_list_ids(old, nullptr, &nl));
+        std::vector<int64_t> lists((size_t)nl);
+        if (nl) qk_check(qk_store_list_ids(old, lists.data(), &nl));
+        for (int64_t p : lists) {
+            int64_t sz = 0;
+            qk_check(qk_store_list_size(old, p, &sz));
+            qk_check(qk_group_add_list(lists_.group, p));
+            if (!sz) continue;
+            Tensor v = torch::empty({sz, (int64_t)d_}, torch::TensorOptions().dtype(torch::kFloat32).device(torch::kCUDA, 0));
+            Tensor id = torch::empty({sz}, torch::TensorOptions().dtype(torch::kInt64).device(torch::kCUDA, 0));
+            qk_check(qk_store_get_list(old, p, v.data_ptr<float>(), id.data_ptr<int64_t>(), QK_MEM_DEVICE));
+            qk_check(qk_ctx_synchronize(qk_device_context(0)));
+            qk_check(qk_group_add_entries(lists_.group, p, sz, id.data_ptr<int64_t>(), v.data_ptr<float>(), QK_MEM_DEVICE));
+            qk_check(qk_store_remove_list(old, p));
+        }
+    } catch (...) {
+        if (lists_.group) qk_group_destroy(lists_.group);
+        lists_.group = nullptr;
+        lists_.store = old;
+        throw;
+    }
+    qk_store_destroy(old);
 }
 
 void PartitionManager::set_partition_core_id(int64_t partition_id, int core_id) { core_of_[partition_id] = core_id; }
 
 int PartitionManager::get_partition_core_id(int64_t partition_id) {
     auto it = core_of_.find(partition_id);
-    return it == core_of_.end() ? -1 : it->second;
+    if (it != core_of_.end()) return it->second;
+    return lists_.group ? qk_group_owner(lists_.group, partition_id) : -1;
 }
 
-int64_t PartitionManager::ntotal() const { return store_ ? qk_store_ntotal(store_) : 0; }
-int64_t PartitionManager::nlist() const { return store_ ? qk_store_nlist(store_) : 0; }
+int64_t PartitionManager::ntotal() const { return lists_ ? lists_.ntotal() : 0; }
+int64_t PartitionManager::nlist() const { return lists_ ? lists_.nlist() : 0; }
 int PartitionManager::d() const { return d_; }
 
 bool PartitionManager::validate() {
-    if (!store_) return false;
+    if (!lists_) return false;
     if ((int64_t)resident_ids_.size() != ntotal()) return false;
     Tensor ids = get_ids();
     const int64_t *ip = ids.data_ptr<int64_t>();
@@ -356,7 +416,7 @@ void PartitionManager::save(const std::string &path) {
     for (int64_t i = 0; i < nl; i++) {  // one partition at a time: the host never holds more than a partition
         std::vector<float> v((size_t)sizes[(size_t)i] * d_);
         std::vector<int64_t> id((size_t)sizes[(size_t)i]);
-        if (sizes[(size_t)i]) qk_check(qk_store_get_list(store_, lists[i].item<int64_t>(), v.data(), id.data(), QK_MEM_HOST));
+        if (sizes[(size_t)i]) qk_check(lists_.get_list(lists[i].item<int64_t>(), v.data(), id.data(), QK_MEM_HOST));
         ofs.write((const char *)v.data(), (std::streamsize)(v.size() * 4));
         ofs.write((const char *)id.data(), (std::streamsize)(id.size() * 8));
     }
@@ -374,6 +434,10 @@ void PartitionManager::load(const std::string &path) {
     ifs.read((char *)&nlist64, 8);
     ifs.read((char *)&code_size, 8);
     ifs.read((char *)&nparts, 8);
+    // nothing is allocated on the word of a header field before it has been checked against the file's size
+    const uint64_t file_size = (uint64_t)std::filesystem::file_size(path);
+    if (!ifs || code_size == 0 || code_size % 4 != 0 || nparts > file_size / 16 || 32 + 16 * nparts + 8 > file_size)
+        throw std::runtime_error("Invalid file format (truncated offset / partition id table).");
     std::vector<uint64_t> offsets((size_t)nparts + 1), pids((size_t)nparts);
     ifs.read((char *)offsets.data(), (std::streamsize)(offsets.size() * 8));
     ifs.read((char *)pids.data(), (std::streamsize)(pids.size() * 8));
@@ -386,6 +450,7 @@ void PartitionManager::load(const std::string &path) {
     for (uint64_t i = 0; i < nparts; i++) {
         if (offsets[i + 1] < offsets[i]) throw std::runtime_error("Invalid file format (partition offsets are not ascending).");
         const uint64_t chunk = offsets[i + 1] - offsets[i];
+        if (start_of_chunks + offsets[i + 1] > file_size) throw std::runtime_error("Invalid file format (truncated partition data).");
         if (chunk % rec != 0) throw std::runtime_error("Partition chunk size not divisible by (code_size+sizeof(idx_t))");
         const int64_t nv = (int64_t)(chunk / rec);
         ifs.seekg((std::streamoff)(start_of_chunks + offsets[i]), std::ios::beg);  // dynamic_inverted_list.cpp:494
@@ -394,8 +459,8 @@ void PartitionManager::load(const std::string &path) {
         ifs.read((char *)v.data(), (std::streamsize)(v.size() * 4));
         ifs.read((char *)id.data(), (std::streamsize)(id.size() * 8));
         if (!ifs) throw std::runtime_error("Invalid file format (truncated partition data).");
-        qk_check(qk_store_add_list(store_, (int64_t)pids[i]));
-        if (nv) qk_check(qk_store_add_entries(store_, (int64_t)pids[i], nv, id.data(), v.data(), QK_MEM_HOST));
+        qk_check(lists_.add_list((int64_t)pids[i]));
+        if (nv) qk_check(lists_.add_entries((int64_t)pids[i], nv, id.data(), v.data(), QK_MEM_HOST));
         resident_ids_.insert(id.begin(), id.end());
         max_pid = std::max<int64_t>(max_pid, (int64_t)pids[i]);
     }

@@ -2,7 +2,10 @@
 // src/cpp/include/partition_manager.h:25-187, over the DEVICE partition store (qk_store, the counterpart of
 // faiss::DynamicInvertedLists).  The reference keeps vectors in host partitions and exposes raw pointers into them
 // (get_vectors); here the vectors live in HBM and every accessor copies out.  Host bookkeeping kept: the resident id
-// set, the next partition id, the partition -> worker map of distribute_partitions.
+// set, the next partition id.  distribute_partitions(num_workers) -- the reference's partition -> core map
+// (partition_manager.cpp:557-603) -- distributes the partitions over a DEVICE GROUP (qk_group: one process, num_workers members,
+// partition p in member p % num_workers, member j on GPU j % #GPUs): from then on every call below goes to the member that
+// holds the partition and searches run on all members at once.
 #pragma once
 #include <set>
 #include <string>
@@ -15,18 +18,53 @@ namespace quake_amd {
 
 class QuakeIndex;
 
+// The device lists a PartitionManager drives: ONE store, or a device group once the partitions are distributed over workers.
+// Same arguments, same status codes either way (include/quake_hip.h).
+struct DeviceLists {
+    qk_store *store = nullptr;
+    qk_group *group = nullptr;
+    explicit operator bool() const { return store || group; }
+    int add_list(int64_t p) const { return group ? qk_group_add_list(group, p) : qk_store_add_list(store, p); }
+    int remove_list(int64_t p) const { return group ? qk_group_remove_list(group, p) : qk_store_remove_list(store, p); }
+    int add_entries(int64_t p, int64_t n, const int64_t *ids, const float *v, int mem) const {
+        return group ? qk_group_add_entries(group, p, n, ids, v, mem) : qk_store_add_entries(store, p, n, ids, v, mem);
+    }
+    int add_batch(int64_t n, const int64_t *ids, const float *v, const int64_t *assign, int mem) const {
+        return group ? qk_group_add_batch(group, n, ids, v, assign, mem) : qk_store_add_batch(store, n, ids, v, assign, mem);
+    }
+    int build_csr(int64_t nlist, const int64_t *off, const int64_t *ids, const float *v, int mem) const {
+        return group ? qk_group_build_csr(group, nlist, off, ids, v, mem) : qk_store_build_csr(store, nlist, off, ids, v, mem);
+    }
+    int remove_ids(int64_t n, const int64_t *ids, int64_t *removed) const {
+        return group ? qk_group_remove_ids(group, n, ids, removed) : qk_store_remove_ids(store, n, ids, removed);
+    }
+    int list_size(int64_t p, int64_t *out) const { return group ? qk_group_list_size(group, p, out) : qk_store_list_size(store, p, out); }
+    int list_ids(int64_t *out, int64_t *n) const { return group ? qk_group_list_ids(group, out, n) : qk_store_list_ids(store, out, n); }
+    int get_list(int64_t p, float *v, int64_t *ids, int mem) const {
+        return group ? qk_group_get_list(group, p, v, ids, mem) : qk_store_get_list(store, p, v, ids, mem);
+    }
+    int get_vector(int64_t id, float *v, int *found) const {
+        return group ? qk_group_get_vector(group, id, v, found) : qk_store_get_vector(store, id, v, found);
+    }
+    int refine_lists(const int64_t *lists, int64_t m, float *c, int metric, int iters, int mem) const {
+        return group ? qk_group_refine_lists(group, lists, m, c, metric, iters, mem) : qk_store_refine_lists(store, lists, m, c, metric, iters, mem);
+    }
+    int64_t ntotal() const { return group ? qk_group_ntotal(group) : qk_store_ntotal(store); }
+    int64_t nlist() const { return group ? qk_group_nlist(group) : qk_store_nlist(store); }
+};
+
 // What the reference exposes as PartitionManager::partition_store_ (faiss::DynamicInvertedLists, dynamic_inverted_list.h:25-33;
 // its tests read list sizes through it, test/cpp/partition_manager.cpp:203-248): here a read-only view of the device store.
 class DynamicInvertedLists {
 public:
-    explicit DynamicInvertedLists(qk_store *s, size_t code_size) : code_size(code_size), s_(s) {}
+    explicit DynamicInvertedLists(const DeviceLists *s, size_t code_size) : code_size(code_size), s_(s) {}
     size_t list_size(size_t list_no) const;  // throws like the reference when the list does not exist (:68-74)
-    size_t ntotal() const { return (size_t)qk_store_ntotal(s_); }
-    size_t get_nlist() const { return (size_t)qk_store_nlist(s_); }
+    size_t ntotal() const { return (size_t)s_->ntotal(); }
+    size_t get_nlist() const { return (size_t)s_->nlist(); }
     size_t code_size;  // bytes per vector (d * 4)
 
 private:
-    qk_store *s_;
+    const DeviceLists *s_;  // the manager's lists (follows a store -> group change)
 };
 
 class PartitionManager {
@@ -71,16 +109,27 @@ public:
     void load(const std::string &path);
 
     // device side
-    qk_store *store() const { return store_; }
-    qk_ctx *ctx() const { return ctx_; }
+    qk_store *store() const { return lists_.store; }    // the one store (nullptr once the partitions are distributed)
+    qk_group *group() const { return lists_.group; }    // the device group (nullptr before distribute_partitions)
+    bool has_lists() const { return (bool)lists_; }
+    const DeviceLists &lists() const { return lists_; }
+    qk_ctx *ctx() const { return ctx_; }                // the shared context of device 0: parent searches, k-means of a split
+    qk_ctx *search_ctx() const;                         // what a search is ordered on: ctx(), or the group's lead member
+    int num_workers() const { return lists_.group ? qk_group_size(lists_.group) : 0; }
+    // the number of workers the partitions will be distributed over, told BEFORE they are initialised (QuakeIndex::build / load
+    // know it from IndexBuildParams::num_workers): the lists then go straight to their members instead of through one store
+    void plan_workers(int num_workers) { planned_workers_ = num_workers; }
     int metric_ = QK_METRIC_L2;  // set by the owning index (the reference reads it from the parent)
 
 private:
     qk_ctx *ctx_ = nullptr;  // shared per-device context (not owned)
-    qk_store *store_ = nullptr;
+    DeviceLists lists_;
     int d_ = 0;
-    std::unordered_map<int64_t, int> core_of_;
+    int planned_workers_ = 0;
+    std::unordered_map<int64_t, int> core_of_;  // set_partition_core_id overrides (bookkeeping only)
     void reset_store(int d);
+    void release_lists();
+    void make_group(int num_workers, int d);
     void require_store(const char *who) const;
 };
 

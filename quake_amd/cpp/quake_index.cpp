@@ -49,7 +49,7 @@ QuakeIndex::QuakeIndex(int current_level) : current_level_(current_level) {}
 QuakeIndex::~QuakeIndex() = default;
 
 void QuakeIndex::require_built(const char *msg) const {
-    if (!partition_manager_ || !partition_manager_->store()) throw std::runtime_error(msg);
+    if (!partition_manager_ || !partition_manager_->has_lists()) throw std::runtime_error(msg);
 }
 
 void QuakeIndex::make_coordinator(int num_workers) {
@@ -72,6 +72,9 @@ shared_ptr<BuildTimingInfo> QuakeIndex::build(Tensor x, Tensor ids, shared_ptr<I
     info->d = d;
     partition_manager_ = std::make_shared<PartitionManager>();
     partition_manager_->metric_ = metric_;
+    // num_workers > 0: the partitions go straight to the members of a device group (initialize_workers -> distribute_partitions
+    // would move them there anyway, through one device)
+    partition_manager_->plan_workers(build_params_->num_workers);
     const int nlist = build_params_->nlist;
     if (nlist > 1) {
         auto t0 = clk::now();
@@ -213,6 +216,7 @@ void QuakeIndex::load(const std::string &dir_path, int n_workers) {
     partition_manager_ = std::make_shared<PartitionManager>();
     partition_manager_->metric_ = metric_;
     partition_manager_->parent_ = parent_;
+    partition_manager_->plan_workers(n_workers);
     partition_manager_->load((fs::path(dir_path) / "partitions").string());
     maintenance_policy_params_ = nullptr;  // load resets the policy to its defaults (:262-264)
     maintenance_policy_ = nullptr;

@@ -27,7 +27,7 @@ struct BoundToTorchStream {
     void *prev = nullptr;
     int prev_kind = 0;
     BoundToTorchStream(qk_ctx *ctx, const Tensor &t) {
-        if (!t.is_cuda()) return;
+        if (!ctx || !t.is_cuda()) return;
         qk_check(qk_ctx_get_stream(ctx, &prev, &prev_kind));
         c = ctx;
         hipStream_t st = c10::hip::getCurrentHIPStream(t.device().index()).stream();
@@ -53,10 +53,14 @@ void QueryCoordinator::initialize_workers(int num_workers) {  // query_coordinat
     if (workers_initialized_) return;
     num_workers_ = num_workers;
     workers_initialized_ = num_workers > 0;
+    // the reference starts one thread per worker and pins partition i to core i % num_workers; here the partitions move into a
+    // device group (one member per worker, member j on GPU j % #GPUs) unless the manager was told the count before it was filled
     if (partition_manager_ && workers_initialized_) partition_manager_->distribute_partitions(num_workers);
 }
 
 void QueryCoordinator::shutdown_workers() {  // :77-95
+    // the reference joins its threads and keeps serving scans serially; the partitions of a device group stay where they are
+    // (they ARE the index) -- only the flag the reference's tests read goes down
     workers_initialized_ = false;
 }
 
@@ -75,10 +79,13 @@ shared_ptr<SearchResult> QueryCoordinator::search(Tensor x, shared_ptr<SearchPar
     auto t0 = clk::now();
     qk_ctx *ctx = partition_manager_->ctx();
     qk_store *store = partition_manager_->store();
-    if (!store) throw std::runtime_error("[QueryCoordinator::search] partitions are not initialized.");
+    qk_group *group = partition_manager_->group();  // partitions distributed over workers (GPUs)
+    if (!store && !group) throw std::runtime_error("[QueryCoordinator::search] partitions are not initialized.");
     const bool on_dev = x.is_cuda();
     Tensor xq = on_dev ? x.to(torch::kFloat32).contiguous() : host_f32(x);
-    BoundToTorchStream bound(ctx, xq);
+    // (workers: the parent search of the hit-tracking path runs on the shared context, the scan on the group's lead -- both are
+    //  ordered on torch's stream)
+    BoundToTorchStream bound(ctx, xq), bound_lead(group ? partition_manager_->search_ctx() : nullptr, xq);
     const int64_t Q = xq.size(0);
     const int k = sp->k > 0 ? sp->k : 1;  // :490
     const int nprobe = std::max(sp->nprobe, 1);
@@ -108,7 +115,10 @@ shared_ptr<SearchResult> QueryCoordinator::search(Tensor x, shared_ptr<SearchPar
             if (c) (void)qk_ctx_set_timing(c, was);
         }
     } timing_mode(ctx, !on_dev);
-    if (sp->recall_target > 0.0f && parent_ && !sp->batched_scan) {
+    if (sp->recall_target > 0.0f && parent_ && !sp->batched_scan && group) {
+        throw std::runtime_error("[QueryCoordinator::search] recall_target with num_workers > 0: adaptive partition scanning is not "
+                                 "implemented over a device group (use fixed nprobe, or num_workers = 0).");
+    } else if (sp->recall_target > 0.0f && parent_ && !sp->batched_scan) {
         // adaptive partition scanning (:502,637-641): candidates = nlist * initial_search_fraction
         Tensor nscan = torch::empty({Q}, torch::TensorOptions().dtype(torch::kInt32).device(xq.device()));
         qk_check(qk_search_aps(ctx, parent_->store(), store, xq.data_ptr<float>(), Q, k, (int)metric_, sp->recall_target,
@@ -121,11 +131,21 @@ shared_ptr<SearchResult> QueryCoordinator::search(Tensor x, shared_ptr<SearchPar
         const int kk = (int)std::min<int64_t>(nprobe, parent_->ntotal());
         Tensor pids = torch::empty({Q, kk}, torch::TensorOptions().dtype(torch::kInt64).device(xq.device()));
         qk_check(qk_coarse(ctx, parent_->store(), xq.data_ptr<float>(), Q, nprobe, (int)metric_, pids.data_ptr<int64_t>(), nullptr, mem));
-        qk_check(qk_scan(ctx, store, xq.data_ptr<float>(), Q, pids.data_ptr<int64_t>(), kk, k, (int)metric_, res->ids.data_ptr<int64_t>(),
-                         res->distances.data_ptr<float>(), mem, &tm));
+        if (group)
+            qk_check(qk_group_scan(group, xq.data_ptr<float>(), Q, pids.data_ptr<int64_t>(), kk, k, (int)metric_,
+                                   res->ids.data_ptr<int64_t>(), res->distances.data_ptr<float>(), mem, &tm));
+        else
+            qk_check(qk_scan(ctx, store, xq.data_ptr<float>(), Q, pids.data_ptr<int64_t>(), kk, k, (int)metric_,
+                             res->ids.data_ptr<int64_t>(), res->distances.data_ptr<float>(), mem, &tm));
         maintenance_policy_->record_query_batch(host_i64(pids));
         ti->partitions_scanned = (int)tm.partitions_scanned;
         ti->job_enqueue_time_ns = (int64_t)(tm.group_ms * 1e6);
+        ti->job_wait_time_ns = (int64_t)(tm.scan_ms * 1e6);
+        ti->result_aggregate_time_ns = (int64_t)(tm.merge_ms * 1e6);
+    } else if (group) {  // workers: every member scans the partitions it holds (worker_scan, :243-469), the lead merges
+        qk_check(qk_group_search(group, parent_->store(), xq.data_ptr<float>(), Q, nprobe, k, (int)metric_,
+                                 res->ids.data_ptr<int64_t>(), res->distances.data_ptr<float>(), mem, &tm));
+        ti->partitions_scanned = (int)tm.partitions_scanned;
         ti->job_wait_time_ns = (int64_t)(tm.scan_ms * 1e6);
         ti->result_aggregate_time_ns = (int64_t)(tm.merge_ms * 1e6);
     } else {
@@ -151,11 +171,12 @@ shared_ptr<SearchResult> QueryCoordinator::scan_partitions(Tensor x, Tensor part
     if (!x.defined() || x.size(0) == 0) return empty_result(sp);
     auto t0 = clk::now();
     qk_store *store = partition_manager_->store();
-    if (!store) throw std::runtime_error("[QueryCoordinator::scan_partitions] partitions are not initialized.");
+    qk_group *group = partition_manager_->group();
+    if (!store && !group) throw std::runtime_error("[QueryCoordinator::scan_partitions] partitions are not initialized.");
     // device queries stay on the device (the list numbers follow them there), host queries go through the staging buffers
     const bool on_dev = x.is_cuda();
     Tensor xq = on_dev ? x.to(torch::kFloat32).contiguous() : host_f32(x);
-    BoundToTorchStream bound(partition_manager_->ctx(), xq);
+    BoundToTorchStream bound(partition_manager_->search_ctx(), xq);
     const int64_t Q = xq.size(0);
     const int k = sp->k > 0 ? sp->k : 1;
     Tensor pids = on_dev ? partition_ids.to(xq.device(), torch::kInt64).contiguous() : host_i64(partition_ids);
@@ -172,8 +193,12 @@ shared_ptr<SearchResult> QueryCoordinator::scan_partitions(Tensor x, Tensor part
     std::memset(&tm, 0, sizeof(tm));
     Tensor none = torch::full({Q, 1}, -1, torch::TensorOptions().dtype(torch::kInt64).device(xq.device()));  // zero partitions: padded output (:459-497)
     const Tensor &pp = P > 0 ? pids : none;
-    qk_check(qk_scan(partition_manager_->ctx(), store, xq.data_ptr<float>(), Q, pp.data_ptr<int64_t>(), (int)pp.size(1), k, (int)metric_,
-                     res->ids.data_ptr<int64_t>(), res->distances.data_ptr<float>(), on_dev ? QK_MEM_DEVICE : QK_MEM_HOST, &tm));
+    if (group)
+        qk_check(qk_group_scan(group, xq.data_ptr<float>(), Q, pp.data_ptr<int64_t>(), (int)pp.size(1), k, (int)metric_,
+                               res->ids.data_ptr<int64_t>(), res->distances.data_ptr<float>(), on_dev ? QK_MEM_DEVICE : QK_MEM_HOST, &tm));
+    else
+        qk_check(qk_scan(partition_manager_->ctx(), store, xq.data_ptr<float>(), Q, pp.data_ptr<int64_t>(), (int)pp.size(1), k, (int)metric_,
+                         res->ids.data_ptr<int64_t>(), res->distances.data_ptr<float>(), on_dev ? QK_MEM_DEVICE : QK_MEM_HOST, &tm));
     ti->partitions_scanned = (int)tm.partitions_scanned;
     ti->total_time_ns = ns_since(t0);
     return res;

@@ -2,8 +2,10 @@
 // src/cpp/include/query_coordinator.h:45-179.  search() = parent search for the nprobe nearest partitions, then
 // scan_partitions(); on the device the three scan variants of the reference (serial_scan, batched_serial_scan, worker_scan:
 // three ways of spreading the same work over CPU threads) are ONE pipeline -- qk_search / qk_scan of libquake_hip.so -- and
-// return the same result, so all three names enqueue it.  "Workers" are a CPU notion: initialize_workers() only records the
-// count (the multi-GPU analogue is quake_amd/sharded.py).
+// return the same result, so all three names enqueue it.  A WORKER IS A GPU: initialize_workers(n) distributes the partitions
+// over a device group of n members (PartitionManager::distribute_partitions -> qk_group, partition p on member p % n) and from
+// then on search / scan_partitions / worker_scan run on all members at once (qk_group_search / qk_group_scan); results -- ids and
+// distance bits -- equal the one-device pipeline's.
 #pragma once
 #include "common.h"
 

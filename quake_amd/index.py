@@ -311,6 +311,22 @@ class QuakeIndex:
         if self._store is None:
             raise RuntimeError(who)
 
+    def _new_lists(self, d, num_workers, partitioned):
+        """the device lists of this level: ONE store, or -- num_workers > 0 and there are partitions to distribute (a flat index is
+        one partition) -- a device group of num_workers members, member j on GPU j % #GPUs, partition p in member p % num_workers:
+        the reference's partition -> worker map (PartitionManager::distribute_partitions, partition_manager.cpp:557-603) with a
+        GPU as the worker.  Both answer to the same method names (capi.Store / capi.Group)."""
+        nw = int(num_workers or 0)
+        if nw > 0 and partitioned:
+            ndev = max(1, torch.cuda.device_count())
+            return capi.Group([(self._device + j) % ndev for j in range(nw)], d)
+        return capi.Store(self._ctx, d)
+
+    @property
+    def num_workers_(self):
+        """members of the device group the partitions are distributed over (0: one store)"""
+        return self._store.size() if isinstance(self._store, capi.Group) else 0
+
     # -- build (quake_index.cpp:29-90) -------------------------------------------------------------------------------
     def build(self, x, ids, build_params):
         t_total = time.perf_counter()
@@ -328,7 +344,7 @@ class QuakeIndex:
         xd = self._to_dev(x, torch.float32)
         idd = self._to_dev(ids, torch.int64)
         nlist = int(build_params.nlist)
-        self._store = capi.Store(self._ctx, d)
+        self._store = self._new_lists(d, getattr(build_params, "num_workers", 0), nlist > 1)
         if nlist > 1:
             t0 = time.perf_counter()
             # kmeans(): clustering.cpp:13-97 (IP: the normalised copy is what gets stored, :25-26,71)
@@ -409,6 +425,12 @@ class QuakeIndex:
         k = search_params.k if search_params.k and search_params.k > 0 else 1  # query_coordinator.cpp:490
         use_aps = (search_params.recall_target is not None and search_params.recall_target > 0.0 and self.parent is not None
                    and not search_params.batched_scan)  # query_coordinator.cpp:502,637-641,659-673
+        grp = self._store if isinstance(self._store, capi.Group) else None
+        if grp is not None:
+            grp.set_stream(torch.cuda.current_stream(grp.device).cuda_stream)  # the lead's stream (see _context)
+        if use_aps and grp is not None:
+            raise RuntimeError("[QueryCoordinator::search] recall_target with num_workers > 0: adaptive partition scanning is not "
+                               "implemented over a device group (use fixed nprobe, or num_workers = 0).")
         if use_aps:
             # adaptive partition scanning: candidates = nlist * initial_search_fraction, per-query early stop
             ids, dist, nscan, tm = self._ctx.search_aps(
@@ -433,8 +455,13 @@ class QuakeIndex:
                 # hit tracking for maintenance(): the probed partitions are needed on the host, so coarse and scan are
                 # two calls here (same kernels, one extra copy of [Q, nprobe] ids)
                 pids, _ = self._ctx.coarse(self.parent._store, xd, nprobe, self.metric_, values=False)
-                ids, dist, tm = self._ctx.scan(self._store, xd, pids, int(k), self.metric_, timing=True)
+                if grp is not None:
+                    ids, dist, tm = grp.scan(xd, pids, int(k), self.metric_, timing=True)
+                else:
+                    ids, dist, tm = self._ctx.scan(self._store, xd, pids, int(k), self.metric_, timing=True)
                 self.record_query_hits(pids.cpu().numpy())
+            elif grp is not None:  # workers: every member scans the partitions it holds, the lead merges (worker_scan)
+                ids, dist, tm = grp.search(self.parent._store, xd, nprobe, int(k), self.metric_, timing=True)
             else:
                 ids, dist, tm = self._ctx.search(self.parent._store if self.parent is not None else None, self._store, xd,
                                                  nprobe, int(k), self.metric_, timing=True)
@@ -717,29 +744,35 @@ class QuakeIndex:
             if version != SERIALIZATION_VERSION:
                 raise RuntimeError("Unsupported file version: %d" % version)
             d = code_size // 4
-            offs = np.frombuffer(f.read(8 * (nparts + 1)), "<u8", nparts + 1)
-            pids = np.frombuffer(f.read(8 * nparts), "<u8", nparts)
             rec = code_size + 8
-            if len(offs) != nparts + 1 or len(pids) != nparts:
+            # nothing is read (or allocated) on the word of a header field before it has been checked against the file's size
+            end = os.fstat(f.fileno()).st_size
+            start_of_chunks = 32 + 8 * (nparts + 1) + 8 * nparts
+            if d <= 0 or code_size % 4 != 0 or start_of_chunks > end:
                 raise RuntimeError("Invalid file format (truncated offset / partition id table).")
+            raw_offs, raw_pids = f.read(8 * (nparts + 1)), f.read(8 * nparts)
+            if len(raw_offs) != 8 * (nparts + 1) or len(raw_pids) != 8 * nparts:
+                raise RuntimeError("Invalid file format (truncated offset / partition id table).")
+            offs = np.frombuffer(raw_offs, "<u8", nparts + 1)
+            pids = np.frombuffer(raw_pids, "<u8", nparts)
+            if nparts and (int(offs[0]) > end or int(offs[-1]) > end):
+                raise RuntimeError("Invalid file format (truncated partition data).")
             sizes = np.diff(offs.astype(np.int64))
             # the reference seeks to start_of_chunks + offsets[i] per partition (dynamic_inverted_list.cpp:481-494); this loader reads
             # the chunks in one forward pass, which is the same thing exactly when the offsets ascend (chunk i ends where chunk
             # i + 1 starts: one cumulative table) -- anything else is refused rather than misparsed
-            if nparts and ((sizes < 0).any() or int(offs[0]) > (1 << 62)):
+            if nparts and (sizes < 0).any():
                 raise RuntimeError("Invalid file format (partition offsets are not ascending).")
             if (sizes % rec != 0).any():
                 raise RuntimeError("Partition chunk size not divisible by (code_size+sizeof(idx_t))")
-            start_of_chunks = 32 + 8 * (nparts + 1) + 8 * nparts
             if nparts:
-                end = os.fstat(f.fileno()).st_size
                 if start_of_chunks + int(offs[-1]) > end:
                     raise RuntimeError("Invalid file format (truncated partition data).")
                 f.seek(start_of_chunks + int(offs[0]))
             nvs = sizes // rec
             self._has_ctx = True
             self._d = int(d)
-            self._store = capi.Store(self._ctx, int(d))
+            self._store = self._new_lists(int(d), n_workers, os.path.isdir(os.path.join(dir_path, "parent")))
             self._resident = _ResidentIds()
             window = max(int(256 << 20), int(sizes.max()) if nparts else 0)
             raw = np.empty(window, np.uint8)

@@ -1,0 +1,175 @@
+"""IndexBuildParams.num_workers through the UNCHANGED QuakeIndex surface: workers are GPUs.  The reference's switch is
+num_workers -> QueryCoordinator::initialize_workers -> PartitionManager::distribute_partitions -> worker_scan
+(query_coordinator.cpp:50-95,243-469; partition_manager.cpp:557-603) and its own test demands worker == serial
+(test/cpp/query_coordinator.cpp:201-254: ids equal, distances <= 1e-4).  Here: both mirrors (compiled `quake._bindings` and
+`quake_amd.index`) with num_workers = G give ids and float32 distance bits equal to num_workers = 0 -- searches on host and device
+tensors, after add / remove / refine / maintenance, after save -> load(n_workers).  On a one-GPU box the G members share
+device 0 (same code path as G devices, local instead of peer addresses)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def qb():
+    from quake_amd.build_ext import build_bindings
+    build_bindings()
+    import quake_amd.bindings as b
+    return b
+
+
+def _corpus(n=40000, d=48, nc=64, seed=3):
+    g = torch.Generator().manual_seed(seed)
+    cent = torch.randn(nc, d, generator=g)
+    x = cent[torch.randint(0, nc, (n,), generator=g)] + 0.3 * torch.randn(n, d, generator=g)
+    q = cent[torch.randint(0, nc, (700,), generator=g)] + 0.3 * torch.randn(700, d, generator=g)
+    return x.contiguous(), torch.arange(n), q.contiguous()
+
+
+def _bits(t):
+    return t.detach().cpu().contiguous().view(torch.int32)
+
+
+def _same(ra, rb):
+    assert torch.equal(ra.ids.cpu(), rb.ids.cpu())
+    assert torch.equal(_bits(ra.distances), _bits(rb.distances))
+
+
+def _build(mod, x, ids, nlist, workers, metric="l2"):
+    bp = mod.IndexBuildParams()
+    bp.nlist, bp.metric, bp.num_workers = nlist, metric, workers
+    idx = mod.QuakeIndex()
+    idx.build(x, ids, bp)
+    return idx
+
+
+def _params(mod, k, nprobe, batched=False):
+    sp = mod.SearchParams()
+    sp.k, sp.nprobe, sp.batched_scan = k, nprobe, batched
+    return sp
+
+
+@pytest.mark.parametrize("mirror", ["compiled", "python"])
+@pytest.mark.parametrize("G", [2, 4])
+def test_num_workers_equals_no_workers(qb, mirror, G):
+    import quake_amd as qa
+    mod = qb if mirror == "compiled" else qa
+    x, ids, q = _corpus()
+    a = _build(mod, x, ids, 64, 0)
+    b = _build(mod, x, ids, 64, G)
+    assert b.ntotal() == a.ntotal() == 40000 and b.nlist() == a.nlist() == 64
+    if mirror == "compiled":
+        pm, qc = b.partition_manager, b.query_coordinator
+        assert pm.num_workers() == G and qc.workers_initialized and qc.num_workers == G
+        assert [pm.get_partition_core_id(p) for p in (0, 1, G, G + 1, 63)] == [0, 1 % G, 0, 1 % G, 63 % G]
+        assert a.partition_manager.num_workers() == 0 and a.partition_manager.get_partition_core_id(3) == -1
+    for k, nprobe in [(10, 1), (10, 8), (100, 5), (1, 64)]:
+        _same(a.search(q, _params(mod, k, nprobe)), b.search(q, _params(mod, k, nprobe)))
+        _same(a.search(q[:3], _params(mod, k, nprobe)), b.search(q[:3], _params(mod, k, nprobe)))  # the one-launch small path
+    rd = b.search(q.cuda(), _params(mod, 10, 6))
+    assert rd.ids.is_cuda
+    _same(a.search(q, _params(mod, 10, 6)), rd)
+    ti = b.search(q, _params(mod, 10, 6)).timing_info
+    assert ti.partitions_scanned == a.search(q, _params(mod, 10, 6)).timing_info.partitions_scanned > 0
+    # add / remove / get / refine: the same index afterwards
+    g = torch.Generator().manual_seed(11)
+    nx = x[torch.randint(0, 40000, (5000,), generator=g)] + 0.05 * torch.randn(5000, 48, generator=g)
+    nid = torch.arange(100000, 105000)
+    for idx in (a, b):
+        assert idx.add(nx, nid).n_vectors == 5000
+        idx.remove(torch.arange(0, 40000, 7))
+    assert b.ntotal() == a.ntotal()
+    assert torch.equal(a.get(nid[:50]), b.get(nid[:50]))
+    assert torch.equal(torch.sort(a.get_ids()).values, torch.sort(b.get_ids()).values)
+    _same(a.search(q, _params(mod, 10, 8)), b.search(q, _params(mod, 10, 8)))
+    some = torch.tensor([1, 2, 3, 10, 17, 30])  # lists of several members
+    if mirror == "compiled":
+        a.refine_partitions(some, 2)
+        b.refine_partitions(some, 2)
+    else:
+        a.refine_partitions(some, 2)
+        b.refine_partitions(some, 2)
+    assert torch.equal(a.parent.get(some), b.parent.get(some))
+    _same(a.search(q, _params(mod, 10, 8)), b.search(q, _params(mod, 10, 8)))
+    with pytest.raises(RuntimeError):
+        b.add(nx[:3], nid[:3])  # duplicate ids are refused exactly as without workers
+    with pytest.raises(RuntimeError):
+        b.remove(torch.tensor([0]))  # already removed
+
+
+@pytest.mark.parametrize("mirror", ["compiled", "python"])
+def test_workers_survive_save_and_load(qb, mirror, tmp_path):
+    import quake_amd as qa
+    mod = qb if mirror == "compiled" else qa
+    x, ids, q = _corpus(20000, 32, 32, seed=5)
+    a = _build(mod, x, ids, 32, 3)
+    d = str(tmp_path / "idx")
+    a.save(d)
+    one, three = mod.QuakeIndex(), mod.QuakeIndex()
+    one.load(d)
+    three.load(d, 3)
+    if mirror == "compiled":
+        assert one.partition_manager.num_workers() == 0 and three.partition_manager.num_workers() == 3
+    for idx in (one, three):
+        assert idx.ntotal() == 20000 and idx.nlist() == 32
+        _same(a.search(q, _params(mod, 10, 4)), idx.search(q, _params(mod, 10, 4)))
+
+
+def test_initialize_workers_on_a_built_index_moves_the_partitions(qb):
+    """QueryCoordinator::initialize_workers after the fact (the reference's tests construct coordinators with and without workers
+    over one manager, test/cpp/query_coordinator.cpp:96-140): the partitions move from the one store into the group."""
+    x, ids, q = _corpus(20000, 32, 32, seed=9)
+    a = _build(qb, x, ids, 32, 0)
+    ref = a.search(q, _params(qb, 10, 5))
+    qc, pm = a.query_coordinator, a.partition_manager
+    assert not qc.workers_initialized and pm.num_workers() == 0
+    qc.initialize_workers(4)
+    assert qc.workers_initialized and pm.num_workers() == 4 and pm.ntotal() == 20000 and pm.nlist() == 32
+    _same(ref, a.search(q, _params(qb, 10, 5)))
+    _same(ref, qc.worker_scan(q, a.parent.search(q, _params(qb, 5, 32)).ids, _params(qb, 10, 5)))
+    qc.shutdown_workers()
+    assert not qc.workers_initialized
+    _same(ref, a.search(q, _params(qb, 10, 5)))  # the partitions stay where they are
+    with pytest.raises(RuntimeError, match="already distributed"):
+        pm.distribute_partitions(2)
+
+
+def test_recall_target_with_workers_is_refused_loudly(qb):
+    x, ids, q = _corpus(20000, 32, 32, seed=9)
+    b = _build(qb, x, ids, 32, 2)
+    sp = _params(qb, 10, 5)
+    sp.recall_target = 0.9
+    with pytest.raises(RuntimeError, match="device group"):
+        b.search(q, sp)
+
+
+@pytest.mark.parametrize("mirror", ["compiled", "python"])
+def test_maintenance_with_workers(qb, mirror):
+    """maintenance() splits / deletes / refines the same partitions with and without workers (split children get the next
+    partition numbers, partition_manager.cpp:492-493, and land on the members those numbers name)."""
+    import quake_amd as qa
+    mod = qb if mirror == "compiled" else qa
+    x, ids, q = _corpus(30000, 32, 24, seed=13)
+    out = []
+    for workers in (0, 3):
+        idx = _build(mod, x, ids, 24, workers)
+        mp = mod.MaintenancePolicyParams()
+        mp.window_size, mp.refinement_radius, mp.refinement_iterations = 200, 4, 1
+        mp.split_threshold_ns, mp.delete_threshold_ns, mp.min_partition_size = 0.0, 0.0, 8
+        mp.enable_split_rejection, mp.enable_delete_rejection = False, False
+        idx.initialize_maintenance_policy(mp)
+        if mirror == "compiled":
+            idx.set_track_hits(True)
+        else:
+            idx.track_hits = True
+        # a skewed window: every query on the same few partitions
+        hot = q[:50].repeat(8, 1)
+        idx.search(hot, _params(mod, 10, 4))
+        m = idx.maintenance()
+        out.append((idx, m.n_splits, m.n_deletes))
+    (a, sa, da), (b, sb, db) = out
+    assert (sa, da) == (sb, db)
+    assert a.nlist() == b.nlist() and a.ntotal() == b.ntotal() == 30000
+    _same(a.search(q, _params(mod, 10, 6)), b.search(q, _params(mod, 10, 6)))
