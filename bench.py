@@ -206,17 +206,28 @@ def pick_nprobe(step, batches, gts, k, target, fixed, recall_fn):
     return nprobe, rec(nprobe), sweep
 
 
-def timed_region(ctx, step, nprobe, steps, warmup, settle, dist, dev, ctxs=None):
+MIN_TIMED_STEPS = 200  # a 20-step region of a 0.3 ms step is 6 ms: one clock excursion moves it by 2-3 %
+
+
+def timed_region(ctx, step, nprobe, steps, warmup, settle, dist, dev, ctxs=None, groups=None, sync=None):
     """settle + warmup untimed, then EXACTLY `steps` steps between barrier + synchronize; one HIP event pair per step around
     the scan kernel (timing mode 3).  ctxs: the contexts the steps rotate over (step i runs on ctxs[i % len]; each has its own
     stream and output buffers, so len(ctxs) batches are in flight at a time); default [ctx].
-    Returns (elapsed seconds max over ranks, scan-kernel event sums, phase sums)."""
+    The region is run `groups` times (default: as many as it takes to time MIN_TIMED_STEPS steps in all, at most 10) -- every
+    group is exactly `steps` steps between barrier + synchronize on both sides -- and the MEDIAN group is the one reported:
+    `elapsed` is its wall time (max over ranks); group_times lists them all.
+    sync: extra synchronisation of the path under test (the device group's members), called beside the contexts'.
+    Returns (elapsed seconds, scan-kernel event sums over all groups, phase sums, group_times)."""
     ctxs = ctxs or [ctx]
     nc = len(ctxs)
+    if groups is None:
+        groups = max(1, min(10, -(-MIN_TIMED_STEPS // max(steps, 1))))
 
     def sync_all():
         for c in ctxs:
             c.synchronize()
+        if sync is not None:
+            sync()
         torch.cuda.synchronize()
 
     for c in ctxs:
@@ -235,16 +246,23 @@ def timed_region(ctx, step, nprobe, steps, warmup, settle, dist, dev, ctxs=None)
         step(nprobe, i % N_BATCHES, i % nc)
     for c in ctxs:
         c.set_timing(3)
-    if dist is not None:
-        dist.barrier()
-    sync_all()
-    t0 = time.perf_counter()
-    for i in range(steps):
-        step(nprobe, i % N_BATCHES, i % nc)
-    if dist is not None:
-        dist.barrier()
-    sync_all()
-    elapsed = time.perf_counter() - t0
+    times = []
+    for _ in range(groups):
+        if dist is not None:
+            dist.barrier()
+        sync_all()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(nprobe, i % N_BATCHES, i % nc)
+        if dist is not None:
+            dist.barrier()
+        sync_all()
+        times.append(time.perf_counter() - t0)
+    if dist is not None:  # a group's time is the slowest rank's
+        tt = torch.tensor(times, dtype=torch.float64, device=dev if str(dist.get_backend()).lower() != "gloo" else "cpu")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        times = tt.tolist()
+    elapsed = sorted(times)[(len(times) - 1) // 2]  # the median group (the lower one of an even count)
     ev = None
     for c in ctxs:  # the scan-kernel event pairs of all streams
         e = c.read_timing()
@@ -256,11 +274,14 @@ def timed_region(ctx, step, nprobe, steps, warmup, settle, dist, dev, ctxs=None)
     ev_ph = ctx.read_timing()
     for c in ctxs:
         c.set_timing(0)
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if str(dist.get_backend()).lower() != "gloo" else "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = tt.item()
-    return elapsed, ev, ev_ph
+    return elapsed, ev, ev_ph, times
+
+
+def groups_of(times, steps, Q):
+    """the timed groups of a region as a field of the result: every group = exactly `steps` steps between synchronisations"""
+    return {"groups": len(times), "steps_each": steps, "reported": "median group",
+            "queries_per_s": [round(Q * steps / t, 1) for t in times],
+            "min": round(Q * steps / max(times), 1), "max": round(Q * steps / min(times), 1)}
 
 
 def roofline_of(scan_bytes, ev, traffic=None, kernel="k_scan", pair_rows=None, d=None, traffic_source=None):
@@ -389,6 +410,54 @@ def committed_traffic(name, n, d, k, nprobe):
     return None
 
 
+def cpu_sgemm_search(qh, hc, hv, hi, ho, nprobe, k, metric, threads):
+    """SURVEY 8(d) CPU leg (iii): batched_serial_scan as the reference's back end computes it (list_scanning.h:313-366 ->
+    faiss::knn_L2sqr / knn_inner_product): queries grouped by probed partition (query_coordinator.cpp:707-721); a group of >= 20
+    queries against its partition is ONE sgemm (torch.mm on the host = MKL) + the |x|^2 + |y|^2 - 2xy fix-up clamped at 0, a
+    smaller group the direct form; k_max = min(k, n_p) best rows per (query, partition), merged per query.  The coarse step is
+    the same thing over the centroids.  Not the checker (summation order is the BLAS's): a timed port of the reference's
+    arithmetic speed.  Returns (ids [Q, k], dist [Q, k])."""
+    torch.set_num_threads(int(threads))
+    q = torch.from_numpy(qh)
+    Q, d = q.shape
+    cent = torch.from_numpy(hc)
+    l2 = metric == "l2"
+
+    def keys(a, b):  # smaller = better
+        if not l2:
+            return -(a @ b.T)
+        if a.shape[0] >= 20:
+            return ((a * a).sum(1, keepdim=True) + (b * b).sum(1)[None, :] - 2.0 * (a @ b.T)).clamp_(min=0)
+        return ((a[:, None, :] - b[None, :, :]) ** 2).sum(2)
+
+    pids = torch.topk(keys(q, cent), min(nprobe, cent.shape[0]), dim=1, largest=False).indices  # [Q, P]
+    flat = pids.reshape(-1)
+    order = torch.argsort(flat, stable=True)
+    uniq, cnt = torch.unique_consecutive(flat[order], return_counts=True)
+    qidx = torch.div(order, pids.shape[1], rounding_mode="floor")
+    best_k = torch.full((Q, pids.shape[1] * k), float("inf"))
+    best_i = torch.full((Q, pids.shape[1] * k), -1, dtype=torch.int64)
+    fill = torch.zeros(Q, dtype=torch.int64)
+    vt, it = torch.from_numpy(hv), torch.from_numpy(hi)
+    pos = 0
+    for p, c in zip(uniq.tolist(), cnt.tolist()):
+        rows = qidx[pos:pos + c]
+        pos += c
+        a, b = int(ho[p]), int(ho[p + 1])
+        if b == a:
+            continue
+        kk = min(k, b - a)
+        v, j = torch.topk(keys(q[rows], vt[a:b]), kk, dim=1, largest=False)
+        col = fill[rows][:, None] + torch.arange(kk)[None, :]
+        best_k[rows[:, None], col] = v
+        best_i[rows[:, None], col] = it[a:b][j]
+        fill[rows] += kk
+    v, j = torch.topk(best_k, k, dim=1, largest=False)
+    ids = torch.gather(best_i, 1, j)
+    dist = torch.sqrt(v) if l2 else -v
+    return ids.numpy(), dist.numpy()
+
+
 def run_single_workload(ctx, dev, args, name, sigma, fixed_nprobe, steps, warmup, settle, cpu_seconds, traffic_file=None,
                         manifold=0, sweep_nprobes=()):
     """Build, sweep nprobe, time, verify against the oracle.  Returns the result dict of one single-GPU workload.
@@ -435,11 +504,11 @@ def run_single_workload(ctx, dev, args, name, sigma, fixed_nprobe, steps, warmup
     _, _, tinfo = ctx.search(parent, store, batches[0], nprobe, k, metric, timing=True)
     log(f"[{name}] phases (ms):", {kk: round(v, 4) if isinstance(v, float) else v for kk, v in tinfo.items()})
     # the timed region of the contract: one batch at a time on one stream
-    elapsed, ev, ev_ph = timed_region(ctx, step, nprobe, steps, warmup, settle, None, dev, ctxs=[ctx])
+    elapsed, ev, ev_ph, gtimes = timed_region(ctx, step, nprobe, steps, warmup, settle, None, dev, ctxs=[ctx])
     piped = None
     if inflight > 1:  # the same steps with `inflight` batches in flight, reported beside the headline figure (never `value`)
         n2 = max(steps // 2, 10)
-        e2, ev2, _ = timed_region(ctx, step, nprobe, n2, min(warmup, 10), 0, None, dev, ctxs=ctxs)
+        e2, ev2, _, _ = timed_region(ctx, step, nprobe, n2, min(warmup, 10), 0, None, dev, ctxs=ctxs, groups=3)
         piped = {"batches_in_flight": inflight, "value": round(Q * n2 / e2, 1), "unit": "queries/s",
                  "ms_per_step": round(1e3 * e2 / n2, 4), "steps": n2,
                  "scan_kernel_ms_avg": round(ev2["scan_ms"] / max(ev2["calls"], 1), 5),
@@ -490,7 +559,7 @@ def run_single_workload(ctx, dev, args, name, sigma, fixed_nprobe, steps, warmup
     for npb in sweep_nprobes:
         if npb == nprobe:
             continue
-        e_s, ev_s, _ = timed_region(ctx, step, npb, 30, 5, 20, None, dev, ctxs=[ctx])
+        e_s, ev_s, _, _ = timed_region(ctx, step, npb, 30, 5, 20, None, dev, ctxs=[ctx], groups=5)
         ctx.set_timing(1)
         sb = int(sum(int(ctx.search(parent, store, batches[b], npb, k, metric, timing=True)[2]["scan_bytes"]) for b in range(N_BATCHES)) // N_BATCHES)
         ctx.set_timing(0)
@@ -504,7 +573,7 @@ def run_single_workload(ctx, dev, args, name, sigma, fixed_nprobe, steps, warmup
                                                   traffic_source=f"rocprofv3 --pmc FETCH_SIZE in this run ({mt['kernel']}, {mt['launches']} launches)" if mt else None)})
     res = {
         "value": round(Q * steps / elapsed, 1), "unit": "queries/s", "ms_per_step": round(1e3 * elapsed / steps, 4),
-        "steps": steps, "warmup": warmup,
+        "steps": steps, "warmup": warmup, "timed_groups": groups_of(gtimes, steps, Q),
         "config": {
             "workload": f"Synthetic {n // 1_000_000}M x {d} f32 {metric.upper()} {'unit-norm ' if unit else ''}{desc}, "
                         f"nlist={nlist}, batch={Q} queries, k={k}, nprobe={nprobe}",
@@ -555,15 +624,42 @@ def run_single_workload(ctx, dev, args, name, sigma, fixed_nprobe, steps, warmup
         qps_s, n_s, reps_s, t_s, ids_s, _ = time_cpu(False, cpu_seconds * 0.35, cores, Q, fast=2)
         n1 = max(8, min(Q, int(qps_s / max(cores, 1) * cpu_seconds * 0.3) or 8))  # a few seconds on one thread
         qps_1, _, _, t_1, _, _ = time_cpu(False, 0.0, 1, n1, fast=2)
+        # leg (iii): the batched path at the reference's arithmetic speed -- per-partition sgemm (MKL through torch.mm) on all
+        # threads and on one; ids compared with the GPU's under the near-tie rule (a BLAS sums in its own order)
+        nt0 = torch.get_num_threads()
+        sg = {}
+        for label, th, budget in (("all", cores, cpu_seconds * 0.15), ("one", 1, cpu_seconds * 0.15)):
+            t, reps, ids_g, dist_g = 0.0, 0, None, None
+            nq_g = Q if label == "all" else max(32, Q // 8)
+            while reps == 0 or (t < budget and reps < 1000):
+                t1 = time.perf_counter()
+                ids_g, dist_g = cpu_sgemm_search(qh[:nq_g], hc, hv, hi, ho, nprobe, k, metric, th)
+                t += time.perf_counter() - t1
+                reps += 1
+            sg[label] = (nq_g * reps / t, ids_g, dist_g, nq_g, reps, t)
+        torch.set_num_threads(nt0)
+        qps_g, ids_g, dist_g = sg["all"][0], sg["all"][1], sg["all"][2]
+        agree = ids_g == gi0
+        with np.errstate(invalid="ignore"):
+            dist_ok = (np.abs(dist_g - gd0) <= 1e-4 * np.maximum(1.0, np.abs(gd0))) | (dist_g == gd0)
         best_batched = qps_b > qps_s
+        best_cpu = max(qps_b, qps_s, qps_g)
         res["cpu_baseline"] = {
-            "value": round(max(qps_b, qps_s), 1), "unit": "queries/s", "cores": cores, "kind": "port",
-            "sample": f"the {Q}-query bench batch 0 replayed {reps_b if best_batched else reps_s}x, same index/nprobe/k, oracle "
+            "value": round(best_cpu, 1), "unit": "queries/s", "cores": cores, "kind": "port",
+            "fastest_leg": "batched_sgemm" if best_cpu == qps_g else ("batched_scan" if best_batched else "serial_scan"),
+            "batched_sgemm_qps": round(qps_g, 1), "batched_sgemm_qps_one_thread": round(sg["one"][0], 1),
+            "batched_sgemm_sample": f"{sg['all'][3]} queries x {sg['all'][4]} on {cores} torch threads in {sg['all'][5]:.1f}s; one "
+                                    f"thread: {sg['one'][3]} queries x {sg['one'][4]} in {sg['one'][5]:.1f}s (torch.mm = MKL sgemm per "
+                                    "partition group of >= 20 queries, direct form below: list_scanning.h:335-338 -> faiss::knn_L2sqr)",
+            "batched_sgemm_ids_equal_to_gpu_frac": round(float(agree.mean()), 5),
+            "batched_sgemm_dist_within_1e-4_frac": round(float(dist_ok.mean()), 5),
+            "sample": f"(oracle legs) the {Q}-query bench batch 0 replayed {reps_b if best_batched else reps_s}x, same index/nprobe/k, oracle "
                       f"search() = coarse + {'batched_serial_scan' if best_batched else 'serial_scan'} semantics on {cores} "
                       f"threads, {t_b if best_batched else t_s:.1f}s (the faster of the reference's two scan variants); "
                       f"single thread: {n1} queries in {t_1:.1f}s.  NOTE: {cores} threads were asked for, the box delivered "
                       f"{eff_cores} cores' worth of arithmetic (effective_cores_measured) and the {cores}-thread run is only "
-                      f"{max(qps_b, qps_s) / max(qps_1, 1e-9):.1f}x one thread -- this leg mostly measures a few cores",
+                      f"{max(qps_b, qps_s) / max(qps_1, 1e-9):.1f}x one thread -- this leg mostly measures a few cores.  `value` is the "
+                      f"fastest of the three legs (fastest_leg)",
             "serial_scan_qps": round(qps_s, 1), "batched_scan_qps": round(qps_b, 1),
             "single_thread_qps": round(qps_1, 1), "threads_speedup": round(max(qps_b, qps_s) / max(qps_1, 1e-9), 1),
             "effective_cores_measured": eff_cores,
@@ -772,12 +868,13 @@ def run_sharded(ctx, dev, args, dist, rank, world):
 
     nprobe, recall, sweep = pick_nprobe(step, batches, gts, k, args.recall_target, args.nprobe, rec)
     log(f"nprobe={nprobe} recall@{k}={recall:.4f} sweep={sweep}")
-    elapsed, ev, ev_ph = timed_region(ctx, step, nprobe, args.steps, args.warmup, args.settle, dist, dev)
+    elapsed, ev, ev_ph, gtimes = timed_region(ctx, step, nprobe, args.steps, args.warmup, args.settle, dist, dev)
     ctx.set_timing(1)
     sb = torch.tensor([float(sharded.engine.last_scan_bytes(batches[0], nprobe, k))], device=dev, dtype=torch.float64)
     ctx.set_timing(0)
     return {
         "value": round(Q * args.steps / elapsed, 1), "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+        "timed_groups": groups_of(gtimes, args.steps, Q),
         "config": {
             "workload": f"Synthetic {n * world // 1_000_000}M x {d} f32 {metric.upper()} Gaussian mixture, nlist={nlist_g} "
                         f"(one k-means over all ranks), lists sharded by number over {world} ranks, batch={Q} queries, k={k}, "
@@ -792,6 +889,198 @@ def run_sharded(ctx, dev, args, dist, rank, world):
         "phases_ms": phases_of(ev_ph),
         "build": {"sharded_kmeans_s": round(t_kmeans, 2), "niter": args.niter},
     }
+
+
+# ---- one rank's step of BASELINE.json configs[3] (8 x MI355X), on ONE GPU, without the exchange ---------------------------------
+def run_rank_step(ctx, dev, args, nprobe, world=8):
+    """What rank 0 of an 8-GPU configs[3] run does per batch, minus the collectives: 100M x 128 / 65536 lists / 4096 queries over 8
+    GPUs = 12.5M local vectors in the 8192 lists p % 8 == 0, all 65536 centroids replicated.  Step = coarse for the rank's 512-query
+    slice against the 65536 centroids + scan of the WHOLE 4096-query batch over the local lists (a probe of another rank's list
+    finds nothing here) with squared keys + qk_pack_topk of the [4096][k] result into the 8 blocks of the all-to-all.  The local
+    centroids come from a k-means of the local vectors (8192 clusters: what the global k-means finds in this rank's region), the
+    other 57344 are the true centres of the other ranks' components."""
+    from quake_amd.capi import Store
+    n, d, k, metric = args.nvec_sharded, 128, args.k, "l2"
+    nl_local, Q = args.nlist_sharded, args.batch_sharded * world
+    nl = nl_local * world
+    per = Q // world
+    g0 = torch.Generator(device=dev).manual_seed(1)
+    cent_true = torch.randn(nl, d, generator=g0, device=dev)
+    local = torch.arange(0, nl, world, device=dev)
+    x, _ = gen_mixture(n, d, nl_local, seed=1000, device=dev, cent=cent_true[local].contiguous())
+    t0 = time.time()
+    c_local, assign, _ = ctx.kmeans(x, nl_local, metric, niter=args.niter, seed=1234)
+    torch.cuda.synchronize()
+    t_km = time.time() - t0
+    order = torch.argsort(assign, stable=True)
+    counts = torch.bincount(assign, minlength=nl_local).cpu().numpy().astype(np.int64)
+    offsets = np.zeros(nl + 1, np.int64)
+    sizes = np.zeros(nl, np.int64)
+    sizes[::world] = counts  # local cluster i is global list i * world
+    offsets[1:] = np.cumsum(sizes)
+    store = Store(ctx, d)
+    store.build_csr(offsets, order.contiguous(), x[order].contiguous())
+    del x, order, assign
+    cent_all = cent_true.clone()
+    cent_all[local] = c_local
+    parent = Store(ctx, d)
+    parent.build_csr(np.array([0, nl], np.int64), torch.arange(nl, device=dev), cent_all.contiguous())
+    batches = [gen_queries(Q, cent_true, seed=2 + b, device=dev) for b in range(N_BATCHES)]
+    pids = [ctx.coarse(parent, q, nprobe, metric, values=False)[0].contiguous() for q in batches]  # what the ranks exchange
+    out_i = torch.empty((Q, k), dtype=torch.int64, device=dev)
+    out_d = torch.empty((Q, k), dtype=torch.float32, device=dev)
+    packed = torch.empty((world, ctx.topk_block_bytes(per, k)), dtype=torch.uint8, device=dev)
+    slice_p = torch.empty((per, nprobe), dtype=torch.int64, device=dev)
+    import ctypes as C
+    from quake_amd.capi import _ptr, check, metric_code
+    from quake_amd._lib import QK_MEM_DEVICE
+
+    def coarse_slice(b):
+        check(ctx.lib.qk_coarse(ctx.h, parent.h, _ptr(batches[b]), per, nprobe, metric_code(metric), _ptr(slice_p), None, QK_MEM_DEVICE))
+
+    def step(b):
+        coarse_slice(b)
+        ctx.set_squared_l2(True)
+        ctx.scan_into(store, batches[b], pids[b], k, metric, (out_i, out_d))
+        ctx.set_squared_l2(False)
+        ctx.pack_topk(out_i, out_d, world, out=packed)
+
+    def timeit(fn, reps):
+        for i in range(10):
+            fn(i % N_BATCHES)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()  # (the context is bound to torch's current stream)
+        for i in range(reps):
+            fn(i % N_BATCHES)
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    for i in range(32):  # form feedback of the scan shape: synchronised calls
+        step(i % N_BATCHES)
+        torch.cuda.synchronize()
+    step_ms = timeit(step, 100)
+    coarse_ms = timeit(coarse_slice, 100)
+    ctx.set_timing(3)
+    for i in range(50):
+        step(i % N_BATCHES)
+    ev = ctx.read_timing()
+    ctx.set_timing(1)
+    sb, pairs = 0, 0
+    for b in range(N_BATCHES):
+        tm = ctx.scan(store, batches[b], pids[b], k, metric, timing=True)[2]
+        sb += int(tm["scan_bytes"])
+        pairs += int(tm["partitions_scanned"])
+    ctx.set_timing(0)
+    kern = ctx.last_scan_kernel()
+    # the step's answer against brute force over the local vectors, restricted to the local probes: ids of batch 0 (parity of the
+    # scan itself is the headline's and the tests' business; this guards the emulation)
+    cf = 2.0 * per * nl * d
+    res = {
+        "config": {"workload": f"one rank's step of BASELINE.json configs[3] (100M x 128 L2, nlist=65536, batch=4096, k={k}, 8 GPUs) on one "
+                               f"GPU without the exchange: {n} local vectors in the {nl_local} lists p % {world} == 0, {nl} replicated "
+                               f"centroids, coarse for the rank's {per}-query slice + scan of all {Q} queries over the local lists + "
+                               f"qk_pack_topk; nprobe={nprobe}",
+                   "nvec_local": n, "nlist": nl, "nlist_local": nl_local, "batch": Q, "slice": per, "k": k, "nprobe": nprobe,
+                   "local_kmeans_s": round(t_km, 2)},
+        "ms_per_step": round(step_ms, 4), "value": round(Q / (step_ms * 1e-3), 1), "unit": "queries/s",
+        "note": "value = batch / step time of ONE rank: the whole-job rate of 8 such ranks if the two collectives (all-gather of the "
+                "list numbers, all-to-all of 12-byte records: 491 KB per rank) were free; device events on the launch stream",
+        "probed_local_pairs_per_batch": pairs // N_BATCHES,
+        "roofline": roofline_of(sb // N_BATCHES, ev, kernel=kern),
+        "coarse": {"kernel_ms": round(coarse_ms, 4), "flops": int(cf), "achieved": round(cf / (coarse_ms * 1e-3) / 1e12, 1),
+                   "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(cf / (coarse_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 3),
+                   "bound": "mfma" if nprobe == 1 else "mfma (bf16 prefilter + exact fp32 finish: algorithmic flops over the fp32 peak)",
+                   "note": f"{per} queries x {nl} centroids x {d}: 2*Q*nlist*d flops / the coarse call's device time (prep + rank + select)"},
+    }
+    store.close()
+    parent.close()
+    torch.cuda.empty_cache()
+    return res
+
+
+# ---- N > 1 in ONE process: the device group (IndexBuildParams::num_workers = N) ---------------------------------------------------
+def run_group(ctx, dev, args, world):
+    """`--gpus N --single-process`: BASELINE.json configs[3] shape through the device group of the C ABI (qk_group_*: what
+    QuakeIndex does with num_workers = N): one process, member j on GPU j % #GPUs, list p in member p % N, the centroids
+    replicated by the library; a step = one qk_group_search of the whole batch with queries and answers in the lead's HBM."""
+    from quake_amd.capi import Group, Store
+    n, d, k, metric = args.nvec_sharded * world, args.dim, args.k, args.metric
+    nlist, Q = args.nlist_sharded * world, args.batch_sharded * world
+    unit = metric == "ip"
+    ndev = torch.cuda.device_count()
+    devices = [j % ndev for j in range(world)]
+    x, cent_true = gen_mixture(n, d, nlist, seed=1, device=dev, unit=unit)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    centroids, assign, _ = ctx.kmeans(x, nlist, metric, niter=args.niter, seed=1234)
+    torch.cuda.synchronize()
+    t_kmeans = time.time() - t0
+    order = torch.argsort(assign, stable=True)
+    counts = torch.bincount(assign, minlength=nlist).cpu().numpy().astype(np.int64)
+    offsets = np.zeros(nlist + 1, np.int64)
+    offsets[1:] = np.cumsum(counts)
+    ids_sorted, x_sorted = order.contiguous(), x[order].contiguous()
+    del order, assign
+    t0 = time.time()
+    grp = Group(devices, d)
+    grp.build_csr(offsets, ids_sorted, x_sorted)
+    parent = Store(ctx, d)
+    parent.build_csr(np.array([0, nlist], np.int64), torch.arange(nlist, device=dev), centroids.contiguous())
+    log(f"group of {world} members on devices {devices}: {n} vectors, nlist={nlist}, k-means {t_kmeans:.2f}s, distribution {time.time() - t0:.1f}s")
+    del ids_sorted, x_sorted
+    batches = [gen_queries(Q, cent_true, seed=2 + b, device=dev, unit=unit) for b in range(N_BATCHES)]
+    gts = [brute_force_topk(q, x, k, metric=metric)[0] for q in batches]
+    del x
+    torch.cuda.empty_cache()
+    grp.set_stream(torch.cuda.current_stream().cuda_stream)
+    out = (torch.empty((Q, k), dtype=torch.int64, device=dev), torch.empty((Q, k), dtype=torch.float32, device=dev))
+
+    def step(nprobe, b, slot=0):
+        return grp.search(parent, batches[b], nprobe, k, metric, out=out)
+
+    nprobe, recall, sweep = pick_nprobe(step, batches, gts, k, args.recall_target, args.nprobe, lambda ri, b: recall_at_k(ri, gts[b], k))
+    log(f"[group] nprobe={nprobe} recall@{k}={recall:.4f} sweep={sweep}")
+    # parity: the group's answer == the one-store search over the same lists (when the whole index also fits one store: N small)
+    elapsed, _, _, gtimes = timed_region(ctx, step, nprobe, args.steps, args.warmup, args.settle, None, dev, sync=grp.synchronize)
+    _, _, tm = grp.search(parent, batches[0], nprobe, k, metric, timing=True)
+    sb = 0
+    for b in range(N_BATCHES):
+        sb += int(grp.search(parent, batches[b], nprobe, k, metric, timing=True)[2]["scan_bytes"])
+    sb //= N_BATCHES
+    # every member streams its share of the unique bytes concurrently: aggregate bytes / the lead's scan phase against N x peak
+    scan_ms = tm["scan_ms"]
+    agg = sb / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
+    distinct = len(set(devices))
+    res = {
+        "value": round(Q * args.steps / elapsed, 1), "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+        "timed_groups": groups_of(gtimes, args.steps, Q),
+        "config": {
+            "workload": f"Synthetic {n // 1_000_000}M x {d} f32 {metric.upper()} Gaussian mixture, nlist={nlist}, device group of {world} "
+                        f"members in ONE process (qk_group_search = QuakeIndex with num_workers={world}), list p in member p % {world}, "
+                        f"batch={Q} queries, k={k}, nprobe={nprobe} (BASELINE.json configs[3] shape: 12.5M vectors, 8192 lists and "
+                        f"512 queries per member)",
+            "nvec": n, "dim": d, "metric_type": metric, "nlist": nlist, "batch": Q, "k": k, "nprobe": nprobe,
+            "recall_at_k": round(recall, 4), "recall_sweep": sweep, "settle_steps": max(args.settle, 0),
+            "query_batches_rotated": N_BATCHES, "devices": devices,
+            "sharding": "single process: coarse split by queries, list numbers and packed top-k peer-written over xGMI, merge on "
+                        "the lead; " + ("members SHARE devices: a functional run, not a scaling figure" if distinct < world else
+                                        "one member per GPU"),
+        },
+        "roofline": {"kernel": "partition scan of every member (lead's scan phase: entry of the scans to the arrival of the last block)",
+                     "bound": "hbm", "achieved": round(agg, 1), "peak": HBM_PEAK_GBS * distinct, "unit": "GB/s",
+                     "frac": round(agg / (HBM_PEAK_GBS * distinct), 4), "traffic": None, "algorithmic_bytes_per_launch": int(sb),
+                     "kernel_ms_avg": round(scan_ms, 5),
+                     "note": "unique probed bytes over ALL members / the lead's scan phase (HIP events on the lead's stream), against "
+                             f"{distinct} x the HBM peak"},
+        "phases_ms": {"coarse": round(tm["coarse_ms"], 4), "group": 0.0, "scan": round(tm["scan_ms"], 4), "merge": round(tm["merge_ms"], 4),
+                      "note": "events on the lead's stream: coarse = batch in to list numbers everywhere; scan = to the last packed block; merge"},
+        "build": {"kmeans_s": round(t_kmeans, 2), "niter": args.niter},
+    }
+    grp.close()
+    parent.close()
+    return res
 
 
 def launch_ranks(n):
@@ -850,8 +1139,14 @@ def main():
     ap.add_argument("--no-pmc", action="store_true", help="skip the in-run rocprofv3 FETCH_SIZE pass (roofline.traffic falls back to profiles/)")
     ap.add_argument("--no-host-api", action="store_true", help="skip the host-buffer (QK_MEM_HOST) rate")
     ap.add_argument("--traffic-probe", action="store_true", help="internal: the short replay measured_traffic() profiles")
+    ap.add_argument("--single-process", action="store_true",
+                    help="--gpus N in ONE process through the device group of the C ABI (qk_group_*: QuakeIndex with num_workers = N) "
+                         "instead of N torch.distributed ranks")
+    ap.add_argument("--only", default="", help="comma-separated subset of the extra workloads (hard,configs0,configs2,configs3_rank_step)")
     args = ap.parse_args()
 
+    if args.single_process:
+        return main_single_process(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # plain `python bench.py --gpus N`: start the N ranks ourselves (the coordinator starts its own workers,
         # query_coordinator.cpp:50-95) -- one process per GPU through torch.distributed.run, rank 0 prints the JSON line
@@ -914,6 +1209,7 @@ def main():
         "warmup": args.warmup, "ms_per_step": main_res["ms_per_step"], "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": main_res["config"],
         "roofline": main_res["roofline"], "phases_ms": main_res["phases_ms"], "build": main_res["build"],
+        "timed_groups": main_res.get("timed_groups"),
     }
     if main_res.get("batches_in_flight"):
         result["batches_in_flight"] = main_res["batches_in_flight"]
@@ -925,11 +1221,24 @@ def main():
             result["speedup_vs_cpu"] = main_res["speedup_vs_cpu"]
         if not args.no_extra:
             extra = {}
+            only = set(v for v in args.only.split(",") if v)
             hard_steps = max(20, min(args.steps, 100))
-            extra["hard"] = run_single_workload(ctx, dev, args, "hard", 0.0, 0, hard_steps, min(args.warmup, 10),
-                                                min(args.settle, 50), args.cpu_seconds * 0.5, traffic_file="r04_pmc_k_scan_hard.json",
-                                                manifold=args.hard_latent)
-            extra["configs0"] = run_configs0(ctx, dev, args)
+            if not only or "hard" in only:
+                extra["hard"] = run_single_workload(ctx, dev, args, "hard", 0.0, 0, hard_steps, min(args.warmup, 10),
+                                                    min(args.settle, 50), args.cpu_seconds * 0.5, traffic_file="r04_pmc_k_scan_hard.json",
+                                                    manifold=args.hard_latent)
+            if not only or "configs0" in only:
+                extra["configs0"] = run_configs0(ctx, dev, args)
+            if (not only or "configs2" in only) and cfg_no == 1:
+                # BASELINE.json configs[2]: 10M x 768 unit-norm IP, nlist 4096, batch 1024, k = 100 -- its own value, roofline (with
+                # the in-run FETCH_SIZE pass), cpu_baseline and in-run parity
+                a2 = argparse.Namespace(**vars(args))
+                a2.dim, a2.metric, a2.k, a2.inflight = 768, "ip", 100, 1
+                extra["configs2"] = run_single_workload(ctx, dev, a2, "configs2", args.sigma, 0, hard_steps, min(args.warmup, 10),
+                                                        min(args.settle, 50), args.cpu_seconds * 0.5)
+                extra["configs2"]["config"]["workload"] += " (BASELINE.json configs[2])"
+            if (not only or "configs3_rank_step" in only) and cfg_no == 1:
+                extra["configs3_rank_step"] = run_rank_step(ctx, dev, args, int(main_res["config"]["nprobe"]))
             if main_res.get("nprobe_sweep"):
                 # the headline index at fixed nprobe 8 / 16 / 32: the regime where a probed list is shared by many queries of the
                 # batch (the mixed work sequence of the row-per-lane scan), each line with its own roofline
@@ -942,6 +1251,26 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def main_single_process(args):
+    world = max(1, args.gpus)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    from quake_amd.capi import Context
+    ctx = Context(0)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    log("device", ctx.device_info(), "| GPUs visible:", torch.cuda.device_count())
+    t_all = time.time()
+    r = run_group(ctx, dev, args, world)
+    result = {
+        "metric": METRIC_NAME, "value": r["value"], "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": r["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic", "config": r["config"], "roofline": r["roofline"], "phases_ms": r["phases_ms"], "build": r["build"],
+        "timed_groups": r["timed_groups"], "launch": "single process, device group (qk_group_*)",
+    }
+    log(f"total bench wall {time.time() - t_all:.1f}s")
+    print(json.dumps(result), flush=True)
 
 
 if __name__ == "__main__":
