@@ -142,10 +142,13 @@ int qk_run_search(qk_ctx *ctx, qk_store *parent, qk_store *s, const float *x, in
     }
     const float4 *xq4 = nullptr;
     const float *xn = nullptr;
-    QK_TRY(qk_prep_queries(ctx, sv.x, Q, d, &xq4, &xn, coarse_only ? 0 : qk_scan_zero_bytes((int64_t)s->parts.size(), Q)));
+    // (the launch is left pending when a nearest-centroid search follows: k_dense_argmin prepares the queries while it stages them;
+    //  every other consumer launches the prep kernel first -- qk_prep_flush)
+    QK_TRY(qk_prep_queries(ctx, sv.x, Q, d, &xq4, &xn, coarse_only ? 0 : qk_scan_zero_bytes((int64_t)s->parts.size(), Q),
+                           use_parent && kk == 1));
     const unsigned long long *packed = nullptr;
     // ---- coarse --------------------------------------------------------------------------------------
-    if (use_parent && kk <= 0 && coarse_only) return QK_OK;
+    if (use_parent && kk <= 0 && coarse_only) return qk_prep_flush(ctx);
     if (use_parent && kk > 0) {
         qk_scan_args ca;
         ca.x = sv.x;

@@ -28,8 +28,12 @@ namespace {
 constexpr int APS_NX = 1001;      // geometry.h:7  NUM_X_VALUES
 constexpr double APS_STOP = 1.0e-8;   // geometry.h:9
 constexpr double APS_TINY = 1.0e-30;  // geometry.h:10
-constexpr int APS_CH = 32;        // partitions per query and round (upper bound)
-constexpr int APS_FIRST = 2;      // partitions of the first round
+// The schedule of the rounds does not change any result (partitions scanned past the stopping point are discarded); it decides how
+// many launches a batch takes.  Measured on the bench mixture (10M x 128, 4096 lists, 81 candidates, target 0.9 / 0.99: the walk
+// visits 48 / 53 lists): first round 2 / cap 32 -> 4 rounds, 3.27 / 3.41 ms; 4 / 48 -> 3 rounds, 3.14 / 3.17; 4 / 80 -> 2 rounds,
+// 2.85 / 3.02; a longer first round loses (8 / 64: 3.29, 16 / 64: 4.20 -- its lists are scanned without a bound).
+constexpr int APS_CH = 80;        // partitions per query and round (upper bound)
+constexpr int APS_FIRST = 4;      // partitions of the first round
 
 // ---- regularised incomplete beta I_x(a, b): Lentz's continued fraction, the published algorithm geometry.h uses.
 // One definition serves the host (table of the precomputed path) and the device (IP metric / use_precomputed = false).
@@ -192,11 +196,29 @@ struct UpdateParams {
     int32_t *run_cnt, *have_probs, *next_p, *want, *nscan;
     uint32_t *run_tau;        // [Q] ~(k-th key of the running result), 0 while it holds fewer than k: next round's bound
     float *radius;
-    int32_t *n_active;
+    int32_t *n_active;        // [0] queries that go on after this round, [1] workgroups that have finished this round (ticket)
+    int32_t *host_flag;       // host-mapped: the last workgroup of the round leaves n_active + 1 here (0 = round still running)
     int64_t *out_ids;         // [Q][k]
     float *out_dist;          // [Q][k]
     int sqrt_l2;
 };
+
+// End of a query's round.  The host decides on the next round from ONE number -- how many queries go on -- and reads it from
+// host-mapped memory without synchronising the stream: every workgroup takes a ticket, the last one of the round publishes the count
+// (+ 1: 0 means "round still running") with a system-scope store and leaves both counters at zero for the next round.
+__device__ __forceinline__ void aps_round_done(const UpdateParams &U, int lane, bool goes_on) {
+    if (lane != 0) return;
+    if (goes_on) atomicAdd(&U.n_active[0], 1);
+    __threadfence();
+    const int t = atomicAdd(&U.n_active[1], 1);
+    if (t == (int)U.Q - 1) {
+        const int left = __hip_atomic_load(&U.n_active[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        U.n_active[0] = 0;
+        U.n_active[1] = 0;
+        __threadfence();
+        __hip_atomic_store(U.host_flag, left + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
 
 template <int MAXCH>
 __global__ __launch_bounds__(64) void k_aps_update(UpdateParams U) {
@@ -205,7 +227,10 @@ __global__ __launch_bounds__(64) void k_aps_update(UpdateParams U) {
     const int64_t q = blockIdx.x;
     const int k = U.k, M = U.M;
     const int w = U.want[q];
-    if (w <= 0) return;  // stopped in an earlier round
+    if (w <= 0) {  // stopped in an earlier round
+        aps_round_done(U, lane, false);
+        return;
+    }
     int64_t *pool_id = (int64_t *)smem;                                  // [2k]
     uint32_t *pool_ord = (uint32_t *)(smem + (size_t)2 * k * 8);         // [2k]
     float *probs = (float *)(smem + (size_t)2 * k * 12);                 // [M]
@@ -319,6 +344,7 @@ __global__ __launch_bounds__(64) void k_aps_update(UpdateParams U) {
             U.want[q] = 0;
             U.nscan[q] = nscan;
         }
+        aps_round_done(U, lane, false);
         return;
     }
     // carry the state into the next round
@@ -350,8 +376,8 @@ __global__ __launch_bounds__(64) void k_aps_update(UpdateParams U) {
         U.radius[q] = qr;
         U.next_p[q] = np;
         U.want[q] = wn;
-        atomicAdd(U.n_active, 1);
     }
+    aps_round_done(U, lane, true);
 }
 
 __global__ void k_aps_init(int64_t Q, int M, int first, int metric, int32_t *run_cnt, int32_t *have_probs, int32_t *next_p, int32_t *want,
@@ -523,12 +549,26 @@ extern "C" int qk_search_aps(qk_ctx *ctx, qk_store *parent, qk_store *s, const f
     up.radius = radius;
     up.run_tau = run_tau;
     up.n_active = n_active;
+    // one host-mapped word per round (rounds <= M + 2 <= QK_MAX_NPROBE + 2)
+    if (!ctx->aps_flags) {
+        QK_HIP(hipHostMalloc((void **)&ctx->aps_flags, (size_t)(QK_MAX_NPROBE + 8) * 4, hipHostMallocMapped));
+        QK_HIP(hipHostGetDevicePointer((void **)&ctx->aps_flags_dev, ctx->aps_flags, 0));
+    }
+    QK_HIP(hipMemsetAsync(n_active, 0, 8, st));
     up.out_ids = d_out_ids;
     up.out_dist = d_out_dist;
     up.sqrt_l2 = ctx->squared_l2 ? 0 : 1;
     const size_t lds_up = (size_t)2 * k * 12 + (size_t)M * 4 + 64;
     const int maxch_u = 2 * k <= 64 ? 1 : 2 * k <= 128 ? 2 : 2 * k <= 256 ? 4 : 2 * k <= 512 ? 8 : 16;
-    QK_TRY(qk_pinned_reserve(ctx, 64));
+    {  // (once per call, not per round)
+        switch (maxch_u) {
+            case 1: QK_HIP(hipFuncSetAttribute((const void *)k_aps_update<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_up)); break;
+            case 2: QK_HIP(hipFuncSetAttribute((const void *)k_aps_update<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_up)); break;
+            case 4: QK_HIP(hipFuncSetAttribute((const void *)k_aps_update<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_up)); break;
+            case 8: QK_HIP(hipFuncSetAttribute((const void *)k_aps_update<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_up)); break;
+            default: QK_HIP(hipFuncSetAttribute((const void *)k_aps_update<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_up)); break;
+        }
+    }
     int rounds = 0;
     int64_t pairs_scanned = 0;
     for (;;) {
@@ -549,12 +589,10 @@ extern "C" int qk_search_aps(qk_ctx *ctx, qk_store *parent, qk_store *s, const f
         sa.tau_init = run_tau;
         sa.sqrt_l2 = false;  // merge keys: squared distances
         QK_TRY(qk_scan_device(ctx, s, sa, nullptr, 4));
-        QK_HIP(hipMemsetAsync(n_active, 0, 4, st));
-#define QK_UP(MC)                                                                                         \
-    {                                                                                                     \
-        QK_HIP(hipFuncSetAttribute((const void *)k_aps_update<MC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_up)); \
-        hipLaunchKernelGGL((k_aps_update<MC>), dim3((unsigned)Q), dim3(64), lds_up, st, up);                \
-    }
+        volatile int32_t *flag = ctx->aps_flags + rounds;
+        *flag = 0;
+        up.host_flag = ctx->aps_flags_dev + rounds;
+#define QK_UP(MC) hipLaunchKernelGGL((k_aps_update<MC>), dim3((unsigned)Q), dim3(64), lds_up, st, up);
         switch (maxch_u) {
             case 1: QK_UP(1) break;
             case 2: QK_UP(2) break;
@@ -564,10 +602,22 @@ extern "C" int qk_search_aps(qk_ctx *ctx, qk_store *parent, qk_store *s, const f
         }
 #undef QK_UP
         QK_HIP(hipGetLastError());
-        QK_HIP(hipMemcpyAsync(ctx->pinned, n_active, 4, hipMemcpyDeviceToHost, st));
-        QK_HIP(hipStreamSynchronize(st));
+        // the round's verdict arrives through host-mapped memory: the stream is not synchronised, the next round is enqueued the
+        // moment the count is visible (a device that has stopped answering shows up as an error of the query below)
+        int32_t got = 0;
+        for (long long spin = 0; (got = *flag) == 0; spin++) {
+            if ((spin & 0xFFFF) == 0xFFFF) {
+                const hipError_t e = hipStreamQuery(st);
+                if (e == hipSuccess) {  // everything enqueued has run: the flag is final
+                    got = *flag;
+                    if (got == 0) QK_FAIL(QK_ERR_HIP, "qk_search_aps: a round finished without reporting");
+                    break;
+                }
+                if (e != hipErrorNotReady) QK_FAIL(QK_ERR_HIP, "qk_search_aps: %s", hipGetErrorString(e));
+            }
+        }
         rounds++;
-        const int32_t left = *(const int32_t *)ctx->pinned;
+        const int32_t left = got - 1;
         if (left <= 0) break;
         if (rounds > M + 2) QK_FAIL(QK_ERR_HIP, "qk_search_aps: rounds did not terminate");
     }

@@ -57,6 +57,7 @@ int qk_ctx_destroy(qk_ctx *c) {
     if (c->small_ws) hipFree(c->small_ws);
     if (c->pinned) hipHostFree(c->pinned);
     if (c->overflow_host) hipHostFree(c->overflow_host);
+    if (c->aps_flags) hipHostFree(c->aps_flags);
     if (c->xcd_host) hipHostFree(c->xcd_host);
     if (c->xcd_ev) hipEventDestroy(c->xcd_ev);
     for (auto &f : c->form_stats) {

@@ -610,9 +610,19 @@ struct ArgminParams {
     int metric;
     int tiles_per_wg;
     unsigned long long *best64;  // [Q], preset to ~0
+    // FUSE: the query preparation of the batch (k_prep_queries, qk_scan.hip) done here, while the queries are staged
+    const float *x;              // [Q][d] raw queries, 16-byte aligned, d % 4 == 0
+    int d;
+    float4 *xq4_out;             // fragment-ordered copy, written by the workgroups of row chunk 0
+    float *xn_out;               // canonical squared norms, likewise
+    float4 *xp4_out;             // row-major copy padded to 16 columns, likewise
+    uint4 *zero16;               // region the scan of this batch wants cleared (everybody clears a share)
+    int64_t n_zero16;
+    unsigned long long *best64_next;  // the NEXT batch's "nothing yet" array (never this one: it is being written)
+    int64_t n_next;
 };
 
-template <int DB, int NQ, bool L2>
+template <int DB, int NQ, bool L2, bool FUSE = false>
 __global__ __launch_bounds__(256) void k_dense_argmin(ArgminParams P) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -624,6 +634,69 @@ __global__ __launch_bounds__(256) void k_dense_argmin(ArgminParams P) {
     unsigned long long *red = (unsigned long long *)(xn_s + NQ * 16);  // [4][NQ*16]
     const int64_t q_base = (int64_t)blockIdx.x * (NQ * 16);
 
+    if (FUSE) {
+        // ---- the batch's query preparation, folded into the staging ------------------------------------------------------
+        const int64_t wg = (int64_t)blockIdx.y * gridDim.x + blockIdx.x, nwg = (int64_t)gridDim.x * gridDim.y;
+        for (int64_t i = wg * 256 + tid; i < P.n_zero16; i += nwg * 256) P.zero16[i] = make_uint4(0u, 0u, 0u, 0u);
+        for (int64_t i = wg * 256 + tid; i < P.n_next; i += nwg * 256) P.best64_next[i] = ~0ull;
+        const bool writer = blockIdx.y == 0;  // one workgroup per query block leaves the prepared copies behind
+        const int d4 = P.d >> 2, p4 = nblk * 4;  // float4 per raw row / per padded row
+        float *qf = (float *)qs;
+        // the NQ*16 rows of this block are contiguous in x: coalesced float4 loads, every component to its fragment slot
+        // (row r of query tile nq, column c = 16 cb + 4 t' + g'  ->  float ((nq*nblk + cb)*64 + g'*16 + r)*4 + t', see qk_internal.h)
+        constexpr int U = 8;  // loads in flight per thread (d = 128, NQ = 4: the whole block in one round trip)
+        const int total4 = NQ * 16 * p4;
+        for (int i0 = 0; i0 < total4; i0 += 256 * U) {
+            float4 v[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int i = i0 + u * 256 + tid;
+                const int r_all = i / p4, c4 = i - r_all * p4;
+                const int64_t row = q_base + r_all;
+                v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (i < total4 && row < P.Q && c4 < d4) v[u] = ((const float4 *)P.x)[row * d4 + c4];
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int i = i0 + u * 256 + tid;
+                if (i < total4) {
+                    const int r_all = i / p4, c4 = i - r_all * p4;
+                    const int64_t row = q_base + r_all;
+                    if (writer && row < P.Q) P.xp4_out[row * p4 + c4] = v[u];
+                    const int nq = r_all >> 4, r = r_all & 15, cb = c4 >> 2, tt = c4 & 3;
+                    float *dst = qf + ((size_t)(nq * nblk + cb) * 64 + r) * 4 + tt;  // g' = 0; + 64 floats per g'
+                    dst[0] = v[u].x;
+                    dst[64] = v[u].y;
+                    dst[128] = v[u].z;
+                    dst[192] = v[u].w;
+                }
+            }
+        }
+        __syncthreads();
+        if (tid < NQ * 16) {  // canonical squared norm: one k-ordered fmaf chain per query (k_prep_queries' arithmetic; the padded
+                              // columns hold 0: fma(0, 0, acc) == acc)
+            const int nq = tid >> 4, r = tid & 15;
+            const float *base = qf + ((size_t)nq * nblk * 64 + r) * 4;
+            float acc = 0.0f;
+            for (int cb = 0; cb < nblk; cb++) {
+                float e[16];
+#pragma unroll
+                for (int w = 0; w < 16; w++) e[w] = base[(size_t)cb * 256 + (w & 3) * 64 + (w >> 2)];
+#pragma unroll
+                for (int w = 0; w < 16; w++) acc = __fmaf_rn(e[w], e[w], acc);
+            }
+            const int64_t row = q_base + tid;
+            xn_s[tid] = (row < P.Q && l2) ? acc : 0.0f;
+            if (writer && row < P.Q) P.xn_out[row] = acc;
+        }
+        if (writer) {
+            for (int t = wave; t < NQ * nblk; t += 4) {
+                const int nq = t / nblk, cb = t - nq * nblk;
+                const int64_t row = q_base + nq * 16 + j;
+                if (row < P.Q) P.xq4_out[(row * nblk + cb) * 4 + g] = qs[(size_t)nq * nblk * 64 + cb * 64 + lane];
+            }
+        }
+    } else {
     for (int t = wave; t < NQ * nblk; t += 4) {
         const int nq = t / nblk, cb = t - nq * nblk;
         const int64_t row = q_base + nq * 16 + j;
@@ -634,6 +707,7 @@ __global__ __launch_bounds__(256) void k_dense_argmin(ArgminParams P) {
     if (tid < NQ * 16) {
         const int64_t row = q_base + tid;
         xn_s[tid] = (row < P.Q && l2) ? P.xn[row] : 0.0f;
+    }
     }
     __syncthreads();
     // running minimum per (lane, query) of key << 32 | id -- the (key, id) order as ONE integer order (ids < 2^32 here), so
@@ -776,6 +850,11 @@ __global__ void k_argmin_finish(const unsigned long long *best64, int64_t Q, int
 
 template <int DB, int NQ, bool L2>
 static int launch_argmin_m(hipStream_t st, dim3 grid, size_t lds, const ArgminParams &ap) {
+    if (ap.x) {  // the batch's query preparation rides along
+        QK_HIP(hipFuncSetAttribute((const void *)k_dense_argmin<DB, NQ, L2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((k_dense_argmin<DB, NQ, L2, true>), grid, dim3(256), lds, st, ap);
+        return QK_OK;
+    }
     QK_HIP(hipFuncSetAttribute((const void *)k_dense_argmin<DB, NQ, L2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL((k_dense_argmin<DB, NQ, L2>), grid, dim3(256), lds, st, ap);
     return QK_OK;
@@ -832,13 +911,22 @@ int qk_dense_device(qk_ctx *ctx, qk_store *s, int64_t list_no, const qk_scan_arg
     // (from 32768 rows on the prefiltered form below is the faster nearest-centroid search too -- 1024 queries: 32768 rows 84 -> 71 us,
     //  65536 rows 154 -> 96 us; at 16384 rows 50 against 54 us the fused fp32 argmin stays)
     const bool pf_k1 = k == 1 && nrows >= 32768 && Q <= 16384 && a.x && a.out_ids && !qk_env_set("QK_NO_DENSE_PF") && qk_dense_pf_supported(ctx, s, Q, nrows, 1);
-    if (k == 1 && !pf_k1 && nrows > 0 && s->max_id_seen < ((int64_t)1 << 32) && s->min_id_seen >= 0 && !qk_env_set("QK_NO_ARGMIN")) {
+    const bool to_argmin = k == 1 && !pf_k1 && nrows > 0 && s->max_id_seen < ((int64_t)1 << 32) && s->min_id_seen >= 0 && !qk_env_set("QK_NO_ARGMIN");
+    const bool argmin_apf = to_argmin && a.x && ((uintptr_t)a.x & 15) == 0 && qk_assign_pf_supported(Q, nrows, s->d, a.metric) &&
+                            !qk_env_set("QK_NO_DENSE_APF");
+    // a query preparation left pending by the caller (qk_prep_queries(.., defer)) is folded into the fp32 nearest-centroid kernel;
+    // every other form below wants the prepared queries in place
+    const bool fuse_prep = ctx->prep_pending && to_argmin && !argmin_apf && a.x == ctx->prep_x && Q == ctx->prep_Q &&
+                           ((uintptr_t)a.x & 15) == 0 && s->d % 4 == 0 && a.xq4 == (const float4 *)ctx->qprep &&
+                           !qk_env_set("QK_NO_FUSED_PREP");
+    if (!fuse_prep) QK_TRY(qk_prep_flush(ctx));
+    if (to_argmin) {
         // nprobe = 1 / nearest centroid: fused argmin, no key matrix
         const size_t lds_a = lds + (size_t)4 * NQ * 16 * 8;
         // many rows (PartitionManager::add's parent search, a nearest-list search of a huge batch): the k-means assign's bf16
         // prefilter (qk_assign_pf.hip) with the list's ids as the tie order -- the same packed words, ~4x the rate
         const float *rm = nullptr;
-        bool apf = a.x && ((uintptr_t)a.x & 15) == 0 && qk_assign_pf_supported(Q, nrows, s->d, a.metric) && !qk_env_set("QK_NO_DENSE_APF");
+        bool apf = argmin_apf;
         if (apf) QK_TRY(qk_store_rowmajor(s, pt.row_off, nrows, &rm));
         if (!rm) apf = false;  // (a list beyond the row-major cap, a table not yet synchronised)
         const size_t apf_bytes = apf ? qk_assign_pf_scratch_bytes(nrows, s->d) : 0;
@@ -846,11 +934,16 @@ int qk_dense_device(qk_ctx *ctx, qk_store *s, int64_t list_no, const qk_scan_arg
         unsigned long long *best64 = (unsigned long long *)qk_ws_alloc(ctx, (size_t)Q * 8);
         void *apf_scratch = apf ? qk_ws_alloc(ctx, apf_bytes) : nullptr;
         if (!best64 || (apf && !apf_scratch)) QK_FAIL(QK_ERR_OOM, "dense argmin: workspace exhausted");
-        // the prep kernel of this batch left a ready-made "nothing yet" array (first use only)
-        const bool preinit = ctx->qprep_best64 && ctx->qprep_best64_n == Q;
+        // the prep kernel of this batch (or the fused kernel of the previous one) left a ready-made "nothing yet" array (first use only)
+        bool preinit = ctx->qprep_best64 && ctx->qprep_best64_n == Q;
+        if (fuse_prep && !preinit) {  // this batch's array is not known to be clean (first batch of a shape): clear it here
+            QK_HIP(hipMemsetAsync(ctx->qprep_best64, 0xFF, (size_t)Q * 8, st));
+            preinit = true;
+        }
         if (preinit) {
             best64 = ctx->qprep_best64;
             ctx->qprep_best64_n = 0;
+            ctx->best64_clean[ctx->best64_cur] = 0;
         }
         const int num_cus_a = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
         QK_TRY(pe.mark(0));
@@ -873,6 +966,20 @@ int qk_dense_device(qk_ctx *ctx, qk_store *s, int64_t list_no, const qk_scan_arg
         ap.Q = Q;
         ap.metric = a.metric;
         ap.best64 = best64;
+        ap.x = nullptr;
+        if (fuse_prep) {
+            ap.x = a.x;
+            ap.d = s->d;
+            ap.xq4_out = (float4 *)a.xq4;
+            ap.xn_out = (float *)a.xn;
+            ap.xp4_out = (float4 *)ctx->qprep_xp4;
+            ap.zero16 = (uint4 *)ctx->qprep_zero;
+            ap.n_zero16 = ctx->qprep_zero ? ctx->prep_zero16 : 0;
+            ap.best64_next = ctx->best64_buf[ctx->best64_cur ^ 1];
+            ap.n_next = Q;
+            ctx->prep_pending = false;
+            ctx->best64_clean[ctx->best64_cur ^ 1] = Q;
+        }
         const int64_t qgroups = (Q + NQ * 16 - 1) / (NQ * 16);
         const int ntile = (nrows + 15) / 16;
         // two workgroups per CU, at least 8 row tiles each (the query tile staging costs about as much as 8 tiles)

@@ -87,6 +87,21 @@ struct qk_ctx {
     size_t qprep_cap = 0;
     unsigned long long *qprep_best64 = nullptr;  // [Q] set to ~0 by the prep kernel; valid while qprep_best64_n == Q
     int64_t qprep_best64_n = 0;
+    // The "nothing yet" array of the nearest-centroid kernel exists twice and batches take them in turn: the kernel that folds the
+    // query preparation into its own staging (k_dense_argmin<.., FUSE>) cannot clear the array it is about to atomicMin into, so it
+    // clears the OTHER one -- the next batch's -- whose last readers (the grouping of the previous batch) are behind it in the stream.
+    unsigned long long *best64_buf[2] = {nullptr, nullptr};
+    int64_t best64_clean[2] = {0, 0};  // leading entries known to hold ~0 at this point of the stream
+    int best64_cur = 0;
+    int64_t qprep_layout_Q = -1;
+    int qprep_layout_d = -1;
+    const char *qprep_layout_base = nullptr;
+    // query preparation left to the consumer (qk_prep_queries(.., defer)): launched by qk_prep_flush, or folded into the
+    // nearest-centroid kernel
+    bool prep_pending = false;
+    const float *prep_x = nullptr;
+    int64_t prep_Q = 0, prep_zero16 = 0;
+    int prep_d = 0;
     const char *last_scan_kernel = "";  // form of the last scan launch (qk_ctx_last_scan_kernel)
     // Which form of the partition scan serves a batch shape best is measured, not only modelled (qk_scan.hip, "form feedback"):
     // per (store, Q / 64, nprobe, k, metric) the context keeps the mean device time of a whole scan call -- grouping, scan
@@ -122,6 +137,8 @@ struct qk_ctx {
     // state of an adaptive (recall-target) search: survives the scan calls of its rounds, which recycle `ws`
     char *aps = nullptr;
     size_t aps_cap = 0;
+    int32_t *aps_flags = nullptr;      // host-mapped: one word per round, written by the round's last workgroup (qk_aps.hip)
+    int32_t *aps_flags_dev = nullptr;
     // XCD balance of the partition scan (qk_scan.hip): relative speed of the 8 workgroup classes blockIdx % 8 per store,
     // learned from the wave times of sampled launches (the physical placement of an arena makes some XCDs stream it up to
     // 25 % slower than others); one sample in flight at a time
@@ -249,7 +266,9 @@ struct qk_scan_args {
 };
 // x[Q][d] -> ctx->qprep (xq4 then xn); returns the two device pointers
 // zero_bytes > 0: the kernel also clears that many bytes for the scan of this batch (qk_scan_zero_bytes)
-int qk_prep_queries(qk_ctx *ctx, const float *x, int64_t Q, int d, const float4 **xq4, const float **xn, size_t zero_bytes = 0);
+int qk_prep_queries(qk_ctx *ctx, const float *x, int64_t Q, int d, const float4 **xq4, const float **xn, size_t zero_bytes = 0,
+                    bool defer = false);
+int qk_prep_flush(qk_ctx *ctx, bool force = false);
 size_t qk_scan_zero_bytes(int64_t npids, int64_t Q);
 // fails (once) if a scan launched earlier on this context dropped records; called at API entry and after synchronising calls
 int qk_check_overflow(qk_ctx *ctx);

@@ -90,11 +90,17 @@ __global__ __launch_bounds__(256) void k_prep_queries(const float *__restrict__ 
 
 size_t qk_scan_zero_bytes(int64_t npids, int64_t Q) { return (size_t)npids * 4 * 2 + 256 + (size_t)Q * 4; }
 
-int qk_prep_queries(qk_ctx *ctx, const float *x, int64_t Q, int d, const float4 **xq4, const float **xn, size_t zero_bytes) {
+// Lays the batch's prep buffer out (fragment-ordered copy | norms | two "nothing yet" arrays of the nearest-centroid kernel, used
+// in turn | row-major padded copy | region cleared for the scan) and either launches k_prep_queries or -- defer -- leaves the launch
+// PENDING (ctx->prep_pending): the nearest-centroid kernel of the same batch then does the preparation itself while it stages its
+// queries (k_dense_argmin<.., FUSE>, qk_dense.hip: one launch and one kernel boundary less in front of a search), and every other
+// consumer of the prepared queries calls qk_prep_flush first.
+int qk_prep_queries(qk_ctx *ctx, const float *x, int64_t Q, int d, const float4 **xq4, const float **xn, size_t zero_bytes, bool defer) {
     const int dpad = qk_round_up(d, 16), nblk = dpad / 16;
     const size_t off_n = ((size_t)Q * dpad * 4 + 255) & ~(size_t)255;
     const size_t off_b = (off_n + (size_t)Q * 4 + 255) & ~(size_t)255;
-    const size_t off_p = (off_b + (size_t)Q * 8 + 255) & ~(size_t)255;
+    const size_t off_b1 = (off_b + (size_t)Q * 8 + 255) & ~(size_t)255;
+    const size_t off_p = (off_b1 + (size_t)Q * 8 + 255) & ~(size_t)255;
     const size_t off_z = (off_p + (size_t)Q * dpad * 4 + 255) & ~(size_t)255;
     const size_t zero_pad = (zero_bytes + 15) & ~(size_t)15;
     size_t need = off_z + zero_pad + 256;
@@ -106,13 +112,45 @@ int qk_prep_queries(qk_ctx *ctx, const float *x, int64_t Q, int d, const float4 
         if (hipMalloc((void **)&ctx->qprep, need + need / 4) != hipSuccess) QK_FAIL(QK_ERR_OOM, "query prep buffer allocation failed");
         ctx->qprep_cap = need + need / 4;
     }
+    // the two "nothing yet" arrays sit where THIS batch size puts them: entries known to hold ~0 survive only an unchanged layout
+    if (ctx->qprep_layout_Q != Q || ctx->qprep_layout_d != d || ctx->qprep_layout_base != ctx->qprep) {
+        ctx->best64_clean[0] = ctx->best64_clean[1] = 0;
+        ctx->qprep_layout_Q = Q;
+        ctx->qprep_layout_d = d;
+        ctx->qprep_layout_base = ctx->qprep;
+    }
+    ctx->best64_cur ^= 1;  // this batch's array; the other one was this array's predecessor
+    ctx->best64_buf[0] = (unsigned long long *)(ctx->qprep + off_b);
+    ctx->best64_buf[1] = (unsigned long long *)(ctx->qprep + off_b1);
     float4 *q4 = (float4 *)ctx->qprep;
     float *n = (float *)(ctx->qprep + off_n);
-    ctx->qprep_best64 = (unsigned long long *)(ctx->qprep + off_b);
-    ctx->qprep_best64_n = Q;  // initialised for Q queries; the first nearest-centroid launch consumes it
+    ctx->qprep_best64 = ctx->best64_buf[ctx->best64_cur];
     ctx->qprep_xp4 = (const float4 *)(ctx->qprep + off_p);
     ctx->qprep_zero = zero_bytes ? ctx->qprep + off_z : nullptr;
     ctx->qprep_zero_bytes = zero_bytes;  // the first qk_scan_device of this batch that needs exactly this much consumes it
+    ctx->prep_pending = false;
+    ctx->prep_x = x;
+    ctx->prep_Q = Q;
+    ctx->prep_d = d;
+    ctx->prep_zero16 = (int64_t)(zero_pad / 16);
+    *xq4 = q4;
+    *xn = n;
+    if (defer) {
+        ctx->prep_pending = true;
+        ctx->qprep_best64_n = ctx->best64_clean[ctx->best64_cur] >= Q ? Q : 0;  // (a fused launch clears what is not clean itself)
+        return QK_OK;
+    }
+    return qk_prep_flush(ctx, true);
+}
+
+// launches the plain prep kernel of the batch laid out last (force: whether or not it is pending)
+int qk_prep_flush(qk_ctx *ctx, bool force) {
+    if (!ctx->prep_pending && !force) return QK_OK;
+    ctx->prep_pending = false;
+    const int64_t Q = ctx->prep_Q;
+    const int d = ctx->prep_d;
+    const int dpad = qk_round_up(d, 16), nblk = dpad / 16;
+    const size_t off_n = ((size_t)Q * dpad * 4 + 255) & ~(size_t)255;
     // queries per workgroup: 16, fewer when that would leave most of the chip idle (1024 x 768: 64 workgroups took 16 us)
     int qpw = 16;
     while (qpw > 2 && (Q + qpw - 1) / qpw < 2 * (int64_t)std::max(1, ctx->prop.multiProcessorCount) && (int64_t)qpw * d > 1024) qpw >>= 1;
@@ -120,11 +158,12 @@ int qk_prep_queries(qk_ctx *ctx, const float *x, int64_t Q, int d, const float4 
     if (lds > 160 * 1024) QK_FAIL(QK_ERR_UNSUPPORTED, "d=%d too large for the query prep kernel", d);
     if (lds > 48 * 1024)
         QK_HIP(hipFuncSetAttribute((const void *)k_prep_queries, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_prep_queries, dim3((unsigned)((Q + qpw - 1) / qpw)), dim3(256), lds, ctx->stream, x, Q, d, nblk, q4, n,
-                       ctx->qprep_best64, qpw, (float4 *)(ctx->qprep + off_p), (uint4 *)(ctx->qprep + off_z), (int64_t)(zero_pad / 16));
+    hipLaunchKernelGGL(k_prep_queries, dim3((unsigned)((Q + qpw - 1) / qpw)), dim3(256), lds, ctx->stream, ctx->prep_x, Q, d, nblk,
+                       (float4 *)ctx->qprep, (float *)(ctx->qprep + off_n), ctx->qprep_best64, qpw, (float4 *)ctx->qprep_xp4,
+                       (uint4 *)ctx->qprep_zero, ctx->qprep_zero ? ctx->prep_zero16 : (int64_t)0);
     QK_HIP(hipGetLastError());
-    *xq4 = q4;
-    *xn = n;
+    ctx->best64_clean[ctx->best64_cur] = Q;  // the kernel writes ~0 for every query of the batch
+    ctx->qprep_best64_n = Q;                 // initialised for Q queries; the first nearest-centroid launch consumes it
     return QK_OK;
 }
 
@@ -1257,6 +1296,7 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
     const bool one_list = a.all_lists && s->nlist == 1 && !emit;
     if (k > QK_MAX_K && !one_list) {
         if (a.per_pair) QK_FAIL(QK_ERR_UNSUPPORTED, "qk_scan: k=%d exceeds QK_MAX_K=%d", k, QK_MAX_K);
+        QK_TRY(qk_prep_flush(ctx));
         return qk_widek_device(ctx, s, a, timing, ev_base);
     }
     if (k > QK_MAX_NPROBE) QK_FAIL(QK_ERR_UNSUPPORTED, "qk_scan: k=%d exceeds %d", k, QK_MAX_NPROBE);
@@ -1269,6 +1309,7 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
         for (int64_t p = 0; p < npids; p++)
             if (s->parts[p].present) return qk_dense_device(ctx, s, p, a, timing, ev_base);
     }
+    QK_TRY(qk_prep_flush(ctx));  // (a query preparation left pending for the nearest-centroid kernel: nobody else folds it in)
     const int P = a.all_lists ? npids : a.P;
     // per-pair results: a bound learnt in one list must not prune another list's own top-k
     const bool share_tau = a.share_tau && !a.per_pair && !emit;
