@@ -145,6 +145,14 @@ QK_API int qk_store_list_ids(qk_store *s, int64_t *out_host, int64_t *n);
 QK_API int qk_store_get_list(qk_store *s, int64_t list_no, float *vecs_out, int64_t *ids_out, int mem);
 /* get_vector_for_id :280-293 (first match in ascending list order); *found = 0 if absent. */
 QK_API int qk_store_get_vector(qk_store *s, int64_t id, float *vec_out_host, int *found);
+/* What the store's mutations have cost so far beyond the rows they were asked to write (no reference counterpart: IndexPartition
+ * reallocs one partition at a time, index_partition.cpp:247-255): out[0] arena re-allocations (new arena, copy of everything, free),
+ * [1] arena compactions, [2] list relocations (a list outgrew its extent), [3] rows copied by [0]-[2], [4] rebuilds of the row-major
+ * copy of a parent's centroids, [5] uploads of the partition table, [6] rebuilds of the id -> list index (lazy: the first remove /
+ * get after a bulk build walks every id), [7] re-allocations of the scratch buffers of the store's CONTEXT (hipFree + hipMalloc
+ * behind a synchronisation).  A harness takes the difference around an operation
+ * to attribute a slow add / remove / maintenance step. */
+QK_API int qk_store_counters(qk_store *s, int64_t *out, int n);
 /* bytes of HBM held by the arena (vectors+norms+ids), for capacity planning */
 QK_API int64_t qk_store_device_bytes(qk_store *s);
 

@@ -67,6 +67,7 @@ SIGNATURES = {
     "qk_store_get_list": (_int, [_vp, _i64, _vp, _vp, _int]),
     "qk_store_get_vector": (_int, [_vp, _i64, _vp, C.POINTER(_int)]),
     "qk_store_device_bytes": (_i64, [_vp]),
+    "qk_store_counters": (_int, [_vp, _vp, _int]),
     "qk_coarse": (_int, [_vp, _vp, _vp, _i64, _int, _int, _vp, _vp, _int]),
     "qk_scan": (_int, [_vp, _vp, _vp, _i64, _vp, _int, _int, _int, _vp, _vp, _int, C.POINTER(QkTiming)]),
     "qk_search": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _int, _int, _vp, _vp, _int, C.POINTER(QkTiming)]),

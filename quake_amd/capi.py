@@ -420,6 +420,15 @@ class Store:
     def device_bytes(self):
         return self.lib.qk_store_device_bytes(self.h)
 
+    COUNTER_NAMES = ("arena_reallocations", "arena_compactions", "list_relocations", "rows_copied", "rowmajor_rebuilds",
+                     "table_uploads", "id_index_rebuilds", "context_scratch_reallocations")
+
+    def counters(self):
+        """what mutations cost beyond the rows they wrote (qk_store_counters), as a dict"""
+        out = np.zeros(8, np.int64)
+        check(self.lib.qk_store_counters(self.h, _ptr(out), 8))
+        return dict(zip(self.COUNTER_NAMES, (int(v) for v in out)))
+
 
 class Group:
     """Device group (qk_group_*): IndexBuildParams.num_workers as GPUs.  One process drives G members -- a context and a shard
@@ -566,6 +575,15 @@ class Group:
 
     def device_bytes(self):
         return self.lib.qk_group_device_bytes(self.h)
+
+    def counters(self):
+        """Store.counters() summed over the members"""
+        tot = np.zeros(8, np.int64)
+        for i in range(self.size()):
+            out = np.zeros(8, np.int64)
+            check(self.lib.qk_store_counters(self.member_handles(i)[1], _ptr(out), 8))
+            tot += out
+        return dict(zip(Store.COUNTER_NAMES, (int(v) for v in tot)))
 
     # ---- search over the members ------------------------------------------------------------------------------------------
     def search(self, parent, x, nprobe, k, metric, timing=False, out=None):

@@ -186,6 +186,7 @@ int qk_ws_reserve(qk_ctx *c, size_t bytes) {
     if (c->ws) QK_HIP(hipFree(c->ws));
     c->ws = nullptr;
     c->ws_cap = 0;
+    c->scratch_reallocs++;
     // powers of two from 64 MB: a few regrowths in the life of a context instead of one per slightly larger request
     size_t want = (size_t)64 << 20;
     while (want < bytes + (1u << 20)) want <<= 1;
@@ -211,6 +212,7 @@ int qk_aps_reserve(qk_ctx *c, size_t bytes) {
     if (c->aps) QK_HIP(hipFree(c->aps));
     c->aps = nullptr;
     c->aps_cap = 0;
+    c->scratch_reallocs++;
     size_t want = bytes + bytes / 4 + (1u << 16);
     hipError_t e = hipMalloc((void **)&c->aps, want);
     if (e != hipSuccess) {
@@ -227,6 +229,7 @@ int qk_pinned_reserve(qk_ctx *c, size_t bytes) {
     if (c->pinned) QK_HIP(hipHostFree(c->pinned));
     c->pinned = nullptr;
     c->pinned_cap = 0;
+    c->scratch_reallocs++;
     size_t want = bytes + bytes / 4 + 4096;
     QK_HIP(hipHostMalloc((void **)&c->pinned, want, hipHostMallocDefault));
     c->pinned_cap = want;
@@ -239,6 +242,7 @@ int qk_stage_reserve(qk_ctx *c, size_t bytes) {
     if (c->stage) QK_HIP(hipFree(c->stage));
     c->stage = nullptr;
     c->stage_cap = 0;
+    c->scratch_reallocs++;
     hipError_t e = hipMalloc((void **)&c->stage, bytes);
     if (e != hipSuccess) {
         qk_set_error("staging allocation of %zu bytes failed: %s", bytes, hipGetErrorString(e));

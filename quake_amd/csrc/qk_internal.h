@@ -137,6 +137,7 @@ struct qk_ctx {
     // state of an adaptive (recall-target) search: survives the scan calls of its rounds, which recycle `ws`
     char *aps = nullptr;
     size_t aps_cap = 0;
+    int64_t scratch_reallocs = 0;      // re-allocations of ws / stage / pinned / qprep / aps so far (qk_store_counters [7])
     int32_t *aps_flags = nullptr;      // host-mapped: one word per round, written by the round's last workgroup (qk_aps.hip)
     int32_t *aps_flags_dev = nullptr;
     // XCD balance of the partition scan (qk_scan.hip): relative speed of the 8 workgroup classes blockIdx % 8 per store,
@@ -194,6 +195,12 @@ struct qk_store {
     int32_t *d_size = nullptr;
     int64_t table_cap = 0;
     bool table_dirty = true;
+    // what mutations cost beyond the rows they were asked to write (qk_store_counters): a harness attributes a slow add / remove /
+    // maintenance step to these -- [0] arena re-allocations (grow: new arena + copy of everything + free), [1] compactions,
+    // [2] list relocations (a list outgrew its extent), [3] rows copied by [0]-[2], [4] row-major copy rebuilds, [5] table uploads,
+    // [6] rebuilds of the id -> list index (lazy: the first remove / get after a bulk build walks every id); [7] is the context's:
+    // re-allocations of its scratch buffers (workspace, staging, pinned, query prep: hipFree + hipMalloc behind a synchronisation)
+    int64_t counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     uint64_t version = 0;  // bumped by every table sync that found the store changed: replicas (qk_group.hip) compare it
     // row-major copy of ONE list's vectors ([rows][d] floats), built on demand for the exact finish of the coarse step without key
     // matrix (qk_dense_pf.hip: a candidate row of the tile-major arena is 32 pieces of 16 bytes in 32 cache lines); dropped whenever

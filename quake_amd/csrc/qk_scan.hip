@@ -109,6 +109,7 @@ int qk_prep_queries(qk_ctx *ctx, const float *x, int64_t Q, int d, const float4 
         if (ctx->qprep) QK_HIP(hipFree(ctx->qprep));
         ctx->qprep = nullptr;
         ctx->qprep_cap = 0;
+        ctx->scratch_reallocs++;
         if (hipMalloc((void **)&ctx->qprep, need + need / 4) != hipSuccess) QK_FAIL(QK_ERR_OOM, "query prep buffer allocation failed");
         ctx->qprep_cap = need + need / 4;
     }

@@ -164,6 +164,10 @@ int qk_store_reserve_rows(qk_store *s, int64_t rows) {
         if (ni) hipFree(ni);
         QK_FAIL(QK_ERR_OOM, "store arena allocation failed for %lld rows x %d dims", (long long)ncap, s->dpad);
     }
+    if (s->cap_rows > 0) {
+        s->counters[0]++;
+        s->counters[3] += s->used_rows;
+    }
     if (s->used_rows > 0) {
         QK_HIP(hipMemcpyAsync(nv, s->vecs, (size_t)s->used_rows * s->dpad * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
         QK_HIP(hipMemcpyAsync(nn, s->norms, (size_t)s->used_rows * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
@@ -188,6 +192,7 @@ int qk_store_reserve_rows(qk_store *s, int64_t rows) {
 int qk_store_sync_table(qk_store *s) {
     if (!s->table_dirty) return QK_OK;
     s->version++;
+    s->counters[5]++;
     s->rowmajor_valid = false;
     qk_ctx *c = s->ctx;
     int64_t n = (int64_t)s->parts.size();
@@ -229,6 +234,7 @@ int qk_store_sync_table(qk_store *s) {
 // id -> list number, built lazily from the id mirrors (the reference has no such index: find_id / remove_vectors scan)
 void qk_store_ensure_index(qk_store *s) {
     if (s->index_valid) return;
+    s->counters[6]++;
     s->id_to_list.clear();
     s->id_to_list.reserve((size_t)s->ntotal + 16);
     for (size_t pi = 0; pi < s->parts.size(); pi++) {
@@ -301,12 +307,14 @@ static int compact_arena(qk_store *s, int64_t extra_rows, int64_t last) {
     QK_HIP(hipMemsetAsync(nv, 0, (size_t)ncap * s->dpad * sizeof(float), c->stream));
     QK_HIP(hipMemsetAsync(nn, 0, (size_t)ncap * sizeof(float), c->stream));
     QK_HIP(hipMemsetAsync(ni, 0xFF, (size_t)ncap * sizeof(int64_t), c->stream));
+    s->counters[1]++;
     int64_t at = 0;
     std::vector<int64_t> new_off(order.size());
     for (size_t i = 0; i < order.size(); i++) {
         const qk_part &p = s->parts[(size_t)order[i]];
         new_off[i] = at;
         if (p.size > 0) mv.push_back({p.row_off, at, p.size});
+        s->counters[3] += p.size;
         at += p.cap;
     }
     if (!mv.empty()) {
@@ -353,6 +361,8 @@ static int ensure_part_capacity(qk_store *s, qk_part &p, int64_t extra) {
     int64_t nrow = s->used_rows;
     s->used_rows += ncap;
     if (p.size > 0) {
+        s->counters[2]++;
+        s->counters[3] += p.size;
         int64_t tiles = (p.size + 15) / 16;
         QK_HIP(hipMemcpyAsync(s->vecs + nrow * s->dpad, s->vecs + p.row_off * s->dpad, (size_t)tiles * 16 * s->dpad * sizeof(float),
                               hipMemcpyDeviceToDevice, c->stream));
@@ -422,6 +432,7 @@ extern "C++" int qk_store_rowmajor(qk_store *s, int64_t row_off, int nrows, cons
     }
     QK_TRY(qk_launch_extract(c, s->vecs, s->nblk, s->d, row_off, nullptr, nrows, s->rowmajor));
     QK_HIP(hipStreamSynchronize(c->stream));
+    s->counters[4]++;
     s->rowmajor_valid = true;
     s->rowmajor_row_off = row_off;
     s->rowmajor_rows = nrows;
@@ -879,6 +890,13 @@ int qk_store_add_batch(qk_store *s, int64_t n, const int64_t *ids, const float *
     IngestMap m{0, nullptr, nullptr, 0, 0, drows};
     QK_TRY(launch_ingest(c, dv, di, n, s->d, s->nblk, s->vecs, s->norms, s->ids, m));
     QK_HIP(hipStreamSynchronize(c->stream));
+    return QK_OK;
+}
+
+int qk_store_counters(qk_store *s, int64_t *out, int n) {
+    if (!s || !out || n <= 0) QK_FAIL(QK_ERR_INVALID, "qk_store_counters: bad arguments");
+    for (int i = 0; i < n; i++) out[i] = i < 8 ? s->counters[i] : 0;
+    if (n > 7) out[7] = s->ctx->scratch_reallocs;
     return QK_OK;
 }
 

@@ -292,6 +292,11 @@ class QuakeIndex:
         self._resident = _ResidentIds()   # PartitionManager::resident_ids_
         self._next_pid = 0       # PartitionManager::curr_partition_id_
         self._d = 0
+        # [Q, nprobe] list numbers of tracked searches not yet handed to the policy (device tensors): a search with hit tracking on
+        # does not synchronise the device or touch the host arrays of the tracker; the lists cross in ONE transfer before anything
+        # that changes a list's size or reads the policy (add / remove / refine / maintenance / a new policy) -- so every hit is
+        # credited with the size its list had when it was scanned, as if it had been recorded inside search
+        self._pending_hits = []
 
     # -- helpers -------------------------------------------------------------------------------------------------
     @property
@@ -459,7 +464,9 @@ class QuakeIndex:
                     ids, dist, tm = grp.scan(xd, pids, int(k), self.metric_, timing=True)
                 else:
                     ids, dist, tm = self._ctx.scan(self._store, xd, pids, int(k), self.metric_, timing=True)
-                self.record_query_hits(pids.cpu().numpy())
+                self._pending_hits.append(pids)
+                if len(self._pending_hits) >= 64:
+                    self._flush_hits()
             elif grp is not None:  # workers: every member scans the partitions it holds, the lead merges (worker_scan)
                 ids, dist, tm = grp.search(self.parent._store, xd, nprobe, int(k), self.metric_, timing=True)
             else:
@@ -502,6 +509,7 @@ class QuakeIndex:
     # -- add (partition_manager.cpp:123-262) ---------------------------------------------------------------------------------
     def add(self, x, ids):
         self._require_built("[QuakeIndex::add()] No partition manager. Build the index first.")
+        self._flush_hits()
         info = ModifyTimingInfo()
         t0 = time.perf_counter()
         if x.shape[0] != ids.shape[0]:
@@ -541,6 +549,7 @@ class QuakeIndex:
     # -- remove (partition_manager.cpp:264-320) -------------------------------------------------------------------------------
     def remove(self, ids):
         self._require_built("[QuakeIndex::remove()] No partition manager. Build the index first.")
+        self._flush_hits()
         info = ModifyTimingInfo()
         info.n_vectors = int(ids.shape[0])
         if ids.shape[0] == 0:
@@ -566,6 +575,7 @@ class QuakeIndex:
         GPU (assign = MFMA kernel, update = ordered sums), replace the partitions, write the centroids back to the parent
         with parent_->modify (:478)."""
         self._require_built("[PartitionManager] refine_partitions: index not built")
+        self._flush_hits()
         if self.parent is None:
             return
         if partition_ids is None:
@@ -580,15 +590,30 @@ class QuakeIndex:
     def initialize_maintenance_policy(self, maintenance_policy_params, cost_estimator=None):
         """quake_index.cpp:165-168.  The policy object (cost model included) is created lazily: profiling the device scan
         for the latency grid costs a few hundred launches, which a search-only user never needs."""
+        if self.maintenance_policy_ is not None:
+            self._flush_hits()  # hits recorded under the old policy reach it before it goes
+        self._pending_hits = []
         self.maintenance_policy_params_ = maintenance_policy_params
         self.maintenance_policy_ = None
         self._policy_cost_estimator = cost_estimator
 
     def _policy(self):
+        if self._pending_hits:  # whoever reads the policy sees every hit recorded so far
+            self._flush_hits()
         if self.maintenance_policy_ is None:
             from .maintenance import MaintenancePolicy
             self.maintenance_policy_ = MaintenancePolicy(self, self.maintenance_policy_params_, self._policy_cost_estimator)
         return self.maintenance_policy_
+
+    def _flush_hits(self):
+        pend, self._pending_hits = self._pending_hits, []
+        if not pend:
+            return
+        if len({tuple(p.shape[1:]) for p in pend}) == 1:
+            self.record_query_hits(torch.cat(pend, 0).cpu().numpy())  # one transfer, one pass over the window
+        else:
+            for p in pend:
+                self.record_query_hits(p.cpu().numpy())
 
     def record_query_hits(self, pids):
         """pids [Q, nprobe] (host): partitions every query scanned.  maintenance_policies.cpp:179-182."""
@@ -606,6 +631,7 @@ class QuakeIndex:
             raise RuntimeError("[QuakeIndex::maintenance()] No maintenance policy set.")
         if self.parent is None:
             return MaintenanceTimingInfo()
+        self._flush_hits()
         return self._policy().perform_maintenance()
 
     def _partition_sizes(self, pids):

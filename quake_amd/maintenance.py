@@ -399,14 +399,13 @@ class MaintenancePolicy:
     def reset(self):
         self.hit_count_tracker_.reset()
 
-    def perform_maintenance(self):
-        import torch
-        from .index import MaintenanceTimingInfo
-        info = MaintenanceTimingInfo()
+    def decide(self):
+        """STEPS 1-2 of perform_maintenance (maintenance_policies.cpp:43-137) without acting: (partitions to delete, partitions to
+        split) under the recorded window and the cost model -- ([], []) while the window is not full.  A second call right after
+        perform_maintenance() says what the policy still wants; an index at the policy's fixed point gets two empty lists."""
         idx, p, tr = self.index_, self.params_, self.hit_count_tracker_
         if tr.get_num_queries_recorded() < p.window_size:  # :36-41
-            return info
-        t_total = time.perf_counter()
+            return [], []
         hits = tr.aggregated_hits()
         all_pids = [int(v) for v in idx._list_ids()]
         total_partitions = idx.nlist()
@@ -440,6 +439,17 @@ class MaintenancePolicy:
             # (safety, not in the reference: a model that wants every partition gone would leave the vectors nowhere to
             #  go -- the largest partition survives)
             to_delete.remove(max(to_delete, key=lambda q_: sizes[q_]))
+        return to_delete, to_split
+
+    def perform_maintenance(self):
+        import torch
+        from .index import MaintenanceTimingInfo
+        info = MaintenanceTimingInfo()
+        idx, p, tr = self.index_, self.params_, self.hit_count_tracker_
+        if tr.get_num_queries_recorded() < p.window_size:  # :36-41
+            return info
+        t_total = time.perf_counter()
+        to_delete, to_split = self.decide()
         t0 = time.perf_counter()
         if to_delete:
             idx._delete_partitions(to_delete, reassign=True)
@@ -451,8 +461,10 @@ class MaintenancePolicy:
             idx._delete_partitions(to_split, reassign=False)
             new_pids = idx._add_partitions(split)
         info.split_time_us = int((time.perf_counter() - t0) * 1e6)
+        t0 = time.perf_counter()
         if new_pids:
             self.local_refinement(new_pids)
+        info.split_refine_time_us = int((time.perf_counter() - t0) * 1e6)
         info.n_splits = len(to_split)
         info.n_deletes = len(to_delete)
         info.total_time_us = int((time.perf_counter() - t_total) * 1e6)

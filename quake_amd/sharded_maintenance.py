@@ -629,6 +629,9 @@ class ShardedQuakeIndex:
 
     # -- maintenance -------------------------------------------------------------------------------------------------------------
     def initialize_maintenance_policy(self, params, cost_estimator=None):
+        # hits recorded under the OLD policy belong to it: they reach it before it is replaced (the reference records hits inside
+        # search, so a policy never sees queries answered before it existed)
+        self._flush_hits()
         self.partitions.initialize_maintenance_policy(params, cost_estimator)
 
     def maintenance(self):
@@ -636,6 +639,7 @@ class ShardedQuakeIndex:
         return self.partitions.maintenance()
 
     def refine_partitions(self, partition_ids=None, iterations=0):
+        self._flush_hits()  # (list sizes are about to change: pending hits are credited with the sizes they scanned)
         self.partitions.refine_partitions(partition_ids, iterations)
 
     def ntotal(self):
