@@ -261,6 +261,12 @@ QK_API int qk_group_scan(qk_group *g, const float *x, int64_t Q, const int64_t *
  * coarse_ms / scan_ms / merge_ms / total_ms between events on the lead, the counters summed over the members. */
 QK_API int qk_group_search(qk_group *g, qk_store *parent, const float *x, int64_t Q, int nprobe, int k, int metric,
                            int64_t *out_ids, float *out_dist, int mem, qk_timing *timing);
+/* qk_search_aps over the members (the APS hook of worker_scan, query_coordinator.cpp:364-428 -- whose outcome depends on thread
+ * timing upstream; here the deterministic walk): the rounds run on the lead, every member scans the pairs of a round whose lists it
+ * holds, the lead takes each pair's top-k from its owner.  Answers and partitions visited equal qk_search_aps on one store. */
+QK_API int qk_group_search_aps(qk_group *g, qk_store *parent, const float *x, int64_t Q, int k, int metric, float recall_target,
+                               float recompute_threshold, int use_precomputed, float initial_search_fraction, int64_t *out_ids,
+                               float *out_dist, int32_t *out_nscanned, int mem, qk_timing *timing);
 
 /* ---- k-means ----------------------------------------------------------------------------------- */
 /* Nearest-centroid assignment: IndexFlat::search(n, x, 1) (clustering.cpp:63-66) and the

@@ -114,6 +114,8 @@ SIGNATURES = {
     "qk_group_refine_lists": (_int, [_vp, _vp, _i64, _vp, _int, _int, _int]),
     "qk_group_scan": (_int, [_vp, _vp, _i64, _vp, _int, _int, _int, _vp, _vp, _int, C.POINTER(QkTiming)]),
     "qk_group_search": (_int, [_vp, _vp, _vp, _i64, _int, _int, _int, _vp, _vp, _int, C.POINTER(QkTiming)]),
+    "qk_group_search_aps": (_int, [_vp, _vp, _vp, _i64, _int, _int, C.c_float, C.c_float, _int, C.c_float, _vp, _vp, _vp, _int,
+                            C.POINTER(QkTiming)]),
 }
 
 _lib = None

@@ -600,6 +600,21 @@ class Group:
                                        _ptr(out_d), _mem_of(x), C.byref(t) if timing else None))
         return (out_i, out_d, timing_dict(t)) if timing else (out_i, out_d)
 
+    def search_aps(self, parent, x, k, metric, recall_target, recompute_threshold=0.001, use_precomputed=True,
+                   initial_search_fraction=0.02, timing=False):
+        """recall-target search over the members (qk_group_search_aps).  Returns (ids, dist, nscanned[, timing])."""
+        x = _f32(x)
+        Q = x.shape[0]
+        k = max(int(k), 1)
+        out_i = _empty_like_mem((Q, k), np.int64, x)
+        out_d = _empty_like_mem((Q, k), np.float32, x)
+        out_n = _empty_like_mem((Q,), np.int32, x)
+        t = QkTiming()
+        check(self.lib.qk_group_search_aps(self.h, parent.h, _ptr(x), Q, k, metric_code(metric), float(recall_target),
+                                           float(recompute_threshold), int(bool(use_precomputed)), float(initial_search_fraction),
+                                           _ptr(out_i), _ptr(out_d), _ptr(out_n), _mem_of(x), C.byref(t) if timing else None))
+        return (out_i, out_d, out_n, timing_dict(t)) if timing else (out_i, out_d, out_n)
+
     def scan(self, x, pids, k, metric, timing=False):
         """scan_partitions with workers (worker_scan): pids [Q, P] (or [P]: the same set for every query), -1 = skip"""
         x, pids = _f32(x), _i64(pids)

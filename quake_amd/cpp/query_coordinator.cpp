@@ -115,15 +115,18 @@ shared_ptr<SearchResult> QueryCoordinator::search(Tensor x, shared_ptr<SearchPar
             if (c) (void)qk_ctx_set_timing(c, was);
         }
     } timing_mode(ctx, !on_dev);
-    if (sp->recall_target > 0.0f && parent_ && !sp->batched_scan && group) {
-        throw std::runtime_error("[QueryCoordinator::search] recall_target with num_workers > 0: adaptive partition scanning is not "
-                                 "implemented over a device group (use fixed nprobe, or num_workers = 0).");
-    } else if (sp->recall_target > 0.0f && parent_ && !sp->batched_scan) {
-        // adaptive partition scanning (:502,637-641): candidates = nlist * initial_search_fraction
+    if (sp->recall_target > 0.0f && parent_ && !sp->batched_scan) {
+        // adaptive partition scanning (:502,637-641): candidates = nlist * initial_search_fraction; with workers the rounds run on
+        // the group's lead and every member scans the pairs whose partitions it holds (the APS hook of worker_scan, :364-428)
         Tensor nscan = torch::empty({Q}, torch::TensorOptions().dtype(torch::kInt32).device(xq.device()));
-        qk_check(qk_search_aps(ctx, parent_->store(), store, xq.data_ptr<float>(), Q, k, (int)metric_, sp->recall_target,
-                               sp->recompute_threshold, sp->use_precomputed ? 1 : 0, sp->initial_search_fraction,
-                               res->ids.data_ptr<int64_t>(), res->distances.data_ptr<float>(), nscan.data_ptr<int32_t>(), mem, &tm));
+        if (group)
+            qk_check(qk_group_search_aps(group, parent_->store(), xq.data_ptr<float>(), Q, k, (int)metric_, sp->recall_target,
+                                         sp->recompute_threshold, sp->use_precomputed ? 1 : 0, sp->initial_search_fraction,
+                                         res->ids.data_ptr<int64_t>(), res->distances.data_ptr<float>(), nscan.data_ptr<int32_t>(), mem, &tm));
+        else
+            qk_check(qk_search_aps(ctx, parent_->store(), store, xq.data_ptr<float>(), Q, k, (int)metric_, sp->recall_target,
+                                   sp->recompute_threshold, sp->use_precomputed ? 1 : 0, sp->initial_search_fraction,
+                                   res->ids.data_ptr<int64_t>(), res->distances.data_ptr<float>(), nscan.data_ptr<int32_t>(), mem, &tm));
         ti->partitions_scanned = (int)nscan.sum().item<int64_t>();
         ti->job_wait_time_ns = (int64_t)(tm.total_ms * 1e6);
     } else if (track) {

@@ -401,6 +401,33 @@ extern "C" int qk_search_aps(qk_ctx *ctx, qk_store *parent, qk_store *s, const f
                              float recall_target, float recompute_threshold, int use_precomputed, float initial_search_fraction,
                              int64_t *out_ids, float *out_dist, int32_t *out_nscanned, int mem, qk_timing *timing) {
     if (!ctx || !s || !parent) QK_FAIL(QK_ERR_INVALID, "qk_search_aps: ctx / parent / store is null (adaptive search needs a parent index)");
+    // a round's scan: the probed (query, list) pairs against the ONE store, results kept apart per pair
+    const qk_aps_scan_fn scan = [ctx, s](const qk_aps_round &r) -> int {
+        qk_scan_args sa;
+        sa.x = r.x;
+        sa.xq4 = r.xq4;
+        sa.xn = r.xn;
+        sa.Q = r.Q;
+        sa.pids = r.round_pids;
+        sa.P = r.CH;
+        sa.k = r.k;
+        sa.metric = r.metric;
+        sa.out_ids = r.pr_ids;
+        sa.out_dist = r.pr_key;
+        sa.per_pair = true;
+        sa.tau_init = r.run_tau;
+        sa.sqrt_l2 = false;  // merge keys: squared distances
+        return qk_scan_device(ctx, s, sa, nullptr, 4);
+    };
+    return qk_aps_run(ctx, parent, s->nlist, s->d, x, Q, k, metric, recall_target, recompute_threshold, use_precomputed,
+                      initial_search_fraction, out_ids, out_dist, out_nscanned, mem, timing, scan);
+}
+
+// The rounds of an adaptive search on `ctx` (candidates, boundary distances, per-round list of partitions, the sequential rule);
+// WHO scans a round's pairs is the caller's: one store (qk_search_aps), or the members of a device group (qk_group_search_aps).
+int qk_aps_run(qk_ctx *ctx, qk_store *parent, int64_t nlist, int d, const float *x, int64_t Q, int k, int metric, float recall_target,
+               float recompute_threshold, int use_precomputed, float initial_search_fraction, int64_t *out_ids, float *out_dist,
+               int32_t *out_nscanned, int mem, qk_timing *timing, const qk_aps_scan_fn &scan) {
     if (metric != QK_METRIC_L2 && metric != QK_METRIC_IP) QK_FAIL(QK_ERR_INVALID, "Metric type not supported");
     if (!(recall_target > 0.0f)) QK_FAIL(QK_ERR_INVALID, "qk_search_aps: recall_target must be > 0");
     QK_HIP(hipSetDevice(ctx->device));
@@ -408,10 +435,9 @@ extern "C" int qk_search_aps(qk_ctx *ctx, qk_store *parent, qk_store *s, const f
     if (Q <= 0) return QK_OK;
     if (k <= 0) k = 1;  // query_coordinator.cpp:490
     if (k > QK_MAX_K) QK_FAIL(QK_ERR_UNSUPPORTED, "qk_search_aps: k=%d exceeds QK_MAX_K=%d", k, QK_MAX_K);
-    const int d = s->d;
     if (parent->d != d) QK_FAIL(QK_ERR_INVALID, "parent store dimension %d != store dimension %d", parent->d, d);
     // query_coordinator.cpp:638-640: (int)(nlist * initial_search_fraction) in float arithmetic, at least 1
-    int M = (int)((float)s->nlist * initial_search_fraction);
+    int M = (int)((float)nlist * initial_search_fraction);
     if (M < 1) M = 1;
     M = (int)std::min<int64_t>(M, parent->ntotal);
     if (M < 2) QK_FAIL(QK_ERR_INVALID, "Boundary distances must have at least 2 partitions to create an estimate.");  // geometry.h:350
@@ -574,21 +600,21 @@ extern "C" int qk_search_aps(qk_ctx *ctx, qk_store *parent, qk_store *s, const f
     for (;;) {
         hipLaunchKernelGGL(k_aps_round_pids, dim3((unsigned)(((size_t)Q * CH + 255) / 256)), dim3(256), 0, st, pids, next_p, want, Q, M,
                            CH, round_pids);
-        qk_scan_args sa;
-        sa.x = dx_;
-        sa.xq4 = xq4;
-        sa.xn = xn;
-        sa.Q = Q;
-        sa.pids = round_pids;
-        sa.P = CH;
-        sa.k = k;
-        sa.metric = metric;
-        sa.out_ids = pr_ids;
-        sa.out_dist = pr_key;
-        sa.per_pair = true;
-        sa.tau_init = run_tau;
-        sa.sqrt_l2 = false;  // merge keys: squared distances
-        QK_TRY(qk_scan_device(ctx, s, sa, nullptr, 4));
+        qk_aps_round rd;
+        rd.x = dx_;
+        rd.xq4 = xq4;
+        rd.xn = xn;
+        rd.Q = Q;
+        rd.round_pids = round_pids;
+        rd.CH = CH;
+        rd.k = k;
+        rd.metric = metric;
+        rd.pr_ids = pr_ids;
+        rd.pr_key = pr_key;
+        rd.run_tau = run_tau;
+        rd.round = rounds;
+        QK_TRY(scan(rd));
+        QK_HIP(hipSetDevice(ctx->device));
         volatile int32_t *flag = ctx->aps_flags + rounds;
         *flag = 0;
         up.host_flag = ctx->aps_flags_dev + rounds;

@@ -180,12 +180,22 @@ __device__ __forceinline__ void apf_stage(const uint4 *__restrict__ cbf, int chu
     constexpr int CHB_U4 = APF_CH * NM * 64 + 64, APF_THREADS = 64 * APF_WAVES;
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint4 *src = cbf + (int64_t)chunk * CHB_U4 + tid;
+    // scalar base + 32-bit lane offset (global_load_lds v_off, s[base]): a 64-bit lane address lives in two VGPRs for the whole
+    // kernel, and at 256 registers it was the value the allocator spilled -- reloaded at the head of every chunk, behind a
+    // s_waitcnt vmcnt(0) that also waited for the prefetch just issued
+    const char *base = (const char *)(cbf + (int64_t)chunk * CHB_U4);
+    const uint32_t voff = (uint32_t)tid * 16u;
 #pragma unroll
     for (int r = 0; r * APF_THREADS < CHB_U4; r++) {
-        if (r * APF_THREADS + wave * 64 < CHB_U4)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + r * APF_THREADS),
-                                             (__attribute__((address_space(3))) void *)(dst + r * APF_THREADS + wave * 64), 16, 0, 0);
+        if (r * APF_THREADS + wave * 64 < CHB_U4) {
+            // (written out: the builtin takes ONE pointer and the compiler folds base + offset into a 64-bit lane address again)
+            const char *sb = base + (size_t)r * APF_THREADS * 16;
+            const uint32_t lds = (uint32_t)(size_t)(__attribute__((address_space(3))) void *)(dst + r * APF_THREADS + wave * 64);
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0"
+                         :
+                         : "s"(sb), "v"(voff), "s"(__builtin_amdgcn_readfirstlane(lds))
+                         : "memory", "m0");
+        }
     }
 }
 
@@ -252,7 +262,8 @@ __global__ __launch_bounds__(64 * APF_WAVES) void k_assign_pf(AssignPfParams P) 
             best_w[xt * 16 + j] = ~0ull;  // "nothing yet"
         }
     }
-    __syncthreads();  // (chunk 0 has landed: the barrier waits for the wave's own loads first)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // (chunk 0 has landed: every wave waited for its own loads first)
 
     const int nch = P.nch;
     // a = x~.y~ - |y|^2 / 2 (IP: x~.y~) comes out of the instruction itself -- the accumulator starts at the norm term -- so the
@@ -262,7 +273,8 @@ __global__ __launch_bounds__(64 * APF_WAVES) void k_assign_pf(AssignPfParams P) 
 #pragma unroll
     for (int xt = 0; xt < XT; xt++) hw[xt] = -__builtin_inff();
     int cnt = 0;  // candidates parked by this wave (uniform)
-    const uint64_t lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    // set bits of a ballot below this lane: v_mbcnt (no per-lane mask to keep in two registers)
+#define APF_BELOW(mk_) ((int)__builtin_amdgcn_mbcnt_hi((uint32_t)((mk_) >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)(mk_), 0u)))
 
     // LDS reads of the streamed operands as inline assembly: the compiler cannot tell a read of THIS chunk from the global_load_lds
     // writes into the OTHER buffer and put s_waitcnt vmcnt(0) -- the whole next chunk -- in front of the first read after every stage
@@ -271,12 +283,18 @@ __global__ __launch_bounds__(64 * APF_WAVES) void k_assign_pf(AssignPfParams P) 
     apf_u32x4 a_[4];                                                                                 \
     f32x4 y4;                                                                                        \
     {                                                                                                \
-        const uint32_t ta_ = cb_addr + (uint32_t)t * (NM * 1024);                                    \
+        /* the two LDS addresses are rebuilt from the thread number for every tile (two VALU each against 32 MFMAs): kept in  */ \
+        /* registers across the passes they were what the allocator spilled at 256 VGPRs, and the reload at the head of every */ \
+        /* chunk of pass 2 sat behind a s_waitcnt vmcnt(0) that also waited for the prefetch just issued                      */ \
+        uint32_t ta_, ya_;                                                                           \
+        asm volatile("v_and_b32 %0, 63, %2\n\tv_lshl_add_u32 %0, %0, 4, %3\n\tv_and_b32 %1, 48, %2\n\tv_add_u32 %1, %1, %4" \
+                     : "=&v"(ta_), "=&v"(ya_)                                                         \
+                     : "v"(tid), "s"(cb_s + (uint32_t)t * (NM * 1024)), "s"(yb_s + (uint32_t)t * 64)); \
         asm volatile("ds_read_b128 %0, %1" : "=v"(a_[0]) : "v"(ta_));                                \
         if (NM > 1) asm volatile("ds_read_b128 %0, %1 offset:1024" : "=v"(a_[1]) : "v"(ta_));        \
         if (NM > 2) asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(a_[2]) : "v"(ta_));        \
         if (NM > 3) asm volatile("ds_read_b128 %0, %1 offset:3072" : "=v"(a_[3]) : "v"(ta_));        \
-        asm volatile("ds_read_b128 %0, %1" : "=v"(y4) : "v"(yb_addr + (uint32_t)t * 64));            \
+        asm volatile("ds_read_b128 %0, %1" : "=v"(y4) : "v"(ya_));                                   \
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a_[0]), "+v"(y4));                                \
         if (NM > 1) asm volatile("" : "+v"(a_[1]));                                                  \
         if (NM > 2) asm volatile("" : "+v"(a_[2]));                                                  \
@@ -296,8 +314,8 @@ __global__ __launch_bounds__(64 * APF_WAVES) void k_assign_pf(AssignPfParams P) 
     for (int it = 0; it < nch; it++) {
         const int cur = it & 1;
         apf_stage<NM, APF_WAVES>(P.cbf, it + 1 < nch ? it + 1 : 0, buf + (size_t)(cur ^ 1) * CHB_U4);  // (the last one: chunk 0 of pass 2)
-        const uint32_t cb_addr = lds0 + (uint32_t)cur * (CHB_U4 * 16) + lane * 16;
-        const uint32_t yb_addr = lds0 + (uint32_t)cur * (CHB_U4 * 16) + CH_U4 * 16 + g * 16;
+        const uint32_t cb_s = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)cur * (CHB_U4 * 16));
+        const uint32_t yb_s = cb_s + CH_U4 * 16;
         for (int t = 0; t < APF_CH; t++) {
             APF_TILE_OPERANDS();
 #pragma unroll
@@ -308,7 +326,8 @@ __global__ __launch_bounds__(64 * APF_WAVES) void k_assign_pf(AssignPfParams P) 
                     hw[x0 + u] = fmaxf(fmaxf(hw[x0 + u], fmaxf(acc[u][0], acc[u][1])), fmaxf(acc[u][2], acc[u][3]));
             }
         }
-        __syncthreads();  // the next chunk has landed (own loads first), everybody is done with this one
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the wave's share of the next chunk (global_load_lds) has landed ...
+        __syncthreads();  // ... everybody's has, and everybody is done with this one
     }
     // the maximum of a row over its four lane groups, then the bound of pass 2.  In the key's scale h = -2 a (IP: -a): a centroid
     // with h > hmin + M, M = 2 E (IP: E as the bound is on the dot product itself... M = c (|x|^2 + max|y|^2)), cannot decide.
@@ -340,8 +359,8 @@ __global__ __launch_bounds__(64 * APF_WAVES) void k_assign_pf(AssignPfParams P) 
 #endif
         const int cur = (nch + it) & 1;
         if (it + 1 < nch) apf_stage<NM, APF_WAVES>(P.cbf, it + 1, buf + (size_t)(cur ^ 1) * CHB_U4);
-        const uint32_t cb_addr = lds0 + (uint32_t)cur * (CHB_U4 * 16) + lane * 16;
-        const uint32_t yb_addr = lds0 + (uint32_t)cur * (CHB_U4 * 16) + CH_U4 * 16 + g * 16;
+        const uint32_t cb_s = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)cur * (CHB_U4 * 16));
+        const uint32_t yb_s = cb_s + CH_U4 * 16;
         for (int t = 0; t < APF_CH; t++) {
             APF_TILE_OPERANDS();
             const int cidx0 = ((it * APF_CH + t) << 4) + 4 * g;
@@ -362,7 +381,7 @@ __global__ __launch_bounds__(64 * APF_WAVES) void k_assign_pf(AssignPfParams P) 
                                 apf_flush<L2>(P.x, P.c, P.cnorm, P.n, P.m, d, wrow0, cbuf, cnt, best_w, xn_w, P.ids);
                                 cnt = 0;
                             }
-                            if (p) cbuf[cnt + __popcll(mk & lt)] = ((uint32_t)(xt * 16 + j) << 24) | (uint32_t)(cidx0 + r);
+                            if (p) cbuf[cnt + APF_BELOW(mk)] = ((uint32_t)(xt * 16 + j) << 24) | (uint32_t)(cidx0 + r);
                             cnt += __popcll(mk);
                             APF_STAT(2, __popcll(mk));
                         }
@@ -370,6 +389,7 @@ __global__ __launch_bounds__(64 * APF_WAVES) void k_assign_pf(AssignPfParams P) 
                 }
             }
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (as in pass 1: the staged chunk is complete before the barrier publishes it)
         __syncthreads();
     }
 #undef APF_TILE_OPERANDS
@@ -397,7 +417,7 @@ __global__ __launch_bounds__(64 * APF_WAVES) void k_assign_pf(AssignPfParams P) 
             const int xl = (int)(pk >> 24);
             const bool need = e < cnt && (ncand[xl] > 1 || best_w[xl] != ~0ull);
             const uint64_t mk = __ballot(need);
-            if (need) cbuf[kept + __popcll(mk & lt)] = pk;
+            if (need) cbuf[kept + APF_BELOW(mk)] = pk;
             kept += __popcll(mk);
         }
         cnt = kept;

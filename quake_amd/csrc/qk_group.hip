@@ -81,6 +81,29 @@ __global__ __launch_bounds__(256) void k_gather_i64(const int64_t *__restrict__ 
     if (i < n) out[i] = src[sel[i]];
 }
 
+// adaptive search over the members: pair (q, i) of a round was scanned by the member that holds its list -- its k entries come from
+// that member's per-pair result (peer reads), the pairs without a list get the padding
+struct GatherArgs {
+    const int64_t *ids[QK_GROUP_MAX];
+    const float *key[QK_GROUP_MAX];
+    int G;
+};
+__global__ __launch_bounds__(256) void k_aps_gather(const int64_t *__restrict__ round_pids, int64_t npairs, int k, int metric, GatherArgs a,
+                                                    int64_t *__restrict__ out_ids, float *__restrict__ out_key) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= npairs * k) return;
+    const int64_t pair = i / k;
+    const int64_t p = round_pids[pair];
+    if (p < 0) {
+        out_ids[i] = -1;
+        out_key[i] = metric == QK_METRIC_L2 ? __builtin_inff() : -__builtin_inff();
+        return;
+    }
+    const int o = (int)(p % a.G);
+    out_ids[i] = a.ids[o][i];
+    out_key[i] = a.key[o][i];
+}
+
 inline unsigned grid_for(int64_t n) { return (unsigned)((n + 255) / 256); }
 
 int sync_all(qk_group *g) {
@@ -815,6 +838,107 @@ int qk_group_scan(qk_group *g, const float *x, int64_t Q, const int64_t *pids, i
         }
     }
     return group_search(g, nullptr, x, Q, pids, P, 0, k, metric, out_ids, out_dist, mem, timing);
+}
+
+// QueryCoordinator::search with recall_target > 0 and workers (the APS hook of worker_scan, query_coordinator.cpp:364-428, whose
+// outcome depends on thread timing upstream; here: the deterministic walk of qk_search_aps).  The rounds run on the lead -- candidates
+// from its replica of the parent, boundary distances, the sequential rule --; a round's list of partitions goes to every member,
+// every member scans the pairs whose lists it holds (per-pair results), the lead picks each pair's answer from its owner (peer
+// reads) and replays the rule.  Results and partitions visited equal the one-store search.
+int qk_group_search_aps(qk_group *g, qk_store *parent, const float *x, int64_t Q, int k, int metric, float recall_target,
+                        float recompute_threshold, int use_precomputed, float initial_search_fraction, int64_t *out_ids, float *out_dist,
+                        int32_t *out_nscanned, int mem, qk_timing *timing) {
+    if (!g || !parent) QK_FAIL(QK_ERR_INVALID, "qk_search_aps: group / parent is null (adaptive search needs a parent index)");
+    if (Q > 0 && (!x || !out_ids)) QK_FAIL(QK_ERR_INVALID, "qk_group_search_aps: null argument");
+    QK_TRY(check_metric(metric));
+    if (Q <= 0) {
+        if (timing) memset(timing, 0, sizeof(*timing));
+        return QK_OK;
+    }
+    const int G = g->G, d = g->d;
+    Member &lead = g->m[0];
+    QK_TRY(sync_parent(g, parent));
+    for (auto &mb : g->m) QK_TRY(qk_check_overflow(mb.ctx));
+    const int kk = k <= 0 ? 1 : k;
+    std::vector<const float4 *> xq4((size_t)G, nullptr);
+    std::vector<const float *> xn((size_t)G, nullptr);
+    size_t bx = 0, bp = 0, bt = 0, bi = 0;
+    const qk_aps_scan_fn scan = [&](const qk_aps_round &r) -> int {
+        const size_t npairs = (size_t)r.Q * r.CH;
+        if (r.round == 0) {
+            bx = al256((size_t)r.Q * d * 4);
+            bp = al256(npairs * 8);
+            bt = al256((size_t)r.Q * 4);
+            bi = al256(npairs * r.k * 8);
+            QK_TRY(reserve_call_buffers(g, bx + bp + bt + bi + al256(npairs * r.k * 4), 0));
+        }
+        auto xb = [&](Member &mb) { return (float *)mb.buf; };
+        auto pb = [&](Member &mb) { return (int64_t *)(mb.buf + bx); };
+        auto tb = [&](Member &mb) { return (uint32_t *)(mb.buf + bx + bp); };
+        auto ib = [&](Member &mb) { return (int64_t *)(mb.buf + bx + bp + bt); };
+        auto kb = [&](Member &mb) { return (float *)(mb.buf + bx + bp + bt + bi); };
+        QK_HIP(hipSetDevice(lead.ctx->device));
+        QK_HIP(hipEventRecord(g->ev_x, lead.ctx->stream));  // the round's list and bounds are in place on the lead
+        GatherArgs ga;
+        ga.G = G;
+        for (int j = 0; j < G; j++) {
+            Member &mb = g->m[(size_t)j];
+            QK_HIP(hipSetDevice(mb.ctx->device));
+            hipStream_t st = mb.ctx->stream;
+            if (j > 0) QK_HIP(hipStreamWaitEvent(st, g->ev_x, 0));
+            const float *xj = r.x;
+            if (j > 0) {
+                if (r.round == 0) QK_HIP(hipMemcpyAsync(xb(mb), r.x, (size_t)r.Q * d * 4, hipMemcpyDefault, st));
+                xj = xb(mb);
+            }
+            if (r.round == 0) {
+                if (j == 0) {
+                    xq4[0] = r.xq4;
+                    xn[0] = r.xn;
+                } else {
+                    QK_TRY(qk_prep_queries(mb.ctx, xj, r.Q, d, &xq4[(size_t)j], &xn[(size_t)j]));
+                }
+            }
+            const int64_t *pj = r.round_pids;
+            const uint32_t *tj = r.run_tau;
+            if (j > 0) {
+                QK_HIP(hipMemcpyAsync(pb(mb), r.round_pids, npairs * 8, hipMemcpyDefault, st));
+                QK_HIP(hipMemcpyAsync(tb(mb), r.run_tau, (size_t)r.Q * 4, hipMemcpyDefault, st));
+                pj = pb(mb);
+                tj = tb(mb);
+            }
+            qk_scan_args sa;
+            sa.x = xj;
+            sa.xq4 = xq4[(size_t)j];
+            sa.xn = xn[(size_t)j];
+            sa.Q = r.Q;
+            sa.pids = pj;
+            sa.P = r.CH;
+            sa.k = r.k;
+            sa.metric = r.metric;
+            sa.out_ids = ib(mb);
+            sa.out_dist = kb(mb);
+            sa.per_pair = true;
+            sa.tau_init = tj;
+            sa.sqrt_l2 = false;
+            QK_TRY(qk_scan_device(mb.ctx, mb.store, sa, nullptr, 4));
+            if (j > 0) QK_HIP(hipEventRecord(mb.ev_done, st));
+            ga.ids[j] = ib(mb);
+            ga.key[j] = kb(mb);
+        }
+        QK_HIP(hipSetDevice(lead.ctx->device));
+        for (int j = 1; j < G; j++) QK_HIP(hipStreamWaitEvent(lead.ctx->stream, g->m[(size_t)j].ev_done, 0));
+        hipLaunchKernelGGL(k_aps_gather, dim3(grid_for((int64_t)npairs * r.k)), dim3(256), 0, lead.ctx->stream, r.round_pids, (int64_t)npairs,
+                           r.k, r.metric, ga, r.pr_ids, r.pr_key);
+        QK_HIP(hipGetLastError());
+        return QK_OK;
+    };
+    // (the lead's context returns merge keys to the group's searches; the adaptive search's own answer is a plain distance)
+    lead.ctx->squared_l2 = false;
+    const int rc = qk_aps_run(lead.ctx, lead.parent, qk_group_nlist(g), d, x, Q, kk, metric, recall_target, recompute_threshold,
+                              use_precomputed, initial_search_fraction, out_ids, out_dist, out_nscanned, mem, timing, scan);
+    lead.ctx->squared_l2 = true;
+    return rc;
 }
 
 int qk_group_search(qk_group *g, qk_store *parent, const float *x, int64_t Q, int nprobe, int k, int metric, int64_t *out_ids,

@@ -3,6 +3,7 @@
 #include "qk_idmap.h"
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <functional>
 #include <string>
 #include <vector>
 #include <unordered_map>
@@ -291,6 +292,23 @@ int qk_run_search(qk_ctx *ctx, qk_store *parent, qk_store *s, const float *x, in
                   int k, int metric, int64_t *out_ids, float *out_dist, int mem, qk_timing *timing, bool coarse_only,
                   bool defer_finish);
 int qk_finish_timing(qk_ctx *ctx, qk_store *s, qk_timing *t, bool have_coarse, int scan_ev_base);
+// adaptive (recall-target) search: the rounds run on `ctx`; a round's (query, list) pairs are scanned by `scan` (qk_aps.hip)
+struct qk_aps_round {
+    const float *x = nullptr;           // [Q][d] queries (device, on the context that runs the rounds)
+    const float4 *xq4 = nullptr;        // that context's prepared copies
+    const float *xn = nullptr;
+    int64_t Q = 0;
+    const int64_t *round_pids = nullptr;  // [Q][CH] partitions of the round, -1 = none
+    int CH = 0, k = 0, metric = 0;
+    int64_t *pr_ids = nullptr;          // out [Q*CH][k] per-pair top-k ids (-1 padding)
+    float *pr_key = nullptr;            // out [Q*CH][k] squared L2 / inner product
+    const uint32_t *run_tau = nullptr;  // [Q] initial bound per query (~ord, 0 = none)
+    int round = 0;
+};
+typedef std::function<int(const qk_aps_round &)> qk_aps_scan_fn;
+int qk_aps_run(qk_ctx *ctx, qk_store *parent, int64_t nlist, int d, const float *x, int64_t Q, int k, int metric, float recall_target,
+               float recompute_threshold, int use_precomputed, float initial_search_fraction, int64_t *out_ids, float *out_dist,
+               int32_t *out_nscanned, int mem, qk_timing *timing, const qk_aps_scan_fn &scan);
 // one-launch search of a small batch (qk_small.hip)
 bool qk_small_supported(qk_ctx *ctx, qk_store *parent, qk_store *s, int64_t Q, int nprobe, int k);
 // coarse step of a mid-sized batch in one launch (qk_small.hip: k_coarse_small)

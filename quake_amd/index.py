@@ -433,15 +433,18 @@ class QuakeIndex:
         grp = self._store if isinstance(self._store, capi.Group) else None
         if grp is not None:
             grp.set_stream(torch.cuda.current_stream(grp.device).cuda_stream)  # the lead's stream (see _context)
-        if use_aps and grp is not None:
-            raise RuntimeError("[QueryCoordinator::search] recall_target with num_workers > 0: adaptive partition scanning is not "
-                               "implemented over a device group (use fixed nprobe, or num_workers = 0).")
         if use_aps:
-            # adaptive partition scanning: candidates = nlist * initial_search_fraction, per-query early stop
-            ids, dist, nscan, tm = self._ctx.search_aps(
-                self.parent._store, self._store, xd, int(k), self.metric_, float(search_params.recall_target),
-                recompute_threshold=float(search_params.recompute_threshold), use_precomputed=bool(search_params.use_precomputed),
-                initial_search_fraction=float(search_params.initial_search_fraction), timing=True)
+            # adaptive partition scanning: candidates = nlist * initial_search_fraction, per-query early stop (with workers the
+            # rounds run on the group's lead and every member scans the pairs whose partitions it holds)
+            aps_args = dict(recompute_threshold=float(search_params.recompute_threshold),
+                            use_precomputed=bool(search_params.use_precomputed),
+                            initial_search_fraction=float(search_params.initial_search_fraction), timing=True)
+            if grp is not None:
+                ids, dist, nscan, tm = grp.search_aps(self.parent._store, xd, int(k), self.metric_,
+                                                      float(search_params.recall_target), **aps_args)
+            else:
+                ids, dist, nscan, tm = self._ctx.search_aps(self.parent._store, self._store, xd, int(k), self.metric_,
+                                                            float(search_params.recall_target), **aps_args)
             ti.n_queries = int(x.shape[0])
             ti.partitions_scanned = int(nscan.sum().item())
             ti.job_wait_time_ns = int(tm["total_ms"] * 1e6)

@@ -232,6 +232,26 @@ def test_group_follows_a_changing_parent(capi):
     assert not (gi == gi0).all()
 
 
+def test_group_aps_equals_single_store(capi):
+    """qk_group_search_aps == qk_search_aps: ids, distance bits and partitions visited per query"""
+    ivf = make_ivf(80000, 32, 256, seed=51)
+    ctx, parent, single, grp = _build(capi, ivf, 4)
+    q = make_queries(300, 32, seed=52, like=ivf["x"])
+    for rt, frac in ((0.9, 0.05), (0.99, 0.2)):
+        si, sd, sn = ctx.search_aps(parent, single, q, 10, "l2", rt, initial_search_fraction=frac)
+        gi, gd, gn, tm = grp.search_aps(parent, q, 10, "l2", rt, initial_search_fraction=frac, timing=True)
+        assert (gi == si).all() and (_bits(gd) == _bits(sd)).all() and (gn == sn).all()
+        assert tm["n_items"] >= 1
+        qd = torch.from_numpy(q).cuda()
+        di, dd, dn = grp.search_aps(parent, qd, 10, "l2", rt, initial_search_fraction=frac)
+        grp.synchronize()
+        assert (_np(di) == si).all() and (_bits(dd) == _bits(sd)).all() and (_np(dn) == sn).all()
+    # a plain search afterwards still returns distances (the lead's merge-key mode was put back)
+    si, sd = ctx.search(parent, single, q, 4, 10, "l2")
+    gi, gd = grp.search(parent, q, 4, 10, "l2")
+    assert (gi == si).all() and (_bits(gd) == _bits(sd)).all()
+
+
 def test_group_errors(capi):
     with pytest.raises(RuntimeError):
         capi.Group([], 16)

@@ -136,33 +136,52 @@ def test_initialize_workers_on_a_built_index_moves_the_partitions(qb):
         pm.distribute_partitions(2)
 
 
-def test_recall_target_with_workers_is_refused_loudly(qb):
-    x, ids, q = _corpus(20000, 32, 32, seed=9)
-    b = _build(qb, x, ids, 32, 2)
-    sp = _params(qb, 10, 5)
-    sp.recall_target = 0.9
-    with pytest.raises(RuntimeError, match="device group"):
-        b.search(q, sp)
+@pytest.mark.parametrize("mirror", ["compiled", "python"])
+def test_recall_target_with_workers(qb, mirror):
+    """adaptive partition scanning with workers (the APS hook of worker_scan, query_coordinator.cpp:364-428): the deterministic
+    walk, so answers AND partitions visited equal the search without workers"""
+    import quake_amd as qa
+    mod = qb if mirror == "compiled" else qa
+    x, ids, q = _corpus(60000, 32, 200, seed=9)
+    a = _build(mod, x, ids, 200, 0)
+    b = _build(mod, x, ids, 200, 3)
+    for rt, frac in ((0.9, 0.1), (0.99, 0.25), (0.5, 0.05)):
+        sp = _params(mod, 10, 1)
+        sp.recall_target, sp.initial_search_fraction = rt, frac
+        ra, rb = a.search(q, sp), b.search(q, sp)
+        _same(ra, rb)
+        assert ra.timing_info.partitions_scanned == rb.timing_info.partitions_scanned > 0
+        rd = b.search(q.cuda(), sp)
+        _same(ra, rd)
 
 
 @pytest.mark.parametrize("mirror", ["compiled", "python"])
-def test_maintenance_with_workers(qb, mirror):
+def test_maintenance_with_workers(qb, mirror, tmp_path):
     """maintenance() splits / deletes / refines the same partitions with and without workers (split children get the next
-    partition numbers, partition_manager.cpp:492-493, and land on the members those numbers name)."""
+    partition numbers, partition_manager.cpp:492-493, and land on the members those numbers name).  The cost model is a FIXED
+    latency profile (100 ns per partition + 1 ns per row, the reference's CSV layout): a grid profiled on the device is a
+    measurement, and two indexes measuring it get two slightly different policies."""
     import quake_amd as qa
+    from quake_amd.maintenance import (DEFAULT_LATENCY_ESTIMATOR_RANGE_K, DEFAULT_LATENCY_ESTIMATOR_RANGE_N,
+                                       ListScanLatencyEstimator, MaintenanceCostEstimator)
     mod = qb if mirror == "compiled" else qa
     x, ids, q = _corpus(30000, 32, 24, seed=13)
+    nv, kv = DEFAULT_LATENCY_ESTIMATOR_RANGE_N, DEFAULT_LATENCY_ESTIMATOR_RANGE_K
+    lat = ListScanLatencyEstimator(32, nv, kv, 1, profile_fn=lambda n, k: 100.0 + 1.0 * n)
+    prof = str(tmp_path / "latency.csv")
+    assert lat.save_latency_profile(prof)
     out = []
     for workers in (0, 3):
         idx = _build(mod, x, ids, 24, workers)
         mp = mod.MaintenancePolicyParams()
         mp.window_size, mp.refinement_radius, mp.refinement_iterations = 200, 4, 1
-        mp.split_threshold_ns, mp.delete_threshold_ns, mp.min_partition_size = 0.0, 0.0, 8
-        mp.enable_split_rejection, mp.enable_delete_rejection = False, False
-        idx.initialize_maintenance_policy(mp)
+        mp.split_threshold_ns, mp.delete_threshold_ns, mp.min_partition_size = 0.1, 0.1, 8
         if mirror == "compiled":
+            idx.initialize_maintenance_policy(mp)
+            idx.set_latency_profile(prof)
             idx.set_track_hits(True)
         else:
+            idx.initialize_maintenance_policy(mp, cost_estimator=MaintenanceCostEstimator(32, mp.alpha, 10, latency_estimator=lat))
             idx.track_hits = True
         # a skewed window: every query on the same few partitions
         hot = q[:50].repeat(8, 1)
@@ -170,6 +189,6 @@ def test_maintenance_with_workers(qb, mirror):
         m = idx.maintenance()
         out.append((idx, m.n_splits, m.n_deletes))
     (a, sa, da), (b, sb, db) = out
-    assert (sa, da) == (sb, db)
+    assert (sa, da) == (sb, db) and sa + da > 0, (sa, da, sb, db)
     assert a.nlist() == b.nlist() and a.ntotal() == b.ntotal() == 30000
     _same(a.search(q, _params(mod, 10, 6)), b.search(q, _params(mod, 10, 6)))
