@@ -389,6 +389,14 @@ class Store:
         check(self.lib.qk_store_get_list(self.h, int(list_no), _ptr(vecs), _ptr(ids), QK_MEM_HOST))
         return vecs, ids
 
+    def get_list_ids(self, list_no):
+        """ids [n] of a list in row order, from the store's host mirror (qk_store_get_list with vecs = NULL: nothing is extracted)"""
+        n = self.list_size(list_no)
+        ids = np.empty(n, np.int64)
+        if n:
+            check(self.lib.qk_store_get_list(self.h, int(list_no), None, _ptr(ids), QK_MEM_HOST))
+        return ids
+
     def get_list_device(self, list_no):
         """(vectors [n, d] as a CUDA tensor on the store's device -- extracted from the tile-major arena on the context's stream,
         no host hop -- , ids [n] as a host array: the store's own id mirror)"""
@@ -547,6 +555,13 @@ class Group:
         ids = np.empty(n, np.int64)
         check(self.lib.qk_group_get_list(self.h, int(list_no), _ptr(vecs), _ptr(ids), QK_MEM_HOST))
         return vecs, ids
+
+    def get_list_ids(self, list_no):
+        n = self.list_size(list_no)
+        ids = np.empty(n, np.int64)
+        if n:
+            check(self.lib.qk_group_get_list(self.h, int(list_no), None, _ptr(ids), QK_MEM_HOST))
+        return ids
 
     def get_list_device(self, list_no):
         """(vectors [n, d] as a CUDA tensor on the LEAD's device, written there by the owner; ids [n] as a host array)"""

@@ -100,10 +100,10 @@ shared_ptr<SearchResult> QueryCoordinator::search(Tensor x, shared_ptr<SearchPar
     std::memset(&tm, 0, sizeof(tm));
     const int mem = on_dev ? QK_MEM_DEVICE : QK_MEM_HOST;
     const bool track = maintenance_policy_ && maintenance_policy_->track_hits_ && parent_;
-    // per-call phase timing for SearchTimingInfo (mode 1: the library synchronises the stream to read its events) -- for HOST
-    // tensors only, whose answers are copied back behind a synchronisation anyway.  Device tensors keep the call asynchronous:
-    // the phase fields then carry whatever mode the caller had set on the (shared, one per device) context, zeros by default.
-    // The caller's mode is put back on every way out.
+    // per-call phase timing for SearchTimingInfo (mode 1: the library reads its events behind a synchronisation of the stream -- which
+    // a call that asks for the counters of SearchTimingInfo performs anyway), for host and device tensors alike: the reference always
+    // fills the phase fields (query_coordinator.cpp:612-657).  The caller's mode on the (shared, one per device) context is put back
+    // on every way out.
     struct TimingMode {
         qk_ctx *c = nullptr;
         int was = 0;
@@ -114,7 +114,7 @@ shared_ptr<SearchResult> QueryCoordinator::search(Tensor x, shared_ptr<SearchPar
         ~TimingMode() {
             if (c) (void)qk_ctx_set_timing(c, was);
         }
-    } timing_mode(ctx, !on_dev);
+    } timing_mode(ctx, true);
     if (sp->recall_target > 0.0f && parent_ && !sp->batched_scan) {
         // adaptive partition scanning (:502,637-641): candidates = nlist * initial_search_fraction; with workers the rounds run on
         // the group's lead and every member scans the pairs whose partitions it holds (the APS hook of worker_scan, :364-428)

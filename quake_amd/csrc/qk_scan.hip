@@ -354,7 +354,9 @@ __device__ __forceinline__ void group_scan_body(const GroupParams &G, long long 
         __syncthreads();
         unsigned long long p0 = 0, t0 = 0, p3 = 0, t3 = 0;
         long long p1 = 0, t1 = 0, t2 = 0;
-#pragma unroll
+        // (not fully unrolled: the compiler then requests all 64 eight-byte partials before the first add -- 128 VGPRs, which at
+        //  1024 threads per workgroup is the whole budget: 20-30 registers went to scratch in the middle of this latency chain)
+#pragma unroll 2
         for (int w = 0; w < 16; w++) {
             const unsigned long long v0 = (unsigned long long)s_w[w];
             const long long v1 = s_w[16 + w];

@@ -18,6 +18,9 @@
 // timed (the caller records measure->e0 / e1 around its launches)
 static int qk_pick_form(qk_ctx *ctx, uint64_t key, int form_static, const bool admissible[3], qk_ctx::form_stat **measure) {
     *measure = nullptr;
+    // (at most 32 entries, reserved once: the entry handed back through *measure stays where it is while the caller's launches are
+    //  in flight, whatever is looked up meanwhile)
+    if (ctx->form_stats.capacity() < 32) ctx->form_stats.reserve(32);
     qk_ctx::form_stat *st = nullptr;
     for (auto &f : ctx->form_stats)
         if (f.key == key) st = &f;
@@ -83,11 +86,14 @@ static int qk_pick_form(qk_ctx *ctx, uint64_t key, int form_static, const bool a
             if (admissible[f] && st->n[f] < 2) next = f;
     }
     if (next < 0 && best >= 0 && st->calls % 512 == 0) {  // re-check a form that lost (the data under the index changes)
+        // ... unless its last figure was more than twice the winner's: such a call is a latency spike on the serving path (5 ms
+        // against 1.2 on a 50M index) and a form that far behind does not come back without the index changing -- which changes
+        // the key (size bucket below) and starts a fresh comparison
         for (int t = 0; t < 3 && next < 0; t++) {
             const int f = (st->rr + t) % 3;
-            if (admissible[f] && f != best) next = f;
+            if (admissible[f] && f != best && !(st->n[f] >= 1 && st->ms[f] > 2.0f * st->ms[best])) next = f;
         }
-        st->rr = (next + 1) % 3;
+        if (next >= 0) st->rr = (next + 1) % 3;
     }
     if (next < 0 && best >= 0 && st->calls % 16 == 0) next = best;  // keep the winner's figure current (and notice a change of regime)
     if (next >= 0) {
@@ -296,8 +302,14 @@ int qk_scan_plan(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, bool emit, int
     {
         const bool admissible[3] = {true, rl_avail, mixed_avail};
         if (ctx->form_feedback && !emit && npairs >= 1024 && P > 1 && (rl_avail || mixed_avail)) {
+            // (size bucket: the store's row count to a quarter of a power of two and its list count to a power of two -- a store that
+            //  grew, shrank or was re-partitioned by maintenance is a new shape with a fresh comparison, not a stale winner)
+            int sb = 0, lb = 0;
+            for (int64_t t = s->ntotal; t > 7; t >>= 1) sb++;
+            const int sq = (int)((s->ntotal >> (sb > 1 ? sb - 1 : 0)) & 3);  // two bits below the leading one
+            for (int64_t t = s->nlist; t > 1; t >>= 1) lb++;
             const uint64_t key = (s->uid * 0x9E3779B97F4A7C15ull) ^ ((uint64_t)(Q >> 6) << 40) ^ ((uint64_t)P << 24) ^ ((uint64_t)k << 8) ^ (uint64_t)a.metric ^
-                                 (a.per_pair ? 1ull << 63 : 0ull);
+                                 (a.per_pair ? 1ull << 63 : 0ull) ^ ((uint64_t)(sb * 4 + sq) * 0xD6E8FEB86659FD93ull) ^ ((uint64_t)lb << 56);
             form = qk_pick_form(ctx, key, form_static, admissible, &fmeasure);
         }
     }

@@ -191,7 +191,7 @@ class GpuPartitions:
         self.ix._next_pid = max(self.ix._next_pid, int(p) + 1)
 
     def remove_list(self, p):
-        _, ids = self.ix._store.get_list_device(int(p)) if self.ix._store.list_size(int(p)) else (None, np.zeros(0, np.int64))
+        ids = self.ix._store.get_list_ids(int(p))  # (the store's host mirror of the ids: no row leaves the arena for this)
         self.ix._resident.discard_all(np.asarray(ids, dtype=np.int64))
         self.ix._store.remove_list(int(p))
 

@@ -73,7 +73,8 @@ def main():
         rows += kernels_of(co)
     names = subprocess.run([CXXFILT], input="\n".join(r["name"] for r in rows), capture_output=True, text=True).stdout.splitlines()
     for r, nm in zip(rows, names):
-        r["demangled"] = re.sub(r"^void ", "", nm).split("(")[0]
+        # (kernels of an anonymous namespace demangle to "(anonymous namespace)::name<..>(args)": cut the ARGUMENT list, not that)
+        r["demangled"] = re.sub(r"^void ", "", nm).replace("(anonymous namespace)::", "").split("(")[0]
     rows = [r for r in rows if flt in r["demangled"]]
     rows.sort(key=lambda r: r["demangled"])
     sep = "," if "--csv" in sys.argv else "  "

@@ -372,3 +372,46 @@ def test_load_streams_the_file(quake, tmp_path):
     a, b = idx.search(q, sp), loaded.search(q, sp)
     np.testing.assert_array_equal(a.ids.numpy(), b.ids.numpy())
     np.testing.assert_array_equal(a.distances.numpy(), b.distances.numpy())
+
+
+@pytest.mark.parametrize("mirror", ["python", "compiled"])
+@pytest.mark.parametrize("workers", [0, 2])
+def test_load_of_a_hand_assembled_directory(mirror, workers):
+    """An index directory assembled byte by byte from the reference's format description (tests/golden/make_disk_image.py: struct +
+    numpy, nothing of this repo) -- partition ids in non-ascending file order, one empty partition, row order != id order -- is read
+    by both loaders: same partitions, same rows in the same order, and it answers searches exactly (dynamic_inverted_list.cpp:338-520,
+    quake_index.cpp:207-267)."""
+    import json
+    here = os.path.dirname(os.path.abspath(__file__))
+    exp = json.load(open(os.path.join(here, "golden", "disk_image.json")))
+    if mirror == "python":
+        import quake_amd as mod
+    else:
+        from quake_amd.build_ext import build_bindings
+        build_bindings()
+        import quake_amd.bindings as mod
+    idx = mod.QuakeIndex()
+    idx.load(os.path.join(here, "golden", "disk_image"), workers)
+    assert idx.ntotal() == exp["ntotal"] and idx.nlist() == exp["nlist"] and idx.parent.ntotal() == 3
+    allv, alli = [], []
+    for pid, part in exp["partitions"].items():
+        ids = torch.tensor(part["ids"], dtype=torch.int64)
+        v = torch.tensor(part["vectors"], dtype=torch.float32).reshape(-1, exp["d"])
+        if ids.numel():
+            assert torch.equal(idx.get(ids), v)  # every row under its id
+            allv.append(v)
+            alli.append(ids)
+    assert torch.equal(idx.parent.get(torch.tensor([9, 5, 0])), torch.tensor([exp["centroids"][k] for k in ("9", "5", "0")]))
+    if mirror == "python":  # row order inside a partition = file order
+        for pid, part in exp["partitions"].items():
+            assert idx._store.get_list_ids(int(pid)).tolist() == part["ids"]
+    x, ids = torch.cat(allv), torch.cat(alli)
+    sp = mod.SearchParams()
+    sp.k, sp.nprobe = 3, 3
+    q = x[::2] + 0.25
+    r = idx.search(q, sp)
+    dist = torch.cdist(q.double(), x.double())
+    key = dist * 1e6 + ids.double()[None, :] * 1e-3  # (distance, id) order: integer data, exact distances
+    want = ids[torch.topk(key, 3, dim=1, largest=False).indices]
+    assert torch.equal(r.ids.cpu(), want)
+    np.testing.assert_allclose(r.distances.cpu().numpy(), torch.topk(dist, 3, dim=1, largest=False).values.numpy(), atol=1e-5)
