@@ -47,7 +47,7 @@ def step(nprobe, b, slot=0):
 
 results = []
 for nprobe in [int(v) for v in a.nprobes.split(",")]:
-    elapsed, ev, ev_ph = B.timed_region(ctx, step, nprobe, a.steps, 10, 30, None, dev)
+    elapsed, ev, ev_ph, _ = B.timed_region(ctx, step, nprobe, a.steps, 10, 30, None, dev, groups=1)
     ctx.set_timing(1)
     sb = 0
     for b in range(B.N_BATCHES):
