@@ -1196,7 +1196,7 @@ def main():
 
     if world == 1 and not force_sharded:
         main_res = run_single_workload(ctx, dev, args, "headline", args.sigma, args.nprobe, args.steps, args.warmup, args.settle,
-                                       args.cpu_seconds, traffic_file="r04_pmc_k_scan.json", manifold=args.manifold,
+                                       args.cpu_seconds, traffic_file="r05_pmc_k_scan.json", manifold=args.manifold,
                                        sweep_nprobes=() if (args.no_extra or args.manifold) else (8, 16, 32))
         cfg_no = 2 if (args.metric == "ip" and args.dim == 768) else 1
         main_res["config"]["workload"] += f" (BASELINE.json configs[{cfg_no}])"
@@ -1225,7 +1225,7 @@ def main():
             hard_steps = max(20, min(args.steps, 100))
             if not only or "hard" in only:
                 extra["hard"] = run_single_workload(ctx, dev, args, "hard", 0.0, 0, hard_steps, min(args.warmup, 10),
-                                                    min(args.settle, 50), args.cpu_seconds * 0.5, traffic_file="r04_pmc_k_scan_hard.json",
+                                                    min(args.settle, 50), args.cpu_seconds * 0.5, traffic_file="r05_pmc_k_scan_hard.json",
                                                     manifold=args.hard_latent)
             if not only or "configs0" in only:
                 extra["configs0"] = run_configs0(ctx, dev, args)
