@@ -169,6 +169,7 @@ __global__ __launch_bounds__(256) void k_aps_boundary(BoundaryParams B) {
 }
 
 // ---- per-round pid matrix ---------------------------------------------------------------------------------------------
+// (CH = this round's row length: no query wants more)
 __global__ void k_aps_round_pids(const int64_t *pids, const int32_t *next_p, const int32_t *want, int64_t Q, int M, int CH,
                                  int64_t *round_pids) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -182,15 +183,15 @@ __global__ void k_aps_round_pids(const int64_t *pids, const int32_t *next_p, con
 // ---- the sequential rule, one wave per query ------------------------------------------------------------------------
 struct UpdateParams {
     int64_t Q;
-    int M, k, d, CH, metric;
+    int M, k, d, CH, CHr, metric;  // CH: most partitions a query takes into a round; CHr: row length of THIS round's pair arrays
     float recall_target, recompute_threshold;
     int precomputed;
     const double *table;
     const int64_t *pids;      // [Q][M]
     const float *bd;          // [Q][M]
     float *probs;             // [Q][M]  (persisted between rounds)
-    const int64_t *pr_ids;    // [Q*CH][k] results of this round's pairs
-    const float *pr_key;      // [Q*CH][k] squared L2 / inner product
+    const int64_t *pr_ids;    // [Q*CHr][k] results of this round's pairs
+    const float *pr_key;      // [Q*CHr][k] squared L2 / inner product
     uint32_t *run_ord;        // [Q][k]
     int64_t *run_id;          // [Q][k]
     int32_t *run_cnt, *have_probs, *next_p, *want, *nscan;
@@ -234,6 +235,7 @@ __global__ __launch_bounds__(64) void k_aps_update(UpdateParams U) {
     int64_t *pool_id = (int64_t *)smem;                                  // [2k]
     uint32_t *pool_ord = (uint32_t *)(smem + (size_t)2 * k * 8);         // [2k]
     float *probs = (float *)(smem + (size_t)2 * k * 12);                 // [M]
+    float *bdl = probs + M;                                              // [M] this query's boundary distances
     const bool euclid = U.metric == QK_METRIC_L2;
     int cnt = U.run_cnt[q];
     for (int e = lane; e < cnt; e += 64) {
@@ -243,24 +245,55 @@ __global__ __launch_bounds__(64) void k_aps_update(UpdateParams U) {
     bool have = U.have_probs[q] != 0;
     if (have)
         for (int jj = lane; jj < M; jj += 64) probs[jj] = U.probs[q * M + jj];
+    for (int jj = lane; jj < M; jj += 64) bdl[jj] = U.bd[q * M + jj];
     float qr = U.radius[q];
     const int p0 = U.next_p[q];
     bool stop = false;
     int nscan = p0;
+    // The walk is a chain of dependent steps; what it reads from global memory -- the next pair's entries and its partition number
+    // -- is requested one step ahead, so a step waits for loads issued a whole step earlier (the step itself touches LDS only).
+    int64_t pf_id = -1, pf_pid = -1;
+    float pf_key = 0.0f;
+    auto fetch = [&](int i) {
+        pf_id = -1;
+        pf_pid = -1;
+        if (i < w && p0 + i < M) {
+            pf_pid = U.pids[q * M + p0 + i];
+            if (lane < k) {
+                pf_id = U.pr_ids[(q * U.CHr + i) * k + lane];
+                pf_key = U.pr_key[(q * U.CHr + i) * k + lane];
+            }
+        }
+    };
+    fetch(0);
+    // the estimate of step p is the sum of probs[0 .. p) taken in order from 0.0f: while the profile stands, the chain is continued
+    // from where the previous step left it (the same additions in the same order)
+    float est_run = 0.0f;
+    int est_n = 0;
     for (int i = 0; i < w && p0 + i < M; i++) {
         const int p = p0 + i;
         nscan = p + 1;
-        if (U.pids[q * M + p] == -1) continue;  // query_coordinator.cpp:540
+        const int64_t c_id = pf_id, c_pid = pf_pid;
+        const float c_key = pf_key;
+        fetch(i + 1);
+        if (c_pid == -1) continue;  // query_coordinator.cpp:540
         // merge this partition's top-k into the running one
-        const int64_t *nid = U.pr_ids + (q * U.CH + i) * k;
-        const float *nkey = U.pr_key + (q * U.CH + i) * k;
+        const int64_t *nid = U.pr_ids + (q * U.CHr + i) * k;
+        const float *nkey = U.pr_key + (q * U.CHr + i) * k;
+        int added = 0;
         for (int base = 0; base < k; base += 64) {
             const int e = base + lane;
             int64_t id = -1;
             uint32_t o = 0xFFFFFFFFu;
             if (e < k) {
-                id = nid[e];
-                const float v = nkey[e];
+                float v;
+                if (base == 0) {
+                    id = c_id;
+                    v = c_key;
+                } else {
+                    id = nid[e];
+                    v = nkey[e];
+                }
                 o = euclid ? ord_from_l2(v) : ord_from_ip(v);
             }
             const bool ok = id >= 0;
@@ -271,8 +304,10 @@ __global__ __launch_bounds__(64) void k_aps_update(UpdateParams U) {
                 pool_id[sl] = id;
             }
             cnt += __popcll(m);
+            added += __popcll(m);
         }
-        cnt = compact_pool<MAXCH>(pool_ord, pool_id, cnt, k, lane);
+        // (a pair that brought nothing leaves the pool as the last step sorted it)
+        if (added) cnt = compact_pool<MAXCH>(pool_ord, pool_id, cnt, k, lane);
         // radius = k-th distance, or the buffer's sentinel while it holds fewer than k (list_scanning.h:57-63,187-191)
         float cur;
         if (cnt >= k) {
@@ -288,7 +323,7 @@ __global__ __launch_bounds__(64) void k_aps_update(UpdateParams U) {
             for (int jj = lane; jj < M; jj += 64) {
                 float pj = 0.0f;
                 if (jj >= 1) {
-                    const float b = U.bd[q * M + jj];
+                    const float b = bdl[jj];
                     if (!(b >= qr)) {
                         const double vr = exp(log_cap_volume((double)qr, (double)b, U.d, U.precomputed != 0, euclid, U.table));
                         pj = (float)((vr > 0.0) ? vr : 0.0);
@@ -311,10 +346,14 @@ __global__ __launch_bounds__(64) void k_aps_update(UpdateParams U) {
             }
             __builtin_amdgcn_wave_barrier();
             have = true;
+            est_run = 0.0f;
+            est_n = 0;
         }
         float est = 0.0f;
-        if (have)
-            for (int t = 0; t < p; t++) est += probs[t];
+        if (have) {
+            for (; est_n < p; est_n++) est_run += probs[est_n];
+            est = est_run;
+        }
         if (est >= U.recall_target) {
             stop = true;
             break;
@@ -415,7 +454,9 @@ extern "C" int qk_search_aps(qk_ctx *ctx, qk_store *parent, qk_store *s, const f
         sa.out_ids = r.pr_ids;
         sa.out_dist = r.pr_key;
         sa.per_pair = true;
+        sa.form_salt = 1 + std::min(r.round, 2);  // the first round (a few lists, no bound yet) is not the later ones' workload
         sa.tau_init = r.run_tau;
+        sa.seed_first = r.round == 0;  // (no running result yet: the bound comes from a sample of every query's nearest list)
         sa.sqrt_l2 = false;  // merge keys: squared distances
         return qk_scan_device(ctx, s, sa, nullptr, 4);
     };
@@ -447,24 +488,46 @@ int qk_aps_run(qk_ctx *ctx, qk_store *parent, int64_t nlist, int d, const float 
     static const int aps_first = std::max(2, qk_env_int("QK_APS_FIRST", APS_FIRST));
     const int CH = std::min(aps_ch, M);
 
-    // ---- partition id -> arena row of its centroid (host mirror of the parent's ids) -------------------------------
-    int64_t max_id = -1;
-    for (auto &pt : parent->parts)
-        if (pt.present)
-            for (int64_t id : pt.ids) max_id = std::max(max_id, id);
-    if (max_id < 0) QK_FAIL(QK_ERR_INVALID, "qk_search_aps: empty parent index");
-    if (max_id > (int64_t)1 << 26) QK_FAIL(QK_ERR_UNSUPPORTED, "qk_search_aps: partition ids above 2^26 are not supported");
-    std::vector<int32_t> row_of((size_t)max_id + 1, -1);
-    for (auto &pt : parent->parts)
-        if (pt.present)
-            for (size_t r = 0; r < pt.ids.size(); r++)
-                if (pt.ids[r] >= 0) row_of[(size_t)pt.ids[r]] = (int32_t)(pt.row_off + (int64_t)r);
-    // ---- table of the precomputed path (geometry.h:163-180) ---------------------------------------------------------------
-    std::vector<double> table(APS_NX);
-    {
+    // ---- partition id -> arena row of its centroid (host mirror of the parent's ids) and the table of the precomputed path
+    // (geometry.h:163-180): both live on the device from one call to the next -- rebuilt when the parent changed (its version is
+    // bumped by the table sync that follows every change) or the dimension did.  1001 continued fractions and a walk over the
+    // parent's ids are 0.2-0.4 ms of host time per call otherwise.
+    QK_TRY(qk_store_sync_table(parent));
+    if (!ctx->aps_rowof || ctx->aps_rowof_uid != parent->uid || ctx->aps_rowof_version != parent->version) {
+        int64_t max_id = -1;
+        for (auto &pt : parent->parts)
+            if (pt.present)
+                for (int64_t id : pt.ids) max_id = std::max(max_id, id);
+        if (max_id < 0) QK_FAIL(QK_ERR_INVALID, "qk_search_aps: empty parent index");
+        if (max_id > (int64_t)1 << 26) QK_FAIL(QK_ERR_UNSUPPORTED, "qk_search_aps: partition ids above 2^26 are not supported");
+        std::vector<int32_t> row_of((size_t)max_id + 1, -1);
+        for (auto &pt : parent->parts)
+            if (pt.present)
+                for (size_t r = 0; r < pt.ids.size(); r++)
+                    if (pt.ids[r] >= 0) row_of[(size_t)pt.ids[r]] = (int32_t)(pt.row_off + (int64_t)r);
+        QK_HIP(hipStreamSynchronize(ctx->stream));  // (an earlier call's kernels may still read the old map)
+        if (row_of.size() > ctx->aps_rowof_cap) {
+            if (ctx->aps_rowof) QK_HIP(hipFree(ctx->aps_rowof));
+            ctx->aps_rowof = nullptr;
+            ctx->aps_rowof_cap = 0;
+            const size_t cap = row_of.size() + row_of.size() / 4 + 256;
+            QK_HIP(hipMalloc((void **)&ctx->aps_rowof, cap * 4));
+            ctx->aps_rowof_cap = cap;
+        }
+        QK_HIP(hipMemcpy(ctx->aps_rowof, row_of.data(), row_of.size() * 4, hipMemcpyHostToDevice));
+        ctx->aps_rowof_n = (int64_t)row_of.size();
+        ctx->aps_rowof_uid = parent->uid;
+        ctx->aps_rowof_version = parent->version;
+    }
+    if (!ctx->aps_table || ctx->aps_table_d != d) {
+        std::vector<double> table(APS_NX);
         const double dx = 1.0 / (APS_NX - 1);
         const double a = (d + 1.0) / 2.0, b = 0.5;
         for (int i = 0; i < APS_NX; i++) table[i] = inc_beta(a, b, i * dx);
+        QK_HIP(hipStreamSynchronize(ctx->stream));
+        if (!ctx->aps_table) QK_HIP(hipMalloc((void **)&ctx->aps_table, APS_NX * 8));
+        QK_HIP(hipMemcpy(ctx->aps_table, table.data(), APS_NX * 8, hipMemcpyHostToDevice));
+        ctx->aps_table_d = d;
     }
 
     // ---- state ----------------------------------------------------------------------------------------------------------------
@@ -474,7 +537,7 @@ int qk_aps_run(qk_ctx *ctx, qk_store *parent, int64_t nlist, int d, const float 
     const size_t o_x = take((size_t)Q * d * 4), o_pids = take(QM * 8), o_bd = take(QM * 4), o_probs = take(QM * 4);
     const size_t o_rord = take(Qk * 4), o_rid = take(Qk * 8), o_q = take((size_t)Q * 4 * 7 + 64);
     const size_t o_rp = take((size_t)Q * CH * 8), o_pri = take(QCk * 8), o_prk = take(QCk * 4);
-    const size_t o_tab = take(APS_NX * 8), o_row = take(row_of.size() * 4), o_oi = take(Qk * 8), o_od = take(Qk * 4);
+    const size_t o_oi = take(Qk * 8), o_od = take(Qk * 4);
     const size_t o_na = take(256);
     QK_TRY(qk_aps_reserve(ctx, need));
     char *B = ctx->aps;
@@ -501,11 +564,9 @@ int qk_aps_run(qk_ctx *ctx, qk_store *parent, int64_t nlist, int d, const float 
     uint32_t *run_tau = (uint32_t *)(radius + Q);
     int64_t *round_pids = (int64_t *)(B + o_rp), *pr_ids = (int64_t *)(B + o_pri);
     float *pr_key = (float *)(B + o_prk);
-    double *d_table = (double *)(B + o_tab);
-    int32_t *d_row_of = (int32_t *)(B + o_row), *n_active = (int32_t *)(B + o_na);
-    QK_HIP(hipMemcpyAsync(d_table, table.data(), APS_NX * 8, hipMemcpyHostToDevice, st));
-    QK_HIP(hipMemcpyAsync(d_row_of, row_of.data(), row_of.size() * 4, hipMemcpyHostToDevice, st));
-    // (both host vectors must outlive the copies: pageable memory -> the runtime stages them before returning)
+    const double *d_table = ctx->aps_table;
+    const int32_t *d_row_of = ctx->aps_rowof;
+    int32_t *n_active = (int32_t *)(B + o_na);
 
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (timing) {
@@ -535,7 +596,7 @@ int qk_aps_run(qk_ctx *ctx, qk_store *parent, int64_t nlist, int d, const float 
         bp.x = dx_;
         bp.pids = pids;
         bp.row_of = d_row_of;
-        bp.n_row_of = (int64_t)row_of.size();
+        bp.n_row_of = ctx->aps_rowof_n;
         bp.cvecs = parent->vecs;
         bp.cnblk = parent->nblk;
         bp.Q = Q;
@@ -584,7 +645,7 @@ int qk_aps_run(qk_ctx *ctx, qk_store *parent, int64_t nlist, int d, const float 
     up.out_ids = d_out_ids;
     up.out_dist = d_out_dist;
     up.sqrt_l2 = ctx->squared_l2 ? 0 : 1;
-    const size_t lds_up = (size_t)2 * k * 12 + (size_t)M * 4 + 64;
+    const size_t lds_up = (size_t)2 * k * 12 + (size_t)M * 8 + 64;
     const int maxch_u = 2 * k <= 64 ? 1 : 2 * k <= 128 ? 2 : 2 * k <= 256 ? 4 : 2 * k <= 512 ? 8 : 16;
     {  // (once per call, not per round)
         switch (maxch_u) {
@@ -598,15 +659,20 @@ int qk_aps_run(qk_ctx *ctx, qk_store *parent, int64_t nlist, int d, const float 
     int rounds = 0;
     int64_t pairs_scanned = 0;
     for (;;) {
-        hipLaunchKernelGGL(k_aps_round_pids, dim3((unsigned)(((size_t)Q * CH + 255) / 256)), dim3(256), 0, st, pids, next_p, want, Q, M,
-                           CH, round_pids);
+        // the first round's rows are as long as its schedule (every query takes `first` partitions): its pair arrays, grouping and
+        // per-pair merges are those of a FIRST-probe search, not of CH mostly empty slots per query
+        const int CHr = rounds == 0 ? std::min(aps_first, CH) : CH;
+        up.CHr = CHr;
+        hipLaunchKernelGGL(k_aps_round_pids, dim3((unsigned)(((size_t)Q * CHr + 255) / 256)), dim3(256), 0, st, pids, next_p, want, Q, M,
+                           CHr, round_pids);
         qk_aps_round rd;
         rd.x = dx_;
         rd.xq4 = xq4;
         rd.xn = xn;
         rd.Q = Q;
         rd.round_pids = round_pids;
-        rd.CH = CH;
+        rd.CH = CHr;
+        rd.CH_max = CH;
         rd.k = k;
         rd.metric = metric;
         rd.pr_ids = pr_ids;

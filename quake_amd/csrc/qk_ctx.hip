@@ -58,6 +58,8 @@ int qk_ctx_destroy(qk_ctx *c) {
     if (c->pinned) hipHostFree(c->pinned);
     if (c->overflow_host) hipHostFree(c->overflow_host);
     if (c->aps_flags) hipHostFree(c->aps_flags);
+    if (c->aps_table) hipFree(c->aps_table);
+    if (c->aps_rowof) hipFree(c->aps_rowof);
     if (c->xcd_host) hipHostFree(c->xcd_host);
     if (c->xcd_ev) hipEventDestroy(c->xcd_ev);
     for (auto &f : c->form_stats) {

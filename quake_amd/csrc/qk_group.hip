@@ -865,12 +865,13 @@ int qk_group_search_aps(qk_group *g, qk_store *parent, const float *x, int64_t Q
     size_t bx = 0, bp = 0, bt = 0, bi = 0;
     const qk_aps_scan_fn scan = [&](const qk_aps_round &r) -> int {
         const size_t npairs = (size_t)r.Q * r.CH;
-        if (r.round == 0) {
+        if (r.round == 0) {  // (sized for the longest round of the call)
+            const size_t npairs_max = (size_t)r.Q * std::max(r.CH, r.CH_max);
             bx = al256((size_t)r.Q * d * 4);
-            bp = al256(npairs * 8);
+            bp = al256(npairs_max * 8);
             bt = al256((size_t)r.Q * 4);
-            bi = al256(npairs * r.k * 8);
-            QK_TRY(reserve_call_buffers(g, bx + bp + bt + bi + al256(npairs * r.k * 4), 0));
+            bi = al256(npairs_max * r.k * 8);
+            QK_TRY(reserve_call_buffers(g, bx + bp + bt + bi + al256(npairs_max * r.k * 4), 0));
         }
         auto xb = [&](Member &mb) { return (float *)mb.buf; };
         auto pb = [&](Member &mb) { return (int64_t *)(mb.buf + bx); };
@@ -919,7 +920,9 @@ int qk_group_search_aps(qk_group *g, qk_store *parent, const float *x, int64_t Q
             sa.out_ids = ib(mb);
             sa.out_dist = kb(mb);
             sa.per_pair = true;
+            sa.form_salt = 1 + std::min(r.round, 2);
             sa.tau_init = tj;
+            sa.seed_first = r.round == 0;  // (a member that holds the query's nearest list learns a bound for its pairs of that query)
             sa.sqrt_l2 = false;
             QK_TRY(qk_scan_device(mb.ctx, mb.store, sa, nullptr, 4));
             if (j > 0) QK_HIP(hipEventRecord(mb.ev_done, st));

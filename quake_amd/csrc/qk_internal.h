@@ -141,6 +141,14 @@ struct qk_ctx {
     int64_t scratch_reallocs = 0;      // re-allocations of ws / stage / pinned / qprep / aps so far (qk_store_counters [7])
     int32_t *aps_flags = nullptr;      // host-mapped: one word per round, written by the round's last workgroup (qk_aps.hip)
     int32_t *aps_flags_dev = nullptr;
+    // what a recall-target search needs and does not change from call to call (qk_aps.hip): the cap-volume table of this dimension
+    // and the parent's id -> arena row map, kept on the device until the dimension / the parent's (uid, version) changes
+    double *aps_table = nullptr;
+    int aps_table_d = -1;
+    int32_t *aps_rowof = nullptr;
+    size_t aps_rowof_cap = 0;
+    int64_t aps_rowof_n = 0;
+    uint64_t aps_rowof_uid = 0, aps_rowof_version = 0;
     // XCD balance of the partition scan (qk_scan.hip): relative speed of the 8 workgroup classes blockIdx % 8 per store,
     // learned from the wave times of sampled launches (the physical placement of an arena makes some XCDs stream it up to
     // 25 % slower than others); one sample in flight at a time
@@ -258,6 +266,11 @@ struct qk_scan_args {
     bool share_tau = true;
     bool sqrt_l2 = true;
     bool record_events = false;  // record the per-call phase events even when no qk_timing is passed
+    // per_pair only: learn every query's bound from a sample of its FIRST list (pids[q][0]) -- valid for each of its pairs when the
+    // pairs are consumed in the order given (qk_aps.hip: nothing worse than the first list's k-th best of a sample can be in a
+    // running top-k from the first list on); replaces tau_init for the call
+    bool seed_first = false;
+    int form_salt = 0;           // form feedback: calls of one shape but different work (the rounds of a recall-target search) keep their figures apart
     bool per_pair = false;       // keep the P results of a query apart: out_* are [Q*P][k], one top-k per (query, list)
     // per_pair only: [Q] initial bound per query as ~ord (0 = none): entries worse than it are dropped in every list
     const uint32_t *tau_init = nullptr;
@@ -299,7 +312,8 @@ struct qk_aps_round {
     const float *xn = nullptr;
     int64_t Q = 0;
     const int64_t *round_pids = nullptr;  // [Q][CH] partitions of the round, -1 = none
-    int CH = 0, k = 0, metric = 0;
+    int CH = 0, k = 0, metric = 0;        // CH = THIS round's row length (the first round's is shorter than the later ones')
+    int CH_max = 0;                       // the longest row any round of this call has (buffers are sized once)
     int64_t *pr_ids = nullptr;          // out [Q*CH][k] per-pair top-k ids (-1 padding)
     float *pr_key = nullptr;            // out [Q*CH][k] squared L2 / inner product
     const uint32_t *run_tau = nullptr;  // [Q] initial bound per query (~ord, 0 = none)

@@ -540,6 +540,7 @@ struct SeedParams {
     int metric;
     uint32_t *gtau;
     int seed_ranks;      // pairs with r < seed_ranks are sampled (the nearest partitions give the tight bound)
+    int strict_first;    // 1: the sample comes from the query's FIRST list or there is no bound (qk_scan_args::seed_first)
 };
 
 // grid = Q * seed_ranks waves: wave w -> query w / seed_ranks, rank w % seed_ranks.  M rows per lane: the sample is the
@@ -555,7 +556,7 @@ __device__ __forceinline__ void seed_tau_body(const SeedParams &S, const int64_t
     int size_p = 0;
     // one seeded rank: the nearest list that HOLDS k rows here (a rank of a sharded index owns one list in N: its nearest owned
     // one is what it can learn a bound from; at most 8 places are tried)
-    for (int tries = 0; tries < (S.seed_ranks == 1 ? 8 : 1) && rr < S.P; tries++, rr++) {
+    for (int tries = 0; tries < (S.seed_ranks == 1 && !S.strict_first ? 8 : 1) && rr < S.P; tries++, rr++) {
         const int64_t pair = qq * S.P + rr;
         if (S.pids_packed) {
             const unsigned long long v = S.pids_packed[pair];
@@ -1492,7 +1493,8 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
     // (measured: for k > 64 a sample bound is far looser than the bound the pools reach by themselves -- no gain, and
     //  the 64*M-row sample costs 0.1 ms at d = 768; the wider instantiations stay available for probing)
     static const int seed_max_k = qk_env_int("QK_SEED_MAX_K", 64);
-    const bool seeded = !no_seed && share_tau && k <= std::min(seed_max_k, 512) && npairs > 0 && npids > 0;
+    const bool seed_pairs = a.per_pair && a.seed_first && !emit;  // (not under QK_NO_SEED: the caller dropped its own bound for this one)
+    const bool seeded = ((!no_seed && share_tau) || seed_pairs) && k <= std::min(seed_max_k, 512) && npairs > 0 && npids > 0;
     bool fused_group = false, fused_count = false;
     if (seeded) {
         // bound seeding: for the first (nearest) partitions of every query, the k-th smallest distance of a 64-row
@@ -1519,7 +1521,8 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
         // batch goes through the larger-batch launch (the scan of the mixed form is 2x slower without any seed and gains
         // 8-16 us from the larger sample; 256 rows cost the seeding what they save the scan: it is bandwidth-bound)
         static const int seed_ranks_env = qk_env_int("QK_SEED_RANKS", 1);
-        sd.seed_ranks = std::min(std::max(1, seed_ranks_env), G.P);
+        sd.seed_ranks = seed_pairs ? 1 : std::min(std::max(1, seed_ranks_env), G.P);
+        sd.strict_first = seed_pairs ? 1 : 0;
         // (a side stream + fork/join events was measured slower than running it in line: 45 vs 40 us group phase.
         //  Larger samples -- 128 / 256 rows, scalar or on MFMA with all tile loads in flight -- take 6-12 us off k_scan and
         //  add 10-40 us here: the kernel is a chain of five dependent memory round trips, not arithmetic.)
@@ -1595,6 +1598,11 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
         sp.tau_publish = 1;
         if (!share_tau && a.tau_init) {  // caller-provided per-query bound (same ~bound format), never updated here
             sp.gtau = const_cast<uint32_t *>(a.tau_init);
+            sp.tau_refresh = 0;
+            sp.tau_publish = 0;
+        }
+        if (seed_pairs && seeded) {  // the sample bound of the first list, read once per pool and never updated
+            sp.gtau = gtau;
             sp.tau_refresh = 0;
             sp.tau_publish = 0;
         }

@@ -309,7 +309,8 @@ int qk_scan_plan(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, bool emit, int
             const int sq = (int)((s->ntotal >> (sb > 1 ? sb - 1 : 0)) & 3);  // two bits below the leading one
             for (int64_t t = s->nlist; t > 1; t >>= 1) lb++;
             const uint64_t key = (s->uid * 0x9E3779B97F4A7C15ull) ^ ((uint64_t)(Q >> 6) << 40) ^ ((uint64_t)P << 24) ^ ((uint64_t)k << 8) ^ (uint64_t)a.metric ^
-                                 (a.per_pair ? 1ull << 63 : 0ull) ^ ((uint64_t)(sb * 4 + sq) * 0xD6E8FEB86659FD93ull) ^ ((uint64_t)lb << 56);
+                                 (a.per_pair ? 1ull << 63 : 0ull) ^ ((uint64_t)(sb * 4 + sq) * 0xD6E8FEB86659FD93ull) ^ ((uint64_t)lb << 56) ^
+                                 ((uint64_t)a.form_salt * 0xA24BAED4963EE407ull);
             form = qk_pick_form(ctx, key, form_static, admissible, &fmeasure);
         }
     }

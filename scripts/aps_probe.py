@@ -19,6 +19,8 @@ def main():
     dev = torch.device("cuda", 0)
     ctx = Context(0)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    if os.environ.get("APS_FEEDBACK") == "0":
+        ctx.set_form_feedback(False)
     x, cent_true = B.gen_mixture(n, d, nlist, seed=1, device=dev)
     centroids, assign, _ = ctx.kmeans(x, nlist, "l2", niter=5, seed=1234)
     order = torch.argsort(assign, stable=True)
@@ -34,7 +36,7 @@ def main():
         host = (xs.cpu().numpy(), ids.cpu().numpy(), offsets, centroids.cpu().numpy(), q.cpu().numpy())
     del x, xs
     for rt in targets:
-        for _ in range(2):
+        for _ in range(int(os.environ.get("APS_WARMUP", "8"))):  # (the form feedback compares three forms twice per round shape)
             ri, rd, rn, tm = ctx.search_aps(parent, store, q, k, "l2", rt, initial_search_fraction=frac, timing=True)
         torch.cuda.synchronize()
         t0 = time.perf_counter(); reps = 10
@@ -45,6 +47,9 @@ def main():
         out = {"recall_target": rt, "qps": round(Q / el, 1), "ms_per_batch": round(el * 1e3, 3), "recall": round(B.recall_at_k(ri, gi, k), 4),
                "nscan_mean": round(rn.float().mean().item(), 2), "nscan_max": int(rn.max().item()), "rounds": int(tm["n_items"]),
                "M": max(int(np.float32(nlist) * np.float32(frac)), 1)}
+        if os.environ.get("APS_ONLY"):  # (for a kernel trace: the last call's launches are the trace's tail)
+            print(json.dumps(out), flush=True)
+            continue
         # fixed nprobe with the same mean work, for reference
         npb = max(1, int(round(out["nscan_mean"])))
         fi, _ = ctx.search(parent, store, q, npb, k, "l2")
