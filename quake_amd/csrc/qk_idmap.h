@@ -4,6 +4,10 @@
 #include <algorithm>
 #include <cstddef>
 #include <cstdint>
+#include <cstdlib>
+#include <new>
+#include <thread>
+#include <utility>
 #include <vector>
 
 // id -> list number: open addressing, linear probing, power-of-two capacity, 16-byte slots, load <= 0.5 (live + erased).  The store
@@ -16,7 +20,47 @@ struct QkIdMap {
         int32_t val;
         int32_t pad;
     };
-    std::vector<Slot> slots;
+    // the slot array: plain storage whose first touch (page faults of a table of gigabytes) can be shared out over threads
+    struct SlotArray {
+        Slot *p = nullptr;
+        size_t n = 0;
+        SlotArray() = default;
+        SlotArray(const SlotArray &) = delete;
+        SlotArray &operator=(const SlotArray &) = delete;
+        ~SlotArray() { free(p); }
+        size_t size() const { return n; }
+        bool empty() const { return n == 0; }
+        Slot *data() { return p; }
+        Slot &operator[](size_t i) { return p[i]; }
+        const Slot &operator[](size_t i) const { return p[i]; }
+        void clear() {
+            free(p);
+            p = nullptr;
+            n = 0;
+        }
+        void swap(SlotArray &o) {
+            std::swap(p, o.p);
+            std::swap(n, o.n);
+        }
+        void assign_empty(size_t cap, int threads) {  // cap slots, all EMPTY
+            clear();
+            p = (Slot *)malloc(cap * sizeof(Slot));
+            if (!p) throw std::bad_alloc();
+            n = cap;
+            const int T = (int)std::min<size_t>((size_t)std::max(1, threads), std::max<size_t>(1, cap >> 20));
+            auto fill = [this](size_t a, size_t b) {
+                for (size_t i = a; i < b; i++) p[i] = Slot{0, EMPTY, 0};
+            };
+            if (T <= 1) {
+                fill(0, cap);
+                return;
+            }
+            std::vector<std::thread> th;
+            for (int t = 0; t < T; t++) th.emplace_back(fill, cap * (size_t)t / (size_t)T, cap * (size_t)(t + 1) / (size_t)T);
+            for (auto &x : th) x.join();
+        }
+    };
+    SlotArray slots;
     size_t live = 0, used = 0;  // used = live + erased
     static inline uint64_t mix(uint64_t x) {
         x ^= x >> 30;
@@ -31,18 +75,18 @@ struct QkIdMap {
         slots.clear();
         live = used = 0;
     }
-    void rehash(size_t want_live) {
+    void rehash(size_t want_live, int threads = 1) {
         size_t cap = 64;
         while (cap < want_live * 2 + 16) cap <<= 1;
-        std::vector<Slot> old;
+        SlotArray old;
         old.swap(slots);
-        slots.assign(cap, Slot{0, EMPTY, 0});
+        slots.assign_empty(cap, threads);
         live = used = 0;
-        for (const Slot &o : old)
-            if (o.val >= 0) set(o.key, o.val);
+        for (size_t i = 0; i < old.size(); i++)
+            if (old[i].val >= 0) set(old[i].key, old[i].val);
     }
-    void reserve(size_t n) {
-        if (slots.size() < n * 2 + 16) rehash(n);
+    void reserve(size_t n, int threads = 1) {
+        if (slots.size() < n * 2 + 16) rehash(n, threads);
     }
     // slot of `key`, or of the first free slot of its probe sequence (erased slots are reused)
     inline size_t probe(int64_t key, bool &found) const {
@@ -85,6 +129,98 @@ struct QkIdMap {
         slots[i].key = key;
         slots[i].val = val;
         live++;
+    }
+    // Bulk build from segments (every key of segment j maps to vals[j]; a key met again keeps its FIRST segment): the table of
+    // a 50M-id store took 1.8 s to fill from one thread -- the first remove / get_vector after a bulk build paid it.  The table
+    // is cut into `threads` slot ranges; a first sweep (segments shared out) notes every key's owner = the range its probe
+    // sequence starts in; then every thread walks the owner bytes in segment order and inserts its own keys, which keeps the
+    // first-segment rule per key without any locking.  A probe that would leave its range is put aside and inserted at the end.
+    void build_from_segments(const int64_t *const *keys, const int64_t *lens, const int32_t *vals, size_t nseg, int threads) {
+        size_t total = 0;
+        std::vector<size_t> seg_off(nseg + 1, 0);
+        for (size_t j = 0; j < nseg; j++) {
+            total += (size_t)std::max<int64_t>(0, lens[j]);
+            seg_off[j + 1] = total;
+        }
+        clear();
+        reserve(total + 16, threads);
+        if (slots.empty()) rehash(16);
+        const size_t cap = slots.size(), mask = cap - 1;
+        const int T = (int)std::min<size_t>((size_t)std::max(1, std::min(threads, 255)), std::max<size_t>(1, total >> 16));
+        if (T <= 1) {
+            for (size_t j = 0; j < nseg; j++)
+                for (int64_t i = 0; i < lens[j]; i++) set_if_absent(keys[j][i], vals[j]);
+            return;
+        }
+        // range t = slots [cap * t / T, cap * (t + 1) / T)
+        auto owner_of = [&](size_t h) { return (uint8_t)(((unsigned __int128)h * (unsigned)T) / cap); };
+        std::vector<uint8_t> owner(total);
+        {
+            std::vector<std::thread> th;
+            for (int t = 0; t < T; t++)
+                th.emplace_back([&, t]() {
+                    for (size_t j = (size_t)t; j < nseg; j += (size_t)T) {
+                        uint8_t *o = owner.data() + seg_off[j];
+                        const int64_t *kj = keys[j];
+                        for (int64_t i = 0; i < lens[j]; i++) o[i] = owner_of((size_t)mix((uint64_t)kj[i]) & mask);
+                    }
+                });
+            for (auto &x : th) x.join();
+        }
+        std::vector<std::vector<std::pair<int64_t, int32_t>>> aside((size_t)T);
+        std::vector<size_t> made((size_t)T, 0);
+        {
+            std::vector<std::thread> th;
+            for (int t = 0; t < T; t++)
+                th.emplace_back([&, t]() {
+                    const size_t hi = (size_t)(((unsigned __int128)cap * (unsigned)(t + 1)) / (unsigned)T);
+                    Slot *sl = slots.data();
+                    size_t n_made = 0;
+                    constexpr int AHEAD = 16;
+                    struct Pend { int64_t key; size_t h; int32_t val; };
+                    Pend ring[AHEAD];
+                    int head = 0, fill = 0;
+                    auto insert = [&](const Pend &pe) {
+                        size_t i = pe.h;
+                        for (; i < hi; i++) {
+                            if (sl[i].val == EMPTY) {
+                                sl[i].key = pe.key;
+                                sl[i].val = pe.val;
+                                n_made++;
+                                return;
+                            }
+                            if (sl[i].key == pe.key) return;  // met before: the first segment stays
+                        }
+                        aside[(size_t)t].emplace_back(pe.key, pe.val);
+                    };
+                    for (size_t j = 0; j < nseg; j++) {
+                        const uint8_t *o = owner.data() + seg_off[j];
+                        const int64_t *kj = keys[j];
+                        for (int64_t i = 0; i < lens[j]; i++) {
+                            if (o[i] != (uint8_t)t) continue;
+                            Pend pe{kj[i], (size_t)mix((uint64_t)kj[i]) & mask, vals[j]};
+                            __builtin_prefetch(&sl[pe.h], 1);
+                            if (fill == AHEAD) {  // the slot asked for AHEAD keys ago is (likely) here by now
+                                insert(ring[head]);
+                                ring[head] = pe;
+                                head = (head + 1) % AHEAD;
+                            } else {
+                                ring[(head + fill) % AHEAD] = pe;
+                                fill++;
+                            }
+                        }
+                    }
+                    for (int r = 0; r < fill; r++) insert(ring[(head + r) % AHEAD]);
+                    made[(size_t)t] = n_made;
+                });
+            for (auto &x : th) x.join();
+        }
+        for (int t = 0; t < T; t++) {
+            live += made[(size_t)t];
+            used += made[(size_t)t];
+        }
+        for (int t = 0; t < T; t++)
+            for (auto &kv : aside[(size_t)t]) set_if_absent(kv.first, kv.second);
     }
     void set(int64_t key, int32_t val) { put(key, val, true); }
     void set_if_absent(int64_t key, int32_t val) { put(key, val, false); }

@@ -195,6 +195,15 @@ __global__ __launch_bounds__(64) void k_merge_flat(MergeParams M) {
     int *s_slots = (int *)(smem + (((size_t)Cm * 12 + 15) & ~(size_t)15));  // [P][32]
     int *s_recs = s_slots + 64 * QK_SLOTS;                                  // [<= P * 31]
     int *s_recn = s_recs + 64 * (QK_SLOTS - 1);
+    if (P == 1 && M.pair_slots[q * QK_SLOTS] == 0) {
+        // per-pair results (the rounds of a recall-target search): most pairs of a round leave no record at all -- the slot is
+        // padding, or the running bound kept everything out -- and their answer is k empty entries
+        for (int e2 = lane; e2 < k; e2 += 64) {
+            M.out_ids[q * k + e2] = -1;
+            if (M.out_dist) M.out_dist[q * k + e2] = M.metric == QK_METRIC_IP ? -INFINITY : INFINITY;
+        }
+        return;
+    }
     for (int i = lane; i < P * QK_SLOTS; i += 64) s_slots[i] = M.pair_slots[q * P * QK_SLOTS + i];
     __syncthreads();
     const int n_p_raw = lane < P ? s_slots[lane * QK_SLOTS] : 0;
