@@ -81,3 +81,32 @@ def test_aps_many_candidates(ctx):
     np.testing.assert_array_equal(gn, on)
     np.testing.assert_array_equal(gi, oi)
     np.testing.assert_array_equal(gd.view(np.uint32), od.view(np.uint32))
+
+
+@pytest.mark.parametrize("metric", ["l2", "ip"])
+def test_aps_first_round_bound_edges(ctx, metric):
+    """The first round's bound is learnt from a sample of every query's NEAREST list (qk_scan_args::seed_first): lists long enough
+    for the row-per-lane / mixed forms of the per-pair scan, some lists cut below k rows with queries placed right at their
+    centroids (no bound may come from a later list for them), an empty list; twice, so that the form feedback takes another form."""
+    k = 10
+    ivf = make_ivf(100000, 64, 40, seed=31, metric=metric, empty=(5,))
+    offs, keep = ivf["offsets"], np.ones(len(ivf["ids"]), bool)
+    short = [3, 17, 22]
+    for p, cut in zip(short, [0, 4, 9]):
+        keep[int(offs[p]) + cut:int(offs[p + 1])] = False
+    sizes = np.array([keep[int(offs[p]):int(offs[p + 1])].sum() for p in range(40)], np.int64)
+    offs2 = np.zeros(41, np.int64)
+    offs2[1:] = np.cumsum(sizes)
+    ids2, vecs2 = np.ascontiguousarray(ivf["ids"][keep]), np.ascontiguousarray(ivf["vecs"][keep])
+    q = make_queries(600, 64, seed=32, like=ivf["x"], metric=metric)
+    for t, p in enumerate(short):
+        q[t] = ivf["centroids"][p]
+    parent, s = build_stores(ctx, dict(ivf, offsets=offs2, ids=ids2, vecs=vecs2))
+    for rt, frac in [(0.9, 0.5), (0.99, 1.0)]:
+        oi, od, on = O.search_aps(q, ivf["centroids"], vecs2, ids2, offs2, k, metric, rt, initial_search_fraction=frac,
+                                  expanded=True, num_threads=8)
+        for _ in range(4):
+            gi, gd, gn = ctx.search_aps(parent, s, q, k, metric, rt, initial_search_fraction=frac)
+            np.testing.assert_array_equal(gn, on)
+            np.testing.assert_array_equal(gi, oi)
+            np.testing.assert_array_equal(gd.view(np.uint32), od.view(np.uint32))
