@@ -653,6 +653,52 @@ class QuakeIndex:
         uniq, counts = torch.unique(flat, return_counts=True)
         return [int(v) for v in uniq.tolist()], [int(v) for v in counts.tolist()]
 
+    def _reassign_targets_many(self, pids, chunk_rows=1 << 18):
+        """_reassign_targets for many partitions with a handful of device calls instead of two host round trips per partition (a
+        50M index has hundreds of delete candidates per maintenance call): the lists are extracted on the device, one nearest-two
+        search per chunk of ~2^18 rows, one unique over (partition, target) keys.  -> {pid: (pids, counts)}."""
+        pids = [int(p) for p in pids]
+        out = {p: ([], []) for p in pids}
+        if not pids:
+            return out
+        npart = None
+        keys = []
+        batch, batch_rows = [], 0
+
+        def flush():
+            nonlocal batch, batch_rows
+            if not batch:
+                return
+            x = torch.cat([v for _, v in batch], 0)
+            seg = torch.cat([torch.full((v.shape[0],), i, dtype=torch.int64, device=x.device) for i, v in batch])
+            own = torch.tensor([pids[i] for i, _ in batch], dtype=torch.int64, device=x.device)
+            own_row = torch.cat([own[j].expand(v.shape[0]) for j, (_, v) in enumerate(batch)])
+            near, _ = self._ctx.coarse(self.parent._store, x, 2, self.metric_, values=False)
+            ok = (near >= 0) & (near != own_row[:, None])
+            k_ = (seg[:, None] * npart + near)[ok]
+            keys.append(k_)
+            batch, batch_rows = [], 0
+
+        all_ids = [int(v) for v in self._list_ids()]
+        npart = max(all_ids) + 2 if all_ids else 2
+        for i, p in enumerate(pids):
+            v, _ = self._store.get_list_device(p)
+            if v.shape[0] == 0:
+                continue
+            batch.append((i, v))
+            batch_rows += v.shape[0]
+            if batch_rows >= chunk_rows:
+                flush()
+        flush()
+        if keys:
+            uniq, counts = torch.unique(torch.cat(keys), return_counts=True)
+            uniq, counts = uniq.cpu().numpy(), counts.cpu().numpy()
+            segs, tgt = uniq // npart, uniq % npart
+            for sgi in np.unique(segs):
+                m = segs == sgi
+                out[pids[int(sgi)]] = ([int(t) for t in tgt[m]], [int(c) for c in counts[m]])
+        return out
+
     def _neighbour_partitions(self, pids, radius):
         """the partitions whose centroids are among the `radius` nearest of each given partition's centroid, sorted
         (maintenance_policies.cpp:187-202)."""

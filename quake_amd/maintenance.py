@@ -417,6 +417,10 @@ class MaintenancePolicy:
         size_v = np.array([sizes[pid] for pid in all_pids], np.int64)
         hr_v = (np.array([hits.get(pid, 0) for pid in all_pids], np.float32) / np.float32(p.window_size)).astype(np.float64)
         dd_v, sd_v = ce.compute_deltas_many(size_v, hr_v, total_partitions, scan_fraction, avg_size)
+        # the delete candidates that the rejection rule examines: where their vectors would go is asked for all of them at once
+        cand = [pid for ix_, pid in enumerate(all_pids)
+                if float(dd_v[ix_]) < -p.delete_threshold_ns and p.enable_delete_rejection and sizes[pid] > p.min_partition_size]
+        targets = idx._reassign_targets_many(cand) if len(cand) > 1 and hasattr(idx, "_reassign_targets_many") else {}
         for ix_, pid in enumerate(all_pids):
             hit_rate = float(hr_v[ix_])
             size = sizes[pid]
@@ -424,7 +428,7 @@ class MaintenancePolicy:
             if dd < -p.delete_threshold_ns:
                 if p.enable_delete_rejection and size > p.min_partition_size:
                     # where would its vectors go?  second-nearest centroid of every vector (:79-101)
-                    uniq, counts = idx._reassign_targets(pid)
+                    uniq, counts = targets[pid] if pid in targets else idx._reassign_targets(pid)
                     rs = idx._partition_sizes(uniq)
                     hr = [float(np.float32(hits.get(u, 0)) / np.float32(p.window_size)) for u in uniq]
                     delta = ce.compute_delete_delta_w_reassign(size, hit_rate, total_partitions, counts, rs, hr)

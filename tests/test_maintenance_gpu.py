@@ -173,3 +173,26 @@ def test_workload_generation_and_evaluation(tmp_path):  # cf. test/python/test_w
     got = walk(torch.arange(20), 7)
     assert got.shape[0] == 7 and (cluster_of[got] == root0).sum() == 5  # the whole root cluster, then its neighbour
     assert walk.root != root0
+
+
+def test_reassign_targets_of_many_partitions_at_once():
+    """QuakeIndex._reassign_targets_many (the delete candidates of one maintenance call asked together: lists extracted on the device,
+    one nearest-two search per chunk, one unique) == _reassign_targets partition by partition -- with chunks of one, several and
+    all partitions, an empty partition among them."""
+    import quake_amd as quake
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(30000, 24, generator=g)
+    idx = quake.QuakeIndex()
+    bp = quake.IndexBuildParams()
+    bp.nlist = 50
+    idx.build(x, torch.arange(30000), bp)
+    pids = [int(p) for p in idx._list_ids()][:23]
+    idx.remove(torch.from_numpy(idx._store.get_list_ids(pids[4])))  # an empty one
+    assert idx._store.list_size(pids[4]) == 0
+    one = {p: idx._reassign_targets(p) for p in pids}
+    for chunk in (1, 2000, 1 << 18):
+        many = idx._reassign_targets_many(pids, chunk_rows=chunk)
+        assert set(many) == set(pids)
+        for p in pids:
+            assert dict(zip(*many[p])) == dict(zip(*one[p])), (p, chunk)
+    assert many[pids[4]] == ([], [])
