@@ -339,6 +339,51 @@ shared_ptr<MaintenanceTimingInfo> MaintenancePolicy::perform_maintenance() {  //
     };
     std::vector<int64_t> to_delete, to_split;
     const auto &ce = *cost_estimator_;
+    // where would a delete candidate's vectors go?  the nearest OTHER centroid of every vector (:79-101) -- asked for ALL the
+    // candidates the rejection rule examines at once: their lists are extracted on the device, one nearest-two search per chunk of
+    // rows, counted per candidate from plain arrays (two host round trips and 5000 tensor element reads per candidate before: a 50M
+    // index has hundreds of candidates per call)
+    std::vector<int64_t> cand;
+    for (const auto &kv : sizes) {
+        const double dd = ce.compute_delete_delta((int)kv.second, hit_rate_of(kv.first), total_partitions, scan_fraction, avg_size);
+        if (dd < -p.delete_threshold_ns && p.enable_delete_rejection && (int)kv.second > p.min_partition_size) cand.push_back(kv.first);
+    }
+    std::map<int64_t, std::map<int64_t, int64_t>> targets;
+    {
+        const int64_t chunk_rows = (int64_t)1 << 18;
+        const int dev = 0;  // (pm.ctx() is the shared context of device 0; a group hands a list out on its lead, device 0 too)
+        const auto fopt = torch::TensorOptions().dtype(torch::kFloat32).device(torch::kCUDA, dev);
+        const auto iopt = torch::TensorOptions().dtype(torch::kInt64).device(torch::kCUDA, dev);
+        size_t c0 = 0;
+        while (c0 < cand.size()) {
+            size_t c1 = c0;
+            int64_t rows = 0;
+            while (c1 < cand.size() && (rows == 0 || rows + sizes[cand[c1]] <= chunk_rows)) rows += sizes[cand[c1++]];
+            if (rows > 0) {
+                Tensor x = torch::empty({rows, (int64_t)pm.d()}, fopt), near = torch::empty({rows, 2}, iopt);
+                int64_t at = 0;
+                for (size_t c = c0; c < c1; c++) {
+                    const int64_t n = sizes[cand[c]];
+                    if (n > 0) qk_check(pm.lists().get_list(cand[c], x.data_ptr<float>() + at * pm.d(), nullptr, QK_MEM_DEVICE));
+                    at += n;
+                }
+                qk_check(qk_coarse(pm.ctx(), pm.parent_->store(), x.data_ptr<float>(), rows, 2, pm.metric_, near.data_ptr<int64_t>(), nullptr,
+                                   QK_MEM_DEVICE));
+                qk_check(qk_ctx_synchronize(pm.ctx()));
+                Tensor nh = near.cpu();
+                const int64_t *np_ = nh.data_ptr<int64_t>();
+                at = 0;
+                for (size_t c = c0; c < c1; c++) {
+                    auto &counts = targets[cand[c]];
+                    const int64_t n = sizes[cand[c]];
+                    for (int64_t i = at * 2; i < (at + n) * 2; i++)
+                        if (np_[i] >= 0 && np_[i] != cand[c]) counts[np_[i]]++;
+                    at += n;
+                }
+            }
+            c0 = c1;
+        }
+    }
     for (const auto &kv : sizes) {
         const int64_t pid = kv.first;
         const int size = (int)kv.second;
@@ -346,18 +391,7 @@ shared_ptr<MaintenanceTimingInfo> MaintenancePolicy::perform_maintenance() {  //
         const double dd = ce.compute_delete_delta(size, hr, total_partitions, scan_fraction, avg_size);
         if (dd < -p.delete_threshold_ns) {
             if (p.enable_delete_rejection && size > p.min_partition_size) {
-                // where would its vectors go?  the nearest OTHER centroid of every vector (:79-101)
-                auto sel = pm.select_partitions(torch::tensor({pid}, torch::kInt64));
-                Tensor v = sel->vectors[0];
-                Tensor near = torch::empty({v.size(0), 2}, torch::kInt64);
-                qk_check(qk_coarse(pm.ctx(), pm.parent_->store(), v.data_ptr<float>(), v.size(0), 2, pm.metric_, near.data_ptr<int64_t>(), nullptr,
-                                   QK_MEM_HOST));
-                std::map<int64_t, int64_t> counts;
-                for (int64_t i = 0; i < near.size(0); i++)
-                    for (int64_t j = 0; j < 2; j++) {
-                        const int64_t t = near[i][j].item<int64_t>();
-                        if (t >= 0 && t != pid) counts[t]++;
-                    }
+                const auto &counts = targets[pid];
                 std::vector<int64_t> rc, rs;
                 std::vector<float> rh;
                 for (const auto &c : counts) {
