@@ -1,0 +1,35 @@
+"""ms per step of the headline search (10M x 128, 4096 lists, 1024 queries, nprobe 1, k = 10) with whatever library QUAKE_HIP_LIB
+names: for A/B runs of a side library (scripts/build_variant.sh) against the product on one box, processes alternating:
+    for i in 1 2 3; do python scripts/step_ab.py; QUAKE_HIP_LIB=quake_amd/lib/libquake_hip_x.so python scripts/step_ab.py; done"""
+import json, os, sys, time
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench as B
+from quake_amd.capi import Context
+
+nprobe = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+dev = torch.device("cuda", 0)
+ctx = Context(0)
+ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+n, d, nlist, Q, k = 10_000_000, 128, 4096, 1024, 10
+x, cent = B.gen_mixture(n, d, nlist, seed=1, device=dev)
+idx = B.build_single(ctx, dev, x, nlist, "l2", 5, keep_host=False)
+del x
+qs = [B.gen_queries(Q, cent, seed=2 + b, device=dev) for b in range(4)]
+out = (torch.empty((Q, k), dtype=torch.int64, device=dev), torch.empty((Q, k), dtype=torch.float32, device=dev))
+
+
+def block(steps=200):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        ctx.search(idx["parent"], idx["store"], qs[i % 4], nprobe, k, "l2", out=out)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps * 1e3
+
+
+block(300)
+ms = sorted(block(200) for _ in range(9))
+chk = int(out[0].sum().item())
+print(json.dumps({"lib": os.environ.get("QUAKE_HIP_LIB", "product"), "nprobe": nprobe, "ms_per_step_median": round(ms[4], 5), "min": round(ms[0], 5),
+                  "max": round(ms[-1], 5), "ids_checksum": chk}))
