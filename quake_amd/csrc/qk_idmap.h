@@ -10,6 +10,24 @@
 #include <utility>
 #include <vector>
 
+// fn(0) ... fn(T - 1) on T threads: T - 1 new ones and the caller's own; shares whose thread could not be started (resource limits)
+// run on the caller's thread too, so the work is always done
+template <class F>
+static inline void qk_run_shares(int T, F &&fn) {
+    std::vector<std::thread> th;
+    th.reserve((size_t)std::max(0, T - 1));
+    int started = 0;
+    for (; started < T - 1; started++) {
+        try {
+            th.emplace_back(fn, started);
+        } catch (...) {
+            break;
+        }
+    }
+    for (int t = started; t < T; t++) fn(t);
+    for (auto &x : th) x.join();
+}
+
 // id -> list number: open addressing, linear probing, power-of-two capacity, 16-byte slots, load <= 0.5 (live + erased).  The store
 // inserts / erases hundreds of thousands of ids per add / remove call: a node-based std::unordered_map spent more time in
 // its allocator than the device spent on the rows.
@@ -55,9 +73,7 @@ struct QkIdMap {
                 fill(0, cap);
                 return;
             }
-            std::vector<std::thread> th;
-            for (int t = 0; t < T; t++) th.emplace_back(fill, cap * (size_t)t / (size_t)T, cap * (size_t)(t + 1) / (size_t)T);
-            for (auto &x : th) x.join();
+            qk_run_shares(T, [&](int t) { fill(cap * (size_t)t / (size_t)T, cap * (size_t)(t + 1) / (size_t)T); });
         }
     };
     SlotArray slots;
@@ -155,24 +171,17 @@ struct QkIdMap {
         // range t = slots [cap * t / T, cap * (t + 1) / T)
         auto owner_of = [&](size_t h) { return (uint8_t)(((unsigned __int128)h * (unsigned)T) / cap); };
         std::vector<uint8_t> owner(total);
-        {
-            std::vector<std::thread> th;
-            for (int t = 0; t < T; t++)
-                th.emplace_back([&, t]() {
-                    for (size_t j = (size_t)t; j < nseg; j += (size_t)T) {
-                        uint8_t *o = owner.data() + seg_off[j];
-                        const int64_t *kj = keys[j];
-                        for (int64_t i = 0; i < lens[j]; i++) o[i] = owner_of((size_t)mix((uint64_t)kj[i]) & mask);
-                    }
-                });
-            for (auto &x : th) x.join();
-        }
+        qk_run_shares(T, [&](int t) {
+            for (size_t j = (size_t)t; j < nseg; j += (size_t)T) {
+                uint8_t *o = owner.data() + seg_off[j];
+                const int64_t *kj = keys[j];
+                for (int64_t i = 0; i < lens[j]; i++) o[i] = owner_of((size_t)mix((uint64_t)kj[i]) & mask);
+            }
+        });
         std::vector<std::vector<std::pair<int64_t, int32_t>>> aside((size_t)T);
         std::vector<size_t> made((size_t)T, 0);
         {
-            std::vector<std::thread> th;
-            for (int t = 0; t < T; t++)
-                th.emplace_back([&, t]() {
+            qk_run_shares(T, [&](int t) {
                     const size_t hi = (size_t)(((unsigned __int128)cap * (unsigned)(t + 1)) / (unsigned)T);
                     Slot *sl = slots.data();
                     size_t n_made = 0;
@@ -213,7 +222,6 @@ struct QkIdMap {
                     for (int r = 0; r < fill; r++) insert(ring[(head + r) % AHEAD]);
                     made[(size_t)t] = n_made;
                 });
-            for (auto &x : th) x.join();
         }
         for (int t = 0; t < T; t++) {
             live += made[(size_t)t];

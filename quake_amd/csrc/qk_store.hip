@@ -778,10 +778,7 @@ int qk_store_remove_ids(qk_store *s, int64_t n, const int64_t *ids_host, int64_t
             removed = o.removed;
         } else {
             std::vector<SweepOut> outs((size_t)T);
-            std::vector<std::thread> th;
-            for (int t = 0; t < T; t++)
-                th.emplace_back(sweep, work.size() * (size_t)t / (size_t)T, work.size() * (size_t)(t + 1) / (size_t)T, std::ref(outs[(size_t)t]));
-            for (auto &x : th) x.join();
+            qk_run_shares(T, [&](int t) { sweep(work.size() * (size_t)t / (size_t)T, work.size() * (size_t)(t + 1) / (size_t)T, outs[(size_t)t]); });
             for (auto &o : outs) {
                 mv_dst.insert(mv_dst.end(), o.dst.begin(), o.dst.end());
                 mv_src.insert(mv_src.end(), o.src.begin(), o.src.end());
