@@ -454,7 +454,7 @@ extern "C" int qk_search_aps(qk_ctx *ctx, qk_store *parent, qk_store *s, const f
         sa.out_ids = r.pr_ids;
         sa.out_dist = r.pr_key;
         sa.per_pair = true;
-        sa.form_salt = 1 + std::min(r.round, 2);  // the first round (a few lists, no bound yet) is not the later ones' workload
+        sa.form_salt = 1 + std::min(r.round, 6);  // every round is a workload of its own (fewer queries go on, with other bounds)
         sa.tau_init = r.run_tau;
         sa.seed_first = r.round == 0;  // (no running result yet: the bound comes from a sample of every query's nearest list)
         sa.sqrt_l2 = false;  // merge keys: squared distances
@@ -486,7 +486,10 @@ int qk_aps_run(qk_ctx *ctx, qk_store *parent, int64_t nlist, int d, const float 
     hipStream_t st = ctx->stream;
     static const int aps_ch = std::max(2, qk_env_int("QK_APS_CH", APS_CH));
     static const int aps_first = std::max(2, qk_env_int("QK_APS_FIRST", APS_FIRST));
-    const int CH = std::min(aps_ch, M);
+    // rows of a later round: as long as the walk may get (M), memory permitting (1 GiB of per-pair results) -- a query takes what its
+    // profile predicts, and a cap under the walk's length costs a further pass over the lists (M = 204 on the bench index: walks
+    // of 118 lists on average, cap 80 -> 4 rounds, 3.7 ms)
+    const int CH = std::min(M, std::max(aps_ch, (int)std::min<size_t>((size_t)M, ((size_t)1 << 30) / ((size_t)Q * (size_t)k * 12))));
 
     // ---- partition id -> arena row of its centroid (host mirror of the parent's ids) and the table of the precomputed path
     // (geometry.h:163-180): both live on the device from one call to the next -- rebuilt when the parent changed (its version is

@@ -920,7 +920,7 @@ int qk_group_search_aps(qk_group *g, qk_store *parent, const float *x, int64_t Q
             sa.out_ids = ib(mb);
             sa.out_dist = kb(mb);
             sa.per_pair = true;
-            sa.form_salt = 1 + std::min(r.round, 2);
+            sa.form_salt = 1 + std::min(r.round, 6);
             sa.tau_init = tj;
             sa.seed_first = r.round == 0;  // (a member that holds the query's nearest list learns a bound for its pairs of that query)
             sa.sqrt_l2 = false;
