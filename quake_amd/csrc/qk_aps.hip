@@ -250,38 +250,68 @@ __global__ __launch_bounds__(64) void k_aps_update(UpdateParams U) {
     const int p0 = U.next_p[q];
     bool stop = false;
     int nscan = p0;
-    // The walk is a chain of dependent steps; what it reads from global memory -- the next pair's entries and its partition number
-    // -- is requested one step ahead, so a step waits for loads issued a whole step earlier (the step itself touches LDS only).
-    int64_t pf_id = -1, pf_pid = -1;
+    // The walk is a chain of dependent steps.  What it needs from global memory is found out up front, 64 pairs per round trip:
+    // which steps have a partition at all (pids != -1) and which pairs hold any entry (a pair's entries are sorted, valid ones
+    // first: entry 0 decides) -- most pairs of a later round hold none, their steps touch LDS only.  The entries of the pairs that
+    // do hold some are requested one non-empty pair ahead.
+    uint64_t *m_valid = (uint64_t *)(bdl + M);            // [ceil(w / 64)] step has a partition  (2k * 12 + 8M bytes in: 8-byte aligned)
+    uint64_t *m_full = m_valid + ((U.CHr + 63) >> 6);      // [ceil(w / 64)] ... and its pair holds entries
+    const int wsteps = min(w, M - p0);
+    for (int base = 0; base < wsteps; base += 64) {
+        const int i = base + lane;
+        bool va = false, fu = false;
+        if (i < wsteps) {
+            va = U.pids[q * M + p0 + i] != -1;
+            fu = va && U.pr_ids[(q * U.CHr + i) * k] >= 0;
+        }
+        const uint64_t bv = __ballot(va), bf = __ballot(fu);
+        if (lane == 0) {
+            m_valid[base >> 6] = bv;
+            m_full[base >> 6] = bf;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    auto next_full = [&](int from) -> int {  // first step >= from whose pair holds entries, or wsteps
+        for (int wd = from >> 6; wd < ((wsteps + 63) >> 6); wd++) {
+            uint64_t bits = m_full[wd];
+            if (wd == (from >> 6)) bits &= ~0ull << (from & 63);
+            if (bits) return (wd << 6) + __ffsll((unsigned long long)bits) - 1;
+        }
+        return wsteps;
+    };
+    int64_t pf_id = -1;
     float pf_key = 0.0f;
+    int pf_at = next_full(0);
     auto fetch = [&](int i) {
         pf_id = -1;
-        pf_pid = -1;
-        if (i < w && p0 + i < M) {
-            pf_pid = U.pids[q * M + p0 + i];
-            if (lane < k) {
-                pf_id = U.pr_ids[(q * U.CHr + i) * k + lane];
-                pf_key = U.pr_key[(q * U.CHr + i) * k + lane];
-            }
+        if (i < wsteps && lane < k) {
+            pf_id = U.pr_ids[(q * U.CHr + i) * k + lane];
+            pf_key = U.pr_key[(q * U.CHr + i) * k + lane];
         }
     };
-    fetch(0);
+    fetch(pf_at);
     // the estimate of step p is the sum of probs[0 .. p) taken in order from 0.0f: while the profile stands, the chain is continued
     // from where the previous step left it (the same additions in the same order)
     float est_run = 0.0f;
     int est_n = 0;
-    for (int i = 0; i < w && p0 + i < M; i++) {
+    for (int i = 0; i < wsteps; i++) {
         const int p = p0 + i;
         nscan = p + 1;
-        const int64_t c_id = pf_id, c_pid = pf_pid;
-        const float c_key = pf_key;
-        fetch(i + 1);
-        if (c_pid == -1) continue;  // query_coordinator.cpp:540
+        if (!((m_valid[i >> 6] >> (i & 63)) & 1ull)) continue;  // query_coordinator.cpp:540
+        int64_t c_id = -1;
+        float c_key = 0.0f;
+        const bool full = i == pf_at;
+        if (full) {
+            c_id = pf_id;
+            c_key = pf_key;
+            pf_at = next_full(i + 1);
+            fetch(pf_at);
+        }
         // merge this partition's top-k into the running one
         const int64_t *nid = U.pr_ids + (q * U.CHr + i) * k;
         const float *nkey = U.pr_key + (q * U.CHr + i) * k;
         int added = 0;
-        for (int base = 0; base < k; base += 64) {
+        for (int base = 0; full && base < k; base += 64) {
             const int e = base + lane;
             int64_t id = -1;
             uint32_t o = 0xFFFFFFFFu;
@@ -648,7 +678,7 @@ int qk_aps_run(qk_ctx *ctx, qk_store *parent, int64_t nlist, int d, const float 
     up.out_ids = d_out_ids;
     up.out_dist = d_out_dist;
     up.sqrt_l2 = ctx->squared_l2 ? 0 : 1;
-    const size_t lds_up = (size_t)2 * k * 12 + (size_t)M * 8 + 64;
+    const size_t lds_up = (size_t)2 * k * 12 + (size_t)M * 8 + 64 + (size_t)2 * ((CH + 63) / 64 + 1) * 8;
     const int maxch_u = 2 * k <= 64 ? 1 : 2 * k <= 128 ? 2 : 2 * k <= 256 ? 4 : 2 * k <= 512 ? 8 : 16;
     {  // (once per call, not per round)
         switch (maxch_u) {
