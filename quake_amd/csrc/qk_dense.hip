@@ -1082,7 +1082,12 @@ int qk_dense_device(qk_ctx *ctx, qk_store *s, int64_t list_no, const qk_scan_arg
     }
     const int64_t ld = qk_round_up64(std::max(nrows, 1), 16);
     const int Cm = qk_round_up(k + 64, 64);
-    const bool large_k = Cm > 1024;  // beyond the LDS pool machinery: bisection select + sort (k_select_rows_large)
+    // beyond the LDS pool machinery: bisection select + sort (k_select_rows_large).  Also where it is simply faster: its cost is ~32
+    // counting passes over the key row whatever k is, the pool selection's grows with k (1024 queries, us per coarse call, pool
+    // form -> bisection; 4096 rows: k = 100 92 -> 90, 150 124 -> 91, 204 206 -> 90, 256 436 -> 91, 819 1927 -> 117; 16384 rows:
+    // 204 292 -> 489, 256 973 -> 491, 819 2720 -> 1039; scripts/coarse_probe.py)
+    // (its tie cut orders ids as unsigned: taken early only for stores without negative ids)
+    const bool large_k = Cm > 1024 || (s->min_id_seen >= 0 && ((k >= 96 && nrows <= 8192) || (k >= 224 && nrows <= 32768)));
     if (k > QK_MAX_NPROBE) QK_FAIL(QK_ERR_UNSUPPORTED, "dense scan: k=%d exceeds QK_MAX_NPROBE=%d", k, QK_MAX_NPROBE);
     const int mc = Cm <= 128 ? 2 : Cm <= 256 ? 4 : Cm <= 512 ? 8 : 16;
     // query batching keeps the key matrix under 1 GiB
