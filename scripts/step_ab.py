@@ -8,10 +8,13 @@ import bench as B
 from quake_amd.capi import Context
 
 nprobe = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+k_arg = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 dev = torch.device("cuda", 0)
 ctx = Context(0)
 ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-n, d, nlist, Q, k = 10_000_000, 128, 4096, 1024, 10
+if os.environ.get("STEP_FEEDBACK") == "0":  # the static form rule alone
+    ctx.set_form_feedback(False)
+n, d, nlist, Q, k = 10_000_000, 128, 4096, 1024, k_arg
 x, cent = B.gen_mixture(n, d, nlist, seed=1, device=dev)
 idx = B.build_single(ctx, dev, x, nlist, "l2", 5, keep_host=False)
 del x
@@ -31,5 +34,5 @@ def block(steps=200):
 block(300)
 ms = sorted(block(200) for _ in range(9))
 chk = int(out[0].sum().item())
-print(json.dumps({"lib": os.environ.get("QUAKE_HIP_LIB", "product"), "nprobe": nprobe, "ms_per_step_median": round(ms[4], 5), "min": round(ms[0], 5),
+print(json.dumps({"lib": os.environ.get("QUAKE_HIP_LIB", "product"), "nprobe": nprobe, "k": k, "feedback": os.environ.get("STEP_FEEDBACK", "1"), "ms_per_step_median": round(ms[4], 5), "min": round(ms[0], 5),
                   "max": round(ms[-1], 5), "ids_checksum": chk}))
