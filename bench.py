@@ -590,6 +590,41 @@ def run_single_workload(ctx, dev, args, name, sigma, fixed_nprobe, steps, warmup
     }
     if sweep_res:
         res["nprobe_sweep"] = sweep_res
+    # the recall-target search (adaptive partition scanning, SearchParams.recall_target > 0) on the same index: rounds on the
+    # device, the reference's defaults (initial_search_fraction 0.02, recompute_threshold 0.001, precomputed table)
+    aps_res = None
+    if sweep_nprobes and k <= 32:
+        rt = 0.9
+        for _ in range(8):  # (the form feedback compares its forms per round shape first)
+            ai, ad, an, atm = ctx.search_aps(parent, store, batches[0], k, metric, rt, timing=True)
+        torch.cuda.synchronize()
+        tt = []
+        for gidx in range(5):
+            t1 = time.perf_counter()
+            for i in range(10):
+                ctx.search_aps(parent, store, batches[i % N_BATCHES], k, metric, rt)
+            torch.cuda.synchronize()
+            tt.append((time.perf_counter() - t1) / 10)
+        tt.sort()
+        ai, ad, an = ctx.search_aps(parent, store, batches[0], k, metric, rt)
+        torch.cuda.synchronize()
+        npe = max(1, int(round(float(an.float().mean().item()))))  # the fixed search that scans as many lists per query
+        for i in range(8):
+            step(npe, i % N_BATCHES)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(20):
+            step(npe, i % N_BATCHES)
+        torch.cuda.synchronize()
+        fixed_qps = Q * 20 / (time.perf_counter() - t1)
+        aps_res = {"recall_target": rt, "value": round(Q / tt[2], 1), "unit": "queries/s", "ms_per_step": round(1e3 * tt[2], 4),
+                   "steps": "median of 5 groups of 10", "recall_at_k": round(recall_at_k(ai, gts[0], k), 4),
+                   "partitions_scanned_mean": round(float(an.float().mean().item()), 2), "partitions_scanned_max": int(an.max().item()),
+                   "rounds": int(atm["n_items"]), "candidates": max(int(np.float32(nlist) * np.float32(0.02)), 1),
+                   "fixed_nprobe_of_equal_work": {"nprobe": npe, "value": round(fixed_qps, 1), "unit": "queries/s"},
+                   "note": "qk_search_aps: results and partitions visited are those of the reference's sequential walk "
+                           "(query_coordinator.cpp:529-579)"}
+        res["recall_target_search"] = aps_res
     # ---- parity + CPU baseline: the oracle port on the host cores (test infrastructure used as checker / timed port) ----
     if want_cpu:
         import oracle as O
@@ -669,6 +704,15 @@ def run_single_workload(ctx, dev, args, name, sigma, fixed_nprobe, steps, warmup
             "timed_serial_leg_ids_agree_frac": round(float((ids_s == gi0).mean()), 5),
         }
         res["speedup_vs_cpu"] = round(res["value"] / res["cpu_baseline"]["value"], 1)
+        if aps_res is not None:  # in-run parity of the recall-target search: the oracle's walk over a sample of the batch
+            nqa = 128
+            oi, od, on = O.search_aps(qh[:nqa], hc, hv, hi, ho, k, metric, aps_res["recall_target"], expanded=True, num_threads=cores)
+            ga, gn = ai[:nqa].cpu().numpy(), an[:nqa].cpu().numpy()
+            gdd = ad[:nqa].cpu().numpy()
+            okp = bool(np.array_equal(ga, oi) and np.array_equal(gn, on) and np.array_equal(gdd.view(np.uint32), od.view(np.uint32)))
+            aps_res["parity_sample"] = f"{nqa} queries vs the oracle's walk: ids, distance bits and partitions visited equal = {okp}"
+            if not okp:
+                raise SystemExit(f"[{name}] PARITY FAILURE: qk_search_aps differs from the oracle's walk on the bench batch")
         if inflight > 1:  # the other stream's answer for the same batch: the same bits
             gi1, gd1 = step(nprobe, 0, 1)
             ctxs[1].synchronize()
@@ -1243,6 +1287,8 @@ def main():
                 # the headline index at fixed nprobe 8 / 16 / 32: the regime where a probed list is shared by many queries of the
                 # batch (the mixed work sequence of the row-per-lane scan), each line with its own roofline
                 extra["nprobe_sweep"] = main_res["nprobe_sweep"]
+            if main_res.get("recall_target_search"):
+                extra["recall_target_search"] = main_res["recall_target_search"]
             result["workloads"] = extra
 
     log(f"total bench wall {time.time() - t_all:.1f}s")
