@@ -750,6 +750,29 @@ def run_configs0(ctx, dev, args):
         ctx.search(parent, store, qs[i], nprobe, k, "l2", out=(out_i, out_d))
     torch.cuda.synchronize()
     t_pipe = time.perf_counter() - t0
+    # (a') the same searches spread over four contexts (own HIP stream each, the same stores): what several client threads of the
+    # reference's batch = 1 traffic amount to -- single-query launches of ~50 workgroups run side by side on the 256 CUs
+    from quake_amd.capi import Context
+    NS = 4
+    cs = [ctx] + [Context(dev.index) for _ in range(NS - 1)]
+    ids_ms = torch.empty((nq, k), dtype=torch.int64, device=dev)
+    dist_ms = torch.empty((nq, k), dtype=torch.float32, device=dev)
+    for i in range(4 * NS):
+        cs[i % NS].search(parent, store, qs[i], nprobe, k, "l2", out=(ids_ms[i:i + 1], dist_ms[i:i + 1]))
+    for c in cs:
+        c.synchronize()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(nq):
+        cs[i % NS].search(parent, store, qs[i], nprobe, k, "l2", out=(ids_ms[i:i + 1], dist_ms[i:i + 1]))
+    for c in cs:
+        c.synchronize()
+    torch.cuda.synchronize()
+    t_ms = time.perf_counter() - t0
+    if not torch.equal(ids_ms, ids_all):
+        raise SystemExit("[configs0] PARITY FAILURE: the four-stream run's ids differ from the one-stream run's")
+    for c in cs[1:]:
+        c.close()
     # (b) one query at a time, synchronised: latency as a caller sees it
     lat = []
     for i in range(min(nq, 200)):
@@ -776,6 +799,8 @@ def run_configs0(ctx, dev, args):
         "note": "batch=1 searches issued back to back on one stream (device buffers), one synchronisation at the end",
         "latency_us_synchronised": {"p50": round(float(np.percentile(lat, 50)), 1), "p99": round(float(np.percentile(lat, 99)), 1)},
         "batch_1000_qps": round(nq / t_batch, 1),
+        "four_streams": {"value": round(nq / t_ms, 1), "unit": "queries/s",
+                         "note": "the same batch = 1 searches round-robin over four contexts (one HIP stream each), ids equal to the one-stream run's"},
     }
     if not args.no_cpu:
         import oracle as O
