@@ -291,3 +291,55 @@ def test_remove_of_an_id_held_many_times(ctx):
     np.testing.assert_array_equal(gi, oi)
     np.testing.assert_array_equal(gd.view(np.uint32), od.view(np.uint32))
     s.close()
+
+
+def test_large_removals_take_the_threaded_paths(ctx):
+    """Millions of rows: the id index is built by several threads (QkIdMap::build_from_segments) and a removal's touched lists are
+    swept by several threads (qk_store_remove_ids) -- same lists, same row order as the one-thread semantics (numpy model of the
+    swap-with-last sweep per list), ids held twice included; get_vector and a second removal go through the built index."""
+    from quake_amd.capi import Store
+    rng = np.random.default_rng(77)
+    d, nlist, n = 4, 900, 4_300_000
+    sizes = rng.integers(3000, 6500, nlist)
+    sizes = (sizes * (n / sizes.sum())).astype(np.int64)
+    n = int(sizes.sum())
+    offs = np.zeros(nlist + 1, np.int64)
+    offs[1:] = np.cumsum(sizes)
+    ids = rng.permutation(n).astype(np.int64)
+    ids[offs[7]] = ids[offs[3]]  # one id held by two lists (the first one answers get_vector; a removal takes both)
+    vecs = rng.standard_normal((n, d)).astype(np.float32)
+    s = Store(ctx, d)
+    s.build_csr(offs, ids, vecs)
+    kill = rng.choice(n, 600_000, replace=False).astype(np.int64)
+    kill[0] = ids[offs[3]]
+    removed = s.remove_ids(kill)
+
+    def model(list_ids, killset):  # the sweep of one list: swap-with-last, re-examine
+        cur = list(list_ids)
+        i = 0
+        while i < len(cur):
+            if cur[i] in killset:
+                cur[i] = cur[-1]
+                cur.pop()
+            else:
+                i += 1
+        return cur
+
+    killset = set(int(v) for v in kill)
+    present = np.isin(ids, kill)
+    assert removed == int(present.sum())
+    assert s.ntotal() == n - removed
+    for p in list(rng.choice(nlist, 25, replace=False)) + [3, 7]:
+        want = model(ids[offs[p]:offs[p + 1]].tolist(), killset)
+        gv, gi = s.get_list(int(p))
+        assert gi.tolist() == want
+        pos = {int(v): t for t, v in enumerate(ids[offs[p]:offs[p + 1]])}
+        np.testing.assert_array_equal(gv, vecs[offs[p] + np.array([pos[v] for v in want], np.int64)] if want else np.zeros((0, d), np.float32))
+    # the index built for the removal answers lookups; removed ids are gone, a second removal finds nothing
+    alive = ids[~present]
+    for v in alive[rng.choice(len(alive), 50, replace=False)]:
+        row = int(np.nonzero(ids == v)[0][0])
+        np.testing.assert_array_equal(s.get_vector(int(v)), vecs[row])
+    assert s.get_vector(int(kill[5])) is None
+    assert s.remove_ids(kill[:1000]) == 0
+    s.close()
