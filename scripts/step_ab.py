@@ -14,9 +14,10 @@ ctx = Context(0)
 ctx.set_stream(torch.cuda.current_stream().cuda_stream)
 if os.environ.get("STEP_FEEDBACK") == "0":  # the static form rule alone
     ctx.set_form_feedback(False)
-n, d, nlist, Q, k = 10_000_000, 128, 4096, 1024, k_arg
+n, d, nlist, Q, k = 10_000_000, int(os.environ.get("STEP_DIM", "128")), 4096, 1024, k_arg
+metric = os.environ.get("STEP_METRIC", "l2")
 x, cent = B.gen_mixture(n, d, nlist, seed=1, device=dev)
-idx = B.build_single(ctx, dev, x, nlist, "l2", 5, keep_host=False)
+idx = B.build_single(ctx, dev, x, nlist, metric, 5, keep_host=False)
 del x
 qs = [B.gen_queries(Q, cent, seed=2 + b, device=dev) for b in range(4)]
 out = (torch.empty((Q, k), dtype=torch.int64, device=dev), torch.empty((Q, k), dtype=torch.float32, device=dev))
@@ -26,7 +27,7 @@ def block(steps=200):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(steps):
-        ctx.search(idx["parent"], idx["store"], qs[i % 4], nprobe, k, "l2", out=out)
+        ctx.search(idx["parent"], idx["store"], qs[i % 4], nprobe, k, metric, out=out)
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / steps * 1e3
 
@@ -34,5 +35,5 @@ def block(steps=200):
 block(300)
 ms = sorted(block(200) for _ in range(9))
 chk = int(out[0].sum().item())
-print(json.dumps({"lib": os.environ.get("QUAKE_HIP_LIB", "product"), "nprobe": nprobe, "k": k, "feedback": os.environ.get("STEP_FEEDBACK", "1"), "ms_per_step_median": round(ms[4], 5), "min": round(ms[0], 5),
+print(json.dumps({"lib": os.environ.get("QUAKE_HIP_LIB", "product"), "d": d, "metric": metric, "nprobe": nprobe, "k": k, "kernel": ctx.last_scan_kernel(), "feedback": os.environ.get("STEP_FEEDBACK", "1"), "ms_per_step_median": round(ms[4], 5), "min": round(ms[0], 5),
                   "max": round(ms[-1], 5), "ids_checksum": chk}))
