@@ -137,31 +137,81 @@ __global__ __launch_bounds__(256) void k_aps_boundary(BoundaryParams B) {
         return;
     }
     const float *xq = B.x + q * B.d;
+    // a row's 16 columns of block c are four float4 of the tile-major arena (float4 g' holds columns 16c + {g', 4+g', 8+g', 12+g'}):
+    // read as float4 -- a quarter of the loads of an element-by-element walk -- and fed to the chains in column order
+    const float4 *v4 = (const float4 *)B.cvecs;
+    const int64_t t0 = r0 >> 4, tj = rj >> 4;
+    const int rr0 = (int)(r0 & 15), rrj = (int)(rj & 15);
+    const int nblk = B.cnblk;
     float out;
     if (B.euclid) {
         float a2 = 0.0f, dot = 0.0f;
-        for (int i = 0; i < B.d; i++) {
-            const float c0 = arena_at(B.cvecs, B.cnblk, r0, i);
-            const float v = arena_at(B.cvecs, B.cnblk, rj, i) - c0;  // line vector c_j - c_0
-            const float res = xq[i] - c0;                            // residual q - c_0
-            a2 = __fmaf_rn(v, v, a2);
-            dot = __fmaf_rn(res, v, dot);
+        for (int c = 0; c < nblk; c++) {
+            float4 f0[4], fj[4];
+#pragma unroll
+            for (int gq = 0; gq < 4; gq++) {
+                f0[gq] = v4[(t0 * nblk + c) * 64 + gq * 16 + rr0];
+                fj[gq] = v4[(tj * nblk + c) * 64 + gq * 16 + rrj];
+            }
+#pragma unroll
+            for (int t = 0; t < 16; t++) {
+                const int i = 16 * c + t;
+                if (i < B.d) {
+                    const float4 a = f0[t & 3], b4 = fj[t & 3];
+                    const int tp = t >> 2;
+                    const float c0 = tp == 0 ? a.x : tp == 1 ? a.y : tp == 2 ? a.z : a.w;
+                    const float cj = tp == 0 ? b4.x : tp == 1 ? b4.y : tp == 2 ? b4.z : b4.w;
+                    const float v = cj - c0;       // line vector c_j - c_0
+                    const float res = xq[i] - c0;  // residual q - c_0
+                    a2 = __fmaf_rn(v, v, a2);
+                    dot = __fmaf_rn(res, v, dot);
+                }
+            }
         }
         const float a = sqrtf(a2);
         out = fabsf(dot - 0.5f * a2) / a;
     } else {
         float n2 = 0.0f;
-        for (int i = 0; i < B.d; i++) {
-            const float c0 = arena_at(B.cvecs, B.cnblk, r0, i);
-            const float mid = c0 + (arena_at(B.cvecs, B.cnblk, rj, i) - c0) / 2.0f;
-            n2 = __fmaf_rn(mid, mid, n2);
+        for (int c = 0; c < nblk; c++) {
+            float4 f0[4], fj[4];
+#pragma unroll
+            for (int gq = 0; gq < 4; gq++) {
+                f0[gq] = v4[(t0 * nblk + c) * 64 + gq * 16 + rr0];
+                fj[gq] = v4[(tj * nblk + c) * 64 + gq * 16 + rrj];
+            }
+#pragma unroll
+            for (int t = 0; t < 16; t++) {
+                if (16 * c + t < B.d) {
+                    const float4 a = f0[t & 3], b4 = fj[t & 3];
+                    const int tp = t >> 2;
+                    const float c0 = tp == 0 ? a.x : tp == 1 ? a.y : tp == 2 ? a.z : a.w;
+                    const float cj = tp == 0 ? b4.x : tp == 1 ? b4.y : tp == 2 ? b4.z : b4.w;
+                    const float mid = c0 + (cj - c0) / 2.0f;
+                    n2 = __fmaf_rn(mid, mid, n2);
+                }
+            }
         }
         const float nrm = sqrtf(n2);
         float ang = 0.0f;
-        for (int i = 0; i < B.d; i++) {
-            const float c0 = arena_at(B.cvecs, B.cnblk, r0, i);
-            const float mid = (c0 + (arena_at(B.cvecs, B.cnblk, rj, i) - c0) / 2.0f) / nrm;
-            ang = __fmaf_rn(xq[i], mid, ang);
+        for (int c = 0; c < nblk; c++) {
+            float4 f0[4], fj[4];
+#pragma unroll
+            for (int gq = 0; gq < 4; gq++) {
+                f0[gq] = v4[(t0 * nblk + c) * 64 + gq * 16 + rr0];
+                fj[gq] = v4[(tj * nblk + c) * 64 + gq * 16 + rrj];
+            }
+#pragma unroll
+            for (int t = 0; t < 16; t++) {
+                const int i = 16 * c + t;
+                if (i < B.d) {
+                    const float4 a = f0[t & 3], b4 = fj[t & 3];
+                    const int tp = t >> 2;
+                    const float c0 = tp == 0 ? a.x : tp == 1 ? a.y : tp == 2 ? a.z : a.w;
+                    const float cj = tp == 0 ? b4.x : tp == 1 ? b4.y : tp == 2 ? b4.z : b4.w;
+                    const float mid = (c0 + (cj - c0) / 2.0f) / nrm;
+                    ang = __fmaf_rn(xq[i], mid, ang);
+                }
+            }
         }
         out = (float)acos((double)ang);
     }
