@@ -605,7 +605,8 @@ int qk_search_small_device(qk_ctx *ctx, qk_store *parent, qk_store *s, const flo
         }
     // workgroups per query: enough that a slice is a few hundred rows, no more than fill the chip a few times over
     const int64_t rows_est = std::max<int64_t>(1, (int64_t)std::min<int64_t>(nprobe, c_n) * std::max<int64_t>(1, s->ntotal / std::max<int64_t>(1, s->nlist)));
-    int W = (int)std::min<int64_t>(64, std::max<int64_t>(1, rows_est / 192));
+    static const int w_rows = std::max(16, qk_env_int("QK_SMALL_W_ROWS", 192)), w_max = std::max(1, qk_env_int("QK_SMALL_W_MAX", 64));  // (probe)
+    int W = (int)std::min<int64_t>(w_max, std::max<int64_t>(1, rows_est / w_rows));
     W = std::min(W, std::max(1, 1024 / k));
     W = std::min<int64_t>(W, std::max<int64_t>(1, 2048 / Q));
     const int cap = 1024;
