@@ -1494,7 +1494,10 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
     //  the 64*M-row sample costs 0.1 ms at d = 768; the wider instantiations stay available for probing)
     static const int seed_max_k = qk_env_int("QK_SEED_MAX_K", 64);
     const bool seed_pairs = a.per_pair && a.seed_first && !emit;  // (not under QK_NO_SEED: the caller dropped its own bound for this one)
-    const bool seeded = ((!no_seed && share_tau) || seed_pairs) && k <= std::min(seed_max_k, 512) && npairs > 0 && npids > 0;
+    // (narrow rows, 64 < k <= 128: a 128-row sample is cheap and pays at every nprobe -- 10M x 128, k = 100, ms per step without ->
+    //  with: nprobe 2 0.648 -> 0.538, 4 0.743 -> 0.637, 8 1.099 -> 0.940, 32 2.04 -> 1.94; k = 70, nprobe 8 1.011 -> 0.880)
+    const int seed_cap = nblk <= 8 ? std::max(seed_max_k, 128) : seed_max_k;
+    const bool seeded = ((!no_seed && share_tau) || seed_pairs) && k <= std::min(seed_cap, 512) && npairs > 0 && npids > 0;
     bool fused_group = false, fused_count = false;
     if (seeded) {
         // bound seeding: for the first (nearest) partitions of every query, the k-th smallest distance of a 64-row
