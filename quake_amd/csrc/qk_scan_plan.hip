@@ -173,6 +173,7 @@ int qk_scan_plan(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, bool emit, int
     int64_t rl_per_list = 0;
     RlCost rlc{12, 8, 1, 16, 4, 32};
     int rl_app = 32;
+    bool rl_small_pools = false;  // the row-per-lane forms only fit with pools of k + 16: admissible, measured by the feedback, not the static choice
     int rl_waves = 4;
     {
         // Measured (10M x 128, 1024 queries, k = 10; k_scan ms old form -> this form): nprobe 1: 0.252 -> 0.246, 2: 0.324 -> 0.313,
@@ -210,6 +211,15 @@ int qk_scan_plan(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, bool emit, int
                     rl_app = 16;
                     break;
                 }
+        }
+        // k = 29 ... 32 at d = 128: 32 pools of k + 32 entries do not fit next to the pass's queries (40.5 KB against the wave's
+        // 40 KB) and these k fell back to the tile form (10M x 128, nprobe 16: k = 28 0.70 ms, k = 29 0.83, k = 32 0.88): pools of
+        // k + 16 entries, appended to by quarter waves, do
+        static const int app16_env = qk_env_int("QK_SCAN_RL_APP16", 0);  // probe: quarter-wave appends for every k
+        if (qb == 32 && rl_app == 32 && (!fits(qb, C_rl) || app16_env) && fits(qb, qk_round_up(k + 16, 4))) {
+            C_rl = qk_round_up(k + 16, 4);
+            rl_app = 16;
+            rl_small_pools = !app16_env;
         }
         rlc = RlCost{std::max(1, rl_h0), std::max(1, rl_h1), std::max(0, rl_e), std::max(0, rl_ovh), std::max(1, rl_m), qb};
         // (4 waves per CU, each with its own LDS copy of the pass's queries and its pools: d = 128 with k = 32 does not fit)
@@ -267,11 +277,12 @@ int qk_scan_plan(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, bool emit, int
         const int64_t mean_rows = s->ntotal / std::max<int64_t>(1, s->n_nonempty);
         const bool long_lists = mean_rows >= hot_mean_rows;
         static const int rl_env2 = qk_env_int("QK_SCAN_RL", -1);
+        // (the walk part of the mixed form has the per-wave form's pools: k + 32 entries, or k + 16 with quarter-wave appends)
+        const int C_rl2 = rl_app == 16 ? qk_round_up(k + 16, 4) : std::min(64, qk_round_up(k + 32, 4));
         const bool rl_possible = nblk <= 8 && k <= 32 && rl_waves == 4 && rlc.qb == 32 && !emit && npairs >= 1024 && P > 1 &&
                                  ctx->qprep_xp4 != nullptr && a.xq4 == (const float4 *)ctx->qprep && rl_env2 != 0 &&
-                                 4 * ((qk_scan_rl_lds_per_wave(nblk, std::min(64, qk_round_up(k + 32, 4)), rlc.qb) + 15) & ~(size_t)15) <= (size_t)160 * 1024;
+                                 4 * ((qk_scan_rl_lds_per_wave(nblk, C_rl2, rlc.qb) + 15) & ~(size_t)15) <= (size_t)160 * 1024;
         if (rl_possible && hot_min > 0 && long_lists) {
-            const int C_rl2 = std::min(64, qk_round_up(k + 32, 4));
             const size_t per_wave = std::max<size_t>((qk_scan_rl_lds_per_wave(nblk, C_rl2, rlc.qb) + 15) & ~(size_t)15, (size_t)(160 * 1024) / 4 - 512) & ~(size_t)15;
             // (pools of k + 22 entries: appends come four at a time at most, and a block's pools share the LDS with its query
             //  tiles in fp32 and in bf16)
@@ -296,7 +307,9 @@ int qk_scan_plan(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, bool emit, int
     // a shape admits are MEASURED: whole calls (grouping + scan + merge) between two HIP events, read back at a later call
     // without synchronising; every admissible form twice, then the fastest, the others re-checked every 512 calls.  All forms
     // give the same bits (the parity suites run each of them), so which one answers is invisible to the caller.
-    const int form_static = mixed_static ? 2 : use_rl ? 1 : 0;
+    // (k = 29 ... 32 at d = 128: at nprobe 8 the tile form is still the faster one -- 0.625 against the mixed form's 0.66 ms at k = 32 --,
+    //  from nprobe 16 on the mixed form is: 0.83 -> 0.66 at k = 29, 0.88 -> 0.86 at k = 32; the feedback decides, the static rule stays)
+    const int form_static = rl_small_pools ? 0 : mixed_static ? 2 : use_rl ? 1 : 0;
     int form = form_static;
     qk_ctx::form_stat *fmeasure = nullptr;
     {
