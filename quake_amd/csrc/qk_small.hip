@@ -590,6 +590,15 @@ bool qk_small_supported(qk_ctx *ctx, qk_store *parent, qk_store *s, int64_t Q, i
     if (parent->nlist != 1 || parent->ntotal <= 0 || parent->ntotal > 256 * QK_SMALL_CPT) return false;  // <= 4096 centroids
     if (parent->min_id_seen < 0 || parent->d != s->d) return false;
     if ((size_t)s->dpad * 4 + 1024 * 12 + (size_t)parent->ntotal * 12 + 8192 > 160 * 1024) return false;
+    // How much there is to scan decides too: a query's slices are at most 64 workgroups and every workgroup ranks all the centroids
+    // itself.  10M x 128 in 4096 lists (2441 rows each), ms per call, this kernel / the batch pipeline: 1 query nprobe 10 0.065 /
+    // 0.089, 32 0.115 / 0.088, 64 0.208 / 0.107; 4 queries 0.074 / 0.088, 0.131 / 0.124, 0.228 / 0.168; 16 queries 0.137 / 0.131,
+    // 0.329 / 0.207, 0.664 / 0.269; 32 queries 0.223 / 0.167, 0.598 / 0.251, 1.258 / 0.329.  On the configs[0] shape (977 rows per
+    // list, nprobe 10) it wins up to 32 queries (98 / 134 us).  So: at most 32k rows per query and 320k rows per call.
+    static const int64_t rows_q_max = qk_env_int("QK_SMALL_ROWS_PER_QUERY", 32768), rows_max = qk_env_int("QK_SMALL_ROWS", 327680);
+    const int64_t mean_rows = std::max<int64_t>(1, s->ntotal / std::max<int64_t>(1, s->n_nonempty > 0 ? s->n_nonempty : s->nlist));
+    const int64_t rows_q = std::min<int64_t>(nprobe, parent->ntotal) * mean_rows;
+    if (rows_q > rows_q_max || rows_q * Q > rows_max) return false;
     return true;
 }
 
