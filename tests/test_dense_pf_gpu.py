@@ -45,8 +45,10 @@ def test_coarse_prefiltered_matches_oracle(ctx, metric, d):
             q = (cent[rng.integers(0, n, nq)] + 0.3 * rng.standard_normal((nq, d))).astype(np.float32)
             if metric == "ip":
                 q /= np.linalg.norm(q, axis=1, keepdims=True)
-            for k in (2, 10, 32, 64):
+            for k in (2, 10, 32, 64) + ((100, 128) if n > 8192 else ()):  # (64 < k <= 128: the form answers from 8193 rows on)
                 _check(ctx, parent, cent, q, k, metric)
+                if k > 64:
+                    assert ctx.last_scan_kernel() == "k_dense_pf", ctx.last_scan_kernel()
         parent.close()
 
 
@@ -57,6 +59,12 @@ def test_coarse_prefiltered_65536_centroids(ctx):
     q = (cent[rng.integers(0, 65536, 512)] + 0.5 * rng.standard_normal((512, 128))).astype(np.float32)
     _check(ctx, parent, cent, q, 32, "l2")
     _check(ctx, parent, cent, q, 1, "l2")   # the nearest centroid alone takes this form from 32768 rows on
+    _check(ctx, parent, cent, q, 100, "l2")
+    cent[2000:2300] = cent[1000]  # 300 identical rows: at k = 128 the cut falls inside the tie (ordered by id)
+    parent2 = _parent(ctx, cent)
+    q[:8] = cent[1000] + 1e-3
+    _check(ctx, parent2, cent, q, 128, "l2")
+    parent2.close()
     parent.close()
 
 
