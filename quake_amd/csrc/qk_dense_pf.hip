@@ -395,9 +395,9 @@ struct PfPlan {
 static bool pf_plan(const qk_ctx *ctx, const qk_store *s, int64_t Q, int nrows, int k, PfPlan *pl) {
     // (k = 1: the caller asks from 32768 rows on.  The workspace is ~14 KB per query -- group minima + a 1536-slot candidate list --:
     //  batches beyond 65536 queries stay on the sliced key-matrix path / the fused argmin, whose state is a few bytes per query)
-    // (64 < k <= 128 on long rows: the key-matrix path selects with one wave per query over the whole row -- 1M rows, k = 100: 19 ms,
+    // (64 < k <= 192 on long rows: the key-matrix path selects with one wave per query over the whole row -- 1M rows, k = 100: 19 ms,
     //  4M rows: 268 ms; the filter's bound, candidate lists and finish are the same code up to Cm = 256)
-    const int k_max = nrows > 8192 ? 128 : 64;
+    const int k_max = nrows > 8192 ? 192 : 64;
     if (!(s->nblk <= 8 && k >= 1 && k <= k_max && nrows >= 1024 && Q >= 64 && Q <= 65536)) return false;
     const int num_cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
     const int ntile = (nrows + 15) / 16;

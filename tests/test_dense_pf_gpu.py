@@ -45,7 +45,7 @@ def test_coarse_prefiltered_matches_oracle(ctx, metric, d):
             q = (cent[rng.integers(0, n, nq)] + 0.3 * rng.standard_normal((nq, d))).astype(np.float32)
             if metric == "ip":
                 q /= np.linalg.norm(q, axis=1, keepdims=True)
-            for k in (2, 10, 32, 64) + ((100, 128) if n > 8192 else ()):  # (64 < k <= 128: the form answers from 8193 rows on)
+            for k in (2, 10, 32, 64) + ((100, 128, 150, 192) if n > 8192 else ()):  # (64 < k <= 192: the form answers from 8193 rows on)
                 _check(ctx, parent, cent, q, k, metric)
                 if k > 64:
                     assert ctx.last_scan_kernel() == "k_dense_pf", ctx.last_scan_kernel()
@@ -64,6 +64,7 @@ def test_coarse_prefiltered_65536_centroids(ctx):
     parent2 = _parent(ctx, cent)
     q[:8] = cent[1000] + 1e-3
     _check(ctx, parent2, cent, q, 128, "l2")
+    _check(ctx, parent2, cent, q, 192, "l2")
     parent2.close()
     parent.close()
 
