@@ -398,7 +398,10 @@ static bool pf_plan(const qk_ctx *ctx, const qk_store *s, int64_t Q, int nrows, 
     // (64 < k <= 192 on long rows: the key-matrix path selects with one wave per query over the whole row -- 1M rows, k = 100: 19 ms,
     //  4M rows: 268 ms; the filter's bound, candidate lists and finish are the same code up to Cm = 256)
     const int k_max = nrows > 8192 ? 192 : 64;
-    if (!(s->nblk <= 8 && k >= 1 && k <= k_max && nrows >= 1024 && Q >= 64 && Q <= 65536)) return false;
+    // (few queries against a long list: the key-matrix path's selection is one wave per query -- 1M rows, 1 query: k = 10 206 us,
+    //  k = 100 3.0 ms; the filter's launches do not care how many queries there are)
+    const int64_t q_min = nrows >= 32768 ? 1 : 64;
+    if (!(s->nblk <= 8 && k >= 1 && k <= k_max && nrows >= 1024 && Q >= q_min && Q <= 65536)) return false;
     const int num_cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
     const int ntile = (nrows + 15) / 16;
     // query tiles per workgroup: up to 256 queries share a pass over the rows (each workgroup streams its rows from L2 / the

@@ -9,7 +9,7 @@ from quake_amd.capi import Context, Store
 ctx = Context(0)
 ctx.set_stream(torch.cuda.current_stream().cuda_stream)
 dev = torch.device("cuda", 0)
-d, Q = 128, 1024
+d, Q = 128, int(sys.argv[3]) if len(sys.argv) > 3 else 1024
 g = torch.Generator(device=dev).manual_seed(0)
 q = torch.randn(Q, d, generator=g, device=dev)
 NLS = [int(v) for v in sys.argv[1].split(',')] if len(sys.argv) > 1 else (4096, 8192, 16384, 32768, 65536)
@@ -27,4 +27,4 @@ for nl in NLS:
             ctx.coarse(parent, q, nprobe, "l2")
         torch.cuda.synchronize()
         us = (time.perf_counter() - t0) / 50 * 1e6
-        print(json.dumps({"nlist": nl, "nprobe": nprobe, "coarse_us": round(us, 1), "TFLOPs": round(2.0 * Q * nl * d / us / 1e6, 1)}), flush=True)
+        print(json.dumps({"nlist": nl, "Q": Q, "nprobe": nprobe, "kernel": ctx.last_scan_kernel(), "coarse_us": round(us, 1), "TFLOPs": round(2.0 * Q * nl * d / us / 1e6, 1)}), flush=True)

@@ -60,6 +60,10 @@ def test_coarse_prefiltered_65536_centroids(ctx):
     _check(ctx, parent, cent, q, 32, "l2")
     _check(ctx, parent, cent, q, 1, "l2")   # the nearest centroid alone takes this form from 32768 rows on
     _check(ctx, parent, cent, q, 100, "l2")
+    for nq in (1, 7, 40):  # few queries against a long list take this form too (from 32768 rows on)
+        for k in (1, 10, 100):
+            _check(ctx, parent, cent, q[:nq], k, "l2")
+            assert ctx.last_scan_kernel() == "k_dense_pf", ctx.last_scan_kernel()
     cent[2000:2300] = cent[1000]  # 300 identical rows: at k = 128 the cut falls inside the tie (ordered by id)
     parent2 = _parent(ctx, cent)
     q[:8] = cent[1000] + 1e-3
