@@ -14,7 +14,7 @@ ctx = Context(0)
 ctx.set_stream(torch.cuda.current_stream().cuda_stream)
 if os.environ.get("STEP_FEEDBACK") == "0":  # the static form rule alone
     ctx.set_form_feedback(False)
-n, d, nlist, Q, k = 10_000_000, int(os.environ.get("STEP_DIM", "128")), int(os.environ.get("STEP_NLIST", "4096")), int(os.environ.get("STEP_Q", "1024")), k_arg
+n, d, nlist, Q, k = int(os.environ.get("STEP_N", "10000000")), int(os.environ.get("STEP_DIM", "128")), int(os.environ.get("STEP_NLIST", "4096")), int(os.environ.get("STEP_Q", "1024")), k_arg
 metric = os.environ.get("STEP_METRIC", "l2")
 x, cent = B.gen_mixture(n, d, nlist, seed=1, device=dev)
 idx = B.build_single(ctx, dev, x, nlist, metric, 5, keep_host=False)
@@ -35,5 +35,5 @@ def block(steps=200):
 block(300)
 ms = sorted(block(200) for _ in range(9))
 chk = int(out[0].sum().item())
-print(json.dumps({"lib": os.environ.get("QUAKE_HIP_LIB", "product"), "d": d, "nlist": nlist, "Q": Q, "metric": metric, "nprobe": nprobe, "k": k, "kernel": ctx.last_scan_kernel(), "feedback": os.environ.get("STEP_FEEDBACK", "1"), "ms_per_step_median": round(ms[4], 5), "min": round(ms[0], 5),
+print(json.dumps({"lib": os.environ.get("QUAKE_HIP_LIB", "product"), "n": n, "d": d, "nlist": nlist, "Q": Q, "metric": metric, "nprobe": nprobe, "k": k, "kernel": ctx.last_scan_kernel(), "feedback": os.environ.get("STEP_FEEDBACK", "1"), "ms_per_step_median": round(ms[4], 5), "min": round(ms[0], 5),
                   "max": round(ms[-1], 5), "ids_checksum": chk}))
