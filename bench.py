@@ -154,10 +154,13 @@ def build_single(ctx, dev, x, nlist, metric, niter, keep_host):
                       # the assign step settles WHICH key decides on bf16 MFMA (two passes over all pairs: qk_assign_pf.hip) and
                       # computes only the deciding keys exactly: `achieved` counts one key per (row, centroid) pair, `executed` the
                       # two bf16 passes, priced against the dense bf16 MFMA peak; an all-fp32 kernel is capped at 157.3 TFLOP/s
-                      "assign": {"ms": round(kt["assign_ms"], 3), "achieved": round(a_tf, 1), "executed": round(2 * a_tf, 1),
-                                 "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(2 * a_tf / MFMA_BF16_PEAK_TFLOPS, 3),
-                                 "bound": "mfma (bf16 prefilter, exact fp32 keys for the candidates)",
-                                 "achieved_over_fp32_mfma_peak": round(a_tf / MFMA_F32_PEAK_TFLOPS, 2)},
+                      # (rows wider than 128 columns take the all-fp32 kernel k_assign: priced against the fp32 MFMA peak)
+                      "assign": ({"ms": round(kt["assign_ms"], 3), "achieved": round(a_tf, 1), "executed": round(2 * a_tf, 1),
+                                  "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(2 * a_tf / MFMA_BF16_PEAK_TFLOPS, 3),
+                                  "bound": "mfma (bf16 prefilter, exact fp32 keys for the candidates)",
+                                  "achieved_over_fp32_mfma_peak": round(a_tf / MFMA_F32_PEAK_TFLOPS, 2)} if d <= 128 else
+                                 {"ms": round(kt["assign_ms"], 3), "achieved": round(a_tf, 1), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                  "frac": round(a_tf / MFMA_F32_PEAK_TFLOPS, 3), "bound": "mfma (fp32: k_assign, rows wider than 128 columns)"}),
                       "update": {"ms": round(kt["update_ms"], 3), "achieved": round(u_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                  "frac": round(u_gbs / HBM_PEAK_GBS, 3), "bound": "hbm",
                                  "note": "rows x d x 4 bytes (each training row read once) / (bucketing by assignment + k_accumulate)"}}
