@@ -14,7 +14,7 @@ def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
     nlist = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
     targets = [float(a) for a in sys.argv[3:]] or [0.8, 0.9, 0.99]
-    d, k, Q = 128, 10, 1024
+    d, k, Q = 128, 10, int(os.environ.get("APS_Q", "1024"))
     frac = float(os.environ.get("APS_FRACTION", "0.02"))
     dev = torch.device("cuda", 0)
     ctx = Context(0)
