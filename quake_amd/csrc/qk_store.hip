@@ -900,6 +900,18 @@ int qk_store_add_batch(qk_store *s, int64_t n, const int64_t *ids, const float *
         QK_TRY(check_list(s, h_assign[i], "add_entries"));
         extra[(size_t)h_assign[i]]++;
     }
+    // what the batch's relocations will ask of the arena, asked for ONCE: a bulk-built store has exactly-sized lists, and the first
+    // large add relocated 3000 of them through three arena re-allocations and a compaction (each a copy of the whole arena plus
+    // multi-GB hipMalloc / hipFree: 50 ... 800 ms for 65536 vectors)
+    {
+        int64_t grow = 0;
+        for (size_t p = 0; p < extra.size(); p++) {
+            const qk_part &pt = s->parts[p];
+            if (extra[p] && pt.size + extra[p] > pt.cap) grow += qk_round_up64(std::max<int64_t>(pt.size + extra[p], pt.cap * 2), 16);
+        }
+        if (grow > 0 && s->used_rows + grow > s->cap_rows && !(s->dead_rows * 4 >= s->cap_rows && s->dead_rows >= 1024))
+            QK_TRY(qk_store_reserve_rows(s, grow));
+    }
     for (size_t p = 0; p < extra.size(); p++)
         if (extra[p]) QK_TRY(ensure_part_capacity(s, s->parts[p], extra[p]));
     std::vector<int64_t> rows((size_t)n);

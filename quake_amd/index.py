@@ -528,7 +528,12 @@ class QuakeIndex:
             raise RuntimeError("[PartitionManager] add: vector_ids must be less than INT_MAX.")
         if int(idn.min()) < 0:
             raise RuntimeError("[PartitionManager] add: vector_ids must be non-negative (-1 marks an empty result slot).")
-        if np.unique(idn).shape[0] != n:
+        # (uniqueness of a large batch is checked by a device sort: np.unique of 1M ids was 60 of the 87 ms this validation took)
+        if n >= 65536:
+            n_unique = int(torch.unique(self._to_dev(ids.reshape(-1), torch.int64)).shape[0])
+        else:
+            n_unique = int(np.unique(idn).shape[0])
+        if n_unique != n:
             raise RuntimeError("[PartitionManager] add: vector_ids must be unique.")
         if self._resident.any_present(idn):
             raise RuntimeError("[PartitionManager] init_partitions: vector ID already exists in the index.")
