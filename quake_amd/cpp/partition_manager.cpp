@@ -105,8 +105,22 @@ void PartitionManager::init_partitions(shared_ptr<QuakeIndex> parent, shared_ptr
 
 void PartitionManager::init_from_csr(shared_ptr<QuakeIndex> parent, const Tensor &offsets, const Tensor &ids, const Tensor &vectors) {
     parent_ = parent;
-    Tensor off = host_i64(offsets), id = host_i64(ids), v = host_f32(vectors);
+    Tensor off = host_i64(offsets);
     const int64_t nlist = off.size(0) - 1;
+    if (vectors.is_cuda() && ids.is_cuda()) {
+        // rows and ids already on the device (QuakeIndex::build buckets them there): the store ingests them in place
+        Tensor v = vectors.to(torch::kFloat32).contiguous(), idd = ids.to(torch::kInt64).contiguous();
+        reset_store((int)v.size(1));
+        torch::cuda::synchronize();  // (torch's stream made them; the store's launches run on the library's)
+        qk_check(lists_.build_csr(nlist, off.data_ptr<int64_t>(), idd.data_ptr<int64_t>(), v.data_ptr<float>(), QK_MEM_DEVICE));
+        qk_check(qk_ctx_synchronize(qk_device_context(0)));
+        Tensor id = idd.cpu();
+        const int64_t *ip = id.data_ptr<int64_t>();
+        resident_ids_.insert(ip, ip + id.size(0));
+        curr_partition_id_ = nlist;
+        return;
+    }
+    Tensor id = host_i64(ids), v = host_f32(vectors);
     reset_store((int)v.size(1));
     qk_check(lists_.build_csr(nlist, off.data_ptr<int64_t>(), id.data_ptr<int64_t>(), v.data_ptr<float>(), QK_MEM_HOST));
     const int64_t *ip = id.data_ptr<int64_t>();
