@@ -506,7 +506,8 @@ class QuakeIndex:
 
     def get_ids(self):
         self._require_built("[QuakeIndex::get_ids()] No partition manager. Index not built?")
-        parts = [torch.from_numpy(self._store.get_list(int(p))[1]) for p in self._store.list_ids()]
+        # (ids only, from the store's host mirror: get_list would extract every vector of the index on the way)
+        parts = [torch.from_numpy(self._store.get_list_ids(int(p))) for p in self._store.list_ids()]
         return torch.cat(parts) if parts else torch.empty((0,), dtype=torch.int64)
 
     # -- add (partition_manager.cpp:123-262) ---------------------------------------------------------------------------------
