@@ -44,7 +44,13 @@ def test_every_call_is_the_oracles_answer_whatever_form_runs(concentrated):
     assert forms[0] == "k_scan_rl (mixed)"                      # the static rule answers the first call of a shape
     tried = set(forms)
     assert {"k_scan_rl (mixed)", "k_scan_rl"} <= tried and any(f.startswith("k_scan") and "rl" not in f for f in tried), tried
-    assert len(set(forms[-12:])) == 1, forms                    # ... and the context settles on one form
+    # ... and the context settles on one form: a run of the same form after the comparison (a timing outlier 1.5 x off may re-open
+    # the comparison once -- that is the rule --, so the claim is a long run, not the last calls)
+    run = best = 1
+    for a_, b_ in zip(forms[6:], forms[7:]):
+        run = run + 1 if a_ == b_ else 1
+        best = max(best, run)
+    assert best >= 8, forms
     # feedback off: the static rule, always
     ctx.set_form_feedback(False)
     for _ in range(3):
