@@ -93,6 +93,11 @@ QK_API int qk_ctx_get_stream(qk_ctx *ctx, void **hip_stream, int *kind);
  * few hundred calls.  Off: the static rule alone (what the first call of a shape always uses).  No reference counterpart:
  * the reference picks serial / batched / worker scans by SearchParams (query_coordinator.cpp:612-673). */
 QK_API int qk_ctx_set_form_feedback(qk_ctx *ctx, int enabled);
+/* The feedback RULE on injected figures: with ms3 = {tile form, per-wave walk, mixed sequence} (all > 0) every measurement the
+ * context harvests reads ms3[form] in place of the elapsed time of its event pair, so which form answers which call is a pure
+ * function of the call sequence (tests/test_scan_feedback_gpu.py asserts the sequence).  NULL: measured times again.  The
+ * environment variable QK_FORM_FEEDBACK=0 creates every context with feedback off. */
+QK_API int qk_ctx_set_form_times(qk_ctx *ctx, const float *ms3);
 QK_API int qk_ctx_synchronize(qk_ctx *ctx);
 /* hipEvent timing of the phases, recorded on the context's stream around the kernels:
  *   0 off; 1 per call (the qk_timing* passed to qk_scan/qk_search is filled, which synchronises the stream);

@@ -43,6 +43,7 @@ SIGNATURES = {
     "qk_ctx_set_null_stream": (_int, [_vp]),
     "qk_ctx_get_stream": (_int, [_vp, C.POINTER(_vp), C.POINTER(_int)]),
     "qk_ctx_set_form_feedback": (_int, [_vp, _int]),
+    "qk_ctx_set_form_times": (_int, [_vp, C.POINTER(C.c_float)]),
     "qk_ctx_synchronize": (_int, [_vp]),
     "qk_ctx_set_timing": (_int, [_vp, _int]),
     "qk_ctx_get_timing": (_int, [_vp, C.POINTER(_int)]),

@@ -100,6 +100,13 @@ class Context:
         """measured choice between the scan forms per batch shape (default on); off = the static rule alone"""
         check(self.lib.qk_ctx_set_form_feedback(self.h, int(bool(enabled))))
 
+    def set_form_times(self, ms3):
+        """the feedback rule on injected figures: ms3 = (tile form, per-wave walk, mixed) in ms, or None for measured times"""
+        if ms3 is None:
+            check(self.lib.qk_ctx_set_form_times(self.h, None))
+        else:
+            check(self.lib.qk_ctx_set_form_times(self.h, (C.c_float * 3)(*[float(v) for v in ms3])))
+
     def set_stream(self, hip_stream):
         """hip_stream: a hipStream_t handle (e.g. torch.cuda.current_stream().cuda_stream); 0 = the device's NULL stream
         (torch's default stream); None = back to the context's private stream.

@@ -1,6 +1,8 @@
 // qk_ctx.hip -- error state, context, scratch memory.
 #include "qk_internal.h"
 
+#include <cstdlib>
+
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -35,6 +37,9 @@ int qk_ctx_create(int device, qk_ctx **out) {
     QK_HIP(hipSetDevice(device));
     qk_ctx *c = new qk_ctx();
     c->device = device;
+    // (the one environment switch of the product library, read at context creation: a whole test suite or a deployment that wants
+    //  the static rule alone for every context, including the ones the mirrors create; include/quake_hip.h)
+    if (const char *e = getenv("QK_FORM_FEEDBACK")) c->form_feedback = atoi(e) != 0;
     QK_HIP(hipGetDeviceProperties(&c->prop, device));
     QK_HIP(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
@@ -110,6 +115,16 @@ int qk_ctx_get_stream(qk_ctx *c, void **hip_stream, int *kind) {
 int qk_ctx_set_form_feedback(qk_ctx *c, int enabled) {
     if (!c) QK_FAIL(QK_ERR_INVALID, "qk_ctx_set_form_feedback: ctx is null");
     c->form_feedback = enabled != 0;
+    return QK_OK;
+}
+
+int qk_ctx_set_form_times(qk_ctx *c, const float *ms3) {
+    if (!c) QK_FAIL(QK_ERR_INVALID, "qk_ctx_set_form_times: ctx is null");
+    c->form_times_set = ms3 != nullptr;
+    for (int f = 0; f < 3; f++) {
+        if (ms3 && !(ms3[f] > 0.f)) QK_FAIL(QK_ERR_INVALID, "qk_ctx_set_form_times: ms3[%d] must be > 0", f);
+        c->form_times[f] = ms3 ? ms3[f] : 0.f;
+    }
     return QK_OK;
 }
 

@@ -118,7 +118,9 @@ struct qk_ctx {
     };
     std::vector<form_stat> form_stats;
     int64_t form_clock = 0;
-    bool form_feedback = true;          // qk_ctx_set_form_feedback
+    bool form_feedback = true;          // qk_ctx_set_form_feedback (QK_FORM_FEEDBACK=0 in the environment: off from the start)
+    bool form_times_set = false;        // qk_ctx_set_form_times: a harvested measurement reads form_times[form], not the event pair
+    float form_times[3] = {0.f, 0.f, 0.f};
     int *overflow_host = nullptr;    // pinned, device-visible: a scan kernel sets it when its record buffer overflows
     int *overflow_dev = nullptr;
     char *qprep_zero = nullptr;      // region cleared by the prep kernel for the scan of the same batch

@@ -50,7 +50,9 @@ static int qk_pick_form(qk_ctx *ctx, uint64_t key, int form_static, const bool a
         const hipError_t q = hipEventQuery(st->e1);
         if (q == hipSuccess) {
             float ms = 0.f;
-            if (hipEventElapsedTime(&ms, st->e0, st->e1) == hipSuccess && ms > 0.f) {
+            hipError_t eq = hipEventElapsedTime(&ms, st->e0, st->e1);
+            if (ctx->form_times_set) ms = ctx->form_times[st->pending];  // (qk_ctx_set_form_times: the rule on injected figures)
+            if (eq == hipSuccess && ms > 0.f) {
                 const int f = st->pending;
                 if (st->n[f] >= 2 && (ms > 1.5f * st->ms[f] || ms < 0.6f * st->ms[f])) {
                     // the same shape takes a very different time: the batches changed (how the queries concentrate on lists is

@@ -267,11 +267,13 @@ class ListScanLatencyEstimator:
         return True
 
 
-def device_profile_fn(d, n_trials=DEFAULT_LATENCY_ESTIMATOR_NTRIALS, device=0, max_rows=1 << 22):
+def device_profile_fn(d, n_trials=DEFAULT_LATENCY_ESTIMATOR_NTRIALS, device=0, max_rows=1 << 22, elapsed=None):
     """profile_fn for a GPU index, THROUGHPUT regime: many partitions of n rows are scanned in one qk_scan call, one query
     each (up to 1024 pairs, at most max_rows rows in total), and the cost of one (query, partition) pair is the call's time
     divided by the number of pairs -- what one more probed partition of that size costs inside a busy serving batch.
-    (A single-query latency, what the reference profiles on the CPU, is flat in n on a GPU: launch-bound.)"""
+    (A single-query latency, what the reference profiles on the CPU, is flat in n on a GPU: launch-bound.)
+    elapsed: optional `elapsed(n, k, npart) -> seconds per call`, read in place of the clock (the scans still run): the grid becomes a
+    function of its arguments, which is what a test of everything downstream of the grid needs."""
     import torch
     from . import capi
 
@@ -297,7 +299,8 @@ def device_profile_fn(d, n_trials=DEFAULT_LATENCY_ESTIMATOR_NTRIALS, device=0, m
         for _ in range(n_trials):
             ctx.scan(s, q, pids, kk, "l2")
         ctx.synchronize()
-        return (time.perf_counter() - t0) / n_trials / state["npart"] * 1e9
+        per_call = (time.perf_counter() - t0) / n_trials if elapsed is None else float(elapsed(n, kk, state["npart"]))
+        return per_call / state["npart"] * 1e9
 
     return fn
 

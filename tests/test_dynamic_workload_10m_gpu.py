@@ -26,7 +26,8 @@ pytestmark = pytest.mark.gpu
 def test_dynamic_replay_10m_with_maintenance():
     import quake_amd as quake
     from quake_amd.index import QuakeIndex
-    from quake_amd.maintenance import MaintenanceCostEstimator
+    from quake_amd.maintenance import (DEFAULT_LATENCY_ESTIMATOR_RANGE_K, DEFAULT_LATENCY_ESTIMATOR_RANGE_N,
+                                       ListScanLatencyEstimator, MaintenanceCostEstimator)
     from quake_amd.workload import HotSamplers, WorkloadSpec, generate_workload, replay_workload
     n, d, n_ops = 10_000_000, 128, 60
     hot_comp, hot_each = 8, 25000
@@ -52,7 +53,12 @@ def test_dynamic_replay_10m_with_maintenance():
         bp.metric, bp.nlist = "l2", n_cold // 2500
         index = QuakeIndex(device=0)
         index.build(x[first], first, bp)
-        ce = MaintenanceCostEstimator(d, 0.9, 10)
+        # the cost model is a RECORDED grid (an MI355X profiled by device_profile_fn, tests/golden/; the reference's CSV layout,
+        # maintenance_cost_estimator.cpp:259-365), not a measurement of this box at test time: what the policy decides is then a
+        # function of the runbook alone
+        lat = ListScanLatencyEstimator(d, DEFAULT_LATENCY_ESTIMATOR_RANGE_N, DEFAULT_LATENCY_ESTIMATOR_RANGE_K, 1,
+                                       profile_filename=os.path.join(os.path.dirname(__file__), "golden", "device_latency_grid_mi355x_d128.csv"))
+        ce = MaintenanceCostEstimator(d, 0.9, 10, latency_estimator=lat)
         scale = ce.get_latency_estimator().estimate_scan_latency(2500, 10) / 100_000.0  # device cost of a mean list over the CPU's
         assert 1e-4 < scale < 0.1, scale
         mp = quake.MaintenancePolicyParams()

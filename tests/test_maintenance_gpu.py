@@ -104,14 +104,22 @@ def test_policy_splits_hot_and_deletes_cold_partitions():
 
 
 def test_device_profiled_cost_model():
+    """device_profile_fn drives the scans whose time the default cost model reads; here the CLOCK is injected (45 ns per pair +
+    0.085 ns per row, the shape of a recorded MI355X grid), so the grid and everything derived from it are values, not timings."""
     from quake_amd.maintenance import ListScanLatencyEstimator, MaintenanceCostEstimator, device_profile_fn
-    fn = device_profile_fn(32, 3)
-    for n_ in (64, 1024, 16384):  # warm-up of every grid point: module load, workspace growth and the first launch of a form are
-        for k_ in (1, 16):         # not part of the model (one cold point once read 15 us per pair for 64 rows)
-            fn(n_, k_)
+    seen = []
+
+    def elapsed(n, k, npart):
+        seen.append((n, k, npart))
+        return npart * (45.0 + 0.085 * n + 0.01 * k) * 1e-9
+
+    fn = device_profile_fn(32, 3, elapsed=elapsed)
     lat = ListScanLatencyEstimator(32, [64, 1024, 16384], [1, 16], 3, profile_fn=fn)
-    a, b, c = (lat.estimate_scan_latency(n, 10) for n in (64, 1024, 16384))
-    assert a > 0 and b > 0 and c > b  # 16x more rows per pair cost more (a timing: no tighter claim)
+    assert sorted(set(seen)) == [(n, k, min(1024, max(16, (1 << 22) // n))) for n in (64, 1024, 16384) for k in (1, 16)]
+    for n in (64, 1024, 16384):
+        for k in (1, 16):
+            assert lat.estimate_scan_latency(n, k) == pytest.approx(45.0 + 0.085 * n + 0.01 * k, rel=1e-9)
+    assert lat.estimate_scan_latency(8192, 10) == pytest.approx(45.0 + 0.085 * 8192 + 0.1, rel=1e-6)
     est = MaintenanceCostEstimator(32, 0.9, 10, latency_estimator=lat)
     assert np.isfinite(est.compute_split_delta(8000, 0.5, 100))
 
