@@ -141,6 +141,9 @@ QK_API int qk_store_build_csr(qk_store *s, int64_t nlist, const int64_t *offsets
  * n_removed (may be NULL) receives the number of rows removed. */
 QK_API int qk_store_remove_ids(qk_store *s, int64_t n, const int64_t *ids_host, int64_t *n_removed);
 QK_API int qk_store_list_size(qk_store *s, int64_t list_no, int64_t *out);      /* list_size :68-74 */
+/* PartitionManager::get_partition_sizes(Tensor) (partition_manager.cpp:296-306): the sizes of n lists in one call (host arrays);
+ * an absent list is QK_ERR_NOT_FOUND like list_size.  The maintenance policy asks for every partition's size on every call. */
+QK_API int qk_store_list_sizes(qk_store *s, const int64_t *list_nos, int64_t n, int64_t *out);
 QK_API int64_t qk_store_ntotal(qk_store *s);                                    /* ntotal :60-66 */
 QK_API int64_t qk_store_nlist(qk_store *s);
 QK_API int qk_store_d(qk_store *s);
@@ -179,6 +182,13 @@ QK_API int qk_scan(qk_ctx *ctx, qk_store *s, const float *x, int64_t Q, const in
  * no host round trip between the two.  parent == NULL: flat index, every list of `s` is scanned (:624-626). */
 QK_API int qk_search(qk_ctx *ctx, qk_store *parent, qk_store *s, const float *x, int64_t Q, int nprobe, int k, int metric,
                      int64_t *out_ids, float *out_dist, int mem, qk_timing *timing);
+
+/* qk_search that also hands out WHICH lists every query scanned -- out_probed [Q][min(nprobe, parent lists)] list numbers in rank
+ * order (host or device like the other buffers) -- in the same enqueue: what QuakeIndex::search passes to
+ * MaintenancePolicy::record_query_hits (maintenance_policies.cpp:179-182; the reference has the list on the host anyway).  The
+ * nearest-centroid step writes the caller's buffer and the scan reads it: no second call, no copy. */
+QK_API int qk_search_tracked(qk_ctx *ctx, qk_store *parent, qk_store *s, const float *x, int64_t Q, int nprobe, int k, int metric,
+                             int64_t *out_ids, float *out_dist, int64_t *out_probed, int mem, qk_timing *timing);
 
 /* QueryCoordinator::search with SearchParams::recall_target > 0 and batched_scan == false: adaptive partition
  * scanning (query_coordinator.cpp:612-657 picks M = max((int)(nlist * initial_search_fraction), 1) candidate partitions
@@ -247,6 +257,7 @@ QK_API int qk_group_build_csr(qk_group *g, int64_t nlist, const int64_t *offsets
                               int mem);                                         /* init_partitions + distribute_partitions */
 QK_API int qk_group_remove_ids(qk_group *g, int64_t n, const int64_t *ids_host, int64_t *n_removed);
 QK_API int qk_group_list_size(qk_group *g, int64_t list_no, int64_t *out);
+QK_API int qk_group_list_sizes(qk_group *g, const int64_t *list_nos, int64_t n, int64_t *out);
 QK_API int64_t qk_group_ntotal(qk_group *g);
 QK_API int64_t qk_group_nlist(qk_group *g);
 QK_API int qk_group_d(qk_group *g);

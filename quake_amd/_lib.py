@@ -61,6 +61,7 @@ SIGNATURES = {
     "qk_store_build_csr": (_int, [_vp, _i64, _vp, _vp, _vp, _int]),
     "qk_store_remove_ids": (_int, [_vp, _i64, _vp, C.POINTER(_i64)]),
     "qk_store_list_size": (_int, [_vp, _i64, C.POINTER(_i64)]),
+    "qk_store_list_sizes": (_int, [_vp, _vp, _i64, _vp]),
     "qk_store_ntotal": (_i64, [_vp]),
     "qk_store_nlist": (_i64, [_vp]),
     "qk_store_d": (_int, [_vp]),
@@ -72,6 +73,7 @@ SIGNATURES = {
     "qk_coarse": (_int, [_vp, _vp, _vp, _i64, _int, _int, _vp, _vp, _int]),
     "qk_scan": (_int, [_vp, _vp, _vp, _i64, _vp, _int, _int, _int, _vp, _vp, _int, C.POINTER(QkTiming)]),
     "qk_search": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _int, _int, _vp, _vp, _int, C.POINTER(QkTiming)]),
+    "qk_search_tracked": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _int, _int, _vp, _vp, _vp, _int, C.POINTER(QkTiming)]),
     "qk_search_aps": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _int, C.c_float, C.c_float, _int, C.c_float, _vp, _vp, _vp, _int,
                       C.POINTER(QkTiming)]),
     "qk_merge_topk": (_int, [_vp, _vp, _vp, _int, _i64, _int, _int, _vp, _vp]),
@@ -105,6 +107,7 @@ SIGNATURES = {
     "qk_group_build_csr": (_int, [_vp, _i64, _vp, _vp, _vp, _int]),
     "qk_group_remove_ids": (_int, [_vp, _i64, _vp, C.POINTER(_i64)]),
     "qk_group_list_size": (_int, [_vp, _i64, C.POINTER(_i64)]),
+    "qk_group_list_sizes": (_int, [_vp, _vp, _i64, _vp]),
     "qk_group_ntotal": (_i64, [_vp]),
     "qk_group_nlist": (_i64, [_vp]),
     "qk_group_d": (_int, [_vp]),

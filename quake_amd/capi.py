@@ -203,6 +203,22 @@ class Context:
                                  metric_code(metric), _ptr(out_i), _ptr(out_d), mem, C.byref(t) if timing else None))
         return (out_i, out_d, timing_dict(t)) if timing else (out_i, out_d)
 
+    def search_tracked(self, parent, store, x, nprobe, k, metric, timing=False):
+        """qk_search_tracked: search + the [Q, min(nprobe, parent lists)] list numbers every query scanned, one enqueue.
+        Returns (ids, dist, probed[, timing])."""
+        x = _f32(x)
+        Q = x.shape[0]
+        mem = _mem_of(x)
+        width = max(min(int(nprobe), int(parent.ntotal())), 0)
+        out_i = _empty_like_mem((Q, k), np.int64, x)
+        out_d = _empty_like_mem((Q, k), np.float32, x)
+        out_p = _empty_like_mem((Q, max(width, 1)), np.int64, x)
+        t = QkTiming()
+        check(self.lib.qk_search_tracked(self.h, parent.h, store.h, _ptr(x), Q, int(nprobe), int(k), metric_code(metric),
+                                         _ptr(out_i), _ptr(out_d), _ptr(out_p), mem, C.byref(t) if timing else None))
+        out_p = out_p[:, :width]
+        return (out_i, out_d, out_p, timing_dict(t)) if timing else (out_i, out_d, out_p)
+
     def search_aps(self, parent, store, x, k, metric, recall_target, recompute_threshold=0.001, use_precomputed=True,
                    initial_search_fraction=0.02, timing=False):
         """recall-target search (adaptive partition scanning).  Returns (ids, dist, nscanned[, timing])."""
@@ -375,6 +391,14 @@ class Store:
         check(self.lib.qk_store_list_size(self.h, int(list_no), C.byref(out)))
         return out.value
 
+    def list_sizes(self, list_nos):
+        """sizes of many lists in one call -> int64 array"""
+        nos = np.ascontiguousarray(list_nos, dtype=np.int64).reshape(-1)
+        out = np.empty(nos.shape[0], np.int64)
+        if nos.shape[0]:
+            check(self.lib.qk_store_list_sizes(self.h, _ptr(nos), nos.shape[0], _ptr(out)))
+        return out
+
     def ntotal(self):
         return self.lib.qk_store_ntotal(self.h)
 
@@ -541,6 +565,13 @@ class Group:
         out = C.c_int64()
         check(self.lib.qk_group_list_size(self.h, int(list_no), C.byref(out)))
         return out.value
+
+    def list_sizes(self, list_nos):
+        nos = np.ascontiguousarray(list_nos, dtype=np.int64).reshape(-1)
+        out = np.empty(nos.shape[0], np.int64)
+        if nos.shape[0]:
+            check(self.lib.qk_group_list_sizes(self.h, _ptr(nos), nos.shape[0], _ptr(out)))
+        return out
 
     def ntotal(self):
         return self.lib.qk_group_ntotal(self.h)

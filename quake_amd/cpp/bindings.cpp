@@ -95,6 +95,7 @@ PYBIND11_MODULE(_bindings, m) {
         .def("worker_scan", &QueryCoordinator::worker_scan)
         .def("initialize_workers", &QueryCoordinator::initialize_workers)  // query_coordinator.h:150-160
         .def("shutdown_workers", &QueryCoordinator::shutdown_workers)
+        .def_readwrite("device_timing", &QueryCoordinator::device_timing_)  // query_coordinator.h: counters for device-tensor searches
         .def_readonly("workers_initialized", &QueryCoordinator::workers_initialized_)
         .def_readonly("num_workers", &QueryCoordinator::num_workers_);
 
@@ -148,6 +149,7 @@ PYBIND11_MODULE(_bindings, m) {
         .def_readwrite("enable_delete_rejection", &MaintenancePolicyParams::enable_delete_rejection)
         .def_readwrite("delete_threshold_ns", &MaintenancePolicyParams::delete_threshold_ns)
         .def_readwrite("split_threshold_ns", &MaintenancePolicyParams::split_threshold_ns)
+        .def_readwrite("split_after_delete_rejection", &MaintenancePolicyParams::split_after_delete_rejection)  // extension, common.h
         .def("__repr__", [](const MaintenancePolicyParams &p) {  // wrap.cpp:211-226
             return Repr().kv("maintenance_policy", p.maintenance_policy).kv("window_size", p.window_size)
                 .kv("refinement_radius", p.refinement_radius).kv("refinement_iterations", p.refinement_iterations)

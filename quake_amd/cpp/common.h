@@ -33,6 +33,11 @@ struct MaintenancePolicyParams {  // common.h:104-118
     bool enable_delete_rejection = true;
     float delete_threshold_ns = 10.0f;
     float split_threshold_ns = 10.0f;
+    // EXTENSION (no reference field): a partition the delete branch examined and the rejection rule KEPT is then tested for a split
+    // like every other kept partition.  The reference (maintenance_policies.cpp:68-131) never reaches its split test for such a
+    // partition -- and its delete model is most negative for the partitions that are both larger and hotter than average, so the
+    // lists a skewed insert stream grows are never split.  false = the reference's decisions.
+    bool split_after_delete_rejection = false;
 };
 
 struct IndexBuildParams {  // common.h:123-143

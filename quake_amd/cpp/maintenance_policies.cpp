@@ -399,7 +399,10 @@ shared_ptr<MaintenanceTimingInfo> MaintenancePolicy::perform_maintenance() {  //
                     rs.push_back(sizes.count(c.first) ? sizes[c.first] : 0);
                     rh.push_back(hit_rate_of(c.first));
                 }
-                if (ce.compute_delete_delta_w_reassign(size, hr, total_partitions, rc, rs, rh) < -p.delete_threshold_ns) to_delete.push_back(pid);
+                if (ce.compute_delete_delta_w_reassign(size, hr, total_partitions, rc, rs, rh) < -p.delete_threshold_ns)
+                    to_delete.push_back(pid);
+                else if (p.split_after_delete_rejection && ce.compute_split_delta(size, hr, total_partitions) < -p.split_threshold_ns)
+                    to_split.push_back(pid);  // (extension, common.h: kept by the rejection -> split test)
             } else {
                 to_delete.push_back(pid);
             }

@@ -114,7 +114,8 @@ shared_ptr<SearchResult> QueryCoordinator::search(Tensor x, shared_ptr<SearchPar
         ~TimingMode() {
             if (c) (void)qk_ctx_set_timing(c, was);
         }
-    } timing_mode(ctx, true);
+    } timing_mode(ctx, !on_dev || device_timing_);
+    qk_timing *tmp = (!on_dev || device_timing_) ? &tm : nullptr;  // device tensors: asynchronous unless the caller opted in
     if (sp->recall_target > 0.0f && parent_ && !sp->batched_scan) {
         // adaptive partition scanning (:502,637-641): candidates = nlist * initial_search_fraction; with workers the rounds run on
         // the group's lead and every member scans the pairs whose partitions it holds (the APS hook of worker_scan, :364-428)
@@ -130,16 +131,19 @@ shared_ptr<SearchResult> QueryCoordinator::search(Tensor x, shared_ptr<SearchPar
         ti->partitions_scanned = (int)nscan.sum().item<int64_t>();
         ti->job_wait_time_ns = (int64_t)(tm.total_ms * 1e6);
     } else if (track) {
-        // hit tracking on: the probe list is needed on the host, so the coarse step and the scan are two calls
+        // hit tracking on: the probed lists go to the policy.  One store: qk_search_tracked (the nearest-centroid step writes `pids`, the
+        // scan reads it, one enqueue); a group: the coarse step on the shared context, then the members' scan
         const int kk = (int)std::min<int64_t>(nprobe, parent_->ntotal());
-        Tensor pids = torch::empty({Q, kk}, torch::TensorOptions().dtype(torch::kInt64).device(xq.device()));
-        qk_check(qk_coarse(ctx, parent_->store(), xq.data_ptr<float>(), Q, nprobe, (int)metric_, pids.data_ptr<int64_t>(), nullptr, mem));
-        if (group)
+        Tensor pids = torch::empty({Q, std::max(kk, 1)}, torch::TensorOptions().dtype(torch::kInt64).device(xq.device()));
+        if (group) {
+            qk_check(qk_coarse(ctx, parent_->store(), xq.data_ptr<float>(), Q, nprobe, (int)metric_, pids.data_ptr<int64_t>(), nullptr, mem));
             qk_check(qk_group_scan(group, xq.data_ptr<float>(), Q, pids.data_ptr<int64_t>(), kk, k, (int)metric_,
                                    res->ids.data_ptr<int64_t>(), res->distances.data_ptr<float>(), mem, &tm));
-        else
-            qk_check(qk_scan(ctx, store, xq.data_ptr<float>(), Q, pids.data_ptr<int64_t>(), kk, k, (int)metric_,
-                             res->ids.data_ptr<int64_t>(), res->distances.data_ptr<float>(), mem, &tm));
+        } else {
+            qk_check(qk_search_tracked(ctx, parent_->store(), store, xq.data_ptr<float>(), Q, nprobe, k, (int)metric_,
+                                       res->ids.data_ptr<int64_t>(), res->distances.data_ptr<float>(), pids.data_ptr<int64_t>(), mem, &tm));
+        }
+        if (kk < 1) pids = pids.slice(1, 0, 0);
         maintenance_policy_->record_query_batch(host_i64(pids));
         ti->partitions_scanned = (int)tm.partitions_scanned;
         ti->job_enqueue_time_ns = (int64_t)(tm.group_ms * 1e6);
@@ -147,13 +151,13 @@ shared_ptr<SearchResult> QueryCoordinator::search(Tensor x, shared_ptr<SearchPar
         ti->result_aggregate_time_ns = (int64_t)(tm.merge_ms * 1e6);
     } else if (group) {  // workers: every member scans the partitions it holds (worker_scan, :243-469), the lead merges
         qk_check(qk_group_search(group, parent_->store(), xq.data_ptr<float>(), Q, nprobe, k, (int)metric_,
-                                 res->ids.data_ptr<int64_t>(), res->distances.data_ptr<float>(), mem, &tm));
+                                 res->ids.data_ptr<int64_t>(), res->distances.data_ptr<float>(), mem, tmp));
         ti->partitions_scanned = (int)tm.partitions_scanned;
         ti->job_wait_time_ns = (int64_t)(tm.scan_ms * 1e6);
         ti->result_aggregate_time_ns = (int64_t)(tm.merge_ms * 1e6);
     } else {
         qk_check(qk_search(ctx, parent_ ? parent_->store() : nullptr, store, xq.data_ptr<float>(), Q, nprobe, k, (int)metric_,
-                           res->ids.data_ptr<int64_t>(), res->distances.data_ptr<float>(), mem, &tm));
+                           res->ids.data_ptr<int64_t>(), res->distances.data_ptr<float>(), mem, tmp));
         ti->partitions_scanned = (int)tm.partitions_scanned;
         ti->job_enqueue_time_ns = (int64_t)(tm.group_ms * 1e6);
         ti->job_wait_time_ns = (int64_t)(tm.scan_ms * 1e6);
@@ -196,12 +200,13 @@ shared_ptr<SearchResult> QueryCoordinator::scan_partitions(Tensor x, Tensor part
     std::memset(&tm, 0, sizeof(tm));
     Tensor none = torch::full({Q, 1}, -1, torch::TensorOptions().dtype(torch::kInt64).device(xq.device()));  // zero partitions: padded output (:459-497)
     const Tensor &pp = P > 0 ? pids : none;
+    qk_timing *tmp = (!on_dev || device_timing_) ? &tm : nullptr;  // (as in search: device tensors stay asynchronous)
     if (group)
         qk_check(qk_group_scan(group, xq.data_ptr<float>(), Q, pp.data_ptr<int64_t>(), (int)pp.size(1), k, (int)metric_,
-                               res->ids.data_ptr<int64_t>(), res->distances.data_ptr<float>(), on_dev ? QK_MEM_DEVICE : QK_MEM_HOST, &tm));
+                               res->ids.data_ptr<int64_t>(), res->distances.data_ptr<float>(), on_dev ? QK_MEM_DEVICE : QK_MEM_HOST, tmp));
     else
         qk_check(qk_scan(partition_manager_->ctx(), store, xq.data_ptr<float>(), Q, pp.data_ptr<int64_t>(), (int)pp.size(1), k, (int)metric_,
-                         res->ids.data_ptr<int64_t>(), res->distances.data_ptr<float>(), on_dev ? QK_MEM_DEVICE : QK_MEM_HOST, &tm));
+                         res->ids.data_ptr<int64_t>(), res->distances.data_ptr<float>(), on_dev ? QK_MEM_DEVICE : QK_MEM_HOST, tmp));
     ti->partitions_scanned = (int)tm.partitions_scanned;
     ti->total_time_ns = ns_since(t0);
     return res;

@@ -24,6 +24,11 @@ public:
     bool workers_initialized_ = false;
     int num_workers_ = 0;
     bool debug_ = false;
+    // Device (CUDA) tensors in -> device tensors out, enqueued on torch's current stream with NO host synchronisation: the counters
+    // and phase times of SearchTimingInfo need one (they are read back from the device), so for device tensors they are filled only
+    // when this is set -- host-tensor searches synchronise anyway and always fill them (query_coordinator.cpp:612-657 always does: its
+    // scan is host code).  Recall-target searches and hit tracking read their counters in either case.
+    bool device_timing_ = false;
 
     QueryCoordinator(shared_ptr<QuakeIndex> parent, shared_ptr<PartitionManager> partition_manager,
                      shared_ptr<MaintenancePolicy> maintenance_policy, MetricType metric, int num_workers = 0);

@@ -58,7 +58,7 @@ int check_metric(int metric) {
 // `timing` are requested but read later, by qk_finish_timing, once every member of the group has been enqueued.
 int qk_run_search(qk_ctx *ctx, qk_store *parent, qk_store *s, const float *x, int64_t Q, const int64_t *pids, int P, int nprobe,
                   int k, int metric, int64_t *out_ids, float *out_dist, int mem, qk_timing *timing, bool coarse_only,
-                  bool defer_finish) {
+                  bool defer_finish, int64_t *probed_out) {
     QK_TRY(qk_check_overflow(ctx));  // a record-buffer overflow of an earlier launch is reported by the next call
     QK_HIP(hipSetDevice(ctx->device));
     if (timing) memset(timing, 0, sizeof(*timing));
@@ -71,6 +71,7 @@ int qk_run_search(qk_ctx *ctx, qk_store *parent, qk_store *s, const float *x, in
         kk = (int)std::min<int64_t>(nprobe, parent->ntotal);  // query_coordinator.cpp:641
         if (kk > QK_MAX_NPROBE) QK_FAIL(QK_ERR_UNSUPPORTED, "nprobe=%d exceeds QK_MAX_NPROBE=%d", kk, QK_MAX_NPROBE);
     }
+    if (!(use_parent && !coarse_only && kk > 0)) probed_out = nullptr;  // (nothing probed: the buffer may have no columns at all)
     const int Ps = coarse_only ? 0 : (use_parent ? kk : P);
     const int kout = coarse_only ? kk : k;
     // ---- stage caller buffers ------------------------------------------------------------------------
@@ -95,7 +96,9 @@ int qk_run_search(qk_ctx *ctx, qk_store *parent, qk_store *s, const float *x, in
         sv.x = x;
         sv.out_ids = out_ids;
         sv.out_dist = out_dist;
-        if (use_parent && !coarse_only) {
+        if (use_parent && !coarse_only && probed_out) {
+            sv.pids = probed_out;  // (qk_search_tracked: the nearest-centroid step writes the caller's [Q][nprobe] buffer, the scan reads it)
+        } else if (use_parent && !coarse_only) {
             QK_TRY(qk_stage_reserve(ctx, bp + 256));
             sv.pids = (const int64_t *)ctx->stage;
         } else {
@@ -103,7 +106,7 @@ int qk_run_search(qk_ctx *ctx, qk_store *parent, qk_store *s, const float *x, in
         }
     }
     // small batches: the whole search in one launch (qk_small.hip) -- no prep / group / seed / merge launches
-    if (use_parent && !coarse_only && kk > 0 && qk_small_supported(ctx, parent, s, Q, kk, k)) {
+    if (use_parent && !coarse_only && kk > 0 && !probed_out && qk_small_supported(ctx, parent, s, Q, kk, k)) {
         const bool tm = ctx->timing && timing;
         // one event pair around the one kernel (an event record costs the stream a few microseconds): ev[4], ev[7] per call,
         // the scan pair of a deferred group otherwise
@@ -161,7 +164,7 @@ int qk_run_search(qk_ctx *ctx, qk_store *parent, qk_store *s, const float *x, in
         ca.out_ids = coarse_only ? sv.out_ids : (int64_t *)sv.pids;
         ca.out_dist = coarse_only ? sv.out_dist : nullptr;
         ca.record_events = timing != nullptr;
-        if (!coarse_only && kk == 1 && k <= QK_MAX_K) ca.packed_out = &packed;  // nprobe = 1: see qk_scan_args::pids_packed
+        if (!coarse_only && kk == 1 && k <= QK_MAX_K && !probed_out) ca.packed_out = &packed;  // nprobe = 1: see qk_scan_args::pids_packed
         QK_TRY(qk_scan_device(ctx, parent, ca, coarse_only ? timing : nullptr, 0));
     }
     // ---- scan ------------------------------------------------------------------------------------------
@@ -196,6 +199,8 @@ int qk_run_search(qk_ctx *ctx, qk_store *parent, qk_store *s, const float *x, in
     if (mem == QK_MEM_HOST) {
         if (out_ids) QK_HIP(hipMemcpyAsync(out_ids, sv.out_ids, (size_t)Q * kout * 8, hipMemcpyDeviceToHost, ctx->stream));
         if (out_dist) QK_HIP(hipMemcpyAsync(out_dist, sv.out_dist, (size_t)Q * kout * 4, hipMemcpyDeviceToHost, ctx->stream));
+        if (probed_out && use_parent && !coarse_only && kk > 0)
+            QK_HIP(hipMemcpyAsync(probed_out, sv.pids, (size_t)Q * kk * 8, hipMemcpyDeviceToHost, ctx->stream));
         QK_HIP(hipStreamSynchronize(ctx->stream));
     }
     if (defer_finish) return QK_OK;
@@ -252,6 +257,15 @@ int qk_search(qk_ctx *ctx, qk_store *parent, qk_store *s, const float *x, int64_
     if (parent && nprobe <= 0) QK_FAIL(QK_ERR_INVALID, "qk_search: nprobe must be positive");
     QK_TRY(check_metric(metric));
     return qk_run_search(ctx, parent, s, x, Q, nullptr, 0, nprobe, k, metric, out_ids, out_dist, mem, timing, false, false);
+}
+
+int qk_search_tracked(qk_ctx *ctx, qk_store *parent, qk_store *s, const float *x, int64_t Q, int nprobe, int k, int metric,
+                      int64_t *out_ids, float *out_dist, int64_t *out_probed, int mem, qk_timing *timing) {
+    if (!ctx || !s || !parent || (Q > 0 && (!x || !out_ids || !out_probed))) QK_FAIL(QK_ERR_INVALID, "qk_search_tracked: null argument");
+    if (k <= 0) QK_FAIL(QK_ERR_INVALID, "qk_search_tracked: k must be positive");
+    if (nprobe <= 0) QK_FAIL(QK_ERR_INVALID, "qk_search_tracked: nprobe must be positive");
+    QK_TRY(check_metric(metric));
+    return qk_run_search(ctx, parent, s, x, Q, nullptr, 0, nprobe, k, metric, out_ids, out_dist, mem, timing, false, false, out_probed);
 }
 
 int qk_ctx_set_squared_l2(qk_ctx *ctx, int enabled) {

@@ -651,7 +651,19 @@ int qk_aps_run(qk_ctx *ctx, qk_store *parent, int64_t nlist, int d, const float 
     const int32_t *d_row_of = ctx->aps_rowof;
     int32_t *n_active = (int32_t *)(B + o_na);
 
-    hipEvent_t e0 = nullptr, e1 = nullptr;
+    // every way out of this function -- also the error exits inside the round loop -- destroys the timing events and leaves no
+    // kernel behind that still writes the context's round state (ctx->aps, the flag words): the next call reuses both
+    struct CallGuard {
+        hipStream_t st;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        bool drain = true;  // set false on the successful way out (which has synchronised or hands the stream on in order)
+        ~CallGuard() {
+            if (drain && hipStreamSynchronize(st) != hipSuccess) (void)hipGetLastError();
+            if (e0) (void)hipEventDestroy(e0);
+            if (e1) (void)hipEventDestroy(e1);
+        }
+    } guard{st};
+    hipEvent_t &e0 = guard.e0, &e1 = guard.e1;
     if (timing) {
         QK_HIP(hipEventCreate(&e0));
         QK_HIP(hipEventCreate(&e1));
@@ -781,7 +793,8 @@ int qk_aps_run(qk_ctx *ctx, qk_store *parent, int64_t nlist, int d, const float 
         // moment the count is visible (a device that has stopped answering shows up as an error of the query below)
         int32_t got = 0;
         for (long long spin = 0; (got = *flag) == 0; spin++) {
-            if ((spin & 0xFFFF) == 0xFFFF) {
+            __builtin_ia32_pause();  // (a round is 0.1-1 ms of device work: the waiting core stays off its sibling's issue slots)
+            if ((spin & 0x3FFF) == 0x3FFF) {
                 const hipError_t e = hipStreamQuery(st);
                 if (e == hipSuccess) {  // everything enqueued has run: the flag is final
                     got = *flag;
@@ -812,9 +825,8 @@ int qk_aps_run(qk_ctx *ctx, qk_store *parent, int64_t nlist, int d, const float 
         QK_HIP(hipEventElapsedTime(&ms, e0, e1));
         timing->total_ms = ms;
         timing->n_items = rounds;
-        QK_HIP(hipEventDestroy(e0));
-        QK_HIP(hipEventDestroy(e1));
     }
     (void)pairs_scanned;
+    guard.drain = false;
     return QK_OK;
 }

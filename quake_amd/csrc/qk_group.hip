@@ -224,7 +224,6 @@ int group_search(qk_group *g, qk_store *parent, const float *x, int64_t Q, const
         kk = (int)std::min<int64_t>(nprobe, parent->ntotal);  // query_coordinator.cpp:641
         if (kk > QK_MAX_NPROBE) QK_FAIL(QK_ERR_UNSUPPORTED, "nprobe=%d exceeds QK_MAX_NPROBE=%d", kk, QK_MAX_NPROBE);
     }
-    if (qk_round_up(k + 64, 64) > 1024) QK_FAIL(QK_ERR_UNSUPPORTED, "qk_group: k=%d exceeds the cross-member merge (k <= 960)", k);
     const bool no_lists = !use_parent && P_in == 0;  // zero partitions: padded output (query_coordinator.cpp:459-497)
     const int P = use_parent ? std::max(kk, 1) : (no_lists ? 1 : P_in);
     const bool split = use_parent && kk > 0 && G > 1 && Q >= QK_GROUP_SPLIT_MIN_Q * G;
@@ -512,6 +511,12 @@ int qk_group_list_size(qk_group *g, int64_t list_no, int64_t *out) {
     if (!g || !out) QK_FAIL(QK_ERR_INVALID, "qk_group_list_size: null argument");
     if (list_no < 0) QK_FAIL(QK_ERR_NOT_FOUND, "List does not exist in list_size (list %lld)", (long long)list_no);
     return qk_store_list_size(owner(g, list_no)->store, list_no, out);
+}
+
+int qk_group_list_sizes(qk_group *g, const int64_t *list_nos, int64_t n, int64_t *out) {
+    if (!g || (n > 0 && (!list_nos || !out))) QK_FAIL(QK_ERR_INVALID, "qk_group_list_sizes: null argument");
+    for (int64_t i = 0; i < n; i++) QK_TRY(qk_group_list_size(g, list_nos[i], out + i));
+    return QK_OK;
 }
 
 int64_t qk_group_ntotal(qk_group *g) {

@@ -305,7 +305,7 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
 // the body of qk_coarse / qk_scan / qk_search (qk_api.hip) and the read-back of its scalars; see there
 int qk_run_search(qk_ctx *ctx, qk_store *parent, qk_store *s, const float *x, int64_t Q, const int64_t *pids, int P, int nprobe,
                   int k, int metric, int64_t *out_ids, float *out_dist, int mem, qk_timing *timing, bool coarse_only,
-                  bool defer_finish);
+                  bool defer_finish, int64_t *probed_out = nullptr);
 int qk_finish_timing(qk_ctx *ctx, qk_store *s, qk_timing *t, bool have_coarse, int scan_ev_base);
 // adaptive (recall-target) search: the rounds run on `ctx`; a round's (query, list) pairs are scanned by `scan` (qk_aps.hip)
 struct qk_aps_round {

@@ -575,11 +575,83 @@ __global__ __launch_bounds__(64) void k_merge_ranks(const int64_t *__restrict__ 
     }
 }
 
+// The same merge for k beyond the LDS pools (k > 960; the single-store search serves k up to 8192, so must a device group and the
+// RCCL exchange): every rank's k entries arrive SORTED under the (key, id) order with the -1 padding behind them, so the merged
+// position of an entry is its own position plus, for every other rank, the number of that rank's entries in front of it -- a
+// binary search each (merge path), no pool, no selection.  One workgroup per query; entry (r, i) goes straight to its place when
+// that is below k.  An id held by two ranks (the stores do not enforce unique ids) keeps the lower rank's copy in front.
+__global__ __launch_bounds__(256) void k_merge_ranks_large(const int64_t *__restrict__ in_ids0, const float *__restrict__ in_key0, int G,
+                                                           size_t id_stride, size_t key_stride, int64_t Q, int k, int metric, int sqrt_l2,
+                                                           int64_t *out_ids, float *out_dist) {
+    __shared__ int nvalid[64];
+    const int tid = threadIdx.x;
+    const int64_t q = blockIdx.x, base0 = q * k;
+    auto ids_of = [&](int r) { return (const int64_t *)((const unsigned char *)in_ids0 + (size_t)r * id_stride) + base0; };
+    auto key_of = [&](int r) { return (const float *)((const unsigned char *)in_key0 + (size_t)r * key_stride) + base0; };
+    if (tid < G) {  // valid entries of rank tid: the first -1 id (padding is a suffix)
+        const int64_t *ids = ids_of(tid);
+        int lo = 0, hi = k;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (ids[mid] >= 0) lo = mid + 1; else hi = mid;
+        }
+        nvalid[tid] = lo;
+    }
+    __syncthreads();
+    int total = 0;
+    for (int r = 0; r < G; r++) total += nvalid[r];
+    for (int64_t e = tid; e < (int64_t)G * k; e += 256) {
+        const int r = (int)(e / k), i = (int)(e - (int64_t)r * k);
+        if (i >= nvalid[r]) continue;
+        const int64_t id = ids_of(r)[i];
+        const float v = key_of(r)[i];
+        const uint32_t o = metric == QK_METRIC_L2 ? ord_from_l2(v) : ord_from_ip(v);
+        int rank = i;
+        for (int r2 = 0; r2 < G && rank < k; r2++) {
+            if (r2 == r) continue;
+            const int64_t *ids2 = ids_of(r2);
+            const float *key2 = key_of(r2);
+            int lo = 0, hi = nvalid[r2];
+            while (lo < hi) {  // entries of r2 in front of (o, id): strictly smaller, or equal when r2 is the lower rank
+                const int mid = (lo + hi) >> 1;
+                const uint32_t o2 = metric == QK_METRIC_L2 ? ord_from_l2(key2[mid]) : ord_from_ip(key2[mid]);
+                const int64_t id2 = ids2[mid];
+                const bool front = o2 < o || (o2 == o && (id2 < id || (id2 == id && r2 < r)));
+                if (front) lo = mid + 1; else hi = mid;
+            }
+            rank += lo;
+        }
+        if (rank < k) {
+            out_ids[base0 + rank] = id;
+            if (out_dist) {
+                float od;
+                if (metric == QK_METRIC_L2) {
+                    const float d2 = __uint_as_float(o);
+                    od = sqrt_l2 ? sqrtf(d2) : d2;
+                } else {
+                    od = ip_from_ord(o);
+                }
+                out_dist[base0 + rank] = od;
+            }
+        }
+    }
+    for (int e = min(total, k) + tid; e < k; e += 256) {
+        out_ids[base0 + e] = -1;
+        if (out_dist) out_dist[base0 + e] = metric == QK_METRIC_IP ? -INFINITY : INFINITY;
+    }
+}
+
 static int launch_merge_ranks(qk_ctx *ctx, const int64_t *in_ids, const float *in_key, int G, size_t id_stride, size_t key_stride,
                               int64_t Q, int k, int metric, int64_t *out_ids, float *out_dist, bool sqrt_l2) {
     if (Q <= 0) return QK_OK;
     const int Cm = qk_round_up(k + 64, 64);
-    if (Cm > 1024) QK_FAIL(QK_ERR_UNSUPPORTED, "qk_merge_topk: k=%d too large", k);
+    if (Cm > 1024) {
+        if (G > 64) QK_FAIL(QK_ERR_UNSUPPORTED, "qk_merge_topk: k=%d with %d ranks (the sorted-run merge holds 64 ranks)", k, G);
+        hipLaunchKernelGGL(k_merge_ranks_large, dim3((unsigned)Q), dim3(256), 0, ctx->stream, in_ids, in_key, G, id_stride, key_stride, Q, k,
+                           metric, sqrt_l2 ? 1 : 0, out_ids, out_dist);
+        QK_HIP(hipGetLastError());
+        return QK_OK;
+    }
     const size_t lds = (size_t)Cm * 12;
     const int mc = Cm <= 128 ? 2 : Cm <= 256 ? 4 : Cm <= 512 ? 8 : 16;
     hipStream_t st = ctx->stream;

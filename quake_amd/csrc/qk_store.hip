@@ -649,7 +649,14 @@ int qk_store_csr_end(qk_store *s, qk_csr_build *b, int rc) {
     b->d_offsets = b->d_part_row = nullptr;
     QK_TRY(rc);
     s->table_dirty = true;
-    return qk_store_sync_table(s);
+    QK_TRY(qk_store_sync_table(s));
+    // the id -> list index is built HERE, with the bulk build (16 host threads: ~0.3 s at 50M ids), not by the first remove / get_vector
+    // that needs it: on a serving index that first call was a 0.3-1.8 s stall (qk_store_counters: id_index_rebuilds stays 0 after this)
+    s->id_to_list.clear();
+    s->index_valid = false;
+    qk_store_ensure_index(s);
+    s->counters[6]--;  // (part of the build, not a rebuild)
+    return QK_OK;
 }
 
 extern "C" {
@@ -810,6 +817,15 @@ int qk_store_list_size(qk_store *s, int64_t list_no, int64_t *out) {
     if (!s || !out) QK_FAIL(QK_ERR_INVALID, "qk_store_list_size: null argument");
     QK_TRY(check_list(s, list_no, "list_size"));
     *out = s->parts[list_no].size;
+    return QK_OK;
+}
+
+int qk_store_list_sizes(qk_store *s, const int64_t *list_nos, int64_t n, int64_t *out) {
+    if (!s || (n > 0 && (!list_nos || !out))) QK_FAIL(QK_ERR_INVALID, "qk_store_list_sizes: null argument");
+    for (int64_t i = 0; i < n; i++) {
+        QK_TRY(check_list(s, list_nos[i], "list_sizes"));
+        out[i] = s->parts[list_nos[i]].size;
+    }
     return QK_OK;
 }
 

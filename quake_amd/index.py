@@ -78,6 +78,14 @@ class MaintenancePolicyParams(_Summary):  # common.h:104-118, wrap.cpp:189-226
         self.enable_delete_rejection = True
         self.delete_threshold_ns = 10.0
         self.split_threshold_ns = 10.0
+        # EXTENSION (not a reference field; not in __repr__, which stays the reference's): a partition that entered the delete
+        # branch and was KEPT by the rejection rule is then examined for a split like every other kept partition.  The reference
+        # (maintenance_policies.cpp:68-131) never does: its delete model spreads a partition's vectors and hits evenly over all
+        # others, which is strongly negative for exactly the partitions that are both larger and hotter than average -- they enter
+        # the delete branch, the rejection (which looks at where the vectors would really go) keeps them, and the `else` with the
+        # split test is never reached: the lists a skewed insert stream grows are the ones that are never split.  False = the
+        # reference's decisions, bit for bit.
+        self.split_after_delete_rejection = False
 
 
 class IndexBuildParams(_Summary):  # common.h:123-143, wrap.cpp:131-150
@@ -297,6 +305,10 @@ class QuakeIndex:
         # that changes a list's size or reads the policy (add / remove / refine / maintenance / a new policy) -- so every hit is
         # credited with the size its list had when it was scanned, as if it had been recorded inside search
         self._pending_hits = []
+        # counts everything that changes a list's contents or a centroid (add / remove / refine / split / delete): what the policy
+        # derived from the lists (where a delete candidate's vectors would go) stays valid while it does not move
+        self._mutations = 0
+        self._reassign_cache = {}
 
     # -- helpers -------------------------------------------------------------------------------------------------
     @property
@@ -460,13 +472,13 @@ class QuakeIndex:
         self._ctx.set_timing(1)
         try:
             if self.track_hits and self.parent is not None:
-                # hit tracking for maintenance(): the probed partitions are needed on the host, so coarse and scan are
-                # two calls here (same kernels, one extra copy of [Q, nprobe] ids)
-                pids, _ = self._ctx.coarse(self.parent._store, xd, nprobe, self.metric_, values=False)
+                # hit tracking for maintenance(): the probed partitions are needed by the policy (later, on the host)
                 if grp is not None:
+                    pids, _ = self._ctx.coarse(self.parent._store, xd, nprobe, self.metric_, values=False)
                     ids, dist, tm = grp.scan(xd, pids, int(k), self.metric_, timing=True)
-                else:
-                    ids, dist, tm = self._ctx.scan(self._store, xd, pids, int(k), self.metric_, timing=True)
+                else:  # one enqueue: the nearest-centroid step writes the list numbers where the policy will read them
+                    ids, dist, pids, tm = self._ctx.search_tracked(self.parent._store, self._store, xd, nprobe, int(k), self.metric_,
+                                                                   timing=True)
                 self._pending_hits.append(pids)
                 if len(self._pending_hits) >= 64:
                     self._flush_hits()
@@ -551,6 +563,7 @@ class QuakeIndex:
         info.find_partition_time_us = _us(t0)
         t0 = time.perf_counter()
         self._store.add_batch(idd, xd, assign.contiguous())  # per-list append order = input order (:245-258)
+        self._mutations += 1
         self._resident.update(idn)  # only once the device step succeeded: a failed add leaves no phantom ids behind
         info.modify_time_us = _us(t0)
         return info
@@ -571,6 +584,7 @@ class QuakeIndex:
         info.input_validation_time_us = _us(t0)
         t0 = time.perf_counter()
         self._store.remove_ids(idn)
+        self._mutations += 1
         info.modify_time_us = _us(t0)
         return info
 
@@ -591,6 +605,7 @@ class QuakeIndex:
             partition_ids = self.parent.get_ids()
         if partition_ids.shape[0] == 0:
             return
+        self._mutations += 1
         cent = self.parent.get(partition_ids)
         new_c = self._store.refine_lists(partition_ids.reshape(-1).cpu().numpy(), cent.numpy(), self.metric_, int(iterations))
         self.parent.modify(partition_ids, torch.from_numpy(np.ascontiguousarray(new_c)))
@@ -644,7 +659,7 @@ class QuakeIndex:
         return self._policy().perform_maintenance()
 
     def _partition_sizes(self, pids):
-        return [int(self._store.list_size(int(p))) for p in pids]
+        return self._store.list_sizes(np.asarray([int(p) for p in pids], np.int64)).tolist()  # one call (qk_store_list_sizes)
 
     def _list_ids(self):
         return [int(p) for p in self._store.list_ids()]
@@ -664,7 +679,15 @@ class QuakeIndex:
         50M index has hundreds of delete candidates per maintenance call): the lists are extracted on the device, one nearest-two
         search per chunk of ~2^18 rows, one unique over (partition, target) keys.  -> {pid: (pids, counts)}."""
         pids = [int(p) for p in pids]
-        out = {p: ([], []) for p in pids}
+        # (the policy asks for the SAME candidates call after call -- the partitions its delete model dislikes are the large, hot ones,
+        #  and they stay that -- : answers are kept while nothing changed a list or a centroid; 16 ms per call at 10M otherwise)
+        if self._reassign_cache.get("epoch") != self._mutations:
+            self._reassign_cache = {"epoch": self._mutations, "targets": {}}
+        known = self._reassign_cache["targets"]
+        out = {p: known[p] for p in pids if p in known}
+        pids = [p for p in pids if p not in known]
+        for p in pids:
+            out[p] = ([], [])
         if not pids:
             return out
         npart = None
@@ -703,6 +726,8 @@ class QuakeIndex:
             for sgi in np.unique(segs):
                 m = segs == sgi
                 out[pids[int(sgi)]] = ([int(t) for t in tgt[m]], [int(c) for c in counts[m]])
+        for p in pids:
+            known[p] = out[p]
         return out
 
     def _neighbour_partitions(self, pids, radius):
@@ -714,9 +739,11 @@ class QuakeIndex:
         return [int(v) for v in out[out != -1].tolist()]
 
     def _select_partitions(self, pids):  # partition_manager.cpp:344-390
+        """(vectors, ids) of the given partitions: vectors as CUDA tensors extracted on the device (no host hop: a maintenance call
+        that splits 200 partitions of a 10M index moved 0.5 GB through the host here), ids from the store's host mirror"""
         vecs, ids = [], []
         for p in pids:
-            v, i = self._store.get_list(int(p))
+            v, i = self._store.get_list_device(int(p))
             vecs.append(v)
             ids.append(i)
         return vecs, ids
@@ -724,18 +751,16 @@ class QuakeIndex:
     def _split_partitions(self, pids):  # :392-444: 2-means of every partition (qk_kmeans on the GPU)
         vecs, ids = self._select_partitions(pids)
         out_c, out_v, out_i = [], [], []
-        for v, i in zip(vecs, ids):
-            assert v.shape[0] >= 4, "Partition must have at least 8 vectors to split."  # (the reference's message, :412)
-            xd = torch.from_numpy(v).cuda(self._device)
+        for xd, i in zip(vecs, ids):
+            assert xd.shape[0] >= 4, "Partition must have at least 8 vectors to split."  # (the reference's message, :412)
             cent, assign, xd = self._ctx.kmeans(xd, 2, self.metric_, niter=5, seed=1234)
-            a = assign.cpu().numpy()
-            vv = xd.cpu().numpy()
+            left = assign == 0
+            lh = left.cpu().numpy()  # (n bytes: the one transfer of a split)
             cent = cent.cpu().numpy()
-            for j in range(2):
-                m = a == j
+            for j, (md, mh) in enumerate(((left, lh), (~left, ~lh))):
                 out_c.append(cent[j])
-                out_v.append(np.ascontiguousarray(vv[m]))
-                out_i.append(np.ascontiguousarray(i[m]))
+                out_v.append(xd[md])                       # stays on the device: add_entries ingests it from there
+                out_i.append(np.ascontiguousarray(i[mh]))
         return {"centroids": np.stack(out_c), "vectors": out_v, "vector_ids": out_i}
 
     def _add_partitions(self, clustering):  # :489-520
@@ -745,26 +770,32 @@ class QuakeIndex:
         for pid, v, i in zip(new_pids, clustering["vectors"], clustering["vector_ids"]):
             self._store.add_list(pid)
             if v.shape[0]:
+                if torch.is_tensor(v) and v.is_cuda:
+                    i = torch.from_numpy(np.ascontiguousarray(i)).cuda(v.device)  # (device vectors: ids follow them)
                 self._store.add_entries(pid, i, v)
         self.parent.add(torch.from_numpy(np.ascontiguousarray(clustering["centroids"])),
                         torch.tensor(new_pids, dtype=torch.int64))
+        self._mutations += 1
         return new_pids
 
     def _delete_partitions(self, pids, reassign=True):  # :522-554
         if self.parent is None:
             raise RuntimeError("Index is not partitioned")
-        vecs, ids = self._select_partitions(pids)
+        vecs, ids = self._select_partitions(pids) if reassign else ([], [])
         self.parent.remove(torch.tensor([int(p) for p in pids], dtype=torch.int64))
         for p in pids:
             self._store.remove_list(int(p))
+        self._mutations += 1
         if reassign:
-            for v, i in zip(vecs, ids):
-                if v.shape[0] == 0:
-                    continue
-                # PartitionManager::add(vectors, ids, {}, check_uniques = false): nearest remaining centroid
-                xd = torch.from_numpy(v).cuda(self._device)
+            # PartitionManager::add(vectors, ids, {}, check_uniques = false): nearest remaining centroid -- of ALL the deleted
+            # partitions' vectors at once (one coarse step, one add_batch: per-list append order = input order, the order of the
+            # one-by-one loop)
+            keep = [(v, i) for v, i in zip(vecs, ids) if v.shape[0]]
+            if keep:
+                xd = torch.cat([v for v, _ in keep], 0)
+                idd = torch.from_numpy(np.concatenate([i for _, i in keep])).cuda(self._device)
                 near, _ = self._ctx.coarse(self.parent._store, xd, 1, self.metric_, values=False)
-                self._store.add_batch(torch.from_numpy(i).cuda(self._device), xd, near.reshape(-1).contiguous())
+                self._store.add_batch(idd, xd, near.reshape(-1).contiguous())
 
     # -- sizes ---------------------------------------------------------------------------------------------------------------
     def ntotal(self):

@@ -372,14 +372,18 @@ class MaintenanceCostEstimator:
         if total_partitions <= 1:
             return 0.0
         assert len(reassign_sizes) == len(reassign_counts) == len(reassign_hit_rates)
-        L = self.latency_estimator_.estimate_scan_latency
+        Ls, Lm = self.latency_estimator_.estimate_scan_latency, self.latency_estimator_.estimate_many
         k = self.k_
-        delta_overhead = L(total_partitions - 1, k) - L(total_partitions, k)
-        removal_delta = hit_rate * L(partition_size, k)
+        delta_overhead = Ls(total_partitions - 1, k) - Ls(total_partitions, k)
+        removal_delta = hit_rate * Ls(partition_size, k)
         reassign_delta = 0.0
-        for sz, hr in zip(reassign_sizes, reassign_hit_rates):
-            old = hr * L(int(sz), k)
-            reassign_delta += (hr + hit_rate) * L(int(sz + partition_size), k) - old
+        if len(reassign_sizes):
+            # the latencies of all targets at once (estimate_many == the scalar call, bit for bit); the sum in the targets' order
+            sz = np.asarray(reassign_sizes, np.int64)
+            hr = np.asarray(reassign_hit_rates, np.float64)
+            terms = (hr + hit_rate) * Lm(sz + int(partition_size), k) - hr * Lm(sz, k)
+            for t in terms.tolist():
+                reassign_delta += t
         return delta_overhead + removal_delta + reassign_delta
 
 
@@ -414,34 +418,52 @@ class MaintenancePolicy:
         total_partitions = idx.nlist()
         scan_fraction = tr.get_current_scan_fraction()
         avg_size = idx.ntotal() // max(total_partitions, 1)
-        sizes = dict(zip(all_pids, idx._partition_sizes(all_pids)))
-        to_delete, to_split = [], []
         ce = self.cost_estimator_
-        size_v = np.array([sizes[pid] for pid in all_pids], np.int64)
-        hr_v = (np.array([hits.get(pid, 0) for pid in all_pids], np.float32) / np.float32(p.window_size)).astype(np.float64)
+        # the walk over the partitions (maintenance_policies.cpp:63-131) as array operations in partition order -- the same decisions:
+        # every delta is the scalar function's value bit for bit (compute_deltas_many / estimate_many), only the Python loop is gone
+        # (a 50M index has 20000 partitions; the loop, a size lookup per partition and per reassignment target through ctypes, and the
+        # scalar cost calls were most of a maintenance call that decided to do nothing)
+        pid_v = np.asarray(all_pids, np.int64)
+        size_v = np.asarray(idx._partition_sizes(all_pids), np.int64)
+        sizes = dict(zip(all_pids, size_v.tolist()))
+        hit_v = np.zeros(pid_v.shape[0], np.float32)
+        if hits:
+            pos = {pid: i for i, pid in enumerate(all_pids)}
+            for pid, h in hits.items():
+                i = pos.get(int(pid))
+                if i is not None:
+                    hit_v[i] = h
+        else:
+            pos = None
+        hr_v = (hit_v / np.float32(p.window_size)).astype(np.float64)
         dd_v, sd_v = ce.compute_deltas_many(size_v, hr_v, total_partitions, scan_fraction, avg_size)
+        in_delete = dd_v < -p.delete_threshold_ns
+        big = size_v > p.min_partition_size
+        split_ok = sd_v < -p.split_threshold_ns
+        examined = in_delete & big if p.enable_delete_rejection else np.zeros_like(in_delete)
+        delete_m = in_delete & ~examined           # the delete branch without the rejection rule (:128-130)
+        split_m = ~in_delete & big & split_ok      # the else branch (:131-139)
         # the delete candidates that the rejection rule examines: where their vectors would go is asked for all of them at once
-        cand = [pid for ix_, pid in enumerate(all_pids)
-                if float(dd_v[ix_]) < -p.delete_threshold_ns and p.enable_delete_rejection and sizes[pid] > p.min_partition_size]
-        targets = idx._reassign_targets_many(cand) if len(cand) > 1 and hasattr(idx, "_reassign_targets_many") else {}
-        for ix_, pid in enumerate(all_pids):
-            hit_rate = float(hr_v[ix_])
-            size = sizes[pid]
-            dd = float(dd_v[ix_])
-            if dd < -p.delete_threshold_ns:
-                if p.enable_delete_rejection and size > p.min_partition_size:
-                    # where would its vectors go?  second-nearest centroid of every vector (:79-101)
-                    uniq, counts = targets[pid] if pid in targets else idx._reassign_targets(pid)
-                    rs = idx._partition_sizes(uniq)
-                    hr = [float(np.float32(hits.get(u, 0)) / np.float32(p.window_size)) for u in uniq]
-                    delta = ce.compute_delete_delta_w_reassign(size, hit_rate, total_partitions, counts, rs, hr)
-                    if delta < -p.delete_threshold_ns:
-                        to_delete.append(pid)
-                else:
-                    to_delete.append(pid)
-            elif size > p.min_partition_size:
-                if float(sd_v[ix_]) < -p.split_threshold_ns:
-                    to_split.append(pid)
+        cand_ix = np.nonzero(examined)[0]
+        cand = [all_pids[i] for i in cand_ix.tolist()]
+        if cand and hasattr(idx, "_reassign_targets_many"):
+            targets = idx._reassign_targets_many(cand)
+        else:
+            targets = {}
+        if cand and pos is None:
+            pos = {pid: i for i, pid in enumerate(all_pids)}
+        split_rejected = bool(getattr(p, "split_after_delete_rejection", False))
+        for i, pid in zip(cand_ix.tolist(), cand):
+            # where would its vectors go?  second-nearest centroid of every vector (:79-101)
+            uniq, counts = targets[pid] if pid in targets else idx._reassign_targets(pid)
+            tix = [pos[int(u)] for u in uniq]
+            delta = ce.compute_delete_delta_w_reassign(int(size_v[i]), float(hr_v[i]), total_partitions, counts, size_v[tix], hr_v[tix])
+            if delta < -p.delete_threshold_ns:
+                delete_m[i] = True
+            elif split_rejected and split_ok[i]:
+                split_m[i] = True  # (extension, MaintenancePolicyParams: kept by the rejection -> split test)
+        to_delete = [all_pids[i] for i in np.nonzero(delete_m)[0].tolist()]
+        to_split = [all_pids[i] for i in np.nonzero(split_m)[0].tolist()]
         if len(to_delete) >= total_partitions:
             # (safety, not in the reference: a model that wants every partition gone would leave the vectors nowhere to
             #  go -- the largest partition survives)

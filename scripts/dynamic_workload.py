@@ -35,7 +35,14 @@ def hot_corpus(n, d, dev, n_hot_comp=8, factor=10, cluster=2500):
     return torch.cat([xc, xh]).cpu(), torch.cat([q_cold, q_hot]).cpu(), n_cold, hot_each
 
 
+def env(name, dflt, typ=int):
+    return typ(os.environ[name]) if name in os.environ else dflt
+
+
 def main():
+    # scenario knobs (environment; the defaults are round 5's scenario): DW_HOT_FACTOR members of a hot component over a cold one's,
+    # DW_HOT_COMP components, DW_QBATCH queries per batch, DW_HOT_Q fraction of a batch asking around hot components, DW_WINDOW the
+    # policy's window, DW_EXT the split_after_delete_rejection extension (index.py MaintenancePolicyParams), DW_NPROBE, DW_TAG
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 2_000_000
     d = int(sys.argv[2]) if len(sys.argv) > 2 else 128
     n_ops = int(sys.argv[3]) if len(sys.argv) > 3 else 60
@@ -52,11 +59,11 @@ def main():
     torch.set_num_threads(8)
     t0 = time.time()
     if hot:
-        x, q, n_cold, hot_each = hot_corpus(n, d, dev)
-        hs = HotSamplers(n, n_cold)
+        x, q, n_cold, hot_each = hot_corpus(n, d, dev, n_hot_comp=env("DW_HOT_COMP", 8), factor=env("DW_HOT_FACTOR", 10))
+        hs = HotSamplers(n, n_cold, env("DW_HOT_Q", 0.5, float))
         n_initial = n_cold
         spec = WorkloadSpec(metric="l2", insert_ratio=0.3, delete_ratio=0.1, query_ratio=0.6, update_batch_size=hot_each // 2,
-                            query_batch_size=1024, number_of_operations=n_ops, initial_size=n_cold, cluster_size=2500, seed=1738)
+                            query_batch_size=env("DW_QBATCH", 1024), number_of_operations=n_ops, initial_size=n_cold, cluster_size=2500, seed=1738)
         rb = generate_workload(os.path.join(out, "w"), x, spec, queries=q, update_sampler=hs.update, query_sampler=hs.query)
     else:
         ncl = max(n // 2500, 16)
@@ -83,14 +90,15 @@ def main():
     results = {}
     for name, maint in (("warmup", False), ("static_partitions", False), ("with_maintenance", True)):
         mp = quake.MaintenancePolicyParams()
-        mp.window_size = 2048
+        mp.window_size = env("DW_WINDOW", 2048)
+        mp.split_after_delete_rejection = bool(env("DW_EXT", 1))
         mp.refinement_radius = 8
         mp.refinement_iterations = 2
         mp.split_threshold_ns = 10.0 * scale
         mp.delete_threshold_ns = 10.0 * scale
         t0 = time.time()
         sp = quake.SearchParams()
-        sp.k, sp.nprobe = 10, 8
+        sp.k, sp.nprobe = 10, env("DW_NPROBE", 8)
         index = None
         if maint:  # (the policy with the grid profiled above: one profiling pass for the whole script)
             import quake_amd
@@ -101,8 +109,17 @@ def main():
             index.build(x[first], first, bp)
             index.initialize_maintenance_policy(mp, cost_estimator=ce)
             index.track_hits = True
+        prof = None
+        if maint and env("DW_PROFILE", 0):
+            import cProfile
+            prof = cProfile.Profile()
+            prof.enable()
         res = replay_workload(os.path.join(out, "w"), os.path.join(out, name), name, nlist=n_initial // 2500, search_params=sp,
                               maintenance_params=mp if maint else None, index=index, keep_policy=maint)
+        if prof is not None:
+            import pstats
+            prof.disable()
+            pstats.Stats(prof, stream=sys.stderr).sort_stats("cumulative").print_stats(45)
         wall = time.time() - t0
 
         def mean(key, typ):
@@ -133,6 +150,13 @@ def main():
                                                                       if r["operation_type"] == "query"] or [0.0])), 4),
             "query_scan_ms_p50_second_half": round(float(np.median([r["phases"].get("scan_ms", 0.0) for r in res[len(res) // 2:]
                                                                      if r["operation_type"] == "query"] or [0.0])), 4),
+            "pair_rows_p50_second_half": int(np.median([r.get("pair_rows", 0) for r in res[len(res) // 2:] if r["operation_type"] == "query"] or [0])),
+            "unique_rows_p50_second_half": int(np.median([r.get("unique_rows", 0) for r in res[len(res) // 2:] if r["operation_type"] == "query"] or [0])),
+            "maintenance_ms_max": round(max([r.get("maintenance_ms", 0.0) for r in res] or [0.0]), 2),
+            "delete_ms_max": round(max([r["latency_ms"] for r in res if r["operation_type"] == "delete"] or [0.0]), 2),
+            "trace": [[r["operation_number"], r["operation_type"][0], r["n_list"], r["max_list_size"], r.get("n_splits", 0), r.get("n_deletes", 0),
+                       round(r.get("maintenance_ms", 0.0), 1), r["phases"].get("scan_ms"), round(r["latency_ms"], 2), r.get("pair_rows"), r.get("unique_rows")]
+                      for r in res],
             "refine_ms_total": round(sum(r.get("maintenance_phases", {}).get("refine_ms", 0.0) for r in res), 2),
             "split_ms_total": round(sum(r.get("maintenance_phases", {}).get("split_ms", 0.0) for r in res), 2),
             # the slow operations, attributed: every operation above 3x its type's median with what it paid for

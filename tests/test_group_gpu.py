@@ -82,6 +82,27 @@ def test_group_search_equals_single_store_and_oracle(capi, G, metric):
         assert (_np(di) == si).all() and (_bits(dd) == _bits(sd)).all()
 
 
+@pytest.mark.parametrize("G,k", [(2, 961), (3, 1500), (4, 4000)])
+def test_group_large_k_equals_single_store(capi, G, k):
+    """k beyond the LDS pools of the cross-member merge (k > 960): the sorted-run merge (k_merge_ranks_large, qk_merge.hip) -- the
+    reference has no k limit with workers (query_coordinator.cpp:243-469), and one store serves k up to 8192.  Also k larger than
+    everything the probed lists hold (padding behind the merged run)."""
+    ivf = make_ivf(30000, 32, 48, seed=9, empty=(3,))
+    ctx, parent, single, grp = _build(capi, ivf, G)
+    for Q, nprobe in [(5, 48), (40, 7), (3, 1)]:
+        q = make_queries(Q, 32, seed=200 + Q, like=ivf["x"])
+        si, sd = ctx.search(parent, single, q, nprobe, k, "l2")
+        gi, gd = grp.search(parent, q, nprobe, k, "l2")
+        assert (gi == si).all(), (G, k, Q, nprobe)
+        assert (_bits(gd) == _bits(sd)).all()
+        if nprobe == 1:
+            assert (gi[:, -1] == -1).all()  # one list of ~625 rows: fewer than k entries, the rest is padding
+    grp.close()
+    single.close()
+    parent.close()
+    ctx.close()
+
+
 def test_group_counters_sum_over_members(capi):
     ivf = make_ivf(40000, 32, 64, seed=5)
     ctx, parent, single, grp = _build(capi, ivf, 4)

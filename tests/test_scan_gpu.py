@@ -433,3 +433,33 @@ def test_two_contexts_search_one_store_concurrently():
     parent.close()
     c2.close()
     c1.close()
+
+
+@pytest.mark.parametrize("mem", ["host", "device"])
+def test_search_tracked_hands_out_the_probed_lists(ctx, mem):
+    """qk_search_tracked = qk_search + the list numbers every query scanned (what QuakeIndex::search passes to
+    MaintenancePolicy::record_query_hits, maintenance_policies.cpp:179-182): ids and distance bits of qk_search and of the oracle,
+    probed lists those of qk_coarse -- for one query and a batch, nprobe 1 (the packed nearest-centroid path of qk_search), nprobe
+    beyond the number of lists, host and device buffers."""
+    import torch
+    ivf = make_ivf(30000, 64, 48, seed=31, empty=(7,))
+    parent, s = build_stores(ctx, ivf)
+    for Q, nprobe, k in [(1, 5, 10), (9, 1, 3), (700, 1, 10), (300, 6, 10), (40, 100, 20)]:
+        q = make_queries(Q, 64, seed=32 + Q, like=ivf["x"])
+        qq = torch.from_numpy(q).cuda() if mem == "device" else q
+        gi, gd, gp, tm = ctx.search_tracked(parent, s, qq, nprobe, k, "l2", timing=True)
+        si, sd = ctx.search(parent, s, qq, nprobe, k, "l2")
+        cp, _ = ctx.coarse(parent, qq, nprobe, "l2")
+        if mem == "device":
+            torch.cuda.synchronize()
+            gi, gd, gp, si, sd, cp = (t.cpu().numpy() for t in (gi, gd, gp, si, sd, cp))
+        assert gp.shape == (Q, min(nprobe, 48))
+        np.testing.assert_array_equal(gp, cp)
+        np.testing.assert_array_equal(gi, si)
+        np.testing.assert_array_equal(gd.view(np.uint32), sd.view(np.uint32))
+        oi, od = O.search(q, ivf["centroids"], ivf["vecs"], ivf["ids"], ivf["offsets"], nprobe, k, "l2", batched_scan=True)
+        np.testing.assert_array_equal(gi, oi)
+        np.testing.assert_array_equal(gd.view(np.uint32), od.view(np.uint32))
+        assert tm["partitions_scanned"] > 0
+    s.close()
+    parent.close()

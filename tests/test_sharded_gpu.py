@@ -178,3 +178,39 @@ def test_packed_exchange_layout_and_merge(G, per, k, metric):
     torch.cuda.synchronize()
     assert torch.equal(pi, mi) and torch.equal(pd.view(torch.int32), md.view(torch.int32))
     ctx.close()
+
+
+@pytest.mark.parametrize("G,per,k,metric", [(2, 3, 961, "l2"), (5, 4, 2000, "ip"), (8, 2, 8192, "l2")])
+def test_merge_of_sorted_runs_for_large_k(G, per, k, metric):
+    """qk_merge_topk beyond k = 960 (k_merge_ranks_large): every rank's entries arrive sorted under (key, id) with the -1 padding
+    behind them -- what qk_search returns --, the merged row is the first k of the union under the same order; ties between ranks,
+    ranks with fewer than k entries, rows with fewer than k entries in total."""
+    from quake_amd.capi import Context
+    ctx = Context(0)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    rng = np.random.default_rng(7 * G + k)
+    rid = np.full((G, per, k), -1, np.int64)
+    rk = np.full((G, per, k), -np.inf if metric == "ip" else np.inf, np.float32)
+    for q in range(per):
+        ids = rng.permutation(G * k * 2)[:G * k].astype(np.int64)
+        for g in range(G):
+            nv = int(rng.integers(0, k + 1)) if q else k // (g + 2)  # row 0: few entries everywhere -> padding in the merged row
+            kk = (rng.integers(0, 40, nv) * 0.25).astype(np.float32)
+            ii = ids[g * k:g * k + nv]
+            order = np.lexsort((ii, -kk if metric == "ip" else kk))
+            rid[g, q, :nv], rk[g, q, :nv] = ii[order], kk[order]
+    mi, md = ctx.merge_topk(torch.from_numpy(rid).cuda(), torch.from_numpy(rk).cuda(), metric)
+    torch.cuda.synchronize()
+    mi, md = mi.cpu().numpy(), md.cpu().numpy()
+    for q in range(per):
+        ii, kk = rid[:, q].reshape(-1), rk[:, q].reshape(-1)
+        ok = ii >= 0
+        ii, kk = ii[ok], kk[ok]
+        order = np.lexsort((ii, -kk if metric == "ip" else kk))[:k]
+        want_i = np.full(k, -1, np.int64)
+        want_d = np.full(k, -np.inf if metric == "ip" else np.inf, np.float32)
+        want_i[:order.size] = ii[order]
+        want_d[:order.size] = kk[order] if metric == "ip" else np.sqrt(kk[order])
+        np.testing.assert_array_equal(mi[q], want_i)
+        np.testing.assert_array_equal(md[q].view(np.uint32), want_d.view(np.uint32))
+    ctx.close()
