@@ -1002,9 +1002,34 @@ def run_sharded(ctx, dev, args, dist, rank, world):
     ctx.set_timing(1)
     sb = torch.tensor([float(sharded.engine.last_scan_bytes(batches[0], nprobe, k))], device=dev, dtype=torch.float64)
     ctx.set_timing(0)
+    # what makes the first run on real hardware self-describing: every rank's own roofline line (its scan kernel's mean duration from
+    # its own HIP events, its own unique bytes), the device each rank sits on (N distinct PCI bus ids = N GPUs really took part),
+    # and the bytes of the two collectives of a step
+    my_roof = roofline_of(int(sb.item()), ev, kernel=ctx.last_scan_kernel())
+    props = torch.cuda.get_device_properties(dev)
+    me = {"rank": rank, "device_index": dev.index, "device": props.name,
+          "pci_bus_id": f"{getattr(props, 'pci_domain_id', 0):04x}:{getattr(props, 'pci_bus_id', -1):02x}:{getattr(props, 'pci_device_id', 0):02x}",
+          "uuid": str(getattr(props, "uuid", "")), "vectors": int(counts.sum()), "lists": int(len(own)),
+          "roofline": my_roof, "phases_ms": phases_of(ev_ph)}
+    seen = [None] * world
+    if world > 1:
+        dist.all_gather_object(seen, me)
+    else:
+        seen = [me]
+    kk = min(nprobe, nlist_g)
+    from quake_amd.sharded import topk_block_bytes
+    exchange = {
+        "all_gather_list_numbers": {"send_bytes_per_rank": per * kk * 8, "recv_bytes_per_rank": Q * kk * 8},
+        "all_to_all_topk": {"send_bytes_per_rank": world * topk_block_bytes(per, k), "recv_bytes_per_rank": world * topk_block_bytes(per, k),
+                            "record": "12 bytes per entry (int64 id + float32 key), block j = the results for the queries rank j owns"},
+        "collectives_per_step": 2,
+    }
     return {
         "value": round(Q * args.steps / elapsed, 1), "ms_per_step": round(1e3 * elapsed / args.steps, 4),
         "timed_groups": groups_of(gtimes, args.steps, Q),
+        "per_rank": seen, "exchange": exchange,
+        "rccl_ranks_seen": {"backend": str(dist.get_backend()), "ranks": world,
+                            "distinct_devices": len({(r_["pci_bus_id"], r_["uuid"], r_["device_index"]) for r_ in seen})},
         "config": {
             "workload": f"Synthetic {n * world // 1_000_000}M x {d} f32 {metric.upper()} Gaussian mixture, nlist={nlist_g} "
                         f"(one k-means over all ranks), lists sharded by number over {world} ranks, batch={Q} queries, k={k}, "
@@ -1015,7 +1040,7 @@ def run_sharded(ctx, dev, args, dist, rank, world):
             "sharding": "list p on rank p % N, centroids replicated; every rank computes the coarse step, scans the probed "
                         "lists it owns; all-to-all of the per-rank top-k, merge on the rank that owns the query",
         },
-        "roofline": roofline_of(int(sb.item()), ev, kernel=ctx.last_scan_kernel()),
+        "roofline": my_roof,
         "phases_ms": phases_of(ev_ph),
         "build": {"sharded_kmeans_s": round(t_kmeans, 2), "niter": args.niter},
     }
@@ -1350,6 +1375,9 @@ def main():
         result["batches_in_flight"] = main_res["batches_in_flight"]
     if main_res.get("host_api"):
         result["host_api"] = main_res["host_api"]
+    for key in ("per_rank", "exchange", "rccl_ranks_seen"):  # the N > 1 path: every rank's own roofline, the devices, the exchange
+        if main_res.get(key):
+            result[key] = main_res[key]
     if world == 1 and not force_sharded:
         result["cpu_baseline"] = main_res.get("cpu_baseline")
         if "speedup_vs_cpu" in main_res:

@@ -151,6 +151,10 @@ QK_API int qk_store_d(qk_store *s);
 QK_API int qk_store_list_ids(qk_store *s, int64_t *out_host, int64_t *n);
 /* get_codes / get_ids :76-90 as a copy-out: rows in partition order, row-major [n][d]. */
 QK_API int qk_store_get_list(qk_store *s, int64_t list_no, float *vecs_out, int64_t *ids_out, int mem);
+/* The same for n lists at once, rows (and ids) laid one list after the other in list_nos order -- the caller sizes the buffers from
+ * qk_store_list_sizes.  PartitionManager::select_partitions (partition_manager.cpp:344-390) / the rejection rule of the maintenance
+ * policy (maintenance_policies.cpp:79-101), which read hundreds of lists per call. */
+QK_API int qk_store_get_lists(qk_store *s, const int64_t *list_nos, int64_t n, float *vecs_out, int64_t *ids_out, int mem);
 /* get_vector_for_id :280-293 (first match in ascending list order); *found = 0 if absent. */
 QK_API int qk_store_get_vector(qk_store *s, int64_t id, float *vec_out_host, int *found);
 /* What the store's mutations have cost so far beyond the rows they were asked to write (no reference counterpart: IndexPartition
@@ -246,6 +250,11 @@ QK_API int qk_group_set_stream(qk_group *g, void *hip_stream);
 QK_API int qk_group_set_null_stream(qk_group *g);
 QK_API int qk_group_get_stream(qk_group *g, void **hip_stream, int *kind);
 QK_API int qk_group_synchronize(qk_group *g);                                   /* every member's stream */
+/* Submit threads (default on, G >= 2): the per-member pieces of a search -- pull the batch, rank a slice of it, scan, pack -- are
+ * enqueued by one persistent host thread per member instead of the caller's thread one member after the other (0.39 ms of host
+ * time per call at 8 members -> one member's share plus two fork-joins).  Same streams, same events, same results; 0 = the
+ * caller's thread does everything.  Reference: one scan thread per worker, query_coordinator.cpp:50-74,98-240. */
+QK_API int qk_group_set_submit_threads(qk_group *g, int enabled);
 QK_API int qk_group_set_form_feedback(qk_group *g, int enabled);                /* qk_ctx_set_form_feedback on every member */
 /* The store surface over the members (same arguments, same errors as the qk_store_* call each one routes to). */
 QK_API int qk_group_reset(qk_group *g);
@@ -263,6 +272,7 @@ QK_API int64_t qk_group_nlist(qk_group *g);
 QK_API int qk_group_d(qk_group *g);
 QK_API int qk_group_list_ids(qk_group *g, int64_t *out_host, int64_t *n);
 QK_API int qk_group_get_list(qk_group *g, int64_t list_no, float *vecs_out, int64_t *ids_out, int mem); /* complete on return */
+QK_API int qk_group_get_lists(qk_group *g, const int64_t *list_nos, int64_t n, float *vecs_out, int64_t *ids_out, int mem);
 QK_API int qk_group_get_vector(qk_group *g, int64_t id, float *vec_out_host, int *found);
 QK_API int64_t qk_group_device_bytes(qk_group *g);
 /* qk_store_refine_lists over lists of several members: they meet in a temporary store on the member holding the first one,

@@ -62,6 +62,7 @@ SIGNATURES = {
     "qk_store_remove_ids": (_int, [_vp, _i64, _vp, C.POINTER(_i64)]),
     "qk_store_list_size": (_int, [_vp, _i64, C.POINTER(_i64)]),
     "qk_store_list_sizes": (_int, [_vp, _vp, _i64, _vp]),
+    "qk_store_get_lists": (_int, [_vp, _vp, _i64, _vp, _vp, _int]),
     "qk_store_ntotal": (_i64, [_vp]),
     "qk_store_nlist": (_i64, [_vp]),
     "qk_store_d": (_int, [_vp]),
@@ -99,6 +100,7 @@ SIGNATURES = {
     "qk_group_get_stream": (_int, [_vp, C.POINTER(_vp), C.POINTER(_int)]),
     "qk_group_synchronize": (_int, [_vp]),
     "qk_group_set_form_feedback": (_int, [_vp, _int]),
+    "qk_group_set_submit_threads": (_int, [_vp, _int]),
     "qk_group_reset": (_int, [_vp]),
     "qk_group_add_list": (_int, [_vp, _i64]),
     "qk_group_remove_list": (_int, [_vp, _i64]),
@@ -108,6 +110,7 @@ SIGNATURES = {
     "qk_group_remove_ids": (_int, [_vp, _i64, _vp, C.POINTER(_i64)]),
     "qk_group_list_size": (_int, [_vp, _i64, C.POINTER(_i64)]),
     "qk_group_list_sizes": (_int, [_vp, _vp, _i64, _vp]),
+    "qk_group_get_lists": (_int, [_vp, _vp, _i64, _vp, _vp, _int]),
     "qk_group_ntotal": (_i64, [_vp]),
     "qk_group_nlist": (_i64, [_vp]),
     "qk_group_d": (_int, [_vp]),

@@ -441,6 +441,16 @@ class Store:
             check(self.lib.qk_store_get_list(self.h, int(list_no), None, _ptr(ids), QK_MEM_HOST))
         return vecs, ids
 
+    def get_lists_device(self, list_nos):
+        """rows of many lists, one list after the other, as ONE CUDA tensor [sum of sizes, d] (qk_store_get_lists) + the sizes"""
+        import torch
+        nos = np.ascontiguousarray(list_nos, dtype=np.int64).reshape(-1)
+        sizes = self.list_sizes(nos)
+        vecs = torch.empty((int(sizes.sum()), self.d), dtype=torch.float32, device=torch.device("cuda", self.ctx.device))
+        if vecs.shape[0]:
+            check(self.lib.qk_store_get_lists(self.h, _ptr(nos), nos.shape[0], _ptr(vecs), None, QK_MEM_DEVICE))
+        return vecs, sizes
+
     def get_vector(self, vid):
         out = np.empty(self.d, np.float32)
         found = C.c_int()
@@ -532,6 +542,10 @@ class Group:
     def set_form_feedback(self, enabled):
         check(self.lib.qk_group_set_form_feedback(self.h, int(bool(enabled))))
 
+    def set_submit_threads(self, enabled):
+        """one persistent enqueue thread per member (default) / everything on the caller's thread"""
+        check(self.lib.qk_group_set_submit_threads(self.h, int(bool(enabled))))
+
     # ---- the Store surface ------------------------------------------------------------------------------------------------
     def reset(self):
         check(self.lib.qk_group_reset(self.h))
@@ -611,6 +625,15 @@ class Group:
             check(self.lib.qk_group_get_list(self.h, int(list_no), _ptr(vecs), None, QK_MEM_DEVICE))
             check(self.lib.qk_group_get_list(self.h, int(list_no), None, _ptr(ids), QK_MEM_HOST))
         return vecs, ids
+
+    def get_lists_device(self, list_nos):
+        import torch
+        nos = np.ascontiguousarray(list_nos, dtype=np.int64).reshape(-1)
+        sizes = self.list_sizes(nos)
+        vecs = torch.empty((int(sizes.sum()), self.d), dtype=torch.float32, device=torch.device("cuda", self.device))
+        if vecs.shape[0]:
+            check(self.lib.qk_group_get_lists(self.h, _ptr(nos), nos.shape[0], _ptr(vecs), None, QK_MEM_DEVICE))
+        return vecs, sizes
 
     def get_vector(self, vid):
         out = np.empty(self.d, np.float32)

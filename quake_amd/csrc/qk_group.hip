@@ -20,7 +20,13 @@
 #include "qk_internal.h"
 
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
 #include <cstring>
+#include <functional>
+#include <mutex>
+#include <string>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -39,11 +45,86 @@ struct Member {
     hipEvent_t ev_coarse = nullptr, ev_done = nullptr;
 };
 
+// One submit thread per member (round 6).  A search enqueues ~45 us of host work per member (two pipeline enqueues, a peer
+// broadcast, a pack, events); one host thread doing that for 8 members took 0.36-0.39 ms per call -- more than a member's device
+// work at the 8-GPU configs[3] shape (0.22 ms), so the ONE host thread bounded the group.  The per-member pieces of a call are
+// independent (own context, own stream, own buffers; only events cross), so they are handed to G - 1 persistent threads while the
+// caller does member 0's: a call costs the host one member's share plus three fork-joins.  The workers spin for ~0.2 ms after a
+// piece (the next piece of the same call, or the next call of a serving loop, arrives within that) and sleep on a condition
+// variable otherwise.  Error text is thread-local in this library: a worker's message travels back with its status.
+struct MemberPool {
+    std::vector<std::thread> th;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::atomic<uint64_t> gen{0};
+    std::atomic<int> pending{0}, sleepers{0};
+    std::atomic<bool> stop{false};
+    const std::function<int(int)> *fn = nullptr;  // published by the bump of `gen`
+    int rc[64];
+    std::string err[64];
+
+    void worker(int j) {
+        uint64_t seen = 0;
+        for (;;) {
+            int spins = 0;
+            while (gen.load() == seen && !stop.load()) {
+                if (++spins < 40000) {
+                    __builtin_ia32_pause();
+                    continue;
+                }
+                std::unique_lock<std::mutex> lk(mu);
+                sleepers.fetch_add(1);
+                cv.wait(lk, [&] { return gen.load() != seen || stop.load(); });
+                sleepers.fetch_sub(1);
+                spins = 0;
+            }
+            if (stop.load()) return;
+            seen = gen.load();
+            rc[j] = (*fn)(j);
+            if (rc[j] != QK_OK) err[j] = qk_last_error();
+            pending.fetch_sub(1);
+        }
+    }
+    void start(int G) {
+        for (int j = 1; j < G; j++) th.emplace_back([this, j] { worker(j); });
+    }
+    void shutdown() {
+        stop.store(true);
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            cv.notify_all();
+        }
+        for (auto &t : th) t.join();
+        th.clear();
+    }
+    // f(j) for every member j in [0, G): j = 0 here, the others on their threads; returns the first failure in member order
+    int run(int G, const std::function<int(int)> &f) {
+        fn = &f;
+        pending.store(G - 1);
+        gen.fetch_add(1);
+        if (sleepers.load() > 0) {
+            std::lock_guard<std::mutex> lk(mu);
+            cv.notify_all();
+        }
+        const int rc0 = f(0);
+        while (pending.load() != 0) __builtin_ia32_pause();
+        if (rc0 != QK_OK) return rc0;
+        for (int j = 1; j < G; j++)
+            if (rc[j] != QK_OK) {
+                qk_set_error("%s", err[j].c_str());
+                return rc[j];
+            }
+        return QK_OK;
+    }
+};
+
 }  // namespace
 
 struct qk_group {
     int G = 0, d = 0;
     std::vector<Member> m;
+    MemberPool *pool = nullptr;  // submit threads (G >= 2); nullptr or submit_threads == false: the caller's thread does every member
+    bool submit_threads = true;  // qk_group_set_submit_threads
     uint64_t parent_uid = 0, parent_version = 0;  // what the replicas were made from
     bool parent_valid = false;
     char *recv = nullptr;  // on the lead: G packed blocks (+ the staging of a host answer)
@@ -209,6 +290,13 @@ int check_metric(int metric) {
     return QK_OK;
 }
 
+// the per-member pieces of a call: on the submit threads when the group has them, else one after the other on the caller's thread
+int for_members(qk_group *g, const std::function<int(int)> &f) {
+    if (g->pool && g->submit_threads && g->G > 1) return g->pool->run(g->G, f);
+    for (int j = 0; j < g->G; j++) QK_TRY(f(j));
+    return QK_OK;
+}
+
 // parent != nullptr: QueryCoordinator::search at fixed nprobe; else scan_partitions over pids [Q][P] (P == 0: padding only)
 int group_search(qk_group *g, qk_store *parent, const float *x, int64_t Q, const int64_t *pids_in, int P_in, int nprobe, int k,
                  int metric, int64_t *out_ids, float *out_dist, int mem, qk_timing *timing) {
@@ -247,51 +335,51 @@ int group_search(qk_group *g, qk_store *parent, const float *x, int64_t Q, const
         else QK_HIP(hipMemcpyAsync(pb(lead), pids_in, (size_t)Q * P * 8, hipMemcpyDefault, ls));
     }
     QK_HIP(hipEventRecord(g->ev_x, ls));
-    for (int j = 1; j < G; j++) {
+    // ---- per member (submit threads when the group has them): pull the batch; coarse step split by queries -- member j ranks the
+    //      centroids for its slice and writes the slice into every other member's copy ------------------------------------------
+    const int64_t per_q = (Q + G - 1) / G;
+    auto pull_and_rank = [&](int j) -> int {
         Member &mb = g->m[j];
         QK_HIP(hipSetDevice(mb.ctx->device));
         hipStream_t st = mb.ctx->stream;
-        QK_HIP(hipStreamWaitEvent(st, g->ev_x, 0));
-        QK_HIP(hipMemcpyAsync(xb(mb), xb(lead), (size_t)Q * d * 4, hipMemcpyDefault, st));
-        if (!use_parent) QK_HIP(hipMemcpyAsync(pb(mb), pb(lead), (size_t)Q * P * 8, hipMemcpyDefault, st));
-    }
-    // ---- coarse step split by queries: member j ranks the centroids for its slice and writes the slice everywhere ----------
-    if (split) {
-        const int64_t per = (Q + G - 1) / G;
-        for (int j = 0; j < G; j++) {
-            Member &mb = g->m[j];
-            const int64_t q0 = (int64_t)j * per, qn = std::min(per, Q - q0);
-            QK_HIP(hipSetDevice(mb.ctx->device));
-            if (qn > 0) {
-                QK_TRY(qk_run_search(mb.ctx, mb.parent, mb.parent, xb(mb) + q0 * d, qn, nullptr, 0, nprobe, 0, metric,
-                                     pb(mb) + q0 * kk, nullptr, QK_MEM_DEVICE, nullptr, true, true));
-                BcastArgs ba;
-                ba.n = 0;
-                for (int t = 0; t < G; t++)
-                    if (t != j) ba.dst[ba.n++] = (unsigned long long *)(pb(g->m[t]) + q0 * kk);
-                const int64_t n8 = qn * kk;
-                hipLaunchKernelGGL(k_bcast, dim3(grid_for(n8)), dim3(256), 0, mb.ctx->stream,
-                                   (const unsigned long long *)(pb(mb) + q0 * kk), ba, n8);
-                QK_HIP(hipGetLastError());
-            }
-            if (j > 0) QK_HIP(hipEventRecord(mb.ev_coarse, mb.ctx->stream));
+        if (j > 0) {
+            QK_HIP(hipStreamWaitEvent(st, g->ev_x, 0));
+            QK_HIP(hipMemcpyAsync(xb(mb), xb(lead), (size_t)Q * d * 4, hipMemcpyDefault, st));
+            if (!use_parent) QK_HIP(hipMemcpyAsync(pb(mb), pb(lead), (size_t)Q * P * 8, hipMemcpyDefault, st));
         }
+        if (!split) return QK_OK;
+        const int64_t q0 = (int64_t)j * per_q, qn = std::min(per_q, Q - q0);
+        if (qn > 0) {
+            QK_TRY(qk_run_search(mb.ctx, mb.parent, mb.parent, xb(mb) + q0 * d, qn, nullptr, 0, nprobe, 0, metric,
+                                 pb(mb) + q0 * kk, nullptr, QK_MEM_DEVICE, nullptr, true, true));
+            BcastArgs ba;
+            ba.n = 0;
+            for (int t = 0; t < G; t++)
+                if (t != j) ba.dst[ba.n++] = (unsigned long long *)(pb(g->m[t]) + q0 * kk);
+            const int64_t n8 = qn * kk;
+            hipLaunchKernelGGL(k_bcast, dim3(grid_for(n8)), dim3(256), 0, st, (const unsigned long long *)(pb(mb) + q0 * kk), ba, n8);
+            QK_HIP(hipGetLastError());
+        }
+        if (j > 0) QK_HIP(hipEventRecord(mb.ev_coarse, st));
+        return QK_OK;
+    };
+    QK_TRY(for_members(g, pull_and_rank));
+    if (split) {
+        // two-hop event sync: members -> lead -> members (2 (G - 1) waits instead of G^2); the members' half is the first thing
+        // their scan piece does (an event must have been recorded on the host before a wait on it is enqueued)
         QK_HIP(hipSetDevice(lead.ctx->device));
         for (int j = 1; j < G; j++) QK_HIP(hipStreamWaitEvent(ls, g->m[j].ev_coarse, 0));
         if (tm) QK_HIP(hipEventRecord(g->tev[1], ls));
         QK_HIP(hipEventRecord(g->ev_all, ls));
-        for (int j = 1; j < G; j++) {
-            QK_HIP(hipSetDevice(g->m[j].ctx->device));
-            QK_HIP(hipStreamWaitEvent(g->m[j].ctx->stream, g->ev_all, 0));
-        }
     } else if (tm) {
         QK_HIP(hipEventRecord(g->tev[1], ls));
     }
     // ---- every member: the whole batch over the lists it holds; its block goes straight into the lead's receive buffer ------
     std::vector<qk_timing> mt(tm ? (size_t)G : 0);
-    for (int j = 0; j < G; j++) {
+    auto scan_and_pack = [&](int j) -> int {
         Member &mb = g->m[j];
         QK_HIP(hipSetDevice(mb.ctx->device));
+        if (split && j > 0) QK_HIP(hipStreamWaitEvent(mb.ctx->stream, g->ev_all, 0));
         qk_timing *tj = tm ? &mt[(size_t)j] : nullptr;
         if (split || !use_parent)
             QK_TRY(qk_run_search(mb.ctx, nullptr, mb.store, xb(mb), Q, pb(mb), split ? kk : P, 0, k, metric, ib(mb), kb(mb),
@@ -301,7 +389,9 @@ int group_search(qk_group *g, qk_store *parent, const float *x, int64_t Q, const
                                  QK_MEM_DEVICE, tj, false, true));
         QK_TRY(qk_pack_topk_device(mb.ctx, ib(mb), kb(mb), 1, Q, k, g->recv + (size_t)j * blk));
         if (j > 0) QK_HIP(hipEventRecord(mb.ev_done, mb.ctx->stream));
-    }
+        return QK_OK;
+    };
+    QK_TRY(for_members(g, scan_and_pack));
     // ---- lead: merge of the G blocks (the cross-worker batch_add, query_coordinator.cpp:167-173,231-235) --------------------
     QK_HIP(hipSetDevice(lead.ctx->device));
     for (int j = 1; j < G; j++) QK_HIP(hipStreamWaitEvent(ls, g->m[j].ev_done, 0));
@@ -411,12 +501,27 @@ int qk_group_create(const int *devices, int G, int d, qk_group **out) {
         qk_group_destroy(g);
         return rc;
     }
+    if (G > 1) {
+        g->pool = new MemberPool();
+        g->pool->start(G);
+    }
     *out = g;
+    return QK_OK;
+}
+
+int qk_group_set_submit_threads(qk_group *g, int enabled) {
+    if (!g) QK_FAIL(QK_ERR_INVALID, "qk_group_set_submit_threads: group is null");
+    g->submit_threads = enabled != 0;
     return QK_OK;
 }
 
 int qk_group_destroy(qk_group *g) {
     if (!g) return QK_OK;
+    if (g->pool) {
+        g->pool->shutdown();
+        delete g->pool;
+        g->pool = nullptr;
+    }
     for (auto &mb : g->m)
         if (mb.ctx) {
             hipSetDevice(mb.ctx->device);
@@ -566,6 +671,18 @@ int qk_group_get_list(qk_group *g, int64_t list_no, float *vecs_out, int64_t *id
     if (mem == QK_MEM_DEVICE) {  // the caller's stream is not the owner's: complete on return
         QK_HIP(hipSetDevice(o->ctx->device));
         QK_HIP(hipStreamSynchronize(o->ctx->stream));
+    }
+    return QK_OK;
+}
+
+int qk_group_get_lists(qk_group *g, const int64_t *list_nos, int64_t n, float *vecs_out, int64_t *ids_out, int mem) {
+    if (!g || (n > 0 && !list_nos)) QK_FAIL(QK_ERR_INVALID, "qk_group_get_lists: null argument");
+    int64_t at = 0;
+    for (int64_t i = 0; i < n; i++) {
+        int64_t sz = 0;
+        QK_TRY(qk_group_list_size(g, list_nos[i], &sz));
+        QK_TRY(qk_group_get_list(g, list_nos[i], vecs_out ? vecs_out + at * g->d : nullptr, ids_out ? ids_out + at : nullptr, mem));
+        at += sz;
     }
     return QK_OK;
 }

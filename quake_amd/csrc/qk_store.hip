@@ -872,6 +872,18 @@ int qk_store_get_list(qk_store *s, int64_t list_no, float *vecs_out, int64_t *id
     return QK_OK;
 }
 
+int qk_store_get_lists(qk_store *s, const int64_t *list_nos, int64_t n, float *vecs_out, int64_t *ids_out, int mem) {
+    if (!s || (n > 0 && !list_nos)) QK_FAIL(QK_ERR_INVALID, "qk_store_get_lists: null argument");
+    int64_t at = 0;
+    for (int64_t i = 0; i < n; i++) {
+        QK_TRY(check_list(s, list_nos[i], "get_codes"));
+        const int64_t sz = s->parts[list_nos[i]].size;
+        QK_TRY(qk_store_get_list(s, list_nos[i], vecs_out ? vecs_out + at * s->d : nullptr, ids_out ? ids_out + at : nullptr, mem));
+        at += sz;
+    }
+    return QK_OK;
+}
+
 int qk_store_get_vector(qk_store *s, int64_t id, float *vec_out_host, int *found) {
     if (!s || !vec_out_host || !found) QK_FAIL(QK_ERR_INVALID, "qk_store_get_vector: null argument");
     qk_ctx *c = s->ctx;
@@ -896,6 +908,9 @@ int qk_store_get_vector(qk_store *s, int64_t id, float *vec_out_host, int *found
 
 // Batched PartitionManager::add (partition_manager.cpp:236-258): n vectors, each appended to list assign[i]; per-list
 // append order = input order.  One grouping pass on the host, one capacity check per touched list, ONE ingest launch.
+static int add_batch_core(qk_store *s, int64_t n, const int64_t *ids, const float *vecs, int mem, const std::vector<int64_t> &h_assign,
+                          const std::vector<int64_t> &h_ids);
+
 int qk_store_add_batch(qk_store *s, int64_t n, const int64_t *ids, const float *vecs, const int64_t *assign, int mem) {
     if (!s) QK_FAIL(QK_ERR_INVALID, "qk_store_add_batch: null store");
     if (n == 0) return QK_OK;
@@ -911,6 +926,27 @@ int qk_store_add_batch(qk_store *s, int64_t n, const int64_t *ids, const float *
         QK_HIP(hipMemcpyAsync(h_ids.data(), ids, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
         QK_HIP(hipStreamSynchronize(c->stream));
     }
+    return add_batch_core(s, n, ids, vecs, mem, h_assign, h_ids);
+}
+
+}  // extern "C"
+
+// rows and ids on the DEVICE, the list of every row known on the HOST (qk_store_refine_lists: its rows come out of the bucketing
+// grouped by list, the counts are on the host): one ingest for all of them instead of an add_entries -- a launch, a copy of the
+// ids and a synchronisation -- per list
+int qk_store_add_batch_host_assign(qk_store *s, int64_t n, const int64_t *ids_dev, const float *vecs_dev, const std::vector<int64_t> &h_assign) {
+    if (n == 0) return QK_OK;
+    qk_ctx *c = s->ctx;
+    QK_HIP(hipSetDevice(c->device));
+    std::vector<int64_t> h_ids((size_t)n);
+    QK_HIP(hipMemcpyAsync(h_ids.data(), ids_dev, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+    QK_HIP(hipStreamSynchronize(c->stream));
+    return add_batch_core(s, n, ids_dev, vecs_dev, QK_MEM_DEVICE, h_assign, h_ids);
+}
+
+static int add_batch_core(qk_store *s, int64_t n, const int64_t *ids, const float *vecs, int mem, const std::vector<int64_t> &h_assign,
+                          const std::vector<int64_t> &h_ids) {
+    qk_ctx *c = s->ctx;
     std::vector<int64_t> extra(s->parts.size(), 0);
     for (int64_t i = 0; i < n; i++) {
         QK_TRY(check_list(s, h_assign[i], "add_entries"));
@@ -963,6 +999,8 @@ int qk_store_add_batch(qk_store *s, int64_t n, const int64_t *ids, const float *
     QK_HIP(hipStreamSynchronize(c->stream));
     return QK_OK;
 }
+
+extern "C" {
 
 int qk_store_counters(qk_store *s, int64_t *out, int n) {
     if (!s || !out || n <= 0) QK_FAIL(QK_ERR_INVALID, "qk_store_counters: bad arguments");

@@ -690,42 +690,37 @@ class QuakeIndex:
             out[p] = ([], [])
         if not pids:
             return out
-        npart = None
-        keys = []
-        batch, batch_rows = [], 0
-
-        def flush():
-            nonlocal batch, batch_rows
-            if not batch:
-                return
-            x = torch.cat([v for _, v in batch], 0)
-            seg = torch.cat([torch.full((v.shape[0],), i, dtype=torch.int64, device=x.device) for i, v in batch])
-            own = torch.tensor([pids[i] for i, _ in batch], dtype=torch.int64, device=x.device)
-            own_row = torch.cat([own[j].expand(v.shape[0]) for j, (_, v) in enumerate(batch)])
-            near, _ = self._ctx.coarse(self.parent._store, x, 2, self.metric_, values=False)
-            ok = (near >= 0) & (near != own_row[:, None])
-            k_ = (seg[:, None] * npart + near)[ok]
-            keys.append(k_)
-            batch, batch_rows = [], 0
-
         all_ids = [int(v) for v in self._list_ids()]
         npart = max(all_ids) + 2 if all_ids else 2
-        for i, p in enumerate(pids):
-            v, _ = self._store.get_list_device(p)
-            if v.shape[0] == 0:
-                continue
-            batch.append((i, v))
-            batch_rows += v.shape[0]
-            if batch_rows >= chunk_rows:
-                flush()
-        flush()
+        keys = []
+        # the candidates' rows in ONE device buffer per ~2^23 rows (qk_store_get_lists: no per-list Python, no per-list tensor),
+        # the nearest-two search in chunks of rows, (candidate, target) keys counted by one unique
+        sizes_all = np.asarray(self._partition_sizes(pids), np.int64)
+        group_rows = 1 << 23
+        g0 = 0
+        while g0 < len(pids):
+            g1, rows = g0, 0
+            while g1 < len(pids) and (rows == 0 or rows + sizes_all[g1] <= group_rows):
+                rows += int(sizes_all[g1])
+                g1 += 1
+            if rows > 0:
+                x, sz = self._store.get_lists_device(pids[g0:g1])
+                dev = x.device
+                seg = torch.repeat_interleave(torch.arange(g0, g1, dtype=torch.int64, device=dev), torch.as_tensor(sz, device=dev))
+                own = torch.as_tensor(pids[g0:g1], dtype=torch.int64, device=dev)[seg - g0]
+                for c0 in range(0, rows, chunk_rows):
+                    c1 = min(rows, c0 + chunk_rows)
+                    near, _ = self._ctx.coarse(self.parent._store, x[c0:c1], 2, self.metric_, values=False)
+                    ok = (near >= 0) & (near != own[c0:c1, None])
+                    keys.append((seg[c0:c1, None] * npart + near)[ok])
+            g0 = g1
         if keys:
             uniq, counts = torch.unique(torch.cat(keys), return_counts=True)
             uniq, counts = uniq.cpu().numpy(), counts.cpu().numpy()
             segs, tgt = uniq // npart, uniq % npart
-            for sgi in np.unique(segs):
-                m = segs == sgi
-                out[pids[int(sgi)]] = ([int(t) for t in tgt[m]], [int(c) for c in counts[m]])
+            cut = np.nonzero(np.diff(segs))[0] + 1  # (uniq is sorted: a candidate's targets are one run)
+            for lo, hi in zip(np.concatenate([[0], cut]).tolist(), np.concatenate([cut, [len(segs)]]).tolist()):
+                out[pids[int(segs[lo])]] = (tgt[lo:hi].tolist(), counts[lo:hi].tolist())
         for p in pids:
             known[p] = out[p]
         return out

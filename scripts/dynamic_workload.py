@@ -90,7 +90,11 @@ def main():
     results = {}
     for name, maint in (("warmup", False), ("static_partitions", False), ("with_maintenance", True)):
         mp = quake.MaintenancePolicyParams()
-        mp.window_size = env("DW_WINDOW", 2048)
+        # the window must hold several hits of an average partition, or a partition that merely was not asked for in the last two
+        # batches looks dead to the policy (the reference's default is 1000 queries -- for its 1000-list test indexes): 8 hits per
+        # partition on average, in whole batches (10M / 3920 lists: 4096 queries; 50M / 19920 lists: 20480)
+        qb = env("DW_QBATCH", 1024)
+        mp.window_size = env("DW_WINDOW", max(2 * qb, -(-8 * (n_initial // 2500) // (env("DW_NPROBE", 8) * qb)) * qb))
         mp.split_after_delete_rejection = bool(env("DW_EXT", 1))
         mp.refinement_radius = 8
         mp.refinement_iterations = 2
@@ -152,6 +156,9 @@ def main():
                                                                      if r["operation_type"] == "query"] or [0.0])), 4),
             "pair_rows_p50_second_half": int(np.median([r.get("pair_rows", 0) for r in res[len(res) // 2:] if r["operation_type"] == "query"] or [0])),
             "unique_rows_p50_second_half": int(np.median([r.get("unique_rows", 0) for r in res[len(res) // 2:] if r["operation_type"] == "query"] or [0])),
+            "maintenance_ms_p50": median("maintenance_ms", "query"),
+            "maintenance_ms_mean_second_half": round(float(np.mean([r.get("maintenance_ms", 0.0) for r in res[len(res) // 2:]])), 2),
+            "window_size": mp.window_size,
             "maintenance_ms_max": round(max([r.get("maintenance_ms", 0.0) for r in res] or [0.0]), 2),
             "delete_ms_max": round(max([r["latency_ms"] for r in res if r["operation_type"] == "delete"] or [0.0]), 2),
             "trace": [[r["operation_number"], r["operation_type"][0], r["n_list"], r["max_list_size"], r.get("n_splits", 0), r.get("n_deletes", 0),

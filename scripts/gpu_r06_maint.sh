@@ -3,7 +3,7 @@
 # usage: scripts/gpu_r06_maint.sh <n> <tag> [VAR=value ...]   -> gpurun_out/r06/dyn_<tag>.json (+ .err with the cProfile when DW_PROFILE=1)
 n=$1; tag=$2; shift 2
 mkdir -p gpurun_out/r06
-env "$@" timeout 1500 python scripts/dynamic_workload.py $n 128 60 hot > gpurun_out/r06/dyn_$tag.json 2> gpurun_out/r06/dyn_$tag.err
+env "$@" timeout 1500 python scripts/dynamic_workload.py $n 128 ${DW_OPS:-60} hot > gpurun_out/r06/dyn_$tag.json 2> gpurun_out/r06/dyn_$tag.err
 echo "== $tag rc=$?"
 python - <<PY
 import json
@@ -12,7 +12,7 @@ try:
     for name, r in j["results"].items():
         print(name, {k: r[k] for k in ("n_list_first_last", "n_splits", "n_deletes", "max_list_size_first_last", "query_batch_ms_p50_second_half",
                                        "query_scan_ms_p50_second_half", "pair_rows_p50_second_half", "unique_rows_p50_second_half",
-                                       "maintenance_ms_mean", "maintenance_ms_max", "delete_ms_max", "query_recall_at_10")})
+                                       "maintenance_ms_mean", "maintenance_ms_p50", "maintenance_ms_mean_second_half", "window_size", "maintenance_ms_max", "delete_ms_max", "query_recall_at_10")})
 except Exception as e:
     print("no result:", e)
 PY

@@ -103,6 +103,38 @@ def test_group_large_k_equals_single_store(capi, G, k):
     ctx.close()
 
 
+def test_group_submit_threads_change_nothing(capi):
+    """one enqueue thread per member (qk_group_set_submit_threads, the default) against the caller's thread doing every member: the
+    same streams and events, so the same bits -- over a few hundred calls of changing shape (the pieces of consecutive calls
+    interleave on the members' streams; an ordering slip between threads would show as a stale or torn answer)."""
+    ivf = make_ivf(40000, 32, 64, seed=12)
+    ctx, parent, single, grp = _build(capi, ivf, 5)
+    rng = np.random.default_rng(3)
+    shapes = [(1, 4, 5), (70, 1, 10), (640, 6, 10), (333, 3, 40), (2000, 2, 7)]
+    want = {}
+    for sh in shapes:
+        q = make_queries(sh[0], 32, seed=300 + sh[0], like=ivf["x"])
+        want[sh] = (q, *ctx.search(parent, single, q, sh[1], sh[2], "l2"))
+    for rep in range(240):
+        if rep % 40 == 0:
+            grp.set_submit_threads(rep % 80 == 0)
+        sh = shapes[int(rng.integers(0, len(shapes)))]
+        q, si, sd = want[sh]
+        if rep % 3 == 0:  # device buffers: nothing synchronises between calls
+            gi, gd = grp.search(parent, torch.from_numpy(q).cuda(), sh[1], sh[2], "l2")
+            if rep % 12 == 0:
+                grp.synchronize()
+                assert (_np(gi) == si).all() and (_bits(gd) == _bits(sd)).all(), (rep, sh)
+        else:
+            gi, gd = grp.search(parent, q, sh[1], sh[2], "l2")
+            assert (gi == si).all() and (_bits(gd) == _bits(sd)).all(), (rep, sh)
+    grp.synchronize()
+    grp.close()
+    single.close()
+    parent.close()
+    ctx.close()
+
+
 def test_group_counters_sum_over_members(capi):
     ivf = make_ivf(40000, 32, 64, seed=5)
     ctx, parent, single, grp = _build(capi, ivf, 4)

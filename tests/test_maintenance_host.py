@@ -154,3 +154,27 @@ def test_vectorised_cost_deltas_have_the_bits_of_the_scalar_calls():
         d1 = np.array([ce.compute_delete_delta(int(z), float(h), tp, sf, avg) for z, h in zip(sizes, hr)])
         s1 = np.array([ce.compute_split_delta(int(z), float(h), tp) for z, h in zip(sizes, hr)])
         assert (dd.view(np.uint64) == d1.view(np.uint64)).all() and (sd.view(np.uint64) == s1.view(np.uint64)).all()
+
+
+def test_batched_rejection_deltas_are_the_scalar_function():
+    """decide() asks compute_delete_delta_w_reassign for every delete candidate at once (_delete_deltas_w_reassign_many): the
+    values must be the scalar function's bit for bit -- the two mirrors and the reference's rule (maintenance_cost_estimator.cpp:
+    456-493) decide on them."""
+    from quake_amd.maintenance import _delete_deltas_w_reassign_many
+    ce, _ = make_estimator(0.9, 10)
+    rng = np.random.default_rng(5)
+    for trial in range(20):
+        C = int(rng.integers(1, 40))
+        sizes = rng.integers(1, 90000, C)
+        hr = (rng.integers(0, 200, C).astype(np.float32) / np.float32(2048)).astype(np.float64)
+        counts = rng.integers(0, 12, C)
+        offsets = np.concatenate([[0], np.cumsum(counts)])
+        t_sizes = rng.integers(0, 70000, int(offsets[-1]))
+        t_hr = (rng.integers(0, 300, int(offsets[-1])).astype(np.float32) / np.float32(2048)).astype(np.float64)
+        total = int(rng.integers(2, 30000))
+        got = _delete_deltas_w_reassign_many(ce, sizes, hr, total, t_sizes, t_hr, offsets)
+        for c in range(C):
+            lo, hi = int(offsets[c]), int(offsets[c + 1])
+            want = ce.compute_delete_delta_w_reassign(int(sizes[c]), float(hr[c]), total, [1] * (hi - lo), t_sizes[lo:hi], t_hr[lo:hi])
+            assert np.float64(got[c]).tobytes() == np.float64(want).tobytes(), (trial, c, got[c], want)
+    assert _delete_deltas_w_reassign_many(ce, [5], [0.1], 1, [], [], [0, 0])[0] == 0.0

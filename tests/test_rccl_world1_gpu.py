@@ -189,7 +189,7 @@ def test_bench_refuses_a_rank_count_mismatch():
     assert r.returncode != 0 and "--gpus 2" in (r.stderr + r.stdout)
 
 
-@pytest.mark.parametrize("nranks", [2, 4])
+@pytest.mark.parametrize("nranks", [2, 4, 8])
 def test_bench_starts_its_own_ranks(nranks):
     """plain `python bench.py --gpus N` (no launcher, WORLD_SIZE unset): bench.py starts the N ranks itself; over gloo they share
     the one GPU of the test box.  One JSON line from rank 0, n_gpus = N, recall as good as the single-GPU path's (N = 4: the
@@ -206,6 +206,14 @@ def test_bench_starts_its_own_ranks(nranks):
     line = json.loads(lines[0])
     assert line["n_gpus"] == nranks and line["config"]["recall_at_k"] >= 0.9 and line["config"]["batch"] == 128 * nranks
     assert f"lists sharded by number over {nranks} ranks" in line["config"]["workload"]
+    # the N > 1 line describes itself: one roofline per rank, the devices the ranks sat on, the bytes of the step's two collectives
+    # (8 ranks = the rank count of BASELINE.json configs[3] / [4]; on this box they share one GPU: distinct_devices == 1)
+    assert [r_["rank"] for r_ in line["per_rank"]] == list(range(nranks))
+    assert all(r_["roofline"]["bound"] == "hbm" and r_["roofline"]["achieved"] > 0 and r_["vectors"] > 0 for r_ in line["per_rank"])
+    assert line["rccl_ranks_seen"] == {"backend": "gloo", "ranks": nranks, "distinct_devices": 1}
+    kk, per, k = min(line["config"]["nprobe"], 128 * nranks), 128, line["config"]["k"]
+    assert line["exchange"]["all_gather_list_numbers"] == {"send_bytes_per_rank": per * kk * 8, "recv_bytes_per_rank": per * nranks * kk * 8}
+    assert line["exchange"]["all_to_all_topk"]["send_bytes_per_rank"] == nranks * ((per * k * 12 + 15) // 16 * 16)
 
 
 def test_bench_refuses_more_ranks_than_gpus_on_rccl():

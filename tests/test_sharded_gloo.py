@@ -93,7 +93,7 @@ def _worker(rank, world, port, metric, ret):
         from helpers import make_ivf, make_queries
         from quake_amd.sharded import ShardedIndex, owner_of_list, shard_offsets
         ivf = make_ivf(6000, 24, 16, seed=3, metric=metric, empty=(2,))
-        q = make_queries(18, 24, seed=4, like=ivf["x"], metric=metric)
+        q = make_queries(18 if world == 2 else 3 * world, 24, seed=4, like=ivf["x"], metric=metric)  # (a multiple of the ranks)
         lo, rows = shard_offsets(ivf["offsets"], rank, world)
         # every list is owned by exactly one rank
         own = [owner_of_list(p, world) for p in range(16)]
@@ -140,16 +140,18 @@ def _worker(rank, world, port, metric, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("metric", ["l2", "ip"])
-def test_sharded_search_equals_unsharded(metric):
+@pytest.mark.parametrize("world,metric", [(2, "l2"), (2, "ip"), (8, "l2")])
+def test_sharded_search_equals_unsharded(world, metric):
+    """world 8 = the rank count of BASELINE.json configs[3] / [4] (16 lists: two per rank; 24 queries: three per rank): the same
+    worker, every collective with 8 participants"""
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     # (each rank leaves a file: a multiprocessing.Manager is a FORK of this process, HIP runtime and all, and its server
     #  died now and then in long sessions)
     ret = tempfile.mkdtemp(prefix="qk_ranks_")
-    mp.spawn(_worker, args=(2, port, metric, ret), nprocs=2, join=True)
-    assert all(os.path.exists(os.path.join(ret, "rank%d.ok" % r)) for r in range(2))
+    mp.spawn(_worker, args=(world, port, metric, ret), nprocs=world, join=True)
+    assert all(os.path.exists(os.path.join(ret, "rank%d.ok" % r)) for r in range(world))
 
 
 class OracleKmeans:

@@ -224,16 +224,17 @@ def _worker(rank, world, port, metric, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("metric", ["l2", "ip"])
-def test_sharded_maintenance_world2(metric):
+@pytest.mark.parametrize("world,metric", [(2, "l2"), (2, "ip"), (8, "l2")])
+def test_sharded_maintenance_world2(world, metric):
+    """(world 8: the rank count of BASELINE.json configs[4] -- split / delete / refine / the whole policy as 8-way collectives)"""
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     # (each rank leaves a file: a multiprocessing.Manager is a FORK of this process, HIP runtime and all, and its server
     #  died now and then in long sessions)
     ret = tempfile.mkdtemp(prefix="qk_ranks_")
-    mp.spawn(_worker, args=(2, port, metric, ret), nprocs=2, join=True)
-    assert all(os.path.exists(os.path.join(ret, "rank%d.ok" % r)) for r in range(2))
+    mp.spawn(_worker, args=(world, port, metric, ret), nprocs=world, join=True)
+    assert all(os.path.exists(os.path.join(ret, "rank%d.ok" % r)) for r in range(world))
 
 
 def test_refine_world1_equals_oracle_refine():
