@@ -491,7 +491,7 @@ def cpu_sgemm_search(qh, hc, hv, hi, ho, nprobe, k, metric, threads):
 
 
 def run_single_workload(ctx, dev, args, name, sigma, fixed_nprobe, steps, warmup, settle, cpu_seconds, traffic_file=None,
-                        manifold=0, sweep_nprobes=()):
+                        manifold=0, sweep_nprobes=(), with_aps=None):
     """Build, sweep nprobe, time, verify against the oracle.  Returns the result dict of one single-GPU workload.
     manifold > 0: the low-intrinsic-dimension corpus (gen_manifold, latent dimension `manifold`) instead of the mixture."""
     n, d, nlist, k, Q, metric = args.nvec, args.dim, args.nlist, args.k, args.batch, args.metric
@@ -645,7 +645,7 @@ def run_single_workload(ctx, dev, args, name, sigma, fixed_nprobe, steps, warmup
     # the recall-target search (adaptive partition scanning, SearchParams.recall_target > 0) on the same index: rounds on the
     # device, the reference's defaults (initial_search_fraction 0.02, recompute_threshold 0.001, precomputed table)
     aps_res = None
-    if sweep_nprobes and k <= 32:
+    if (bool(sweep_nprobes) if with_aps is None else with_aps) and k <= 32:
         rt = 0.9
         for _ in range(8):  # (the form feedback compares its forms per round shape first)
             ai, ad, an, atm = ctx.search_aps(parent, store, batches[0], k, metric, rt, timing=True)
@@ -1389,7 +1389,7 @@ def main():
             if not only or "hard" in only:
                 extra["hard"] = run_single_workload(ctx, dev, args, "hard", 0.0, 0, hard_steps, min(args.warmup, 10),
                                                     min(args.settle, 50), args.cpu_seconds * 0.5, traffic_file="r05_pmc_k_scan_hard.json",
-                                                    manifold=args.hard_latent)
+                                                    manifold=args.hard_latent, with_aps=True)
             if not only or "configs0" in only:
                 extra["configs0"] = run_configs0(ctx, dev, args)
             if (not only or "configs2" in only) and cfg_no == 1:
@@ -1408,6 +1408,11 @@ def main():
                 extra["nprobe_sweep"] = main_res["nprobe_sweep"]
             if main_res.get("recall_target_search"):
                 extra["recall_target_search"] = main_res["recall_target_search"]
+            if extra.get("hard", {}).get("recall_target_search"):
+                # the fair APS benchmark: on the mixture every boundary lies beyond the query radius and the reference's estimate falls
+                # back to uniform probabilities (geometry.h:389-393) -- 48 lists scanned where nprobe 1 already has recall 0.95; on the
+                # low-intrinsic-dimension corpus the probabilities discriminate
+                extra["recall_target_search_hard"] = extra["hard"].pop("recall_target_search")
             result["workloads"] = extra
 
     log(f"total bench wall {time.time() - t_all:.1f}s")

@@ -164,6 +164,11 @@ QK_API int qk_store_get_vector(qk_store *s, int64_t id, float *vec_out_host, int
  * get after a bulk build walks every id), [7] re-allocations of the scratch buffers of the store's CONTEXT (hipFree + hipMalloc
  * behind a synchronisation).  A harness takes the difference around an operation
  * to attribute a slow add / remove / maintenance step. */
+/* Make pending changes visible to searches NOW: a store that was modified uploads its list table (and, a one-list store, rebuilds
+ * the row-major copy of its rows) at the next search -- two or three stream synchronisations and a copy, ~0.2 ms, inside a query.
+ * A caller that has just finished a batch of modifications (add / remove / maintenance) calls this so that the queries after it do
+ * not pay.  No reference counterpart (its lists are host vectors). */
+QK_API int qk_store_publish(qk_store *s);
 QK_API int qk_store_counters(qk_store *s, int64_t *out, int n);
 /* bytes of HBM held by the arena (vectors+norms+ids), for capacity planning */
 QK_API int64_t qk_store_device_bytes(qk_store *s);

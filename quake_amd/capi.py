@@ -441,6 +441,10 @@ class Store:
             check(self.lib.qk_store_get_list(self.h, int(list_no), None, _ptr(ids), QK_MEM_HOST))
         return vecs, ids
 
+    def publish(self):
+        """pending modifications become visible to searches now (list table upload, row-major copy) instead of inside the next query"""
+        check(self.lib.qk_store_publish(self.h))
+
     def get_lists_device(self, list_nos):
         """rows of many lists, one list after the other, as ONE CUDA tensor [sum of sizes, d] (qk_store_get_lists) + the sizes"""
         import torch

@@ -133,6 +133,15 @@ struct QkIdMap {
         const size_t i = probe(key, f);
         return f ? slots[i].val : -1;
     }
+    // the value of a key that is PRESENT is replaced in place (returns false, and does nothing, when it is absent): no slot changes its
+    // state, so calls for different keys may run on different threads at the same time
+    bool overwrite_present(int64_t key, int32_t val) {
+        if (slots.empty()) return false;
+        bool f;
+        const size_t i = probe(key, f);
+        if (f) slots[i].val = val;
+        return f;
+    }
     void put(int64_t key, int32_t val, bool overwrite) {
         if ((used + 1) * 2 > slots.size()) rehash(std::max<size_t>(live + 1, live * 2));
         bool f;

@@ -226,7 +226,9 @@ struct qk_store {
     bool index_valid = false;
 };
 void qk_store_ensure_index(qk_store *s);
-int qk_store_add_batch_host_assign(qk_store *s, int64_t n, const int64_t *ids_dev, const float *vecs_dev, const std::vector<int64_t> &h_assign);
+int qk_store_add_batch_host_assign(qk_store *s, int64_t n, const int64_t *ids_dev, const float *vecs_dev, const std::vector<int64_t> &h_assign,
+                                   bool ids_indexed = false);
+int qk_store_remove_list_ex(qk_store *s, int64_t list_no, bool keep_index);
 
 int qk_store_sync_table(qk_store *s);                  // upload (row_off, size) if dirty
 // qk_store_build_csr in three steps, with an ownership filter (qk_group.hip: member `rem` of `mod` members takes the lists

@@ -1018,12 +1018,12 @@ int qk_store_refine_lists(qk_store *s, const int64_t *list_nos, int64_t m, float
     std::vector<int64_t> h_assign((size_t)total);
     pos = 0;
     for (int64_t c = 0; c < m; c++) {
-        QK_TRY(qk_store_remove_list(s, list_nos[c]));
+        QK_TRY(qk_store_remove_list_ex(s, list_nos[c], true));  // (the same ids come back below: their index entries are overwritten)
         QK_TRY(qk_store_add_list(s, list_nos[c]));
         std::fill(h_assign.begin() + pos, h_assign.begin() + pos + hcounts[c], list_nos[c]);
         pos += hcounts[c];
     }
-    return qk_store_add_batch_host_assign(s, total, ia, xa, h_assign);
+    return qk_store_add_batch_host_assign(s, total, ia, xa, h_assign, true);
 }
 
 int qk_kmeans(qk_ctx *ctx, float *x, int64_t n, int d, int64_t m, int metric, int niter, uint64_t seed, float *centroids,

@@ -489,11 +489,17 @@ int qk_store_add_list(qk_store *s, int64_t list_no) {
     return QK_OK;
 }
 
-int qk_store_remove_list(qk_store *s, int64_t list_no) {
+int qk_store_remove_list(qk_store *s, int64_t list_no) { return qk_store_remove_list_ex(s, list_no, false); }
+
+}  // extern "C"
+
+// keep_index: the id -> list entries of the list's ids stay as they are -- for a caller that re-adds the SAME ids right away
+// (qk_store_refine_lists: its rows only change lists), which then overwrites them in place instead of erasing and inserting
+int qk_store_remove_list_ex(qk_store *s, int64_t list_no, bool keep_index) {
     if (!s) QK_FAIL(QK_ERR_INVALID, "qk_store_remove_list: null store");
     if (list_no < 0 || list_no >= (int64_t)s->parts.size() || !s->parts[list_no].present) return QK_OK;  // "Already doesn't exist"
     qk_part &p = s->parts[list_no];
-    if (s->index_valid)
+    if (s->index_valid && !keep_index)
         for (int64_t id : p.ids) {
             // only the entries that still name THIS list: while refine_lists replaces its lists one after the other, an id of
             // this list's old contents may already live in (and be indexed under) a list replaced before it
@@ -506,6 +512,8 @@ int qk_store_remove_list(qk_store *s, int64_t list_no) {
     s->table_dirty = true;
     return QK_OK;
 }
+
+extern "C" {
 
 int qk_store_add_entries(qk_store *s, int64_t list_no, int64_t n, const int64_t *ids, const float *vecs, int mem) {
     if (!s) QK_FAIL(QK_ERR_INVALID, "qk_store_add_entries: null store");
@@ -872,6 +880,27 @@ int qk_store_get_list(qk_store *s, int64_t list_no, float *vecs_out, int64_t *id
     return QK_OK;
 }
 
+int qk_store_publish(qk_store *s) {
+    if (!s) QK_FAIL(QK_ERR_INVALID, "qk_store_publish: null store");
+    QK_HIP(hipSetDevice(s->ctx->device));
+    QK_TRY(qk_store_sync_table(s));
+    // the row-major copy a one-list store (the parent: its centroids) keeps for the coarse step's exact finish: rebuilt here if the
+    // store had one, so that the next search finds it
+    if (s->rowmajor_rows > 0 && !s->rowmajor_valid) {
+        int64_t only = -1, present = 0;
+        for (size_t p = 0; p < s->parts.size(); p++)
+            if (s->parts[p].present) {
+                present++;
+                only = (int64_t)p;
+            }
+        if (present == 1 && s->parts[(size_t)only].size > 0 && s->parts[(size_t)only].size <= INT32_MAX) {
+            const float *rm = nullptr;
+            QK_TRY(qk_store_rowmajor(s, s->parts[(size_t)only].row_off, (int)s->parts[(size_t)only].size, &rm));
+        }
+    }
+    return QK_OK;
+}
+
 int qk_store_get_lists(qk_store *s, const int64_t *list_nos, int64_t n, float *vecs_out, int64_t *ids_out, int mem) {
     if (!s || (n > 0 && !list_nos)) QK_FAIL(QK_ERR_INVALID, "qk_store_get_lists: null argument");
     int64_t at = 0;
@@ -909,7 +938,7 @@ int qk_store_get_vector(qk_store *s, int64_t id, float *vec_out_host, int *found
 // Batched PartitionManager::add (partition_manager.cpp:236-258): n vectors, each appended to list assign[i]; per-list
 // append order = input order.  One grouping pass on the host, one capacity check per touched list, ONE ingest launch.
 static int add_batch_core(qk_store *s, int64_t n, const int64_t *ids, const float *vecs, int mem, const std::vector<int64_t> &h_assign,
-                          const std::vector<int64_t> &h_ids);
+                          const std::vector<int64_t> &h_ids, bool ids_indexed = false);
 
 int qk_store_add_batch(qk_store *s, int64_t n, const int64_t *ids, const float *vecs, const int64_t *assign, int mem) {
     if (!s) QK_FAIL(QK_ERR_INVALID, "qk_store_add_batch: null store");
@@ -934,18 +963,19 @@ int qk_store_add_batch(qk_store *s, int64_t n, const int64_t *ids, const float *
 // rows and ids on the DEVICE, the list of every row known on the HOST (qk_store_refine_lists: its rows come out of the bucketing
 // grouped by list, the counts are on the host): one ingest for all of them instead of an add_entries -- a launch, a copy of the
 // ids and a synchronisation -- per list
-int qk_store_add_batch_host_assign(qk_store *s, int64_t n, const int64_t *ids_dev, const float *vecs_dev, const std::vector<int64_t> &h_assign) {
+int qk_store_add_batch_host_assign(qk_store *s, int64_t n, const int64_t *ids_dev, const float *vecs_dev, const std::vector<int64_t> &h_assign,
+                                   bool ids_indexed) {
     if (n == 0) return QK_OK;
     qk_ctx *c = s->ctx;
     QK_HIP(hipSetDevice(c->device));
     std::vector<int64_t> h_ids((size_t)n);
     QK_HIP(hipMemcpyAsync(h_ids.data(), ids_dev, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
     QK_HIP(hipStreamSynchronize(c->stream));
-    return add_batch_core(s, n, ids_dev, vecs_dev, QK_MEM_DEVICE, h_assign, h_ids);
+    return add_batch_core(s, n, ids_dev, vecs_dev, QK_MEM_DEVICE, h_assign, h_ids, ids_indexed);
 }
 
 static int add_batch_core(qk_store *s, int64_t n, const int64_t *ids, const float *vecs, int mem, const std::vector<int64_t> &h_assign,
-                          const std::vector<int64_t> &h_ids) {
+                          const std::vector<int64_t> &h_ids, bool ids_indexed) {
     qk_ctx *c = s->ctx;
     std::vector<int64_t> extra(s->parts.size(), 0);
     for (int64_t i = 0; i < n; i++) {
@@ -967,17 +997,34 @@ static int add_batch_core(qk_store *s, int64_t n, const int64_t *ids, const floa
     for (size_t p = 0; p < extra.size(); p++)
         if (extra[p]) QK_TRY(ensure_part_capacity(s, s->parts[p], extra[p]));
     std::vector<int64_t> rows((size_t)n);
-    if (s->index_valid) s->id_to_list.reserve(s->id_to_list.size() + (size_t)n);  // (no rehash inside the loop)
+    // ids_indexed: every id is in the index already (under the list it just left): its entry is overwritten in place, which needs no
+    // slot to change state -- shared out over threads for a large batch (2M rows of a 50M index: 80 ms of cache misses on one thread)
+    const bool index_here = s->index_valid && !ids_indexed;
+    if (index_here) s->id_to_list.reserve(s->id_to_list.size() + (size_t)n);  // (no rehash inside the loop)
     constexpr int64_t AHEAD = 16;
     for (int64_t i = 0; i < n; i++) {
-        if (s->index_valid && i + AHEAD < n) s->id_to_list.prefetch(h_ids[i + AHEAD]);
+        if (index_here && i + AHEAD < n) s->id_to_list.prefetch(h_ids[i + AHEAD]);
         qk_part &p = s->parts[(size_t)h_assign[i]];
         rows[i] = p.row_off + p.size;
         p.ids.push_back(h_ids[i]);
         if (h_ids[i] > s->max_id_seen) s->max_id_seen = h_ids[i];
         if (h_ids[i] < s->min_id_seen) s->min_id_seen = h_ids[i];
         p.size++;
-        if (s->index_valid) s->id_to_list.set(h_ids[i], (int32_t)h_assign[i]);
+        if (index_here) s->id_to_list.set(h_ids[i], (int32_t)h_assign[i]);
+    }
+    if (s->index_valid && ids_indexed) {
+        const unsigned hw = std::thread::hardware_concurrency();
+        const int T = (int)std::min<int64_t>(std::min<unsigned>(16u, hw ? hw : 1u), std::max<int64_t>(1, n >> 16));
+        std::vector<std::vector<int64_t>> missing((size_t)T);
+        qk_run_shares(T, [&](int t) {
+            const int64_t a = n * t / T, b = n * (t + 1) / T;
+            for (int64_t i = a; i < b; i++) {
+                if (i + AHEAD < b) s->id_to_list.prefetch(h_ids[i + AHEAD]);
+                if (!s->id_to_list.overwrite_present(h_ids[i], (int32_t)h_assign[i])) missing[(size_t)t].push_back(i);
+            }
+        });
+        for (auto &mv : missing)  // (an id the index did not hold: inserted the plain way)
+            for (int64_t i : mv) s->id_to_list.set(h_ids[i], (int32_t)h_assign[i]);
     }
     s->ntotal += n;
     s->table_dirty = true;

@@ -565,6 +565,7 @@ class QuakeIndex:
         self._store.add_batch(idd, xd, assign.contiguous())  # per-list append order = input order (:245-258)
         self._mutations += 1
         self._resident.update(idn)  # only once the device step succeeded: a failed add leaves no phantom ids behind
+        self._publish()
         info.modify_time_us = _us(t0)
         return info
 
@@ -585,6 +586,7 @@ class QuakeIndex:
         t0 = time.perf_counter()
         self._store.remove_ids(idn)
         self._mutations += 1
+        self._publish()
         info.modify_time_us = _us(t0)
         return info
 
@@ -656,7 +658,16 @@ class QuakeIndex:
         if self.parent is None:
             return MaintenanceTimingInfo()
         self._flush_hits()
-        return self._policy().perform_maintenance()
+        info = self._policy().perform_maintenance()
+        self._publish()
+        return info
+
+    def _publish(self):
+        """what a modification left for the next search to do (list table upload, the parent's row-major copy) is done now: the
+        queries after an add / remove / maintenance do not pay for it"""
+        for st in (self._store, self.parent._store if self.parent is not None else None):
+            if st is not None and hasattr(st, "publish"):
+                st.publish()
 
     def _partition_sizes(self, pids):
         return self._store.list_sizes(np.asarray([int(p) for p in pids], np.int64)).tolist()  # one call (qk_store_list_sizes)
