@@ -157,6 +157,9 @@ QK_API int qk_store_get_list(qk_store *s, int64_t list_no, float *vecs_out, int6
 QK_API int qk_store_get_lists(qk_store *s, const int64_t *list_nos, int64_t n, float *vecs_out, int64_t *ids_out, int mem);
 /* get_vector_for_id :280-293 (first match in ascending list order); *found = 0 if absent. */
 QK_API int qk_store_get_vector(qk_store *s, int64_t id, float *vec_out_host, int *found);
+/* PartitionManager::get(ids) (partition_manager.cpp:264-283): n vectors by id in ONE call -- found[i] = 0 and row i undefined for an
+ * id the store does not hold.  (The maintenance policy reads hundreds of centroids of the parent per call.) */
+QK_API int qk_store_get_vectors(qk_store *s, const int64_t *ids_host, int64_t n, float *vecs_out_host, int *found);
 /* What the store's mutations have cost so far beyond the rows they were asked to write (no reference counterpart: IndexPartition
  * reallocs one partition at a time, index_partition.cpp:247-255): out[0] arena re-allocations (new arena, copy of everything, free),
  * [1] arena compactions, [2] list relocations (a list outgrew its extent), [3] rows copied by [0]-[2], [4] rebuilds of the row-major

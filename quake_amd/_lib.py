@@ -64,6 +64,7 @@ SIGNATURES = {
     "qk_store_list_sizes": (_int, [_vp, _vp, _i64, _vp]),
     "qk_store_get_lists": (_int, [_vp, _vp, _i64, _vp, _vp, _int]),
     "qk_store_publish": (_int, [_vp]),
+    "qk_store_get_vectors": (_int, [_vp, _vp, _i64, _vp, _vp]),
     "qk_store_ntotal": (_i64, [_vp]),
     "qk_store_nlist": (_i64, [_vp]),
     "qk_store_d": (_int, [_vp]),

@@ -441,6 +441,15 @@ class Store:
             check(self.lib.qk_store_get_list(self.h, int(list_no), None, _ptr(ids), QK_MEM_HOST))
         return vecs, ids
 
+    def get_vectors(self, ids):
+        """vectors of many ids in one call -> (float32 [n, d], bool [n] found)"""
+        ids = np.ascontiguousarray(ids, dtype=np.int64).reshape(-1)
+        out = np.empty((ids.shape[0], self.d), np.float32)
+        found = np.zeros(ids.shape[0], np.int32)
+        if ids.shape[0]:
+            check(self.lib.qk_store_get_vectors(self.h, _ptr(ids), ids.shape[0], _ptr(out), _ptr(found)))
+        return out, found.astype(bool)
+
     def publish(self):
         """pending modifications become visible to searches now (list table upload, row-major copy) instead of inside the next query"""
         check(self.lib.qk_store_publish(self.h))

@@ -49,6 +49,9 @@ struct DeviceLists {
     int refine_lists(const int64_t *lists, int64_t m, float *c, int metric, int iters, int mem) const {
         return group ? qk_group_refine_lists(group, lists, m, c, metric, iters, mem) : qk_store_refine_lists(store, lists, m, c, metric, iters, mem);
     }
+    // pending modifications become visible to searches now (list table upload) instead of inside the next query (qk_store_publish);
+    // a group's members upload theirs at their next scan
+    int publish() const { return (!group && store) ? qk_store_publish(store) : 0; }
     int64_t ntotal() const { return group ? qk_group_ntotal(group) : qk_store_ntotal(store); }
     int64_t nlist() const { return group ? qk_group_nlist(group) : qk_store_nlist(store); }
 };

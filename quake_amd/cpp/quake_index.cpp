@@ -136,12 +136,24 @@ Tensor QuakeIndex::get_ids() {
 
 shared_ptr<ModifyTimingInfo> QuakeIndex::add(Tensor x, Tensor ids) {
     require_built("[QuakeIndex::add()] No partition manager. Build the index first.");
-    return partition_manager_->add(x, ids);
+    auto info = partition_manager_->add(x, ids);
+    publish();
+    return info;
+}
+
+// what a modification left for the next search to do (list table upload, the parent's row-major copy) is done now: the queries
+// after an add / remove / maintenance do not pay for it (qk_store_publish, include/quake_hip.h)
+void QuakeIndex::publish() {
+    if (!partition_manager_) return;
+    qk_check(partition_manager_->lists().publish());
+    if (parent_ && parent_->partition_manager_) qk_check(parent_->partition_manager_->lists().publish());
 }
 
 shared_ptr<ModifyTimingInfo> QuakeIndex::remove(Tensor ids) {
     require_built("[QuakeIndex::remove()] No partition manager. Build the index first.");
-    return partition_manager_->remove(ids);
+    auto info = partition_manager_->remove(ids);
+    publish();
+    return info;
 }
 
 shared_ptr<ModifyTimingInfo> QuakeIndex::modify(Tensor ids, Tensor x) {  // :147-150
@@ -173,7 +185,9 @@ void QuakeIndex::set_track_hits(bool on) {
 
 shared_ptr<MaintenanceTimingInfo> QuakeIndex::maintenance() {  // :157-163
     if (!maintenance_policy_) throw std::runtime_error("[QuakeIndex::maintenance()] No maintenance policy set.");
-    return maintenance_policy_->perform_maintenance();
+    auto info = maintenance_policy_->perform_maintenance();
+    publish();
+    return info;
 }
 
 void QuakeIndex::refine_partitions(Tensor partition_ids, int iterations) {

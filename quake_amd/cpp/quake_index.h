@@ -45,6 +45,7 @@ public:
     // scan-latency grid of the maintenance cost model from a CSV in the reference's profile format
     // (maintenance_cost_estimator.cpp:259-365): loaded if the file exists, else profiled on the device and saved there
     void set_latency_profile(const std::string &path);
+    void publish();  // pending modifications visible to searches now, not inside the next query (qk_store_publish)
     bool validate();
     void save(const std::string &path);
     void load(const std::string &path, int n_workers = 0);

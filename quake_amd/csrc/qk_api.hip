@@ -216,6 +216,19 @@ int qk_coarse(qk_ctx *ctx, qk_store *parent, const float *x, int64_t Q, int npro
     if (!ctx || !parent || (Q > 0 && (!x || !out_pids))) QK_FAIL(QK_ERR_INVALID, "qk_coarse: null argument");
     if (nprobe <= 0) QK_FAIL(QK_ERR_INVALID, "qk_coarse: nprobe must be positive");
     QK_TRY(check_metric(metric));
+    // nprobe >= 2 over a huge batch (the maintenance policy ranks 10^5 ... 10^6 rows of its delete candidates against the parent): the
+    // prefiltered selection (qk_dense_pf.hip) takes batches of up to 65536 queries, beyond it the call fell to the key-matrix path --
+    // 262144 rows x 19920 centroids: 26.5 ms against 4 x 1.2 ms in pieces of 65536
+    const int64_t piece = 65536;
+    if (Q > piece && nprobe >= 2) {
+        const int64_t kk = std::min<int64_t>(nprobe, parent->ntotal);
+        for (int64_t q0 = 0; q0 < Q; q0 += piece) {
+            const int64_t qn = std::min(piece, Q - q0);
+            QK_TRY(qk_run_search(ctx, parent, parent, x + q0 * parent->d, qn, nullptr, 0, nprobe, 0, metric, out_pids + q0 * kk,
+                                 out_dist ? out_dist + q0 * kk : nullptr, mem, nullptr, true, false));
+        }
+        return QK_OK;
+    }
     return qk_run_search(ctx, parent, parent, x, Q, nullptr, 0, nprobe, 0, metric, out_pids, out_dist, mem, nullptr, true, false);
 }
 

@@ -880,6 +880,63 @@ int qk_store_get_list(qk_store *s, int64_t list_no, float *vecs_out, int64_t *id
     return QK_OK;
 }
 
+int qk_store_get_vectors(qk_store *s, const int64_t *ids_host, int64_t n, float *vecs_out_host, int *found) {
+    if (!s || (n > 0 && (!ids_host || !vecs_out_host || !found))) QK_FAIL(QK_ERR_INVALID, "qk_store_get_vectors: null argument");
+    if (n <= 0) return QK_OK;
+    qk_ctx *c = s->ctx;
+    QK_HIP(hipSetDevice(c->device));
+    qk_store_ensure_index(s);
+    // arena row of every id: the list from the id index, the place inside the list from a position table built ONCE per list the
+    // request touches more than a few times (get_vector scans the list per id: 20000 centroids of a parent asked for one by one
+    // were 20000 scans of a 20000-id list)
+    std::vector<int64_t> rows((size_t)n, -1);
+    std::vector<int32_t> holder((size_t)n);
+    std::vector<int64_t> asked(s->parts.size(), 0);
+    for (int64_t i = 0; i < n; i++) {
+        holder[(size_t)i] = s->id_to_list.find(ids_host[i]);
+        if (holder[(size_t)i] >= 0) asked[(size_t)holder[(size_t)i]]++;
+    }
+    std::vector<QkIdMap> pos(s->parts.size());
+    int64_t n_found = 0;
+    for (int64_t i = 0; i < n; i++) {
+        found[i] = 0;
+        const int32_t h = holder[(size_t)i];
+        if (h < 0) continue;
+        const qk_part &p = s->parts[(size_t)h];
+        int64_t at = -1;
+        if (asked[(size_t)h] >= 8 && p.size > 64) {
+            QkIdMap &m = pos[(size_t)h];
+            if (m.size() == 0) {
+                m.reserve((size_t)p.size);
+                for (int64_t r = p.size - 1; r >= 0; r--) m.set(p.ids[(size_t)r], (int32_t)r);  // (first occurrence wins: find_id's order)
+            }
+            at = m.find(ids_host[i]);
+        } else {
+            for (int64_t r = 0; r < p.size; r++)
+                if (p.ids[(size_t)r] == ids_host[i]) {
+                    at = r;
+                    break;
+                }
+        }
+        if (at < 0) continue;
+        rows[(size_t)i] = p.row_off + at;
+        found[i] = 1;
+        n_found++;
+    }
+    if (n_found == 0) return QK_OK;
+    const size_t rb = ((size_t)n * 8 + 255) & ~(size_t)255, vb = (size_t)n * s->d * sizeof(float);
+    QK_TRY(qk_stage_reserve(c, rb + vb));
+    int64_t *drows = (int64_t *)c->stage;
+    float *dv = (float *)(c->stage + rb);
+    for (auto &r : rows)
+        if (r < 0) r = 0;  // (absent ids: any valid row; the caller looks at found[])
+    QK_HIP(hipMemcpyAsync(drows, rows.data(), (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+    QK_TRY(qk_launch_extract(c, s->vecs, s->nblk, s->d, 0, drows, n, dv));
+    QK_HIP(hipMemcpyAsync(vecs_out_host, dv, vb, hipMemcpyDeviceToHost, c->stream));
+    QK_HIP(hipStreamSynchronize(c->stream));
+    return QK_OK;
+}
+
 int qk_store_publish(qk_store *s) {
     if (!s) QK_FAIL(QK_ERR_INVALID, "qk_store_publish: null store");
     QK_HIP(hipSetDevice(s->ctx->device));

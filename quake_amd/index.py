@@ -508,6 +508,11 @@ class QuakeIndex:
     # -- get / get_ids (partition_manager.cpp:322-343) --------------------------------------------------------------------
     def get(self, ids):
         self._require_built("[QuakeIndex::get()] No partition manager. Index not built?")
+        if hasattr(self._store, "get_vectors") and ids.shape[0] > 1:  # one call, one gather (qk_store_get_vectors)
+            vecs, found = self._store.get_vectors(ids.reshape(-1).cpu().numpy())
+            if not found.all():
+                raise RuntimeError("ID not found in any partition")
+            return torch.from_numpy(vecs)
         out = torch.empty((ids.shape[0], self._d), dtype=torch.float32)
         for i, v in enumerate(ids.reshape(-1).tolist()):
             vec = self._store.get_vector(int(v))
@@ -773,12 +778,25 @@ class QuakeIndex:
         n = len(clustering["vectors"])
         new_pids = list(range(self._next_pid, self._next_pid + n))
         self._next_pid += n
-        for pid, v, i in zip(new_pids, clustering["vectors"], clustering["vector_ids"]):
+        vs, ii = clustering["vectors"], clustering["vector_ids"]
+        for pid in new_pids:
             self._store.add_list(pid)
-            if v.shape[0]:
-                if torch.is_tensor(v) and v.is_cuda:
-                    i = torch.from_numpy(np.ascontiguousarray(i)).cuda(v.device)  # (device vectors: ids follow them)
-                self._store.add_entries(pid, i, v)
+        if n and all(torch.is_tensor(v) and v.is_cuda for v in vs):
+            # device rows (the halves of split partitions): ONE ingest for all the new partitions -- rows in partition order, so a
+            # partition's append order is its own row order, exactly what one add_entries per partition leaves behind (each of those was
+            # a launch, a copy of the ids and a synchronisation: 0.27 ms x 2 per split)
+            keep = [j for j in range(n) if vs[j].shape[0]]
+            if keep:
+                dev = vs[keep[0]].device
+                x = torch.cat([vs[j] for j in keep], 0)
+                idd = torch.from_numpy(np.concatenate([np.ascontiguousarray(ii[j], dtype=np.int64) for j in keep])).to(dev)
+                assign = torch.repeat_interleave(torch.tensor([new_pids[j] for j in keep], dtype=torch.int64, device=dev),
+                                                 torch.tensor([vs[j].shape[0] for j in keep], dtype=torch.int64, device=dev))
+                self._store.add_batch(idd, x, assign)
+        else:
+            for pid, v, i in zip(new_pids, vs, ii):
+                if v.shape[0]:
+                    self._store.add_entries(pid, i, v)
         self.parent.add(torch.from_numpy(np.ascontiguousarray(clustering["centroids"])),
                         torch.tensor(new_pids, dtype=torch.int64))
         self._mutations += 1

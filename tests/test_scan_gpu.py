@@ -463,3 +463,27 @@ def test_search_tracked_hands_out_the_probed_lists(ctx, mem):
         assert tm["partitions_scanned"] > 0
     s.close()
     parent.close()
+
+
+def test_get_vectors_in_one_call(ctx):
+    """qk_store_get_vectors == qk_store_get_vector id by id (PartitionManager::get, partition_manager.cpp:264-283): a few ids per list
+    (the list is scanned), hundreds from one list (a position table is built for it), ids the store does not hold, an id asked twice."""
+    ivf = make_ivf(5000, 20, 9, seed=41, empty=(2,))
+    parent, s = build_stores(ctx, ivf)
+    rng = np.random.default_rng(42)
+    few = rng.choice(ivf["ids"], 12, replace=False)
+    many = ivf["part_ids"][4][:300]
+    ask = np.concatenate([few, many, [10**9, few[0]], np.arange(9)])  # (0 .. 8: whatever of them the corpus holds)
+    vecs, found = s.get_vectors(ask)
+    for i, vid in enumerate(ask):
+        one = s.get_vector(int(vid))
+        assert bool(found[i]) == (one is not None), (i, vid)
+        if one is not None:
+            np.testing.assert_array_equal(vecs[i], one)
+    assert not found[len(few) + len(many)] and found[:len(few) + len(many)].all()
+    c, f = parent.get_vectors(np.arange(9))  # the parent: one list of 9 centroids
+    assert f.all()
+    np.testing.assert_array_equal(c, ivf["centroids"])
+    assert s.get_vectors(np.zeros(0, np.int64))[0].shape == (0, 20)
+    s.close()
+    parent.close()
