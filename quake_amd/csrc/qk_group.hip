@@ -230,10 +230,29 @@ int reserve_call_buffers(qk_group *g, size_t per_member, size_t lead_recv) {
     return QK_OK;
 }
 
+// Members read buffers on `device` directly (the parent's lists, a caller's device tensors): fine when it is a member's device --
+// qk_group_create enabled peer access among those --, else peer access is enabled on demand, or the call fails cleanly instead of
+// faulting on the device.
+int reachable(qk_group *g, int device, const char *what) {
+    for (auto &mb : g->m)
+        if (mb.ctx->device == device) return QK_OK;
+    for (auto &mb : g->m) {
+        int can = 0;
+        QK_HIP(hipDeviceCanAccessPeer(&can, mb.ctx->device, device));
+        if (!can) QK_FAIL(QK_ERR_UNSUPPORTED, "qk_group: %s lives on device %d, which member device %d cannot access", what, device, mb.ctx->device);
+        QK_HIP(hipSetDevice(mb.ctx->device));
+        const hipError_t e = hipDeviceEnablePeerAccess(device, 0);
+        if (e == hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+        else if (e != hipSuccess) QK_FAIL(QK_ERR_HIP, "qk_group: hipDeviceEnablePeerAccess(%d -> %d): %s", mb.ctx->device, device, hipGetErrorString(e));
+    }
+    return QK_OK;
+}
+
 // the parent's lists (the centroids, ids = list numbers) on every member's device; redone when the parent has changed
 int sync_parent(qk_group *g, qk_store *parent) {
     if (parent->d != g->d) QK_FAIL(QK_ERR_INVALID, "parent store dimension %d != group dimension %d", parent->d, g->d);
     qk_ctx *pc = parent->ctx;
+    QK_TRY(reachable(g, pc->device, "the parent store"));
     QK_HIP(hipSetDevice(pc->device));
     QK_TRY(qk_store_sync_table(parent));  // (bumps parent->version when the parent was touched since)
     if (g->parent_valid && g->parent_uid == parent->uid && g->parent_version == parent->version) return QK_OK;
@@ -667,6 +686,13 @@ int qk_group_get_list(qk_group *g, int64_t list_no, float *vecs_out, int64_t *id
     if (!g) QK_FAIL(QK_ERR_INVALID, "qk_group_get_list: group is null");
     if (list_no < 0) QK_FAIL(QK_ERR_NOT_FOUND, "List does not exist in get_codes (list %lld)", (long long)list_no);
     Member *o = owner(g, list_no);
+    if (mem == QK_MEM_DEVICE && (vecs_out || ids_out)) {  // the owner writes the caller's device buffer: it must be able to reach it
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, vecs_out ? (const void *)vecs_out : (const void *)ids_out) == hipSuccess)
+            QK_TRY(reachable(g, at.device, "the destination buffer"));
+        else
+            (void)hipGetLastError();
+    }
     QK_TRY(qk_store_get_list(o->store, list_no, vecs_out, ids_out, mem));
     if (mem == QK_MEM_DEVICE) {  // the caller's stream is not the owner's: complete on return
         QK_HIP(hipSetDevice(o->ctx->device));

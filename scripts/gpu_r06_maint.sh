@@ -2,8 +2,9 @@
 # round 6: the hot dynamic workload under variants of the scenario and of the policy (scripts/dynamic_workload.py, DW_* knobs)
 # usage: scripts/gpu_r06_maint.sh <n> <tag> [VAR=value ...]   -> gpurun_out/r06/dyn_<tag>.json (+ .err with the cProfile when DW_PROFILE=1)
 n=$1; tag=$2; shift 2
+ops=60; for kv in "$@"; do case $kv in DW_OPS=*) ops=${kv#DW_OPS=};; esac; done
 mkdir -p gpurun_out/r06
-env "$@" timeout 1500 python scripts/dynamic_workload.py $n 128 ${DW_OPS:-60} hot > gpurun_out/r06/dyn_$tag.json 2> gpurun_out/r06/dyn_$tag.err
+env "$@" timeout 1500 python scripts/dynamic_workload.py $n 128 $ops hot > gpurun_out/r06/dyn_$tag.json 2> gpurun_out/r06/dyn_$tag.err
 echo "== $tag rc=$?"
 python - <<PY
 import json
