@@ -60,6 +60,7 @@ int qk_ctx_destroy(qk_ctx *c) {
     if (c->qprep) hipFree(c->qprep);
     if (c->aps) hipFree(c->aps);
     if (c->small_ws) hipFree(c->small_ws);
+    if (c->km_pool) hipFree(c->km_pool);
     if (c->pinned) hipHostFree(c->pinned);
     if (c->overflow_host) hipHostFree(c->overflow_host);
     if (c->aps_flags) hipHostFree(c->aps_flags);

@@ -103,6 +103,9 @@ struct qk_ctx {
     const float *prep_x = nullptr;
     int64_t prep_Q = 0, prep_zero16 = 0;
     int prep_d = 0;
+    char *km_pool = nullptr;         // scratch of the k-means calls (qk_kmeans.hip, KmScratch): grown to the largest call's need
+    size_t km_pool_cap = 0;
+    bool km_pool_busy = false;
     const char *last_scan_kernel = "";  // form of the last scan launch (qk_ctx_last_scan_kernel)
     // Which form of the partition scan serves a batch shape best is measured, not only modelled (qk_scan.hip, "form feedback"):
     // per (store, Q / 64, nprobe, k, metric) the context keeps the mean device time of a whole scan call -- grouping, scan

@@ -608,18 +608,54 @@ __global__ void k_gather_ids_i32(const int64_t *__restrict__ ids, const int32_t 
 // ---- host side ----------------------------------------------------------------------------------------------
 static inline unsigned km_grid(int64_t n, int b) { return (unsigned)((n + b - 1) / b); }
 
-struct KmScratch {  // device buffers owned by one qk_kmeans* call
+// Device buffers owned by one qk_kmeans* call.  They come out of a per-context pool (qk_ctx::km_pool) by bump allocation: a
+// maintenance call splits ~50 partitions (a 2-means each: ten buffers) and refines ~600 (two copies of 1.5M rows) -- with a hipMalloc
+// per buffer and a hipFree per buffer on return (each hipFree drains the device) the allocator was most of a 0.5 ms split and of a
+// 130 ms refine.  A request the pool cannot serve falls back to hipMalloc (pointers handed out never move during a call); what the
+// call asked for in total is remembered, and the pool is regrown to it when the call returns.  One user at a time (km_pool_busy):
+// a nested call allocates the old way.
+struct KmScratch {
+    static constexpr size_t POOL_MAX = (size_t)8 << 30;
+    qk_ctx *ctx;
+    bool own_pool = false;
+    size_t used = 0, wanted = 0;
     std::vector<void *> ptrs;
+    explicit KmScratch(qk_ctx *c) : ctx(c) {
+        if (ctx && !ctx->km_pool_busy) {
+            ctx->km_pool_busy = true;
+            own_pool = true;
+        }
+    }
+    KmScratch(const KmScratch &) = delete;
+    KmScratch &operator=(const KmScratch &) = delete;
     ~KmScratch() {
         for (void *p : ptrs)
             if (p) (void)hipFree(p);
+        if (!own_pool) return;
+        if (wanted > ctx->km_pool_cap && wanted <= POOL_MAX) {
+            if (hipStreamSynchronize(ctx->stream) != hipSuccess) (void)hipGetLastError();
+            if (ctx->km_pool) (void)hipFree(ctx->km_pool);
+            ctx->km_pool = nullptr;
+            ctx->km_pool_cap = 0;
+            const size_t want = wanted + wanted / 4 + 4096;
+            if (hipMalloc((void **)&ctx->km_pool, want) == hipSuccess) ctx->km_pool_cap = want;
+            else (void)hipGetLastError();
+        }
+        ctx->km_pool_busy = false;
     }
     template <typename T>
     int alloc(T **out, size_t count) {
+        const size_t bytes = (std::max<size_t>(count, 1) * sizeof(T) + 255) & ~(size_t)255;
+        wanted += bytes;
+        if (own_pool && used + bytes <= ctx->km_pool_cap) {
+            *out = (T *)(ctx->km_pool + used);
+            used += bytes;
+            return QK_OK;
+        }
         void *p = nullptr;
-        hipError_t e = hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T));
+        hipError_t e = hipMalloc(&p, bytes);
         if (e != hipSuccess) {
-            qk_set_error("k-means scratch allocation of %zu bytes failed: %s", count * sizeof(T), hipGetErrorString(e));
+            qk_set_error("k-means scratch allocation of %zu bytes failed: %s", bytes, hipGetErrorString(e));
             return QK_ERR_OOM;
         }
         ptrs.push_back(p);
@@ -859,7 +895,7 @@ int qk_kmeans_assign(qk_ctx *ctx, const float *x, int64_t n, const float *c, int
     if (metric != QK_METRIC_L2 && metric != QK_METRIC_IP) QK_FAIL(QK_ERR_INVALID, "Metric type not supported");
     if (n == 0) return QK_OK;
     QK_HIP(hipSetDevice(ctx->device));
-    KmScratch ks;
+    KmScratch ks(ctx);
     const int dpad = qk_round_up(d, 16);
     const int64_t mt16 = ((m + 15) / 16) * 16;
     float *ctile, *cnorm;
@@ -896,7 +932,7 @@ static int kmeans_accumulate_api(qk_ctx *ctx, const float *x, int64_t n, int d, 
     if (!ctx || !x || !assign || !sums || !counts) QK_FAIL(QK_ERR_INVALID, "qk_kmeans_accumulate: null argument");
     if (n < 0 || m <= 0 || d <= 0) QK_FAIL(QK_ERR_INVALID, "qk_kmeans_accumulate: bad sizes");
     QK_HIP(hipSetDevice(ctx->device));
-    KmScratch ks;
+    KmScratch ks(ctx);
     AccumScratch as;
     QK_TRY(accum_prepare(ctx->stream, ks, as, std::max<int64_t>(n, 1), m, d));
     const float *dx = x;
@@ -959,7 +995,7 @@ int qk_store_refine_lists(qk_store *s, const int64_t *list_nos, int64_t m, float
         total += s->parts[p].size;
     }
     const int iterations = refinement_iterations > 0 ? refinement_iterations : 1;  // clustering.cpp:110
-    KmScratch ks;
+    KmScratch ks(ctx);
     float *xa, *xb, *dc, *dsums, *ctile, *cnorm;
     int64_t *ia, *ib, *dassign, *dcounts;
     const int dpad = qk_round_up(d, 16);
@@ -1033,7 +1069,7 @@ int qk_kmeans(qk_ctx *ctx, float *x, int64_t n, int d, int64_t m, int metric, in
     if (metric != QK_METRIC_L2 && metric != QK_METRIC_IP) QK_FAIL(QK_ERR_INVALID, "Metric type not supported");
     QK_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
-    KmScratch ks;
+    KmScratch ks(ctx);
     float *dx = x;
     if (mem == QK_MEM_HOST) {
         QK_TRY(ks.alloc(&dx, (size_t)n * d));
@@ -1130,7 +1166,7 @@ int qk_normalize_rows(qk_ctx *ctx, float *x, int64_t n, int d, int mem) {
     if (n == 0) return QK_OK;
     QK_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
-    KmScratch ks;
+    KmScratch ks(ctx);
     float *dx = x;
     if (mem == QK_MEM_HOST) {
         QK_TRY(ks.alloc(&dx, (size_t)n * d));
