@@ -743,6 +743,10 @@ __global__ __launch_bounds__(64 * W) void k_seed_tau_wg(SeedParams S) {
     if (rk == S.k - 1 && key != 0xFFFFFFFFu) atomicMax(&S.gtau[qq], ~key);  // gtau holds ~bound: 0 = no bound yet
 }
 
+#ifndef QK_SEED_M_WIDE
+#define QK_SEED_M_WIDE 2   // 64 < k <= 128: rows of the nearest list sampled for the bound = 64 * this (2 / 4 / 8 instantiated)
+#endif
+
 // ---- the scan kernel ---------------------------------------------------------------------------------
 // Compile-time experiment switches (scripts/scan_ab.sh builds one library per combination)
 #ifndef QK_OPT_EARLY_LOAD
@@ -1559,7 +1563,7 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
         else if (k <= 64)
             hipLaunchKernelGGL((k_seed_tau<1>), sg, dim3(64), 0, st, sd);
         else if (k <= 128)
-            hipLaunchKernelGGL((k_seed_tau<2>), sg, dim3(64), 0, st, sd);
+            hipLaunchKernelGGL((k_seed_tau<QK_SEED_M_WIDE>), sg, dim3(64), 0, st, sd);
         else if (k <= 256)
             hipLaunchKernelGGL((k_seed_tau<4>), sg, dim3(64), 0, st, sd);
         else

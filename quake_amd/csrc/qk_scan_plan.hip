@@ -116,7 +116,10 @@ int qk_scan_plan(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, bool emit, int
     const size_t lds_budget = 160 * 1024 - 64;
     const size_t q_bytes = (size_t)nblk * 1024;
     static const int slack_min = std::max(4, qk_env_int("QK_SCAN_SLACK", 28));
-    int C = qk_round_up(k + std::max(slack_min, std::min(k, 64)), 4);
+#ifndef QK_SLACK_CAP
+#define QK_SLACK_CAP 64
+#endif
+    int C = qk_round_up(k + std::max(slack_min, std::min(k, QK_SLACK_CAP)), 4);
     while ((size_t)16 * C * 12 + q_bytes > lds_budget && C > k + 4) C -= 4;
     if ((size_t)16 * C * 12 + q_bytes > lds_budget || C < k + 4 || C > 512)
         QK_FAIL(QK_ERR_UNSUPPORTED, "qk_scan: k=%d with d=%d does not fit the LDS top-k pools", k, s->d);

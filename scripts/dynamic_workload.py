@@ -154,6 +154,12 @@ def main():
                                                                       if r["operation_type"] == "query"] or [0.0])), 4),
             "query_scan_ms_p50_second_half": round(float(np.median([r["phases"].get("scan_ms", 0.0) for r in res[len(res) // 2:]
                                                                      if r["operation_type"] == "query"] or [0.0])), 4),
+            # the index call alone (QuakeIndex.search, host wall clock: without the harness's tensor indexing and fences) and the sum of
+            # its kernel-event phases (coarse + group + scan + merge)
+            "query_call_ms_p50_second_half": round(float(np.median([r["phases"].get("call_ms", 0.0) for r in res[len(res) // 2:]
+                                                                     if r["operation_type"] == "query"] or [0.0])), 4),
+            "query_device_ms_p50_second_half": round(float(np.median([sum(r["phases"].get(k_, 0.0) for k_ in ("coarse_ms", "group_ms", "scan_ms", "merge_ms"))
+                                                                       for r in res[len(res) // 2:] if r["operation_type"] == "query"] or [0.0])), 4),
             "pair_rows_p50_second_half": int(np.median([r.get("pair_rows", 0) for r in res[len(res) // 2:] if r["operation_type"] == "query"] or [0])),
             "unique_rows_p50_second_half": int(np.median([r.get("unique_rows", 0) for r in res[len(res) // 2:] if r["operation_type"] == "query"] or [0])),
             "maintenance_ms_p50": median("maintenance_ms", "query"),

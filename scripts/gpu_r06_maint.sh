@@ -12,7 +12,7 @@ try:
     j = json.load(open("gpurun_out/r06/dyn_$tag.json"))
     for name, r in j["results"].items():
         print(name, {k: r[k] for k in ("n_list_first_last", "n_splits", "n_deletes", "max_list_size_first_last", "query_batch_ms_p50_second_half",
-                                       "query_scan_ms_p50_second_half", "pair_rows_p50_second_half", "unique_rows_p50_second_half",
+                                       "query_scan_ms_p50_second_half", "query_call_ms_p50_second_half", "query_device_ms_p50_second_half", "pair_rows_p50_second_half", "unique_rows_p50_second_half",
                                        "maintenance_ms_mean", "maintenance_ms_p50", "maintenance_ms_mean_second_half", "window_size", "maintenance_ms_max", "delete_ms_max", "query_recall_at_10")})
 except Exception as e:
     print("no result:", e)
