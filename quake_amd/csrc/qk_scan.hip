@@ -744,7 +744,7 @@ __global__ __launch_bounds__(64 * W) void k_seed_tau_wg(SeedParams S) {
 }
 
 #ifndef QK_SEED_M_WIDE
-#define QK_SEED_M_WIDE 2   // 64 < k <= 128: rows of the nearest list sampled for the bound = 64 * this (2 / 4 / 8 instantiated)
+#define QK_SEED_M_WIDE 0   // 64 < k <= 128: rows of the nearest list sampled for the bound = 64 * this (2 / 4 / 8); 0 = by nprobe (4, 8 from 16 on)
 #endif
 
 // ---- the scan kernel ---------------------------------------------------------------------------------
@@ -1562,9 +1562,13 @@ int qk_scan_device(qk_ctx *ctx, qk_store *s, const qk_scan_args &a, qk_timing *t
             hipLaunchKernelGGL((k_seed_tau_wg<2>), sg, dim3(128), 0, st, sd);
         else if (k <= 64)
             hipLaunchKernelGGL((k_seed_tau<1>), sg, dim3(64), 0, st, sd);
-        else if (k <= 128)
-            hipLaunchKernelGGL((k_seed_tau<QK_SEED_M_WIDE>), sg, dim3(64), 0, st, sd);
-        else if (k <= 256)
+        else if (k <= 128) {
+            // (round 6, profiles/r06_ab_k100.jsonl: 10M x 128, k = 100, ms per step with a 128 / 256 / 512-row sample -- nprobe 2: 0.535 /
+            //  0.531 / 0.582, nprobe 8: 0.938 / 0.934 / 0.982, nprobe 32: 1.936 / 1.849 / 1.782: 256 rows, 512 from nprobe 16 on)
+            if (QK_SEED_M_WIDE == 8 || (QK_SEED_M_WIDE == 0 && G.P >= 16)) hipLaunchKernelGGL((k_seed_tau<8>), sg, dim3(64), 0, st, sd);
+            else if (QK_SEED_M_WIDE == 2) hipLaunchKernelGGL((k_seed_tau<2>), sg, dim3(64), 0, st, sd);
+            else hipLaunchKernelGGL((k_seed_tau<4>), sg, dim3(64), 0, st, sd);
+        } else if (k <= 256)
             hipLaunchKernelGGL((k_seed_tau<4>), sg, dim3(64), 0, st, sd);
         else
             hipLaunchKernelGGL((k_seed_tau<8>), sg, dim3(64), 0, st, sd);
