@@ -355,7 +355,7 @@ def test_world2_random_streams(seed):
     assert all(os.path.exists(os.path.join(ret, "rank%d.ok" % r)) for r in range(2))
 
 
-def _replay_worker(rank, world, port, wdir, ret):
+def _replay_worker(rank, world, port, wdir, ret, maintain=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -380,28 +380,43 @@ def _replay_worker(rank, world, port, wdir, ret):
         offs = np.concatenate([[0], np.cumsum([len(i) for _, i in lists])]).astype(np.int64)
         sh = ShardedQuakeIndex.from_global(dist, world, rank, plain.parent.get(torch.tensor(pids)).numpy(), offs,
                                            np.concatenate([i for _, i in lists]), np.concatenate([v for v, _ in lists]), "l2")
-        ra = replay_workload(wdir, os.path.join(wdir, f"plain_r{rank}"), "plain", nlist=8, search_params=sp, index=plain)
-        rb = replay_workload(wdir, os.path.join(wdir, f"sharded_r{rank}"), "sharded", nlist=8, search_params=sp, index=sh)
+        mp_ = None
+        if maintain:  # maintenance after every operation on both (split / delete / refine as collectives on the sharded one); the cost
+            mp_ = _policy_params(128, 1)  # model is a fixed grid, so both indexes take the same decisions
+            for ix in (plain, sh):
+                ix.initialize_maintenance_policy(mp_, cost_estimator=_cost(16))
+                ix.track_hits = True
+        ra = replay_workload(wdir, os.path.join(wdir, f"plain_r{rank}"), "plain", nlist=8, search_params=sp, index=plain,
+                             maintenance_params=mp_, keep_policy=True)
+        rb = replay_workload(wdir, os.path.join(wdir, f"sharded_r{rank}"), "sharded", nlist=8, search_params=sp, index=sh,
+                             maintenance_params=mp_, keep_policy=True)
         assert len(ra) == len(rb) > 0
         for a, b in zip(ra, rb):  # same resident set, same answers (recall is computed from the ids found)
             assert (a["operation_type"], a["n_total"], a["n_list"]) == (b["operation_type"], b["n_total"], b["n_list"]), (a, b)
             assert a["recall"] == b["recall"], (a, b)
             assert b["n_total"] == b["n_resident"]
+            if maintain:
+                assert (a["n_splits"], a["n_deletes"]) == (b["n_splits"], b["n_deletes"]), (a, b)
+        if maintain:
+            assert sum(r["n_splits"] + r["n_deletes"] for r in rb) > 0, "the policy never acted: the replay would prove nothing"
         open(os.path.join(ret, "rank%d.ok" % rank), "w").close()
     finally:
         dist.destroy_process_group()
 
 
-def test_world2_workload_replay(tmp_path):
-    """the dynamic-workload harness over a sharded index: two ranks replay a runbook (inserts, deletes, query batches) and get
-    the recalls and resident counts of one process replaying it on a plain index"""
+@pytest.mark.parametrize("world,maintain", [(2, False), (8, True)])
+def test_world2_workload_replay(tmp_path, world, maintain):
+    """the dynamic-workload harness over a sharded index: the ranks replay a runbook (inserts, deletes, query batches) and get the
+    recalls and resident counts of one process replaying it on a plain index.  (8, True) = BASELINE.json configs[4] in CI size: 8
+    ranks (over gloo, sharing this box's GPU), maintenance() after every operation -- split / delete / refine and the policy run as
+    8-way collectives and take the decisions of the unsharded index."""
     import torch.multiprocessing as mp
     from quake_amd.workload import WorkloadSpec, generate_workload
     g = torch.Generator().manual_seed(77)
     cent = torch.randn(8, 16, generator=g) * 3
     base = cent[torch.randint(0, 8, (20000,), generator=g)] + torch.randn(20000, 16, generator=g)
     wdir = str(tmp_path / "w")
-    spec = WorkloadSpec(metric="l2", insert_ratio=0.3, delete_ratio=0.2, query_ratio=0.5, update_batch_size=500, query_batch_size=65,
+    spec = WorkloadSpec(metric="l2", insert_ratio=0.3, delete_ratio=0.2, query_ratio=0.5, update_batch_size=500, query_batch_size=64 if maintain else 65,
                         number_of_operations=20, initial_size=8000, cluster_size=2500, seed=5)
     generate_workload(wdir, base, spec)
     with socket.socket() as s:
@@ -410,5 +425,5 @@ def test_world2_workload_replay(tmp_path):
     # (each rank leaves a file: a multiprocessing.Manager is a FORK of this process, HIP runtime and all, and its server
     #  died now and then in long sessions)
     ret = tempfile.mkdtemp(prefix="qk_ranks_")
-    mp.spawn(_replay_worker, args=(2, port, wdir, ret), nprocs=2, join=True)
-    assert all(os.path.exists(os.path.join(ret, "rank%d.ok" % r)) for r in range(2))
+    mp.spawn(_replay_worker, args=(world, port, wdir, ret, maintain), nprocs=world, join=True)
+    assert all(os.path.exists(os.path.join(ret, "rank%d.ok" % r)) for r in range(world))
