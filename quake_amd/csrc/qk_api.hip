@@ -5,6 +5,10 @@
 #include <algorithm>
 #include <cstring>
 
+#ifndef QK_HOST_PINNED_IO
+#define QK_HOST_PINNED_IO 1
+#endif
+
 namespace {
 
 struct Staged {  // device-side views of the caller's buffers for one call
@@ -78,14 +82,48 @@ int qk_run_search(qk_ctx *ctx, qk_store *parent, qk_store *s, const float *x, in
     size_t bx = al256((size_t)Q * d * 4), bp = al256((size_t)Q * std::max(Ps, 1) * 8);
     size_t bi = al256((size_t)Q * std::max(kout, 1) * 8), bd = al256((size_t)Q * std::max(kout, 1) * 4);
     Staged sv;
+    // host buffers through the context's pinned staging (qk_internal.h, pin_io) up to 64 MB per call; larger calls transfer directly
+    char *pin = nullptr;
+    size_t pin_x = 0, pin_p = 0, pin_i = 0, pin_d = 0, pin_pr = 0;
+    if (mem == QK_MEM_HOST && QK_HOST_PINNED_IO) {
+        const size_t need = bx + bp + bi + bd + bp + 256;
+        if (need <= ((size_t)64 << 20)) {
+            if (need > ctx->pin_io_cap) {
+                QK_HIP(hipStreamSynchronize(ctx->stream));
+                if (ctx->pin_io) QK_HIP(hipHostFree(ctx->pin_io));
+                ctx->pin_io = nullptr;
+                ctx->pin_io_cap = 0;
+                if (hipHostMalloc((void **)&ctx->pin_io, need + need / 2, hipHostMallocDefault) == hipSuccess) ctx->pin_io_cap = need + need / 2;
+                else (void)hipGetLastError();
+            }
+            if (need <= ctx->pin_io_cap) {
+                pin = ctx->pin_io;
+                pin_x = 0;
+                pin_p = bx;
+                pin_i = bx + bp;
+                pin_d = bx + bp + bi;
+                pin_pr = bx + bp + bi + bd;
+            }
+        }
+    }
     if (mem == QK_MEM_HOST) {
         QK_TRY(qk_stage_reserve(ctx, bx + bp + bi + bd + 256));
         char *b = ctx->stage;
-        QK_HIP(hipMemcpyAsync(b, x, (size_t)Q * d * 4, hipMemcpyHostToDevice, ctx->stream));
+        const void *hx = x;
+        if (pin) {
+            memcpy(pin + pin_x, x, (size_t)Q * d * 4);
+            hx = pin + pin_x;
+        }
+        QK_HIP(hipMemcpyAsync(b, hx, (size_t)Q * d * 4, hipMemcpyHostToDevice, ctx->stream));
         sv.x = (const float *)b;
         b += bx;
         if (!use_parent && pids && Ps > 0) {
-            QK_HIP(hipMemcpyAsync(b, pids, (size_t)Q * Ps * 8, hipMemcpyHostToDevice, ctx->stream));
+            const void *hp = pids;
+            if (pin) {
+                memcpy(pin + pin_p, pids, (size_t)Q * Ps * 8);
+                hp = pin + pin_p;
+            }
+            QK_HIP(hipMemcpyAsync(b, hp, (size_t)Q * Ps * 8, hipMemcpyHostToDevice, ctx->stream));
         }
         sv.pids = (const int64_t *)b;
         b += bp;
@@ -125,9 +163,11 @@ int qk_run_search(qk_ctx *ctx, qk_store *parent, qk_store *s, const float *x, in
         QK_TRY(pe.mark(3));  // (no event of its own: parks the group)
         if (tm) QK_HIP(hipEventRecord(ctx->ev[7], ctx->stream));
         if (mem == QK_MEM_HOST) {
-            if (out_ids) QK_HIP(hipMemcpyAsync(out_ids, sv.out_ids, (size_t)Q * kout * 8, hipMemcpyDeviceToHost, ctx->stream));
-            if (out_dist) QK_HIP(hipMemcpyAsync(out_dist, sv.out_dist, (size_t)Q * kout * 4, hipMemcpyDeviceToHost, ctx->stream));
+            if (out_ids) QK_HIP(hipMemcpyAsync(pin ? (void *)(pin + pin_i) : (void *)out_ids, sv.out_ids, (size_t)Q * kout * 8, hipMemcpyDeviceToHost, ctx->stream));
+            if (out_dist) QK_HIP(hipMemcpyAsync(pin ? (void *)(pin + pin_d) : (void *)out_dist, sv.out_dist, (size_t)Q * kout * 4, hipMemcpyDeviceToHost, ctx->stream));
             QK_HIP(hipStreamSynchronize(ctx->stream));
+            if (pin && out_ids) memcpy(out_ids, pin + pin_i, (size_t)Q * kout * 8);
+            if (pin && out_dist) memcpy(out_dist, pin + pin_d, (size_t)Q * kout * 4);
         }
         if (timing) {  // one kernel: everything is "scan"; the pair / byte counters are not collected on this path
             timing->partitions_scanned = Q * (int64_t)kk;
@@ -197,11 +237,14 @@ int qk_run_search(qk_ctx *ctx, qk_store *parent, qk_store *s, const float *x, in
     }
     // ---- results back ------------------------------------------------------------------------------------
     if (mem == QK_MEM_HOST) {
-        if (out_ids) QK_HIP(hipMemcpyAsync(out_ids, sv.out_ids, (size_t)Q * kout * 8, hipMemcpyDeviceToHost, ctx->stream));
-        if (out_dist) QK_HIP(hipMemcpyAsync(out_dist, sv.out_dist, (size_t)Q * kout * 4, hipMemcpyDeviceToHost, ctx->stream));
-        if (probed_out && use_parent && !coarse_only && kk > 0)
-            QK_HIP(hipMemcpyAsync(probed_out, sv.pids, (size_t)Q * kk * 8, hipMemcpyDeviceToHost, ctx->stream));
+        const bool pr = probed_out && use_parent && !coarse_only && kk > 0;
+        if (out_ids) QK_HIP(hipMemcpyAsync(pin ? (void *)(pin + pin_i) : (void *)out_ids, sv.out_ids, (size_t)Q * kout * 8, hipMemcpyDeviceToHost, ctx->stream));
+        if (out_dist) QK_HIP(hipMemcpyAsync(pin ? (void *)(pin + pin_d) : (void *)out_dist, sv.out_dist, (size_t)Q * kout * 4, hipMemcpyDeviceToHost, ctx->stream));
+        if (pr) QK_HIP(hipMemcpyAsync(pin ? (void *)(pin + pin_pr) : (void *)probed_out, sv.pids, (size_t)Q * kk * 8, hipMemcpyDeviceToHost, ctx->stream));
         QK_HIP(hipStreamSynchronize(ctx->stream));
+        if (pin && out_ids) memcpy(out_ids, pin + pin_i, (size_t)Q * kout * 8);
+        if (pin && out_dist) memcpy(out_dist, pin + pin_d, (size_t)Q * kout * 4);
+        if (pin && pr) memcpy(probed_out, pin + pin_pr, (size_t)Q * kk * 8);
     }
     if (defer_finish) return QK_OK;
     if (timing) QK_TRY(qk_finish_timing(ctx, coarse_only ? parent : s, timing, use_parent && !coarse_only, coarse_only ? 0 : 4));

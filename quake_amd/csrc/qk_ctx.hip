@@ -62,6 +62,7 @@ int qk_ctx_destroy(qk_ctx *c) {
     if (c->small_ws) hipFree(c->small_ws);
     if (c->km_pool) hipFree(c->km_pool);
     if (c->pinned) hipHostFree(c->pinned);
+    if (c->pin_io) hipHostFree(c->pin_io);
     if (c->overflow_host) hipHostFree(c->overflow_host);
     if (c->aps_flags) hipHostFree(c->aps_flags);
     if (c->aps_table) hipFree(c->aps_table);

@@ -80,6 +80,12 @@ struct qk_ctx {
     // pinned staging for host<->device result/query traffic
     char *pinned = nullptr;
     size_t pinned_cap = 0;
+    // pinned staging of the HOST-buffer entry points (qk_search / qk_scan / qk_coarse with QK_MEM_HOST): the caller's pageable
+    // queries are copied here and go to the device in one asynchronous transfer, the answers come back here in asynchronous
+    // transfers behind the kernels and are copied out after the call's one synchronisation (a transfer from / to pageable memory
+    // blocks the host once per buffer).  Its own buffer: `pinned` above is rewritten inside a call (list table, scalars).
+    char *pin_io = nullptr;
+    size_t pin_io_cap = 0;
     // device staging for ingest of host data
     char *stage = nullptr;
     size_t stage_cap = 0;

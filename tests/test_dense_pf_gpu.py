@@ -171,13 +171,21 @@ def test_row_major_copy_follows_the_store(ctx, d):
 
 
 def test_huge_batches_leave_the_prefiltered_form(ctx):
-    """the prefiltered form keeps ~14 KB of state per query: beyond 65536 queries (k = 1 over many rows: beyond 16384 -- the
-    assignment batches of PartitionManager::add) the sliced key-matrix path / the fused argmin serve the call, same answers"""
+    """the prefiltered form keeps ~14 KB of state per query: qk_coarse hands it a batch beyond 65536 queries in pieces of 65536 (round
+    6: the maintenance policy ranks 10^5 ... 10^6 rows per call; the key-matrix path took 26.5 ms where four pieces take 4.8); k = 1
+    over many rows beyond 16384 queries -- the assignment batches of PartitionManager::add -- goes to the fused argmin; same answers,
+    host and device buffers"""
     rng = np.random.default_rng(21)
     cent = rng.standard_normal((2048, 16)).astype(np.float32)
     parent = _parent(ctx, cent)
     q = (cent[rng.integers(0, 2048, 70000)] + 0.3 * rng.standard_normal((70000, 16))).astype(np.float32)
     _check(ctx, parent, cent, q, 4, "l2")
+    import torch
+    gp, gd = ctx.coarse(parent, torch.from_numpy(q).cuda(), 2, "ip")  # (device buffers: the pieces write at their offsets)
+    torch.cuda.synchronize()
+    op, od = O.coarse(q, cent, None, 2, "ip")
+    np.testing.assert_array_equal(gp.cpu().numpy(), op)
+    np.testing.assert_array_equal(gd.cpu().numpy().view(np.uint32), od.view(np.uint32))
     parent.close()
     cent = rng.standard_normal((33000, 16)).astype(np.float32)
     parent = _parent(ctx, cent)
