@@ -322,11 +322,21 @@ void PartitionManager::add_partitions(shared_ptr<Clustering> c) {  // :489-520
     curr_partition_id_ += n;
     c->partition_ids = new_ids;
     parent_->add(c->centroids, new_ids);
+    // ONE ingest for all the new partitions (rows in partition order: a partition's append order is its own row order, what one
+    // add_entries per partition leaves behind -- each of those was a transfer, a launch and a synchronisation)
+    std::vector<Tensor> vs, is_, as_;
     for (int64_t i = 0; i < n; i++) {
         const int64_t pid = new_ids[i].item<int64_t>();
         qk_check(lists_.add_list(pid));
         Tensor v = host_f32(c->vectors[(size_t)i]), id = host_i64(c->vector_ids[(size_t)i]).reshape({-1});
-        if (id.size(0)) qk_check(lists_.add_entries(pid, id.size(0), id.data_ptr<int64_t>(), v.data_ptr<float>(), QK_MEM_HOST));
+        if (!id.size(0)) continue;
+        vs.push_back(v);
+        is_.push_back(id);
+        as_.push_back(torch::full({id.size(0)}, pid, torch::kInt64));
+    }
+    if (!vs.empty()) {
+        Tensor v = torch::cat(vs, 0).contiguous(), id = torch::cat(is_, 0).contiguous(), a = torch::cat(as_, 0).contiguous();
+        qk_check(lists_.add_batch(id.size(0), id.data_ptr<int64_t>(), v.data_ptr<float>(), a.data_ptr<int64_t>(), QK_MEM_HOST));
         const int64_t *ip = id.data_ptr<int64_t>();
         resident_ids_.insert(ip, ip + id.size(0));
     }

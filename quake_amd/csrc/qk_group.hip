@@ -68,7 +68,7 @@ struct MemberPool {
         for (;;) {
             int spins = 0;
             while (gen.load() == seen && !stop.load()) {
-                if (++spins < 40000) {
+                if (++spins < 8000) {  // (~0.2 ms of pauses)
                     __builtin_ia32_pause();
                     continue;
                 }
