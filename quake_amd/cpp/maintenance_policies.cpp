@@ -423,10 +423,13 @@ shared_ptr<MaintenanceTimingInfo> MaintenancePolicy::perform_maintenance() {  //
     Tensor new_pids;
     if (!to_split.empty()) {
         Tensor sp = torch::tensor(to_split, torch::kInt64);
-        auto split = pm.split_partitions(sp);
-        pm.delete_partitions(sp, false);
-        pm.add_partitions(split);
-        new_pids = split->partition_ids;
+        new_pids = pm.split_partitions_in_place(sp);  // (rows stay on the device: partition_manager.h)
+        if (!new_pids.defined()) {
+            auto split = pm.split_partitions(sp);
+            pm.delete_partitions(sp, false);
+            pm.add_partitions(split);
+            new_pids = split->partition_ids;
+        }
     }
     info->split_time_us = us_since(t0);
     if (new_pids.defined() && new_pids.numel() > 0) {

@@ -314,6 +314,55 @@ shared_ptr<Clustering> PartitionManager::split_partitions(const Tensor &partitio
     return out;
 }
 
+Tensor PartitionManager::split_partitions_in_place(const Tensor &partition_ids) {
+    require_store("split_partitions");
+    if (!parent_) throw std::runtime_error("[PartitionManager] split_partitions: no parent index.");
+    Tensor p = host_i64(partition_ids).reshape({-1}).contiguous();
+    const int64_t np = p.size(0);
+    if (np == 0) return torch::empty({0}, torch::kInt64);
+    std::vector<int64_t> sz((size_t)np);
+    int64_t total = 0;
+    for (int64_t i = 0; i < np; i++) {
+        sz[(size_t)i] = get_partition_size(p[i].item<int64_t>());
+        if (sz[(size_t)i] < 8) return Tensor();  // (the host path keeps such a partition whole: rare, left to it)
+        total += sz[(size_t)i];
+    }
+    const auto fopt = torch::TensorOptions().dtype(torch::kFloat32).device(torch::kCUDA, 0);
+    const auto iopt = torch::TensorOptions().dtype(torch::kInt64).device(torch::kCUDA, 0);
+    // (torch only allocates here: every kernel and copy below runs on the library's stream, synchronised before a buffer changes hands)
+    Tensor x = torch::empty({total, (int64_t)d_}, fopt), idd = torch::empty({total}, iopt), assign = torch::empty({total}, iopt);
+    Tensor cents_dev = torch::empty({2 * np, (int64_t)d_}, fopt);
+    qk_check(lists_.get_lists(p.data_ptr<int64_t>(), np, x.data_ptr<float>(), idd.data_ptr<int64_t>(), QK_MEM_DEVICE));
+    int64_t at = 0;
+    for (int64_t i = 0; i < np; i++) {  // the same call split_partitions makes per partition, on device memory
+        qk_check(qk_kmeans(ctx_, x.data_ptr<float>() + at * d_, sz[(size_t)i], d_, 2, metric_, DEFAULT_NITER, 1234ULL,
+                           cents_dev.data_ptr<float>() + 2 * i * d_, assign.data_ptr<int64_t>() + at, QK_MEM_DEVICE));
+        at += sz[(size_t)i];
+    }
+    qk_check(qk_ctx_synchronize(ctx_));
+    Tensor ah = assign.cpu(), cents = cents_dev.cpu();
+    Tensor new_ids = torch::arange(curr_partition_id_, curr_partition_id_ + 2 * np, torch::kInt64);
+    curr_partition_id_ += 2 * np;
+    // list number of every row: half a[r] of partition i -> new_ids[2 i + a[r]]; rows stay in their order, so every half keeps the
+    // order index_select(nonzero(a == h)) gives it
+    Tensor listno = torch::empty({total}, torch::kInt64);
+    {
+        const int64_t *ap = ah.data_ptr<int64_t>();
+        int64_t *lp = listno.data_ptr<int64_t>();
+        int64_t r = 0;
+        for (int64_t i = 0; i < np; i++)
+            for (int64_t j = 0; j < sz[(size_t)i]; j++, r++) lp[r] = curr_partition_id_ - 2 * np + 2 * i + (ap[r] != 0 ? 1 : 0);
+    }
+    Tensor listno_dev = listno.to(x.device());
+    torch::cuda::synchronize(0);
+    parent_->remove(p);
+    for (int64_t i = 0; i < np; i++) qk_check(lists_.remove_list(p[i].item<int64_t>()));
+    parent_->add(cents, new_ids);
+    for (int64_t j = 0; j < 2 * np; j++) qk_check(lists_.add_list(new_ids[j].item<int64_t>()));
+    qk_check(lists_.add_batch(total, idd.data_ptr<int64_t>(), x.data_ptr<float>(), listno_dev.data_ptr<int64_t>(), QK_MEM_DEVICE));
+    return new_ids;  // (the rows' ids never left the index: resident_ids_ is unchanged)
+}
+
 void PartitionManager::add_partitions(shared_ptr<Clustering> c) {  // :489-520
     require_store("add_partitions");
     if (!parent_) throw std::runtime_error("[PartitionManager] add_partitions: no parent index.");

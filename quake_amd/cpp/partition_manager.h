@@ -43,6 +43,9 @@ struct DeviceLists {
     int get_list(int64_t p, float *v, int64_t *ids, int mem) const {
         return group ? qk_group_get_list(group, p, v, ids, mem) : qk_store_get_list(store, p, v, ids, mem);
     }
+    int get_lists(const int64_t *ps, int64_t n, float *v, int64_t *ids, int mem) const {
+        return group ? qk_group_get_lists(group, ps, n, v, ids, mem) : qk_store_get_lists(store, ps, n, v, ids, mem);
+    }
     int get_vector(int64_t id, float *v, int *found) const {
         return group ? qk_group_get_vector(group, id, v, found) : qk_store_get_vector(store, id, v, found);
     }
@@ -141,6 +144,11 @@ public:
     shared_ptr<ModifyTimingInfo> remove(const Tensor &ids);
     Tensor get(const Tensor &ids);
     shared_ptr<Clustering> split_partitions(const Tensor &partition_ids);
+    // split_partitions + delete_partitions(.., false) + add_partitions in one step WITHOUT the host round trip of the rows (what
+    // perform_maintenance does with its splits): lists extracted on the device, the same 2-means each, one ingest for all the halves.
+    // Returns the new partition ids ([2 * n]), or an undefined tensor when a partition is too small for the device path (the
+    // caller then takes the three calls above).  Same partitions, same row order, same centroid bits as the three calls.
+    Tensor split_partitions_in_place(const Tensor &partition_ids);
     void refine_partitions(Tensor partition_ids = Tensor(), int refinement_iterations = 0);
     void delete_partitions(const Tensor &partition_ids, bool reassign = false);
     void add_partitions(shared_ptr<Clustering> partitions);
