@@ -104,7 +104,26 @@ def main():
         sp = quake.SearchParams()
         sp.k, sp.nprobe = 10, env("DW_NPROBE", 8)
         index = None
-        if maint:  # (the policy with the grid profiled above: one profiling pass for the whole script)
+        compiled = os.environ.get("DW_MIRROR", "python") == "compiled"
+        if compiled:  # the compiled C++ mirror (`import quake`, quake_amd/cpp/) behind the same harness: same runbook, same policy
+            import quake as qc
+            first = torch.load(os.path.join(out, "w", "initial_indices.pt"), weights_only=True).to(torch.int64)
+            bpc, spc, mpc = qc.IndexBuildParams(), qc.SearchParams(), qc.MaintenancePolicyParams()
+            bpc.metric, bpc.nlist = "l2", n_initial // 2500
+            spc.k, spc.nprobe = sp.k, sp.nprobe
+            for f in ("window_size", "refinement_radius", "refinement_iterations", "split_threshold_ns", "delete_threshold_ns",
+                      "split_after_delete_rejection"):
+                setattr(mpc, f, getattr(mp, f))
+            index = qc.QuakeIndex()
+            index.build(x[first], first, bpc)
+            if maint:
+                prof_csv = os.path.join(out, "latency_grid.csv")
+                lat.save_latency_profile(prof_csv)
+                index.initialize_maintenance_policy(mpc)
+                index.set_latency_profile(prof_csv)
+                index.set_track_hits(True)
+            sp, mp = spc, mpc
+        elif maint:  # (the policy with the grid profiled above: one profiling pass for the whole script)
             import quake_amd
             first = torch.load(os.path.join(out, "w", "initial_indices.pt"), weights_only=True).to(torch.int64)
             bp = quake.IndexBuildParams()
@@ -119,7 +138,7 @@ def main():
             prof = cProfile.Profile()
             prof.enable()
         res = replay_workload(os.path.join(out, "w"), os.path.join(out, name), name, nlist=n_initial // 2500, search_params=sp,
-                              maintenance_params=mp if maint else None, index=index, keep_policy=maint)
+                              maintenance_params=mp if maint else None, index=index, keep_policy=maint or compiled)
         if prof is not None:
             import pstats
             prof.disable()
@@ -164,7 +183,7 @@ def main():
             "unique_rows_p50_second_half": int(np.median([r.get("unique_rows", 0) for r in res[len(res) // 2:] if r["operation_type"] == "query"] or [0])),
             "maintenance_ms_p50": median("maintenance_ms", "query"),
             "maintenance_ms_mean_second_half": round(float(np.mean([r.get("maintenance_ms", 0.0) for r in res[len(res) // 2:]])), 2),
-            "window_size": mp.window_size,
+            "window_size": mp.window_size, "mirror": "compiled (import quake)" if compiled else "python (quake_amd.index)",
             "maintenance_ms_max": round(max([r.get("maintenance_ms", 0.0) for r in res] or [0.0]), 2),
             "delete_ms_max": round(max([r["latency_ms"] for r in res if r["operation_type"] == "delete"] or [0.0]), 2),
             "trace": [[r["operation_number"], r["operation_type"][0], r["n_list"], r["max_list_size"], r.get("n_splits", 0), r.get("n_deletes", 0),
