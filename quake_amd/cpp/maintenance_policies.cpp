@@ -300,11 +300,14 @@ void MaintenancePolicy::record_query_hits(std::vector<int64_t> partition_ids) {
 void MaintenancePolicy::record_query_batch(const Tensor &partition_ids) {
     Tensor p = host_i64(partition_ids);
     if (p.dim() == 1) p = p.unsqueeze(0);
+    p = p.contiguous();
+    const int64_t *pp = p.data_ptr<int64_t>();  // (plain reads: an element access through the tensor API is ~0.6 us, 8192 of them per batch)
+    const int64_t P_ = p.size(1);
     std::map<int64_t, int64_t> size_of;
     for (int64_t i = 0; i < p.size(0); i++) {
         std::vector<int64_t> hits, sizes;
-        for (int64_t j = 0; j < p.size(1); j++) {
-            const int64_t pid = p[i][j].item<int64_t>();
+        for (int64_t j = 0; j < P_; j++) {
+            const int64_t pid = pp[i * P_ + j];
             if (pid < 0) continue;
             auto it = size_of.find(pid);
             if (it == size_of.end()) it = size_of.emplace(pid, partition_manager_->get_partition_size(pid)).first;
@@ -332,7 +335,11 @@ shared_ptr<MaintenanceTimingInfo> MaintenancePolicy::perform_maintenance() {  //
     const float scan_fraction = tr.get_current_scan_fraction();
     const float avg_size = (float)(pm.ntotal() / std::max(total_partitions, 1));
     std::map<int64_t, int64_t> sizes;
-    for (int64_t i = 0; i < all_pids.size(0); i++) sizes[all_pids[i].item<int64_t>()] = pm.get_partition_size(all_pids[i].item<int64_t>());
+    {
+        Tensor ap = all_pids.contiguous();
+        const int64_t *ip = ap.data_ptr<int64_t>();
+        for (int64_t i = 0; i < ap.size(0); i++) sizes[ip[i]] = pm.get_partition_size(ip[i]);
+    }
     auto hit_rate_of = [&](int64_t pid) {
         auto it = hits.find(pid);
         return (float)(it == hits.end() ? 0 : it->second) / (float)p.window_size;

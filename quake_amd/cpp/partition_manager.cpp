@@ -247,9 +247,11 @@ std::vector<int64_t> PartitionManager::get_partition_sizes(std::vector<int64_t> 
 
 Tensor PartitionManager::get_partition_sizes(Tensor partition_ids) {
     if (!partition_ids.defined() || partition_ids.numel() == 0) partition_ids = get_partition_ids();
-    Tensor p = host_i64(partition_ids).reshape({-1});
+    Tensor p = host_i64(partition_ids).reshape({-1}).contiguous();
     Tensor out = torch::empty({p.size(0)}, torch::kInt64);
-    for (int64_t i = 0; i < p.size(0); i++) out[i] = get_partition_size(p[i].item<int64_t>());
+    const int64_t *ip = p.data_ptr<int64_t>();
+    int64_t *op = out.data_ptr<int64_t>();
+    for (int64_t i = 0; i < p.size(0); i++) op[i] = get_partition_size(ip[i]);
     return out;
 }
 
@@ -400,7 +402,9 @@ void PartitionManager::delete_partitions(const Tensor &partition_ids, bool reass
     for (int64_t i = 0; i < p.size(0); i++) {
         qk_check(lists_.remove_list(p[i].item<int64_t>()));
         Tensor id = sel->vector_ids[(size_t)i];
-        for (int64_t j = 0; j < id.size(0); j++) resident_ids_.erase(id[j].item<int64_t>());
+        Tensor idc = id.contiguous();
+        const int64_t *ip = idc.data_ptr<int64_t>();
+        for (int64_t j = 0; j < idc.size(0); j++) resident_ids_.erase(ip[j]);
     }
     if (reassign && sel->ntotal() > 0) {
         Tensor v = torch::cat(sel->vectors, 0), id = torch::cat(sel->vector_ids, 0);
