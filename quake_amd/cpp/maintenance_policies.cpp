@@ -318,13 +318,28 @@ void MaintenancePolicy::record_query_batch(const Tensor &partition_ids) {
     }
 }
 
-void MaintenancePolicy::reset() { hit_count_tracker_->reset(); }
+void MaintenancePolicy::record_query_batch_later(const Tensor &partition_ids) {
+    pending_hits_.push_back(partition_ids);
+    if (pending_hits_.size() >= 64) flush_hits();
+}
+
+void MaintenancePolicy::flush_hits() {
+    std::vector<Tensor> pend;
+    pend.swap(pending_hits_);
+    for (const Tensor &t : pend) record_query_batch(host_i64(t));
+}
+
+void MaintenancePolicy::reset() {
+    pending_hits_.clear();
+    hit_count_tracker_->reset();
+}
 
 shared_ptr<MaintenanceTimingInfo> MaintenancePolicy::perform_maintenance() {  // maintenance_policies.cpp:33-177
     auto info = std::make_shared<MaintenanceTimingInfo>();
     auto &pm = *partition_manager_;
     auto &p = *params_;
     auto &tr = *hit_count_tracker_;
+    flush_hits();
     if (tr.get_num_queries_recorded() < p.window_size) return info;  // :36-41 window not full yet
     if (!pm.parent_) return info;                                    // a flat index has nothing to split or delete
     ensure_cost_estimator();

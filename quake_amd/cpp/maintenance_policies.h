@@ -93,6 +93,12 @@ public:
     shared_ptr<MaintenanceTimingInfo> perform_maintenance();
     void record_query_hits(std::vector<int64_t> partition_ids);
     void record_query_batch(const Tensor &partition_ids);  // [Q, P] host tensor, -1 = none: one record_query_hits per row
+    // the same, LATER: a tracked search hands its [Q, P] list numbers over (host or device tensor) and returns -- no device
+    // synchronisation, no window bookkeeping inside the search; flush_hits() records everything pending, in order.  Called before
+    // anything that changes a partition's size or reads the window (add / remove / refine / maintenance), so every hit is credited
+    // with the size its partition had when it was scanned -- as if it had been recorded inside search().
+    void record_query_batch_later(const Tensor &partition_ids);
+    void flush_hits();
     void reset();
     void local_refinement(const Tensor &partition_ids);
     bool track_hits_ = false;  // QueryCoordinator::search records the probed partitions when set
@@ -102,6 +108,7 @@ public:
 
 private:
     shared_ptr<PartitionManager> partition_manager_;
+    std::vector<Tensor> pending_hits_;
     void ensure_cost_estimator();
 };
 

@@ -136,6 +136,7 @@ Tensor QuakeIndex::get_ids() {
 
 shared_ptr<ModifyTimingInfo> QuakeIndex::add(Tensor x, Tensor ids) {
     require_built("[QuakeIndex::add()] No partition manager. Build the index first.");
+    if (maintenance_policy_) maintenance_policy_->flush_hits();  // (hits are credited with the sizes of the moment they were scanned)
     auto info = partition_manager_->add(x, ids);
     publish();
     return info;
@@ -151,6 +152,7 @@ void QuakeIndex::publish() {
 
 shared_ptr<ModifyTimingInfo> QuakeIndex::remove(Tensor ids) {
     require_built("[QuakeIndex::remove()] No partition manager. Build the index first.");
+    if (maintenance_policy_) maintenance_policy_->flush_hits();
     auto info = partition_manager_->remove(ids);
     publish();
     return info;
@@ -164,6 +166,7 @@ shared_ptr<ModifyTimingInfo> QuakeIndex::modify(Tensor ids, Tensor x) {  // :147
 void QuakeIndex::initialize_maintenance_policy(shared_ptr<MaintenancePolicyParams> p) {  // :152-155
     maintenance_policy_params_ = p;
     if (partition_manager_) {
+        if (maintenance_policy_) maintenance_policy_->flush_hits();  // (hits recorded under the old policy reach it before it goes)
         const bool track = maintenance_policy_ && maintenance_policy_->track_hits_;
         maintenance_policy_ = std::make_shared<MaintenancePolicy>(partition_manager_, p);
         maintenance_policy_->track_hits_ = track;
@@ -192,6 +195,7 @@ shared_ptr<MaintenanceTimingInfo> QuakeIndex::maintenance() {  // :157-163
 
 void QuakeIndex::refine_partitions(Tensor partition_ids, int iterations) {
     require_built("[PartitionManager] refine_partitions: index not built");
+    if (maintenance_policy_) maintenance_policy_->flush_hits();
     partition_manager_->refine_partitions(partition_ids, iterations);
 }
 

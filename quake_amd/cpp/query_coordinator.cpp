@@ -144,7 +144,7 @@ shared_ptr<SearchResult> QueryCoordinator::search(Tensor x, shared_ptr<SearchPar
                                        res->ids.data_ptr<int64_t>(), res->distances.data_ptr<float>(), pids.data_ptr<int64_t>(), mem, &tm));
         }
         if (kk < 1) pids = pids.slice(1, 0, 0);
-        maintenance_policy_->record_query_batch(host_i64(pids));
+        maintenance_policy_->record_query_batch_later(pids);  // (recorded before the next modification / maintenance: flush_hits)
         ti->partitions_scanned = (int)tm.partitions_scanned;
         ti->job_enqueue_time_ns = (int64_t)(tm.group_ms * 1e6);
         ti->job_wait_time_ns = (int64_t)(tm.scan_ms * 1e6);
