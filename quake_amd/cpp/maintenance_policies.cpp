@@ -439,7 +439,10 @@ shared_ptr<MaintenanceTimingInfo> MaintenancePolicy::perform_maintenance() {  //
         to_delete.erase(keep);
     }
     auto t0 = clk::now();
-    if (!to_delete.empty()) pm.delete_partitions(torch::tensor(to_delete, torch::kInt64), true);
+    if (!to_delete.empty()) {
+        Tensor td = torch::tensor(to_delete, torch::kInt64);
+        if (!pm.delete_partitions_in_place(td)) pm.delete_partitions(td, true);  // (rows stay on the device: partition_manager.h)
+    }
     info->delete_time_us = us_since(t0);
     t0 = clk::now();
     Tensor new_pids;

@@ -365,6 +365,27 @@ Tensor PartitionManager::split_partitions_in_place(const Tensor &partition_ids) 
     return new_ids;  // (the rows' ids never left the index: resident_ids_ is unchanged)
 }
 
+bool PartitionManager::delete_partitions_in_place(const Tensor &partition_ids) {
+    require_store("delete_partitions");
+    if (!parent_) throw std::runtime_error("[PartitionManager] delete_partitions: no parent index.");
+    Tensor p = host_i64(partition_ids).reshape({-1}).contiguous();
+    const int64_t np = p.size(0);
+    const int64_t *pp = p.data_ptr<int64_t>();
+    int64_t total = 0;
+    for (int64_t i = 0; i < np; i++) total += get_partition_size(pp[i]);
+    if (np == 0 || total == 0 || np >= nlist()) return false;
+    const auto fopt = torch::TensorOptions().dtype(torch::kFloat32).device(torch::kCUDA, 0);
+    const auto iopt = torch::TensorOptions().dtype(torch::kInt64).device(torch::kCUDA, 0);
+    Tensor x = torch::empty({total, (int64_t)d_}, fopt), idd = torch::empty({total}, iopt), assign = torch::empty({total}, iopt);
+    qk_check(lists_.get_lists(pp, np, x.data_ptr<float>(), idd.data_ptr<int64_t>(), QK_MEM_DEVICE));
+    parent_->remove(p);
+    for (int64_t i = 0; i < np; i++) qk_check(lists_.remove_list(pp[i]));
+    // PartitionManager::add(vectors, ids, {}, check_uniques = false) (:533-552): the nearest remaining centroid of every row
+    qk_check(qk_coarse(ctx_, parent_->store(), x.data_ptr<float>(), total, 1, metric_, assign.data_ptr<int64_t>(), nullptr, QK_MEM_DEVICE));
+    qk_check(lists_.add_batch(total, idd.data_ptr<int64_t>(), x.data_ptr<float>(), assign.data_ptr<int64_t>(), QK_MEM_DEVICE));
+    return true;  // (the rows' ids never left the index: resident_ids_ is unchanged)
+}
+
 void PartitionManager::add_partitions(shared_ptr<Clustering> c) {  // :489-520
     require_store("add_partitions");
     if (!parent_) throw std::runtime_error("[PartitionManager] add_partitions: no parent index.");

@@ -149,6 +149,10 @@ public:
     // Returns the new partition ids ([2 * n]), or an undefined tensor when a partition is too small for the device path (the
     // caller then takes the three calls above).  Same partitions, same row order, same centroid bits as the three calls.
     Tensor split_partitions_in_place(const Tensor &partition_ids);
+    // delete_partitions(partition_ids, reassign = true) with the rows staying on the device: extracted there, ranked against the
+    // remaining centroids there, re-ingested from there (the other path carries every row to the host and back).  Same lists, same
+    // row order.  false: nothing done (no rows), the caller takes delete_partitions.
+    bool delete_partitions_in_place(const Tensor &partition_ids);
     void refine_partitions(Tensor partition_ids = Tensor(), int refinement_iterations = 0);
     void delete_partitions(const Tensor &partition_ids, bool reassign = false);
     void add_partitions(shared_ptr<Clustering> partitions);
