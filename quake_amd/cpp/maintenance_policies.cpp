@@ -1,6 +1,9 @@
 // maintenance_policies.cpp -- see maintenance_policies.h.
 #include "maintenance_policies.h"
 
+#include <cstdio>
+#include <cstdlib>
+
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -344,7 +347,14 @@ shared_ptr<MaintenanceTimingInfo> MaintenancePolicy::perform_maintenance() {  //
     if (!pm.parent_) return info;                                    // a flat index has nothing to split or delete
     ensure_cost_estimator();
     auto t_total = clk::now();
+    static const bool trace = getenv("QUAKE_MAINTENANCE_TRACE") != nullptr;  // stage times of a call on stderr (scripts/dynamic_workload.py)
+    auto t_stage = clk::now();
+    auto stage = [&](const char *what) {
+        if (trace) fprintf(stderr, "[maintenance] %-22s %8.2f ms\n", what, (double)us_since(t_stage) / 1e3);
+        t_stage = clk::now();
+    };
     const auto hits = tr.aggregated_hits();
+    stage("aggregated hits");
     Tensor all_pids = pm.get_partition_ids();
     const int total_partitions = (int)pm.nlist();
     const float scan_fraction = tr.get_current_scan_fraction();
@@ -370,7 +380,10 @@ shared_ptr<MaintenanceTimingInfo> MaintenancePolicy::perform_maintenance() {  //
         const double dd = ce.compute_delete_delta((int)kv.second, hit_rate_of(kv.first), total_partitions, scan_fraction, avg_size);
         if (dd < -p.delete_threshold_ns && p.enable_delete_rejection && (int)kv.second > p.min_partition_size) cand.push_back(kv.first);
     }
+    stage("sizes + candidates");
+    if (trace) fprintf(stderr, "[maintenance] %zu partitions, %zu delete candidates\n", sizes.size(), cand.size());
     std::map<int64_t, std::map<int64_t, int64_t>> targets;
+    std::vector<int32_t> flat;  // per-target counter of the candidate at hand, all zero between candidates
     {
         const int64_t chunk_rows = (int64_t)1 << 18;
         const int dev = 0;  // (pm.ctx() is the shared context of device 0; a group hands a list out on its lead, device 0 too)
@@ -395,23 +408,21 @@ shared_ptr<MaintenanceTimingInfo> MaintenancePolicy::perform_maintenance() {  //
                 Tensor nh = near.cpu();
                 const int64_t *np_ = nh.data_ptr<int64_t>();
                 at = 0;
-                // (a candidate's rows name a few dozen distinct targets: counted in a small flat table, most recent hit first -- a
-                //  std::map increment per row was 150 ms of a 50M index's call -- and handed over in ascending target order)
                 std::vector<std::pair<int64_t, int64_t>> tab;
+                // (counted in a flat array indexed by the target's partition number -- a candidate's rows name ~100 distinct targets, and a
+                //  std::map increment, or a search of a small table, per row was 120 ms of a 50M index's call)
                 for (size_t c = c0; c < c1; c++) {
                     const int64_t n = sizes[cand[c]], own = cand[c];
                     tab.clear();
                     for (int64_t i = at * 2; i < (at + n) * 2; i++) {
                         const int64_t t = np_[i];
                         if (t < 0 || t == own) continue;
-                        size_t j = 0;
-                        while (j < tab.size() && tab[j].first != t) j++;
-                        if (j == tab.size()) {
-                            tab.emplace_back(t, 1);
-                        } else {
-                            tab[j].second++;
-                            if (j > 0) std::swap(tab[j], tab[j - 1]);  // (frequent targets drift to the front)
-                        }
+                        if ((size_t)t >= flat.size()) flat.resize((size_t)t + 1024, 0);
+                        if (flat[(size_t)t]++ == 0) tab.emplace_back(t, 0);
+                    }
+                    for (auto &e : tab) {
+                        e.second = flat[(size_t)e.first];
+                        flat[(size_t)e.first] = 0;
                     }
                     auto &counts = targets[own];
                     for (const auto &e : tab) counts[e.first] += e.second;
@@ -421,6 +432,7 @@ shared_ptr<MaintenanceTimingInfo> MaintenancePolicy::perform_maintenance() {  //
             c0 = c1;
         }
     }
+    stage("reassign targets");
     for (const auto &kv : sizes) {
         const int64_t pid = kv.first;
         const int size = (int)kv.second;
@@ -453,6 +465,7 @@ shared_ptr<MaintenanceTimingInfo> MaintenancePolicy::perform_maintenance() {  //
         auto keep = std::max_element(to_delete.begin(), to_delete.end(), [&](int64_t a, int64_t b) { return sizes[a] < sizes[b]; });
         to_delete.erase(keep);
     }
+    stage("walk");
     auto t0 = clk::now();
     if (!to_delete.empty()) {
         Tensor td = torch::tensor(to_delete, torch::kInt64);
