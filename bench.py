@@ -1013,7 +1013,11 @@ def run_sharded(ctx, dev, args, dist, rank, world):
           "roofline": my_roof, "phases_ms": phases_of(ev_ph)}
     seen = [None] * world
     if world > 1:
-        dist.all_gather_object(seen, me)
+        try:
+            dist.all_gather_object(seen, me)
+        except Exception as e:  # (the description of the run must not cost the run its line: the timed region is over)
+            log(f"per-rank description not gathered: {type(e).__name__}: {e}")
+            seen = [me]
     else:
         seen = [me]
     kk = min(nprobe, nlist_g)
@@ -1029,7 +1033,8 @@ def run_sharded(ctx, dev, args, dist, rank, world):
         "timed_groups": groups_of(gtimes, args.steps, Q),
         "per_rank": seen, "exchange": exchange,
         "rccl_ranks_seen": {"backend": str(dist.get_backend()), "ranks": world,
-                            "distinct_devices": len({(r_["pci_bus_id"], r_["uuid"], r_["device_index"]) for r_ in seen})},
+                            "distinct_devices": len({(r_["pci_bus_id"], r_["uuid"], r_["device_index"]) for r_ in seen}),
+                            "ranks_described": len(seen)},
         "config": {
             "workload": f"Synthetic {n * world // 1_000_000}M x {d} f32 {metric.upper()} Gaussian mixture, nlist={nlist_g} "
                         f"(one k-means over all ranks), lists sharded by number over {world} ranks, batch={Q} queries, k={k}, "

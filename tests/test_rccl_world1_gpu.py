@@ -210,7 +210,7 @@ def test_bench_starts_its_own_ranks(nranks):
     # (8 ranks = the rank count of BASELINE.json configs[3] / [4]; on this box they share one GPU: distinct_devices == 1)
     assert [r_["rank"] for r_ in line["per_rank"]] == list(range(nranks))
     assert all(r_["roofline"]["bound"] == "hbm" and r_["roofline"]["achieved"] > 0 and r_["vectors"] > 0 for r_ in line["per_rank"])
-    assert line["rccl_ranks_seen"] == {"backend": "gloo", "ranks": nranks, "distinct_devices": 1}
+    assert line["rccl_ranks_seen"] == {"backend": "gloo", "ranks": nranks, "distinct_devices": 1, "ranks_described": nranks}
     kk, per, k = min(line["config"]["nprobe"], 128 * nranks), 128, line["config"]["k"]
     assert line["exchange"]["all_gather_list_numbers"] == {"send_bytes_per_rank": per * kk * 8, "recv_bytes_per_rank": per * nranks * kk * 8}
     assert line["exchange"]["all_to_all_topk"]["send_bytes_per_rank"] == nranks * ((per * k * 12 + 15) // 16 * 16)
