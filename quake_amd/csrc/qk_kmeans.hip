@@ -731,7 +731,10 @@ static void rs_plan(int64_t n, int64_t m, AccumScratch &as) {
     as.bits = kb <= 8 ? 8 : 12;
     as.passes = (kb + as.bits - 1) / as.bits;
     // a wave's share: 1024 rows, more once the table would pass ~64 MB
-    int64_t wr = 1024;
+#ifndef QK_RS_WAVE_ROWS
+#define QK_RS_WAVE_ROWS 1024
+#endif
+    int64_t wr = QK_RS_WAVE_ROWS;
     while (((n + 4 * wr - 1) / (4 * wr)) * ((int64_t)4 << as.bits) > ((int64_t)64 << 20)) wr *= 2;
     as.wave_rows = (int)wr;
     as.nchunks = (int)std::max<int64_t>(1, (n + 4 * wr - 1) / (4 * wr));
