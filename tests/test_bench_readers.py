@@ -37,3 +37,28 @@ def test_malformed_vecs_are_refused(tmp_path):
     p.write_bytes(b"")
     with pytest.raises(SystemExit):
         B.read_vecs(str(p), np.float32)
+
+
+@pytest.mark.gpu
+def test_bench_runs_on_a_dataset_directory(tmp_path):
+    """`bench.py --sift-dir DIR`: the headline workload on the files of a TEXMEX-layout directory (here a 200k x 128 integer-valued
+    stand-in written by this test), end to end on the GPU: one JSON line, `data` says where the vectors came from, recall at the
+    target, parity against the oracle enforced inside the run (bench.py exits non-zero otherwise)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    rng = np.random.default_rng(3)
+    cent = rng.integers(0, 200, (256, 128)).astype(np.float32)
+    base = np.clip(cent[rng.integers(0, 256, 200000)] + rng.normal(0, 12, (200000, 128)), 0, 255).round().astype(np.float32)
+    query = np.clip(cent[rng.integers(0, 256, 2048)] + rng.normal(0, 12, (2048, 128)), 0, 255).round().astype(np.float32)
+    _write_vecs(tmp_path / "sift_base.fvecs", base)
+    _write_vecs(tmp_path / "sift_query.fvecs", query)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--sift-dir", str(tmp_path), "--nlist", "256", "--batch", "512",
+                        "--steps", "5", "--warmup", "2", "--settle", "5", "--no-extra", "--no-pmc", "--cpu-seconds", "1", "--inflight", "1"],
+                       cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["data"] == "dataset files (--sift-dir)" and line["config"]["nvec"] == 200000 and line["config"]["dim"] == 128
+    assert line["config"]["recall_at_k"] >= 0.9 and line["value"] > 0 and line["cpu_baseline"]["ids_equal_to_gpu_frac"] == 1.0
