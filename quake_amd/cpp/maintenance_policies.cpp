@@ -1,7 +1,9 @@
 // maintenance_policies.cpp -- see maintenance_policies.h.
 #include "maintenance_policies.h"
 
+#include <cmath>
 #include <cstdio>
+#include <set>
 #include <cstdlib>
 
 #include <algorithm>
@@ -134,6 +136,17 @@ double ListScanLatencyEstimator::estimate_scan_latency(int n, int k) const {
     if (!a.inside && b.inside) return (1 - u) * extrap(f11, f21, t) + u * extrap(f12, f22, t);
     if (a.inside && !b.inside) return (1 - t) * extrap(f11, f12, u) + t * extrap(f21, f22, u);
     return extrap(extrap(f11, f21, t), extrap(f12, f22, t), u);
+}
+
+int ListScanLatencyEstimator::monotone_from(int k) const {
+    if (k < k_values_.front() || n_values_.size() < 2) return -1;
+    const AxisPos b = axis_pos(k_values_, k);
+    if (!b.inside) return -1;
+    const auto &m = scan_latency_model_;
+    size_t i0 = n_values_.size() - 1;
+    if (m[i0][b.lo] < m[i0 - 1][b.lo] || m[i0][b.hi] < m[i0 - 1][b.hi]) return -1;
+    while (i0 > 0 && m[i0][b.lo] >= m[i0 - 1][b.lo] && m[i0][b.hi] >= m[i0 - 1][b.hi]) i0--;
+    return n_values_[i0];
 }
 
 // the reference's CSV layout (maintenance_cost_estimator.cpp:259-365): header, "n_size,k_size", n values, k values, rows
@@ -375,10 +388,35 @@ shared_ptr<MaintenanceTimingInfo> MaintenancePolicy::perform_maintenance() {  //
     // candidates the rejection rule examines at once: their lists are extracted on the device, one nearest-two search per chunk of
     // rows, counted per candidate from plain arrays (two host round trips and 5000 tensor element reads per candidate before: a 50M
     // index has hundreds of candidates per call)
+    // Which of the delete-branch partitions need the search at all?  The rule deletes when (overhead + hit_rate L(size)) + [a sum whose
+    // every term is >= 0 where L is nondecreasing] < -threshold: a candidate whose first bracket is already >= -threshold (beyond a guard
+    // band for the last-bit wobble of the interpolation) is KEPT whatever its targets are, and is not searched -- the large, hot partitions,
+    // two thirds of the candidates of a 50M index.  Taken only when every partition's size lies where the grid is nondecreasing.
+    std::set<int64_t> kept_early;
+    bool shortcut = total_partitions > 1;
+    {
+        const int n0 = ce.get_latency_estimator()->monotone_from(ce.get_k());
+        if (n0 < 0) shortcut = false;
+        for (const auto &kv : sizes)
+            if (kv.second > 0 && kv.second < n0) shortcut = false;
+    }
+    const auto &Lat = *ce.get_latency_estimator();
+    const double d_overhead = total_partitions > 1 ? Lat.estimate_scan_latency(total_partitions - 1, ce.get_k()) - Lat.estimate_scan_latency(total_partitions, ce.get_k()) : 0.0;
     std::vector<int64_t> cand;
     for (const auto &kv : sizes) {
-        const double dd = ce.compute_delete_delta((int)kv.second, hit_rate_of(kv.first), total_partitions, scan_fraction, avg_size);
-        if (dd < -p.delete_threshold_ns && p.enable_delete_rejection && (int)kv.second > p.min_partition_size) cand.push_back(kv.first);
+        const float hr = hit_rate_of(kv.first);
+        const double dd = ce.compute_delete_delta((int)kv.second, hr, total_partitions, scan_fraction, avg_size);
+        if (dd < -p.delete_threshold_ns && p.enable_delete_rejection && (int)kv.second > p.min_partition_size) {
+            if (shortcut) {
+                const double bracket = d_overhead + hr * Lat.estimate_scan_latency((int)kv.second, ce.get_k());
+                const double guard = 1e-9 * (std::fabs(bracket) + std::fabs((double)p.delete_threshold_ns) + 1.0);
+                if (bracket >= -(double)p.delete_threshold_ns + guard) {
+                    kept_early.insert(kv.first);
+                    continue;
+                }
+            }
+            cand.push_back(kv.first);
+        }
     }
     stage("sizes + candidates");
     if (trace) fprintf(stderr, "[maintenance] %zu partitions, %zu delete candidates\n", sizes.size(), cand.size());
@@ -439,7 +477,10 @@ shared_ptr<MaintenanceTimingInfo> MaintenancePolicy::perform_maintenance() {  //
         const float hr = hit_rate_of(pid);
         const double dd = ce.compute_delete_delta(size, hr, total_partitions, scan_fraction, avg_size);
         if (dd < -p.delete_threshold_ns) {
-            if (p.enable_delete_rejection && size > p.min_partition_size) {
+            if (p.enable_delete_rejection && size > p.min_partition_size && kept_early.count(pid)) {
+                // (kept by the rejection rule without the search: the same split test as any kept partition under the extension)
+                if (p.split_after_delete_rejection && ce.compute_split_delta(size, hr, total_partitions) < -p.split_threshold_ns) to_split.push_back(pid);
+            } else if (p.enable_delete_rejection && size > p.min_partition_size) {
                 const auto &counts = targets[pid];
                 std::vector<int64_t> rc, rs;
                 std::vector<float> rh;

@@ -53,6 +53,9 @@ public:
                              bool adaptive_nprobe = false, const std::string &profile_filename = "", ScanProfileFn profile_fn = nullptr);
     void profile_scan_latency(ScanProfileFn fn = nullptr);
     double estimate_scan_latency(int n, int k) const;
+    // the smallest grid value n0 from which the modelled latency is nondecreasing in n at this k (along the grid in both k columns
+    // that bracket k, hence for every interpolated / extrapolated n >= n0), or -1 when it never is / k lies beyond the grid
+    int monotone_from(int k) const;
     void set_scan_latency(int n, int k, double latency_ns);
     bool save_latency_profile(const std::string &filename) const;
     bool load_latency_profile(const std::string &filename);

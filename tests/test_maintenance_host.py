@@ -178,3 +178,76 @@ def test_batched_rejection_deltas_are_the_scalar_function():
             want = ce.compute_delete_delta_w_reassign(int(sizes[c]), float(hr[c]), total, [1] * (hi - lo), t_sizes[lo:hi], t_hr[lo:hi])
             assert np.float64(got[c]).tobytes() == np.float64(want).tobytes(), (trial, c, got[c], want)
     assert _delete_deltas_w_reassign_many(ce, [5], [0.1], 1, [], [], [0, 0])[0] == 0.0
+
+
+class _StubIndex:
+    """what MaintenancePolicy.decide() asks of an index: partition numbers and sizes, and where a delete candidate's rows would go"""
+
+    def __init__(self, sizes, targets):
+        self.sizes, self.targets, self.asked = dict(sizes), targets, []
+
+    def _list_ids(self):
+        return sorted(self.sizes)
+
+    def nlist(self):
+        return len(self.sizes)
+
+    def ntotal(self):
+        return int(sum(self.sizes.values()))
+
+    def d(self):
+        return 128
+
+    def _partition_sizes(self, pids):
+        return [self.sizes[int(p)] for p in pids]
+
+    def _reassign_targets_many(self, pids):
+        self.asked.extend(int(p) for p in pids)
+        return {int(p): self.targets[int(p)] for p in pids}
+
+
+def test_candidates_kept_without_the_nearest_two_search_get_the_same_verdict():
+    """A delete candidate whose (overhead + hit_rate L(size)) is already above -threshold is kept whatever its rows' second-nearest
+    centroids are (every reassignment term is >= 0 where the grid is nondecreasing): decide() skips the search for it.  The verdicts
+    must be those of the full rule (maintenance_policies.cpp:68-131) -- compared here on random indexes, with and without the
+    extension -- and the search must be asked for fewer candidates."""
+    from quake_amd.index import MaintenancePolicyParams
+    from quake_amd.maintenance import MaintenancePolicy
+    rng = np.random.default_rng(11)
+    saved = 0
+    for trial in range(30):
+        T = int(rng.integers(20, 400))
+        sizes = {p: int(rng.choice([0, int(rng.integers(40, 400)), int(rng.integers(400, 30000))], p=[0.02, 0.3, 0.68])) for p in range(T)}
+        targets = {}
+        for p in range(T):
+            others = [q for q in range(T) if q != p]
+            t = sorted(int(v) for v in rng.choice(others, size=int(rng.integers(1, min(12, T - 1))), replace=False))
+            targets[p] = (t, [int(rng.integers(1, 500)) for _ in t])
+        window = 256
+        mp = MaintenancePolicyParams()
+        mp.window_size, mp.min_partition_size = window, 32
+        mp.delete_threshold_ns = mp.split_threshold_ns = float(rng.choice([0.02, 0.5, 10.0]))
+        mp.split_after_delete_rejection = bool(trial % 2)
+        ce, lat = make_estimator(0.9, 10)
+        hot = rng.choice(T, size=max(2, T // 6), replace=False)
+        hits = np.where(rng.random((window, 4)) < 0.7, rng.choice(hot, (window, 4)), rng.integers(0, T, (window, 4)))
+        out = []
+        for shortcut in (True, False):
+            idx = _StubIndex(sizes, targets)
+            pol = MaintenancePolicy(idx, mp, cost_estimator=ce)
+            pol.hit_count_tracker_.add_batch(hits, np.vectorize(sizes.get)(hits))
+            if not shortcut:
+                lat.monotone_from = lambda k: None
+            try:
+                out.append((pol.decide(), len(idx.asked)))
+            finally:
+                if not shortcut:
+                    del lat.monotone_from
+        assert out[0][0] == out[1][0], (trial, out[0][0], out[1][0])
+        assert out[0][1] <= out[1][1]
+        saved += out[1][1] - out[0][1]
+    assert saved > 0
+    # a grid that wobbles where partitions live: no shortcut (every candidate is examined)
+    lat2 = ListScanLatencyEstimator(128, [1, 64, 1024, 65536], [1, 16], 1, profile_fn=lambda n, k: 100.0 - 0.5 * n if n <= 64 else 70.0 + 0.01 * n)
+    assert lat2.monotone_from(10) == 64 and make_estimator()[1].monotone_from(10) == 1
+    assert ListScanLatencyEstimator(128, [1, 64], [1, 16], 1, profile_fn=lambda n, k: 100.0 - n).monotone_from(10) is None
