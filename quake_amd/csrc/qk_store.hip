@@ -6,6 +6,8 @@
 // layout is NOT the reference's row-major malloc array: it is the MFMA-fragment tile-major layout
 // described in qk_internal.h / DESIGN.md section 4, plus a per-row squared norm.
 #include "qk_internal.h"
+
+#include <unordered_map>
 #include <atomic>
 
 #include <algorithm>
@@ -896,7 +898,7 @@ int qk_store_get_vectors(qk_store *s, const int64_t *ids_host, int64_t n, float 
         holder[(size_t)i] = s->id_to_list.find(ids_host[i]);
         if (holder[(size_t)i] >= 0) asked[(size_t)holder[(size_t)i]]++;
     }
-    std::vector<QkIdMap> pos(s->parts.size());
+    std::unordered_map<int32_t, QkIdMap> pos;  // (only for the lists the request touches often: a store has tens of thousands)
     int64_t n_found = 0;
     for (int64_t i = 0; i < n; i++) {
         found[i] = 0;
@@ -905,7 +907,7 @@ int qk_store_get_vectors(qk_store *s, const int64_t *ids_host, int64_t n, float 
         const qk_part &p = s->parts[(size_t)h];
         int64_t at = -1;
         if (asked[(size_t)h] >= 8 && p.size > 64) {
-            QkIdMap &m = pos[(size_t)h];
+            QkIdMap &m = pos[h];
             if (m.size() == 0) {
                 m.reserve((size_t)p.size);
                 for (int64_t r = p.size - 1; r >= 0; r--) m.set(p.ids[(size_t)r], (int32_t)r);  // (first occurrence wins: find_id's order)
@@ -1059,15 +1061,23 @@ static int add_batch_core(qk_store *s, int64_t n, const int64_t *ids, const floa
     const bool index_here = s->index_valid && !ids_indexed;
     if (index_here) s->id_to_list.reserve(s->id_to_list.size() + (size_t)n);  // (no rehash inside the loop)
     constexpr int64_t AHEAD = 16;
-    for (int64_t i = 0; i < n; i++) {
-        if (index_here && i + AHEAD < n) s->id_to_list.prefetch(h_ids[i + AHEAD]);
+    // (runs of rows bound for the same list -- a refinement hands its rows over grouped by list, a split by half -- are appended to the
+    //  list's id mirror in one piece)
+    for (int64_t i = 0; i < n;) {
+        int64_t j = i + 1;
+        while (j < n && h_assign[j] == h_assign[i]) j++;
         qk_part &p = s->parts[(size_t)h_assign[i]];
-        rows[i] = p.row_off + p.size;
-        p.ids.push_back(h_ids[i]);
-        if (h_ids[i] > s->max_id_seen) s->max_id_seen = h_ids[i];
-        if (h_ids[i] < s->min_id_seen) s->min_id_seen = h_ids[i];
-        p.size++;
-        if (index_here) s->id_to_list.set(h_ids[i], (int32_t)h_assign[i]);
+        const int64_t at = p.row_off + p.size;
+        for (int64_t t = i; t < j; t++) rows[t] = at + (t - i);
+        p.ids.insert(p.ids.end(), h_ids.begin() + i, h_ids.begin() + j);
+        p.size += j - i;
+        for (int64_t t = i; t < j; t++) {
+            if (index_here && t + AHEAD < n) s->id_to_list.prefetch(h_ids[t + AHEAD]);
+            if (h_ids[t] > s->max_id_seen) s->max_id_seen = h_ids[t];
+            if (h_ids[t] < s->min_id_seen) s->min_id_seen = h_ids[t];
+            if (index_here) s->id_to_list.set(h_ids[t], (int32_t)h_assign[t]);
+        }
+        i = j;
     }
     if (s->index_valid && ids_indexed) {
         const unsigned hw = std::thread::hardware_concurrency();
