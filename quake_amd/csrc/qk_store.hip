@@ -156,7 +156,9 @@ int qk_store_reserve_rows(qk_store *s, int64_t rows) {
     int64_t need = s->used_rows + rows;
     if (need <= s->cap_rows) return QK_OK;
     qk_ctx *c = s->ctx;
-    int64_t ncap = std::max<int64_t>(need, s->cap_rows + s->cap_rows / 2);
+    // growth doubles: a re-allocation is a hipMalloc + copy + hipFree of the whole arena -- 1-2 s at 50M rows, measured inside a
+    // maintenance call -- and an index that is modified at all keeps being modified (refinements re-add millions of rows at the tail)
+    int64_t ncap = std::max<int64_t>(need, s->cap_rows * 2);
     ncap = qk_round_up64(std::max<int64_t>(ncap, 1024), 16);
     float *nv = nullptr, *nn = nullptr;
     int64_t *ni = nullptr;
@@ -303,7 +305,9 @@ static int compact_arena(qk_store *s, int64_t extra_rows, int64_t last) {
     if (last >= 0 && last < (int64_t)s->parts.size() && s->parts[(size_t)last].present) order.push_back(last);
     int64_t live_cap = 0;
     for (int64_t pi : order) live_cap += s->parts[(size_t)pi].cap;
-    int64_t ncap = qk_round_up64(std::max<int64_t>(live_cap + extra_rows + live_cap / 4, 1024), 16);
+    // (never smaller than the arena it replaces: a compaction that shrank the arena to its live rows + 25 % was followed, a few
+    //  refinements later, by a re-allocation -- the two alternated every ~10 maintenance calls of a 50M index)
+    int64_t ncap = qk_round_up64(std::max<int64_t>(std::max<int64_t>(live_cap + extra_rows + live_cap / 4, s->cap_rows), 1024), 16);
     float *nv = nullptr, *nn = nullptr;
     int64_t *ni = nullptr;
     if (hipMalloc((void **)&nv, (size_t)ncap * s->dpad * sizeof(float)) != hipSuccess ||
