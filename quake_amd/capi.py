@@ -327,6 +327,12 @@ class Context:
         check(self.lib.qk_kmeans(self.h, _ptr(x), n, d, m, metric_code(metric), int(niter), int(seed), _ptr(c), _ptr(a), mem))
         return c, a, x
 
+    def kmeans_inplace(self, x, m, metric, centroids, assign, niter=5, seed=1234):
+        """qk_kmeans on CUDA tensors the caller owns: x [n, d] (IP: normalised IN PLACE), centroids [m, d] and assign [n] written"""
+        n, d = x.shape
+        check(self.lib.qk_kmeans(self.h, _ptr(x), n, d, int(m), metric_code(metric), int(niter), int(seed), _ptr(centroids), _ptr(assign),
+                                 QK_MEM_DEVICE))
+
     def kmeans_last_timing(self):
         """kernel-side ms of the assign / update step of the last Lloyd iteration of the last kmeans() (qk_kmeans_last_timing)"""
         am, um = C.c_float(0), C.c_float(0)
@@ -454,15 +460,18 @@ class Store:
         """pending modifications become visible to searches now (list table upload, row-major copy) instead of inside the next query"""
         check(self.lib.qk_store_publish(self.h))
 
-    def get_lists_device(self, list_nos):
-        """rows of many lists, one list after the other, as ONE CUDA tensor [sum of sizes, d] (qk_store_get_lists) + the sizes"""
+    def get_lists_device(self, list_nos, with_ids=False):
+        """rows of many lists, one list after the other, as ONE CUDA tensor [sum of sizes, d] (qk_store_get_lists) + the sizes
+        (+ with_ids: the rows' ids as a CUDA tensor)"""
         import torch
         nos = np.ascontiguousarray(list_nos, dtype=np.int64).reshape(-1)
         sizes = self.list_sizes(nos)
-        vecs = torch.empty((int(sizes.sum()), self.d), dtype=torch.float32, device=torch.device("cuda", self.ctx.device))
+        dev = torch.device("cuda", self.ctx.device)
+        vecs = torch.empty((int(sizes.sum()), self.d), dtype=torch.float32, device=dev)
+        ids = torch.empty((vecs.shape[0],), dtype=torch.int64, device=dev) if with_ids else None
         if vecs.shape[0]:
-            check(self.lib.qk_store_get_lists(self.h, _ptr(nos), nos.shape[0], _ptr(vecs), None, QK_MEM_DEVICE))
-        return vecs, sizes
+            check(self.lib.qk_store_get_lists(self.h, _ptr(nos), nos.shape[0], _ptr(vecs), _ptr(ids) if with_ids else None, QK_MEM_DEVICE))
+        return (vecs, sizes, ids) if with_ids else (vecs, sizes)
 
     def get_vector(self, vid):
         out = np.empty(self.d, np.float32)

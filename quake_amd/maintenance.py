@@ -553,9 +553,11 @@ class MaintenancePolicy:
         t0 = time.perf_counter()
         new_pids = []
         if to_split:
-            split = idx._split_partitions(to_split)
-            idx._delete_partitions(to_split, reassign=False)
-            new_pids = idx._add_partitions(split)
+            new_pids = idx._split_partitions_in_place(to_split) if hasattr(idx, "_split_partitions_in_place") else None
+            if new_pids is None:
+                split = idx._split_partitions(to_split)
+                idx._delete_partitions(to_split, reassign=False)
+                new_pids = idx._add_partitions(split)
         info.split_time_us = int((time.perf_counter() - t0) * 1e6)
         t0 = time.perf_counter()
         if new_pids:
