@@ -1358,7 +1358,7 @@ def main():
 
     if world == 1 and not force_sharded:
         main_res = run_single_workload(ctx, dev, args, "headline", args.sigma, args.nprobe, args.steps, args.warmup, args.settle,
-                                       args.cpu_seconds, traffic_file="r05_pmc_k_scan.json", manifold=args.manifold,
+                                       args.cpu_seconds, traffic_file="r06_pmc_k_scan.json", manifold=args.manifold,
                                        sweep_nprobes=() if (args.no_extra or args.manifold) else (8, 16, 32))
         cfg_no = 2 if (args.metric == "ip" and args.dim == 768) else 1
         main_res["config"]["workload"] += f" (BASELINE.json configs[{cfg_no}])"
