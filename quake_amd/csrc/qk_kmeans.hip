@@ -234,17 +234,22 @@ struct RsPass {
     const int32_t *keys_in;   // later passes: keys / values of the previous pass
     const int32_t *vals_in;
     int64_t n;                // rows of the first pass (host value); later passes read the rows kept from n_dev
-    int32_t *n_dev;           // [1] rows kept = sum of the digit totals, written by every k_rs_scan
+    int32_t *n_dev;           // [1] rows kept = sum of the digits' totals, written by every k_rs_scan
     int m, shift;
     int wave_rows;            // rows per wave (multiple of 64); a workgroup's chunk = 4 * wave_rows consecutive rows
     int nchunks;              // workgroups
     int32_t *table;           // [nchunks][1 << BITS]: counts, then (after k_rs_scan) the first output position of (chunk, digit)
-    int32_t *totals;          // [1 << BITS], zeroed before k_rs_hist
+    int32_t *totals;          // [1 << BITS] words, zero before k_rs_scan: word g = 1 + the rows of the digits of scan workgroup g
     int32_t *keys_out;        // may be null on the last pass
     int32_t *vals_out;
     int64_t *dbase_out;       // k_rs_scan: first output position of every digit ([(1 << BITS) + 1], may be null) -- with a single pass
                               // these ARE the segment bounds of the centroids
 };
+
+// rows in flight per lane: a workgroup's chunk is 4 waves x 1024 rows on 256 CUs -- ONE wave per SIMD, nothing to hide a load behind --
+// so every loop below asks for RS_U rows before it touches the first (round 5 walked them one dependent round trip at a time:
+// 16 trips of ~0.7 us per wave in the count and again in the placement)
+constexpr int RS_U = 16;
 
 // digit counts of this wave's rows into its private LDS row hw[1 << BITS] (zeroed here)
 template <int BITS, bool FIRST>
@@ -252,9 +257,17 @@ __device__ __forceinline__ void rs_count_wave(const RsPass &P, int32_t *hw, int6
     constexpr int NB = 1 << BITS;
     for (int i = lane; i < NB; i += 64) hw[i] = 0;
     __builtin_amdgcn_wave_barrier();
-    for (int64_t i = r0 + lane; i < r1; i += 64) {
-        const int32_t key = rs_key<FIRST>(P.assign, P.keys_in, i, P.m);
-        if (key >= 0) atomicAdd(&hw[(key >> P.shift) & (NB - 1)], 1);
+    for (int64_t i0 = r0; i0 < r1; i0 += 64 * RS_U) {
+        int32_t kk[RS_U];
+#pragma unroll
+        for (int u = 0; u < RS_U; u++) {
+            const int64_t i = i0 + u * 64 + lane;
+            const int32_t key = rs_key<FIRST>(P.assign, P.keys_in, min(i, r1 - 1), P.m);  // (unconditional: the loads leave together)
+            kk[u] = i < r1 ? key : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < RS_U; u++)
+            if (kk[u] >= 0) atomicAdd(&hw[(kk[u] >> P.shift) & (NB - 1)], 1);
     }
     __builtin_amdgcn_wave_barrier();
 }
@@ -267,65 +280,99 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const RsPass P) {
     __syncthreads();
     const int64_t n = FIRST ? P.n : (int64_t)*P.n_dev;
     const int64_t r0 = (int64_t)blockIdx.x * RS_WAVES * P.wave_rows, r1 = min(n, r0 + (int64_t)RS_WAVES * P.wave_rows);
-    for (int64_t i = r0 + threadIdx.x; i < r1; i += RS_THREADS) {
-        const int32_t key = rs_key<FIRST>(P.assign, P.keys_in, i, P.m);
-        if (key >= 0) atomicAdd(&rs_lds[(key >> P.shift) & (NB - 1)], 1);
+    for (int64_t i0 = r0; i0 < r1; i0 += RS_THREADS * RS_U) {
+        int32_t kk[RS_U];
+#pragma unroll
+        for (int u = 0; u < RS_U; u++) {
+            const int64_t i = i0 + u * RS_THREADS + threadIdx.x;
+            const int32_t key = rs_key<FIRST>(P.assign, P.keys_in, min(i, r1 - 1), P.m);  // (unconditional: the loads leave together)
+            kk[u] = i < r1 ? key : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < RS_U; u++)
+            if (kk[u] >= 0) atomicAdd(&rs_lds[(kk[u] >> P.shift) & (NB - 1)], 1);
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < NB; i += RS_THREADS) {
-        const int32_t v = rs_lds[i];
-        P.table[(int64_t)blockIdx.x * NB + i] = v;
-        if (v) atomicAdd(&P.totals[i], v);
-    }
+    // (no digit totals from here: 256 chunks x ~2600 non-empty digits were 665 000 device-scope atomics on 4096 words; the scan adds
+    // the columns up anyway)
+    for (int i = threadIdx.x; i < NB; i += RS_THREADS) P.table[(int64_t)blockIdx.x * NB + i] = rs_lds[i];
 }
 
 // exclusive scan over [chunk][digit] in place, digit-major order (all chunks of digit 0, then digit 1, ...): workgroup g owns the
-// 64 digits 64g .. 64g+63 -- their bases are the sums of the digit totals below them (k_rs_hist added those up with one atomic per
-// non-empty (chunk, digit)) -- and walks the chunks in four contiguous quarters (thread = (quarter, digit): 64 consecutive digits
-// of one chunk are one coalesced 256-byte read)
+// 64 digits 64g .. 64g+63 and walks the chunks in RS_SCAN_WAVES contiguous parts (thread = (part, digit): 64 consecutive digits of
+// one chunk are one coalesced 256-byte read; 16 parts of 16 chunks at 2^20 rows -- one batch of loads per part and pass).  The
+// digits' totals are the column sums of the first walk; the base of the workgroup's first digit is the sum of the totals of the
+// workgroups below it, which they publish (total + 1: zero = not yet) in P.totals[g] -- at most 64 workgroups, dispatched in index
+// order, every one publishing before it waits.
+constexpr int RS_SCAN_WAVES = 16;
+
 template <int BITS>
-__global__ __launch_bounds__(256) void k_rs_scan(const RsPass P) {
+__global__ __launch_bounds__(RS_SCAN_WAVES * 64) void k_rs_scan(const RsPass P) {
     constexpr int NB = 1 << BITS;
-    __shared__ int32_t s_part[4];
-    __shared__ int32_t s_q[4][64];
+    __shared__ int32_t s_part[RS_SCAN_WAVES];
+    __shared__ int32_t s_q[RS_SCAN_WAVES][64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int dg0 = blockIdx.x * 64;
-    int32_t below = 0;  // totals of the digits under dg0
-    for (int i = tid; i < dg0; i += 256) below += P.totals[i];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) below += __shfl_xor(below, o);
-    if (lane == 0) s_part[wave] = below;
+    // part `wave` of the chunks
+    const int per = (P.nchunks + RS_SCAN_WAVES - 1) / RS_SCAN_WAVES, c0 = min(P.nchunks, wave * per), c1 = min(P.nchunks, c0 + per);
+    int32_t *col = P.table + dg0 + lane;
+    int32_t qs = 0;
+#pragma unroll 16
+    for (int c = c0; c < c1; c++) qs += col[(int64_t)c * NB];
+    s_q[wave][lane] = qs;
     __syncthreads();
-    const int32_t base0 = s_part[0] + s_part[1] + s_part[2] + s_part[3];
     // exclusive prefix of this workgroup's 64 digit totals (every wave computes it: lane = digit)
-    const int32_t tot = P.totals[dg0 + lane];
+    int32_t tot = 0, before = 0;  // the digit's total; its rows in the parts under this wave's
+#pragma unroll
+    for (int w = 0; w < RS_SCAN_WAVES; w++) {
+        const int32_t v = s_q[w][lane];
+        before += w < wave ? v : 0;
+        tot += v;
+    }
     int32_t inc = tot;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
         const int32_t u = __shfl_up(inc, o);
         if (lane >= o) inc += u;
     }
+    // (relaxed on both sides: the word IS the message -- nothing else written by the publisher is read through it, so no cache
+    // write-back / invalidate rides on the exchange)
+    if (wave == 0 && lane == 63) __hip_atomic_store(&P.totals[blockIdx.x], inc + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int32_t below = 0;  // totals of the digits under dg0
+    for (int g = tid; g < (int)blockIdx.x; g += RS_SCAN_WAVES * 64) {
+        int32_t v;
+        while ((v = __hip_atomic_load(&P.totals[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0) __builtin_amdgcn_s_sleep(1);
+        below += v - 1;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) below += __shfl_xor(below, o);
+    if (lane == 0) s_part[wave] = below;
+    __syncthreads();
+    int32_t base0 = 0;
+#pragma unroll
+    for (int w = 0; w < RS_SCAN_WAVES; w++) base0 += s_part[w];
     const int32_t dbase = base0 + inc - tot;
     if (wave == 0 && P.dbase_out) P.dbase_out[dg0 + lane] = dbase;
     if (wave == 0 && lane == 63 && blockIdx.x == gridDim.x - 1) {  // rows kept (all digits) = the end of the last segment
         *P.n_dev = base0 + inc;
         if (P.dbase_out) P.dbase_out[NB] = base0 + inc;
     }
-    // quarter `wave` of the chunks
-    const int per = (P.nchunks + 3) / 4, c0 = min(P.nchunks, wave * per), c1 = min(P.nchunks, c0 + per);
-    int32_t *col = P.table + dg0 + lane;
-    int32_t qs = 0;
-#pragma unroll 8
-    for (int c = c0; c < c1; c++) qs += col[(int64_t)c * NB];
-    s_q[wave][lane] = qs;
-    __syncthreads();
-    int32_t run = dbase;
-    for (int w = 0; w < wave; w++) run += s_q[w][lane];
-#pragma unroll 8
-    for (int c = c0; c < c1; c++) {
-        const int32_t v = col[(int64_t)c * NB];
-        col[(int64_t)c * NB] = run;
-        run += v;
+    // second walk: 16 counts asked for together, their running positions written together (a store between two loads would make the
+    // wait for the later load a wait for the store: one counter, vmcnt, counts both on gfx950)
+    int32_t run = dbase + before;
+    for (int cb = c0; cb < c1; cb += 16) {
+        int32_t v[16];
+#pragma unroll
+        for (int t = 0; t < 16; t++) v[t] = col[(int64_t)min(cb + t, c1 - 1) * NB];
+#pragma unroll
+        for (int t = 0; t < 16; t++) {
+            const int32_t cnt = v[t];
+            v[t] = run;
+            run += cnt;
+        }
+#pragma unroll
+        for (int t = 0; t < 16; t++)
+            if (cb + t < c1) col[(int64_t)(cb + t) * NB] = v[t];
     }
 }
 
@@ -350,37 +397,44 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const RsPass P) {
         }
     }
     __syncthreads();
-    // the digit totals go back to zero for the next pass / call (their only reader, k_rs_scan, ran before this launch)
+    // the scan's published totals go back to zero for the next pass / call (their only reader, k_rs_scan, ran before this launch)
     if (blockIdx.x == 0)
         for (int i = threadIdx.x; i < NB; i += RS_THREADS) P.totals[i] = 0;
     int32_t *pos = rs_lds + wave * NB;
     const uint64_t lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
-    for (int64_t i0 = r0; i0 < r1; i0 += 64) {
-        const int64_t i = i0 + lane;
-        bool valid = i < r1;
-        int32_t key = 0, val = 0;
-        if (valid) {
-            key = rs_key<FIRST>(P.assign, P.keys_in, i, P.m);
-            val = FIRST ? (int32_t)i : P.vals_in[i];
-            valid = key >= 0;
-        }
-        const int digit = (key >> P.shift) & (NB - 1);
-        uint64_t peers = __ballot(valid);
+    for (int64_t b0 = r0; b0 < r1; b0 += 64 * RS_U) {
+        int32_t kk[RS_U], vv[RS_U];
 #pragma unroll
-        for (int b = 0; b < BITS; b++) {
-            const bool bit = (digit >> b) & 1;
-            const uint64_t bal = __ballot(valid && bit);
-            peers &= bit ? bal : ~bal;
+        for (int u = 0; u < RS_U; u++) {
+            const int64_t i = b0 + u * 64 + lane;
+            const int32_t key = rs_key<FIRST>(P.assign, P.keys_in, min(i, r1 - 1), P.m);  // (unconditional: the loads leave together)
+            kk[u] = i < r1 ? key : -1;
+            vv[u] = FIRST ? (int32_t)i : P.vals_in[min(i, r1 - 1)];
         }
-        const int rank = __popcll(peers & lt);
-        int at = 0;
-        if (valid) at = pos[digit] + rank;
-        __builtin_amdgcn_wave_barrier();
-        if (valid && rank == 0) pos[digit] += __popcll(peers);  // (one lane per distinct digit of the round)
-        __builtin_amdgcn_wave_barrier();
-        if (valid) {
-            if (P.keys_out) P.keys_out[at] = key;
-            P.vals_out[at] = val;
+        // (the store of a round leaves inside it: holding the 16 positions back and storing at the end measured 2.4 us slower)
+#pragma unroll
+        for (int u = 0; u < RS_U; u++) {
+            if (b0 + u * 64 >= r1) break;
+            const int32_t key = kk[u];
+            const bool valid = key >= 0;
+            const int digit = (key >> P.shift) & (NB - 1);
+            uint64_t peers = __ballot(valid);
+#pragma unroll
+            for (int b = 0; b < BITS; b++) {
+                const bool bit = (digit >> b) & 1;
+                const uint64_t bal = __ballot(valid && bit);
+                peers &= bit ? bal : ~bal;
+            }
+            const int rank = __popcll(peers & lt);
+            int at = 0;
+            if (valid) at = pos[digit] + rank;
+            __builtin_amdgcn_wave_barrier();
+            if (valid && rank == 0) pos[digit] += __popcll(peers);  // (one lane per distinct digit of the round)
+            __builtin_amdgcn_wave_barrier();
+            if (valid) {
+                if (P.keys_out) P.keys_out[at] = key;
+                P.vals_out[at] = vv[u];
+            }
         }
     }
 }
@@ -772,7 +826,7 @@ static int rs_pass_launch(hipStream_t st, const RsPass &P, bool first) {
     const dim3 grid((unsigned)P.nchunks), block(RS_THREADS);
     if (first) hipLaunchKernelGGL((k_rs_hist<BITS, true>), grid, block, lds_hist, st, P);
     else hipLaunchKernelGGL((k_rs_hist<BITS, false>), grid, block, lds_hist, st, P);
-    hipLaunchKernelGGL((k_rs_scan<BITS>), dim3((1u << BITS) / 64), dim3(256), 0, st, P);
+    hipLaunchKernelGGL((k_rs_scan<BITS>), dim3((1u << BITS) / 64), dim3(RS_SCAN_WAVES * 64), 0, st, P);
     if (first) hipLaunchKernelGGL((k_rs_scatter<BITS, true>), grid, block, lds, st, P);
     else hipLaunchKernelGGL((k_rs_scatter<BITS, false>), grid, block, lds, st, P);
     QK_HIP(hipGetLastError());
