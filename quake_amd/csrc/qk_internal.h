@@ -225,6 +225,11 @@ struct qk_store {
     // row-major copy of ONE list's vectors ([rows][d] floats), built on demand for the exact finish of the coarse step without key
     // matrix (qk_dense_pf.hip: a candidate row of the tile-major arena is 32 pieces of 16 bytes in 32 cache lines); dropped whenever
     // the table changes
+    // bounce buffers of the in-place arena compaction (compact_arena, qk_store.hip): ~1 GiB of rows, allocated by the first
+    // compaction and kept
+    float *bounce_v = nullptr, *bounce_n = nullptr;
+    int64_t *bounce_i = nullptr;
+    int64_t bounce_rows = 0;
     float *rowmajor = nullptr;
     int64_t rowmajor_cap = 0;      // floats
     int64_t rowmajor_row_off = -1, rowmajor_rows = 0;

@@ -296,7 +296,7 @@ __global__ __launch_bounds__(256) void k_compact_copy(const CompactMove *__restr
 // end so that it can grow in place, and room for `extra_rows` more.  Called when a partition has to move and a quarter or
 // more of the arena is abandoned extents: under skewed inserts the bump pointer would otherwise run through 10x the live
 // data (every doubling of a hot partition leaves its old extent behind).
-static int compact_arena(qk_store *s, int64_t extra_rows, int64_t last) {
+static int compact_arena_fresh(qk_store *s, int64_t extra_rows, int64_t last) {
     qk_ctx *c = s->ctx;
     std::vector<CompactMove> mv;
     std::vector<int64_t> order;
@@ -348,6 +348,209 @@ static int compact_arena(qk_store *s, int64_t extra_rows, int64_t last) {
     s->ids = ni;
     s->cap_rows = ncap;
     for (size_t i = 0; i < order.size(); i++) s->parts[(size_t)order[i]].row_off = new_off[i];
+    s->used_rows = at;
+    s->dead_rows = 0;
+    s->table_dirty = true;
+    return QK_OK;
+}
+
+// ---- arena compaction IN PLACE ------------------------------------------------------------------------------------------------
+// The form above replaces the arena: at 50M rows a hipMalloc / hipFree pair of 50 GB, 1.2 s inside one maintenance call
+// (profiles/r06_dynamic_workload_hot_50M.json, the one call above 0.25 s after the first).  Here the live extents slide DOWN inside the
+// arena they are in.  In ascending order of their offsets the shift of an extent (the abandoned rows below it) never decreases, so the
+// extents that stay are a prefix and every later one moves to at or below where it was; its destination ends where the next extent's
+// destination begins, which is at or below that extent's source -- a move never lands on rows that are still to be read, EXCEPT the
+// rows of the extents moved with it.  So the moves go in batches through a bounce buffer (~1 GiB of rows): arena -> bounce, then
+// bounce -> arena, one launch each, batches in stream order; an extent larger than the buffer goes in consecutive pieces (the same
+// argument holds piece by piece).  Every row is read and written twice: 50M x 128 with a quarter abandoned is ~80 GB of traffic,
+// ~25 ms.  No allocation, no free, the arena keeps its capacity (a compaction never shrank it anyway).
+struct RowMove {
+    int64_t from, to;  // first row (multiples of 16)
+    int64_t rows;      // whole tiles
+};
+__global__ __launch_bounds__(256) void k_move_rows(const RowMove *__restrict__ mv, int dpad, const float4 *__restrict__ sv,
+                                                   const float *__restrict__ sn, const int64_t *__restrict__ si, float4 *__restrict__ dv,
+                                                   float *__restrict__ dn, int64_t *__restrict__ di) {
+    const RowMove m = mv[blockIdx.y];
+    const int64_t n4 = m.rows * (dpad / 4);
+    const float4 *src = sv + m.from * (dpad / 4);
+    float4 *dst = dv + m.to * (dpad / 4);
+    const int64_t step = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += step) dst[i] = src[i];
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < m.rows; i += step) {
+        dn[m.to + i] = sn[m.from + i];
+        di[m.to + i] = si[m.from + i];
+    }
+}
+// rows of a moved extent past its data: finite and deterministic, like a fresh arena's (they are only ever read masked)
+struct RowFill {
+    int64_t vrow0, vrows;  // vector rows to clear (from the end of the last tile in use to the end of the extent)
+    int64_t nrow0, nrows;  // norm / id entries to clear (from the first unused row)
+};
+__global__ __launch_bounds__(256) void k_fill_rows(const RowFill *__restrict__ fl, int dpad, float4 *__restrict__ v, float *__restrict__ n,
+                                                   int64_t *__restrict__ ids) {
+    const RowFill f = fl[blockIdx.y];
+    const int64_t n4 = f.vrows * (dpad / 4);
+    float4 *dst = v + f.vrow0 * (dpad / 4);
+    const int64_t step = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += step) dst[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < f.nrows; i += step) {
+        n[f.nrow0 + i] = 0.0f;
+        ids[f.nrow0 + i] = -1;
+    }
+}
+
+static int compact_arena(qk_store *s, int64_t extra_rows, int64_t last) {
+    qk_ctx *c = s->ctx;
+    static const bool fresh = std::getenv("QK_COMPACT_FRESH") != nullptr;  // (A/B switch, read once: tests compare the two forms)
+    if (fresh) return compact_arena_fresh(s, extra_rows, last);
+    if (!s->bounce_v) {
+        int64_t rows = std::max<int64_t>(16, (((int64_t)1 << 30) / ((int64_t)s->dpad * 4)) & ~(int64_t)15);
+        // (test hook: a buffer of a few tiles makes a small store go through many batches and through extents cut in pieces)
+        if (const char *e = std::getenv("QK_COMPACT_BOUNCE_ROWS")) rows = std::max<int64_t>(16, (int64_t)atoll(e) & ~(int64_t)15);
+        float *bv = nullptr, *bn = nullptr;
+        int64_t *bi = nullptr;
+        if (hipMalloc((void **)&bv, (size_t)rows * s->dpad * sizeof(float)) != hipSuccess ||
+            hipMalloc((void **)&bn, (size_t)rows * sizeof(float)) != hipSuccess ||
+            hipMalloc((void **)&bi, (size_t)rows * sizeof(int64_t)) != hipSuccess) {
+            if (bv) hipFree(bv);
+            if (bn) hipFree(bn);
+            if (bi) hipFree(bi);
+            (void)hipGetLastError();
+            return compact_arena_fresh(s, extra_rows, last);  // (no room for the bounce buffer: the replacing form says so if it fails too)
+        }
+        s->bounce_v = bv;
+        s->bounce_n = bn;
+        s->bounce_i = bi;
+        s->bounce_rows = rows;
+    }
+    // `last` goes to the very end (it is about to grow: there it grows in place and abandons nothing): its rows wait in a buffer of
+    // their own while the others slide over the place they were in.  (A `last` larger than the bounce buffer stays in line; the
+    // caller then moves it like any extent that outgrew its place.)
+    const int64_t B = s->bounce_rows;
+    bool hold_last = last >= 0 && last < (int64_t)s->parts.size() && s->parts[(size_t)last].present && s->parts[(size_t)last].cap > 0 &&
+                     ((s->parts[(size_t)last].size + 15) & ~(int64_t)15) <= B;
+    const int64_t hold_rows = hold_last ? ((s->parts[(size_t)last].size + 15) & ~(int64_t)15) : 0;
+    float *hv = nullptr, *hn = nullptr;
+    int64_t *hi = nullptr;
+    if (hold_rows > 0) {
+        if (hipMalloc((void **)&hv, (size_t)hold_rows * s->dpad * sizeof(float)) != hipSuccess ||
+            hipMalloc((void **)&hn, (size_t)hold_rows * sizeof(float)) != hipSuccess ||
+            hipMalloc((void **)&hi, (size_t)hold_rows * sizeof(int64_t)) != hipSuccess) {
+            if (hv) hipFree(hv);
+            if (hn) hipFree(hn);
+            if (hi) hipFree(hi);
+            hv = hn = nullptr;
+            hi = nullptr;
+            (void)hipGetLastError();
+            hold_last = false;
+        }
+    }
+    struct HoldFree {  // (every exit below)
+        float *v, *n;
+        int64_t *i;
+        ~HoldFree() {
+            if (v) hipFree(v);
+            if (n) hipFree(n);
+            if (i) hipFree(i);
+        }
+    } hold_free{hv, hn, hi};
+    std::vector<int64_t> order;
+    int64_t live_cap = 0;
+    for (size_t pi = 0; pi < s->parts.size(); pi++)
+        if (s->parts[pi].present) {
+            live_cap += s->parts[pi].cap;
+            if (!(hold_last && (int64_t)pi == last)) order.push_back((int64_t)pi);
+        }
+    // the caller is about to take `extra_rows` at the end (with `last` there: its new capacity in place of the old one).  If the
+    // arena cannot hold that even compacted, it has to be replaced anyway: the replacing form sizes the new one to what is live
+    // (in place first and a re-allocation after it would double the arena: tests/test_store_dynamic_gpu.py bounds it)
+    if (live_cap + extra_rows - (hold_last ? s->parts[(size_t)last].cap : 0) > s->cap_rows) return compact_arena_fresh(s, extra_rows, last);
+    std::sort(order.begin(), order.end(), [&](int64_t a, int64_t b) {
+        const qk_part &x = s->parts[(size_t)a], &y = s->parts[(size_t)b];
+        return x.row_off != y.row_off ? x.row_off < y.row_off : a < b;  // (extents of capacity 0 share an offset with a neighbour)
+    });
+    std::vector<RowMove> out_mv, in_mv;   // arena -> bounce, bounce -> arena: entry i of both is piece i
+    std::vector<size_t> batch_begin;      // first piece of every batch (+ the end)
+    std::vector<RowFill> fills;
+    std::vector<int64_t> new_off(order.size());
+    int64_t at = 0, in_batch = 0, moved_rows = 0;
+    batch_begin.push_back(0);
+    for (size_t i = 0; i < order.size(); i++) {
+        const qk_part &p = s->parts[(size_t)order[i]];
+        new_off[i] = at;
+        if (p.cap > 0 && at > p.row_off) return compact_arena_fresh(s, extra_rows, last);  // (extents that overlap: never, by construction)
+        const int64_t rows = ((p.size + 15) >> 4) << 4;
+        if (at != p.row_off && p.cap > 0) {
+            for (int64_t o = 0; o < rows; o += B) {
+                const int64_t r = std::min<int64_t>(B, rows - o);
+                if (in_batch + r > B || out_mv.size() - batch_begin.back() == 65535) {
+                    batch_begin.push_back(out_mv.size());
+                    in_batch = 0;
+                }
+                out_mv.push_back({p.row_off + o, in_batch, r});
+                in_mv.push_back({in_batch, at + o, r});
+                in_batch += r;
+            }
+            moved_rows += p.size;
+            if (p.cap > rows || p.cap > p.size) fills.push_back({at + rows, p.cap - rows, at + p.size, p.cap - p.size});
+        }
+        at += p.cap;
+    }
+    batch_begin.push_back(out_mv.size());
+    const size_t np = out_mv.size();  // pieces of the batches; the two moves of `last` ride behind them in the same arrays
+    int64_t last_new_off = -1;
+    if (hold_last) {
+        const qk_part &p = s->parts[(size_t)last];
+        last_new_off = at;
+        out_mv.push_back({p.row_off, 0, hold_rows});
+        in_mv.push_back({0, at, hold_rows});
+        moved_rows += p.size;
+        if (p.cap > hold_rows || p.cap > p.size) fills.push_back({at + hold_rows, p.cap - hold_rows, at + p.size, p.cap - p.size});
+        at += p.cap;
+    }
+    s->counters[1]++;
+    s->counters[3] += moved_rows;
+    if (!out_mv.empty()) {
+        const size_t mv_bytes = out_mv.size() * sizeof(RowMove), fl_bytes = fills.size() * sizeof(RowFill);
+        QK_TRY(qk_stage_reserve(c, 2 * mv_bytes + fl_bytes + 64));
+        char *dst = (char *)c->stage;
+        QK_HIP(hipMemcpyAsync(dst, out_mv.data(), mv_bytes, hipMemcpyHostToDevice, c->stream));
+        QK_HIP(hipMemcpyAsync(dst + mv_bytes, in_mv.data(), mv_bytes, hipMemcpyHostToDevice, c->stream));
+        if (fl_bytes) QK_HIP(hipMemcpyAsync(dst + 2 * mv_bytes, fills.data(), fl_bytes, hipMemcpyHostToDevice, c->stream));
+        const RowMove *d_out = (const RowMove *)dst, *d_in = (const RowMove *)(dst + mv_bytes);
+        const RowFill *d_fl = (const RowFill *)(dst + 2 * mv_bytes);
+        if (hold_last && hold_rows > 0)  // out of the way first ...
+            hipLaunchKernelGGL(k_move_rows, dim3(64, 1), dim3(256), 0, c->stream, d_out + np, s->dpad, (const float4 *)s->vecs,
+                               (const float *)s->norms, (const int64_t *)s->ids, (float4 *)hv, hn, hi);
+        for (size_t b = 0; b + 1 < batch_begin.size(); b++) {
+            const size_t p0 = batch_begin[b], cnt = batch_begin[b + 1] - p0;
+            if (cnt == 0) continue;
+            // (a batch of many small extents: few workgroups each; a batch that is one piece of a huge extent: many)
+            const unsigned gx = (unsigned)std::max<size_t>(1, std::min<size_t>(256, 4096 / cnt));
+            hipLaunchKernelGGL(k_move_rows, dim3(gx, (unsigned)cnt), dim3(256), 0, c->stream, d_out + p0, s->dpad, (const float4 *)s->vecs,
+                               (const float *)s->norms, (const int64_t *)s->ids, (float4 *)s->bounce_v, s->bounce_n, s->bounce_i);
+            hipLaunchKernelGGL(k_move_rows, dim3(gx, (unsigned)cnt), dim3(256), 0, c->stream, d_in + p0, s->dpad, (const float4 *)s->bounce_v,
+                               (const float *)s->bounce_n, (const int64_t *)s->bounce_i, (float4 *)s->vecs, s->norms, s->ids);
+        }
+        if (hold_last && hold_rows > 0)  // ... and behind everybody else at the end
+            hipLaunchKernelGGL(k_move_rows, dim3(64, 1), dim3(256), 0, c->stream, d_in + np, s->dpad, (const float4 *)hv, (const float *)hn,
+                               (const int64_t *)hi, (float4 *)s->vecs, s->norms, s->ids);
+        for (size_t f0 = 0; f0 < fills.size(); f0 += 65535) {
+            const size_t cnt = std::min<size_t>(65535, fills.size() - f0);
+            hipLaunchKernelGGL(k_fill_rows, dim3(8, (unsigned)cnt), dim3(256), 0, c->stream, d_fl + f0, s->dpad, (float4 *)s->vecs, s->norms, s->ids);
+        }
+        QK_HIP(hipGetLastError());
+    }
+    // what the bump pointer hands out next: rows the moved extents left behind
+    if (at < s->used_rows) {
+        QK_HIP(hipMemsetAsync(s->vecs + at * s->dpad, 0, (size_t)(s->used_rows - at) * s->dpad * sizeof(float), c->stream));
+        QK_HIP(hipMemsetAsync(s->norms + at, 0, (size_t)(s->used_rows - at) * sizeof(float), c->stream));
+        QK_HIP(hipMemsetAsync(s->ids + at, 0xFF, (size_t)(s->used_rows - at) * sizeof(int64_t), c->stream));
+    }
+    QK_HIP(hipStreamSynchronize(c->stream));  // (also keeps the pageable piece lists alive for their copies)
+    for (size_t i = 0; i < order.size(); i++) s->parts[(size_t)order[i]].row_off = new_off[i];
+    if (hold_last) s->parts[(size_t)last].row_off = last_new_off;
     s->used_rows = at;
     s->dead_rows = 0;
     s->table_dirty = true;
@@ -464,6 +667,9 @@ int qk_store_destroy(qk_store *s) {
     if (s->d_off) hipFree(s->d_off);
     if (s->d_size) hipFree(s->d_size);
     if (s->rowmajor) hipFree(s->rowmajor);
+    if (s->bounce_v) hipFree(s->bounce_v);
+    if (s->bounce_n) hipFree(s->bounce_n);
+    if (s->bounce_i) hipFree(s->bounce_i);
     delete s;
     return QK_OK;
 }

@@ -154,7 +154,11 @@ def test_skewed_inserts_compact_the_arena(ctx):
             model.remove(kill)
     check_equal(s, model, d)
     live_bytes = s.ntotal() * d * 4
-    assert s.device_bytes() < 4.5 * live_bytes, (s.device_bytes(), live_bytes)  # bump-only growth would be >> 10x here
+    # bump-only growth would be >> 10x here.  What bounds the arena: it doubles when it must grow, a list's extent doubles, and up to
+    # a quarter of it may be abandoned before a compaction pays (2 x 2 x 4/3); where in its doubling sequence the arena stands at the
+    # end depends on the compaction's form (in place: the arena keeps its size; replaced: sized to what is live)
+    assert s.device_bytes() < 6.0 * live_bytes, (s.device_bytes(), live_bytes)
+    assert s.counters()["arena_compactions"] >= 1, s.counters()
     keys, (vecs, ids_, offsets) = model.csr(d)
     q = make_queries(30, d, seed=63, like=ivf["x"])
     pids = np.tile(np.arange(nlist, dtype=np.int64), (30, 1))
@@ -162,6 +166,50 @@ def test_skewed_inserts_compact_the_arena(ctx):
     oi, od = O.batched_serial_scan(q, vecs, ids_, offsets, pids, 10, "l2")
     np.testing.assert_array_equal(gi, oi)
     np.testing.assert_array_equal(gd.view(np.uint32), od.view(np.uint32))
+
+
+@pytest.mark.parametrize("bounce_rows", [16, 48, 1024, None])
+def test_compaction_in_place_keeps_every_list(ctx, bounce_rows, monkeypatch):
+    """compact_arena (qk_store.hip) slides the live extents down inside the arena through a bounce buffer, in batches; an extent
+    larger than the buffer goes in pieces.  With a buffer of one tile (16 rows), three tiles, 1024 rows and the product's 1 GiB:
+    lists dropped in the middle of the arena, hot lists that outgrow their extents again and again -- contents and order of every
+    list, and a scan of all of them, as the host model and the oracle have them."""
+    from quake_amd.capi import Store
+    if bounce_rows is None:
+        monkeypatch.delenv("QK_COMPACT_BOUNCE_ROWS", raising=False)
+    else:
+        monkeypatch.setenv("QK_COMPACT_BOUNCE_ROWS", str(bounce_rows))
+    d, nlist = 20, 40
+    ivf = make_ivf(30000, d, nlist, seed=71)
+    s = Store(ctx, d)
+    s.build_csr(ivf["offsets"], ivf["ids"], ivf["vecs"])
+    model = HostModel(ivf)
+    rng = np.random.default_rng(72)
+    next_id = 1000000
+    for p in (3, 4, 11, 12, 13, 25, 31):  # abandoned extents all over the arena
+        s.remove_list(p)
+        del model.parts[p]
+    live = sorted(model.parts)
+    for step in range(80):
+        p = int(live[int(rng.integers(0, 4))]) if step % 5 else int(rng.choice(live))  # four hot lists, now and then any list
+        n = int(rng.integers(100, 2500))
+        vecs = rng.standard_normal((n, d)).astype(np.float32)
+        ids = np.arange(next_id, next_id + n, dtype=np.int64)
+        next_id += n
+        s.add_entries(p, ids, vecs)
+        model.add(p, ids, vecs)
+        if step % 9 == 8:
+            kill = rng.choice(np.array(model.parts[p][0]), 200, replace=False)
+            s.remove_ids(kill)
+            model.remove(kill)
+        if step % 20 == 19:
+            check_equal(s, model, d)
+    cnt = s.counters()
+    assert cnt["arena_compactions"] >= 1, cnt
+    check_equal(s, model, d)
+    for _ in range(3):
+        _search_equals_oracle(ctx, s, model, d, rng, "l2", 10)
+    s.close()
 
 
 def _search_equals_oracle(ctx, s, m, d, rng, metric, k):
