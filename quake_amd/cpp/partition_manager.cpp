@@ -2,6 +2,10 @@
 // vectors = the coarse step (qk_coarse), 2-means split = qk_kmeans, refinement = qk_store_refine_lists.
 #include "partition_manager.h"
 
+#include <cstdlib>
+#include <mutex>
+#include <thread>
+
 #include <algorithm>
 #include <chrono>
 #include <climits>
@@ -335,11 +339,48 @@ Tensor PartitionManager::split_partitions_in_place(const Tensor &partition_ids) 
     Tensor x = torch::empty({total, (int64_t)d_}, fopt), idd = torch::empty({total}, iopt), assign = torch::empty({total}, iopt);
     Tensor cents_dev = torch::empty({2 * np, (int64_t)d_}, fopt);
     qk_check(lists_.get_lists(p.data_ptr<int64_t>(), np, x.data_ptr<float>(), idd.data_ptr<int64_t>(), QK_MEM_DEVICE));
-    int64_t at = 0;
-    for (int64_t i = 0; i < np; i++) {  // the same call split_partitions makes per partition, on device memory
-        qk_check(qk_kmeans(ctx_, x.data_ptr<float>() + at * d_, sz[(size_t)i], d_, 2, metric_, DEFAULT_NITER, 1234ULL,
-                           cents_dev.data_ptr<float>() + 2 * i * d_, assign.data_ptr<int64_t>() + at, QK_MEM_DEVICE));
-        at += sz[(size_t)i];
+    // the same call split_partitions makes per partition, on device memory.  The 2-means are independent problems of ~0.5 ms of
+    // launch latency each (5 Lloyd iterations on a 512-row sample, a synchronisation per iteration) -- hundreds of them when the
+    // window first fills: several in flight at once on worker contexts (a private stream and k-means scratch each), the same bits
+    std::vector<int64_t> start((size_t)np + 1, 0);
+    for (int64_t i = 0; i < np; i++) start[(size_t)i + 1] = start[(size_t)i] + sz[(size_t)i];
+    float *xp = x.data_ptr<float>(), *cp = cents_dev.data_ptr<float>();
+    int64_t *ap_dev = assign.data_ptr<int64_t>();
+    auto one = [&](qk_ctx *c, int64_t i) {
+        return qk_kmeans(c, xp + start[(size_t)i] * d_, sz[(size_t)i], d_, 2, metric_, DEFAULT_NITER, 1234ULL, cp + 2 * i * d_,
+                         ap_dev + start[(size_t)i], QK_MEM_DEVICE);
+    };
+    int nw = 8;
+    if (const char *e = std::getenv("QUAKE_SPLIT_THREADS")) nw = std::max(1, atoi(e));
+    nw = (int)std::min<int64_t>(nw, np);
+    if (nw >= 2) {
+        static std::mutex mu;
+        static std::vector<qk_ctx *> workers;  // (kept for the life of the process, like the index's own context)
+        std::vector<qk_ctx *> mine;
+        {
+            std::lock_guard<std::mutex> g(mu);
+            while ((int)workers.size() < nw) {
+                qk_ctx *c = nullptr;
+                qk_check(qk_ctx_create(0, &c));
+                workers.push_back(c);
+            }
+            mine.assign(workers.begin(), workers.begin() + nw);
+            qk_check(qk_ctx_synchronize(ctx_));  // the rows were gathered on the index's stream
+            std::vector<int> rc((size_t)nw, QK_OK);
+            std::vector<std::string> msg((size_t)nw);
+            std::vector<std::thread> th;
+            for (int w = 0; w < nw; w++)
+                th.emplace_back([&, w] {
+                    for (int64_t i = w; i < np && rc[(size_t)w] == QK_OK; i += nw) rc[(size_t)w] = one(mine[(size_t)w], i);
+                    if (rc[(size_t)w] == QK_OK) rc[(size_t)w] = qk_ctx_synchronize(mine[(size_t)w]);
+                    if (rc[(size_t)w] != QK_OK) msg[(size_t)w] = qk_last_error();  // (the message is the calling thread's)
+                });
+            for (auto &t : th) t.join();
+            for (int w = 0; w < nw; w++)
+                if (rc[(size_t)w] != QK_OK) throw std::runtime_error("[PartitionManager] split_partitions: " + msg[(size_t)w]);
+        }
+    } else {
+        for (int64_t i = 0; i < np; i++) qk_check(one(ctx_, i));
     }
     qk_check(qk_ctx_synchronize(ctx_));
     Tensor ah = assign.cpu(), cents = cents_dev.cpu();
