@@ -206,3 +206,36 @@ def test_reassign_targets_of_many_partitions_at_once():
         for p in pids:
             assert dict(zip(*many[p])) == dict(zip(*one[p])), (p, chunk)
     assert many[pids[4]] == ([], [])
+
+
+@pytest.mark.parametrize("metric", ["l2", "ip"])
+def test_splits_on_worker_threads_change_nothing(metric, monkeypatch):
+    """QuakeIndex._split_partitions_in_place runs the 2-means of its partitions on worker contexts (QUAKE_SPLIT_THREADS, default 8):
+    the same library call on the same rows each -- children, their row order, their ids and the new centroids must be the ones of
+    the calls made one after the other (partition_manager.cpp:402-447 splits partition by partition)."""
+    import quake_amd as quake
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(60000, 32, generator=g)
+    if metric == "ip":
+        x = torch.nn.functional.normalize(x, dim=1)
+    out = {}
+    for threads in ("1", "8", "3"):
+        monkeypatch.setenv("QUAKE_SPLIT_THREADS", threads)
+        idx = quake.QuakeIndex()
+        bp = quake.IndexBuildParams()
+        bp.nlist = 60
+        bp.metric = metric
+        idx.build(x, torch.arange(60000), bp)
+        pids = [int(p) for p in idx._list_ids()][:37]
+        new = idx._split_partitions_in_place(pids)
+        assert new is not None and len(new) == 2 * len(pids)
+        lists = {int(p): (idx._store.get_list_ids(int(p)).copy(), idx._store.get_list(int(p))[0].copy()) for p in new}
+        cents = idx.parent._store.get_list(0)
+        out[threads] = (new, lists, cents)
+    for threads in ("8", "3"):
+        assert out[threads][0] == out["1"][0]
+        for p in out["1"][0]:
+            np.testing.assert_array_equal(out[threads][1][p][0], out["1"][1][p][0])
+            np.testing.assert_array_equal(out[threads][1][p][1].view(np.uint32), out["1"][1][p][1].view(np.uint32))
+        np.testing.assert_array_equal(out[threads][2][1], out["1"][2][1])
+        np.testing.assert_array_equal(out[threads][2][0].view(np.uint32), out["1"][2][0].view(np.uint32))
